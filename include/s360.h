@@ -1,0 +1,207 @@
+/*
+ * s360.h — C ABI of the MI355X-native stereo-panorama hot path (libs360.so).
+ *
+ * Drop-in boundary for surround360_render's per-frame render path. Every entry point
+ * names the reference interface it replaces (paths relative to the reference repo,
+ * SR/ = surround360_render/source/). Plain C types only: pointers, sizes, POD structs.
+ * All functions return S360_OK (0) or a negative error code; s360_last_error() gives the
+ * message (the reference throws VrCamException / CHECK-aborts instead — the host binary
+ * maps a non-zero code back to that behaviour).
+ *
+ * Device: the library drives gfx950 through HIP. There is NO CPU fallback: if no HIP
+ * device is usable every compute entry point fails with S360_ERR_NO_DEVICE.
+ *
+ * Image layouts are the reference's cv::Mat layouts: row-major, channel-interleaved,
+ * 8-bit BGR / BGRA (CV_8UC3 / CV_8UC4), float32 x2 for flow (CV_32FC2: fx, fy).
+ * "Host" pointers are ordinary memory; "dev" pointers are HIP device pointers (e.g.
+ * torch.Tensor.data_ptr()) and must be on the context's device.
+ */
+#ifndef S360_H_
+#define S360_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S360_OK 0
+#define S360_ERR_INVALID_ARG (-1)
+#define S360_ERR_NO_DEVICE (-2)
+#define S360_ERR_HIP (-3)
+#define S360_ERR_UNKNOWN_ALG (-4) /* makeOpticalFlowByName throws, SR/optical_flow/OpticalFlowFactory.h:63 */
+#define S360_ERR_IO (-5)
+#define S360_ERR_STATE (-6)
+
+/* OpticalFlowInterface::DirectionHint, SR/optical_flow/OpticalFlowInterface.h:24 */
+enum { S360_HINT_UNKNOWN = 0, S360_HINT_RIGHT = 1, S360_HINT_DOWN = 2, S360_HINT_LEFT = 3, S360_HINT_UP = 4 };
+/* Camera::Type, SR/render/Camera.h:87 */
+enum { S360_CAM_FTHETA = 0, S360_CAM_RECTILINEAR = 1 };
+
+/* One camera of the rig after Camera(const dynamic& json) (SR/render/Camera.cpp:44-83):
+ * rotation is the re-unitarised row-major matrix with rows right/up/backward. */
+typedef struct s360_camera {
+  int32_t type;
+  int32_t is_side; /* group contains "side" (SR/render/RigDescription.cpp:20-24) */
+  double position[3];
+  double rotation[9];
+  double resolution[2];
+  double principal[2];
+  double distortion[2];
+  double focal[2];
+  double fov_threshold; /* cos(fov)*|cos(fov)|, SR/render/Camera.h:98 */
+  char id[32];
+} s360_camera;
+
+/* The gflags of SR/test/TestRenderStereoPanorama.cpp:44-70 that influence pixels. */
+typedef struct s360_params {
+  double interpupilary_dist;       /* 6.4 */
+  double zero_parallax_dist;       /* 10000 */
+  double sharpening;               /* 0.0 */
+  int32_t side_alpha_feather_size; /* 100 */
+  int32_t std_alpha_feather_size;  /* 31 */
+  int32_t enable_top, enable_bottom;
+  int32_t eqr_width, eqr_height;
+  int32_t final_eqr_width, final_eqr_height;
+  char side_flow_alg[32];  /* "pixflow_low" | "pixflow_search_20" */
+  char polar_flow_alg[32];
+} s360_params;
+
+/* Derived sizes (SR/test/TestRenderStereoPanorama.cpp:153-173, 309-348, 656-659). */
+typedef struct s360_geometry {
+  int32_t cam_image_width, cam_image_height; /* side spherical projection */
+  int32_t overlap_image_width, num_novel_views;
+  int32_t top_rows, bottom_rows;   /* pole spherical heights */
+  int32_t out_width, out_height;   /* stacked stereo equirect */
+  float h_radians, v_radians, fov_horizontal_radians;
+  float verge_at_infinity_slab_displacement, zero_parallax_novel_view_shift_pixels;
+} s360_geometry;
+
+typedef struct s360_ctx s360_ctx;
+
+/* ---- library / device ----------------------------------------------------------------- */
+const char* s360_version(void);
+int s360_device_count(void);
+const char* s360_last_error(const s360_ctx* ctx); /* ctx may be NULL: last error of this thread */
+
+/* ---- rig loading (host; replaces Camera::loadRig + RigDescription ctor,
+ *      SR/render/Camera.cpp:243-254, SR/render/RigDescription.cpp:18-31) -------------------- */
+/* Parses a rig JSON file (RIG_JSON.md). Writes up to max_cams cameras, returns the count (<0 on error). */
+int s360_rig_load_json(const char* path, s360_camera* cams, int max_cams);
+/* Camera(const dynamic& json) from already-parsed vectors; principal/distortion/fov may be NULL. */
+int s360_camera_init(s360_camera* out, int type, const double origin[3], const double forward[3], const double up[3],
+                     const double right[3], const double resolution[2], const double* principal,
+                     const double* distortion, const double focal[2], const double* fov, const char* group,
+                     const char* id);
+/* Camera::pixel (SR/render/Camera.h:133-140), Camera::getFov (Camera.cpp:150-154), host side. */
+void s360_camera_pixel(const s360_camera* cam, const double rig_point[3], double pixel_out[2]);
+double s360_camera_get_fov(const s360_camera* cam);
+/* RigDescription::findCameraByDirection(+Z / -Z) (SR/render/RigDescription.cpp:33-47); index or <0. */
+int s360_rig_find_top(const s360_camera* cams, int n);
+int s360_rig_find_bottom(const s360_camera* cams, int n);
+
+/* ---- context: one per device; owns streams, persistent HBM buffers, cached warp maps -------- */
+/* cams: the whole rig (side cameras in rig order + pole cameras), as RigDescription holds it. */
+int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams, const s360_params* params);
+void s360_destroy(s360_ctx* ctx);
+int s360_get_geometry(const s360_ctx* ctx, s360_geometry* out);
+/* The HIP stream all of this context's work is enqueued on (hipStream_t as void*). */
+void* s360_stream(s360_ctx* ctx);
+int s360_synchronize(s360_ctx* ctx);
+
+/* ---- operator level (host pointers in/out; each call uploads, runs on the GPU, downloads) --- */
+/* OpticalFlowInterface::computeOpticalFlow via makeOpticalFlowByName(alg)
+ * (SR/optical_flow/OpticalFlowInterface.h:34-41, OpticalFlowFactory.h:23-64, PixFlow.h:81-183).
+ * prev_* == NULL means "empty Mat" (no temporal regularisation). flow_out: w*h*2 floats. */
+int s360_compute_optical_flow(s360_ctx* ctx, const char* alg, const uint8_t* i0_bgra, const uint8_t* i1_bgra, int w,
+                              int h, const float* prev_flow, const uint8_t* prev_i0_bgra,
+                              const uint8_t* prev_i1_bgra, int hint, float* flow_out);
+/* Same, `batch` independent pairs of identical size in one launch sequence (how the 14 side pairs x 2
+ * directions and the 4 pole flows are issued). Arrays are contiguous [batch][h][w][c]. */
+int s360_compute_optical_flow_batch(s360_ctx* ctx, const char* alg, int batch, const uint8_t* i0_bgra,
+                                    const uint8_t* i1_bgra, int w, int h, const float* prev_flow,
+                                    const uint8_t* prev_i0_bgra, const uint8_t* prev_i1_bgra, int hint,
+                                    float* flow_out);
+/* bicubicRemapToSpherical (SR/render/ImageWarper.cpp:143-174): dst_channels 3 or 4 decides BGR2BGRA. */
+int s360_bicubic_remap_to_spherical(s360_ctx* ctx, uint8_t* dst, int dst_w, int dst_h, int dst_channels,
+                                    const uint8_t* src, int src_w, int src_h, int src_channels,
+                                    const s360_camera* camera, float left_angle, float right_angle, float top_angle,
+                                    float bottom_angle);
+/* The float warp map of the same call (pixel - 0.5 per dst pixel), for parity tests. map_out: dst_w*dst_h*2. */
+int s360_spherical_warp_map(s360_ctx* ctx, float* map_out, int dst_w, int dst_h, const s360_camera* camera,
+                            float left_angle, float right_angle, float top_angle, float bottom_angle);
+/* NovelViewGeneratorLazyFlow::combineLazyNovelViews with the LazyNovelViewBuffer of
+ * renderStereoPanoramaChunksThread (SR/optical_flow/NovelView.cpp:226-268, TRSP:259-292).
+ * image_l/r: overlap images (overlap_image_width x cam_image_height BGRA), flows same size.
+ * chunk_l/r out: (eqr_width/n_side) x cam_image_height BGRA. */
+int s360_combine_lazy_novel_views(s360_ctx* ctx, const uint8_t* image_l, const uint8_t* image_r,
+                                  const float* flow_l_to_r, const float* flow_r_to_l, uint8_t* chunk_l,
+                                  uint8_t* chunk_r);
+/* flattenLayersDeghostPreferBase (SR/util/CvUtil.cpp:224-260). BGRA in, BGRA out. */
+int s360_flatten_layers_deghost_prefer_base(s360_ctx* ctx, const uint8_t* bottom_layer, const uint8_t* top_layer, int w,
+                                            int h, uint8_t* out);
+/* offsetHorizontalWrap (SR/util/CvUtil.cpp:93-115). */
+int s360_offset_horizontal_wrap(s360_ctx* ctx, const uint8_t* src, int w, int h, int channels, float offset,
+                                uint8_t* out);
+/* featherAlphaChannel (SR/util/CvUtil.cpp:140-157). BGRA. */
+int s360_feather_alpha_channel(s360_ctx* ctx, const uint8_t* src, int w, int h, int erode_size, uint8_t* out);
+/* poleToSideFlowThread (SR/test/TestRenderStereoPanorama.cpp:388-561) without temporal state:
+ * side: eqr_width x eqr_height BGRA eye panorama, pole: eqr_width x pole_rows BGRA.
+ * warped_out: eqr_width x eqr_height BGRA. flow_out (nullable): extendedWidth x pole_rows x 2. */
+int s360_pole_to_side_flow(s360_ctx* ctx, const uint8_t* side, const uint8_t* pole, int pole_rows, uint8_t* warped_out,
+                           float* flow_out);
+/* sharpenThread (TRSP:688-696, SR/util/Filter.h:40-127), in place on BGR. */
+int s360_sharpen(s360_ctx* ctx, uint8_t* bgr, int w, int h, float sharpening);
+
+/* ---- frame level: renderStereoPanorama (SR/test/TestRenderStereoPanorama.cpp:716-972) ------- */
+/* Inputs stay resident in HBM between upload and render (bench timing starts after upload). */
+int s360_frame_upload_side(s360_ctx* ctx, int side_idx, const uint8_t* img, int w, int h, int channels);
+int s360_frame_upload_top(s360_ctx* ctx, const uint8_t* bgr, int w, int h);
+int s360_frame_upload_bottom(s360_ctx* ctx, const uint8_t* bgr, int w, int h);
+/* Enqueue the whole frame on the context stream (asynchronous). use_prev != 0 applies the
+ * temporal regularisation against the previous s360_frame_render's device-resident state
+ * (the reference's --prev_frame_data_dir, TRSP:215-235, 421-436). */
+int s360_frame_render(s360_ctx* ctx, int use_prev);
+/* Sharded form for multi-GPU: render only side pairs [pair_begin, pair_end) into this
+ * context's strip buffers; strips of other pairs are filled in by the caller (RCCL gather) through
+ * s360_frame_strip_ptr before s360_frame_finish assembles panoramas, runs the pole units given by
+ * pole_mask (bit0 top_left, bit1 top_right, bit2 bottom_left, bit3 bottom_right) and composites. */
+int s360_frame_render_pairs(s360_ctx* ctx, int pair_begin, int pair_end, int use_prev);
+/* Device pointer + byte size of the strip buffer of one eye: [n_side][cam_image_height][strip_w][4]. */
+int s360_frame_strip_ptr(s360_ctx* ctx, int eye, void** dev_ptr, size_t* bytes_per_pair);
+int s360_frame_finish(s360_ctx* ctx, int pole_mask, int use_prev);
+/* Stacked stereo equirect (left eye over right eye), BGR, out_width x out_height (host / device). */
+int s360_frame_download_equirect(s360_ctx* ctx, uint8_t* out_bgr);
+int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* Intermediates for stage-by-stage parity tests and for the reference's on-disk state
+ * (overlap_<i>_{L,R}.png, flow{LtoR,RtoL}_<i>.bin, extended*Spherical_<eye>.png, flow_<eye>.bin).
+ * Names: "projection"(idx cam) "overlap_l" "overlap_r" "side_pano_l" "side_pano_r" "top_spherical"
+ * "bottom_spherical" "pole_warped"(idx 0..3) "extended_side" "extended_fisheye" "eye_l" "eye_r".
+ * whc receives width/height/channels; dst may be NULL for a size query. */
+int s360_frame_get_u8(s360_ctx* ctx, const char* name, int idx, int whc[3], uint8_t* dst);
+/* "flow_l_to_r" "flow_r_to_l" (idx pair) "flow_pole" (idx 0..3). */
+int s360_frame_get_f32(s360_ctx* ctx, const char* name, int idx, int whc[3], float* dst);
+
+/* Keep copies of the eye panoramas as they are before the pole composite ("side_pano_l/r"); costs two
+ * device copies per frame, off by default. */
+int s360_set_keep_intermediates(s360_ctx* ctx, int on);
+/* Test tap: the flow field after every pyramid level (coarsest first, concatenated) of one pair, i.e. the value
+ * of `flow` at PixFlow.h:167 per level. levels_out capacity in floats. */
+int s360_debug_flow_levels(s360_ctx* ctx, const char* alg, const uint8_t* i0_bgra, const uint8_t* i1_bgra, int w, int h,
+                           int hint, float* levels_out, size_t cap_floats, int* n_levels);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Per-kernel-family device time of the last frame/flow call measured with HIP events on the context
+ * stream, when enabled. names_out receives a ';'-separated list matching ms_out entries. */
+int s360_profile_enable(s360_ctx* ctx, int on);
+int s360_profile_get(s360_ctx* ctx, char* names_out, size_t names_cap, float* ms_out, int* launches_out, int cap);
+
+/* ---- flow state file format (saveFlowToFile / readFlowFromFile, SR/util/CvUtil.cpp:159-199) -- */
+int s360_save_flow_to_file(const char* path, const float* flow, int w, int h);
+int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, size_t cap_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S360_H_ */

@@ -1,0 +1,565 @@
+// api.hip — the C ABI of libs360 (include/s360.h). Thin: argument checks, host<->device copies for
+// the operator-level calls, exception -> error-code translation. No CPU fallback anywhere.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "../../include/s360.h"
+#include "ctx.hpp"
+#include "render.hpp"
+
+using namespace s360;
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guard(s360_ctx* c, F&& f) {
+  try {
+    if (c) c->make_current();
+    f();
+    return S360_OK;
+  } catch (const Error& e) {
+    (c ? c->err : g_err) = e.what();
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    (c ? c->err : g_err) = e.what();
+    g_err = e.what();
+    return S360_ERR_STATE;
+  }
+}
+static void need(bool ok, const char* what) {
+  if (!ok) throw Error(S360_ERR_INVALID_ARG, what);
+}
+static void h2d(s360_ctx* c, void* d, const void* h, size_t n) {
+  S360_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->st));
+}
+static void d2h(s360_ctx* c, void* h, const void* d, size_t n) {
+  S360_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->st));
+  S360_HIP(hipStreamSynchronize(c->st));
+}
+
+extern "C" {
+
+const char* s360_version(void) { return "surround360_amd 0.1 (gfx950)"; }
+int s360_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char* s360_last_error(const s360_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+// ---- rig -------------------------------------------------------------------------------------
+int s360_rig_load_json(const char* path, s360_camera* cams, int max_cams) {
+  int n = 0;
+  const int rc = guard(nullptr, [&] {
+    need(path && cams, "null argument");
+    std::ifstream f(path);
+    if (!f) throw Error(S360_ERR_IO, std::string("could not read JSON file: ") + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::vector<s360_camera> v = parse_rig_json(ss.str());
+    need((int)v.size() <= max_cams, "rig has more cameras than max_cams");
+    for (size_t i = 0; i < v.size(); ++i) cams[i] = v[i];
+    n = (int)v.size();
+  });
+  return rc == S360_OK ? n : rc;
+}
+int s360_camera_init(s360_camera* out, int type, const double origin[3], const double forward[3], const double up[3],
+                     const double right[3], const double resolution[2], const double* principal,
+                     const double* distortion, const double focal[2], const double* fov, const char* group,
+                     const char* id) {
+  return guard(nullptr, [&] {
+    need(out && origin && forward && up && right && resolution && focal, "null argument");
+    need(type == S360_CAM_FTHETA || type == S360_CAM_RECTILINEAR, "bad camera type");
+    std::memset(out, 0, sizeof(*out));
+    out->type = type;
+    if (id) std::strncpy(out->id, id, sizeof(out->id) - 1);
+    for (int i = 0; i < 3; ++i) out->position[i] = origin[i];
+    camera_set_rotation(out, forward, up, right);
+    for (int i = 0; i < 2; ++i) {
+      out->resolution[i] = resolution[i];
+      out->principal[i] = principal ? principal[i] : resolution[i] / 2;
+      out->distortion[i] = distortion ? distortion[i] : 0.0;
+      out->focal[i] = focal[i];
+    }
+    if (fov) camera_set_fov(out, *fov); else camera_set_default_fov(out);
+    out->is_side = (group && std::strstr(group, "side")) ? 1 : 0;
+  });
+}
+void s360_camera_pixel(const s360_camera* cam, const double rig_point[3], double pixel_out[2]) {
+  camera_pixel(cam, rig_point, pixel_out);
+}
+double s360_camera_get_fov(const s360_camera* cam) { return camera_get_fov(cam); }
+static int find_dir(const s360_camera* cams, int n, double z) {
+  Rig r;
+  r.all.assign(cams, cams + n);
+  const double d[3] = {0, 0, z};
+  return r.find_by_direction(d);
+}
+int s360_rig_find_top(const s360_camera* cams, int n) { return find_dir(cams, n, 1.0); }
+int s360_rig_find_bottom(const s360_camera* cams, int n) { return find_dir(cams, n, -1.0); }
+
+// ---- context -----------------------------------------------------------------------------------
+int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams, const s360_params* params) {
+  if (!out) return S360_ERR_INVALID_ARG;
+  *out = nullptr;
+  s360_ctx* c = nullptr;
+  const int rc = guard(nullptr, [&] {
+    need(cams && params && n_cams > 0, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw Error(S360_ERR_NO_DEVICE, "no HIP device available (libs360 has no CPU path)");
+    need(device >= 0 && device < ndev, "device index out of range");
+    c = new s360_ctx;
+    c->device = device;
+    S360_HIP(hipSetDevice(device));
+    S360_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    c->prof.st = c->st;
+    c->rig.all.assign(cams, cams + n_cams);
+    c->rig.finalize();
+    need(!c->rig.side.empty(), "rig has no side cameras");  // RigDescription.cpp:27 CHECK_NE
+    c->P = *params;
+    pixflow_consts_by_name(c->P.side_flow_alg);   // validate early (throws S360_ERR_UNKNOWN_ALG)
+    pixflow_consts_by_name(c->P.polar_flow_alg);
+    c->g = derive_geometry(c->rig, c->P);
+    const double up[3] = {0, 0, 1}, down[3] = {0, 0, -1};
+    c->top_idx = c->rig.find_by_direction(up);
+    c->bottom_idx = c->rig.find_by_direction(down);
+    if (c->bottom_idx >= 0) c->ramp = pole_ramp(c->rig);
+    c->flow.reset(new FlowEngine(&c->prof));
+  });
+  if (rc != S360_OK) {
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return S360_OK;
+}
+void s360_destroy(s360_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  c->frame.reset();
+  c->flow.reset();
+  c->flow_pole.reset();
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+int s360_get_geometry(const s360_ctx* c, s360_geometry* out) {
+  if (!c || !out) return S360_ERR_INVALID_ARG;
+  *out = c->g;
+  return S360_OK;
+}
+void* s360_stream(s360_ctx* c) { return c ? (void*)c->st : nullptr; }
+int s360_synchronize(s360_ctx* c) {
+  return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); });
+}
+int s360_set_keep_intermediates(s360_ctx* c, int on) {
+  return guard(c, [&] { need(c, "null ctx"); frame_state(c).keep_intermediates = on != 0; });
+}
+
+// ---- operator level ------------------------------------------------------------------------------
+int s360_compute_optical_flow_batch(s360_ctx* c, const char* alg, int batch, const uint8_t* i0, const uint8_t* i1,
+                                    int w, int h, const float* prev_flow, const uint8_t* prev_i0,
+                                    const uint8_t* prev_i1, int hint, float* flow_out) {
+  return guard(c, [&] {
+    need(c && alg && i0 && i1 && flow_out, "null argument");
+    need(w >= 50 && h >= 50, "image too small for the flow pyramid");
+    need(batch >= 1 && batch <= kMaxFlows, "batch out of range");
+    need(hint >= 0 && hint <= 4, "bad direction hint");
+    need(!prev_flow || (prev_i0 && prev_i1), "prev_flow given without previous images");
+    const PixFlowConsts pc = pixflow_consts_by_name(alg);
+    const size_t n = (size_t)w * h, B = batch;
+    c->op_a.ensure(2 * B * n * 4);
+    c->op_b.ensure(B * n * sizeof(float2));
+    h2d(c, c->op_a.p, i0, B * n * 4);
+    h2d(c, c->op_a.as<uint8_t>() + B * n * 4, i1, B * n * 4);
+    const uchar4* pimg = nullptr;
+    const float2* pflow = nullptr;
+    if (prev_flow) {
+      c->op_c.ensure(2 * B * n * 4);
+      c->op_d.ensure(B * n * sizeof(float2));
+      h2d(c, c->op_c.p, prev_i0, B * n * 4);
+      h2d(c, c->op_c.as<uint8_t>() + B * n * 4, prev_i1, B * n * 4);
+      h2d(c, c->op_d.p, prev_flow, B * n * sizeof(float2));
+      pimg = c->op_c.as<uchar4>();
+      pflow = c->op_d.as<float2>();
+    }
+    FlowIdx idx;
+    std::memset(&idx, 0, sizeof(idx));
+    for (int b = 0; b < batch; ++b) { idx.i0[b] = b; idx.i1[b] = batch + b; }
+    c->flow->compute(c->st, pc, 2 * batch, batch, idx, c->op_a.as<uchar4>(), w, h, pimg, pflow, hint,
+                     c->op_b.as<float2>());
+    d2h(c, flow_out, c->op_b.p, B * n * sizeof(float2));
+  });
+}
+int s360_compute_optical_flow(s360_ctx* c, const char* alg, const uint8_t* i0, const uint8_t* i1, int w, int h,
+                              const float* prev_flow, const uint8_t* prev_i0, const uint8_t* prev_i1, int hint,
+                              float* flow_out) {
+  return s360_compute_optical_flow_batch(c, alg, 1, i0, i1, w, h, prev_flow, prev_i0, prev_i1, hint, flow_out);
+}
+// test tap: flow after every pyramid level (coarsest first) of the last single-pair call configuration
+int s360_debug_flow_levels(s360_ctx* c, const char* alg, const uint8_t* i0, const uint8_t* i1, int w, int h, int hint,
+                           float* levels_out, size_t cap_floats, int* n_levels) {
+  return guard(c, [&] {
+    need(c && alg && i0 && i1 && levels_out, "null argument");
+    const PixFlowConsts pc = pixflow_consts_by_name(alg);
+    const size_t n = (size_t)w * h;
+    c->op_a.ensure(2 * n * 4);
+    c->op_b.ensure(n * sizeof(float2));
+    h2d(c, c->op_a.p, i0, n * 4);
+    h2d(c, c->op_a.as<uint8_t>() + n * 4, i1, n * 4);
+    FlowIdx idx;
+    std::memset(&idx, 0, sizeof(idx));
+    idx.i0[0] = 0; idx.i1[0] = 1;
+    std::vector<std::vector<float>> lv;
+    c->flow->capture_levels = &lv;
+    try {
+      c->flow->compute(c->st, pc, 2, 1, idx, c->op_a.as<uchar4>(), w, h, nullptr, nullptr, hint, c->op_b.as<float2>());
+    } catch (...) {
+      c->flow->capture_levels = nullptr;
+      throw;
+    }
+    c->flow->capture_levels = nullptr;
+    S360_HIP(hipStreamSynchronize(c->st));
+    size_t off = 0;
+    for (auto& v : lv) {
+      need(off + v.size() <= cap_floats, "levels_out too small");
+      std::memcpy(levels_out + off, v.data(), v.size() * sizeof(float));
+      off += v.size();
+    }
+    if (n_levels) *n_levels = (int)lv.size();
+  });
+}
+
+int s360_spherical_warp_map(s360_ctx* c, float* map_out, int dw, int dh, const s360_camera* cam, float l, float r,
+                            float t, float b) {
+  return guard(c, [&] {
+    need(c && map_out && cam && dw > 0 && dh > 0, "bad argument");
+    c->op_a.ensure((size_t)dw * dh * sizeof(float2));
+    build_spherical_map(c, c->op_a.as<float2>(), dw, dh, *cam, l, r, t, b);
+    d2h(c, map_out, c->op_a.p, (size_t)dw * dh * sizeof(float2));
+  });
+}
+int s360_bicubic_remap_to_spherical(s360_ctx* c, uint8_t* dst, int dw, int dh, int dc, const uint8_t* src, int sw,
+                                    int sh, int sc, const s360_camera* cam, float l, float r, float t, float b) {
+  return guard(c, [&] {
+    need(c && dst && src && cam, "null argument");
+    need((dc == 3 || dc == 4) && (sc == 3 || sc == 4), "channels must be 3 or 4");
+    need(!(sc == 4 && dc == 3), "4-channel source into 3-channel destination is not a reference use");
+    FrameState& F = frame_state(c);
+    const size_t sn = (size_t)sw * sh, dn = (size_t)dw * dh;
+    c->op_a.ensure(dn * sizeof(float2));
+    c->op_b.ensure(sn * 4);
+    c->op_c.ensure(sn * sizeof(uchar4));
+    c->op_d.ensure(dn * sizeof(uchar4));
+    build_spherical_map(c, c->op_a.as<float2>(), dw, dh, *cam, l, r, t, b);
+    h2d(c, c->op_b.p, src, sn * sc);
+    launch_bgr_to_bgra(c->st, c->op_b.as<uint8_t>(), sc, c->op_c.as<uchar4>(), sn);
+    launch_remap_cubic_u8c4(c->st, c->op_c.as<uchar4>(), sw, sh, c->op_a.as<float2>(), c->op_d.as<uchar4>(), dw, dh,
+                            F.tab.dev, 0, 0, 1);
+    if (dc == 4) {
+      d2h(c, dst, c->op_d.p, dn * 4);
+    } else {
+      c->op_e.ensure(dn * 3);
+      launch_pack_bgr(c->st, c->op_d.as<uchar4>(), dw, dh, c->op_e.as<uint8_t>());
+      d2h(c, dst, c->op_e.p, dn * 3);
+    }
+  });
+}
+int s360_combine_lazy_novel_views(s360_ctx* c, const uint8_t* image_l, const uint8_t* image_r, const float* flow_l_to_r,
+                                  const float* flow_r_to_l, uint8_t* chunk_l, uint8_t* chunk_r) {
+  return guard(c, [&] {
+    need(c && image_l && image_r && flow_l_to_r && flow_r_to_l && chunk_l && chunk_r, "null argument");
+    FrameState& F = frame_state(c);
+    const s360_geometry& g = c->g;
+    const int P = F.P, ow = g.overlap_image_width, camH = g.cam_image_height, stripW = c->P.eqr_width / P;
+    const size_t on = (size_t)ow * camH, sn = (size_t)stripW * camH;
+    c->op_a.ensure(2 * on * 4);
+    c->op_b.ensure(2 * on * sizeof(float2));
+    c->op_c.ensure(2 * sn * 4);
+    h2d(c, c->op_a.p, image_l, on * 4);
+    h2d(c, c->op_a.as<uint8_t>() + on * 4, image_r, on * 4);
+    h2d(c, c->op_b.p, flow_l_to_r, on * sizeof(float2));
+    h2d(c, c->op_b.as<float2>() + on, flow_r_to_l, on * sizeof(float2));
+    NovelViewParams nv;
+    nv.overlapW = ow; nv.camH = camH; nv.stripW = stripW; nv.numNovelViews = g.num_novel_views;
+    nv.numPairs = 1; nv.numLocal = 1;
+    nv.camImageWidthHalf = float(g.cam_image_width) * 0.5f;
+    nv.disp = g.verge_at_infinity_slab_displacement;
+    launch_novel_view(c->st, c->op_a.as<uchar4>(), c->op_b.as<float2>(), c->op_c.as<uchar4>(), nv, 0, 1, F.tab.dev);
+    d2h(c, chunk_l, c->op_c.p, sn * 4);
+    d2h(c, chunk_r, c->op_c.as<uint8_t>() + sn * 4, sn * 4);
+  });
+}
+int s360_flatten_layers_deghost_prefer_base(s360_ctx* c, const uint8_t* bottom_layer, const uint8_t* top_layer, int w,
+                                            int h, uint8_t* out) {
+  return guard(c, [&] {
+    need(c && bottom_layer && top_layer && out && w > 0 && h > 0, "bad argument");
+    FrameState& F = frame_state(c);
+    const size_t n = (size_t)w * h;
+    c->op_a.ensure(n * 4); c->op_b.ensure(n * 4); c->op_c.ensure(n * 4);
+    h2d(c, c->op_a.p, bottom_layer, n * 4);
+    h2d(c, c->op_b.p, top_layer, n * 4);
+    launch_flatten(c->st, c->op_a.as<uchar4>(), c->op_b.as<uchar4>(), c->op_c.as<uchar4>(), w, h, 0, F.tab.dev);
+    d2h(c, out, c->op_c.p, n * 4);
+  });
+}
+int s360_offset_horizontal_wrap(s360_ctx* c, const uint8_t* src, int w, int h, int channels, float offset,
+                                uint8_t* out) {
+  return guard(c, [&] {
+    need(c && src && out && w > 0 && h > 0, "bad argument");
+    need(channels == 4, "only BGRA panoramas are shifted on this path");
+    const size_t n = (size_t)w * h;
+    c->op_a.ensure(n * 4); c->op_b.ensure(n * 4);
+    h2d(c, c->op_a.p, src, n * 4);
+    // one "strip" of the full width, no padding: pure offsetHorizontalWrap
+    launch_assemble_pano(c->st, c->op_a.as<uchar4>(), 1, h, w, offset, c->op_b.as<uchar4>(), w, h);
+    d2h(c, out, c->op_b.p, n * 4);
+  });
+}
+int s360_feather_alpha_channel(s360_ctx* c, const uint8_t* src, int w, int h, int erode_size, uint8_t* out) {
+  return guard(c, [&] {
+    need(c && src && out && w > 0 && h > 0, "bad argument");
+    need(erode_size == c->P.std_alpha_feather_size, "erode_size must equal the context's std_alpha_feather_size");
+    const size_t n = (size_t)w * h;
+    c->op_a.ensure(n * 4); c->op_b.ensure(n * 4);
+    h2d(c, c->op_a.p, src, n * 4);
+    dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), w, h, c->op_b.as<uchar4>(), w);
+    d2h(c, out, c->op_b.p, n * 4);
+  });
+}
+int s360_pole_to_side_flow(s360_ctx* c, const uint8_t* side, const uint8_t* pole, int pole_rows, uint8_t* warped_out,
+                           float* flow_out) {
+  return guard(c, [&] {
+    need(c && side && pole && warped_out && pole_rows > 0, "bad argument");
+    need(c->bottom_idx >= 0, "rig has no bottom camera (pole ramp uses its fov, TRSP:461)");
+    const int W = c->P.eqr_width, H = c->P.eqr_height;
+    need(pole_rows <= H, "pole_rows larger than eqr_height");
+    const int extW = int(float(W) * 1.2f);
+    const size_t en = (size_t)W * H, pn = (size_t)W * pole_rows, xn = (size_t)extW * pole_rows;
+    c->op_a.ensure(en * 4); c->op_b.ensure(pn * 4); c->op_c.ensure(2 * xn * 4); c->op_d.ensure(xn * sizeof(float2));
+    c->op_e.ensure(en * 4);
+    h2d(c, c->op_a.p, side, en * 4);
+    h2d(c, c->op_b.p, pole, pn * 4);
+    uchar4* ext = c->op_c.as<uchar4>();
+    dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), W, pole_rows, ext, extW);
+    launch_extend_wrap(c->st, c->op_b.as<uchar4>(), nullptr, W, pole_rows, ext + xn, extW);
+    if (!c->flow_pole) c->flow_pole.reset(new FlowEngine(&c->prof));
+    FlowIdx idx;
+    std::memset(&idx, 0, sizeof(idx));
+    idx.i0[0] = 0; idx.i1[0] = 1;
+    c->flow_pole->compute(c->st, pixflow_consts_by_name(c->P.polar_flow_alg), 2, 1, idx, ext, extW, pole_rows, nullptr,
+                          nullptr, S360_HINT_DOWN, c->op_d.as<float2>());
+    dev_pole_unit_post(c, ext + xn, c->op_d.as<float2>(), W, pole_rows, extW, c->op_e.as<uchar4>(), H);
+    d2h(c, warped_out, c->op_e.p, en * 4);
+    if (flow_out) d2h(c, flow_out, c->op_d.p, xn * sizeof(float2));
+  });
+}
+int s360_sharpen(s360_ctx* c, uint8_t* bgr, int w, int h, float sharpening) {
+  return guard(c, [&] {
+    need(c && bgr && w > 1 && h > 1, "bad argument");
+    const size_t n = (size_t)w * h;
+    c->op_a.ensure(n * 3); c->op_b.ensure(n * 4); c->op_c.ensure(n * 4); c->op_d.ensure(n * 3 * sizeof(float));
+    h2d(c, c->op_a.p, bgr, n * 3);
+    launch_bgr_to_bgra(c->st, c->op_a.as<uint8_t>(), 3, c->op_b.as<uchar4>(), n);
+    launch_sharpen(c->st, c->op_b.as<uchar4>(), c->op_c.as<uchar4>(), c->op_d.as<float>(), w, h, 1.0f + sharpening);
+    launch_pack_bgr(c->st, c->op_b.as<uchar4>(), w, h, c->op_a.as<uint8_t>());
+    d2h(c, bgr, c->op_a.p, n * 3);
+  });
+}
+
+// ---- frame level ------------------------------------------------------------------------------------
+int s360_frame_upload_side(s360_ctx* c, int side_idx, const uint8_t* img, int w, int h, int channels) {
+  return guard(c, [&] { need(c && img && w > 0 && h > 0, "bad argument"); frame_upload_side(c, side_idx, img, w, h, channels); });
+}
+int s360_frame_upload_top(s360_ctx* c, const uint8_t* bgr, int w, int h) {
+  return guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, true, bgr, w, h); });
+}
+int s360_frame_upload_bottom(s360_ctx* c, const uint8_t* bgr, int w, int h) {
+  return guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, false, bgr, w, h); });
+}
+int s360_frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
+  return guard(c, [&] { need(c, "null ctx"); frame_render_pairs(c, p0, p1, use_prev); });
+}
+int s360_frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
+  return guard(c, [&] { need(c, "null ctx"); frame_finish(c, pole_mask, use_prev); });
+}
+int s360_frame_render(s360_ctx* c, int use_prev) {
+  return guard(c, [&] {
+    need(c, "null ctx");
+    frame_render_pairs(c, 0, (int)c->rig.side.size(), use_prev);
+    frame_finish(c, 15, use_prev);
+  });
+}
+int s360_frame_strip_ptr(s360_ctx* c, int eye, void** dev_ptr, size_t* bytes_per_pair) {
+  return guard(c, [&] {
+    need(c && dev_ptr && (eye == 0 || eye == 1), "bad argument");
+    FrameState& F = frame_state(c);
+    const int P = F.P, camH = c->g.cam_image_height, stripW = c->P.eqr_width / P;
+    const size_t per = (size_t)camH * stripW * sizeof(uchar4);
+    F.strips.ensure(2 * P * per);
+    *dev_ptr = F.strips.as<uint8_t>() + (size_t)eye * P * per;
+    if (bytes_per_pair) *bytes_per_pair = per;
+  });
+}
+int s360_frame_equirect_dev(s360_ctx* c, void** dev_ptr, size_t* bytes) {
+  return guard(c, [&] {
+    need(c && dev_ptr, "bad argument");
+    FrameState& F = frame_state(c);
+    need(F.outBGR.p != nullptr, "no frame rendered yet");
+    *dev_ptr = F.outBGR.p;
+    if (bytes) *bytes = (size_t)c->g.out_width * c->g.out_height * 3;
+  });
+}
+int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
+  return guard(c, [&] {
+    need(c && out_bgr, "bad argument");
+    FrameState& F = frame_state(c);
+    need(F.outBGR.p != nullptr, "no frame rendered yet");
+    d2h(c, out_bgr, F.outBGR.p, (size_t)c->g.out_width * c->g.out_height * 3);
+  });
+}
+
+int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_t* dst) {
+  return guard(c, [&] {
+    need(c && name && whc, "bad argument");
+    FrameState& F = frame_state(c);
+    const s360_geometry& g = c->g;
+    const int W = c->P.eqr_width, H = c->P.eqr_height, P = F.P;
+    const std::string n(name);
+    const void* src = nullptr;
+    int w = 0, h = 0, ch = 4;
+    const int nloc = F.side_p1 - F.side_p0;
+    if (n == "projection") {
+      need(idx >= 0 && idx < P && F.proj.p, "projection not available");
+      w = g.cam_image_width; h = g.cam_image_height;
+      src = F.proj.as<uchar4>() + (size_t)w * h * idx;
+    } else if (n == "overlap_l" || n == "overlap_r") {
+      need(idx >= F.side_p0 && idx < F.side_p1 && F.overlaps[F.last_side].p, "overlap not available");
+      w = g.overlap_image_width; h = g.cam_image_height;
+      const int j = idx - F.side_p0 + (n == "overlap_r" ? nloc : 0);
+      src = F.overlaps[F.last_side].as<uchar4>() + (size_t)w * h * j;
+    } else if (n == "side_pano_l" || n == "side_pano_r") {
+      const int e = n == "side_pano_r";
+      need(F.panoDbg[e].p, "enable keep_intermediates before rendering");
+      w = W; h = H; src = F.panoDbg[e].p;
+    } else if (n == "top_spherical") {
+      need(F.topSph.p, "not available"); w = W; h = g.top_rows; src = F.topSph.p;
+    } else if (n == "bottom_spherical") {
+      need(F.botSph.p, "not available"); w = W; h = g.bottom_rows; src = F.botSph.p;
+    } else if (n == "pole_warped") {
+      need(idx >= 0 && idx < 4 && F.poleWarped[idx].p, "not available"); w = W; h = H; src = F.poleWarped[idx].p;
+    } else if (n == "extended_side" || n == "extended_fisheye") {
+      need(idx >= 0 && idx < 4 && F.extImgs[F.last_pole].p, "not available");
+      w = F.extW; h = F.poleRows;
+      const int slot = n == "extended_side" ? idx : (idx < 2 ? 4 : 5);
+      src = F.extImgs[F.last_pole].as<uchar4>() + (size_t)w * h * slot;
+    } else if (n == "eye_l" || n == "eye_r") {
+      const int e = n == "eye_r";
+      need(F.pano[e].p, "not available");
+      w = W; h = H; ch = 3;
+      if (dst) {
+        c->op_f.ensure((size_t)w * h * 3);
+        launch_pack_bgr(c->st, F.pano[e].as<uchar4>(), w, h, c->op_f.as<uint8_t>());
+        src = c->op_f.p;
+      }
+    } else {
+      throw Error(S360_ERR_INVALID_ARG, "unknown intermediate name: " + n);
+    }
+    whc[0] = w; whc[1] = h; whc[2] = ch;
+    if (dst) d2h(c, dst, src, (size_t)w * h * ch);
+  });
+}
+int s360_frame_get_f32(s360_ctx* c, const char* name, int idx, int whc[3], float* dst) {
+  return guard(c, [&] {
+    need(c && name && whc, "bad argument");
+    FrameState& F = frame_state(c);
+    const s360_geometry& g = c->g;
+    const std::string n(name);
+    const void* src = nullptr;
+    int w = 0, h = 0;
+    const int nloc = F.side_p1 - F.side_p0;
+    if (n == "flow_l_to_r" || n == "flow_r_to_l") {
+      need(idx >= F.side_p0 && idx < F.side_p1 && F.sideFlows[F.last_side].p, "flow not available");
+      w = g.overlap_image_width; h = g.cam_image_height;
+      const int j = idx - F.side_p0 + (n == "flow_r_to_l" ? nloc : 0);
+      src = F.sideFlows[F.last_side].as<float2>() + (size_t)w * h * j;
+    } else if (n == "flow_pole") {
+      need(idx >= 0 && idx < 4 && F.poleFlows[F.last_pole].p, "flow not available");
+      w = F.extW; h = F.poleRows;
+      src = F.poleFlows[F.last_pole].as<float2>() + (size_t)w * h * idx;
+    } else {
+      throw Error(S360_ERR_INVALID_ARG, "unknown intermediate name: " + n);
+    }
+    whc[0] = w; whc[1] = h; whc[2] = 2;
+    if (dst) d2h(c, dst, src, (size_t)w * h * sizeof(float2));
+  });
+}
+
+// ---- measurement -----------------------------------------------------------------------------------
+int s360_profile_enable(s360_ctx* c, int on) {
+  return guard(c, [&] {
+    need(c, "null ctx");
+    S360_HIP(hipStreamSynchronize(c->st));
+    c->prof.clear();
+    c->prof.on = on != 0;
+  });
+}
+int s360_profile_get(s360_ctx* c, char* names_out, size_t names_cap, float* ms_out, int* launches_out, int cap) {
+  int n = 0;
+  const int rc = guard(c, [&] {
+    need(c && names_out && ms_out, "bad argument");
+    std::vector<float> ms;
+    std::vector<int> cnt;
+    c->prof.collect(ms, cnt);
+    std::string names;
+    for (size_t i = 0; i < c->prof.names.size() && (int)i < cap; ++i) {
+      if (i) names += ';';
+      names += c->prof.names[i];
+      ms_out[i] = ms[i];
+      if (launches_out) launches_out[i] = cnt[i];
+      n = (int)i + 1;
+    }
+    need(names.size() + 1 <= names_cap, "names buffer too small");
+    std::memcpy(names_out, names.c_str(), names.size() + 1);
+  });
+  return rc == S360_OK ? n : rc;
+}
+
+// ---- flow state files (CvUtil.cpp:159-199) -----------------------------------------------------------
+int s360_save_flow_to_file(const char* path, const float* flow, int w, int h) {
+  return guard(nullptr, [&] {
+    need(path && flow && w > 0 && h > 0, "bad argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) throw Error(S360_ERR_IO, std::string("file not found: ") + path);
+    const int rows = h, cols = w;
+    bool ok = std::fwrite(&rows, sizeof(rows), 1, f) == 1 && std::fwrite(&cols, sizeof(cols), 1, f) == 1;
+    ok = ok && std::fwrite(flow, sizeof(float) * 2, (size_t)w * h, f) == (size_t)w * h;
+    std::fclose(f);
+    if (!ok) throw Error(S360_ERR_IO, std::string("short write: ") + path);
+  });
+}
+int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, size_t cap_floats) {
+  return guard(nullptr, [&] {
+    need(path && w && h, "bad argument");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) throw Error(S360_ERR_IO, std::string("file not found: ") + path);
+    int rows = 0, cols = 0;
+    bool ok = std::fread(&rows, sizeof(rows), 1, f) == 1 && std::fread(&cols, sizeof(cols), 1, f) == 1;
+    if (ok && rows > 0 && cols > 0) {
+      *w = cols; *h = rows;
+      if (flow_out) {
+        const size_t n = (size_t)rows * cols * 2;
+        if (n > cap_floats) { std::fclose(f); throw Error(S360_ERR_INVALID_ARG, "flow_out too small"); }
+        ok = std::fread(flow_out, sizeof(float), n, f) == n;
+      }
+    } else ok = false;
+    std::fclose(f);
+    if (!ok) throw Error(S360_ERR_IO, std::string("bad flow file: ") + path);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+// ctx.hpp — the s360_ctx object behind the C ABI: one per device.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "core.hpp"
+#include "flow.hpp"
+#include "rig.hpp"
+
+namespace s360 {
+struct FrameState;  // render.hip
+}
+
+struct s360_ctx {
+  int device = 0;
+  hipStream_t st = nullptr;
+  s360::Rig rig;
+  s360_params P;
+  s360_geometry g;
+  s360::PoleRamp ramp;
+  int top_idx = -1, bottom_idx = -1;
+  s360::Profiler prof;
+  std::unique_ptr<s360::FlowEngine> flow;       // operator-level calls + side flows
+  std::unique_ptr<s360::FlowEngine> flow_pole;  // pole flows (different sizes: keeps both buffer sets resident)
+  std::string err;
+  // scratch for operator-level calls
+  s360::DevBuf op_a, op_b, op_c, op_d, op_e, op_f;
+  std::shared_ptr<s360::FrameState> frame;
+  void make_current() const { S360_HIP(hipSetDevice(device)); }
+};

@@ -1,0 +1,201 @@
+// flow.hip — FlowEngine: PixFlow::computeOpticalFlow (PixFlow.h:81-183) as a batched HIP
+// launch sequence on one stream. See flow.hpp.
+#include "flow.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace s360 {
+
+PixFlowConsts pixflow_consts_by_name(const std::string& name) {
+  PixFlowConsts c;
+  c.pyrScaleFactor = 0.9f;
+  c.smoothnessCoef = 0.001f;
+  c.verticalRegularizationCoef = 0.01f;
+  c.horizontalRegularizationCoef = 0.01f;
+  c.gradientStepSize = 0.5f;
+  c.downscaleFactor = 0.5f;
+  c.maxPercentage = 0;
+  if (name == "pixflow_low") return c;
+  if (name == "pixflow_search_20") {
+    c.maxPercentage = 20;
+    return c;
+  }
+  throw Error(-4, "unrecognized flow algorithm name: " + name);
+}
+
+BlurTaps gaussian_taps(int n, double sigma) {
+  // cv::getGaussianKernel(n, sigma, CV_32F): exp in double, taps stored as float, normalised by
+  // the double sum of the float taps.
+  float k[16];
+  const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  const double scale2X = -0.5 / (sigmaX * sigmaX);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    k[i] = (float)std::exp(scale2X * x * x);
+    sum += k[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
+  BlurTaps t;
+  std::memset(&t, 0, sizeof(t));
+  t.r = n / 2;
+  for (int j = 0; j <= t.r; ++j) t.k[j] = k[t.r + j];
+  return t;
+}
+
+void FlowLevels::build(int dw, int dh, float pyrScale) {
+  w.clear(); h.clear(); off.clear();
+  total = 0;
+  int cw = dw, ch = dh;
+  for (;;) {
+    w.push_back(cw); h.push_back(ch); off.push_back(total);
+    total += (size_t)cw * ch;
+    const int nw = int(cw * pyrScale + 0.5f), nh = int(ch * pyrScale + 0.5f);
+    if (nh <= 24 || nw <= 24 || w.size() >= 1000) break;  // kPyrMinImageSize, kPyrMaxLevels
+    cw = nw; ch = nh;
+  }
+}
+
+void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, const FlowIdx& idx,
+                         const uchar4* images, int w, int h, const uchar4* prev_images, const float2* prev_flow,
+                         int hint, float2* out) {
+  if (B > kMaxFlows) throw Error(-1, "FlowEngine: batch too large");
+  Profiler& P = *prof_;
+  dw_ = int(w * pc.downscaleFactor);
+  dh_ = int(h * pc.downscaleFactor);
+  const size_t n0 = (size_t)dw_ * dh_;
+  lv_.build(dw_, dh_, pc.pyrScaleFactor);
+  const int L = (int)lv_.w.size();
+  const bool usePrev = prev_flow != nullptr;
+
+  down_.ensure(N * n0 * sizeof(uchar4));
+  gray_.ensure(N * n0 * sizeof(float));
+  pyrI_.ensure(N * lv_.total * sizeof(float));
+  pyrA_.ensure(N * lv_.total * sizeof(float));
+  G_.ensure(N * n0 * sizeof(float2));
+  Gtmp_.ensure(N * n0 * sizeof(float2));
+  flowA_.ensure(B * n0 * sizeof(float2));
+  flowB_.ensure(B * n0 * sizeof(float2));
+  blurred_.ensure(B * n0 * sizeof(float2));
+  full_.ensure((size_t)B * w * h * sizeof(float2));
+  float* pyrI = pyrI_.as<float>();
+  float* pyrA = pyrA_.as<float>();
+  auto LI = [&](int l) { return pyrI + (size_t)N * lv_.off[l]; };
+  auto LA = [&](int l) { return pyrA + (size_t)N * lv_.off[l]; };
+
+  const BlurTaps tPre = gaussian_taps(5, 0.25f), tGrad = gaussian_taps(3, 0.5f), tFlow = gaussian_taps(15, 8.0f),
+                 tFinal = gaussian_taps(3, 1.0f);
+  {
+    ProfScope ps(P, "flow_entry");
+    launch_resize_cubic_u8c4(st, images, w, h, (size_t)w * h, down_.as<uchar4>(), dw_, dh_, n0, N);
+    launch_gray_alpha(st, down_.as<uchar4>(), n0, n0, gray_.as<float>(), LA(0), n0, N);
+    launch_sepblur(st, gray_.as<float>(), LI(0), dw_, dh_, 1, n0, N, tPre);
+  }
+  {
+    ProfScope ps(P, "flow_pyramid");
+    for (int l = 1; l < L; ++l) {
+      const size_t ns = (size_t)lv_.w[l - 1] * lv_.h[l - 1], nd = (size_t)lv_.w[l] * lv_.h[l];
+      launch_resize_linear_f32(st, LI(l - 1), lv_.w[l - 1], lv_.h[l - 1], ns, LI(l), lv_.w[l], lv_.h[l], nd, 1, N, 1.f,
+                               0);
+      launch_resize_linear_f32(st, LA(l - 1), lv_.w[l - 1], lv_.h[l - 1], ns, LA(l), lv_.w[l], lv_.h[l], nd, 1, N, 1.f,
+                               0);
+    }
+  }
+  float2* prevPyr = nullptr;
+  float* motionPyr = nullptr;
+  if (usePrev) {
+    ProfScope ps(P, "flow_prev");
+    prevdown_.ensure(N * n0 * sizeof(uchar4));
+    prevPyr_.ensure(B * lv_.total * sizeof(float2));
+    motionPyr_.ensure(N * lv_.total * sizeof(float));
+    prevPyr = prevPyr_.as<float2>();
+    motionPyr = motionPyr_.as<float>();
+    launch_resize_cubic_u8c4(st, prev_images, w, h, (size_t)w * h, prevdown_.as<uchar4>(), dw_, dh_, n0, N);
+    launch_motion(st, down_.as<uchar4>(), prevdown_.as<uchar4>(), n0, n0, motionPyr, n0, N);
+    // prevFlowDownscaled = resize(prevFlow) * (rows_down / rows_full)  (PixFlow.h:103-104)
+    launch_resize_cubic_f32c2(st, prev_flow, w, h, (size_t)w * h, prevPyr, dw_, dh_, n0, B, float(dh_) / float(h));
+    for (int l = 1; l < L; ++l) {
+      const size_t ns = (size_t)lv_.w[l - 1] * lv_.h[l - 1], nd = (size_t)lv_.w[l] * lv_.h[l];
+      launch_resize_linear_f32(st, (const float*)(prevPyr + (size_t)B * lv_.off[l - 1]), lv_.w[l - 1], lv_.h[l - 1], ns,
+                               (float*)(prevPyr + (size_t)B * lv_.off[l]), lv_.w[l], lv_.h[l], nd, 2, B, 1.f, 0);
+      launch_resize_linear_f32(st, motionPyr + (size_t)N * lv_.off[l - 1], lv_.w[l - 1], lv_.h[l - 1], ns,
+                               motionPyr + (size_t)N * lv_.off[l], lv_.w[l], lv_.h[l], nd, 1, N, 1.f, 0);
+    }
+    // rescale the previous flow at each level (PixFlow.h:147-153); level 0 factor is exactly 1
+    for (int l = 1; l < L; ++l)
+      launch_scale_f32(st, (float*)(prevPyr + (size_t)B * lv_.off[l]), (size_t)B * lv_.w[l] * lv_.h[l] * 2,
+                       float(lv_.h[l]) / float(lv_.h[0]));
+  }
+
+  float2* cur = flowA_.as<float2>();
+  float2* oth = flowB_.as<float2>();
+  const float invPyr = 1.0f / pc.pyrScaleFactor;
+  if (capture_levels) capture_levels->clear();
+  for (int l = L - 1; l >= 0; --l) {
+    const int wl = lv_.w[l], hl = lv_.h[l];
+    const size_t nl = (size_t)wl * hl;
+    {
+      ProfScope ps(P, "flow_gradients");
+      launch_sobel(st, LI(l), wl, hl, nl, Gtmp_.as<float2>(), N);
+      launch_sepblur(st, Gtmp_.as<float>(), G_.as<float>(), wl, hl, 2, nl, N, tGrad);
+    }
+    if (l == L - 1) {
+      S360_HIP(hipMemsetAsync(cur, 0, B * nl * sizeof(float2), st));
+      if (pc.maxPercentage > 0 && hint != 0) {
+        ProfScope ps(P, "flow_search_init");
+        I1eq_.ensure(B * nl * sizeof(float));
+        const int dist = (24 * pc.maxPercentage + 50) / 100;
+        launch_search_init(st, LI(l), LA(l), wl, hl, nl, B, idx, cur, hint, dist, I1eq_.as<float>());
+      }
+    }
+    {
+      ProfScope ps(P, "flow_blur15");
+      launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
+    }
+    {
+      ProfScope ps(P, "flow_sweep");
+      launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), cur, wl, hl, nl, B, idx, +1, pc);
+    }
+    {
+      ProfScope ps(P, "flow_median");
+      launch_median5_c2(st, cur, oth, wl, hl, nl, B);
+    }
+    {
+      ProfScope ps(P, "flow_sweep");
+      launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), oth, wl, hl, nl, B, idx, -1, pc);
+    }
+    {
+      ProfScope ps(P, "flow_median");
+      launch_median5_c2(st, oth, cur, wl, hl, nl, B);
+    }
+    {
+      ProfScope ps(P, "flow_diffusion");
+      launch_diffusion(st, cur, oth, wl, hl, nl, B, tFlow, LA(l), idx);
+    }
+    if (usePrev) {
+      ProfScope ps(P, "flow_prev");
+      launch_adjust_toward_prev(st, oth, prevPyr + (size_t)B * lv_.off[l], motionPyr + (size_t)N * lv_.off[l], nl, nl, B,
+                                idx);
+    }
+    if (capture_levels) {
+      std::vector<float> hbuf(B * nl * 2);
+      S360_HIP(hipMemcpyAsync(hbuf.data(), oth, hbuf.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+      S360_HIP(hipStreamSynchronize(st));
+      capture_levels->push_back(std::move(hbuf));
+    }
+    if (l > 0) {
+      ProfScope ps(P, "flow_upscale");
+      launch_resize_cubic_f32c2(st, oth, wl, hl, nl, cur, lv_.w[l - 1], lv_.h[l - 1],
+                                (size_t)lv_.w[l - 1] * lv_.h[l - 1], B, invPyr);
+    } else {
+      ProfScope ps(P, "flow_final");
+      launch_resize_linear_f32(st, (const float*)oth, wl, hl, nl, full_.as<float>(), w, h, (size_t)w * h, 2, B,
+                               1.0f / pc.downscaleFactor, 1);
+      launch_sepblur(st, full_.as<float>(), (float*)out, w, h, 2, (size_t)w * h, B, tFinal);
+    }
+  }
+}
+
+}  // namespace s360

@@ -1,0 +1,52 @@
+// flow.hpp — host orchestration of PixFlow::computeOpticalFlow on the GPU.
+//
+// FlowEngine computes B flows over N images of identical size in one batched launch
+// sequence (PixFlow.h:81-183). Flow b matches image idx.i0[b] against idx.i1[b]; all
+// per-image work (downscale, grey/alpha, pyramids, gradients) is done once per image.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "core.hpp"
+#include "flow_kernels.hpp"
+
+namespace s360 {
+
+// makeOpticalFlowByName (OpticalFlowFactory.h:23-64). Throws Error(-4) for unknown names.
+PixFlowConsts pixflow_consts_by_name(const std::string& name);
+// OpenCV getGaussianKernel(n, sigma, CV_32F) folded to centre + symmetric taps.
+BlurTaps gaussian_taps(int ksize, double sigma);
+
+struct FlowLevels {
+  std::vector<int> w, h;          // level sizes, finest first (PixFlow.h:477-491)
+  std::vector<size_t> off;        // pixel offset of each level inside a per-image pyramid plane
+  size_t total = 0;               // pixels per image over all levels
+  void build(int dw, int dh, float pyrScale);
+};
+
+class FlowEngine {
+ public:
+  explicit FlowEngine(Profiler* prof) : prof_(prof) {}
+  // images: device [N][h][w] uchar4. prev_images (nullable): previous frame's same packing;
+  // prev_flow (nullable): device [B][h][w] float2. out: device [B][h][w] float2.
+  void compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, const FlowIdx& idx, const uchar4* images, int w,
+               int h, const uchar4* prev_images, const float2* prev_flow, int hint, float2* out);
+  // debugging taps for parity tests (valid after compute() + stream sync)
+  const uchar4* dbg_down() const { return down_.as<uchar4>(); }
+  const float* dbg_pyr_I() const { return pyrI_.as<float>(); }
+  const float* dbg_pyr_A() const { return pyrA_.as<float>(); }
+  const FlowLevels& levels() const { return lv_; }
+  int dw() const { return dw_; }
+  int dh() const { return dh_; }
+  // optional per-level flow capture (coarsest first), host side, for tests
+  std::vector<std::vector<float>>* capture_levels = nullptr;
+
+ private:
+  Profiler* prof_;
+  FlowLevels lv_;
+  int dw_ = 0, dh_ = 0;
+  DevBuf down_, prevdown_, gray_, pyrI_, pyrA_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
+      motionPyr_, I1eq_;
+};
+
+}  // namespace s360

@@ -1,0 +1,567 @@
+// flow_kernels.hip — HIP kernels of PixFlow::computeOpticalFlow for gfx950 (CDNA4).
+//
+// Reference: surround360_render/source/optical_flow/PixFlow.h:81-534. Every kernel is
+// batched: blockIdx.z selects one of B independent flows (the 28 side flows, or the 4 pole
+// flows, of one frame share their dimensions), buffers are [plane][B][h][w].
+// All arithmetic is float32 in the reference's operation order (no FMA contraction, IEEE
+// sqrt/div) so results are bit-identical to the CPU restatement.
+//
+// Layouts: BGRA images uchar4; grey/alpha planes float; gradients packed float2 (Ix,Iy) so a
+// bilinear gather is two 16-byte loads; flow float2 (fx,fy).
+#include "flow_kernels.hpp"
+
+#include <stdexcept>
+
+#include "devmath.hpp"
+
+namespace s360 {
+
+// ------------------------------------------------------------------------------------------
+// resize INTER_CUBIC 8UC4 (PixFlow.h:98-107 entry downscale; TRSP:938-957 final resize).
+// OpenCV fixed point: short taps = round(w*2048); H pass int; V pass (sum + 2^21) >> 22.
+__global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restrict__ src, int sw, int sh,
+                                                           size_t sbs, uchar4* __restrict__ dst, int dw, int dh,
+                                                           size_t dbs, double scx, double scy) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  src += sbs * blockIdx.z;
+  dst += dbs * blockIdx.z;
+  int sx, sy;
+  float fx, fy, cb[4];
+  int ax[4], ay[4];
+  resize_coord(dx, scx, &sx, &fx);
+  cubic_coeffs(fx, cb);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ax[k] = sat_s16(cv_round(cb[k] * 2048.f));
+  resize_coord(dy, scy, &sy, &fy);
+  cubic_coeffs(fy, cb);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ay[k] = sat_s16(cv_round(cb[k] * 2048.f));
+  int vx = 0, vy = 0, vz = 0, vw = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uchar4* S = src + (size_t)clip_idx(sy - 1 + r, sh) * sw;
+    int hx = 0, hy = 0, hz = 0, hw = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uchar4 p = S[clip_idx(sx - 1 + q, sw)];
+      hx += p.x * ax[q]; hy += p.y * ax[q]; hz += p.z * ax[q]; hw += p.w * ax[q];
+    }
+    vx += hx * ay[r]; vy += hy * ay[r]; vz += hz * ay[r]; vw += hw * ay[r];
+  }
+  uchar4 o;
+  o.x = (unsigned char)sat_u8((vx + (1 << 21)) >> 22);
+  o.y = (unsigned char)sat_u8((vy + (1 << 21)) >> 22);
+  o.z = (unsigned char)sat_u8((vz + (1 << 21)) >> 22);
+  o.w = (unsigned char)sat_u8((vw + (1 << 21)) >> 22);
+  dst[(size_t)dy * dw + dx] = o;
+}
+
+// BGRA -> grey float in [0,1] (pre-blur) and alpha float (PixFlow.h:121-135).
+// cvtColor BGRA2GRAY 8-bit: (B*1868 + G*9617 + R*4899 + 2^13) >> 14; "/= 255.0f" == * float(1/255.).
+__global__ __launch_bounds__(256) void k_gray_alpha(const uchar4* __restrict__ src, size_t n, size_t sbs,
+                                                    float* __restrict__ gray, float* __restrict__ alpha,
+                                                    size_t pbs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uchar4 p = src[sbs * blockIdx.z + i];
+  const float inv255 = (float)(1.0 / 255.0);
+  const int g = (p.x * 1868 + p.y * 9617 + p.z * 4899 + (1 << 13)) >> 14;
+  gray[pbs * blockIdx.z + i] = (float)g * inv255;
+  alpha[pbs * blockIdx.z + i] = (float)p.w * inv255;
+}
+
+// motion map for temporal regularisation (PixFlow.h:109-117): sum|dBGR| / (255*3), double then float.
+__global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, const uchar4* __restrict__ prev,
+                                                size_t n, size_t sbs, float* __restrict__ motion, size_t pbs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uchar4 a = cur[sbs * blockIdx.z + i], b = prev[sbs * blockIdx.z + i];
+  const double s = fabs((double)((int)a.x - (int)b.x)) + fabs((double)((int)a.y - (int)b.y)) +
+                   fabs((double)((int)a.z - (int)b.z));
+  motion[pbs * blockIdx.z + i] = (float)(s / (double)(255.0f * 3.0f));
+}
+
+// ------------------------------------------------------------------------------------------
+// Separable symmetric Gaussian, BORDER_REFLECT_101, row pass then column pass, evaluation
+// order k[c]*x[c] + sum_j k[c+j]*(x[c+j] + x[c-j]) (GaussianBlur; PixFlow.h:137-138, 363-366,
+// 379-383, 439-443, 178-182). One LDS tile with halo per workgroup; the row-pass result is
+// rounded to float in LDS exactly like the intermediate image of the two-pass reference.
+// EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453).
+constexpr int SB_TW = 64, SB_TH = 16;
+template <int R, int CN, int EPI>
+__global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
+                                                 size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
+                                                 const float* __restrict__ A, FlowIdx idx) {
+  constexpr int IW = SB_TW + 2 * R, IH = SB_TH + 2 * R;
+  __shared__ float s_in[IH][IW][CN];
+  __shared__ float s_mid[IH][SB_TW][CN];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
+  src += bs * CN * blockIdx.z;
+  dst += bs * CN * blockIdx.z;
+  for (int i = tid; i < IH * IW; i += 256) {
+    const int ly = i / IW, lx = i - ly * IW;
+    const int gy = reflect101(ty0 - R + ly, h), gx = reflect101(tx0 - R + lx, w);
+    const float* p = src + ((size_t)gy * w + gx) * CN;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) s_in[ly][lx][k] = p[k];
+  }
+  __syncthreads();
+  for (int i = tid; i < IH * SB_TW; i += 256) {
+    const int ly = i / SB_TW, lx = i - ly * SB_TW;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+      float s = taps.k[0] * s_in[ly][lx + R][k];
+#pragma unroll
+      for (int j = 1; j <= R; ++j) s += taps.k[j] * (s_in[ly][lx + R + j][k] + s_in[ly][lx + R - j][k]);
+      s_mid[ly][lx][k] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < SB_TH * SB_TW; i += 256) {
+    const int ly = i / SB_TW, lx = i - ly * SB_TW;
+    const int gx = tx0 + lx, gy = ty0 + ly;
+    if (gx >= w || gy >= h) continue;
+    float out[CN];
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+      float s = taps.k[0] * s_mid[ly + R][lx][k];
+#pragma unroll
+      for (int j = 1; j <= R; ++j) s += taps.k[j] * (s_mid[ly + R + j][lx][k] + s_mid[ly + R - j][lx][k]);
+      out[k] = s;
+    }
+    const size_t o = (size_t)gy * w + gx;
+    if (EPI == 1) {
+      const float c = 1.0f - A[bs * idx.i0[blockIdx.z] + o] * A[bs * idx.i1[blockIdx.z] + o];
+#pragma unroll
+      for (int k = 0; k < CN; ++k) out[k] = c * out[k] + (1.0f - c) * s_in[ly + R][lx + R][k];
+    }
+#pragma unroll
+    for (int k = 0; k < CN; ++k) dst[o * CN + k] = out[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// resize INTER_LINEAR float (pyramid x0.9, PixFlow.h:487; final upscale :176).
+// Horizontal: s<0 => (0, f=0); s>=sw-1 => S[sw-1]*1; vertical rows clipped, f kept.
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restrict__ src, int sw, int sh, size_t sbs,
+                                                           float* __restrict__ dst, int dw, int dh, size_t dbs,
+                                                           double scx, double scy, float post_scale, int do_scale) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  src += sbs * CN * blockIdx.z;
+  dst += dbs * CN * blockIdx.z;
+  int sx, sy;
+  float fx, fy;
+  resize_coord(dx, scx, &sx, &fx);
+  if (sx < 0) { fx = 0; sx = 0; }
+  if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+  resize_coord(dy, scy, &sy, &fy);
+  const float* S0 = src + (size_t)clip_idx(sy, sh) * sw * CN;
+  const float* S1 = src + (size_t)clip_idx(sy + 1, sh) * sw * CN;
+  const float b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+  for (int k = 0; k < CN; ++k) {
+    float h0, h1;
+    if (sx >= sw - 1) {
+      h0 = S0[sx * CN + k] * 1.0f;
+      h1 = S1[sx * CN + k] * 1.0f;
+    } else {
+      const float a0 = 1.f - fx, a1 = fx;
+      h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
+      h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
+    }
+    float v = h0 * b0 + h1 * b1;
+    if (do_scale) v *= post_scale;
+    dst[((size_t)dy * dw + dx) * CN + k] = v;
+  }
+}
+
+// resize INTER_CUBIC float2 (flow upscale between levels, PixFlow.h:170-171; prevFlow :103-104),
+// followed by the scalar multiply.
+__global__ __launch_bounds__(256) void k_resize_cubic_f32c2(const float2* __restrict__ src, int sw, int sh,
+                                                            size_t sbs, float2* __restrict__ dst, int dw, int dh,
+                                                            size_t dbs, double scx, double scy, float post_scale) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  src += sbs * blockIdx.z;
+  dst += dbs * blockIdx.z;
+  int sx, sy;
+  float fx, fy, ax[4], ay[4];
+  resize_coord(dx, scx, &sx, &fx);
+  cubic_coeffs(fx, ax);
+  resize_coord(dy, scy, &sy, &fy);
+  cubic_coeffs(fy, ay);
+  const int x0 = clip_idx(sx - 1, sw), x1 = clip_idx(sx, sw), x2 = clip_idx(sx + 1, sw), x3 = clip_idx(sx + 2, sw);
+  float hx[4], hy[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float2* S = src + (size_t)clip_idx(sy - 1 + r, sh) * sw;
+    const float2 p0 = S[x0], p1 = S[x1], p2 = S[x2], p3 = S[x3];
+    hx[r] = p0.x * ax[0] + p1.x * ax[1] + p2.x * ax[2] + p3.x * ax[3];
+    hy[r] = p0.y * ax[0] + p1.y * ax[1] + p2.y * ax[2] + p3.y * ax[3];
+  }
+  float2 o;
+  o.x = hx[0] * ay[0] + hx[1] * ay[1] + hx[2] * ay[2] + hx[3] * ay[3];
+  o.y = hy[0] * ay[0] + hy[1] * ay[1] + hy[2] * ay[2] + hy[3] * ay[3];
+  o.x *= post_scale;
+  o.y *= post_scale;
+  dst[(size_t)dy * dw + dx] = o;
+}
+
+__global__ __launch_bounds__(256) void k_scale_f32(float* __restrict__ p, size_t n, float s) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] *= s;
+}
+
+// adjustFlowTowardPrevious (PixFlow.h:185-193), in place.
+__global__ __launch_bounds__(256) void k_adjust_toward_prev(float2* __restrict__ flow, const float2* __restrict__ prev,
+                                                            const float* __restrict__ motion, size_t n, size_t bs,
+                                                            FlowIdx idx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t o = bs * blockIdx.z + i;
+  const float w = 1.0f - motion[bs * idx.i1[blockIdx.z] + i];
+  float2 f = flow[o];
+  const float2 p = prev[o];
+  f.x = f.x * (1.0f - w) + p.x * w;
+  f.y = f.y * (1.0f - w) + p.y * w;
+  flow[o] = f;
+}
+
+// Sobel ksize=1 on I -> packed (Ix, Iy), BORDER_REPLICATE, no scale (PixFlow.h:356-359).
+__global__ __launch_bounds__(256) void k_sobel(const float* __restrict__ I, int w, int h, size_t bs,
+                                               float2* __restrict__ G) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  I += bs * blockIdx.z;
+  G += bs * blockIdx.z;
+  const float* r = I + (size_t)y * w;
+  float2 g;
+  g.x = r[min(x + 1, w - 1)] - r[max(x - 1, 0)];
+  g.y = I[(size_t)min(y + 1, h - 1) * w + x] - I[(size_t)max(y - 1, 0) * w + x];
+  G[(size_t)y * w + x] = g;
+}
+
+// ------------------------------------------------------------------------------------------
+// medianBlur(5) on CV_32FC2, replicate border (PixFlow.h:398,411): exact per-channel median of
+// 25 by forgetful selection (drop min and max of a shrinking working set).
+__device__ __forceinline__ void mnmx(float& a, float& b) {
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+__device__ __forceinline__ float median25(const float* v) {
+  // Forgetful selection: a working set of 14 can never contain the median as its min or max;
+  // drop both, insert the next sample into the freed slot, repeat until 3 remain.
+  float ws[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) ws[i] = v[i];
+#pragma unroll
+  for (int n = 14; n >= 3; --n) {
+#pragma unroll
+    for (int i = 1; i < n; ++i) mnmx(ws[0], ws[i]);
+#pragma unroll
+    for (int i = 1; i < n - 1; ++i) mnmx(ws[i], ws[n - 1]);
+    if (n > 3) ws[0] = v[14 + (14 - n)];
+  }
+  return ws[1];
+}
+__global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ src, float2* __restrict__ dst, int w,
+                                                    int h, size_t bs) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  src += bs * blockIdx.z;
+  dst += bs * blockIdx.z;
+  float vx[25], vy[25];
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const float2* r = src + (size_t)clip_idx(y + dy, h) * w;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const float2 p = r[clip_idx(x + dx, w)];
+      vx[(dy + 2) * 5 + dx + 2] = p.x;
+      vy[(dy + 2) * 5 + dx + 2] = p.y;
+    }
+  }
+  float2 o;
+  o.x = median25(vx);
+  o.y = median25(vy);
+  dst[(size_t)y * w + x] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// The propagation sweeps (PixFlow.h:388-410). errorFunction (PixFlow.h:493-534, no directional
+// term), getPixBilinear32FExtend (:457-475), proposeFlowUpdate (:415-435), errorGradient (:195-217).
+struct SweepConst {
+  float smoothnessCoef, vertCoef, horizCoef, gradStep;
+  float fcols, frows;  // float(I0.cols), float(I0.rows)
+  float wm2, hm2;      // w - 2.0f, h - 2.0f
+};
+
+__device__ __forceinline__ float2 bilinear_g1(const float2* __restrict__ G1, int w, float x, float y,
+                                              const SweepConst& c) {
+  x = (0.0f < x) ? x : 0.0f;
+  x = (x < c.wm2) ? x : c.wm2;
+  y = (0.0f < y) ? y : 0.0f;
+  y = (y < c.hm2) ? y : c.hm2;
+  const int x0 = (int)x, y0 = (int)y;
+  const float xR = x - (float)x0, yR = y - (float)y0;
+  const float2* p = G1 + (size_t)y0 * w + x0;
+  const float2 f00 = p[0], f10 = p[1], f01 = p[w], f11 = p[w + 1];
+  float2 r;
+  {
+    const float a1 = f00.x, a2 = f10.x - f00.x, a3 = f01.x - f00.x, a4 = f00.x + f11.x - f10.x - f01.x;
+    r.x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  {
+    const float a1 = f00.y, a2 = f10.y - f00.y, a3 = f01.y - f00.y, a4 = f00.y + f11.y - f10.y - f01.y;
+    r.y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  return r;
+}
+
+__device__ __forceinline__ float error_fn(const float2* __restrict__ G1, int w, int x, int y, float2 g0, float2 bf,
+                                          float fdx, float fdy, const SweepConst& c) {
+  const float matchX = (float)x + fdx;
+  const float matchY = (float)y + fdy;
+  const float2 g1 = bilinear_g1(G1, w, matchX, matchY, c);
+  const float dfx = bf.x - fdx, dfy = bf.y - fdy;
+  const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
+  const float ex = g0.x - g1.x, ey = g0.y - g1.y;
+  float err = sqrtf(ex * ex + ey * ey) + smoothness * c.smoothnessCoef + c.vertCoef * fabsf(fdy) / c.fcols +
+              c.horizCoef * fabsf(fdx) / c.frows;
+  return err;
+}
+
+// v1: one workgroup per flow, anti-diagonal wavefront, one barrier per diagonal. The previous
+// diagonal's flow lives in LDS indexed by row, so left = diag[prev][yi], up = diag[prev][yi-1].
+// dir=+1: top-left sweep; dir=-1: bottom-right sweep expressed through mirrored virtual coordinates.
+__global__ __launch_bounds__(1024) void k_sweep_diag(const float2* __restrict__ G, const float* __restrict__ A,
+                                                     const float2* __restrict__ blurred, float2* __restrict__ flow,
+                                                     int w, int h, size_t bs, FlowIdx idx, int dir, SweepConst c) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2* diag = reinterpret_cast<float2*>(smem_raw);  // [2][h]
+  const int b = blockIdx.x;
+  const float2* __restrict__ G0 = G + bs * idx.i0[b];
+  const float2* __restrict__ G1 = G + bs * idx.i1[b];
+  const float* __restrict__ A0 = A + bs * idx.i0[b];
+  const float* __restrict__ A1 = A + bs * idx.i1[b];
+  blurred += bs * b;
+  flow += bs * b;
+  const float kEps = 0.001f, kThr = 0.9f;
+  const int nd = w + h - 1;
+  for (int d = 0; d < nd; ++d) {
+    const int cur = d & 1, prv = cur ^ 1;
+    const int ylo = max(0, d - (w - 1)), yhi = min(h - 1, d);
+    for (int yi = ylo + (int)threadIdx.x; yi <= yhi; yi += blockDim.x) {
+      const int xi = d - yi;
+      const int x = dir > 0 ? xi : w - 1 - xi;
+      const int y = dir > 0 ? yi : h - 1 - yi;
+      const size_t idx = (size_t)y * w + x;
+      float2 f = flow[idx];
+      if (A0[idx] > kThr && A1[idx] > kThr) {
+        const float2 g0 = G0[idx], bf = blurred[idx];
+        float currErr = error_fn(G1, w, x, y, g0, bf, f.x, f.y, c);
+        if (xi > 0) {
+          const float2 p = diag[prv * h + yi];
+          const float e = error_fn(G1, w, x, y, g0, bf, p.x, p.y, c);
+          if (e < currErr) { f = p; currErr = e; }
+        }
+        if (yi > 0) {
+          const float2 p = diag[prv * h + yi - 1];
+          const float e = error_fn(G1, w, x, y, g0, bf, p.x, p.y, c);
+          if (e < currErr) { f = p; currErr = e; }
+        }
+        const float ex = error_fn(G1, w, x, y, g0, bf, f.x + kEps, f.y + 0.0f, c);
+        const float ey = error_fn(G1, w, x, y, g0, bf, f.x + 0.0f, f.y + kEps, c);
+        const float gx = (ex - currErr) / kEps, gy = (ey - currErr) / kEps;
+        f.x = f.x - c.gradStep * gx;
+        f.y = f.y - c.gradStep * gy;
+        flow[idx] = f;
+      }
+      diag[cur * h + yi] = f;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- pixflow_search_20 only: adjustInitialFlow at the coarsest level (PixFlow.h:219-342) ----
+__global__ void k_search_init(const float* __restrict__ I, const float* __restrict__ A, int w, int h, size_t pbs,
+                              FlowIdx idx, float2* __restrict__ flow, int hint, int dist, float* __restrict__ I1eq) {
+  // one workgroup per flow; thread 0 computes the global ratio sequentially, then all threads search.
+  const int b = blockIdx.x;
+  const float* __restrict__ I0 = I + pbs * idx.i0[b];
+  const float* __restrict__ I1 = I + pbs * idx.i1[b];
+  const float* __restrict__ A0 = A + pbs * idx.i0[b];
+  const float* __restrict__ A1 = A + pbs * idx.i1[b];
+  flow += pbs * b;
+  I1eq += pbs * b;
+  __shared__ float s_ratio;
+  if (threadIdx.x == 0) {
+    float sumL = 0, sumR = 0;
+    for (int i = 0; i < w * h; ++i) {
+      const float a = A0[i] * A1[i];
+      sumL += a * I0[i];
+      sumR += a * I1[i];
+    }
+    s_ratio = sumL / sumR;
+  }
+  __syncthreads();
+  const float ratio = s_ratio;
+  for (int i = threadIdx.x; i < w * h; i += blockDim.x) I1eq[i] = I1[i] * ratio;
+  __syncthreads();
+  const int kRatio = 8;
+  const int ortho = (dist + kRatio / 2) / kRatio;
+  const int thickness = 2 * ortho + 1;
+  int bx, by, bw, bh;
+  if (hint == 1) { bx = 0; by = -ortho; bw = dist + 1; bh = thickness; }
+  else if (hint == 2) { bx = -ortho; by = 0; bw = thickness; bh = dist + 1; }
+  else if (hint == 3) { bx = -dist; by = -ortho; bw = dist + 1; bh = thickness; }
+  else { bx = -ortho; by = -dist; bw = thickness; bh = dist + 1; }
+  auto patchErr = [&](int i0x, int i0y, int i1x, int i1y) -> float {
+    float sad = 0, alpha = 0;
+    for (int dy = -2; dy <= 2; ++dy) {
+      const int d0y = i0y + dy;
+      if (0 <= d0y && d0y < h) {
+        const int d1y = min(max(i1y + dy, 0), h - 1);
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int d0x = i0x + dx;
+          if (0 <= d0x && d0x < w) {
+            const int d1x = min(max(i1x + dx, 0), w - 1);
+            const float difference = I0[d0y * w + d0x] - I1eq[d1y * w + d1x];
+            sad += fabsf(difference);
+            alpha += A0[d0y * w + d0x] * A1[d1y * w + d1x];
+          }
+        }
+      }
+    }
+    sad /= alpha;
+    const float ddx = (float)(i1x - i0x), ddy = (float)(i1y - i0y);
+    const float length = (float)sqrt((double)ddx * ddx + (double)ddy * ddy);
+    sad *= 1 + length / dist;
+    return sad;
+  };
+  for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    const int i0y = i / w, i0x = i - i0y * w;
+    if (A0[i] > 0.9f) {
+      float errorBest = 0.8f * patchErr(i0x, i0y, i0x, i0y);
+      int bxb = i0x, byb = i0y;
+      for (int dy = by; dy < by + bh; ++dy)
+        for (int dx = bx; dx < bx + bw; ++dx) {
+          const int i1x = i0x + dx, i1y = i0y + dy;
+          if (0 <= i1x && i1x < w && 0 <= i1y && i1y < h) {
+            const float e = patchErr(i0x, i0y, i1x, i1y);
+            if (errorBest > e) { errorBest = e; bxb = i1x; byb = i1y; }
+          }
+        }
+      flow[i] = make_float2((float)(bxb - i0x), (float)(byb - i0y));
+    }
+  }
+}
+
+// ==========================================================================================
+// launchers
+static inline dim3 grid2d(int w, int h, int B, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y, B); }
+
+void launch_resize_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, size_t sbs, uchar4* dst, int dw,
+                              int dh, size_t dbs, int B) {
+  const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(k_resize_cubic_u8c4, grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx,
+                     scy);
+}
+void launch_gray_alpha(hipStream_t st, const uchar4* src, size_t n, size_t sbs, float* gray, float* alpha, size_t pbs,
+                       int B) {
+  hipLaunchKernelGGL(k_gray_alpha, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, src, n, sbs, gray, alpha,
+                     pbs);
+}
+void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t n, size_t sbs, float* motion,
+                   size_t pbs, int B) {
+  hipLaunchKernelGGL(k_motion, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, cur, prev, n, sbs, motion,
+                     pbs);
+}
+template <int R, int CN, int EPI>
+static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w, int h, size_t bs, int B,
+                             const BlurTaps& t, const float* A, const FlowIdx& idx) {
+  dim3 blk(64, 4);
+  dim3 grd((w + SB_TW - 1) / SB_TW, (h + SB_TH - 1) / SB_TH, B);
+  hipLaunchKernelGGL((k_sepblur<R, CN, EPI>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx);
+}
+void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
+                    const BlurTaps& t) {
+  static const FlowIdx none = {};
+  if (t.r == 1 && cn == 1) launch_sepblur_t<1, 1, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
+  else if (t.r == 1 && cn == 2) launch_sepblur_t<1, 2, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
+  else if (t.r == 2 && cn == 1) launch_sepblur_t<2, 1, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
+  else if (t.r == 7 && cn == 2) launch_sepblur_t<7, 2, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
+  else throw std::runtime_error("launch_sepblur: unsupported radius/channels");
+}
+void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
+                      const BlurTaps& t, const float* A, const FlowIdx& idx) {
+  launch_sepblur_t<7, 2, 1>(st, (const float*)flow, (float*)dst, w, h, bs, B, t, A, idx);
+}
+void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
+                              size_t dbs, int cn, int B, float post_scale, int do_scale) {
+  const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
+  dim3 blk(32, 8);
+  if (cn == 1)
+    hipLaunchKernelGGL((k_resize_linear_f32<1>), grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs,
+                       scx, scy, post_scale, do_scale);
+  else
+    hipLaunchKernelGGL((k_resize_linear_f32<2>), grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs,
+                       scx, scy, post_scale, do_scale);
+}
+void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
+                               int dh, size_t dbs, int B, float post_scale) {
+  const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
+  dim3 blk(32, 8);
+  hipLaunchKernelGGL(k_resize_cubic_f32c2, grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx,
+                     scy, post_scale);
+}
+void launch_scale_f32(hipStream_t st, float* p, size_t n, float s) {
+  hipLaunchKernelGGL(k_scale_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, s);
+}
+void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
+                               size_t bs, int B, const FlowIdx& idx) {
+  hipLaunchKernelGGL(k_adjust_toward_prev, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, flow, prev,
+                     motion, n, bs, idx);
+}
+void launch_sobel(hipStream_t st, const float* I, int w, int h, size_t bs, float2* G, int B) {
+  dim3 blk(64, 4);
+  hipLaunchKernelGGL(k_sobel, grid2d(w, h, B, blk), blk, 0, st, I, w, h, bs, G);
+}
+void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B) {
+  dim3 blk(64, 4);
+  hipLaunchKernelGGL(k_median5_c2, grid2d(w, h, B, blk), blk, 0, st, src, dst, w, h, bs);
+}
+void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow, int w, int h,
+                  size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc) {
+  SweepConst c;
+  c.smoothnessCoef = pc.smoothnessCoef;
+  c.vertCoef = pc.verticalRegularizationCoef;
+  c.horizCoef = pc.horizontalRegularizationCoef;
+  c.gradStep = pc.gradientStepSize;
+  c.fcols = (float)w;
+  c.frows = (float)h;
+  c.wm2 = (float)w - 2.0f;
+  c.hm2 = (float)h - 2.0f;
+  const int md = w < h ? w : h;
+  int threads = ((md + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  const size_t lds = (size_t)2 * h * sizeof(float2);
+  hipLaunchKernelGGL(k_sweep_diag, dim3(B), dim3(threads), lds, st, G, A, blurred, flow, w, h, bs, idx, dir, c);
+}
+void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
+                        const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq) {
+  hipLaunchKernelGGL(k_search_init, dim3(B), dim3(256), 0, st, I, A, w, h, pbs, idx, flow, hint, dist, I1eq);
+}
+
+}  // namespace s360

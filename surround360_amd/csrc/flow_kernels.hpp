@@ -1,0 +1,49 @@
+// flow_kernels.hpp — launchers of the PixFlow HIP kernels (flow_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace s360 {
+
+struct BlurTaps {  // centre tap k[0] and the r symmetric taps k[1..r]
+  int r;
+  float k[8];
+};
+// Which image planes a flow of the batch uses: flow b matches image i0[b] (I0) against i1[b] (I1).
+// The 14 side pairs need only 28 image pyramids for 28 flows (LtoR and RtoL share them).
+constexpr int kMaxFlows = 32;
+struct FlowIdx {
+  int i0[kMaxFlows];
+  int i1[kMaxFlows];
+};
+struct PixFlowConsts {  // OpticalFlowFactory.h:26-41 / :45-60
+  float pyrScaleFactor, smoothnessCoef, verticalRegularizationCoef, horizontalRegularizationCoef;
+  float gradientStepSize, downscaleFactor;
+  int maxPercentage;
+};
+
+void launch_resize_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, size_t sbs, uchar4* dst, int dw,
+                              int dh, size_t dbs, int B);
+void launch_gray_alpha(hipStream_t st, const uchar4* src, size_t n, size_t sbs, float* gray, float* alpha, size_t pbs,
+                       int B);
+void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t n, size_t sbs, float* motion,
+                   size_t pbs, int B);
+void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
+                    const BlurTaps& t);
+void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
+                      const BlurTaps& t, const float* A, const FlowIdx& idx);
+void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
+                              size_t dbs, int cn, int B, float post_scale, int do_scale);
+void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
+                               int dh, size_t dbs, int B, float post_scale);
+void launch_scale_f32(hipStream_t st, float* p, size_t n, float s);
+void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
+                               size_t bs, int B, const FlowIdx& idx);
+void launch_sobel(hipStream_t st, const float* I, int w, int h, size_t bs, float2* G, int B);
+void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
+void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow, int w, int h,
+                  size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc);
+void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
+                        const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
+
+}  // namespace s360

@@ -1,0 +1,469 @@
+// render.hip — renderStereoPanorama (TRSP:716-972) as a device-resident HIP pipeline.
+// Everything between "inputs uploaded" and "stacked equirect in HBM" runs on the context stream
+// with no host round trips; buffers are persistent (sized once from rig + eqr size).
+#include "render.hpp"
+
+#include <cmath>
+#include <cstring>
+
+#include "devmath.hpp"
+
+namespace s360 {
+
+// ------------------------------------------------------------------------------------------
+// Host-built lookup tables (the host's libm is the reference's libm: tanhf / exp of NovelView.cpp:138-141
+// and CvUtil.cpp:239-246 are evaluated here for every possible 8-bit input, so the device needs no
+// transcendental for them).
+void Tables::build(hipStream_t st, int std_feather) {
+  // OpenCV initInterTab2D(INTER_CUBIC, fixpt) — see SURVEY App. A.2
+  std::vector<float> tf(1024 * 16);
+  std::vector<short> ti(1024 * 16);
+  float t1[32][4];
+  for (int k = 0; k < 32; ++k) cubic_coeffs(k * (1.f / 32), t1[k]);
+  for (int iy = 0; iy < 32; ++iy)
+    for (int ix = 0; ix < 32; ++ix) {
+      float* f = &tf[(iy * 32 + ix) * 16];
+      short* i = &ti[(iy * 32 + ix) * 16];
+      int isum = 0;
+      for (int k1 = 0; k1 < 4; ++k1)
+        for (int k2 = 0; k2 < 4; ++k2) {
+          const float v = t1[iy][k1] * t1[ix][k2];
+          f[k1 * 4 + k2] = v;
+          isum += i[k1 * 4 + k2] = (short)sat_s16(cv_round(v * 32768.f));
+        }
+      if (isum != 32768) {
+        const int diff = isum - 32768;
+        int Mk1 = 2, Mk2 = 2, mk1 = 2, mk2 = 2;
+        for (int k1 = 2; k1 < 4; ++k1)
+          for (int k2 = 2; k2 < 4; ++k2) {
+            if (i[k1 * 4 + k2] < i[mk1 * 4 + mk2]) mk1 = k1, mk2 = k2;
+            else if (i[k1 * 4 + k2] > i[Mk1 * 4 + Mk2]) Mk1 = k1, Mk2 = k2;
+          }
+        if (diff < 0) i[Mk1 * 4 + Mk2] = (short)(i[Mk1 * 4 + Mk2] - diff);
+        else i[mk1 * 4 + mk2] = (short)(i[mk1 * 4 + mk2] - diff);
+      }
+    }
+  std::vector<float> t10(766), t5(766), fs(256);
+  for (int s = 0; s < 766; ++s) {
+    const float colorDiff = (float)s / 255.0f;
+    t10[s] = tanhf(colorDiff * 10.0f);
+    t5[s] = tanhf(colorDiff * 5.0f);
+  }
+  for (int a = 0; a < 256; ++a) {  // CvUtil.cpp:243-250
+    const float alphaR = (float)a / 255.0f;
+    const float alphaL = 1.0f - alphaR;
+    // `using namespace std` + float arguments: the reference resolves exp() to expf here
+    const double expL = (double)expf(5.0f * alphaL * 2.0f);
+    const double expR = (double)expf(5.0f * alphaR);
+    const double sumExp = expL + expR + 0.00001;
+    fs[a] = float(expL / sumExp);
+  }
+  // 8-bit Gaussian of featherAlphaChannel: ksize = erodeSize, sigma = erodeSize / 2.0f, taps round(k*256)
+  gauss_ksize = std_feather;
+  std::vector<int> ik(std::max(gauss_ksize, 1));
+  {
+    const int n = gauss_ksize;
+    std::vector<float> k(n);
+    const double sigma = std_feather / 2.0f;
+    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+      const double x = i - (n - 1) * 0.5;
+      k[i] = (float)std::exp(scale2X * x * x);
+      sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) ik[i] = cv_round((float)(k[i] * sum) * 256.f);
+  }
+  bi.ensure(ti.size() * sizeof(short));
+  bf.ensure(tf.size() * sizeof(float));
+  this->t10.ensure(766 * sizeof(float));
+  this->t5.ensure(766 * sizeof(float));
+  this->fs.ensure(256 * sizeof(float));
+  gik.ensure(ik.size() * sizeof(int));
+  S360_HIP(hipMemcpyAsync(bi.p, ti.data(), ti.size() * sizeof(short), hipMemcpyHostToDevice, st));
+  S360_HIP(hipMemcpyAsync(bf.p, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  S360_HIP(hipMemcpyAsync(this->t10.p, t10.data(), 766 * sizeof(float), hipMemcpyHostToDevice, st));
+  S360_HIP(hipMemcpyAsync(this->t5.p, t5.data(), 766 * sizeof(float), hipMemcpyHostToDevice, st));
+  S360_HIP(hipMemcpyAsync(this->fs.p, fs.data(), 256 * sizeof(float), hipMemcpyHostToDevice, st));
+  S360_HIP(hipMemcpyAsync(gik.p, ik.data(), ik.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  S360_HIP(hipStreamSynchronize(st));
+  dev.bicubic_i = bi.as<short>();
+  dev.bicubic_f = bf.as<float>();
+  dev.tanh10 = this->t10.as<float>();
+  dev.tanh5 = this->t5.as<float>();
+  dev.flat_softmaxL = this->fs.as<float>();
+}
+
+static DevCamera dev_camera(const s360_camera& c) {
+  DevCamera d;
+  d.type = c.type;
+  for (int i = 0; i < 3; ++i) d.pos[i] = c.position[i];
+  for (int i = 0; i < 9; ++i) d.R[i] = c.rotation[i];
+  for (int i = 0; i < 2; ++i) {
+    d.principal[i] = c.principal[i];
+    d.focal[i] = c.focal[i];
+    d.distortion[i] = c.distortion[i];
+  }
+  return d;
+}
+
+void build_spherical_map(s360_ctx* c, float2* map, int dw, int dh, const s360_camera& cam, float l, float r, float t,
+                         float b) {
+  // ImageWarper.cpp:151-162: the angles depend on x or y only; cos/sin resolve to the float overloads.
+  std::vector<float> trig(2 * dw + 2 * dh);
+  float* cosX = trig.data();
+  float* sinX = cosX + dw;
+  float* cosY = sinX + dw;
+  float* sinY = cosY + dh;
+  for (int x = 0; x < dw; ++x) {
+    const float xFrac = (x + 0.5f) / dw;
+    const float xAngle = (1 - xFrac) * l + xFrac * r;
+    cosX[x] = cosf(xAngle);
+    sinX[x] = sinf(xAngle);
+  }
+  for (int y = 0; y < dh; ++y) {
+    const float yFrac = (y + 0.5f) / dh;
+    const float yAngle = (1 - yFrac) * t + yFrac * b;
+    cosY[y] = cosf(yAngle);
+    sinY[y] = sinf(yAngle);
+  }
+  DevBuf d;
+  d.ensure(trig.size() * sizeof(float));
+  S360_HIP(hipMemcpyAsync(d.p, trig.data(), trig.size() * sizeof(float), hipMemcpyHostToDevice, c->st));
+  const float* dp = d.as<float>();
+  launch_spherical_map(c->st, map, dw, dh, dev_camera(cam), dp, dp + dw, dp + 2 * dw, dp + 2 * dw + dh);
+  S360_HIP(hipStreamSynchronize(c->st));  // trig buffer is freed on return
+}
+
+// ------------------------------------------------------------------------------------------
+FrameState& frame_state(s360_ctx* c) {
+  if (!c->frame) {
+    c->frame = std::make_shared<FrameState>();
+    c->frame->P = (int)c->rig.side.size();
+    c->frame->tab.build(c->st, c->P.std_alpha_feather_size);
+  }
+  return *c->frame;
+}
+
+void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, int ch) {
+  FrameState& F = frame_state(c);
+  if (idx < 0 || idx >= F.P) throw Error(S360_ERR_INVALID_ARG, "side_idx out of range");
+  if (ch != 3 && ch != 4) throw Error(S360_ERR_INVALID_ARG, "side image must have 3 or 4 channels");
+  if (F.have_side && (w != F.srcW || h != F.srcH)) throw Error(S360_ERR_INVALID_ARG, "side image size changed");
+  F.srcW = w;
+  F.srcH = h;
+  const size_t n = (size_t)w * h;
+  F.sideSrc.ensure(F.P * n * sizeof(uchar4));
+  F.staging.ensure(n * 4);
+  S360_HIP(hipMemcpyAsync(F.staging.p, img, n * ch, hipMemcpyHostToDevice, c->st));
+  launch_prepare_side_src(c->st, F.staging.as<uint8_t>(), ch, F.sideSrc.as<uchar4>() + n * idx, w, h,
+                          c->P.side_alpha_feather_size);
+  S360_HIP(hipStreamSynchronize(c->st));  // staging is reused by the next upload
+  F.have_side = true;
+}
+void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) {
+  FrameState& F = frame_state(c);
+  F.poleW = w;
+  F.poleH = h;
+  const size_t n = (size_t)w * h;
+  DevBuf& dst = top ? F.topSrc : F.botSrc;
+  dst.ensure(n * sizeof(uchar4));
+  F.staging.ensure(n * 4);
+  S360_HIP(hipMemcpyAsync(F.staging.p, bgr, n * 3, hipMemcpyHostToDevice, c->st));
+  launch_bgr_to_bgra(c->st, F.staging.as<uint8_t>(), 3, dst.as<uchar4>(), n);
+  S360_HIP(hipStreamSynchronize(c->st));
+  (top ? F.have_top : F.have_bottom) = true;
+}
+
+static void ensure_maps(s360_ctx* c, FrameState& F) {
+  if (F.maps_ready) return;
+  const s360_geometry& g = c->g;
+  const size_t mn = (size_t)g.cam_image_width * g.cam_image_height;
+  F.sideMaps.ensure(F.P * mn * sizeof(float2));
+  for (int i = 0; i < F.P; ++i) {
+    float l, r, t, b;
+    side_camera_angles(g, i, F.P, &l, &r, &t, &b);
+    build_spherical_map(c, F.sideMaps.as<float2>() + mn * i, g.cam_image_width, g.cam_image_height, c->rig.side[i], l, r,
+                        t, b);
+  }
+  if (c->P.enable_top && c->top_idx >= 0) {  // TRSP:655-667
+    const s360_camera& cam = c->rig.all[c->top_idx];
+    F.topMap.ensure((size_t)c->P.eqr_width * g.top_rows * sizeof(float2));
+    build_spherical_map(c, F.topMap.as<float2>(), c->P.eqr_width, g.top_rows, cam, (float)(2.0f * M_PI), 0.f,
+                        (float)(M_PI / 2.0f), (float)(M_PI / 2.0f - camera_get_fov(&cam)));
+  }
+  if (c->P.enable_bottom && c->bottom_idx >= 0) {  // TRSP:606-618
+    const s360_camera& cam = c->rig.all[c->bottom_idx];
+    F.botMap.ensure((size_t)c->P.eqr_width * g.bottom_rows * sizeof(float2));
+    build_spherical_map(c, F.botMap.as<float2>(), c->P.eqr_width, g.bottom_rows, cam, 0.f, (float)(2.0f * M_PI),
+                        (float)(-(M_PI / 2.0f)), (float)(-(M_PI / 2.0f - camera_get_fov(&cam))));
+  }
+  F.maps_ready = true;
+}
+
+// Side stage for pairs [p0,p1): projections of the cameras those pairs touch, overlap crops, the two flows
+// per pair, and the fused novel-view/blend into the strip buffers.
+void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
+  FrameState& F = frame_state(c);
+  const s360_geometry& g = c->g;
+  const int P = F.P;
+  if (!F.have_side) throw Error(S360_ERR_STATE, "side images not uploaded");
+  if (p0 < 0 || p1 > P || p1 < p0) throw Error(S360_ERR_INVALID_ARG, "bad pair range");
+  if (c->P.eqr_width % P != 0)
+    throw Error(S360_ERR_INVALID_ARG, "eqr_width must be evenly divisible by the number of cameras");  // TRSP:729-738
+  if (g.num_novel_views != c->P.eqr_width / P)
+    throw Error(S360_ERR_INVALID_ARG, "numNovelViews != eqr_width / numCams for this rig");
+  ensure_maps(c, F);
+  Profiler& prof = c->prof;
+  hipStream_t st = c->st;
+  const int camW = g.cam_image_width, camH = g.cam_image_height, ow = g.overlap_image_width;
+  const int stripW = c->P.eqr_width / P;
+  const size_t pn = (size_t)camW * camH, sn = (size_t)F.srcW * F.srcH, on = (size_t)ow * camH;
+  const int n = p1 - p0;
+  F.proj.ensure(P * pn * sizeof(uchar4));
+  F.strips.ensure((size_t)2 * P * camH * stripW * sizeof(uchar4));
+  if (n == 0) return;
+  {
+    ProfScope ps(prof, "project_side");
+    std::vector<char> need(P, 0);
+    for (int p = p0; p < p1; ++p) need[p] = need[(p + 1) % P] = 1;
+    for (int i = 0; i < P; ++i)
+      if (need[i])
+        launch_remap_cubic_u8c4(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, F.sideMaps.as<float2>() + pn * i,
+                                F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1);
+  }
+  const bool repartition = (F.side_p0 != p0 || F.side_p1 != p1);
+  const bool usePrev = use_prev && F.have_prev_side && !repartition;
+  const int cur = F.cur_side, prv = cur ^ 1;
+  F.overlaps[cur].ensure(2 * n * on * sizeof(uchar4));
+  F.sideFlows[cur].ensure(2 * n * on * sizeof(float2));
+  {
+    ProfScope ps(prof, "crop_overlaps");
+    launch_crop_overlaps(st, F.proj.as<uchar4>(), camW, camH, P, ow, F.overlaps[cur].as<uchar4>(), p0, p1);
+  }
+  {
+    // NovelViewGeneratorAsymmetricFlow::prepare (NovelView.cpp:270-299): flowLtoR = flow(I0=L, I1=R, LEFT),
+    // flowRtoL = flow(I0=R, I1=L, RIGHT). Both hints only matter for pixflow_search_20; the batch is split by
+    // hint in that case.
+    if (!c->flow) c->flow.reset(new FlowEngine(&c->prof));
+    const PixFlowConsts pc = pixflow_consts_by_name(c->P.side_flow_alg);
+    FlowIdx idx;
+    std::memset(&idx, 0, sizeof(idx));
+    if (2 * n > kMaxFlows) throw Error(S360_ERR_INVALID_ARG, "too many pairs for one batch");
+    for (int j = 0; j < n; ++j) {
+      idx.i0[j] = j; idx.i1[j] = n + j;          // LtoR
+      idx.i0[n + j] = n + j; idx.i1[n + j] = j;  // RtoL
+    }
+    const uchar4* prevImgs = usePrev ? F.overlaps[prv].as<uchar4>() : nullptr;
+    const float2* prevFlow = usePrev ? F.sideFlows[prv].as<float2>() : nullptr;
+    if (pc.maxPercentage == 0) {
+      c->flow->compute(st, pc, 2 * n, 2 * n, idx, F.overlaps[cur].as<uchar4>(), ow, camH, prevImgs, prevFlow,
+                       S360_HINT_LEFT, F.sideFlows[cur].as<float2>());
+    } else {
+      FlowIdx a = idx, b;
+      std::memset(&b, 0, sizeof(b));
+      for (int j = 0; j < n; ++j) { b.i0[j] = idx.i0[n + j]; b.i1[j] = idx.i1[n + j]; }
+      c->flow->compute(st, pc, 2 * n, n, a, F.overlaps[cur].as<uchar4>(), ow, camH, prevImgs, prevFlow, S360_HINT_LEFT,
+                       F.sideFlows[cur].as<float2>());
+      c->flow->compute(st, pc, 2 * n, n, b, F.overlaps[cur].as<uchar4>(), ow, camH, prevImgs,
+                       prevFlow ? prevFlow + n * on : nullptr, S360_HINT_RIGHT, F.sideFlows[cur].as<float2>() + n * on);
+    }
+  }
+  {
+    ProfScope ps(prof, "novel_view");
+    NovelViewParams nv;
+    nv.overlapW = ow; nv.camH = camH; nv.stripW = stripW; nv.numNovelViews = g.num_novel_views;
+    nv.numPairs = P; nv.numLocal = n;
+    nv.camImageWidthHalf = float(camW) * 0.5f;
+    nv.disp = g.verge_at_infinity_slab_displacement;
+    launch_novel_view(st, F.overlaps[cur].as<uchar4>(), F.sideFlows[cur].as<float2>(), F.strips.as<uchar4>(), nv, p0,
+                      p1, F.tab.dev);
+  }
+  F.side_p0 = p0;
+  F.side_p1 = p1;
+  F.have_prev_side = true;
+  F.last_side = cur;
+  F.cur_side ^= 1;
+}
+
+// featherAlphaChannel (CvUtil.cpp:140-157) on `rows` rows of a pano, then the x % cols extension (TRSP:399-411).
+void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano, int cols, int rows, uchar4* ext, int extW) {
+  FrameState& F = frame_state(c);
+  hipStream_t st = c->st;
+  const size_t n = (size_t)cols * rows;
+  F.a8a.ensure(n);
+  F.a8b.ensure(n);
+  F.gtmp.ensure(n * sizeof(int));
+  const int e = c->P.std_alpha_feather_size;
+  launch_extract_alpha(st, pano, cols, rows, F.a8a.as<uint8_t>());
+  launch_erode_cross(st, F.a8a.as<uint8_t>(), F.a8b.as<uint8_t>(), cols, rows, e);
+  if (F.tab.gauss_ksize > 1) {
+    const int r = F.tab.gauss_ksize / 2;
+    launch_gauss_u8_rows(st, F.a8b.as<uint8_t>(), F.gtmp.as<int>(), cols, rows, F.tab.gik.as<int>(), r);
+    launch_gauss_u8_cols(st, F.gtmp.as<int>(), F.a8a.as<uint8_t>(), cols, rows, F.tab.gik.as<int>(), r);
+    launch_extend_wrap(st, pano, F.a8a.as<uint8_t>(), cols, rows, ext, extW);
+  } else {
+    launch_extend_wrap(st, pano, F.a8b.as<uint8_t>(), cols, rows, ext, extW);
+  }
+}
+
+void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flow, int cols, int rows, int extW,
+                        uchar4* warped_out, int eqrH) {
+  FrameState& F = frame_state(c);
+  PoleWarpParams pw;
+  pw.cols = cols; pw.rows = rows; pw.extW = extW;
+  pw.maxBlendX = int(float(cols) * (1.2f - 1.0f));  // TRSP:507 (kExtendFrac - 1.0f)
+  pw.poleCameraRadius = c->ramp.poleCameraRadius;
+  pw.phiRampStart = c->ramp.phiRampStart;
+  pw.phiMid = c->ramp.phiMid;
+  pw.phiRampEnd = c->ramp.phiRampEnd;
+  F.warpedExt.ensure((size_t)extW * rows * sizeof(uchar4));
+  launch_pole_warp(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev);
+  launch_pole_finish(c->st, F.warpedExt.as<uchar4>(), warped_out, eqrH, pw);
+}
+
+void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
+  FrameState& F = frame_state(c);
+  const s360_geometry& g = c->g;
+  Profiler& prof = c->prof;
+  hipStream_t st = c->st;
+  const int P = F.P, W = c->P.eqr_width, H = c->P.eqr_height, camH = g.cam_image_height, stripW = W / P;
+  const size_t en = (size_t)W * H;
+  if (!c->P.enable_top) pole_mask &= ~3;
+  if (!c->P.enable_bottom) pole_mask &= ~12;
+  for (int e = 0; e < 2; ++e) F.pano[e].ensure(en * sizeof(uchar4));
+  F.panoTmp.ensure(en * sizeof(uchar4));
+  {
+    ProfScope ps(prof, "assemble_pano");  // TRSP:380-384, 806-807
+    const float sh = g.zero_parallax_novel_view_shift_pixels;
+    launch_assemble_pano(st, F.strips.as<uchar4>(), P, camH, stripW, sh, F.pano[0].as<uchar4>(), W, H);
+    launch_assemble_pano(st, F.strips.as<uchar4>() + (size_t)P * camH * stripW, P, camH, stripW, -sh,
+                         F.pano[1].as<uchar4>(), W, H);
+  }
+  if (F.keep_intermediates)
+    for (int e = 0; e < 2; ++e) {
+      F.panoDbg[e].ensure(en * sizeof(uchar4));
+      S360_HIP(hipMemcpyAsync(F.panoDbg[e].p, F.pano[e].p, en * sizeof(uchar4), hipMemcpyDeviceToDevice, st));
+    }
+  // ---- pole units (TRSP:811-860): 0 top_left, 1 top_right, 2 bottom_left, 3 bottom_right ----
+  if (pole_mask) {
+    ensure_maps(c, F);
+    const int rowsT = g.top_rows, rowsB = g.bottom_rows;
+    const int rows = (pole_mask & 3) ? rowsT : rowsB;
+    if ((pole_mask & 3) && (pole_mask & 12) && rowsT != rowsB)
+      throw Error(S360_ERR_INVALID_ARG, "top and bottom pole projections of different height are not batched yet");
+    const int extW = int(float(W) * 1.2f);  // TRSP:400-401
+    const size_t xn = (size_t)extW * rows;
+    const int cur = F.cur_pole, prv = cur ^ 1;
+    const bool usePrev = use_prev && F.have_prev_pole && F.extW == extW && F.poleRows == rows;
+    F.extImgs[cur].ensure(6 * xn * sizeof(uchar4));
+    F.poleFlows[cur].ensure(4 * xn * sizeof(float2));
+    uchar4* ext = F.extImgs[cur].as<uchar4>();
+    {
+      ProfScope ps(prof, "project_pole");
+      if (pole_mask & 3) {
+        if (!F.have_top) throw Error(S360_ERR_STATE, "top image not uploaded");
+        F.topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
+        const int yfs = rowsT - 1 - c->P.std_alpha_feather_size;
+        launch_remap_cubic_u8c4(st, F.topSrc.as<uchar4>(), F.poleW, F.poleH, F.topMap.as<float2>(),
+                                F.topSph.as<uchar4>(), W, rowsT, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
+        launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xn, extW);
+      }
+      if (pole_mask & 12) {
+        if (!F.have_bottom) throw Error(S360_ERR_STATE, "bottom image not uploaded");
+        F.botSph.ensure((size_t)W * rowsB * sizeof(uchar4));
+        const int yfs = rowsB - 1 - c->P.std_alpha_feather_size;
+        launch_remap_cubic_u8c4(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, F.botMap.as<float2>(),
+                                F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
+        launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xn, extW);
+      }
+    }
+    {
+      ProfScope ps(prof, "pole_prepare");
+      if (pole_mask & 12) {
+        for (int e = 0; e < 2; ++e) {
+          F.panoFlip[e].ensure(en * sizeof(uchar4));
+          launch_flip_both(st, F.pano[e].as<uchar4>(), F.panoFlip[e].as<uchar4>(), W, H);  // TRSP:842-843
+        }
+      }
+      for (int u = 0; u < 4; ++u)
+        if (pole_mask & (1 << u)) {
+          const uchar4* side = (u < 2) ? F.pano[u & 1].as<uchar4>() : F.panoFlip[u & 1].as<uchar4>();
+          dev_feather_alpha_to_ext(c, side, W, rows, ext + u * xn, extW);
+        }
+    }
+    {
+      // computeOpticalFlow(extendedSide, extendedFisheye, ..., DOWN) for every enabled unit (TRSP:438-448)
+      if (!c->flow_pole) c->flow_pole.reset(new FlowEngine(&c->prof));
+      const PixFlowConsts pc = pixflow_consts_by_name(c->P.polar_flow_alg);
+      int u = 0;
+      while (u < 4) {
+        if (!(pole_mask & (1 << u))) { ++u; continue; }
+        int u1 = u;
+        while (u1 < 4 && (pole_mask & (1 << u1))) ++u1;
+        FlowIdx idx;
+        std::memset(&idx, 0, sizeof(idx));
+        for (int k = u; k < u1; ++k) { idx.i0[k - u] = k; idx.i1[k - u] = k < 2 ? 4 : 5; }
+        c->flow_pole->compute(st, pc, 6, u1 - u, idx, ext, extW, rows, usePrev ? F.extImgs[prv].as<uchar4>() : nullptr,
+                              usePrev ? F.poleFlows[prv].as<float2>() + u * xn : nullptr, S360_HINT_DOWN,
+                              F.poleFlows[cur].as<float2>() + u * xn);
+        u = u1;
+      }
+    }
+    {
+      ProfScope ps(prof, "pole_warp");
+      for (int u = 0; u < 4; ++u)
+        if (pole_mask & (1 << u)) {
+          F.poleWarped[u].ensure(en * sizeof(uchar4));
+          dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xn, F.poleFlows[cur].as<float2>() + u * xn, W, rows, extW,
+                             F.poleWarped[u].as<uchar4>(), H);
+        }
+    }
+    F.extW = extW;
+    F.poleRows = rows;
+    F.have_prev_pole = true;
+    F.last_pole = cur;
+    F.cur_pole ^= 1;
+  }
+  {
+    ProfScope ps(prof, "flatten");  // TRSP:864-885
+    for (int e = 0; e < 2; ++e) {
+      if (pole_mask & (1 << e)) {
+        launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 0,
+                       F.tab.dev);
+        std::swap(F.pano[e].p, F.panoTmp.p);
+        std::swap(F.pano[e].cap, F.panoTmp.cap);
+      }
+      if (pole_mask & (4 << e)) {
+        launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[2 + e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 1,
+                       F.tab.dev);
+        std::swap(F.pano[e].p, F.panoTmp.p);
+        std::swap(F.pano[e].cap, F.panoTmp.cap);
+      }
+    }
+  }
+  {
+    ProfScope ps(prof, "finish");  // TRSP:890-961
+    const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
+    F.outBGR.ensure((size_t)outW * outH * 3);
+    const bool resize = (outW != W) || (eyeH != H);
+    for (int e = 0; e < 2; ++e) {
+      uchar4* eye = F.pano[e].as<uchar4>();
+      if (c->P.sharpening > 0.0) {
+        F.sharpLp.ensure(en * sizeof(uchar4));
+        F.sharpBuf.ensure(en * 3 * sizeof(float));
+        launch_sharpen(st, eye, F.sharpLp.as<uchar4>(), F.sharpBuf.as<float>(), W, H, 1.0f + (float)c->P.sharpening);
+      }
+      if (resize) {
+        F.eyeFinal[e].ensure((size_t)outW * eyeH * sizeof(uchar4));
+        launch_resize_cubic_u8c4(st, eye, W, H, en, F.eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);
+        eye = F.eyeFinal[e].as<uchar4>();
+      }
+      launch_pack_bgr(st, eye, outW, eyeH, F.outBGR.as<uint8_t>() + (size_t)e * outW * eyeH * 3);
+    }
+  }
+}
+
+}  // namespace s360

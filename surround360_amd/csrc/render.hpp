@@ -1,0 +1,58 @@
+// render.hpp — device-resident per-frame pipeline state (renderStereoPanorama, TRSP:716-972).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "core.hpp"
+#include "ctx.hpp"
+#include "render_kernels.hpp"
+
+namespace s360 {
+
+struct Tables {
+  DevBuf bi, bf, t10, t5, fs, gik;
+  DevTables dev;
+  int gauss_ksize = 0;
+  void build(hipStream_t st, int std_alpha_feather_size);
+};
+
+// Warp map of bicubicRemapToSpherical for (camera, dst size, angles): built once, cached in HBM.
+void build_spherical_map(s360_ctx* c, float2* map, int dw, int dh, const s360_camera& cam, float l, float r, float t,
+                         float b);
+
+struct FrameState {
+  Tables tab;
+  int P = 0;                       // number of side cameras / pairs
+  int srcW = 0, srcH = 0, poleW = 0, poleH = 0;
+  bool have_side = false, have_top = false, have_bottom = false, maps_ready = false;
+  DevBuf staging, sideSrc, topSrc, botSrc;
+  DevBuf sideMaps, topMap, botMap;
+  DevBuf proj;
+  DevBuf overlaps[2], sideFlows[2];  // [cur/prev] temporal double buffer
+  int side_p0 = 0, side_p1 = 0;       // pairs held by overlaps/sideFlows (local partition)
+  DevBuf strips;                      // [2][P][camH][stripW]
+  DevBuf pano[2], panoFlip[2], panoTmp;
+  DevBuf topSph, botSph;
+  DevBuf a8a, a8b, gtmp;
+  DevBuf extImgs[2], poleFlows[2];    // [cur/prev]; slots: ext 0-3 side units, 4 top fisheye, 5 bottom fisheye
+  DevBuf warpedExt, poleWarped[4];
+  DevBuf eyeFinal[2], sharpLp, sharpBuf, outBGR;
+  int cur_side = 0, cur_pole = 0, last_side = 0, last_pole = 0;
+  bool have_prev_side = false, have_prev_pole = false;
+  bool keep_intermediates = false;  // copy panoramas before the pole composite (parity tests)
+  DevBuf panoDbg[2];
+  int extW = 0, poleRows = 0;
+};
+
+FrameState& frame_state(s360_ctx* c);
+void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, int ch);
+void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h);
+void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev);
+void frame_finish(s360_ctx* c, int pole_mask, int use_prev);
+
+// operator-level helpers on device buffers
+void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano_top_rows, int cols, int rows, uchar4* ext, int extW);
+void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flow, int cols, int rows, int extW,
+                        uchar4* warped_out /*cols x eqrH*/, int eqrH);
+
+}  // namespace s360

@@ -1,0 +1,545 @@
+// render_kernels.hip — reprojection, novel-view warp, strip blend and pole composite kernels for
+// gfx950. All of these are gather/stream kernels bounded by HBM/L2 bandwidth (no dense
+// contraction, no MFMA). 8-bit arithmetic follows OpenCV's fixed-point remap;
+// float arithmetic follows the reference's operation order (compiled with -ffp-contract=off).
+//
+// References: SR/render/ImageWarper.cpp:143-174, SR/optical_flow/NovelView.cpp:101-268,
+// SR/test/TestRenderStereoPanorama.cpp:99-135, 259-292, 380-384, 388-561, 701-713,
+// SR/util/CvUtil.cpp:93-115, 140-157, 224-260, SR/util/Filter.h:40-127.
+#include "render_kernels.hpp"
+
+#include "devmath.hpp"
+
+namespace s360 {
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bgr_to_bgra(const uint8_t* __restrict__ src, int cn, uchar4* __restrict__ dst,
+                                                     size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = src + i * cn;
+  dst[i] = make_uchar4(p[0], p[1], p[2], cn == 4 ? p[3] : 255);
+}
+__global__ __launch_bounds__(256) void k_prepare_side_src(const uint8_t* __restrict__ src, int cn,
+                                                          uchar4* __restrict__ dst, int w, int h, int feather) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const uint8_t* p = src + ((size_t)y * w + x) * cn;
+  int a = cn == 4 ? p[3] : 255;
+  // rows [0,feather) and [h-feather,h): alpha = uint8(255.0f * float(yy + 0.5f) / float(feather)), yy being
+  // the loop iteration of TRSP:117-124 that touches this row.
+  int yy = -1;
+  if (y < feather) yy = y;
+  if (h - 1 - y < feather) yy = max(yy, h - 1 - y);  // the later loop iteration wins
+  if (yy >= 0) a = (int)(unsigned char)(255.0f * (float)(yy + 0.5f) / (float)feather);
+  dst[(size_t)y * w + x] = make_uchar4(p[0], p[1], p[2], (unsigned char)a);
+}
+
+// ------------------------------------------------------------------------------------------
+// Warp map of bicubicRemapToSpherical: unit vector products in float (cosf/sinf tables from the host's
+// libm, separable in x and y), Camera::pixel in double, stored as float (pixel - 0.5).
+__global__ __launch_bounds__(256) void k_spherical_map(float2* __restrict__ map, int dw, int dh, DevCamera cam,
+                                                       const float* __restrict__ cosX, const float* __restrict__ sinX,
+                                                       const float* __restrict__ cosY,
+                                                       const float* __restrict__ sinY) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  const float ux = cosY[y] * cosX[x];
+  const float uy = cosY[y] * sinX[x];
+  const float uz = sinY[y];
+  const int kNear = 1000000;  // int(Camera::kNearInfinity)
+  const double dx = (double)ux * kNear - cam.pos[0], dy = (double)uy * kNear - cam.pos[1],
+               dz = (double)uz * kNear - cam.pos[2];
+  const double cx = cam.R[0] * dx + cam.R[1] * dy + cam.R[2] * dz;
+  const double cy = cam.R[3] * dx + cam.R[4] * dy + cam.R[5] * dz;
+  const double cz = cam.R[6] * dx + cam.R[7] * dy + cam.R[8] * dz;
+  double sx, sy;
+  if (cam.type == 0) {  // FTHETA
+    const double norm = sqrt(cx * cx + cy * cy);
+    const double r = atan2(norm, -cz);
+    const double r2 = r * r;
+    const double f = ((1 + r2 * (cam.distortion[0] + r2 * cam.distortion[1])) * r) / norm;
+    sx = f * cx;
+    sy = f * cy;
+  } else {  // RECTILINEAR
+    const double px = cx / -cz, py = cy / -cz;
+    const double r2 = px * px + py * py;
+    const double f = 1 + r2 * (cam.distortion[0] + r2 * cam.distortion[1]);
+    sx = f * px;
+    sy = f * py;
+  }
+  const double pxx = cam.focal[0] * sx + cam.principal[0];
+  const double pyy = cam.focal[1] * sy + cam.principal[1];
+  map[(size_t)y * dw + x] = make_float2((float)(pxx - 0.5), (float)(pyy - 0.5));
+}
+
+// ------------------------------------------------------------------------------------------
+// cv::remap INTER_CUBIC, BORDER_CONSTANT(0), 8UC4: integer weights (sum 32768), (sum + 2^14) >> 15.
+__device__ __forceinline__ uchar4 remap_cubic_u8c4_at(const uchar4* __restrict__ src, int sw, int sh, float mx,
+                                                      float my, const short* __restrict__ tab) {
+  int sx, sy, fxy;
+  remap_coord(mx, my, &sx, &sy, &fxy);
+  if (sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0) return make_uchar4(0, 0, 0, 0);
+  const short* w = tab + fxy * 16;
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int yi = sy + r;
+    if (yi < 0 || yi >= sh) continue;
+    const uchar4* S = src + (size_t)yi * sw;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int xi = sx + q;
+      if (xi < 0 || xi >= sw) continue;
+      const uchar4 p = S[xi];
+      const int ww = w[r * 4 + q];
+      s0 += p.x * ww; s1 += p.y * ww; s2 += p.z * ww; s3 += p.w * ww;
+    }
+  }
+  return make_uchar4((unsigned char)sat_u8((s0 + (1 << 14)) >> 15), (unsigned char)sat_u8((s1 + (1 << 14)) >> 15),
+                     (unsigned char)sat_u8((s2 + (1 << 14)) >> 15), (unsigned char)sat_u8((s3 + (1 << 14)) >> 15));
+}
+// cv::remap INTER_CUBIC, BORDER_CONSTANT(0), 32FC2 (NovelView.cpp:191): float weights; interior sums row by
+// row (4-term left-associated, then sum += row), border taps are added one by one.
+__device__ __forceinline__ float2 remap_cubic_f32c2_at(const float2* __restrict__ src, int sw, int sh, float mx,
+                                                       float my, const float* __restrict__ tab) {
+  int sx, sy, fxy;
+  remap_coord(mx, my, &sx, &sy, &fxy);
+  const float* w = tab + fxy * 16;
+  const unsigned width1 = sw - 3 > 0 ? sw - 3 : 0, height1 = sh - 3 > 0 ? sh - 3 : 0;
+  float2 o;
+  if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+    const float2* S = src + (size_t)sy * sw + sx;
+    float2 a = S[0], b = S[1], c = S[2], d = S[3];
+    o.x = a.x * w[0] + b.x * w[1] + c.x * w[2] + d.x * w[3];
+    o.y = a.y * w[0] + b.y * w[1] + c.y * w[2] + d.y * w[3];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      S += sw;
+      a = S[0]; b = S[1]; c = S[2]; d = S[3];
+      o.x += a.x * w[r * 4] + b.x * w[r * 4 + 1] + c.x * w[r * 4 + 2] + d.x * w[r * 4 + 3];
+      o.y += a.y * w[r * 4] + b.y * w[r * 4 + 1] + c.y * w[r * 4 + 2] + d.y * w[r * 4 + 3];
+    }
+  } else if (sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0) {
+    o = make_float2(0.f, 0.f);
+  } else {
+    o = make_float2(0.f, 0.f);
+    for (int r = 0; r < 4; ++r) {
+      const int yi = sy + r;
+      if (yi < 0 || yi >= sh) continue;
+      for (int q = 0; q < 4; ++q) {
+        const int xi = sx + q;
+        if (xi < 0 || xi >= sw) continue;
+        const float2 p = src[(size_t)yi * sw + xi];
+        o.x += p.x * w[r * 4 + q];
+        o.y += p.y * w[r * 4 + q];
+      }
+    }
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(256) void k_remap_cubic_u8c4(const uchar4* __restrict__ src, int sw, int sh,
+                                                          const float2* __restrict__ map, uchar4* __restrict__ dst,
+                                                          int dw, int dh, const short* __restrict__ tab,
+                                                          int alpha_mode, int yFeatherStart, int featherSize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  const float2 m = map[(size_t)y * dw + x];
+  uchar4 o = remap_cubic_u8c4_at(src, sw, sh, m.x, m.y, tab);
+  if (alpha_mode == 1) {
+    // remap ran on 3 channels, cvtColor BGR2BGRA sets 255, the feather loop overwrites the last rows
+    int a = 255;
+    if (y >= yFeatherStart) {
+      const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
+      a = (int)(unsigned char)(255.0f * alpha);
+    }
+    o.w = (unsigned char)a;
+  }
+  dst[(size_t)y * dw + x] = o;
+}
+
+__global__ __launch_bounds__(256) void k_crop_overlaps(const uchar4* __restrict__ proj, int camW, int camH, int P,
+                                                       int overlapW, uchar4* __restrict__ out, int p0, int n) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, j = blockIdx.z;
+  if (x >= overlapW) return;
+  const int cam = j < n ? p0 + j : (p0 + (j - n) + 1) % P;
+  const int x0 = j < n ? camW - overlapW : 0;
+  out[((size_t)j * camH + y) * overlapW + x] = proj[((size_t)cam * camH + y) * camW + x0 + x];
+}
+
+// ------------------------------------------------------------------------------------------
+// One lazily rendered novel-view sample (renderLazyNovelView, NovelView.cpp:174-224).
+struct LazySample { uchar4 c; float mag; };
+__device__ __forceinline__ LazySample lazy_sample(const uchar4* __restrict__ img, const float2* __restrict__ flow,
+                                                  int ow, int oh, float xs, float ys, float t,
+                                                  const DevTables& T) {
+  const float2 f = remap_cubic_f32c2_at(flow, ow, oh, xs, ys, T.bicubic_f);
+  const float wx = xs + f.x * t, wy = ys + f.y * t;
+  LazySample s;
+  s.c = remap_cubic_u8c4_at(img, ow, oh, wx, wy, T.bicubic_i);
+  s.c.w = (unsigned char)(int)((1.0f - t) * (float)s.c.w);
+  s.mag = sqrtf(f.x * f.x + f.y * f.y);
+  return s;
+}
+// combineLazyViews (NovelView.cpp:101-154)
+__device__ __forceinline__ uchar4 combine_lazy(uchar4 cL, uchar4 cR, float flowMagL, float flowMagR, float fcols,
+                                               const DevTables& T) {
+  const unsigned char mx = cL.w > cR.w ? cL.w : cR.w;
+  const unsigned char outAlpha = ((double)((float)mx / 255.0f) > 0.1) ? 255 : 0;
+  if (cL.w == 0 && cR.w == 0) return make_uchar4(0, 0, 0, outAlpha);
+  if (cL.w == 0) return make_uchar4(cR.x, cR.y, cR.z, outAlpha);
+  if (cR.w == 0) return make_uchar4(cL.x, cL.y, cL.z, outAlpha);
+  const float magL = flowMagL / fcols, magR = flowMagR / fcols;
+  float blendL = (float)cL.w, blendR = (float)cR.w;
+  const float norm = blendL + blendR;
+  blendL /= norm;
+  blendR /= norm;
+  const int sdiff = abs((int)cL.x - (int)cR.x) + abs((int)cL.y - (int)cR.y) + abs((int)cL.z - (int)cR.z);
+  const float deghostCoef = T.tanh10[sdiff];
+  const double expL = exp((double)(10.0f * blendL) * (1.0 + (double)(20.0f * magL)));
+  const double expR = exp((double)(10.0f * blendR) * (1.0 + (double)(20.0f * magR)));
+  const double sumExp = expL + expR + 0.00001;
+  const float softmaxL = (float)(expL / sumExp);
+  const float softmaxR = (float)(expR / sumExp);
+  const float wL = lerpf(blendL, softmaxL, deghostCoef), wR = lerpf(blendR, softmaxR, deghostCoef);
+  return make_uchar4((unsigned char)trunc_u8((float)cL.x * wL + (float)cR.x * wR),
+                     (unsigned char)trunc_u8((float)cL.y * wL + (float)cR.y * wR),
+                     (unsigned char)trunc_u8((float)cL.z * wL + (float)cR.z * wR), 255);
+}
+// grid: (ceil(stripW/64), camH, 2*(p1-p0)); z = 2*pairLocal + eye
+__global__ __launch_bounds__(64) void k_novel_view(const uchar4* __restrict__ overlaps,
+                                                   const float2* __restrict__ flows, uchar4* __restrict__ strips,
+                                                   NovelViewParams nv, int p0, DevTables T) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= nv.stripW) return;
+  const int j = (int)(blockIdx.z >> 1), pair = p0 + j, eye = blockIdx.z & 1;
+  const size_t isz = (size_t)nv.overlapW * nv.camH;
+  const uchar4* imgL = overlaps + isz * j;
+  const uchar4* imgR = overlaps + isz * (nv.numLocal + j);
+  const float2* flowLtoR = flows + isz * j;
+  const float2* flowRtoL = flows + isz * (nv.numLocal + j);
+  uchar4 out = make_uchar4(0, 0, 0, 0);
+  if (u < nv.numNovelViews) {
+    // LazyNovelViewBuffer column u (TRSP:273-285)
+    const float shift = (float)u / (float)nv.numNovelViews;
+    const float slabShift = nv.camImageWidthHalf - (float)(nv.numNovelViews - u);
+    const float xs = eye == 0 ? slabShift + nv.disp : slabShift - nv.disp;
+    const float ys = (float)v;
+    // from-left: (imageL, flowRtoL, t); from-right: (imageR, flowLtoR, 1 - t)   (NovelView.cpp:230-255)
+    const LazySample a = lazy_sample(imgL, flowRtoL, nv.overlapW, nv.camH, xs, ys, shift, T);
+    const LazySample b = lazy_sample(imgR, flowLtoR, nv.overlapW, nv.camH, xs, ys, 1.0f - shift, T);
+    out = combine_lazy(a.c, b.c, a.mag, b.mag, (float)nv.stripW, T);
+  } else {
+    // unfilled LazyNovelViewBuffer columns are (0,0,0) warps; never reached when eqr_width % numCams == 0
+    const LazySample a = lazy_sample(imgL, flowRtoL, nv.overlapW, nv.camH, 0.f, 0.f, 0.f, T);
+    const LazySample b = lazy_sample(imgR, flowLtoR, nv.overlapW, nv.camH, 0.f, 0.f, 1.0f, T);
+    out = combine_lazy(a.c, b.c, a.mag, b.mag, (float)nv.stripW, T);
+  }
+  strips[(((size_t)eye * nv.numPairs + pair) * nv.camH + v) * nv.stripW + u] = out;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble_pano(const uchar4* __restrict__ strips, int P, int camH, int stripW,
+                                                       float offset, uchar4* __restrict__ pano, int W, int H,
+                                                       int padAbove) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  uchar4 o = make_uchar4(0, 0, 0, 0);
+  const int ys = y - padAbove;
+  if (ys >= 0 && ys < camH) {
+    // offsetHorizontalWrap (CvUtil.cpp:93-115): nearest remap with BORDER_WRAP
+    float srcX = (float)x - offset;
+    if (srcX < 0) srcX += (float)W;
+    if (srcX >= (float)W) srcX -= (float)W;
+    int sx = sat_s16(cv_round(srcX));
+    if (sx < 0) sx -= ((sx - W + 1) / W) * W;
+    if (sx >= W) sx %= W;
+    const int pair = sx / stripW, u = sx - pair * stripW;
+    o = strips[((size_t)pair * camH + ys) * stripW + u];
+  }
+  pano[(size_t)y * W + x] = o;
+}
+__global__ __launch_bounds__(256) void k_flip_both(const uchar4* __restrict__ src, uchar4* __restrict__ dst, int w,
+                                                   int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  dst[(size_t)(h - 1 - y) * w + (w - 1 - x)] = src[(size_t)y * w + x];
+}
+
+// ---- featherAlphaChannel ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extract_alpha(const uchar4* __restrict__ img, int w, int rows,
+                                                       uint8_t* __restrict__ a) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  a[(size_t)y * w + x] = img[(size_t)y * w + x].w;
+}
+// erode with MORPH_CROSS (2e+1)^2, outside treated as +inf. Horizontal arm through LDS, vertical arm direct.
+__global__ __launch_bounds__(256) void k_erode_cross(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, int w,
+                                                     int h, int e) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint8_t* row = reinterpret_cast<uint8_t*>(smem_raw);  // [blockDim.x + 2e]
+  const int x0 = blockIdx.x * blockDim.x, y = blockIdx.y;
+  for (int i = threadIdx.x; i < (int)blockDim.x + 2 * e; i += blockDim.x) {
+    const int gx = x0 - e + i;
+    row[i] = (gx >= 0 && gx < w) ? a[(size_t)y * w + gx] : 255;
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x >= w) return;
+  int m = 255;
+  for (int i = 0; i <= 2 * e; ++i) m = min(m, (int)row[threadIdx.x + i]);
+  const int ylo = max(0, y - e), yhi = min(h - 1, y + e);
+  for (int yy = ylo; yy <= yhi; ++yy) m = min(m, (int)a[(size_t)yy * w + x]);
+  out[(size_t)y * w + x] = (uint8_t)m;
+}
+__global__ __launch_bounds__(256) void k_gauss_u8_rows(const uint8_t* __restrict__ a, int* __restrict__ tmp, int w,
+                                                       int h, const int* __restrict__ ik, int r) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const uint8_t* S = a + (size_t)y * w;
+  int s = ik[r] * S[x];
+  for (int j = 1; j <= r; ++j) s += ik[r + j] * ((int)S[reflect101(x + j, w)] + (int)S[reflect101(x - j, w)]);
+  tmp[(size_t)y * w + x] = s;
+}
+__global__ __launch_bounds__(256) void k_gauss_u8_cols(const int* __restrict__ tmp, uint8_t* __restrict__ out, int w,
+                                                       int h, const int* __restrict__ ik, int r) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  int s = ik[r] * tmp[(size_t)y * w + x];
+  for (int j = 1; j <= r; ++j)
+    s += ik[r + j] * (tmp[(size_t)reflect101(y + j, h) * w + x] + tmp[(size_t)reflect101(y - j, h) * w + x]);
+  out[(size_t)y * w + x] = (uint8_t)sat_u8((s + (1 << 15)) >> 16);
+}
+__global__ __launch_bounds__(256) void k_extend_wrap(const uchar4* __restrict__ img, const uint8_t* __restrict__ alpha,
+                                                     int cols, int rows, uchar4* __restrict__ ext, int extW) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= extW) return;
+  const int sx = x % cols;
+  uchar4 p = img[(size_t)y * cols + sx];
+  if (alpha) p.w = alpha[(size_t)y * cols + sx];
+  ext[(size_t)y * extW + x] = p;
+}
+
+// ---- pole warp / finish ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pole_warp(const uchar4* __restrict__ extFisheye,
+                                                   const float2* __restrict__ flow, uchar4* __restrict__ warpedExt,
+                                                   PoleWarpParams pw, const short* __restrict__ tab) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= pw.extW) return;
+  const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
+  const float alpha = 1.0f - rampf(phi, pw.phiRampStart, pw.phiMid);
+  const float2 f = flow[(size_t)y * pw.extW + x];
+  const float wx = (float)x + (1.0f - alpha) * f.x;
+  const float wy = (float)y + (1.0f - alpha) * f.y;
+  warpedExt[(size_t)y * pw.extW + x] = remap_cubic_u8c4_at(extFisheye, pw.extW, pw.rows, wx, wy, tab);
+}
+__global__ __launch_bounds__(256) void k_pole_finish(const uchar4* __restrict__ warpedExt, uchar4* __restrict__ out,
+                                                     int eqrH, PoleWarpParams pw) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= pw.cols) return;
+  uchar4 o = make_uchar4(0, 0, 0, 0);
+  if (y < pw.rows) {
+    o = warpedExt[(size_t)y * pw.extW + x];
+    if (x < pw.maxBlendX) {
+      const int xw = min(x + pw.cols, pw.extW - 1);
+      const uchar4 wr = warpedExt[(size_t)y * pw.extW + xw];
+      const float alpha = 1.0f - rampf((float)x, (float)pw.maxBlendX * 0.333f, (float)pw.maxBlendX * 0.667f);
+      const float srcB = o.x, srcG = o.y, srcR = o.z, srcA = o.w;
+      o.x = (unsigned char)trunc_u8((float)wr.x * alpha + srcB * (1.0f - alpha));
+      o.y = (unsigned char)trunc_u8((float)wr.y * alpha + srcG * (1.0f - alpha));
+      o.z = (unsigned char)trunc_u8((float)wr.z * alpha + srcR * (1.0f - alpha));
+      o.w = (unsigned char)trunc_u8(srcA);
+    }
+    const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
+    const float a2 = 1.0f - rampf(phi, pw.phiMid, pw.phiRampEnd);
+    o.w = (unsigned char)trunc_u8((float)o.w * a2);
+  }
+  out[(size_t)y * pw.cols + x] = o;
+}
+
+// flattenLayersDeghostPreferBase (CvUtil.cpp:224-260)
+__global__ __launch_bounds__(256) void k_flatten(const uchar4* __restrict__ base, const uchar4* __restrict__ top,
+                                                 uchar4* __restrict__ out, int w, int h, int flip_top, DevTables T) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const uchar4 b = base[(size_t)y * w + x];
+  const uchar4 t = flip_top ? top[(size_t)(h - 1 - y) * w + (w - 1 - x)] : top[(size_t)y * w + x];
+  const int sdiff = abs((int)b.x - (int)t.x) + abs((int)b.y - (int)t.y) + abs((int)b.z - (int)t.z);
+  const float deghostCoef = T.tanh5[sdiff];
+  const float alphaR = (float)t.w / 255.0f;
+  const float alphaL = 1.0f - alphaR;
+  const float softmaxL = T.flat_softmaxL[t.w];
+  const float softmaxR = 1.0f - softmaxL;
+  const float wL = lerpf(alphaL, softmaxL, deghostCoef), wR = lerpf(alphaR, softmaxR, deghostCoef);
+  uchar4 o;
+  o.x = (unsigned char)trunc_u8((float)b.x * wL + (float)t.x * wR);
+  o.y = (unsigned char)trunc_u8((float)b.y * wL + (float)t.y * wR);
+  o.z = (unsigned char)trunc_u8((float)b.z * wL + (float)t.z * wR);
+  o.w = t.w > b.w ? t.w : b.w;
+  out[(size_t)y * w + x] = o;
+}
+
+__global__ __launch_bounds__(256) void k_pack_bgr(const uchar4* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uchar4 p = src[i];
+  dst[i * 3] = p.x;
+  dst[i * 3 + 1] = p.y;
+  dst[i * 3 + 2] = p.z;
+}
+
+// ---- sharpen (Filter.h:40-127): 2-tap IIR low pass, wrap horizontally / reflect vertically ----
+__device__ __forceinline__ int wrap_i(int x, int r) { return x < 0 ? r + x : x >= r ? x - r : x; }
+__device__ __forceinline__ int refl_i(int x, int r) { return x < 0 ? -x : x >= r ? 2 * r - x - 2 : x; }
+__device__ __forceinline__ float clamp255(float v) { return v < 0.0f ? 0.0f : v > 255.0f ? 255.0f : v; }
+__global__ __launch_bounds__(64) void k_iir_rows(const uchar4* __restrict__ img, uchar4* __restrict__ lp,
+                                                 float* __restrict__ buf, int w, int h, float alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h) return;
+  const uchar4* R = img + (size_t)i * w;
+  float* B = buf + (size_t)i * w * 3;
+  uchar4 p = R[0];
+  float v0 = p.x, v1 = p.y, v2 = p.z;
+  for (int j = 1; j <= w; ++j) {
+    p = R[wrap_i(j, w)];
+    v0 = (float)p.x * (1.0f - alpha) + v0 * alpha;
+    v1 = (float)p.y * (1.0f - alpha) + v1 * alpha;
+    v2 = (float)p.z * (1.0f - alpha) + v2 * alpha;
+    float* b = B + (size_t)wrap_i(j - 1, w) * 3;
+    b[0] = v0; b[1] = v1; b[2] = v2;
+  }
+  for (int j = w - 2; j >= -1; --j) {
+    const float* b = B + (size_t)wrap_i(j, w) * 3;
+    v0 = b[0] * (1.0f - alpha) + v0 * alpha;
+    v1 = b[1] * (1.0f - alpha) + v1 * alpha;
+    v2 = b[2] * (1.0f - alpha) + v2 * alpha;
+    lp[(size_t)i * w + j + 1] = make_uchar4((unsigned char)clamp255(v0), (unsigned char)clamp255(v1),
+                                            (unsigned char)clamp255(v2), 255);
+  }
+}
+__global__ __launch_bounds__(64) void k_iir_cols(uchar4* __restrict__ lp, float* __restrict__ buf, int w, int h,
+                                                 float alpha) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= w) return;
+  uchar4 p = lp[j];
+  float v0 = p.x, v1 = p.y, v2 = p.z;
+  for (int i = 1; i <= h; ++i) {
+    p = lp[(size_t)refl_i(i, h) * w + j];
+    v0 = (float)p.x * (1.0f - alpha) + v0 * alpha;
+    v1 = (float)p.y * (1.0f - alpha) + v1 * alpha;
+    v2 = (float)p.z * (1.0f - alpha) + v2 * alpha;
+    float* b = buf + ((size_t)refl_i(i - 1, h) * w + j) * 3;
+    b[0] = v0; b[1] = v1; b[2] = v2;
+  }
+  for (int i = h - 2; i >= -1; --i) {
+    const float* b = buf + ((size_t)refl_i(i, h) * w + j) * 3;
+    v0 = b[0] * (1.0f - alpha) + v0 * alpha;
+    v1 = b[1] * (1.0f - alpha) + v1 * alpha;
+    v2 = b[2] * (1.0f - alpha) + v2 * alpha;
+    lp[(size_t)(i + 1) * w + j] = make_uchar4((unsigned char)clamp255(v0), (unsigned char)clamp255(v1),
+                                              (unsigned char)clamp255(v2), 255);
+  }
+}
+__global__ __launch_bounds__(256) void k_unsharp(uchar4* __restrict__ img, const uchar4* __restrict__ lp, size_t n,
+                                                 float amount) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uchar4 p = img[i];
+  const uchar4 l = lp[i];
+  auto f = [&](unsigned char pc, unsigned char lc) -> unsigned char {
+    const float lf = (float)lc;
+    const float hp = (float)pc - lf;
+    // noise coring: 1 - expf(-(hp^2 * 100)). hp is an integer: the factor is exactly 0 for hp == 0 and
+    // exactly 1.0f otherwise (expf(-100) < 2^-24), so no transcendental is needed on the device.
+    const float ng = hp == 0.0f ? 0.0f : 1.0f;
+    return (unsigned char)clamp255(lf + hp * ng * amount);
+  };
+  p.x = f(p.x, l.x); p.y = f(p.y, l.y); p.z = f(p.z, l.z);
+  img[i] = p;
+}
+
+// ==========================================================================================
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_bgr_to_bgra(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, size_t n) {
+  hipLaunchKernelGGL(k_bgr_to_bgra, dim3(cdiv(n, 256)), dim3(256), 0, st, src, channels, dst, n);
+}
+void launch_prepare_side_src(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, int w, int h, int feather) {
+  hipLaunchKernelGGL(k_prepare_side_src, dim3(cdiv(w, 256), h), dim3(256), 0, st, src, channels, dst, w, h, feather);
+}
+void launch_spherical_map(hipStream_t st, float2* map, int dw, int dh, const DevCamera& cam, const float* cosX,
+                          const float* sinX, const float* cosY, const float* sinY) {
+  dim3 blk(64, 4);
+  hipLaunchKernelGGL(k_spherical_map, dim3(cdiv(dw, 64), cdiv(dh, 4)), blk, 0, st, map, dw, dh, cam, cosX, sinX, cosY,
+                     sinY);
+}
+void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, uchar4* dst, int dw,
+                             int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize) {
+  dim3 blk(64, 4);
+  hipLaunchKernelGGL(k_remap_cubic_u8c4, dim3(cdiv(dw, 64), cdiv(dh, 4)), blk, 0, st, src, sw, sh, map, dst, dw, dh,
+                     T.bicubic_i, alpha_mode, yFeatherStart, featherSize);
+}
+void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH, int P, int overlapW, uchar4* out,
+                          int p0, int p1) {
+  const int n = p1 - p0;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_crop_overlaps, dim3(cdiv(overlapW, 256), camH, 2 * n), dim3(256), 0, st, proj, camW, camH, P,
+                     overlapW, out, p0, n);
+}
+void launch_novel_view(hipStream_t st, const uchar4* overlaps, const float2* flows, uchar4* strips,
+                       const NovelViewParams& nv, int p0, int p1, const DevTables& T) {
+  if (p1 <= p0) return;
+  hipLaunchKernelGGL(k_novel_view, dim3(cdiv(nv.stripW, 64), nv.camH, 2 * (p1 - p0)), dim3(64), 0, st, overlaps, flows,
+                     strips, nv, p0, T);
+}
+void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int camH, int stripW, float offset,
+                          uchar4* pano, int eqrW, int eqrH) {
+  const int padAbove = (eqrH - camH) / 2;
+  hipLaunchKernelGGL(k_assemble_pano, dim3(cdiv(eqrW, 256), eqrH), dim3(256), 0, st, strips_eye, P, camH, stripW, offset,
+                     pano, eqrW, eqrH, padAbove);
+}
+void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h) {
+  hipLaunchKernelGGL(k_flip_both, dim3(cdiv(w, 256), h), dim3(256), 0, st, src, dst, w, h);
+}
+void launch_extract_alpha(hipStream_t st, const uchar4* img, int w, int rows, uint8_t* a) {
+  hipLaunchKernelGGL(k_extract_alpha, dim3(cdiv(w, 256), rows), dim3(256), 0, st, img, w, rows, a);
+}
+void launch_erode_cross(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, int e) {
+  hipLaunchKernelGGL(k_erode_cross, dim3(cdiv(w, 256), h), dim3(256), 256 + 2 * e, st, a, out, w, h, e);
+}
+void launch_gauss_u8_rows(hipStream_t st, const uint8_t* a, int* tmp, int w, int h, const int* ik, int r) {
+  hipLaunchKernelGGL(k_gauss_u8_rows, dim3(cdiv(w, 256), h), dim3(256), 0, st, a, tmp, w, h, ik, r);
+}
+void launch_gauss_u8_cols(hipStream_t st, const int* tmp, uint8_t* out, int w, int h, const int* ik, int r) {
+  hipLaunchKernelGGL(k_gauss_u8_cols, dim3(cdiv(w, 256), h), dim3(256), 0, st, tmp, out, w, h, ik, r);
+}
+void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha, int cols, int rows, uchar4* ext,
+                        int extW) {
+  hipLaunchKernelGGL(k_extend_wrap, dim3(cdiv(extW, 256), rows), dim3(256), 0, st, img, alpha, cols, rows, ext, extW);
+}
+void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
+                      const PoleWarpParams& pw, const DevTables& T) {
+  hipLaunchKernelGGL(k_pole_warp, dim3(cdiv(pw.extW, 256), pw.rows), dim3(256), 0, st, extFisheye, flow, warpedExt, pw,
+                     T.bicubic_i);
+}
+void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
+  hipLaunchKernelGGL(k_pole_finish, dim3(cdiv(pw.cols, 256), eqrH), dim3(256), 0, st, warpedExt, out, eqrH, pw);
+}
+void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar4* out, int w, int h, int flip_top,
+                    const DevTables& T) {
+  hipLaunchKernelGGL(k_flatten, dim3(cdiv(w, 256), h), dim3(256), 0, st, base, top, out, w, h, flip_top, T);
+}
+void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst) {
+  const size_t n = (size_t)w * h;
+  hipLaunchKernelGGL(k_pack_bgr, dim3(cdiv(n, 256)), dim3(256), 0, st, src, n, dst);
+}
+void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount) {
+  const float alpha = powf(0.25f, 1.0f / 4.0f);  // host libm, Filter.h:49
+  hipLaunchKernelGGL(k_iir_rows, dim3(cdiv(h, 64)), dim3(64), 0, st, img, lp, scratch, w, h, alpha);
+  hipLaunchKernelGGL(k_iir_cols, dim3(cdiv(w, 64)), dim3(64), 0, st, lp, scratch, w, h, alpha);
+  const size_t n = (size_t)w * h;
+  hipLaunchKernelGGL(k_unsharp, dim3(cdiv(n, 256)), dim3(256), 0, st, img, lp, n, amount);
+}
+
+}  // namespace s360

@@ -1,0 +1,76 @@
+// render_kernels.hpp — launchers of the warp / blend / composite HIP kernels (render_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace s360 {
+
+struct DevCamera {  // Camera (SR/render/Camera.h:87-99) as kernel argument
+  int type;
+  double pos[3], R[9], principal[2], focal[2], distortion[2];
+};
+// Lookup tables shared by the warp/blend kernels; built on the host (tables.cpp), resident in HBM.
+struct DevTables {
+  const short* bicubic_i;   // [1024][16] remap weights, sum == 32768
+  const float* bicubic_f;   // [1024][16]
+  const float* tanh10;      // [766] tanhf(10 * (s/255)), s = sum |dBGR|   (NovelView.cpp:131-138)
+  const float* tanh5;       // [766] tanhf(5 * (s/255))                    (CvUtil.cpp:236-242)
+  const float* flat_softmaxL;  // [256] softmaxL of flattenLayersDeghostPreferBase by top alpha (CvUtil.cpp:243-250)
+};
+struct NovelViewParams {  // TRSP:259-292 + NovelView.cpp:174-268
+  int overlapW, camH, stripW, numNovelViews;
+  int numPairs;   // P: strip layout [eye][P][camH][stripW]
+  int numLocal;   // pairs held by the local overlap/flow arrays: L at j, R at numLocal + j
+  float camImageWidthHalf;  // float(camImageWidth) * 0.5f
+  float disp;               // vergeAtInfinitySlabDisplacement
+};
+struct PoleWarpParams {  // TRSP:483-536
+  int cols, rows, extW, maxBlendX;
+  float poleCameraRadius, phiRampStart, phiMid, phiRampEnd;
+};
+
+// generic
+void launch_bgr_to_bgra(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, size_t n);
+// projectSideToSpherical's source preparation: BGR(A) -> BGRA with the top/bottom alpha ramp (TRSP:108-125)
+void launch_prepare_side_src(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, int w, int h, int feather);
+// bicubicRemapToSpherical's warp map (ImageWarper.cpp:151-167); trig tables per column / row are host-built.
+void launch_spherical_map(hipStream_t st, float2* map, int dw, int dh, const DevCamera& cam, const float* cosX,
+                          const float* sinX, const float* cosY, const float* sinY);
+// remap INTER_CUBIC / BORDER_CONSTANT(0) of a BGRA image through a float2 map. alpha_mode 0: keep interpolated
+// alpha; 1: pole rule (alpha = 255 above yFeatherStart, 255*ramp below; TRSP:669-678, 629-637).
+void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, uchar4* dst, int dw,
+                             int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize);
+// overlap crops (TRSP:196-198) for pairs [p0,p1): out[j] = right part of proj p0+j, out[n+j] = left part of
+// proj (p0+j+1)%P, n = p1-p0
+void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH, int P, int overlapW, uchar4* out,
+                          int p0, int p1);
+// fused renderLazyNovelView x4 + combineLazyViews x2 for pairs [p0,p1): strips[eye][pair][camH][stripW]
+void launch_novel_view(hipStream_t st, const uchar4* overlaps, const float2* flows /*[2n]: LtoR[n], RtoL[n]*/,
+                       uchar4* strips, const NovelViewParams& nv, int p0, int p1, const DevTables& T);
+// stackHorizontal + offsetHorizontalWrap + padToheight (TRSP:380-384, 806-807) for one eye
+void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int camH, int stripW, float offset,
+                          uchar4* pano, int eqrW, int eqrH);
+void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h);
+// featherAlphaChannel pieces (CvUtil.cpp:140-157) on the top `rows` rows of a pano
+void launch_extract_alpha(hipStream_t st, const uchar4* img, int w, int rows, uint8_t* a);
+void launch_erode_cross(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, int e);
+void launch_gauss_u8_rows(hipStream_t st, const uint8_t* a, int* tmp, int w, int h, const int* ik, int r);
+void launch_gauss_u8_cols(hipStream_t st, const int* tmp, uint8_t* out, int w, int h, const int* ik, int r);
+// extended (x % cols wrapped) flow inputs (TRSP:399-411): side image takes the feathered alpha plane
+void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha /*nullable*/, int cols, int rows,
+                        uchar4* ext, int extW);
+// pole warp map + remap (TRSP:487-503)
+void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
+                      const PoleWarpParams& pw, const DevTables& T);
+// seam blend + alpha ramp + bottom padding (TRSP:505-546): out is eqrW x eqrH
+void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw);
+// flattenLayersDeghostPreferBase (CvUtil.cpp:224-260); flip_top: top layer is indexed (W-1-x, H-1-y)
+void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar4* out, int w, int h, int flip_top,
+                    const DevTables& T);
+// BGRA rows -> packed BGR at row offset (stackVertical + BGRA2BGR, TRSP:890-894, 960)
+void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst);
+// sharpen (Filter.h:40-127) on BGRA in place, lp scratch same size
+void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount);
+
+}  // namespace s360

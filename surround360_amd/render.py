@@ -1,0 +1,337 @@
+"""Host-side mirror of the reference's operator interface for the stereo-panorama path, over the
+C ABI of libs360 (include/s360.h). Names follow the reference:
+
+  RigDescription                      SR/render/RigDescription.h:27-59
+  make_optical_flow_by_name           SR/optical_flow/OpticalFlowFactory.h:23-64
+  OpticalFlow.compute_optical_flow    SR/optical_flow/OpticalFlowInterface.h:34-41
+  NovelViewGeneratorAsymmetricFlow    SR/optical_flow/NovelView.h:160-190
+  bicubic_remap_to_spherical          SR/render/ImageWarper.h:59-66
+  flatten_layers_deghost_prefer_base, offset_horizontal_wrap, feather_alpha_channel   SR/util/CvUtil.h
+  StereoPanoramaRenderer.render       renderStereoPanorama, SR/test/TestRenderStereoPanorama.cpp:716-972
+
+Everything computes on the GPU through libs360; numpy arrays are the cv::Mat stand-ins
+(H x W x C uint8, H x W x 2 float32 for flow).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import HINT, Camera, Geometry, Params, S360Error, check, lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+class VrCamException(S360Error):
+    """The reference's exception type for bad arguments / unknown algorithms (VrCamException.h:18-23)."""
+
+
+class RigDescription:
+    """RigDescription(filename): rig JSON -> cameras; rig_side_only = cameras whose group contains 'side'."""
+
+    MAX_CAMS = 64
+
+    def __init__(self, filename):
+        arr = (Camera * self.MAX_CAMS)()
+        n = check(lib().s360_rig_load_json(str(filename).encode(), arr, self.MAX_CAMS))
+        self.rig = (Camera * n)(*arr[:n])
+        self.rig_side_only = [c for c in self.rig if c.is_side]
+        if not self.rig_side_only:
+            raise VrCamException(_capi.ERR_INVALID_ARG, "rig has no side cameras")
+        self.top_index = lib().s360_rig_find_top(self.rig, n)
+        self.bottom_index = lib().s360_rig_find_bottom(self.rig, n)
+
+    def get_side_camera_count(self):
+        return len(self.rig_side_only)
+
+    def get_side_camera_id(self, idx):
+        return self.rig_side_only[idx].id.decode()
+
+    def get_top_camera_id(self):
+        return self.rig[self.top_index].id.decode()
+
+    def get_bottom_camera_id(self):
+        return self.rig[self.bottom_index].id.decode()
+
+    def top_camera(self):
+        return self.rig[self.top_index]
+
+    def bottom_camera(self):
+        return self.rig[self.bottom_index]
+
+
+def make_params(**kw):
+    """The gflags defaults of TestRenderStereoPanorama.cpp:44-70."""
+    p = Params()
+    p.interpupilary_dist = 6.4
+    p.zero_parallax_dist = 10000.0
+    p.sharpening = 0.0
+    p.side_alpha_feather_size = 100
+    p.std_alpha_feather_size = 31
+    p.enable_top = 0
+    p.enable_bottom = 0
+    p.eqr_width = 256
+    p.eqr_height = 128
+    p.final_eqr_width = 3480
+    p.final_eqr_height = 960
+    p.side_flow_alg = b"pixflow_low"
+    p.polar_flow_alg = b"pixflow_low"
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown flag: " + k)
+        setattr(p, k, v.encode() if isinstance(v, str) else v)
+    return p
+
+
+class Context:
+    """One s360_ctx: one GPU, its stream and its persistent HBM buffers."""
+
+    def __init__(self, rig, params=None, device=0):
+        self.rig = rig
+        self.params = params if params is not None else make_params()
+        h = C.c_void_p()
+        check(lib().s360_create(C.byref(h), int(device), rig.rig, len(rig.rig), C.byref(self.params)))
+        self.h = h
+        g = Geometry()
+        check(lib().s360_get_geometry(self.h, C.byref(g)), self.h)
+        self.geometry = g
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().s360_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        return check(rc, self.h)
+
+    def synchronize(self):
+        self._ck(lib().s360_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().s360_stream(self.h)
+
+    # ---- operators --------------------------------------------------------------------------
+    def compute_optical_flow(self, i0, i1, alg="pixflow_low", hint="UNKNOWN", prev_flow=None, prev_i0=None,
+                             prev_i1=None):
+        i0, i1 = _u8(i0), _u8(i1)
+        batched = i0.ndim == 4
+        b = i0.shape[0] if batched else 1
+        h, w = i0.shape[-3], i0.shape[-2]
+        flow = np.empty(i0.shape[:-1] + (2,), np.float32)
+        pf = np.ascontiguousarray(prev_flow, np.float32) if prev_flow is not None else None
+        p0 = _u8(prev_i0) if prev_i0 is not None else None
+        p1 = _u8(prev_i1) if prev_i1 is not None else None
+        rc = lib().s360_compute_optical_flow_batch(self.h, alg.encode(), b, _p(i0), _p(i1), w, h, _p(pf), _p(p0), _p(p1),
+                                                   HINT[hint], _p(flow))
+        if rc == _capi.ERR_UNKNOWN_ALG:
+            raise VrCamException(rc, "unrecognized flow algorithm name: " + alg)
+        self._ck(rc)
+        return flow
+
+    def debug_flow_levels(self, i0, i1, alg="pixflow_low", hint="UNKNOWN"):
+        i0, i1 = _u8(i0), _u8(i1)
+        h, w = i0.shape[:2]
+        cap = w * h * 8
+        buf = np.empty(cap, np.float32)
+        n = C.c_int()
+        self._ck(lib().s360_debug_flow_levels(self.h, alg.encode(), _p(i0), _p(i1), w, h, HINT[hint], _p(buf),
+                                              C.c_size_t(cap), C.byref(n)))
+        return buf, n.value
+
+    def spherical_warp_map(self, cam, dw, dh, l, r, t, b):
+        m = np.empty((dh, dw, 2), np.float32)
+        self._ck(lib().s360_spherical_warp_map(self.h, _p(m), dw, dh, C.byref(cam), C.c_float(l), C.c_float(r),
+                                               C.c_float(t), C.c_float(b)))
+        return m
+
+    def bicubic_remap_to_spherical(self, src, cam, dw, dh, dc, l, r, t, b):
+        src = _u8(src)
+        dst = np.empty((dh, dw, dc), np.uint8)
+        self._ck(lib().s360_bicubic_remap_to_spherical(self.h, _p(dst), dw, dh, dc, _p(src), src.shape[1], src.shape[0],
+                                                       src.shape[2], C.byref(cam), C.c_float(l), C.c_float(r),
+                                                       C.c_float(t), C.c_float(b)))
+        return dst
+
+    def combine_lazy_novel_views(self, image_l, image_r, flow_l_to_r, flow_r_to_l):
+        g = self.geometry
+        w = self.params.eqr_width // self.rig.get_side_camera_count()
+        cl = np.empty((g.cam_image_height, w, 4), np.uint8)
+        cr = np.empty_like(cl)
+        self._ck(lib().s360_combine_lazy_novel_views(
+            self.h, _p(_u8(image_l)), _p(_u8(image_r)), _p(np.ascontiguousarray(flow_l_to_r, np.float32)),
+            _p(np.ascontiguousarray(flow_r_to_l, np.float32)), _p(cl), _p(cr)))
+        return cl, cr
+
+    def flatten_layers_deghost_prefer_base(self, bottom_layer, top_layer):
+        b, t = _u8(bottom_layer), _u8(top_layer)
+        out = np.empty_like(b)
+        self._ck(lib().s360_flatten_layers_deghost_prefer_base(self.h, _p(b), _p(t), b.shape[1], b.shape[0], _p(out)))
+        return out
+
+    def offset_horizontal_wrap(self, src, offset):
+        s = _u8(src)
+        out = np.empty_like(s)
+        self._ck(lib().s360_offset_horizontal_wrap(self.h, _p(s), s.shape[1], s.shape[0], s.shape[2], C.c_float(offset),
+                                                   _p(out)))
+        return out
+
+    def feather_alpha_channel(self, src, erode_size):
+        s = _u8(src)
+        out = np.empty_like(s)
+        self._ck(lib().s360_feather_alpha_channel(self.h, _p(s), s.shape[1], s.shape[0], int(erode_size), _p(out)))
+        return out
+
+    def pole_to_side_flow(self, side, pole, want_flow=False):
+        side, pole = _u8(side), _u8(pole)
+        out = np.empty_like(side)
+        rows = pole.shape[0]
+        fl = None
+        if want_flow:
+            fl = np.empty((rows, int(np.float32(side.shape[1]) * np.float32(1.2)), 2), np.float32)
+        self._ck(lib().s360_pole_to_side_flow(self.h, _p(side), _p(pole), rows, _p(out), _p(fl)))
+        return (out, fl) if want_flow else out
+
+    def sharpen(self, bgr, sharpening):
+        b = _u8(bgr).copy()
+        self._ck(lib().s360_sharpen(self.h, _p(b), b.shape[1], b.shape[0], C.c_float(sharpening)))
+        return b
+
+    # ---- frame level -----------------------------------------------------------------------
+    def upload_frame(self, side, top=None, bottom=None):
+        for i, s in enumerate(side):
+            s = _u8(s)
+            self._ck(lib().s360_frame_upload_side(self.h, i, _p(s), s.shape[1], s.shape[0], s.shape[2]))
+        if top is not None:
+            t = _u8(top)
+            self._ck(lib().s360_frame_upload_top(self.h, _p(t), t.shape[1], t.shape[0]))
+        if bottom is not None:
+            b = _u8(bottom)
+            self._ck(lib().s360_frame_upload_bottom(self.h, _p(b), b.shape[1], b.shape[0]))
+
+    def render(self, use_prev=False):
+        self._ck(lib().s360_frame_render(self.h, int(use_prev)))
+
+    def render_pairs(self, p0, p1, use_prev=False):
+        self._ck(lib().s360_frame_render_pairs(self.h, p0, p1, int(use_prev)))
+
+    def finish(self, pole_mask=15, use_prev=False):
+        self._ck(lib().s360_frame_finish(self.h, pole_mask, int(use_prev)))
+
+    def strip_ptr(self, eye):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._ck(lib().s360_frame_strip_ptr(self.h, eye, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def equirect_dev(self):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._ck(lib().s360_frame_equirect_dev(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def download_equirect(self):
+        g = self.geometry
+        out = np.empty((g.out_height, g.out_width, 3), np.uint8)
+        self._ck(lib().s360_frame_download_equirect(self.h, _p(out)))
+        return out
+
+    def keep_intermediates(self, on=True):
+        self._ck(lib().s360_set_keep_intermediates(self.h, int(on)))
+
+    def get_u8(self, name, idx=0):
+        whc = (C.c_int * 3)()
+        self._ck(lib().s360_frame_get_u8(self.h, name.encode(), idx, whc, None))
+        d = np.empty((whc[1], whc[0], whc[2]), np.uint8)
+        self._ck(lib().s360_frame_get_u8(self.h, name.encode(), idx, whc, _p(d)))
+        return d
+
+    def get_f32(self, name, idx=0):
+        whc = (C.c_int * 3)()
+        self._ck(lib().s360_frame_get_f32(self.h, name.encode(), idx, whc, None))
+        d = np.empty((whc[1], whc[0], whc[2]), np.float32)
+        self._ck(lib().s360_frame_get_f32(self.h, name.encode(), idx, whc, _p(d)))
+        return d
+
+    # ---- measurement ------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ck(lib().s360_profile_enable(self.h, int(on)))
+
+    def profile_get(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        cnt = (C.c_int * 64)()
+        n = self._ck(lib().s360_profile_get(self.h, names, 4096, ms, cnt, 64))
+        ns = names.value.decode().split(";") if n else []
+        return {ns[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+# ---- reference-shaped operator objects ----------------------------------------------------------
+class OpticalFlow:
+    """OpticalFlowInterface implementation returned by make_optical_flow_by_name."""
+
+    def __init__(self, ctx, name):
+        self.ctx, self.name = ctx, name
+
+    def compute_optical_flow(self, i0_bgra, i1_bgra, prev_flow=None, prev_i0_bgra=None, prev_i1_bgra=None,
+                             hint="UNKNOWN"):
+        return self.ctx.compute_optical_flow(i0_bgra, i1_bgra, self.name, hint, prev_flow, prev_i0_bgra, prev_i1_bgra)
+
+
+def make_optical_flow_by_name(ctx, flow_alg_name):
+    if flow_alg_name not in ("pixflow_low", "pixflow_search_20"):
+        raise VrCamException(_capi.ERR_UNKNOWN_ALG, "unrecognized flow algorithm name: " + flow_alg_name)
+    return OpticalFlow(ctx, flow_alg_name)
+
+
+class NovelViewGeneratorAsymmetricFlow:
+    """prepare() computes flowLtoR / flowRtoL (NovelView.cpp:270-299); combine_lazy_novel_views renders the
+    left/right eye chunks of the pair (NovelView.cpp:226-268)."""
+
+    def __init__(self, ctx, flow_alg_name):
+        self.ctx, self.flow_alg_name = ctx, flow_alg_name
+        self.image_l = self.image_r = self.flow_l_to_r = self.flow_r_to_l = None
+
+    def prepare(self, color_image_l, color_image_r, prev_flow_l_to_r=None, prev_flow_r_to_l=None,
+                prev_color_image_l=None, prev_color_image_r=None):
+        alg = make_optical_flow_by_name(self.ctx, self.flow_alg_name)
+        self.image_l, self.image_r = _u8(color_image_l).copy(), _u8(color_image_r).copy()
+        self.flow_l_to_r = alg.compute_optical_flow(self.image_l, self.image_r, prev_flow_l_to_r, prev_color_image_l,
+                                                    prev_color_image_r, "LEFT")
+        self.flow_r_to_l = alg.compute_optical_flow(self.image_r, self.image_l, prev_flow_r_to_l, prev_color_image_r,
+                                                    prev_color_image_l, "RIGHT")
+
+    def get_flow_l_to_r(self):
+        return self.flow_l_to_r
+
+    def get_flow_r_to_l(self):
+        return self.flow_r_to_l
+
+    def combine_lazy_novel_views(self):
+        return self.ctx.combine_lazy_novel_views(self.image_l, self.image_r, self.flow_l_to_r, self.flow_r_to_l)
+
+
+class StereoPanoramaRenderer:
+    """renderStereoPanorama for one rig + flag set; frames are uploaded, rendered and downloaded explicitly."""
+
+    def __init__(self, rig_json_file, device=0, **flags):
+        self.rig = RigDescription(rig_json_file)
+        self.params = make_params(**flags)
+        if self.params.eqr_width % self.rig.get_side_camera_count() != 0:
+            raise VrCamException(_capi.ERR_INVALID_ARG,
+                                 "eqr_width must be evenly divisible by the number of cameras")
+        self.ctx = Context(self.rig, self.params, device)
+
+    def render(self, side_images, top_image=None, bottom_image=None, use_prev=False):
+        self.ctx.upload_frame(side_images, top_image, bottom_image)
+        self.ctx.render(use_prev)
+        return self.ctx.download_equirect()

@@ -1,0 +1,51 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+RIG_JSON = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rig_json():
+    return RIG_JSON
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def s360lib():
+    """Loads libs360.so (building it if the sources are newer)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "surround360_amd", "csrc"), "-j8", "-s"])
+    from surround360_amd import _capi
+    return _capi.lib()
+
+
+def _have_gpu():
+    try:
+        from surround360_amd import _capi
+        return _capi.lib().s360_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_rig(s360lib, rig_json):
+    from surround360_amd import render as R
+    if s360lib.s360_device_count() <= 0:
+        pytest.fail("no HIP device: -m gpu tests must run on the GPU box (there is no CPU fallback)")
+    return R.RigDescription(rig_json)

@@ -1,0 +1,363 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by the product package.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ORACLE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+_LIB = None
+
+
+class CameraC(C.Structure):
+    _fields_ = [
+        ("type", C.c_int), ("is_side", C.c_int), ("has_fov", C.c_int), ("pad_", C.c_int),
+        ("origin", C.c_double * 3), ("forward", C.c_double * 3), ("up", C.c_double * 3), ("right", C.c_double * 3),
+        ("resolution", C.c_double * 2), ("principal", C.c_double * 2), ("distortion", C.c_double * 2),
+        ("focal", C.c_double * 2), ("fov", C.c_double),
+    ]
+
+
+class ParamsC(C.Structure):
+    _fields_ = [
+        ("interpupilary_dist", C.c_double), ("zero_parallax_dist", C.c_double), ("sharpening", C.c_double),
+        ("side_alpha_feather_size", C.c_int), ("std_alpha_feather_size", C.c_int),
+        ("enable_top", C.c_int), ("enable_bottom", C.c_int),
+        ("eqr_width", C.c_int), ("eqr_height", C.c_int), ("final_eqr_width", C.c_int), ("final_eqr_height", C.c_int),
+        ("side_flow_search20", C.c_int), ("polar_flow_search20", C.c_int),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".h", ".cpp", "Makefile"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_frame_create.restype = C.c_void_p
+        _LIB.orc_frame_render.restype = C.c_double
+        _LIB.orc_camera_get_fov.restype = C.c_double
+        _LIB.orc_camera_undistort_distort.restype = C.c_double
+        _LIB.orc_approximate_fov.restype = C.c_float
+    return _LIB
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def camera_from_json(j):
+    """Camera(const dynamic& json), Camera.cpp:44-83."""
+    c = CameraC()
+    c.type = 0 if j["type"] == "FTHETA" else 1
+    c.is_side = 1 if "side" in j.get("group", "") else 0
+    for k, n in (("origin", 3), ("forward", 3), ("up", 3), ("right", 3), ("resolution", 2), ("focal", 2)):
+        for i in range(n):
+            getattr(c, k)[i] = float(j[k][i])
+    pr = j.get("principal", [j["resolution"][0] / 2, j["resolution"][1] / 2])
+    di = j.get("distortion", [0, 0])
+    for i in range(2):
+        c.principal[i] = float(pr[i])
+        c.distortion[i] = float(di[i])
+    c.has_fov = 1 if "fov" in j else 0
+    c.fov = float(j.get("fov", 0.0))
+    return c
+
+
+def load_rig(path):
+    with open(path) as f:
+        cams = json.load(f)["cameras"]
+    arr = (CameraC * len(cams))(*[camera_from_json(c) for c in cams])
+    return arr, [c["id"] for c in cams]
+
+
+def make_params(**kw):
+    p = ParamsC()
+    p.interpupilary_dist = 6.4
+    p.zero_parallax_dist = 10000.0
+    p.sharpening = 0.0
+    p.side_alpha_feather_size = 100
+    p.std_alpha_feather_size = 31
+    p.enable_top = 0
+    p.enable_bottom = 0
+    p.eqr_width = 256
+    p.eqr_height = 128
+    p.final_eqr_width = 3480
+    p.final_eqr_height = 960
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+# ---- primitives ---------------------------------------------------------------
+def resize_cubic_u8(src, dw, dh):
+    h, w, c = src.shape
+    d = np.empty((dh, dw, c), np.uint8)
+    lib().orc_resize_cubic_u8(_p(np.ascontiguousarray(src)), w, h, c, _p(d), dw, dh)
+    return d
+
+
+def _f3(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return a[:, :, None] if a.ndim == 2 else a
+
+
+def resize_cubic_f32(src, dw, dh):
+    s = _f3(src)
+    h, w, c = s.shape
+    d = np.empty((dh, dw, c), np.float32)
+    lib().orc_resize_cubic_f32(_p(s), w, h, c, _p(d), dw, dh)
+    return d if src.ndim == 3 else d[:, :, 0]
+
+
+def resize_linear_f32(src, dw, dh):
+    s = _f3(src)
+    h, w, c = s.shape
+    d = np.empty((dh, dw, c), np.float32)
+    lib().orc_resize_linear_f32(_p(s), w, h, c, _p(d), dw, dh)
+    return d if src.ndim == 3 else d[:, :, 0]
+
+
+def remap_cubic_u8(src, mp):
+    src = np.ascontiguousarray(src)
+    mp = np.ascontiguousarray(mp, np.float32)
+    h, w, c = src.shape
+    dh, dw, _ = mp.shape
+    d = np.empty((dh, dw, c), np.uint8)
+    lib().orc_remap_cubic_u8(_p(src), w, h, c, _p(mp), dw, dh, _p(d))
+    return d
+
+
+def remap_cubic_f32(src, mp):
+    s = _f3(src)
+    mp = np.ascontiguousarray(mp, np.float32)
+    h, w, c = s.shape
+    dh, dw, _ = mp.shape
+    d = np.empty((dh, dw, c), np.float32)
+    lib().orc_remap_cubic_f32(_p(s), w, h, c, _p(mp), dw, dh, _p(d))
+    return d
+
+
+def gaussian_blur_f32(src, ksize, sigma):
+    s = _f3(src)
+    h, w, c = s.shape
+    d = np.empty_like(s)
+    lib().orc_gaussian_blur_f32(_p(s), w, h, c, ksize, C.c_double(sigma), _p(d))
+    return d if src.ndim == 3 else d[:, :, 0]
+
+
+def gaussian_kernel(n, sigma):
+    k = np.empty(n, np.float32)
+    lib().orc_gaussian_kernel(n, C.c_double(sigma), _p(k))
+    return k
+
+
+def sobel(src, dir_y):
+    s = np.ascontiguousarray(src, np.float32)
+    d = np.empty_like(s)
+    lib().orc_sobel(_p(s), s.shape[1], s.shape[0], int(dir_y), _p(d))
+    return d
+
+
+def median5(src):
+    s = _f3(src)
+    h, w, c = s.shape
+    d = np.empty_like(s)
+    lib().orc_median5_f32(_p(s), w, h, c, _p(d))
+    return d if src.ndim == 3 else d[:, :, 0]
+
+
+def bicubic_tab():
+    tf = np.empty((1024, 16), np.float32)
+    ti = np.empty((1024, 16), np.int16)
+    lib().orc_bicubic_tab(_p(tf), _p(ti))
+    return tf, ti
+
+
+def feather_alpha_channel(src, erode_size):
+    s = np.ascontiguousarray(src)
+    d = np.empty_like(s)
+    lib().orc_feather_alpha_channel(_p(s), s.shape[1], s.shape[0], erode_size, _p(d))
+    return d
+
+
+def offset_horizontal_wrap(src, offset):
+    s = np.ascontiguousarray(src)
+    d = np.empty_like(s)
+    lib().orc_offset_horizontal_wrap(_p(s), s.shape[1], s.shape[0], s.shape[2], C.c_float(offset), _p(d))
+    return d
+
+
+def flatten_layers(base, top):
+    b = np.ascontiguousarray(base)
+    t = np.ascontiguousarray(top)
+    d = np.empty_like(b)
+    lib().orc_flatten_layers_deghost_prefer_base(_p(b), _p(t), b.shape[1], b.shape[0], _p(d))
+    return d
+
+
+def sharpen(bgr, amount):
+    b = np.ascontiguousarray(bgr).copy()
+    lib().orc_sharpen(_p(b), b.shape[1], b.shape[0], C.c_float(amount))
+    return b
+
+
+# ---- PixFlow --------------------------------------------------------------------
+HINT = {"UNKNOWN": 0, "RIGHT": 1, "DOWN": 2, "LEFT": 3, "UP": 4}
+
+
+def pixflow_levels(w, h):
+    lw = (C.c_int * 64)()
+    lh = (C.c_int * 64)()
+    n = lib().orc_pixflow_levels(w, h, lw, lh)
+    return [(lw[i], lh[i]) for i in range(n)]
+
+
+def compute_optical_flow(i0, i1, alg="pixflow_low", hint="UNKNOWN", prev_flow=None, prev_i0=None, prev_i1=None,
+                         want_levels=False):
+    i0 = np.ascontiguousarray(i0)
+    i1 = np.ascontiguousarray(i1)
+    h, w, _ = i0.shape
+    flow = np.empty((h, w, 2), np.float32)
+    lv = None
+    if want_levels:
+        sizes = pixflow_levels(w, h)
+        lv = np.empty(sum(a * b * 2 for a, b in sizes), np.float32)
+    pf = np.ascontiguousarray(prev_flow, np.float32) if prev_flow is not None else None
+    p0 = np.ascontiguousarray(prev_i0) if prev_i0 is not None else None
+    p1 = np.ascontiguousarray(prev_i1) if prev_i1 is not None else None
+    rc = lib().orc_compute_optical_flow(alg.encode(), _p(i0), _p(i1), w, h, _p(pf), _p(p0), _p(p1), HINT[hint],
+                                        _p(flow), _p(lv))
+    if rc != 0:
+        raise ValueError("unrecognized flow algorithm name: " + alg)
+    if want_levels:
+        out, off = [], 0
+        for (a, b) in reversed(sizes):
+            out.append(lv[off:off + a * b * 2].reshape(b, a, 2))
+            off += a * b * 2
+        return flow, out
+    return flow
+
+
+def pixflow_entry(i0):
+    i0 = np.ascontiguousarray(i0)
+    h, w, _ = i0.shape
+    dw, dh = int(w * 0.5), int(h * 0.5)
+    down = np.empty((dh, dw, 4), np.uint8)
+    I = np.empty((dh, dw), np.float32)
+    A = np.empty((dh, dw), np.float32)
+    lib().orc_pixflow_entry(_p(i0), w, h, _p(down), _p(I), _p(A))
+    return down, I, A
+
+
+def pixflow_level(I0, I1, a0, a1, flow=None, hint="UNKNOWN", search20=False):
+    h, w = I0.shape
+    f = np.zeros((h, w, 2), np.float32) if flow is None else np.ascontiguousarray(flow, np.float32).copy()
+    lib().orc_pixflow_level(_p(np.ascontiguousarray(I0, np.float32)), _p(np.ascontiguousarray(I1, np.float32)),
+                            _p(np.ascontiguousarray(a0, np.float32)), _p(np.ascontiguousarray(a1, np.float32)), w, h,
+                            _p(f), 0 if flow is None else 1, HINT[hint], int(search20))
+    return f
+
+
+# ---- geometry ---------------------------------------------------------------------
+def spherical_warp_map(cam, dw, dh, l, r, t, b):
+    m = np.empty((dh, dw, 2), np.float32)
+    lib().orc_spherical_warp_map(C.byref(cam), dw, dh, C.c_float(l), C.c_float(r), C.c_float(t), C.c_float(b), _p(m))
+    return m
+
+
+def bicubic_remap_to_spherical(cam, src, dw, dh, dc, l, r, t, b):
+    src = np.ascontiguousarray(src)
+    d = np.empty((dh, dw, dc), np.uint8)
+    lib().orc_bicubic_remap_to_spherical(C.byref(cam), _p(src), src.shape[1], src.shape[0], src.shape[2], dw, dh, dc,
+                                         C.c_float(l), C.c_float(r), C.c_float(t), C.c_float(b), _p(d))
+    return d
+
+
+class Frame:
+    """renderStereoPanorama (TestRenderStereoPanorama.cpp:716-972) on the oracle."""
+
+    def __init__(self, cams, params):
+        self.cams, self.params = cams, params
+        self.h = C.c_void_p(lib().orc_frame_create(cams, len(cams), C.byref(params)))
+        ints = (C.c_int * 6)()
+        fl = (C.c_float * 5)()
+        lib().orc_frame_geometry(self.h, ints, fl)
+        (self.cam_image_width, self.cam_image_height, self.overlap_image_width, self.num_novel_views,
+         self.top_rows, self.bottom_rows) = list(ints)
+        (self.h_radians, self.v_radians, self.fov_horizontal_radians, self.verge_disp,
+         self.zero_parallax_shift) = list(fl)
+        self.n_side = sum(1 for c in cams if c.is_side)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_frame_destroy(self.h)
+            self.h = None
+
+    def pole_ramp(self):
+        o = (C.c_float * 4)()
+        lib().orc_frame_pole_ramp(self.h, o)
+        return list(o)
+
+    def render(self, side, top=None, bottom=None, use_prev=False, threaded=False):
+        side = [np.ascontiguousarray(s) for s in side]
+        h, w, ch = side[0].shape
+        ptrs = (C.c_void_p * len(side))(*[s.ctypes.data for s in side])
+        top = np.ascontiguousarray(top) if top is not None else None
+        bottom = np.ascontiguousarray(bottom) if bottom is not None else None
+        pole = top if top is not None else bottom
+        ph, pw = (pole.shape[0], pole.shape[1]) if pole is not None else (0, 0)
+        sec = lib().orc_frame_render(self.h, ptrs, w, h, ch, _p(top), _p(bottom), pw, ph, int(use_prev), int(threaded))
+        return self.get_u8("out"), sec
+
+    def stage_seconds(self):
+        o = (C.c_double * 5)()
+        lib().orc_frame_stage_seconds(self.h, o)
+        return dict(zip(["projection", "side_flow", "novel_view", "poles", "total"], list(o)))
+
+    def get_u8(self, name, idx=0):
+        whc = (C.c_int * 3)()
+        if lib().orc_frame_get_u8(self.h, name.encode(), idx, whc, None) != 0:
+            raise KeyError(name)
+        d = np.empty((whc[1], whc[0], whc[2]), np.uint8)
+        lib().orc_frame_get_u8(self.h, name.encode(), idx, whc, _p(d))
+        return d
+
+    def get_f32(self, name, idx=0):
+        whc = (C.c_int * 3)()
+        if lib().orc_frame_get_f32(self.h, name.encode(), idx, whc, None) != 0:
+            raise KeyError(name)
+        d = np.empty((whc[1], whc[0], whc[2]), np.float32)
+        lib().orc_frame_get_f32(self.h, name.encode(), idx, whc, _p(d))
+        return d
+
+    def combine_lazy_novel_views(self, img_l, img_r, flow_l_to_r, flow_r_to_l):
+        w = self.params.eqr_width // self.n_side
+        cl = np.empty((self.cam_image_height, w, 4), np.uint8)
+        cr = np.empty_like(cl)
+        lib().orc_frame_combine_lazy_novel_views(
+            self.h, _p(np.ascontiguousarray(img_l)), _p(np.ascontiguousarray(img_r)),
+            _p(np.ascontiguousarray(flow_l_to_r, np.float32)), _p(np.ascontiguousarray(flow_r_to_l, np.float32)),
+            _p(cl), _p(cr))
+        return cl, cr
+
+    def pole_to_side_flow(self, side, pole, want_flow=False):
+        side = np.ascontiguousarray(side)
+        pole = np.ascontiguousarray(pole)
+        sh, sw, _ = side.shape
+        ph, pw, _ = pole.shape
+        out = np.empty_like(side)
+        fl = np.empty((ph, int(np.float32(pw) * np.float32(1.2)), 2), np.float32) if want_flow else None
+        lib().orc_frame_pole_to_side_flow(self.h, _p(side), sw, sh, _p(pole), pw, ph, _p(out), _p(fl))
+        return (out, fl) if want_flow else out

@@ -1,0 +1,79 @@
+"""GPU parity of PixFlow::computeOpticalFlow (PixFlow.h:81-183) through the C ABI, bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+from surround360_amd import render as R, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_rig):
+    c = R.Context(gpu_rig, R.make_params(eqr_width=1008, eqr_height=504))
+    yield c
+    c.close()
+
+
+def test_flow_levels_bit_exact(ctx, oracle):
+    i0, i1 = synth.flow_pair(200, 168, seed=3)
+    want_final, want_levels = oracle.compute_optical_flow(i0, i1, "pixflow_low", "LEFT", want_levels=True)
+    buf, n = ctx.debug_flow_levels(i0, i1, "pixflow_low", "LEFT")
+    assert n == len(want_levels)
+    off = 0
+    for li, wl in enumerate(want_levels):
+        got = buf[off:off + wl.size].reshape(wl.shape)
+        off += wl.size
+        assert np.array_equal(bits(got), bits(wl)), "level %d (coarsest first) differs: max abs %g" % (
+            li, np.abs(got - wl).max())
+
+
+@pytest.mark.parametrize("w,h,seed", [(160, 192, 1), (297, 444, 2), (333, 257, 5)])
+def test_flow_bit_exact(ctx, oracle, w, h, seed):
+    i0, i1 = synth.flow_pair(w, h, seed=seed)
+    for hint, a, b in (("LEFT", i0, i1), ("RIGHT", i1, i0)):
+        got = ctx.compute_optical_flow(a, b, "pixflow_low", hint)
+        want = oracle.compute_optical_flow(a, b, "pixflow_low", hint)
+        assert np.array_equal(bits(got), bits(want)), "max abs diff %g" % np.abs(got - want).max()
+
+
+def test_flow_search20_bit_exact(ctx, oracle):
+    i0, i1 = synth.flow_pair(180, 200, seed=11)
+    for hint in ("LEFT", "DOWN", "UNKNOWN"):
+        got = ctx.compute_optical_flow(i0, i1, "pixflow_search_20", hint)
+        want = oracle.compute_optical_flow(i0, i1, "pixflow_search_20", hint)
+        assert np.array_equal(bits(got), bits(want)), hint
+
+
+def test_flow_temporal_bit_exact(ctx, oracle):
+    a0, a1 = synth.flow_pair(192, 224, seed=21)
+    b0, b1 = synth.flow_pair(192, 224, seed=21, max_disp=6.0)
+    prev = oracle.compute_optical_flow(a0, a1, "pixflow_low", "LEFT")
+    got = ctx.compute_optical_flow(b0, b1, "pixflow_low", "LEFT", prev_flow=prev, prev_i0=a0, prev_i1=a1)
+    want = oracle.compute_optical_flow(b0, b1, "pixflow_low", "LEFT", prev_flow=prev, prev_i0=a0, prev_i1=a1)
+    assert np.array_equal(bits(got), bits(want)), "max abs diff %g" % np.abs(got - want).max()
+
+
+def test_flow_batch_matches_single(ctx):
+    pairs = [synth.flow_pair(160, 176, seed=s) for s in (31, 32, 33)]
+    i0 = np.stack([p[0] for p in pairs])
+    i1 = np.stack([p[1] for p in pairs])
+    batch = ctx.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+    for k, (a, b) in enumerate(pairs):
+        single = ctx.compute_optical_flow(a, b, "pixflow_low", "LEFT")
+        assert np.array_equal(bits(batch[k]), bits(single))
+
+
+def test_unknown_algorithm_raises(ctx):
+    i0, i1 = synth.flow_pair(160, 176, seed=1)
+    with pytest.raises(R.VrCamException):
+        ctx.compute_optical_flow(i0, i1, "no_such_flow")
+
+
+def test_identical_images_near_zero_flow(ctx):
+    i0, _ = synth.flow_pair(192, 192, seed=9)
+    f = ctx.compute_optical_flow(i0, i0)
+    assert np.abs(f).max() < 0.5
