@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — stereo-equirect frames/sec at 8K (17-camera rig) on N MI355X.
+
+One "step" = one pass of the hot path over one synthetic 17-camera frame: spherical reprojection, 28 side
+PixFlow flows, novel-view strips, panorama assembly, 4 pole flows + warps, composite, final resize to
+8192x8192 — everything renderStereoPanorama does between decoded inputs and the stacked equirect
+(TestRenderStereoPanorama.cpp:716-972). Inputs are uploaded to HBM before the timed region.
+
+N=1: all pairs on one GPU (BASELINE.json configs[2]).  N>1 (launched by torch.distributed.run, one rank per
+GPU): the 14 side pairs are sharded over the ranks, one RCCL exchange gathers the strips on rank 0, which
+runs the pole units and the composite (configs[3]); total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
+(measured live with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle = an OpenCV-free
+port of the reference, timed on a bounded sample on the host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+RIG = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
+FLAGS_8K = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192,
+                final_eqr_height=8192)  # the reference's "8k" preset, batch_process_video.py:194-199
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SWEEP_BYTES_PER_PX = 48  # sweep reads 40 B + writes 8 B per pixel-level
+
+
+def pyramid_levels(w, h):
+    """PixFlow.h:477-491 on the x0.5 downscaled input."""
+    cw, ch = int(w * 0.5), int(h * 0.5)
+    out = []
+    while True:
+        out.append((cw, ch))
+        nw, nh = int(np.float32(cw) * np.float32(0.9) + np.float32(0.5)), int(
+            np.float32(ch) * np.float32(0.9) + np.float32(0.5))
+        if nh <= 24 or nw <= 24:
+            break
+        cw, ch = nw, nh
+    return out
+
+
+def sweep_algorithmic_bytes(geom, n_side_flows, n_pole_flows, eqr_w):
+    side = sum(w * h for w, h in pyramid_levels(geom.overlap_image_width, geom.cam_image_height))
+    ext_w = int(np.float32(eqr_w) * np.float32(1.2))
+    pole = sum(w * h for w, h in pyramid_levels(ext_w, geom.top_rows)) if n_pole_flows else 0
+    # two sweeps (forward, backward) per level per flow
+    return 2 * SWEEP_BYTES_PER_PX * (n_side_flows * side + n_pole_flows * pole)
+
+
+def cpu_baseline(side, top, bottom):
+    """The oracle (kind "port") with the reference's thread shape on a bounded sample: the same 17-camera
+    frame rendered at eqr 2058x1029 (2K). Converted to 8K-equivalent frames/s by the ratio of flow
+    pixel-levels (flow is >95 % of the CPU time at both sizes)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # test infrastructure: used here only as the timed CPU baseline
+    cams, _ = O.load_rig(RIG)
+    f = O.Frame(cams, O.make_params(eqr_width=2058, eqr_height=1029, enable_top=1, enable_bottom=1,
+                                    final_eqr_width=0, final_eqr_height=0))
+    t0 = time.time()
+    f.render(side, top, bottom, threaded=True)
+    sec_2k = time.time() - t0
+
+    def px_levels(fr, eqr_w):
+        s = sum(w * h for w, h in pyramid_levels(fr.overlap_image_width, fr.cam_image_height))
+        p = sum(w * h for w, h in pyramid_levels(int(np.float32(eqr_w) * np.float32(1.2)), fr.top_rows))
+        return 28 * s + 4 * p
+    f8 = O.Frame(cams, O.make_params(**FLAGS_8K))
+    ratio = px_levels(f8, 8400) / px_levels(f, 2058)
+    cores = os.cpu_count() or 1
+    return {"value": 1.0 / (sec_2k * ratio), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "CPU restatement of Surround360 (OpenCV-free), reference thread shape (14 pair threads + 4 "
+                      "pole threads on %d cores): one 17-cam frame at eqr 2058x1029 took %.2f s; scaled to 8K by "
+                      "the flow pixel-level ratio %.1fx" % (cores, sec_2k, ratio)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", default="8k", choices=["8k", "2k"], help="2k is a debugging aid, not a bench config")
+    args = ap.parse_args()
+
+    import torch
+    from surround360_amd import parallel, render as R, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    flags = dict(FLAGS_8K) if args.size == "8k" else dict(eqr_width=2058, eqr_height=1029, enable_top=1,
+                                                           enable_bottom=1, final_eqr_width=0, final_eqr_height=0)
+    side, top, bottom = synth.rig_frame(RIG, size=2048, world_h=1024, seed=360)
+    rig = R.RigDescription(RIG)
+    ctx = R.Context(rig, R.make_params(**flags), device=local_rank)
+    P = rig.get_side_camera_count()
+    bounds = parallel.partition_pairs(P, world)
+    p0, p1 = bounds[rank], bounds[rank + 1]
+    ctx.upload_frame(side, top, bottom)  # inputs resident in HBM before the timed region
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    strips = parallel.strips_tensor(ctx, dev) if world > 1 else None
+
+    def step():
+        if world == 1:
+            ctx.render(False)
+        else:
+            ctx.render_pairs(p0, p1, False)
+            with torch.cuda.stream(ext):
+                parallel.gather_strips(strips, bounds, rank, world, 0)
+            if rank == 0:
+                ctx.finish(15, False)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    g = ctx.geometry
+    sweep_ms, sweep_launches = prof.get("flow_sweep", (0.0, 0))
+    n_side_flows = 2 * (p1 - p0)
+    bytes_per_frame = sweep_algorithmic_bytes(g, n_side_flows, 4, flags["eqr_width"])
+    achieved = (bytes_per_frame * args.steps) / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    out = {
+        "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
+        "value": args.steps / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo 8192x8192, "
+                               "top+bottom poles, pixflow_low, sharpening 0" if args.size == "8k" else
+                               "DEBUG 2K frame (not a bench config)",
+                   "parallelism": "pairs sharded over %d GPU(s), strip gather to rank 0" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_sweep_diag (PixFlow propagation sweeps)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "avg_launch_ms": sweep_ms / max(sweep_launches, 1), "launches_per_frame": sweep_launches / args.steps,
+                     "algorithmic_bytes_per_frame": bytes_per_frame,
+                     "note": "dependency-latency-bound wavefront kernel; see DESIGN.md"},
+        "kernel_ms_per_frame": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(side, top, bottom)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

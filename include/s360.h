@@ -101,6 +101,12 @@ double s360_camera_get_fov(const s360_camera* cam);
 int s360_rig_find_top(const s360_camera* cams, int n);
 int s360_rig_find_bottom(const s360_camera* cams, int n);
 
+/* Derived panorama geometry for a rig + flag set (host only; what s360_create computes and caches). */
+int s360_derive_geometry(const s360_camera* cams, int n_cams, const s360_params* params, s360_geometry* out);
+/* Pole ramp constants of poleToSideFlowThread (TRSP:454-481): poleCameraRadius, phiRampStart, phiMid, phiRampEnd
+ * (degrees). Host only. */
+int s360_pole_ramp(const s360_camera* cams, int n_cams, float out4[4]);
+
 /* ---- context: one per device; owns streams, persistent HBM buffers, cached warp maps -------- */
 /* cams: the whole rig (side cameras in rig order + pole cameras), as RigDescription holds it. */
 int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams, const s360_params* params);

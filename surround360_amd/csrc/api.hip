@@ -101,6 +101,29 @@ static int find_dir(const s360_camera* cams, int n, double z) {
 int s360_rig_find_top(const s360_camera* cams, int n) { return find_dir(cams, n, 1.0); }
 int s360_rig_find_bottom(const s360_camera* cams, int n) { return find_dir(cams, n, -1.0); }
 
+int s360_derive_geometry(const s360_camera* cams, int n_cams, const s360_params* params, s360_geometry* out) {
+  return guard(nullptr, [&] {
+    need(cams && params && out && n_cams > 0, "null argument");
+    Rig r;
+    r.all.assign(cams, cams + n_cams);
+    r.finalize();
+    need(!r.side.empty(), "rig has no side cameras");
+    *out = derive_geometry(r, *params);
+  });
+}
+int s360_pole_ramp(const s360_camera* cams, int n_cams, float out4[4]) {
+  return guard(nullptr, [&] {
+    need(cams && out4 && n_cams > 0, "null argument");
+    Rig r;
+    r.all.assign(cams, cams + n_cams);
+    r.finalize();
+    const double down[3] = {0, 0, -1};
+    need(!r.side.empty() && r.find_by_direction(down) >= 0, "rig needs side cameras and a bottom camera");
+    const PoleRamp p = pole_ramp(r);
+    out4[0] = p.poleCameraRadius; out4[1] = p.phiRampStart; out4[2] = p.phiMid; out4[3] = p.phiRampEnd;
+  });
+}
+
 // ---- context -----------------------------------------------------------------------------------
 int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams, const s360_params* params) {
   if (!out) return S360_ERR_INVALID_ARG;
