@@ -35,9 +35,16 @@ static void need(bool ok, const char* what) {
 static void h2d(s360_ctx* c, void* d, const void* h, size_t n) {
   S360_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->st));
 }
+static void check_sweep_error(s360_ctx* c) {
+  unsigned e = 0;
+  if (c->flow) e |= c->flow->take_error(c->st);
+  if (c->flow_pole) e |= c->flow_pole->take_error(c->st);
+  if (e) throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
+}
 static void d2h(s360_ctx* c, void* h, const void* d, size_t n) {
   S360_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->st));
   S360_HIP(hipStreamSynchronize(c->st));
+  check_sweep_error(c);
 }
 
 extern "C" {
@@ -177,7 +184,7 @@ int s360_get_geometry(const s360_ctx* c, s360_geometry* out) {
 }
 void* s360_stream(s360_ctx* c) { return c ? (void*)c->st : nullptr; }
 int s360_synchronize(s360_ctx* c) {
-  return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); });
+  return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); check_sweep_error(c); });
 }
 int s360_set_keep_intermediates(s360_ctx* c, int on) {
   return guard(c, [&] { need(c, "null ctx"); frame_state(c).keep_intermediates = on != 0; });

@@ -3,6 +3,7 @@
 #include "flow.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace s360 {
@@ -80,6 +81,18 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   flowB_.ensure(B * n0 * sizeof(float2));
   blurred_.ensure(B * n0 * sizeof(float2));
   full_.ensure((size_t)B * w * h * sizeof(float2));
+  if (sweep_mode_ < 0) {
+    const char* e = std::getenv("S360_SWEEP");  // debugging/A-B knob: "diag" selects the v1 kernel
+    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : 1;
+  }
+  if (sweep_mode_ == 1) {
+    rec_.ensure(B * n0 * sizeof(float4));
+    handoff_.ensure((size_t)B * sweep_num_bands(dh_) * dw_ * sizeof(unsigned long long));
+    if (!err_.p) {
+      err_.ensure(sizeof(unsigned));
+      S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
+    }
+  }
   float* pyrI = pyrI_.as<float>();
   float* pyrA = pyrA_.as<float>();
   auto LI = [&](int l) { return pyrI + (size_t)N * lv_.off[l]; };
@@ -154,18 +167,24 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       ProfScope ps(P, "flow_blur15");
       launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
     }
-    {
-      ProfScope ps(P, "flow_sweep");
-      launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), cur, wl, hl, nl, B, idx, +1, pc);
+    if (sweep_mode_ == 1) {
+      ProfScope ps(P, "flow_records");
+      launch_make_records(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), rec_.as<float4>(), nl, B, idx);
     }
+    auto sweep = [&](float2* fl, int dir) {
+      ProfScope ps(P, "flow_sweep");
+      if (sweep_mode_ == 1)
+        launch_sweep_band(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.as<unsigned long long>(),
+                          err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc);
+      else
+        launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), fl, wl, hl, nl, B, idx, dir, pc);
+    };
+    sweep(cur, +1);
     {
       ProfScope ps(P, "flow_median");
       launch_median5_c2(st, cur, oth, wl, hl, nl, B);
     }
-    {
-      ProfScope ps(P, "flow_sweep");
-      launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), oth, wl, hl, nl, B, idx, -1, pc);
-    }
+    sweep(oth, -1);
     {
       ProfScope ps(P, "flow_median");
       launch_median5_c2(st, oth, cur, wl, hl, nl, B);
@@ -196,6 +215,15 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       launch_sepblur(st, full_.as<float>(), (float*)out, w, h, 2, (size_t)w * h, B, tFinal);
     }
   }
+}
+
+unsigned FlowEngine::take_error(hipStream_t st) {
+  if (!err_.p) return 0;
+  unsigned v = 0;
+  S360_HIP(hipMemcpyAsync(&v, err_.p, sizeof(v), hipMemcpyDeviceToHost, st));
+  S360_HIP(hipStreamSynchronize(st));
+  if (v) S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
+  return v;
 }
 
 }  // namespace s360

@@ -46,7 +46,14 @@ class FlowEngine {
   FlowLevels lv_;
   int dw_ = 0, dh_ = 0;
   DevBuf down_, prevdown_, gray_, pyrI_, pyrA_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
-      motionPyr_, I1eq_;
+      motionPyr_, I1eq_, rec_, handoff_, err_;
+  int sweep_mode_ = -1;  // 0: v1 one-workgroup diagonal kernel, 1: v2 banded multi-workgroup kernel (default)
+
+ public:
+  // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag
+  unsigned take_error(hipStream_t st);
+
+ private:
 };
 
 }  // namespace s360

@@ -393,6 +393,199 @@ __global__ __launch_bounds__(1024) void k_sweep_diag(const float2* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v2 sweep: banded wavefront. One wave (64 lanes) owns a band of 64 consecutive rows; lane l walks row
+// (band*64 + l) one pixel per step, skewed by l, so at step s it handles column s - l. Inside the wave the
+// raster-order dependencies are register hand-offs: left neighbour = the lane's own previous result, up
+// neighbour = the previous result of lane l-1 (one DPP shuffle). Bands of one flow run as separate
+// workgroups on different CUs; band k+1 receives the final flow of band k's last row through an 8-byte
+// {fx,fy} granule per column in global memory (agent-scope relaxed atomics, NaN-pattern sentinel = "not yet
+// written"; MI355X_MICROARCH.md "data IS the flag"), polled 16 columns at a time. Every spin is bounded.
+// The per-pixel inputs that do not change during a sweep are packed into one 16-byte record
+// {I0x, I0y, blurredFlow.x, blurredFlow.y}; I0x = NaN marks "alpha0 <= 0.9 || alpha1 <= 0.9" (pixel not updated).
+constexpr unsigned long long kHandoffEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kBandRows = 64, kChunk = 16, kBlk = 4;
+
+__global__ __launch_bounds__(256) void k_make_records(const float2* __restrict__ G, const float* __restrict__ A,
+                                                      const float2* __restrict__ blurred, float4* __restrict__ rec,
+                                                      size_t n, size_t bs, FlowIdx idx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = blockIdx.z;
+  const float2 g = G[bs * idx.i0[b] + i];
+  const float2 bf = blurred[bs * b + i];
+  const bool upd = A[bs * idx.i0[b] + i] > 0.9f && A[bs * idx.i1[b] + i] > 0.9f;
+  rec[bs * b + i] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, bf.x, bf.y);
+}
+
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+struct Texels { float4 r0, r1; };  // (x0,y0),(x0+1,y0) and (x0,y0+1),(x0+1,y0+1) as (Ix,Iy,Ix,Iy)
+struct Foot { int off; float xR, yR; };
+__device__ __forceinline__ Foot footprint(int w, float x, float y, const SweepConst& c) {
+  x = (0.0f < x) ? x : 0.0f;
+  x = (x < c.wm2) ? x : c.wm2;
+  y = (0.0f < y) ? y : 0.0f;
+  y = (y < c.hm2) ? y : c.hm2;
+  const int x0 = (int)x, y0 = (int)y;
+  Foot f;
+  f.off = y0 * w + x0;
+  f.xR = x - (float)x0;
+  f.yR = y - (float)y0;
+  return f;
+}
+__device__ __forceinline__ Texels load_texels(const float2* __restrict__ G1, int w, int off) {
+  Texels t;
+  const f4a8 a = *reinterpret_cast<const f4a8*>(G1 + off);
+  const f4a8 b = *reinterpret_cast<const f4a8*>(G1 + off + w);
+  t.r0 = make_float4(a.x, a.y, a.z, a.w);
+  t.r1 = make_float4(b.x, b.y, b.z, b.w);
+  return t;
+}
+__device__ __forceinline__ float error_from(const Texels& t, const Foot& ft, float g0x, float g0y, float bfx,
+                                            float bfy, float fdx, float fdy, const SweepConst& c) {
+  // getPixBilinear32FExtend on I1x and I1y (f00 = r0.xy, f10 = r0.zw, f01 = r1.xy, f11 = r1.zw)
+  float i1x, i1y;
+  {
+    const float a1 = t.r0.x, a2 = t.r0.z - t.r0.x, a3 = t.r1.x - t.r0.x, a4 = t.r0.x + t.r1.z - t.r0.z - t.r1.x;
+    i1x = a1 + a2 * ft.xR + a3 * ft.yR + a4 * ft.xR * ft.yR;
+  }
+  {
+    const float a1 = t.r0.y, a2 = t.r0.w - t.r0.y, a3 = t.r1.y - t.r0.y, a4 = t.r0.y + t.r1.w - t.r0.w - t.r1.y;
+    i1y = a1 + a2 * ft.xR + a3 * ft.yR + a4 * ft.xR * ft.yR;
+  }
+  const float dfx = bfx - fdx, dfy = bfy - fdy;
+  const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
+  const float ex = g0x - i1x, ey = g0y - i1y;
+  return sqrtf(ex * ex + ey * ey) + smoothness * c.smoothnessCoef + c.vertCoef * fabsf(fdy) / c.fcols +
+         c.horizCoef * fabsf(fdx) / c.frows;
+}
+
+__device__ __forceinline__ float2 sweep_pixel(const float2* __restrict__ G1, int w, int x, int y, float4 rc, float2 f,
+                                              bool hasLeft, float2 left, bool hasUp, float2 up, const SweepConst& c) {
+  const float kEps = 0.001f;
+  const float fx = (float)x, fy = (float)y;
+  // the three candidate errors are independent of each other: gather all footprints first
+  const Foot f0 = footprint(w, fx + f.x, fy + f.y, c);
+  const Foot fL = footprint(w, fx + left.x, fy + left.y, c);
+  const Foot fU = footprint(w, fx + up.x, fy + up.y, c);
+  const Texels t0 = load_texels(G1, w, f0.off);
+  Texels tL = t0, tU = t0;
+  if (hasLeft && fL.off != f0.off) tL = load_texels(G1, w, fL.off);
+  if (hasUp && fU.off != f0.off) tU = (hasLeft && fU.off == fL.off) ? tL : load_texels(G1, w, fU.off);
+  float currErr = error_from(t0, f0, rc.x, rc.y, rc.z, rc.w, f.x, f.y, c);
+  Texels tc = t0;
+  int offc = f0.off;
+  if (hasLeft) {
+    const float e = error_from(tL, fL, rc.x, rc.y, rc.z, rc.w, left.x, left.y, c);
+    if (e < currErr) { f = left; currErr = e; tc = tL; offc = fL.off; }
+  }
+  if (hasUp) {
+    const float e = error_from(tU, fU, rc.x, rc.y, rc.z, rc.w, up.x, up.y, c);
+    if (e < currErr) { f = up; currErr = e; tc = tU; offc = fU.off; }
+  }
+  // errorGradient: the +eps probes almost always fall into the texel cell already held in registers
+  const Foot gx = footprint(w, fx + (f.x + kEps), fy + (f.y + 0.0f), c);
+  const Foot gy = footprint(w, fx + (f.x + 0.0f), fy + (f.y + kEps), c);
+  Texels tx = tc, ty = tc;
+  if (gx.off != offc) tx = load_texels(G1, w, gx.off);
+  if (gy.off != offc) ty = load_texels(G1, w, gy.off);
+  const float ex = error_from(tx, gx, rc.x, rc.y, rc.z, rc.w, f.x + kEps, f.y + 0.0f, c);
+  const float ey = error_from(ty, gy, rc.x, rc.y, rc.z, rc.w, f.x + 0.0f, f.y + kEps, c);
+  const float ggx = (ex - currErr) / kEps, ggy = (ey - currErr) / kEps;
+  f.x = f.x - c.gradStep * ggx;
+  f.y = f.y - c.gradStep * ggy;
+  return f;
+}
+
+__global__ __launch_bounds__(64) void k_sweep_band(const float4* __restrict__ rec, const float2* __restrict__ G,
+                                                   float2* __restrict__ flow, unsigned long long* __restrict__ H,
+                                                   int w, int h, size_t bs, FlowIdx idx, int dir, SweepConst c, int nb,
+                                                   unsigned* __restrict__ errflag) {
+  const int band = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float2* __restrict__ G1 = G + bs * idx.i1[b];
+  rec += bs * b;
+  flow += bs * b;
+  H += (size_t)b * nb * w;
+  const int yi = band * kBandRows + lane;
+  const bool rowValid = yi < h;
+  const int yic = rowValid ? yi : h - 1;
+  const int y = dir > 0 ? yic : h - 1 - yic;
+  const int lastLane = min(kBandRows - 1, h - 1 - band * kBandRows);
+  const float4* __restrict__ recRow = rec + (size_t)y * w;
+  float2* __restrict__ flowRow = flow + (size_t)y * w;
+  const unsigned long long* Hin = H + (size_t)band * w;
+  unsigned long long* Hout = H + (size_t)(band + 1) * w;
+  const bool produce = (band + 1 < nb) && lane == lastLane;
+  float2 fl = make_float2(0.f, 0.f);  // final flow of the previous pixel of this row
+  unsigned long long hv = 0;          // lanes 0..kChunk-1: up-row flow granules of the current chunk
+  const int nsteps = w + lastLane;    // local steps 0 .. w-1+lastLane
+  float4 crec[kBlk], nrec[kBlk];
+  float2 cfl[kBlk], nfl[kBlk];
+  auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    const int x = col(j - lane);
+    crec[j] = recRow[x];
+    cfl[j] = flowRow[x];
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += kBlk) {
+    if (band > 0 && (s0 % kChunk) == 0) {
+      // poll the granules of columns s0 .. s0+kChunk-1 written by the band above
+      const int xi = s0 + lane;
+      const bool want = lane < kChunk && xi < w;
+      unsigned spins = 0;
+      for (;;) {
+        unsigned long long v = kHandoffEmpty;
+        if (want) v = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = !want || v != kHandoffEmpty;
+        if (__all(ok)) { hv = v; break; }
+        __builtin_amdgcn_s_sleep(4);
+        ++spins;
+        if ((spins & 1023u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (spins > (1u << 22)) {  // ~seconds: the producer is gone; flag and bail out (results invalid)
+          if (lane == 0) atomicExch(errflag, 1u);
+          return;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {  // next block of per-pixel inputs
+      const int x = col(s0 + kBlk + j - lane);
+      nrec[j] = recRow[x];
+      nfl[j] = flowRow[x];
+    }
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const int s = s0 + j;
+      const int xi = s - lane;
+      const bool active = rowValid && xi >= 0 && xi < w;
+      // up neighbour: lane l-1's previous result; lane 0 takes the granule of column xi == s from the chunk
+      float2 up;
+      up.x = __shfl_up(fl.x, 1);
+      up.y = __shfl_up(fl.y, 1);
+      const int hs = s & (kChunk - 1);
+      const unsigned long long hg = __shfl(hv, hs);
+      if (lane == 0) { up.x = __uint_as_float((unsigned)hg); up.y = __uint_as_float((unsigned)(hg >> 32)); }
+      const int x = dir > 0 ? xi : w - 1 - xi;
+      float2 f = cfl[j];
+      if (active) {
+        const float4 rc = crec[j];
+        if (rc.x == rc.x) {  // not NaN: both alphas above the update threshold
+          f = sweep_pixel(G1, w, x, y, rc, f, xi > 0, fl, yi > 0, up, c);
+          flowRow[x] = f;
+        }
+        if (produce)
+          __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(f.y) << 32) | __float_as_uint(f.x),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fl = f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) { crec[j] = nrec[j]; cfl[j] = nfl[j]; }
+  }
+}
+
 // ---- pixflow_search_20 only: adjustInitialFlow at the coarsest level (PixFlow.h:219-342) ----
 __global__ void k_search_init(const float* __restrict__ I, const float* __restrict__ A, int w, int h, size_t pbs,
                               FlowIdx idx, float2* __restrict__ flow, int hint, int dist, float* __restrict__ I1eq) {
@@ -558,6 +751,29 @@ void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2*
   if (threads > 1024) threads = 1024;
   const size_t lds = (size_t)2 * h * sizeof(float2);
   hipLaunchKernelGGL(k_sweep_diag, dim3(B), dim3(threads), lds, st, G, A, blurred, flow, w, h, bs, idx, dir, c);
+}
+void launch_make_records(hipStream_t st, const float2* G, const float* A, const float2* blurred, float4* rec, size_t n,
+                         int B, const FlowIdx& idx) {
+  hipLaunchKernelGGL(k_make_records, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, G, A, blurred, rec, n, n,
+                     idx);
+}
+int sweep_num_bands(int h) { return (h + kBandRows - 1) / kBandRows; }
+void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, unsigned long long* H,
+                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
+                       const PixFlowConsts& pc) {
+  SweepConst c;
+  c.smoothnessCoef = pc.smoothnessCoef;
+  c.vertCoef = pc.verticalRegularizationCoef;
+  c.horizCoef = pc.horizontalRegularizationCoef;
+  c.gradStep = pc.gradientStepSize;
+  c.fcols = (float)w;
+  c.frows = (float)h;
+  c.wm2 = (float)w - 2.0f;
+  c.hm2 = (float)h - 2.0f;
+  const int nb = sweep_num_bands(h);
+  // granules start as "empty" (all ones) for every band boundary of every flow
+  hipMemsetAsync(H, 0xFF, (size_t)B * nb * w * sizeof(unsigned long long), st);
+  hipLaunchKernelGGL(k_sweep_band, dim3(nb, B), dim3(64), 0, st, rec, G, flow, H, w, h, bs, idx, dir, c, nb, errflag);
 }
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq) {
