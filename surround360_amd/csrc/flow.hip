@@ -87,7 +87,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   }
   if (sweep_mode_ == 1) {
     rec_.ensure(B * n0 * sizeof(float4));
-    handoff_.ensure((size_t)B * sweep_num_bands(dh_) * dw_ * sizeof(unsigned long long));
+    handoff_.ensure(sweep_handoff_bytes(dw_, dh_, B));
     if (!err_.p) {
       err_.ensure(sizeof(unsigned));
       S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
@@ -174,8 +174,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       if (sweep_mode_ == 1)
-        launch_sweep_band(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.as<unsigned long long>(),
-                          err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc);
+        launch_sweep_band(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
+                          idx, dir, pc);
       else
         launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), fl, wl, hl, nl, B, idx, dir, pc);
     };

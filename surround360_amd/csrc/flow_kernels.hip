@@ -395,17 +395,26 @@ __global__ __launch_bounds__(1024) void k_sweep_diag(const float2* __restrict__ 
 
 
 // ------------------------------------------------------------------------------------------
-// v2 sweep: banded wavefront. One wave (64 lanes) owns a band of 64 consecutive rows; lane l walks row
-// (band*64 + l) one pixel per step, skewed by l, so at step s it handles column s - l. Inside the wave the
-// raster-order dependencies are register hand-offs: left neighbour = the lane's own previous result, up
-// neighbour = the previous result of lane l-1 (one DPP shuffle). Bands of one flow run as separate
-// workgroups on different CUs; band k+1 receives the final flow of band k's last row through an 8-byte
-// {fx,fy} granule per column in global memory (agent-scope relaxed atomics, NaN-pattern sentinel = "not yet
-// written"; MI355X_MICROARCH.md "data IS the flag"), polled 16 columns at a time. Every spin is bounded.
-// The per-pixel inputs that do not change during a sweep are packed into one 16-byte record
-// {I0x, I0y, blurredFlow.x, blurredFlow.y}; I0x = NaN marks "alpha0 <= 0.9 || alpha1 <= 0.9" (pixel not updated).
+// Banded wavefront sweep ("hex16"): the production kernel for PixFlow.h:388-410.
+//
+// Geometry. A wave owns a band of 4 consecutive rows; each row gets 16 lanes. Row r of the band handles
+// column s - r at step s (skewed), so inside the wave the raster-order dependencies are register hand-offs:
+// left neighbour = the row's own previous result (every lane of the row holds it), up neighbour = the row
+// above's previous result (DPP row_bcast:15). Bands of one flow are separate workgroups on different CUs;
+// band k+1 receives the final flow of band k's last row through one 8-byte {fx,fy} granule per column
+// (agent-scope relaxed atomic store/load; all-ones = "not written yet" — MI355X_MICROARCH.md: the data IS
+// the flag). Bands take their (band, flow) from a ticket counter in band-major order, so a band's
+// predecessor has always started before it: no co-residency assumption. Every spin is bounded.
+//
+// Latency. One pixel update needs 5 errorFunction evaluations in 2 dependent rounds (3 proposals, then 2
+// finite-difference probes of the winner). The 16 lanes of a row evaluate all 9 possible ones at once —
+// lanes 0-2: current / left / up flow; lanes 3-8: the +eps probes of each of them — and exchange the 9
+// scalars with DPP row broadcasts; every lane then replays the reference's sequential selection. A step is
+// therefore ONE gather round + ONE evaluation deep instead of two rounds and five evaluations.
+// Per-pixel inputs that are constant during a sweep come packed as one 16-byte record
+// {I0x, I0y, blurredFlow.x, blurredFlow.y}; I0x = NaN marks "alpha0 <= 0.9 || alpha1 <= 0.9" (not updated).
 constexpr unsigned long long kHandoffEmpty = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kBandRows = 64, kChunk = 16, kBlk = 4;
+constexpr int kBandRows = 4, kPoll = 8;
 
 __global__ __launch_bounds__(256) void k_make_records(const float2* __restrict__ G, const float* __restrict__ A,
                                                       const float2* __restrict__ blurred, float4* __restrict__ rec,
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(256) void k_make_records(const float2* __restrict__
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 struct Texels { float4 r0, r1; };  // (x0,y0),(x0+1,y0) and (x0,y0+1),(x0+1,y0+1) as (Ix,Iy,Ix,Iy)
 struct Foot { int off; float xR, yR; };
+// getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464)
 __device__ __forceinline__ Foot footprint(int w, float x, float y, const SweepConst& c) {
   x = (0.0f < x) ? x : 0.0f;
   x = (x < c.wm2) ? x : c.wm2;
@@ -434,17 +444,9 @@ __device__ __forceinline__ Foot footprint(int w, float x, float y, const SweepCo
   f.yR = y - (float)y0;
   return f;
 }
-__device__ __forceinline__ Texels load_texels(const float2* __restrict__ G1, int w, int off) {
-  Texels t;
-  const f4a8 a = *reinterpret_cast<const f4a8*>(G1 + off);
-  const f4a8 b = *reinterpret_cast<const f4a8*>(G1 + off + w);
-  t.r0 = make_float4(a.x, a.y, a.z, a.w);
-  t.r1 = make_float4(b.x, b.y, b.z, b.w);
-  return t;
-}
+// errorFunction (PixFlow.h:493-534) on already-gathered texels
 __device__ __forceinline__ float error_from(const Texels& t, const Foot& ft, float g0x, float g0y, float bfx,
                                             float bfy, float fdx, float fdy, const SweepConst& c) {
-  // getPixBilinear32FExtend on I1x and I1y (f00 = r0.xy, f10 = r0.zw, f01 = r1.xy, f11 = r1.zw)
   float i1x, i1y;
   {
     const float a1 = t.r0.x, a2 = t.r0.z - t.r0.x, a3 = t.r1.x - t.r0.x, a4 = t.r0.x + t.r1.z - t.r0.z - t.r1.x;
@@ -460,129 +462,216 @@ __device__ __forceinline__ float error_from(const Texels& t, const Foot& ft, flo
   return sqrtf(ex * ex + ey * ey) + smoothness * c.smoothnessCoef + c.vertCoef * fabsf(fdy) / c.fcols +
          c.horizCoef * fabsf(fdx) / c.frows;
 }
-
-__device__ __forceinline__ float2 sweep_pixel(const float2* __restrict__ G1, int w, int x, int y, float4 rc, float2 f,
-                                              bool hasLeft, float2 left, bool hasUp, float2 up, const SweepConst& c) {
-  const float kEps = 0.001f;
-  const float fx = (float)x, fy = (float)y;
-  // the three candidate errors are independent of each other: gather all footprints first
-  const Foot f0 = footprint(w, fx + f.x, fy + f.y, c);
-  const Foot fL = footprint(w, fx + left.x, fy + left.y, c);
-  const Foot fU = footprint(w, fx + up.x, fy + up.y, c);
-  const Texels t0 = load_texels(G1, w, f0.off);
-  Texels tL = t0, tU = t0;
-  if (hasLeft && fL.off != f0.off) tL = load_texels(G1, w, fL.off);
-  if (hasUp && fU.off != f0.off) tU = (hasLeft && fU.off == fL.off) ? tL : load_texels(G1, w, fU.off);
-  float currErr = error_from(t0, f0, rc.x, rc.y, rc.z, rc.w, f.x, f.y, c);
-  Texels tc = t0;
-  int offc = f0.off;
-  if (hasLeft) {
-    const float e = error_from(tL, fL, rc.x, rc.y, rc.z, rc.w, left.x, left.y, c);
-    if (e < currErr) { f = left; currErr = e; tc = tL; offc = fL.off; }
-  }
-  if (hasUp) {
-    const float e = error_from(tU, fU, rc.x, rc.y, rc.z, rc.w, up.x, up.y, c);
-    if (e < currErr) { f = up; currErr = e; tc = tU; offc = fU.off; }
-  }
-  // errorGradient: the +eps probes almost always fall into the texel cell already held in registers
-  const Foot gx = footprint(w, fx + (f.x + kEps), fy + (f.y + 0.0f), c);
-  const Foot gy = footprint(w, fx + (f.x + 0.0f), fy + (f.y + kEps), c);
-  Texels tx = tc, ty = tc;
-  if (gx.off != offc) tx = load_texels(G1, w, gx.off);
-  if (gy.off != offc) ty = load_texels(G1, w, gy.off);
-  const float ex = error_from(tx, gx, rc.x, rc.y, rc.z, rc.w, f.x + kEps, f.y + 0.0f, c);
-  const float ey = error_from(ty, gy, rc.x, rc.y, rc.z, rc.w, f.x + 0.0f, f.y + kEps, c);
-  const float ggx = (ex - currErr) / kEps, ggy = (ey - currErr) / kEps;
-  f.x = f.x - c.gradStep * ggx;
-  f.y = f.y - c.gradStep * ggy;
-  return f;
+template <int K>
+__device__ __forceinline__ float row_get(float v) {  // value of lane K of this lane's 16-lane row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float from_row_above(float v) {  // lane 15 of the previous row (rows 1..3)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xE, 0xF, false));
 }
 
-__global__ __launch_bounds__(64) void k_sweep_band(const float4* __restrict__ rec, const float2* __restrict__ G,
+// LDS rings between the compute wave (wave 0) and the service wave (wave 1) of a band, indexed by step.
+// On gfx950 a wave's loads AND stores retire in order through one counter (vmcnt), so a compute wave that
+// also stored its results or polled granules would wait for L2/HBM round trips every step. The service wave
+// owns all of that traffic: it streams the per-pixel inputs in (16 steps x 4 rows per load instruction),
+// polls the up-row granules, writes results back and publishes the band's last row. The compute wave's
+// memory queue then only ever holds the bilinear gathers (L1 hits).
+constexpr int kRing = 64;  // steps (power of two)
+struct __attribute__((aligned(16))) InSlot {
+  float4 rec;
+  float2 flow;
+  float2 pad;
+};
+enum { C_IN = 0, C_UP = 1, C_DONE = 2, C_FLUSHED = 3, C_TICKET = 4, C_ABORT = 5 };
+
+__device__ __forceinline__ unsigned lds_acquire(unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_release(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(128) void k_sweep_hex(const float4* __restrict__ rec, const float2* __restrict__ G,
                                                    float2* __restrict__ flow, unsigned long long* __restrict__ H,
-                                                   int w, int h, size_t bs, FlowIdx idx, int dir, SweepConst c, int nb,
+                                                   unsigned* __restrict__ ticket, int w, int h, size_t bs, FlowIdx idx,
+                                                   int dir, SweepConst c, int nb, int B,
                                                    unsigned* __restrict__ errflag) {
-  const int band = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  __shared__ InSlot s_in[kRing][kBandRows];
+  __shared__ unsigned long long s_up[kRing];
+  __shared__ float2 s_out[kRing][kBandRows];
+  __shared__ unsigned s_ctr[8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) {
+    s_ctr[C_TICKET] = atomicAdd(ticket, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
+    s_ctr[C_IN] = 0; s_ctr[C_UP] = 0; s_ctr[C_DONE] = 0; s_ctr[C_FLUSHED] = 0; s_ctr[C_ABORT] = 0;
+  }
+  __syncthreads();
+  const unsigned t = s_ctr[C_TICKET];
+  const int band = (int)(t / (unsigned)B), b = (int)(t - (unsigned)band * (unsigned)B);
+  if (band >= nb) return;
   const float2* __restrict__ G1 = G + bs * idx.i1[b];
   rec += bs * b;
   flow += bs * b;
   H += (size_t)b * nb * w;
-  const int yi = band * kBandRows + lane;
-  const bool rowValid = yi < h;
-  const int yic = rowValid ? yi : h - 1;
-  const int y = dir > 0 ? yic : h - 1 - yic;
-  const int lastLane = min(kBandRows - 1, h - 1 - band * kBandRows);
-  const float4* __restrict__ recRow = rec + (size_t)y * w;
-  float2* __restrict__ flowRow = flow + (size_t)y * w;
   const unsigned long long* Hin = H + (size_t)band * w;
   unsigned long long* Hout = H + (size_t)(band + 1) * w;
-  const bool produce = (band + 1 < nb) && lane == lastLane;
-  float2 fl = make_float2(0.f, 0.f);  // final flow of the previous pixel of this row
-  unsigned long long hv = 0;          // lanes 0..kChunk-1: up-row flow granules of the current chunk
-  const int nsteps = w + lastLane;    // local steps 0 .. w-1+lastLane
-  float4 crec[kBlk], nrec[kBlk];
-  float2 cfl[kBlk], nfl[kBlk];
+  const int lastRow = min(kBandRows - 1, h - 1 - band * kBandRows);
+  const int nsteps = w + lastRow;
   auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) {
-    const int x = col(j - lane);
-    crec[j] = recRow[x];
-    cfl[j] = flowRow[x];
-  }
-  for (int s0 = 0; s0 < nsteps; s0 += kBlk) {
-    if (band > 0 && (s0 % kChunk) == 0) {
-      // poll the granules of columns s0 .. s0+kChunk-1 written by the band above
-      const int xi = s0 + lane;
-      const bool want = lane < kChunk && xi < w;
-      unsigned spins = 0;
-      for (;;) {
+
+  if (wave == 1) {
+    // ------------------------------ service wave ------------------------------
+    const int st = lane & 15, rr = lane >> 4;
+    const int yi = band * kBandRows + rr;
+    const bool rowValid = yi < h;
+    const int yic = rowValid ? yi : h - 1;
+    const int y = dir > 0 ? yic : h - 1 - yic;
+    const float4* __restrict__ recRow = rec + (size_t)y * w;
+    float2* __restrict__ flowRow = flow + (size_t)y * w;
+    const bool produceRow = (band + 1 < nb) && rr == lastRow;
+    int filled = 0, upFilled = 0, flushed = 0;
+    const int upNeed = band > 0 ? w : 0;
+    unsigned idle = 0;
+    while (flushed < nsteps) {
+      bool progress = false;
+      const int done = (int)lds_acquire(&s_ctr[C_DONE]);
+      while (flushed < done) {  // results of steps [flushed, done) -> global flow (+ granules of the last row)
+        const int n = min(16, done - flushed);
+        const int sidx = flushed + st;
+        const int xi = sidx - rr;
+        if (st < n && rowValid && xi >= 0 && xi < w) {
+          const float2 v = s_out[sidx & (kRing - 1)][rr];
+          flowRow[col(xi)] = v;
+          if (produceRow)
+            __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        flushed += n;
+        progress = true;
+      }
+      lds_release(&s_ctr[C_FLUSHED], (unsigned)flushed);
+      if (filled < nsteps && filled + 16 <= done + kRing) {  // inputs of steps [filled, filled+16)
+        const int sidx = filled + st;
+        const int x = col(sidx - rr);
+        InSlot v;
+        v.rec = recRow[x];
+        v.flow = flowRow[x];
+        v.pad = make_float2(0.f, 0.f);
+        s_in[sidx & (kRing - 1)][rr] = v;
+        filled += 16;
+        lds_release(&s_ctr[C_IN], (unsigned)filled);
+        progress = true;
+      }
+      if (upFilled < upNeed && upFilled + 16 <= done + kRing) {  // granules of columns [upFilled, upFilled+16)
+        const int xi = upFilled + lane;
+        const bool want = lane < 16 && xi < w;
         unsigned long long v = kHandoffEmpty;
         if (want) v = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = !want || v != kHandoffEmpty;
-        if (__all(ok)) { hv = v; break; }
-        __builtin_amdgcn_s_sleep(4);
-        ++spins;
-        if ((spins & 1023u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        if (spins > (1u << 22)) {  // ~seconds: the producer is gone; flag and bail out (results invalid)
+        const unsigned long long bad = __ballot(lane < 16 && (xi >= w || v == kHandoffEmpty));
+        const int nvalid = bad ? (int)__ffsll((long long)bad) - 1 : 16;  // leading run of written granules
+        if (nvalid > 0) {
+          if (lane < nvalid) s_up[xi & (kRing - 1)] = v;
+          upFilled += nvalid;
+          lds_release(&s_ctr[C_UP], (unsigned)upFilled);
+          progress = true;
+        }
+      }
+      if (progress) {
+        idle = 0;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        ++idle;
+        if ((idle & 1023u) == 0 &&
+            (__hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || lds_acquire(&s_ctr[C_ABORT]))) {
+          lds_release(&s_ctr[C_ABORT], 1u);
+          return;
+        }
+        if (idle > (1u << 22)) {  // seconds without progress: a neighbour band is gone (results invalid)
           if (lane == 0) atomicExch(errflag, 1u);
+          lds_release(&s_ctr[C_ABORT], 1u);
           return;
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) {  // next block of per-pixel inputs
-      const int x = col(s0 + kBlk + j - lane);
-      nrec[j] = recRow[x];
-      nfl[j] = flowRow[x];
+    return;
+  }
+
+  // ------------------------------ compute wave ------------------------------
+  const int r = lane >> 4, k = lane & 15;
+  const int yi = band * kBandRows + r;
+  const bool rowValid = yi < h;
+  const int yic = rowValid ? yi : h - 1;
+  const int y = dir > 0 ? yic : h - 1 - yic;
+  const bool hasUp = yi > 0;
+  const float kEps = 0.001f;
+  const bool evalLane = k < 9;
+  const int ci = k < 3 ? k : (k - 3) >> 1;  // which candidate: 0 current, 1 left, 2 up
+  const float ox = (k >= 3 && k < 9 && ((k - 3) & 1) == 0) ? kEps : 0.0f;
+  const float oy = (k >= 3 && k < 9 && ((k - 3) & 1) == 1) ? kEps : 0.0f;
+  const float fy = (float)y;
+  const float kInf = __int_as_float(0x7f800000);
+  float2 fl = make_float2(0.f, 0.f);  // final flow of the previous pixel of this row (same in all 16 lanes)
+  int inAvail = 0, upAvail = band > 0 ? 0 : 0x7fffffff, flushedSeen = 0;
+  auto wait_ctr = [&](unsigned* ctr, int need) -> int {  // spin (bounded) until *ctr >= need; returns value or -1
+    unsigned spins = 0;
+    for (;;) {
+      const int v = (int)lds_acquire(ctr);
+      if (v >= need) return v;
+      __builtin_amdgcn_s_sleep(0);
+      if ((++spins & 4095u) == 0 && lds_acquire(&s_ctr[C_ABORT])) return -1;
     }
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) {
-      const int s = s0 + j;
-      const int xi = s - lane;
-      const bool active = rowValid && xi >= 0 && xi < w;
-      // up neighbour: lane l-1's previous result; lane 0 takes the granule of column xi == s from the chunk
-      float2 up;
-      up.x = __shfl_up(fl.x, 1);
-      up.y = __shfl_up(fl.y, 1);
-      const int hs = s & (kChunk - 1);
-      const unsigned long long hg = __shfl(hv, hs);
-      if (lane == 0) { up.x = __uint_as_float((unsigned)hg); up.y = __uint_as_float((unsigned)(hg >> 32)); }
-      const int x = dir > 0 ? xi : w - 1 - xi;
-      float2 f = cfl[j];
-      if (active) {
-        const float4 rc = crec[j];
-        if (rc.x == rc.x) {  // not NaN: both alphas above the update threshold
-          f = sweep_pixel(G1, w, x, y, rc, f, xi > 0, fl, yi > 0, up, c);
-          flowRow[x] = f;
-        }
-        if (produce)
-          __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(f.y) << 32) | __float_as_uint(f.x),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fl = f;
-      }
+  };
+  for (int s = 0; s < nsteps; ++s) {
+    if (inAvail <= s) { inAvail = wait_ctr(&s_ctr[C_IN], s + 1); if (inAvail < 0) return; }
+    if (s < w && upAvail <= s) { upAvail = wait_ctr(&s_ctr[C_UP], s + 1); if (upAvail < 0) return; }
+    if (s - flushedSeen >= kRing - 2) { flushedSeen = wait_ctr(&s_ctr[C_FLUSHED], s - (kRing - 2) + 1); if (flushedSeen < 0) return; }
+    const int slot = s & (kRing - 1);
+    const InSlot in = s_in[slot][r];
+    const unsigned long long hg = s_up[slot];
+    const int xi = s - r;
+    const bool active = rowValid && xi >= 0 && xi < w;
+    // up neighbour: previous result of the row above; row 0 takes the granule of column xi == s
+    float2 up;
+    up.x = from_row_above(fl.x);
+    up.y = from_row_above(fl.y);
+    if (r == 0) { up.x = __uint_as_float((unsigned)hg); up.y = __uint_as_float((unsigned)(hg >> 32)); }
+    const float4 rc = in.rec;
+    const float2 fo = in.flow;
+    const int x = col(xi);
+    const bool upd = active && (rc.x == rc.x);
+    const float2 cand = ci == 0 ? fo : (ci == 1 ? fl : up);
+    const float ax = cand.x + ox, ay = cand.y + oy;
+    float e = kInf;
+    if (evalLane && upd) {
+      const Foot ft = footprint(w, (float)x + ax, fy + ay, c);
+      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1 + ft.off);
+      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1 + ft.off + w);
+      Texels tt;
+      tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+      tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+      e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
     }
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) { crec[j] = nrec[j]; cfl[j] = nfl[j]; }
+    const float e0 = row_get<0>(e);
+    float e1 = row_get<1>(e), e2 = row_get<2>(e);
+    const float e3 = row_get<3>(e), e4 = row_get<4>(e), e5 = row_get<5>(e), e6 = row_get<6>(e), e7 = row_get<7>(e),
+                e8 = row_get<8>(e);
+    if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column (PixFlow.h:392 / :405)
+    if (!hasUp) e2 = kInf;     // no up proposal in the first row (:393 / :406)
+    // proposeFlowUpdate x2 in the reference's order, then the gradient step on the winner
+    float2 f = fo;
+    float cur = e0, ex = e3, ey = e4;
+    if (e1 < cur) { f = fl; cur = e1; ex = e5; ey = e6; }
+    if (e2 < cur) { f = up; cur = e2; ex = e7; ey = e8; }
+    const float ggx = (ex - cur) / kEps, ggy = (ey - cur) / kEps;
+    float2 res;
+    res.x = f.x - c.gradStep * ggx;
+    res.y = f.y - c.gradStep * ggy;
+    if (active) {
+      if (!upd) res = fo;
+      if (k == 0) s_out[slot][r] = res;
+      fl = res;
+    }
+    if (lane == 0) lds_release(&s_ctr[C_DONE], (unsigned)(s + 1));
   }
 }
 
@@ -758,7 +847,10 @@ void launch_make_records(hipStream_t st, const float2* G, const float* A, const 
                      idx);
 }
 int sweep_num_bands(int h) { return (h + kBandRows - 1) / kBandRows; }
-void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, unsigned long long* H,
+size_t sweep_handoff_bytes(int w, int h, int B) {
+  return 256 + (size_t)B * sweep_num_bands(h) * w * sizeof(unsigned long long);
+}
+void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc) {
   SweepConst c;
@@ -771,9 +863,12 @@ void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float
   c.wm2 = (float)w - 2.0f;
   c.hm2 = (float)h - 2.0f;
   const int nb = sweep_num_bands(h);
-  // granules start as "empty" (all ones) for every band boundary of every flow
-  hipMemsetAsync(H, 0xFF, (size_t)B * nb * w * sizeof(unsigned long long), st);
-  hipLaunchKernelGGL(k_sweep_band, dim3(nb, B), dim3(64), 0, st, rec, G, flow, H, w, h, bs, idx, dir, c, nb, errflag);
+  // ticket counter (first 256 bytes) and every granule start as all-ones
+  hipMemsetAsync(handoff, 0xFF, sweep_handoff_bytes(w, h, B), st);
+  unsigned* ticket = reinterpret_cast<unsigned*>(handoff);
+  unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
+  hipLaunchKernelGGL(k_sweep_hex, dim3(nb * B), dim3(128), 0, st, rec, G, flow, H, ticket, w, h, bs, idx, dir, c, nb, B,
+                     errflag);
 }
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq) {

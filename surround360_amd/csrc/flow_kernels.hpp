@@ -43,11 +43,12 @@ void launch_sobel(hipStream_t st, const float* I, int w, int h, size_t bs, float
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
 void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow, int w, int h,
                   size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc);
-// v2 banded sweep (see flow_kernels.hip): records = {I0x|NaN mask, I0y, blurred.x, blurred.y}
+// banded "hex16" sweep (see flow_kernels.hip): records = {I0x|NaN mask, I0y, blurred.x, blurred.y}
 void launch_make_records(hipStream_t st, const float2* G, const float* A, const float2* blurred, float4* rec, size_t n,
                          int B, const FlowIdx& idx);
 int sweep_num_bands(int h);
-void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, unsigned long long* H,
+size_t sweep_handoff_bytes(int w, int h, int B);
+void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
