@@ -2,6 +2,7 @@
 // launch sequence on one stream. See flow.hpp.
 #include "flow.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -82,12 +83,14 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   blurred_.ensure(B * n0 * sizeof(float2));
   full_.ensure((size_t)B * w * h * sizeof(float2));
   if (sweep_mode_ < 0) {
-    const char* e = std::getenv("S360_SWEEP");  // debugging/A-B knob: "diag" selects the v1 kernel
-    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : 1;
+    const char* e = std::getenv("S360_SWEEP");  // debugging/A-B knob: "diag" = v1 kernel, "hex" = v2 hex16 kernel
+    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : 2;
+    const char* n = std::getenv("S360_SWEEP_NW");
+    sweep_nw_ = (n && std::atoi(n) == 8) ? 8 : 4;
   }
-  if (sweep_mode_ == 1) {
+  if (sweep_mode_ >= 1) {
     rec_.ensure(B * n0 * sizeof(float4));
-    handoff_.ensure(sweep_handoff_bytes(dw_, dh_, B));
+    handoff_.ensure(std::max(sweep_handoff_bytes(dw_, dh_, B), sweep_lock_handoff_bytes(dw_, dh_, B, 4)));
     if (!err_.p) {
       err_.ensure(sizeof(unsigned));
       S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
@@ -167,13 +170,16 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       ProfScope ps(P, "flow_blur15");
       launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
     }
-    if (sweep_mode_ == 1) {
+    if (sweep_mode_ >= 1) {
       ProfScope ps(P, "flow_records");
       launch_make_records(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), rec_.as<float4>(), nl, B, idx);
     }
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
-      if (sweep_mode_ == 1)
+      if (sweep_mode_ == 2)
+        launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
+                          idx, dir, pc, sweep_nw_);
+      else if (sweep_mode_ == 1)
         launch_sweep_band(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
                           idx, dir, pc);
       else

@@ -47,7 +47,8 @@ class FlowEngine {
   int dw_ = 0, dh_ = 0;
   DevBuf down_, prevdown_, gray_, pyrI_, pyrA_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
       motionPyr_, I1eq_, rec_, handoff_, err_;
-  int sweep_mode_ = -1;  // 0: v1 one-workgroup diagonal kernel, 1: v2 banded multi-workgroup kernel (default)
+  int sweep_mode_ = -1;  // 0: v1 one-workgroup diagonal kernel, 1: v2 hex16 banded kernel, 2: lockstep kernel (default)
+  int sweep_nw_ = 4;     // compute waves per workgroup of the lockstep kernel
 
  public:
   // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag

@@ -13,6 +13,7 @@
 #include <stdexcept>
 
 #include "devmath.hpp"
+#include "sweep_common.hpp"
 
 namespace s360 {
 
@@ -300,12 +301,6 @@ __global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // The propagation sweeps (PixFlow.h:388-410). errorFunction (PixFlow.h:493-534, no directional
 // term), getPixBilinear32FExtend (:457-475), proposeFlowUpdate (:415-435), errorGradient (:195-217).
-struct SweepConst {
-  float smoothnessCoef, vertCoef, horizCoef, gradStep;
-  float fcols, frows;  // float(I0.cols), float(I0.rows)
-  float wm2, hm2;      // w - 2.0f, h - 2.0f
-};
-
 __device__ __forceinline__ float2 bilinear_g1(const float2* __restrict__ G1, int w, float x, float y,
                                               const SweepConst& c) {
   x = (0.0f < x) ? x : 0.0f;
@@ -428,40 +423,6 @@ __global__ __launch_bounds__(256) void k_make_records(const float2* __restrict__
   rec[bs * b + i] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, bf.x, bf.y);
 }
 
-typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
-struct Texels { float4 r0, r1; };  // (x0,y0),(x0+1,y0) and (x0,y0+1),(x0+1,y0+1) as (Ix,Iy,Ix,Iy)
-struct Foot { int off; float xR, yR; };
-// getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464)
-__device__ __forceinline__ Foot footprint(int w, float x, float y, const SweepConst& c) {
-  x = (0.0f < x) ? x : 0.0f;
-  x = (x < c.wm2) ? x : c.wm2;
-  y = (0.0f < y) ? y : 0.0f;
-  y = (y < c.hm2) ? y : c.hm2;
-  const int x0 = (int)x, y0 = (int)y;
-  Foot f;
-  f.off = y0 * w + x0;
-  f.xR = x - (float)x0;
-  f.yR = y - (float)y0;
-  return f;
-}
-// errorFunction (PixFlow.h:493-534) on already-gathered texels
-__device__ __forceinline__ float error_from(const Texels& t, const Foot& ft, float g0x, float g0y, float bfx,
-                                            float bfy, float fdx, float fdy, const SweepConst& c) {
-  float i1x, i1y;
-  {
-    const float a1 = t.r0.x, a2 = t.r0.z - t.r0.x, a3 = t.r1.x - t.r0.x, a4 = t.r0.x + t.r1.z - t.r0.z - t.r1.x;
-    i1x = a1 + a2 * ft.xR + a3 * ft.yR + a4 * ft.xR * ft.yR;
-  }
-  {
-    const float a1 = t.r0.y, a2 = t.r0.w - t.r0.y, a3 = t.r1.y - t.r0.y, a4 = t.r0.y + t.r1.w - t.r0.w - t.r1.y;
-    i1y = a1 + a2 * ft.xR + a3 * ft.yR + a4 * ft.xR * ft.yR;
-  }
-  const float dfx = bfx - fdx, dfy = bfy - fdy;
-  const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
-  const float ex = g0x - i1x, ey = g0y - i1y;
-  return sqrtf(ex * ex + ey * ey) + smoothness * c.smoothnessCoef + c.vertCoef * fabsf(fdy) / c.fcols +
-         c.horizCoef * fabsf(fdx) / c.frows;
-}
 template <int K>
 __device__ __forceinline__ float row_get(float v) {  // value of lane K of this lane's 16-lane row
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xF, 0xF, false));

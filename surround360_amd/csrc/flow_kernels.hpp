@@ -51,6 +51,12 @@ size_t sweep_handoff_bytes(int w, int h, int B);
 void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc);
+// lockstep banded sweep (sweep_lock.hip): nw compute waves (4 rows each) + 2 service waves per workgroup
+int sweep_lock_num_wgs(int h, int nw);
+size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw);
+void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
+                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
+                       const PixFlowConsts& pc, int nw);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

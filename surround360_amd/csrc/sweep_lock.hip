@@ -1,0 +1,372 @@
+// sweep_lock.hip — the production PixFlow propagation sweep for gfx950: "lockstep" banded wavefront.
+//
+// Reference: PixFlow.h:388-410 (the forward / backward raster sweeps of patchMatchPropagationAndSearch), with
+// errorFunction (:493-534), proposeFlowUpdate (:415-435) and errorGradient (:195-217). The raster order is a
+// Gauss-Seidel recurrence — pixel (x,y) reads the already-updated flow at (x-1,y) and (x,y-1) — so the only
+// parallel order that reproduces it bit-for-bit is an anti-diagonal wavefront. The kernel is bound by the
+// LATENCY of one pixel update (its dependent instruction chain), not by HBM or ALU throughput; everything here
+// is arranged to keep that chain short.
+//
+// Geometry. A workgroup owns R = 4*NW consecutive rows of one flow: NW compute waves x 4 rows, 16 lanes per
+// pixel. Row r of wave j handles column s - r at the wave's local step s; wave j runs kLag steps behind wave
+// j-1. The whole workgroup advances one step per s_barrier ("lockstep"), so every intra-workgroup dependency
+// is either a register/DPP hand-off (left neighbour = the row's own previous result; up neighbour = the row
+// above's previous result, DPP row_bcast:15) or an LDS slot written at least two barriers earlier — no
+// counters, no polling between compute waves. Workgroups of one flow are chained through 8-byte {fx,fy}
+// granules in global memory (one per column of the band's last row; all-ones = "not written yet": the data is
+// the flag, MI355X_MICROARCH.md hand-off price list). Bands take (band, flow) from a ticket counter in
+// band-major order, so a band's predecessor has always started: no co-residency assumption, every spin bounded.
+//
+// Speculation. A pixel update needs 5 errorFunction evaluations in two dependent rounds (current / left / up
+// proposals, then the two finite-difference probes of the winner). The 16 lanes of a pixel evaluate all 9
+// possible ones at once (bank 0: current flow, bank 1: left, bank 2: up; lane 0/1/2 of a bank: f, f+(eps,0),
+// f+(0,eps)), exchange the 9 scalars with DPP row broadcasts and replay the reference's sequential selection.
+// One step is therefore ONE gather round + ONE evaluation deep.
+//
+// Service waves. On gfx950 a wave's loads and stores retire in order through one counter (vmcnt), so a compute
+// wave that also streamed its inputs/outputs would wait for HBM round trips every step. Two extra waves per
+// workgroup own that traffic: wave NW ("bulk") streams the per-pixel records {I0x|NaN mask, I0y, blurredFlow}
+// and the current flow into an LDS ring 16-32 steps ahead, writes results back, and touches the I1-gradient
+// lines the coming pixels will sample so that the compute waves' bilinear gathers hit L1; wave NW+1 ("hand-off")
+// polls the granules of the band above and publishes the band's last row. The compute waves' memory queue
+// only ever holds their own gathers.
+#include "devmath.hpp"
+#include "sweep_common.hpp"
+
+namespace s360 {
+
+namespace {
+
+constexpr unsigned long long kEmptyGranule = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kLag = 5;     // steps between consecutive compute waves of a workgroup (>= 5: see preload below)
+constexpr int kRingK = 32;  // LDS ring depth in steps (two chunks)
+constexpr int kChunk = 16;  // steps per bulk-service transfer (16 steps x 4 rows = 64 lanes)
+
+struct __attribute__((aligned(16))) LkIn {
+  float4 rec;   // {I0x (NaN: pixel not updated), I0y, blurredFlow.x, blurredFlow.y}
+  float2 flow;  // the flow before this sweep touches the pixel
+  float2 pad;
+};
+
+typedef float f4n __attribute__((ext_vector_type(4)));
+typedef float f2n __attribute__((ext_vector_type(2)));
+
+// One barrier per step. Hand-written so that no vmcnt wait is attached (the service waves keep loads in flight
+// across steps; __syncthreads()/the s_barrier builtin would drain them on gfx9-class targets).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {  // value of lane K of this lane's 16-lane row
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x150 + K, 0xF, 0xF, true));
+}
+// lane 15 of the previous 16-lane row, written only to rows 1..3 and only to the banks in BANKS; others keep old
+template <int BANKS>
+__device__ __forceinline__ float from_row_above(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                              0x142, 0xE, BANKS, false));
+}
+
+}  // namespace
+
+template <int NW>
+__global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __restrict__ rec,
+                                                              const float2* __restrict__ G, float2* __restrict__ flow,
+                                                              unsigned long long* __restrict__ H,
+                                                              unsigned* __restrict__ hdr, int w, int h, size_t bs,
+                                                              FlowIdx idx, int dir, SweepConst c, int nwg, int B,
+                                                              unsigned* __restrict__ errflag) {
+  constexpr int R = NW * 4;
+  __shared__ LkIn s_in[NW][kRingK][4];
+  __shared__ float2 s_out[NW][kRingK][4];
+  __shared__ float2 s_up0[kRingK];
+  __shared__ unsigned s_ticket;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(hdr, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
+  __syncthreads();
+  const unsigned tk = s_ticket;
+  const int wgband = (int)(tk / (unsigned)B), b = (int)(tk - (unsigned)wgband * (unsigned)B);
+  if (wgband >= nwg) return;
+  const float2* __restrict__ G1 = G + bs * idx.i1[b];
+  rec += bs * b;
+  flow += bs * b;
+  H += (size_t)b * nwg * w;
+  const int rows0 = wgband * R;
+  const int nsteps = w + 3;                // local steps of one compute wave (row skew 0..3)
+  const int T = nsteps + kLag * (NW - 1);  // global steps of the workgroup
+  auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
+
+  if (wave < NW) {
+    // ------------------------------------ compute waves ------------------------------------
+    const int j = wave;
+    const int rr = lane >> 4, k = lane & 15, bank = k >> 2, role = k & 3;
+    const int yi = rows0 + j * 4 + rr;
+    const bool rowValid = yi < h;
+    const int yic = rowValid ? yi : h - 1;
+    const int y = dir > 0 ? yic : h - 1 - yic;
+    const bool hasUp = yi > 0;
+    const float kEps = 0.001f;
+    const float ox = role == 1 ? kEps : 0.0f, oy = role == 2 ? kEps : 0.0f;
+    const float fy = (float)y;
+    const bool fromLds = bank == 0 || (bank == 2 && rr == 0);  // candidate is the old flow / the granule-fed up value
+    const float kInf = __int_as_float(0x7f800000);
+    float2 fl = make_float2(0.f, 0.f);  // final flow of the previous pixel of this row (same in all 16 lanes)
+    LkIn nin;
+    nin.rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    nin.flow = make_float2(0.f, 0.f);
+    float2 nup = make_float2(0.f, 0.f);
+    for (int t = -1; t < T; ++t) {
+      wg_barrier();
+      const int s = t - kLag * j;
+      const LkIn in = nin;
+      const float2 upl = nup;
+      // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
+      // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written two barriers ago.
+      const int s1 = s + 1;
+      if (s1 >= 0 && s1 < nsteps) {
+        nin = s_in[j][s1 & (kRingK - 1)][rr];
+        nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
+      }
+      if (s < 0 || s >= nsteps) continue;
+      const int xi = s - rr;
+      const bool active = rowValid && xi >= 0 && xi < w;
+      const int x = col(xi);
+      const float4 rc = in.rec;
+      const float2 fo = in.flow;
+      const bool upd = active && (rc.x == rc.x);
+      // up neighbour in every lane (needed by the selection below)
+      float2 up;
+      up.x = from_row_above<0xF>(upl.x, fl.x);
+      up.y = from_row_above<0xF>(upl.y, fl.y);
+      // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
+      float2 cand;
+      cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
+      cand.y = fromLds ? (bank == 0 ? fo.y : upl.y) : fl.y;
+      cand.x = from_row_above<0x4>(cand.x, fl.x);
+      cand.y = from_row_above<0x4>(cand.y, fl.y);
+      const float ax = cand.x + ox, ay = cand.y + oy;
+      // every lane evaluates (idle lanes and masked pixels produce values nobody reads; addresses are clamped)
+      const Foot ft = footprint(w, (float)x + ax, fy + ay, c);
+      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1 + ft.off);
+      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1 + ft.off + w);
+      Texels tt;
+      tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+      tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+      const float e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+      const float e0 = row_bcast<0>(e), e0x = row_bcast<1>(e), e0y = row_bcast<2>(e);
+      float e1 = row_bcast<4>(e);
+      const float e1x = row_bcast<5>(e), e1y = row_bcast<6>(e);
+      float e2 = row_bcast<8>(e);
+      const float e2x = row_bcast<9>(e), e2y = row_bcast<10>(e);
+      if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column (PixFlow.h:392 / :405)
+      if (!hasUp) e2 = kInf;     // no up proposal in the first row (:393 / :406)
+      // proposeFlowUpdate x2 in the reference's order, then the gradient step on the winner
+      float2 f = fo;
+      float cur = e0, ex = e0x, ey = e0y;
+      if (e1 < cur) { f = fl; cur = e1; ex = e1x; ey = e1y; }
+      if (e2 < cur) { f = up; cur = e2; ex = e2x; ey = e2y; }
+      const float ggx = (ex - cur) / kEps, ggy = (ey - cur) / kEps;
+      float2 res;
+      res.x = f.x - c.gradStep * ggx;
+      res.y = f.y - c.gradStep * ggy;
+      if (active) {
+        if (!upd) res = fo;
+        if (k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
+        fl = res;
+      }
+    }
+    wg_barrier();
+    return;
+  }
+
+  if (wave == NW) {
+    // ------------------------------------ bulk service wave ------------------------------------
+    const int st = lane & 15, rr = lane >> 4;
+    const f4n* __restrict__ recN = reinterpret_cast<const f4n*>(rec);
+    const f2n* __restrict__ flowN = reinterpret_cast<const f2n*>(flow);
+    const unsigned* __restrict__ G1w = reinterpret_cast<const unsigned*>(G1);
+    int rowOff[NW];
+    bool rowOk[NW];
+    float rowY[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int yi = rows0 + j * 4 + rr;
+      rowOk[j] = yi < h;
+      const int yic = rowOk[j] ? yi : h - 1;
+      const int y = dir > 0 ? yic : h - 1 - yic;
+      rowOff[j] = y * w;
+      rowY[j] = (float)y;
+    }
+    f4n rRec[NW];
+    f2n rFlow[NW];
+    unsigned sink = 0, pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+    const int nchunks = (nsteps + kChunk - 1) / kChunk;
+    auto load_chunk = [&](int j, int cidx) {
+      const int x = col(cidx * kChunk + st - rr);
+      rRec[j] = __builtin_nontemporal_load(recN + rowOff[j] + x);
+      rFlow[j] = __builtin_nontemporal_load(flowN + rowOff[j] + x);
+    };
+    auto write_chunk = [&](int j, int cidx) {
+      LkIn v;
+      v.rec = make_float4(rRec[j].x, rRec[j].y, rRec[j].z, rRec[j].w);
+      v.flow = make_float2(rFlow[j].x, rFlow[j].y);
+      v.pad = make_float2(0.f, 0.f);
+      s_in[j][(cidx * kChunk + st) & (kRingK - 1)][rr] = v;
+    };
+    // Touch the I1-gradient lines around where the coming pixels will sample (predicted by the blurred flow
+    // and by the current flow) so that they are L1-resident when the compute waves gather them.
+    auto prefetch_chunk = [&](int j, int cidx) {
+      sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // consume the previous round (long since landed)
+      const float xf = (float)col(cidx * kChunk + st - rr);
+      const Foot fa = footprint(w, xf + rRec[j].z, rowY[j] + rRec[j].w, c);
+      const Foot fb = footprint(w, xf + rFlow[j].x, rowY[j] + rFlow[j].y, c);
+      pf0 = G1w[2 * fa.off];
+      pf1 = G1w[2 * (fa.off + w)];
+      pf2 = G1w[2 * fb.off];
+      pf3 = G1w[2 * (fb.off + w)];
+    };
+    auto flush_chunk = [&](int j, int cidx) {
+      const int sidx = cidx * kChunk + st;
+      const int xi = sidx - rr;
+      if (rowOk[j] && xi >= 0 && xi < w && sidx < nsteps) flow[rowOff[j] + col(xi)] = s_out[j][sidx & (kRingK - 1)][rr];
+    };
+    // prologue: chunk 0 into LDS, chunk 1 into registers
+#pragma unroll
+    for (int j = 0; j < NW; ++j) load_chunk(j, 0);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      write_chunk(j, 0);
+      prefetch_chunk(j, 0);
+      if (nchunks > 1) load_chunk(j, 1);
+    }
+    for (int t = -1; t < T; ++t) {
+      wg_barrier();
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int s = t - kLag * j;
+        if (s >= 1 && (s & (kChunk - 1)) == 1) {
+          const int cc = s >> 4;  // wave j is inside chunk cc; chunk cc-1 is complete, its slots are free
+          if (cc + 1 < nchunks) {
+            write_chunk(j, cc + 1);
+            prefetch_chunk(j, cc + 1);
+          }
+          if (cc + 2 < nchunks) load_chunk(j, cc + 2);
+          if (cc >= 1) flush_chunk(j, cc - 1);
+        }
+      }
+    }
+    wg_barrier();
+    // epilogue: the chunks the loop did not reach
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int sl = T - 1 - kLag * j;
+      const int done = sl >= 1 ? ((sl - 1) >> 4) : 0;  // chunks [0, done) were flushed in the loop
+      for (int cidx = done; cidx < nchunks; ++cidx) flush_chunk(j, cidx);
+    }
+    sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;
+    if (sink == 0x9e3779b9u && lane == 0) hdr[1] = sink;  // keeps the prefetch loads alive; never true in practice
+    return;
+  }
+
+  // ------------------------------------ hand-off service wave ------------------------------------
+  {
+    const bool hasUpWg = wgband > 0;
+    const bool publishes = wgband + 1 < nwg;
+    const unsigned long long* Hin = H + (size_t)wgband * w;
+    unsigned long long* Hout = H + (size_t)(wgband + 1) * w;
+    constexpr int jl = NW - 1;
+    int upFilled = hasUpWg ? 0 : 0x3fffffff, pub = 0;
+    bool pending = false, dead = false;
+    int pendT = 0;
+    unsigned long long pv = kEmptyGranule;
+    auto issue = [&](int t) {
+      const int xi = upFilled + lane;
+      pv = kEmptyGranule;
+      if (lane < 16 && xi < w) pv = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending = true;
+      pendT = t;
+    };
+    auto process = [&](int t) {  // leading run of written granules -> s_up0 (bounded by the ring)
+      const int xi = upFilled + lane;
+      const unsigned long long bad = __ballot(lane < 16 && (xi >= w || (pv == kEmptyGranule && !dead)));
+      int n = bad ? (int)__ffsll((long long)bad) - 1 : 16;
+      n = min(n, t + 31 - upFilled);
+      if (n > 0) {
+        if (lane < n) s_up0[xi & (kRingK - 1)] = make_float2(__uint_as_float((unsigned)pv), __uint_as_float((unsigned)(pv >> 32)));
+        upFilled += n;
+      }
+      pending = false;
+    };
+    auto ensure = [&](int t, int need) {  // block (bounded) until columns [0, need) are in LDS
+      unsigned spins = 0;
+      while (upFilled < need) {
+        if (!pending) issue(t);
+        process(t);
+        if (upFilled < need) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 21) || ((spins & 1023u) == 0 &&
+                                       __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            // the band above is gone: give up waiting, flag the result invalid, keep the pipeline draining
+            dead = true;
+            if (lane == 0) atomicExch(errflag, 1u);
+          }
+        }
+      }
+    };
+    auto publish = [&](int xdone, bool force) {
+      const int xd = min(xdone, w - 1);
+      const int avail = xd - pub + 1;
+      if (avail >= 4 || (force && avail > 0)) {
+        const int n = min(16, avail);
+        if (lane < n) {
+          const int xi = pub + lane;
+          const float2 v = s_out[jl][(xi + 3) & (kRingK - 1)][3];
+          __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pub += n;
+      }
+    };
+    if (hasUpWg) ensure(-2, min(w, 1));
+    for (int t = -1; t < T; ++t) {
+      wg_barrier();
+      if (hasUpWg && upFilled < w) {
+        const int need = min(w, t + 3);
+        if (pending && (t - pendT >= 2 || upFilled < need)) process(t);
+        if (!pending && upFilled < min(w, t + 24)) issue(t);
+        if (upFilled < need) ensure(t, need);
+      }
+      // columns of the band's last row that are complete and visible: wave jl finished local step t-1-kLag*jl
+      if (publishes) publish(t - 1 - kLag * jl - 3, false);
+    }
+    wg_barrier();
+    if (publishes)
+      while (pub < w) publish(w - 1, true);
+  }
+}
+
+// ==========================================================================================
+int sweep_lock_rows_per_wg(int nw) { return 4 * nw; }
+int sweep_lock_num_wgs(int h, int nw) { return (h + 4 * nw - 1) / (4 * nw); }
+size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw) {
+  return 256 + (size_t)B * sweep_lock_num_wgs(h, nw) * w * sizeof(unsigned long long);
+}
+void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
+                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
+                       const PixFlowConsts& pc, int nw) {
+  const SweepConst c = make_sweep_const(pc, w, h);
+  const int nwg = sweep_lock_num_wgs(h, nw);
+  // ticket counter (first 256 bytes) and every granule start as all-ones
+  (void)hipMemsetAsync(handoff, 0xFF, sweep_lock_handoff_bytes(w, h, B, nw), st);
+  unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
+  unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
+  if (nw == 4)
+    hipLaunchKernelGGL((k_sweep_lock<4>), dim3(nwg * B), dim3(6 * 64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+                       nwg, B, errflag);
+  else
+    hipLaunchKernelGGL((k_sweep_lock<8>), dim3(nwg * B), dim3(10 * 64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir,
+                       c, nwg, B, errflag);
+}
+
+}  // namespace s360
