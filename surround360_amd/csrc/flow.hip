@@ -87,6 +87,18 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : 2;
     const char* n = std::getenv("S360_SWEEP_NW");
     sweep_nw_ = (n && std::atoi(n) == 8) ? 8 : 4;
+    const char* d = std::getenv("S360_SWEEP_DIV");  // "ieee" disables the verified fast division / sqrt
+    sweep_fast_ = !(d && std::string(d) == "ieee");
+  }
+  bool fastOk = false;
+  if (sweep_mode_ == 2 && sweep_fast_) {
+    std::vector<float> divs;
+    divs.push_back(0.001f);
+    for (int l = 0; l < L; ++l) {
+      divs.push_back((float)lv_.w[l]);
+      divs.push_back((float)lv_.h[l]);
+    }
+    fastOk = sweep_verify_divisors(st, divs);
   }
   if (sweep_mode_ >= 1) {
     rec_.ensure(B * n0 * sizeof(float4));
@@ -178,7 +190,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       ProfScope ps(P, "flow_sweep");
       if (sweep_mode_ == 2)
         launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
-                          idx, dir, pc, sweep_nw_);
+                          idx, dir, pc, sweep_nw_, fastOk);
       else if (sweep_mode_ == 1)
         launch_sweep_band(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
                           idx, dir, pc);

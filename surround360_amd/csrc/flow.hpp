@@ -49,6 +49,7 @@ class FlowEngine {
       motionPyr_, I1eq_, rec_, handoff_, err_;
   int sweep_mode_ = -1;  // 0: v1 one-workgroup diagonal kernel, 1: v2 hex16 banded kernel, 2: lockstep kernel (default)
   int sweep_nw_ = 4;     // compute waves per workgroup of the lockstep kernel
+  bool sweep_fast_ = true;
 
  public:
   // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <vector>
+
 namespace s360 {
 
 struct BlurTaps {  // centre tap k[0] and the r symmetric taps k[1..r]
@@ -56,7 +58,9 @@ int sweep_lock_num_wgs(int h, int nw);
 size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw);
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, int nw);
+                       const PixFlowConsts& pc, int nw, bool fast);
+// true when the kernel's fast exact division may be used for all of these divisors (checked on the device, cached)
+bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& divisors);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

@@ -30,12 +30,31 @@
 // lines the coming pixels will sample so that the compute waves' bilinear gathers hit L1; wave NW+1 ("hand-off")
 // polls the granules of the band above and publishes the band's last row. The compute waves' memory queue
 // only ever holds their own gathers.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "devmath.hpp"
 #include "sweep_common.hpp"
 
 namespace s360 {
 
 namespace {
+
+#ifdef S360_SWEEP_TIMING  // tools/sweep_microbench only: per-phase cycle counts of compute wave 0 of ticket 0 -> hdr[8..]
+#define TS_DECL unsigned long long ts_last = __builtin_amdgcn_s_memtime(), ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts_acc[i] += t_ - ts_last; ts_last = t_; } while (0)
+#define TS_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define TS_DUMP() do { if (tk == 0 && j == 0 && lane == 0) for (int q = 0; q < 8; ++q) ((unsigned long long*)(hdr + 8))[q] = ts_acc[q]; } while (0)
+#else
+#define TS_DECL
+#define TS(i)
+#define TS_WAITV()
+#define TS_DUMP()
+#endif
 
 constexpr unsigned long long kEmptyGranule = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kLag = 5;     // steps between consecutive compute waves of a workgroup (>= 5: see preload below)
@@ -67,15 +86,77 @@ __device__ __forceinline__ float from_row_above(float old, float v) {
                                                               0x142, 0xE, BANKS, false));
 }
 
+// Correctly rounded x / c for a divisor known in advance (Markstein's sequence): q = RN(x*rc), r = x - q*c (exact
+// in one FMA), q' = RN(q + r*rc), with rc = RN(1/c). For the (c, rc) pairs this kernel is launched with, the
+// result has been checked on the device against the IEEE division for every float significand
+// (k_verify_div below); that covers every x whose intermediates stay normal, i.e. x == 0 or |x| >= 2^-96 —
+// smaller non-zero numerators take the IEEE path (see `tiny`).
+__device__ __forceinline__ float fdiv_m(float x, float c, float rc) {
+  const float q = x * rc;
+  const float r = __builtin_fmaf(-q, c, x);
+  return __builtin_fmaf(r, rc, q);
+}
+// Correctly rounded sqrtf for x == 0 or x >= 2^-96: v_sqrt_f32 (1 ulp) + the two-sided residual fix-up that the
+// compiler's own IEEE expansion uses, without its denormal pre-scaling.
+__device__ __forceinline__ float sqrt_cr(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  s = (rm <= 0.0f) ? sm : s;
+  s = (rp > 0.0f) ? sp : s;
+  return s;
+}
+// key for the "tiny non-zero" test of a non-negative float: bits - 1 (0 wraps to 0xFFFFFFFF, NaN/inf are large)
+__device__ __forceinline__ unsigned tiny_key(float v) { return __float_as_uint(v) - 1u; }
+constexpr unsigned kTinyBits = 0x0F800000u;  // 2^-96
+
+struct SweepFast {  // reciprocals of the three divisors of the sweep, verified on the device
+  float rcCols, rcRows, rcEps;
+  int dbg;  // timing experiments only (results invalid when non-zero): 1 no granule polls, 2 no publish, 4 no prefetch,
+            // 8 no bulk events, 16 no compute body
+};
+
+// errorFunction (PixFlow.h:493-534) with the verified fast divisions / square roots. Sets tinyFlag when an
+// operand falls outside their proven range (the caller then re-evaluates with the IEEE expansion).
+__device__ __forceinline__ float error_fast(const Texels& t, float xR, float yR, float g0x, float g0y, float bfx,
+                                            float bfy, float fdx, float fdy, const SweepConst& c, const SweepFast& fc,
+                                            bool& tinyFlag) {
+  float i1x, i1y;
+  {
+    const float a1 = t.r0.x, a2 = t.r0.z - t.r0.x, a3 = t.r1.x - t.r0.x, a4 = t.r0.x + t.r1.z - t.r0.z - t.r1.x;
+    i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  {
+    const float a1 = t.r0.y, a2 = t.r0.w - t.r0.y, a3 = t.r1.y - t.r0.y, a4 = t.r0.y + t.r1.w - t.r0.w - t.r1.y;
+    i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  const float dfx = bfx - fdx, dfy = bfy - fdy;
+  const float sm2 = dfx * dfx + dfy * dfy;
+  const float smoothness = sqrt_cr(sm2);
+  const float ex = g0x - i1x, ey = g0y - i1y;
+  const float d2 = ex * ex + ey * ey;
+  const float vn = c.vertCoef * fabsf(fdy), hn = c.horizCoef * fabsf(fdx);
+  const unsigned key = min(min(tiny_key(sm2), tiny_key(d2)), min(tiny_key(vn), tiny_key(hn)));
+  tinyFlag = key < kTinyBits - 1u;
+  return sqrt_cr(d2) + smoothness * c.smoothnessCoef + fdiv_m(vn, c.fcols, fc.rcCols) + fdiv_m(hn, c.frows, fc.rcRows);
+}
+
 }  // namespace
 
-template <int NW>
+__global__ __launch_bounds__(256) void k_verify_div(const float* __restrict__ cs, unsigned* __restrict__ bad) {
+  const float cc = cs[blockIdx.y];
+  const float rc = 1.0f / cc;
+  const float x = __uint_as_float(0x3f800000u | (blockIdx.x * 256u + threadIdx.x));
+  if (x / cc != fdiv_m(x, cc, rc) || (-x) / cc != fdiv_m(-x, cc, rc)) atomicOr(bad + blockIdx.y, 1u);
+}
+
+template <int NW, bool FAST>
 __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __restrict__ rec,
                                                               const float2* __restrict__ G, float2* __restrict__ flow,
                                                               unsigned long long* __restrict__ H,
                                                               unsigned* __restrict__ hdr, int w, int h, size_t bs,
-                                                              FlowIdx idx, int dir, SweepConst c, int nwg, int B,
-                                                              unsigned* __restrict__ errflag) {
+                                                              FlowIdx idx, int dir, SweepConst c, SweepFast fc,
+                                                              int nwg, int B, unsigned* __restrict__ errflag) {
   constexpr int R = NW * 4;
   __shared__ LkIn s_in[NW][kRingK][4];
   __shared__ float2 s_out[NW][kRingK][4];
@@ -111,49 +192,91 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     const float fy = (float)y;
     const bool fromLds = bank == 0 || (bank == 2 && rr == 0);  // candidate is the old flow / the granule-fed up value
     const float kInf = __int_as_float(0x7f800000);
+    const char* __restrict__ G1b0 = reinterpret_cast<const char*>(G1);
+    const char* __restrict__ G1b1 = reinterpret_cast<const char*>(G1 + w);
     float2 fl = make_float2(0.f, 0.f);  // final flow of the previous pixel of this row (same in all 16 lanes)
     LkIn nin;
     nin.rec = make_float4(0.f, 0.f, 0.f, 0.f);
     nin.flow = make_float2(0.f, 0.f);
     float2 nup = make_float2(0.f, 0.f);
+    TS_DECL;
+    // One iteration = one step. The barrier sits in the shadow of the bilinear gathers: everything a step needs
+    // from other waves was read from LDS one iteration earlier (after that iteration's barrier), so the wave
+    // starts its dependent chain without waiting for anybody.
     for (int t = -1; t < T; ++t) {
-      wg_barrier();
+      TS(0);
       const int s = t - kLag * j;
+      const bool run = s >= 0 && s < nsteps && !(fc.dbg & 16);
       const LkIn in = nin;
       const float2 upl = nup;
+      const int xi = s - rr;
+      const bool active = rowValid && xi >= 0 && xi < w;
+      const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
+      const float4 rc = in.rec;
+      const float2 fo = in.flow;
+      const bool upd = rc.x == rc.x;
+      float2 up = make_float2(0.f, 0.f);
+      float ax = 0.f, ay = 0.f, xR = 0.f, yR = 0.f;
+      f4a8 ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+      if (run) {
+        // up neighbour in every lane (needed by the selection below)
+        up.x = from_row_above<0xF>(upl.x, fl.x);
+        up.y = from_row_above<0xF>(upl.y, fl.y);
+        // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
+        float2 cand;
+        cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
+        cand.y = fromLds ? (bank == 0 ? fo.y : upl.y) : fl.y;
+        cand.x = from_row_above<0x4>(cand.x, fl.x);
+        cand.y = from_row_above<0x4>(cand.y, fl.y);
+        ax = cand.x + ox;
+        ay = cand.y + oy;
+        // Every lane evaluates (idle lanes and masked pixels produce values nobody reads; addresses are clamped).
+        // getPixBilinear32FExtend's clamp (PixFlow.h:457-464): max(0, .) then min(., size-2) == med3 here; the
+        // operands are non-negative, so (int) truncation == floor and x - float(int(x)) == fract(x) exactly.
+        const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
+        const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
+        const int x0 = (int)mx, y0 = (int)my;
+        xR = __builtin_amdgcn_fractf(mx);
+        yR = __builtin_amdgcn_fractf(my);
+        const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+        if (!(fc.dbg & 64)) {  // (timing experiment: 64 = no gathers)
+          ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
+          tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
+        } else {
+          ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
+        }
+      }
+      TS(1);
+      wg_barrier();
+      TS(2);
       // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
-      // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written two barriers ago.
+      // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.
       const int s1 = s + 1;
       if (s1 >= 0 && s1 < nsteps) {
         nin = s_in[j][s1 & (kRingK - 1)][rr];
         nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
       }
-      if (s < 0 || s >= nsteps) continue;
-      const int xi = s - rr;
-      const bool active = rowValid && xi >= 0 && xi < w;
-      const int x = col(xi);
-      const float4 rc = in.rec;
-      const float2 fo = in.flow;
-      const bool upd = active && (rc.x == rc.x);
-      // up neighbour in every lane (needed by the selection below)
-      float2 up;
-      up.x = from_row_above<0xF>(upl.x, fl.x);
-      up.y = from_row_above<0xF>(upl.y, fl.y);
-      // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
-      float2 cand;
-      cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
-      cand.y = fromLds ? (bank == 0 ? fo.y : upl.y) : fl.y;
-      cand.x = from_row_above<0x4>(cand.x, fl.x);
-      cand.y = from_row_above<0x4>(cand.y, fl.y);
-      const float ax = cand.x + ox, ay = cand.y + oy;
-      // every lane evaluates (idle lanes and masked pixels produce values nobody reads; addresses are clamped)
-      const Foot ft = footprint(w, (float)x + ax, fy + ay, c);
-      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1 + ft.off);
-      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1 + ft.off + w);
+      if (!run) continue;
+      TS_WAITV();
+      TS(3);
       Texels tt;
       tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
       tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-      const float e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+      float e;
+      if (FAST) {
+        bool tiny;
+        e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
+          Foot ft;
+          ft.off = 0; ft.xR = xR; ft.yR = yR;
+          e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+        }
+      } else {
+        Foot ft;
+        ft.off = 0; ft.xR = xR; ft.yR = yR;
+        e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+      }
+      TS(4);
       const float e0 = row_bcast<0>(e), e0x = row_bcast<1>(e), e0y = row_bcast<2>(e);
       float e1 = row_bcast<4>(e);
       const float e1x = row_bcast<5>(e), e1y = row_bcast<6>(e);
@@ -166,22 +289,42 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       float cur = e0, ex = e0x, ey = e0y;
       if (e1 < cur) { f = fl; cur = e1; ex = e1x; ey = e1y; }
       if (e2 < cur) { f = up; cur = e2; ex = e2x; ey = e2y; }
-      const float ggx = (ex - cur) / kEps, ggy = (ey - cur) / kEps;
+      const float nx = ex - cur, ny = ey - cur;
+      float ggx, ggy;
+      if (FAST) {
+        ggx = fdiv_m(nx, kEps, fc.rcEps);
+        ggy = fdiv_m(ny, kEps, fc.rcEps);
+        const bool tiny = min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
+          ggx = nx / kEps;
+          ggy = ny / kEps;
+        }
+      } else {
+        ggx = nx / kEps;
+        ggy = ny / kEps;
+      }
       float2 res;
       res.x = f.x - c.gradStep * ggx;
       res.y = f.y - c.gradStep * ggy;
-      if (active) {
-        if (!upd) res = fo;
-        if (k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
-        fl = res;
-      }
+      // not-updated pixels keep their flow; inactive lanes keep the previous result
+      const bool take = active && upd;
+      const float2 alt = active ? fo : fl;
+      res.x = take ? res.x : alt.x;
+      res.y = take ? res.y : alt.y;
+      fl = res;
+      if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
+      TS(5);
     }
+    TS_DUMP();
     wg_barrier();
     return;
   }
 
+  if (wave >= NW && (fc.dbg & 32)) return;  // timing experiment: compute waves alone
   if (wave == NW) {
     // ------------------------------------ bulk service wave ------------------------------------
+    // One event per compute wave every 16 steps (staggered by kLag). An event first consumes what was issued at
+    // earlier events (>= kLag steps old: no stall), then issues new loads/stores and returns without waiting.
     const int st = lane & 15, rr = lane >> 4;
     const f4n* __restrict__ recN = reinterpret_cast<const f4n*>(rec);
     const f2n* __restrict__ flowN = reinterpret_cast<const f2n*>(flow);
@@ -214,46 +357,46 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       v.pad = make_float2(0.f, 0.f);
       s_in[j][(cidx * kChunk + st) & (kRingK - 1)][rr] = v;
     };
-    // Touch the I1-gradient lines around where the coming pixels will sample (predicted by the blurred flow
-    // and by the current flow) so that they are L1-resident when the compute waves gather them.
-    auto prefetch_chunk = [&](int j, int cidx) {
-      sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // consume the previous round (long since landed)
-      const float xf = (float)col(cidx * kChunk + st - rr);
-      const Foot fa = footprint(w, xf + rRec[j].z, rowY[j] + rRec[j].w, c);
-      const Foot fb = footprint(w, xf + rFlow[j].x, rowY[j] + rFlow[j].y, c);
-      pf0 = G1w[2 * fa.off];
-      pf1 = G1w[2 * (fa.off + w)];
-      pf2 = G1w[2 * fb.off];
-      pf3 = G1w[2 * (fb.off + w)];
-    };
     auto flush_chunk = [&](int j, int cidx) {
       const int sidx = cidx * kChunk + st;
       const int xi = sidx - rr;
       if (rowOk[j] && xi >= 0 && xi < w && sidx < nsteps) flow[rowOff[j] + col(xi)] = s_out[j][sidx & (kRingK - 1)][rr];
     };
+    // event of wave j when it enters chunk cc: chunk cc-1 is complete and its ring slots are free
+    auto event = [&](int j, int cc) {
+      sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // previous prefetch round (long since landed)
+      int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+      if (fc.dbg & 8) return;
+      const bool wr = cc + 1 < nchunks;
+      if (wr) {
+        // Where the pixels of chunk cc+1 will sample I1's gradients, predicted by the blurred flow and by the
+        // current flow: touching those lines now makes the compute waves' gathers L1 hits.
+        const float xf = (float)col((cc + 1) * kChunk + st - rr);
+        const Foot fa = footprint(w, xf + rRec[j].z, rowY[j] + rRec[j].w, c);
+        const Foot fb = footprint(w, xf + rFlow[j].x, rowY[j] + rFlow[j].y, c);
+        o0 = 2 * fa.off; o1 = 2 * (fa.off + w); o2 = 2 * fb.off; o3 = 2 * (fb.off + w);
+        write_chunk(j, cc + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (cc + 2 < nchunks) load_chunk(j, cc + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (cc >= 1) flush_chunk(j, cc - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (wr && !(fc.dbg & 4)) {
+        pf0 = G1w[o0]; pf1 = G1w[o1]; pf2 = G1w[o2]; pf3 = G1w[o3];
+      }
+    };
     // prologue: chunk 0 into LDS, chunk 1 into registers
 #pragma unroll
     for (int j = 0; j < NW; ++j) load_chunk(j, 0);
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      write_chunk(j, 0);
-      prefetch_chunk(j, 0);
-      if (nchunks > 1) load_chunk(j, 1);
-    }
+    for (int j = 0; j < NW; ++j) event(j, -1);
     for (int t = -1; t < T; ++t) {
       wg_barrier();
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int s = t - kLag * j;
-        if (s >= 1 && (s & (kChunk - 1)) == 1) {
-          const int cc = s >> 4;  // wave j is inside chunk cc; chunk cc-1 is complete, its slots are free
-          if (cc + 1 < nchunks) {
-            write_chunk(j, cc + 1);
-            prefetch_chunk(j, cc + 1);
-          }
-          if (cc + 2 < nchunks) load_chunk(j, cc + 2);
-          if (cc >= 1) flush_chunk(j, cc - 1);
-        }
+        if (s >= 1 && (s & (kChunk - 1)) == 1) event(j, s >> 4);
       }
     }
     wg_barrier();
@@ -270,54 +413,55 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
   }
 
   // ------------------------------------ hand-off service wave ------------------------------------
+  // Acts every 4th step: (1) take in the granule poll issued 4 steps ago, (2) block only if the band above has
+  // fallen behind what the next 4 steps need, (3) publish the finished columns of this band's last row,
+  // (4) issue the next poll. Everything waited on is >= 4 steps old.
   {
-    const bool hasUpWg = wgband > 0;
-    const bool publishes = wgband + 1 < nwg;
+    const bool hasUpWg = wgband > 0 && !(fc.dbg & 1);
+    const bool publishes = wgband + 1 < nwg && !(fc.dbg & 2);
     const unsigned long long* Hin = H + (size_t)wgband * w;
     unsigned long long* Hout = H + (size_t)(wgband + 1) * w;
     constexpr int jl = NW - 1;
     int upFilled = hasUpWg ? 0 : 0x3fffffff, pub = 0;
     bool pending = false, dead = false;
-    int pendT = 0;
     unsigned long long pv = kEmptyGranule;
-    auto issue = [&](int t) {
+    auto issue = [&]() {
       const int xi = upFilled + lane;
       pv = kEmptyGranule;
       if (lane < 16 && xi < w) pv = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pending = true;
-      pendT = t;
     };
-    auto process = [&](int t) {  // leading run of written granules -> s_up0 (bounded by the ring)
+    auto process = [&](int limit) {  // leading run of written granules -> s_up0; upFilled never exceeds limit
       const int xi = upFilled + lane;
       const unsigned long long bad = __ballot(lane < 16 && (xi >= w || (pv == kEmptyGranule && !dead)));
       int n = bad ? (int)__ffsll((long long)bad) - 1 : 16;
-      n = min(n, t + 31 - upFilled);
+      n = min(n, limit - upFilled);
       if (n > 0) {
-        if (lane < n) s_up0[xi & (kRingK - 1)] = make_float2(__uint_as_float((unsigned)pv), __uint_as_float((unsigned)(pv >> 32)));
-        upFilled += n;
+        if (lane < n)
+          s_up0[xi & (kRingK - 1)] = make_float2(__uint_as_float((unsigned)pv), __uint_as_float((unsigned)(pv >> 32)));
+        upFilled = __builtin_amdgcn_readfirstlane(upFilled + n);
       }
       pending = false;
     };
-    auto ensure = [&](int t, int need) {  // block (bounded) until columns [0, need) are in LDS
+    auto ensure = [&](int need, int limit) {  // block (bounded) until columns [0, need) are in LDS
       unsigned spins = 0;
       while (upFilled < need) {
-        if (!pending) issue(t);
-        process(t);
+        if (!pending) issue();
+        process(limit);
         if (upFilled < need) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21) || ((spins & 1023u) == 0 &&
-                                       __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            // the band above is gone: give up waiting, flag the result invalid, keep the pipeline draining
+          if (++spins > (1u << 21) ||
+              ((spins & 1023u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            // the band above is gone: stop waiting, flag the result invalid, keep the pipeline draining
             dead = true;
             if (lane == 0) atomicExch(errflag, 1u);
           }
         }
       }
     };
-    auto publish = [&](int xdone, bool force) {
-      const int xd = min(xdone, w - 1);
-      const int avail = xd - pub + 1;
-      if (avail >= 4 || (force && avail > 0)) {
+    auto publish = [&](int xdone) {
+      const int avail = min(xdone, w - 1) - pub + 1;
+      if (avail > 0) {
         const int n = min(16, avail);
         if (lane < n) {
           const int xi = pub + lane;
@@ -328,45 +472,104 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         pub += n;
       }
     };
-    if (hasUpWg) ensure(-2, min(w, 1));
+    if (hasUpWg) {
+      ensure(min(w, 2), 26);
+      if (upFilled < w) issue();
+    }
     for (int t = -1; t < T; ++t) {
       wg_barrier();
+      if (((t + 1) & 3) != 0) continue;
+      // this step and the next three read columns <= t+5; the ring allows columns <= t+32
       if (hasUpWg && upFilled < w) {
-        const int need = min(w, t + 3);
-        if (pending && (t - pendT >= 2 || upFilled < need)) process(t);
-        if (!pending && upFilled < min(w, t + 24)) issue(t);
-        if (upFilled < need) ensure(t, need);
+        if (pending) process(t + 31);
+        ensure(min(w, t + 7), t + 31);
       }
       // columns of the band's last row that are complete and visible: wave jl finished local step t-1-kLag*jl
-      if (publishes) publish(t - 1 - kLag * jl - 3, false);
+      if (publishes) publish(t - 1 - kLag * jl - 3);
+      if (hasUpWg && upFilled < w && !pending) issue();
     }
     wg_barrier();
     if (publishes)
-      while (pub < w) publish(w - 1, true);
+      while (pub < w) publish(w - 1);
   }
 }
 
 // ==========================================================================================
-int sweep_lock_rows_per_wg(int nw) { return 4 * nw; }
 int sweep_lock_num_wgs(int h, int nw) { return (h + 4 * nw - 1) / (4 * nw); }
 size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw) {
   return 256 + (size_t)B * sweep_lock_num_wgs(h, nw) * w * sizeof(unsigned long long);
 }
+
+// Device check of fdiv_m for a set of divisors: every significand, both signs. Results are cached per process.
+bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& cs) {
+  static std::mutex mu;
+  static std::map<unsigned, bool> known;
+  std::lock_guard<std::mutex> lk(mu);
+  std::vector<float> todo;
+  for (float v : cs) {
+    unsigned bits;
+    std::memcpy(&bits, &v, 4);
+    if (!known.count(bits) && std::find(todo.begin(), todo.end(), v) == todo.end()) todo.push_back(v);
+  }
+  if (!todo.empty()) {
+    float* dc = nullptr;
+    unsigned* dbad = nullptr;
+    std::vector<unsigned> bad(todo.size(), 1u);
+    if (hipMalloc(&dc, todo.size() * sizeof(float)) == hipSuccess &&
+        hipMalloc(&dbad, todo.size() * sizeof(unsigned)) == hipSuccess) {
+      (void)hipMemcpyAsync(dc, todo.data(), todo.size() * sizeof(float), hipMemcpyHostToDevice, st);
+      (void)hipMemsetAsync(dbad, 0, todo.size() * sizeof(unsigned), st);
+      hipLaunchKernelGGL(k_verify_div, dim3((1u << 23) / 256, (unsigned)todo.size()), dim3(256), 0, st, dc, dbad);
+      if (hipMemcpyAsync(bad.data(), dbad, todo.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        std::fill(bad.begin(), bad.end(), 1u);
+    }
+    if (dc) (void)hipFree(dc);
+    if (dbad) (void)hipFree(dbad);
+    for (size_t i = 0; i < todo.size(); ++i) {
+      unsigned bits;
+      std::memcpy(&bits, &todo[i], 4);
+      known[bits] = bad[i] == 0;
+    }
+  }
+  for (float v : cs) {
+    unsigned bits;
+    std::memcpy(&bits, &v, 4);
+    if (!known[bits]) return false;
+  }
+  return true;
+}
+
+template <int NW, bool FAST>
+static void launch_lock_t(hipStream_t st, const float4* rec, const float2* G, float2* flow, unsigned long long* H,
+                          unsigned* hdr, unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
+                          const SweepConst& c, const SweepFast& fc, int nwg) {
+  hipLaunchKernelGGL((k_sweep_lock<NW, FAST>), dim3(nwg * B), dim3((NW + 2) * 64), 0, st, rec, G, flow, H, hdr, w, h, bs,
+                     idx, dir, c, fc, nwg, B, errflag);
+}
+
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, int nw) {
+                       const PixFlowConsts& pc, int nw, bool fast) {
   const SweepConst c = make_sweep_const(pc, w, h);
+  SweepFast fc;
+  fc.rcCols = 1.0f / c.fcols;
+  fc.rcRows = 1.0f / c.frows;
+  fc.rcEps = 1.0f / 0.001f;
+  const char* dbgEnv = std::getenv("S360_SWEEP_DBG");
+  fc.dbg = dbgEnv ? std::atoi(dbgEnv) : 0;
   const int nwg = sweep_lock_num_wgs(h, nw);
   // ticket counter (first 256 bytes) and every granule start as all-ones
   (void)hipMemsetAsync(handoff, 0xFF, sweep_lock_handoff_bytes(w, h, B, nw), st);
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  if (nw == 4)
-    hipLaunchKernelGGL((k_sweep_lock<4>), dim3(nwg * B), dim3(6 * 64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
-                       nwg, B, errflag);
-  else
-    hipLaunchKernelGGL((k_sweep_lock<8>), dim3(nwg * B), dim3(10 * 64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir,
-                       c, nwg, B, errflag);
+  if (nw == 4) {
+    if (fast) launch_lock_t<4, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
+    else launch_lock_t<4, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
+  } else {
+    if (fast) launch_lock_t<8, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
+    else launch_lock_t<8, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
+  }
 }
 
 }  // namespace s360

@@ -1,0 +1,118 @@
+// sweep_microbench.hip — timing harness for the sweep kernels on synthetic buffers (results are not checked here;
+// parity lives in tests/). Build: make -C tools   Run on the GPU box: tools/sweep_microbench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../surround360_amd/csrc/flow_kernels.hip"
+#include "../surround360_amd/csrc/sweep_lock.hip"
+
+using namespace s360;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static unsigned long long g_ts[8];
+static float run(int w, int h, int B, int nw, bool fast, int mode /*2 lock, 1 hex*/, int reps) {
+  const size_t n = (size_t)w * h;
+  std::mt19937 rng(1234);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<float> hG(2 * B * n * 2), hrec(B * n * 4), hflow(B * n * 2);
+  for (auto& v : hG) v = 0.05f * U(rng);
+  for (size_t i = 0; i < (size_t)B * n; ++i) {
+    hrec[4 * i + 0] = 0.05f * U(rng);
+    hrec[4 * i + 1] = 0.05f * U(rng);
+    hrec[4 * i + 2] = 2.0f * U(rng);
+    hrec[4 * i + 3] = 1.0f * U(rng);
+    hflow[2 * i + 0] = hrec[4 * i + 2] + 0.3f * U(rng);
+    hflow[2 * i + 1] = hrec[4 * i + 3] + 0.3f * U(rng);
+  }
+  float *dG, *drec, *dflow;
+  void* hand;
+  unsigned* err;
+  CK(hipMalloc(&dG, hG.size() * 4));
+  CK(hipMalloc(&drec, hrec.size() * 4));
+  CK(hipMalloc(&dflow, hflow.size() * 4));
+  const size_t hb = std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4));
+  CK(hipMalloc(&hand, hb));
+  CK(hipMalloc(&err, 8));
+  CK(hipMemset(err, 0, 8));
+  CK(hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(drec, hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dflow, hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
+  FlowIdx idx;
+  for (int b = 0; b < kMaxFlows; ++b) { idx.i0[b] = b % (2 * B); idx.i1[b] = (b + B) % (2 * B); }
+  PixFlowConsts pc{0.9f, 0.001f, 0.01f, 0.01f, 0.5f, 0.5f, 0};
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  if (fast) {
+    std::vector<float> d{0.001f, (float)w, (float)h};
+    if (!sweep_verify_divisors(st, d)) printf("  (fast division not verified for %d x %d)\n", w, h);
+  }
+  hipEvent_t a, b2;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b2));
+  auto once = [&](int dir) {
+    if (mode == 2)
+      launch_sweep_lock(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, nw, fast);
+    else
+      launch_sweep_band(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc);
+  };
+  once(1);
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  for (int r = 0; r < reps; ++r) once(r & 1 ? -1 : 1);
+  CK(hipEventRecord(b2, st));
+  CK(hipEventSynchronize(b2));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b2));
+  unsigned e = 0;
+  CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
+  if (e) printf("  (errflag set)\n");
+  CK(hipMemcpy(g_ts, (char*)hand + 32, sizeof(g_ts), hipMemcpyDeviceToHost));
+  hipFree(dG); hipFree(drec); hipFree(dflow); hipFree(hand); hipFree(err);
+  hipStreamDestroy(st);
+  return ms * 1000.f / reps;
+}
+
+int main(int argc, char** argv) {
+  struct Cfg { int w, h, B; const char* name; };
+  const Cfg cfgs[] = {{127, 27, 4, "polar L35"}, {613, 128, 4, "polar L20"}, {5040, 1052, 4, "polar L0"},
+                      {27, 38, 28, "side L30"}, {140, 203, 28, "side L14"}, {607, 884, 28, "side L0"}};
+  const int dbgs[] = {0, 3, 15, 47, 111, 31};
+  printf("%-10s %6s %6s %3s | %8s |", "config", "w", "h", "B", "hex16");
+  for (int d : dbgs) printf(" lock d%-2d |", d);
+  printf(" lock ieee | lock nw8 |  (us per launch; steps = w+3+15)\n");
+  for (const Cfg& c : cfgs) {
+    const int reps = c.w > 1000 ? 6 : 20;
+    printf("%-10s %6d %6d %3d |", c.name, c.w, c.h, c.B);
+    unsetenv("S360_SWEEP_DBG");
+    printf(" %8.1f |", run(c.w, c.h, c.B, 4, true, 1, reps));
+    for (int d : dbgs) {
+      char buf[16];
+      snprintf(buf, sizeof buf, "%d", d);
+      setenv("S360_SWEEP_DBG", buf, 1);
+      printf(" %8.1f |", run(c.w, c.h, c.B, 4, true, 2, reps));
+    }
+    unsetenv("S360_SWEEP_DBG");
+    printf(" %9.1f |", run(c.w, c.h, c.B, 4, false, 2, reps));
+    printf(" %8.1f |", run(c.w, c.h, c.B, 8, true, 2, reps));
+    printf("  us/step(d0) %.3f\n", run(c.w, c.h, c.B, 4, true, 2, reps) / (c.w + 18));
+#ifdef S360_SWEEP_TIMING
+    for (int d : {0, 47, 111}) {
+      char buf[16];
+      snprintf(buf, sizeof buf, "%d", d);
+      setenv("S360_SWEEP_DBG", buf, 1);
+      run(c.w, c.h, c.B, 4, true, 2, 1);
+      const double st = c.w + 3;
+      printf("    d%-2d cycles/step of wave 0: loop-top %.0f | pre-gather %.0f | barrier %.0f | preload+gather wait %.0f | error %.0f | select+grad %.0f\n", d,
+             g_ts[0] / st, g_ts[1] / st, g_ts[2] / st, g_ts[3] / st, g_ts[4] / st, g_ts[5] / st);
+    }
+#endif
+    unsetenv("S360_SWEEP_DBG");
+    fflush(stdout);
+  }
+  return 0;
+}
