@@ -174,7 +174,7 @@ def main():
                                "top+bottom poles, pixflow_low, sharpening 0" if args.size == "8k" else
                                "DEBUG 2K frame (not a bench config)",
                    "parallelism": "pairs sharded over %d GPU(s), strip gather to rank 0" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_sweep_diag (PixFlow propagation sweeps)",
+        "roofline": {"bound": "hbm", "kernel": "k_sweep_lock (PixFlow propagation sweeps, PixFlow.h:388-410)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,
                      "avg_launch_ms": sweep_ms / max(sweep_launches, 1), "launches_per_frame": sweep_launches / args.steps,
