@@ -181,6 +181,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
   if (wave < NW) {
     // ------------------------------------ compute waves ------------------------------------
     const int j = wave;
+    if (!(fc.dbg & 128)) __builtin_amdgcn_s_setprio(3);  // the update chain outranks the service waves on its SIMD
     const int rr = lane >> 4, k = lane & 15, bank = k >> 2, role = k & 3;
     const int yi = rows0 + j * 4 + rr;
     const bool rowValid = yi < h;
@@ -413,9 +414,9 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
   }
 
   // ------------------------------------ hand-off service wave ------------------------------------
-  // Acts every 4th step: (1) take in the granule poll issued 4 steps ago, (2) block only if the band above has
-  // fallen behind what the next 4 steps need, (3) publish the finished columns of this band's last row,
-  // (4) issue the next poll. Everything waited on is >= 4 steps old.
+  // Every step: (1) take in the granule poll issued two steps ago, (2) block only if the band above has fallen
+  // behind what the next step needs, (3) publish the finished columns of this band's last row, (4) issue the next
+  // poll. Everything waited on is two steps old.
   {
     const bool hasUpWg = wgband > 0 && !(fc.dbg & 1);
     const bool publishes = wgband + 1 < nwg && !(fc.dbg & 2);
@@ -472,21 +473,27 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         pub += n;
       }
     };
+    int pendT = -100;
     if (hasUpWg) {
       ensure(min(w, 2), 26);
       if (upFilled < w) issue();
     }
     for (int t = -1; t < T; ++t) {
       wg_barrier();
-      if (((t + 1) & 3) != 0) continue;
-      // this step and the next three read columns <= t+5; the ring allows columns <= t+32
+      // By the end of this iteration the compute waves need columns <= t+2; the ring allows columns <= t+32.
+      // Order per iteration: take in the poll issued two iterations ago, publish, issue the next poll — so that
+      // whatever the next wait covers is two steps old.
       if (hasUpWg && upFilled < w) {
-        if (pending) process(t + 31);
-        ensure(min(w, t + 7), t + 31);
+        const int need = min(w, t + 3);
+        if (pending && (t - pendT >= 2 || upFilled < need)) process(t + 31);
+        if (upFilled < need) ensure(need, t + 31);
       }
       // columns of the band's last row that are complete and visible: wave jl finished local step t-1-kLag*jl
       if (publishes) publish(t - 1 - kLag * jl - 3);
-      if (hasUpWg && upFilled < w && !pending) issue();
+      if (hasUpWg && upFilled < w && !pending) {
+        issue();
+        pendT = t;
+      }
     }
     wg_barrier();
     if (publishes)

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
   struct Cfg { int w, h, B; const char* name; };
   const Cfg cfgs[] = {{127, 27, 4, "polar L35"}, {613, 128, 4, "polar L20"}, {5040, 1052, 4, "polar L0"},
                       {27, 38, 28, "side L30"}, {140, 203, 28, "side L14"}, {607, 884, 28, "side L0"}};
-  const int dbgs[] = {0, 3, 15, 47, 111, 31};
+  const int dbgs[] = {0, 128, 3, 15, 47, 31};
   printf("%-10s %6s %6s %3s | %8s |", "config", "w", "h", "B", "hex16");
   for (int d : dbgs) printf(" lock d%-2d |", d);
   printf(" lock ieee | lock nw8 |  (us per launch; steps = w+3+15)\n");
