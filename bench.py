@@ -6,9 +6,12 @@ PixFlow flows, novel-view strips, panorama assembly, 4 pole flows + warps, compo
 8192x8192 — everything renderStereoPanorama does between decoded inputs and the stacked equirect
 (TestRenderStereoPanorama.cpp:716-972). Inputs are uploaded to HBM before the timed region.
 
-N=1: all pairs on one GPU (BASELINE.json configs[2]).  N>1 (launched by torch.distributed.run, one rank per
-GPU): the 14 side pairs are sharded over the ranks, one RCCL exchange gathers the strips on rank 0, which
-runs the pole units and the composite (configs[3]); total work is fixed => "scaling": "strong".
+Timed region: every rank renders K independent frames of BASELINE.json configs[2] with up to `--inflight` frames
+in flight on its GPU (one context + HIP stream each; a single frame is latency-bound by PixFlow's raster-order
+sweeps and leaves most of the chip idle). Per-GPU work is fixed => "scaling": "weak"; `value` is
+the aggregate over all ranks. The same run then measures ONE frame at a time ("single_frame"): on 1 GPU that is
+configs[2] as a latency; on N GPUs it is configs[3] — the 14 side pairs sharded over the ranks, one RCCL exchange
+gathering the strips on rank 0, which runs the pole units and the composite.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
 (measured live with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle = an OpenCV-free
@@ -80,15 +83,23 @@ def cpu_baseline(side, top, bottom):
                       "the flow pixel-level ratio %.1fx" % (cores, sec_2k, ratio)}
 
 
+# compulsory bytes per 8K frame of the warp/blend kernel families (MB)
+WARP_BLEND_MB = {"project_side": 176 + 180, "project_pole": 2 * 12.6 + 141, "novel_view": 840, "assemble_pano": 400,
+                 "pole_warp": 1600, "flatten": 1650}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", default="8k", choices=["8k", "2k"], help="2k is a debugging aid, not a bench config")
+    ap.add_argument("--inflight", type=int, default=8,
+                    help="independent frames in flight per GPU (one context + HIP stream each); 1 = one frame at a time")
     args = ap.parse_args()
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per in-flight frame (read at HIP init)
     import torch
     from surround360_amd import parallel, render as R, synth
 
@@ -109,15 +120,55 @@ def main():
                                                            enable_bottom=1, final_eqr_width=0, final_eqr_height=0)
     side, top, bottom = synth.rig_frame(RIG, size=2048, world_h=1024, seed=360)
     rig = R.RigDescription(RIG)
-    ctx = R.Context(rig, R.make_params(**flags), device=local_rank)
+    F = max(1, args.inflight)
+    ctxs = [R.Context(rig, R.make_params(**flags), device=local_rank) for _ in range(F)]
+    ctx = ctxs[0]
     P = rig.get_side_camera_count()
+    for c in ctxs:
+        c.upload_frame(side, top, bottom)  # inputs resident in HBM before the timed region
+
+    def sync():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- timed region: every rank renders K whole frames, up to F in flight (independent frames: no collective) ----
+    counter = [0]
+
+    def step():
+        ctxs[counter[0] % F].render(False)  # asynchronous enqueue on that context's stream
+        counter[0] += 1
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    for c in ctxs:
+        c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = {}
+    for c in ctxs:
+        for k, v in c.profile_get().items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + v[0], a[1] + v[1])
+        c.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- one frame at a time (BASELINE configs[2] on 1 GPU; configs[3] = pairs sharded + strip gather on N GPUs) ----
     bounds = parallel.partition_pairs(P, world)
     p0, p1 = bounds[rank], bounds[rank + 1]
-    ctx.upload_frame(side, top, bottom)  # inputs resident in HBM before the timed region
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
     strips = parallel.strips_tensor(ctx, dev) if world > 1 else None
 
-    def step():
+    def single():
         if world == 1:
             ctx.render(False)
         else:
@@ -127,26 +178,20 @@ def main():
             if rank == 0:
                 ctx.finish(15, False)
 
-    def sync():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
+    single()
     sync()
     ctx.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    n_single = 3
+    t1 = time.perf_counter()
+    for _ in range(n_single):
+        single()
     sync()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_get()
+    dt1 = time.perf_counter() - t1
+    prof1 = ctx.profile_get()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt1], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt1 = float(t.item())
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -154,34 +199,64 @@ def main():
 
     g = ctx.geometry
     sweep_ms, sweep_launches = prof.get("flow_sweep", (0.0, 0))
-    n_side_flows = 2 * (p1 - p0)
-    bytes_per_frame = sweep_algorithmic_bytes(g, n_side_flows, 4, flags["eqr_width"])
-    achieved = (bytes_per_frame * args.steps) / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    bytes_per_frame = sweep_algorithmic_bytes(g, 2 * P, 4, flags["eqr_width"])
+    launches_per_frame = sweep_launches / max(args.steps, 1)
+    bytes_per_launch = bytes_per_frame / max(launches_per_frame, 1)
+    avg_launch_ms = sweep_ms / max(sweep_launches, 1)
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    s1_ms, s1_launches = prof1.get("flow_sweep", (0.0, 0))
+    n_side_flows_1 = 2 * (p1 - p0)
+    bytes_1 = sweep_algorithmic_bytes(g, n_side_flows_1, 4, flags["eqr_width"]) * n_single
+    wb = {}
+    if world == 1:
+        for k, mb in WARP_BLEND_MB.items():
+            ms = prof1.get(k, (0.0, 0))[0] / n_single
+            if ms > 0:
+                gbs = mb * 1e6 / (ms * 1e-3) / 1e9
+                wb[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     out = {
         "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
-        "value": args.steps / dt,
+        "value": world * args.steps / dt,
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo 8192x8192, "
                                "top+bottom poles, pixflow_low, sharpening 0" if args.size == "8k" else
                                "DEBUG 2K frame (not a bench config)",
-                   "parallelism": "pairs sharded over %d GPU(s), strip gather to rank 0" % world},
+                   "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
+                                  "(one context + HIP stream each), no data-path collective" % (world, F),
+                   "frames_in_flight": F},
         "roofline": {"bound": "hbm", "kernel": "k_sweep_lock (PixFlow propagation sweeps, PixFlow.h:388-410)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,
-                     "avg_launch_ms": sweep_ms / max(sweep_launches, 1), "launches_per_frame": sweep_launches / args.steps,
-                     "algorithmic_bytes_per_frame": bytes_per_frame,
-                     "note": "dependency-latency-bound wavefront kernel; see DESIGN.md"},
+                     "avg_launch_ms": avg_launch_ms, "launches_per_frame": launches_per_frame,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "aggregate_GBps_all_streams": bytes_per_frame * args.steps / dt / 1e9,
+                     "note": "dependency-latency-bound wavefront kernel (DESIGN.md §5); launches of up to %d frames "
+                             "overlap in the timed region, durations are per launch" % F},
+        "single_frame": {"mode": "one frame at a time, all pairs on 1 GPU" if world == 1 else
+                                 "one frame at a time, 14 pairs sharded over %d GPUs + one RCCL strip gather, pole units "
+                                 "and composite on rank 0" % world,
+                         "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / dt1,
+                         "sweep_roofline_frac": (bytes_1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s1_ms > 0 else None,
+                         "kernel_ms_per_frame": {k: round(v[0] / n_single, 3)
+                                                 for k, v in sorted(prof1.items(), key=lambda kv: -kv[1][0])},
+                         "warp_blend_roofline": wb},
         "kernel_ms_per_frame": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
     }
+    traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+    if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+        try:
+            out["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(side, top, bottom)
     print(json.dumps(out))

@@ -2,7 +2,9 @@
 // parity lives in tests/). Build: make -C tools   Run on the GPU box: tools/sweep_microbench
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -77,7 +79,66 @@ static float run(int w, int h, int B, int nw, bool fast, int mode /*2 lock, 1 he
   return ms * 1000.f / reps;
 }
 
+// Saturated throughput: the same sweep on NS independent buffer sets / streams at once; returns Gpx/s.
+static float throughput(int w, int h, int B, int mode, int NS, int reps) {
+  const size_t n = (size_t)w * h;
+  std::mt19937 rng(99);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<float> hG(2 * B * n * 2), hrec(B * n * 4), hflow(B * n * 2);
+  for (auto& v : hG) v = 0.05f * U(rng);
+  for (size_t i = 0; i < (size_t)B * n; ++i) {
+    hrec[4 * i + 0] = 0.05f * U(rng); hrec[4 * i + 1] = 0.05f * U(rng);
+    hrec[4 * i + 2] = 2.0f * U(rng); hrec[4 * i + 3] = 1.0f * U(rng);
+    hflow[2 * i + 0] = hrec[4 * i + 2] + 0.3f * U(rng); hflow[2 * i + 1] = hrec[4 * i + 3] + 0.3f * U(rng);
+  }
+  std::vector<float*> dG(NS), drec(NS), dflow(NS);
+  std::vector<void*> hand(NS);
+  std::vector<unsigned*> err(NS);
+  std::vector<hipStream_t> st(NS);
+  const size_t hb = std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4));
+  for (int k = 0; k < NS; ++k) {
+    CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
+    CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
+    CK(hipMemcpy(dG[k], hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(drec[k], hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dflow[k], hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
+    CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+  }
+  FlowIdx idx;
+  for (int b = 0; b < kMaxFlows; ++b) { idx.i0[b] = b % (2 * B); idx.i1[b] = (b + B) % (2 * B); }
+  PixFlowConsts pc{0.9f, 0.001f, 0.01f, 0.01f, 0.5f, 0.5f, 0};
+  std::vector<float> d{0.001f, (float)w, (float)h};
+  sweep_verify_divisors(st[0], d);
+  auto once = [&](int k, int dir) {
+    if (mode == 2)
+      launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, 4, true);
+    else
+      launch_sweep_band(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc);
+  };
+  for (int k = 0; k < NS; ++k) once(k, 1);
+  CK(hipDeviceSynchronize());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; ++r)
+    for (int k = 0; k < NS; ++k) once(k, r & 1 ? -1 : 1);
+  CK(hipDeviceSynchronize());
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int k = 0; k < NS; ++k) { hipFree(dG[k]); hipFree(drec[k]); hipFree(dflow[k]); hipFree(hand[k]); hipFree(err[k]); hipStreamDestroy(st[k]); }
+  return (float)((double)NS * reps * B * n / sec / 1e9);
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "tp") {
+    printf("saturated sweep throughput, Gpx/s (one px = one pixel update of one sweep)\n");
+    struct C2 { int w, h, B; const char* name; };
+    const C2 cs[] = {{5040, 1052, 4, "polar L0"}, {607, 884, 28, "side L0"}, {1153, 240, 4, "polar L14"}, {140, 203, 28, "side L14"}};
+    for (const C2& c : cs)
+      for (int ns : {1, 2, 4, 8}) {
+        printf("%-10s B=%2d streams=%d : hex16 %7.2f   lock %7.2f\n", c.name, c.B, ns, throughput(c.w, c.h, c.B, 1, ns, 4),
+               throughput(c.w, c.h, c.B, 2, ns, 4));
+        fflush(stdout);
+      }
+    return 0;
+  }
   struct Cfg { int w, h, B; const char* name; };
   const Cfg cfgs[] = {{127, 27, 4, "polar L35"}, {613, 128, 4, "polar L20"}, {5040, 1052, 4, "polar L0"},
                       {27, 38, 28, "side L30"}, {140, 203, 28, "side L14"}, {607, 884, 28, "side L0"}};
