@@ -189,6 +189,16 @@ int s360_frame_get_u8(s360_ctx* ctx, const char* name, int idx, int whc[3], uint
 /* "flow_l_to_r" "flow_r_to_l" (idx pair) "flow_pole" (idx 0..3). */
 int s360_frame_get_f32(s360_ctx* ctx, const char* name, int idx, int whc[3], float* dst);
 
+/* Temporal state from a previous process (the reference's --prev_frame_data_dir files, TRSP:215-235, 421-436):
+ * previous flows (readFlowFromFile) and the exact 8UC4 images that went into them (overlap_<i>_{L,R}.png,
+ * extendedSideSpherical_<eye>.png, extendedFisheyeSpherical_<eye>.png). Call for every pair / enabled pole unit
+ * before s360_frame_render(ctx, use_prev = 1). Sizes: overlap_image_width x cam_image_height for the side pairs;
+ * int(eqr_width * 1.2) x pole rows for the pole units (0 top_left, 1 top_right, 2 bottom_left, 3 bottom_right). */
+int s360_frame_set_prev_side(s360_ctx* ctx, int pair_idx, const float* flow_l_to_r, const float* flow_r_to_l,
+                             const uint8_t* overlap_l_bgra, const uint8_t* overlap_r_bgra);
+int s360_frame_set_prev_pole(s360_ctx* ctx, int unit, const float* flow, const uint8_t* extended_side_bgra,
+                             const uint8_t* extended_fisheye_bgra);
+
 /* Keep copies of the eye panoramas as they are before the pole composite ("side_pano_l/r"); costs two
  * device copies per frame, off by default. */
 int s360_set_keep_intermediates(s360_ctx* ctx, int on);

@@ -424,6 +424,48 @@ int s360_frame_render(s360_ctx* c, int use_prev) {
     frame_finish(c, 15, use_prev);
   });
 }
+int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, const float* flow_r_to_l,
+                             const uint8_t* overlap_l, const uint8_t* overlap_r) {
+  return guard(c, [&] {
+    need(c && flow_l_to_r && flow_r_to_l && overlap_l && overlap_r, "bad argument");
+    FrameState& F = frame_state(c);
+    const int P = F.P;
+    need(pair >= 0 && pair < P, "pair_idx out of range");
+    const size_t on = (size_t)c->g.overlap_image_width * c->g.cam_image_height;
+    // previous-frame slot of the double buffer, laid out for the full partition [0, P): L images / LtoR flows
+    // first, then R images / RtoL flows (frame_render_pairs)
+    const int prv = F.cur_side ^ 1;
+    F.overlaps[prv].ensure(2 * P * on * sizeof(uchar4));
+    F.sideFlows[prv].ensure(2 * P * on * sizeof(float2));
+    h2d(c, F.overlaps[prv].as<uchar4>() + on * pair, overlap_l, on * sizeof(uchar4));
+    h2d(c, F.overlaps[prv].as<uchar4>() + on * (P + pair), overlap_r, on * sizeof(uchar4));
+    h2d(c, F.sideFlows[prv].as<float2>() + on * pair, flow_l_to_r, on * sizeof(float2));
+    h2d(c, F.sideFlows[prv].as<float2>() + on * (P + pair), flow_r_to_l, on * sizeof(float2));
+    F.side_p0 = 0;
+    F.side_p1 = P;
+    F.have_prev_side = true;
+  });
+}
+int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uint8_t* ext_side,
+                             const uint8_t* ext_fisheye) {
+  return guard(c, [&] {
+    need(c && flow && ext_side && ext_fisheye && unit >= 0 && unit < 4, "bad argument");
+    FrameState& F = frame_state(c);
+    const int extW = int(float(c->P.eqr_width) * 1.2f);
+    const int rows = unit < 2 ? c->g.top_rows : c->g.bottom_rows;
+    need(F.poleRows == 0 || F.poleRows == rows || !F.have_prev_pole, "pole units of different height");
+    const size_t xn = (size_t)extW * rows;
+    const int prv = F.cur_pole ^ 1;
+    F.extImgs[prv].ensure(6 * xn * sizeof(uchar4));
+    F.poleFlows[prv].ensure(4 * xn * sizeof(float2));
+    h2d(c, F.extImgs[prv].as<uchar4>() + xn * unit, ext_side, xn * sizeof(uchar4));
+    h2d(c, F.extImgs[prv].as<uchar4>() + xn * (unit < 2 ? 4 : 5), ext_fisheye, xn * sizeof(uchar4));
+    h2d(c, F.poleFlows[prv].as<float2>() + xn * unit, flow, xn * sizeof(float2));
+    F.extW = extW;
+    F.poleRows = rows;
+    F.have_prev_pole = true;
+  });
+}
 int s360_frame_strip_ptr(s360_ctx* c, int eye, void** dev_ptr, size_t* bytes_per_pair) {
   return guard(c, [&] {
     need(c && dev_ptr && (eye == 0 || eye == 1), "bad argument");

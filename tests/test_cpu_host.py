@@ -1,0 +1,52 @@
+"""Host-side pieces that need no GPU: the PNG codec of the host binary against PIL, and its command-line checks."""
+import os
+import subprocess
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SNIPPET = r'''
+#include "png_io.hpp"
+int main(int argc, char** argv) {  // argv: in.png keep_alpha out.png
+  pngio::Image im = pngio::read(argv[1], argv[2][0] == '1');
+  pngio::write(argv[3], im.px.data(), im.w, im.h, im.c);
+  std::printf("%d %d %d\n", im.w, im.h, im.c);
+  return 0;
+}
+'''
+
+
+def test_png_codec_round_trip(tmp_path):
+    src = tmp_path / "rt.cpp"
+    src.write_text(SNIPPET)
+    exe = str(tmp_path / "rt")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz"])
+    rng = np.random.default_rng(5)
+    for mode, ch in (("RGB", 3), ("RGBA", 4), ("L", 1), ("P", 1)):
+        a = rng.integers(0, 256, (37, 53, ch), dtype=np.uint8)
+        img = Image.fromarray(a if ch > 1 else a[:, :, 0], "L" if ch == 1 else mode)
+        if mode == "P":
+            img = Image.fromarray(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), "RGB").quantize(64)
+        p_in, p_out = str(tmp_path / ("in_%s.png" % mode)), str(tmp_path / ("out_%s.png" % mode))
+        img.save(p_in)
+        for keep in ("0", "1"):
+            out = subprocess.check_output([exe, p_in, keep, p_out], text=True).split()
+            want_c = 4 if (keep == "1" and mode == "RGBA") else 3
+            assert [int(v) for v in out] == [53, 37, want_c]
+            got = np.asarray(Image.open(p_out))
+            want = np.asarray(img.convert("RGBA" if want_c == 4 else "RGB"))
+            assert np.array_equal(got, want), (mode, keep)
+
+
+def test_required_flags_and_unknown_flags():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "surround360_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "rig_json_file" in r.stderr  # requireArg order of TRSP:717
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown command line flag" in r.stderr
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--eqr_width" in r.stdout and "--prev_frame_data_dir" in r.stdout
