@@ -139,14 +139,104 @@ __device__ __forceinline__ float2 remap_cubic_f32c2_at(const float2* __restrict_
   return o;
 }
 
-__global__ __launch_bounds__(256) void k_remap_cubic_u8c4(const uchar4* __restrict__ src, int sw, int sh,
-                                                          const float2* __restrict__ map, uchar4* __restrict__ dst,
-                                                          int dw, int dh, const short* __restrict__ tab,
-                                                          int alpha_mode, int yFeatherStart, int featherSize) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dw || y >= dh) return;
-  const float2 m = map[(size_t)y * dw + x];
-  uchar4 o = remap_cubic_u8c4_at(src, sw, sh, m.x, m.y, tab);
+// ------------------------------------------------------------------------------------------
+// Tiled bicubic remap: one workgroup renders a 64x8 tile of the destination. The source taps of the tile lie in a
+// small box (the maps on this path are smooth); the box is found with wavefront min/max reductions of the tap
+// origins, loaded ONCE into LDS with coalesced row reads (zero outside the image = BORDER_CONSTANT(0), so the taps
+// need no bounds checks), and the 16 taps per pixel are LDS reads. Tiles whose box does not fit fall back to the
+// per-tap global gather. Integer arithmetic: the result does not depend on the summation order.
+constexpr int RT_W = 64, RT_H = 8, RT_CAP = 4608;
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+struct MapFromBuffer {  // bicubicRemapToSpherical: cached warp map (ImageWarper.cpp:151-173)
+  const float2* map;
+  int dw;
+  __device__ __forceinline__ float2 operator()(int x, int y) const { return map[(size_t)y * dw + x]; }
+};
+struct MapFromPoleFlow {  // poleToSideFlowThread's ramped warp (TRSP:483-503)
+  const float2* flow;
+  PoleWarpParams pw;
+  __device__ __forceinline__ float2 operator()(int x, int y) const {
+    const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
+    const float alpha = 1.0f - rampf(phi, pw.phiRampStart, pw.phiMid);
+    const float2 f = flow[(size_t)y * pw.extW + x];
+    return make_float2((float)x + (1.0f - alpha) * f.x, (float)y + (1.0f - alpha) * f.y);
+  }
+};
+
+template <class MapFn>
+__global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uchar4* __restrict__ src, int sw, int sh,
+                                                                       MapFn mapfn, uchar4* __restrict__ dst, int dw,
+                                                                       int dh, const short* __restrict__ tab,
+                                                                       int alpha_mode, int yFeatherStart,
+                                                                       int featherSize) {
+  __shared__ uchar4 s_tile[RT_CAP];
+  __shared__ int s_box[4];
+  const int x = blockIdx.x * RT_W + threadIdx.x, y = blockIdx.y * RT_H + threadIdx.y;
+  const int tid = threadIdx.y * RT_W + threadIdx.x;
+  const bool inside = x < dw && y < dh;
+  int sx = 0, sy = 0, fxy = 0;
+  bool live = false;
+  float2 m = make_float2(0.f, 0.f);
+  if (inside) {
+    m = mapfn(x, y);
+    remap_coord(m.x, m.y, &sx, &sy, &fxy);
+    live = !(sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0);
+  }
+  if (tid == 0) { s_box[0] = INT_MAX; s_box[1] = INT_MIN; s_box[2] = INT_MAX; s_box[3] = INT_MIN; }
+  const int mnx = wave_min_i(live ? sx : INT_MAX), mxx = wave_max_i(live ? sx : INT_MIN);
+  const int mny = wave_min_i(live ? sy : INT_MAX), mxy = wave_max_i(live ? sy : INT_MIN);
+  __syncthreads();
+  if ((tid & 63) == 0 && mnx <= mxx) {
+    atomicMin(&s_box[0], mnx); atomicMax(&s_box[1], mxx);
+    atomicMin(&s_box[2], mny); atomicMax(&s_box[3], mxy);
+  }
+  __syncthreads();
+  const int bx0 = s_box[0], by0 = s_box[2];
+  const bool any = bx0 <= s_box[1];
+  const int bw = any ? s_box[1] + 4 - bx0 : 0, bh = any ? s_box[3] + 4 - by0 : 0;
+  uchar4 o = make_uchar4(0, 0, 0, 0);
+  if (any && (long long)bw * bh <= RT_CAP) {
+    for (int ly = threadIdx.y; ly < bh; ly += RT_H) {
+      const int gy = by0 + ly;
+      const bool rowIn = gy >= 0 && gy < sh;
+      const uchar4* S = src + (size_t)(rowIn ? gy : 0) * sw;
+      for (int lx = threadIdx.x; lx < bw; lx += RT_W) {
+        const int gx = bx0 + lx;
+        s_tile[ly * bw + lx] = (rowIn && gx >= 0 && gx < sw) ? S[gx] : make_uchar4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (live) {
+      const short* w = tab + fxy * 16;
+      const uchar4* T = s_tile + (sy - by0) * bw + (sx - bx0);
+      int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uchar4 p = T[r * bw + q];
+          const int ww = w[r * 4 + q];
+          s0 += p.x * ww; s1 += p.y * ww; s2 += p.z * ww; s3 += p.w * ww;
+        }
+      }
+      o = make_uchar4((unsigned char)sat_u8((s0 + (1 << 14)) >> 15), (unsigned char)sat_u8((s1 + (1 << 14)) >> 15),
+                      (unsigned char)sat_u8((s2 + (1 << 14)) >> 15), (unsigned char)sat_u8((s3 + (1 << 14)) >> 15));
+    }
+  } else if (live) {
+    o = remap_cubic_u8c4_at(src, sw, sh, m.x, m.y, tab);
+  }
+  if (!inside) return;
   if (alpha_mode == 1) {
     // remap ran on 3 channels, cvtColor BGR2BGRA sets 255, the feather loop overwrites the last rows
     int a = 255;
@@ -240,25 +330,45 @@ __global__ __launch_bounds__(64) void k_novel_view(const uchar4* __restrict__ ov
 }
 
 // ------------------------------------------------------------------------------------------
+// offsetHorizontalWrap's source column (CvUtil.cpp:93-115): nearest remap with BORDER_WRAP
+__device__ __forceinline__ int wrap_src_col(int x, float offset, int W) {
+  float srcX = (float)x - offset;
+  if (srcX < 0) srcX += (float)W;
+  if (srcX >= (float)W) srcX -= (float)W;
+  int sx = sat_s16(cv_round(srcX));
+  if (sx < 0) sx -= ((sx - W + 1) / W) * W;
+  if (sx >= W) sx %= W;
+  return sx;
+}
+// 4 output pixels per thread: 4 source loads (adjacent except at strip seams / the wrap point), one 16-byte store.
 __global__ __launch_bounds__(256) void k_assemble_pano(const uchar4* __restrict__ strips, int P, int camH, int stripW,
                                                        float offset, uchar4* __restrict__ pano, int W, int H,
                                                        int padAbove) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
   if (x >= W) return;
-  uchar4 o = make_uchar4(0, 0, 0, 0);
   const int ys = y - padAbove;
-  if (ys >= 0 && ys < camH) {
-    // offsetHorizontalWrap (CvUtil.cpp:93-115): nearest remap with BORDER_WRAP
-    float srcX = (float)x - offset;
-    if (srcX < 0) srcX += (float)W;
-    if (srcX >= (float)W) srcX -= (float)W;
-    int sx = sat_s16(cv_round(srcX));
-    if (sx < 0) sx -= ((sx - W + 1) / W) * W;
-    if (sx >= W) sx %= W;
-    const int pair = sx / stripW, u = sx - pair * stripW;
-    o = strips[((size_t)pair * camH + ys) * stripW + u];
+  const bool rowIn = ys >= 0 && ys < camH;
+  uchar4 o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = make_uchar4(0, 0, 0, 0);
+  const int nvalid = min(4, W - x);
+  if (rowIn) {
+    int sx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sx[k] = wrap_src_col(min(x + k, W - 1), offset, W);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pk = sx[k] / stripW, uk = sx[k] - pk * stripW;
+      o[k] = strips[((size_t)pk * camH + ys) * stripW + uk];
+    }
   }
-  pano[(size_t)y * W + x] = o;
+  uchar4* D = pano + (size_t)y * W + x;
+  if (nvalid == 4 && (W & 3) == 0) {
+    *reinterpret_cast<uint4*>(D) = make_uint4(__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[1]),
+                                              __builtin_bit_cast(unsigned, o[2]), __builtin_bit_cast(unsigned, o[3]));
+  } else {
+    for (int k = 0; k < nvalid; ++k) D[k] = o[k];
+  }
 }
 __global__ __launch_bounds__(256) void k_flip_both(const uchar4* __restrict__ src, uchar4* __restrict__ dst, int w,
                                                    int h) {
@@ -322,18 +432,6 @@ __global__ __launch_bounds__(256) void k_extend_wrap(const uchar4* __restrict__ 
 }
 
 // ---- pole warp / finish ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pole_warp(const uchar4* __restrict__ extFisheye,
-                                                   const float2* __restrict__ flow, uchar4* __restrict__ warpedExt,
-                                                   PoleWarpParams pw, const short* __restrict__ tab) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= pw.extW) return;
-  const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
-  const float alpha = 1.0f - rampf(phi, pw.phiRampStart, pw.phiMid);
-  const float2 f = flow[(size_t)y * pw.extW + x];
-  const float wx = (float)x + (1.0f - alpha) * f.x;
-  const float wy = (float)y + (1.0f - alpha) * f.y;
-  warpedExt[(size_t)y * pw.extW + x] = remap_cubic_u8c4_at(extFisheye, pw.extW, pw.rows, wx, wy, tab);
-}
 __global__ __launch_bounds__(256) void k_pole_finish(const uchar4* __restrict__ warpedExt, uchar4* __restrict__ out,
                                                      int eqrH, PoleWarpParams pw) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -359,12 +457,7 @@ __global__ __launch_bounds__(256) void k_pole_finish(const uchar4* __restrict__ 
 }
 
 // flattenLayersDeghostPreferBase (CvUtil.cpp:224-260)
-__global__ __launch_bounds__(256) void k_flatten(const uchar4* __restrict__ base, const uchar4* __restrict__ top,
-                                                 uchar4* __restrict__ out, int w, int h, int flip_top, DevTables T) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  const uchar4 b = base[(size_t)y * w + x];
-  const uchar4 t = flip_top ? top[(size_t)(h - 1 - y) * w + (w - 1 - x)] : top[(size_t)y * w + x];
+__device__ __forceinline__ uchar4 flatten_px(uchar4 b, uchar4 t, const DevTables& T) {
   const int sdiff = abs((int)b.x - (int)t.x) + abs((int)b.y - (int)t.y) + abs((int)b.z - (int)t.z);
   const float deghostCoef = T.tanh5[sdiff];
   const float alphaR = (float)t.w / 255.0f;
@@ -377,7 +470,35 @@ __global__ __launch_bounds__(256) void k_flatten(const uchar4* __restrict__ base
   o.y = (unsigned char)trunc_u8((float)b.y * wL + (float)t.y * wR);
   o.z = (unsigned char)trunc_u8((float)b.z * wL + (float)t.z * wR);
   o.w = t.w > b.w ? t.w : b.w;
-  out[(size_t)y * w + x] = o;
+  return o;
+}
+__global__ __launch_bounds__(256) void k_flatten(const uchar4* __restrict__ base, const uchar4* __restrict__ top,
+                                                 uchar4* __restrict__ out, int w, int h, int flip_top, DevTables T) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const uchar4 b = base[(size_t)y * w + x];
+  const uchar4 t = flip_top ? top[(size_t)(h - 1 - y) * w + (w - 1 - x)] : top[(size_t)y * w + x];
+  out[(size_t)y * w + x] = flatten_px(b, t, T);
+}
+// w % 4 == 0: 4 pixels per thread, 16-byte loads and stores (the flipped top layer is read mirrored)
+__global__ __launch_bounds__(256) void k_flatten_v4(const uint4* __restrict__ base, const uint4* __restrict__ top,
+                                                    uint4* __restrict__ out, int w4, int h, int flip_top, DevTables T) {
+  const int x4 = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x4 >= w4) return;
+  const uint4 b = base[(size_t)y * w4 + x4];
+  uint4 t;
+  if (flip_top) {
+    const uint4 r = top[(size_t)(h - 1 - y) * w4 + (w4 - 1 - x4)];
+    t = make_uint4(r.w, r.z, r.y, r.x);
+  } else {
+    t = top[(size_t)y * w4 + x4];
+  }
+  uint4 o;
+  o.x = __builtin_bit_cast(unsigned, flatten_px(__builtin_bit_cast(uchar4, b.x), __builtin_bit_cast(uchar4, t.x), T));
+  o.y = __builtin_bit_cast(unsigned, flatten_px(__builtin_bit_cast(uchar4, b.y), __builtin_bit_cast(uchar4, t.y), T));
+  o.z = __builtin_bit_cast(unsigned, flatten_px(__builtin_bit_cast(uchar4, b.z), __builtin_bit_cast(uchar4, t.z), T));
+  o.w = __builtin_bit_cast(unsigned, flatten_px(__builtin_bit_cast(uchar4, b.w), __builtin_bit_cast(uchar4, t.w), T));
+  out[(size_t)y * w4 + x4] = o;
 }
 
 __global__ __launch_bounds__(256) void k_pack_bgr(const uchar4* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
@@ -476,9 +597,9 @@ void launch_spherical_map(hipStream_t st, float2* map, int dw, int dh, const Dev
 }
 void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, uchar4* dst, int dw,
                              int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize) {
-  dim3 blk(64, 4);
-  hipLaunchKernelGGL(k_remap_cubic_u8c4, dim3(cdiv(dw, 64), cdiv(dh, 4)), blk, 0, st, src, sw, sh, map, dst, dw, dh,
-                     T.bicubic_i, alpha_mode, yFeatherStart, featherSize);
+  MapFromBuffer mf{map, dw};
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromBuffer>), dim3(cdiv(dw, RT_W), cdiv(dh, RT_H)), dim3(RT_W, RT_H), 0,
+                     st, src, sw, sh, mf, dst, dw, dh, T.bicubic_i, alpha_mode, yFeatherStart, featherSize);
 }
 void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH, int P, int overlapW, uchar4* out,
                           int p0, int p1) {
@@ -496,7 +617,7 @@ void launch_novel_view(hipStream_t st, const uchar4* overlaps, const float2* flo
 void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int camH, int stripW, float offset,
                           uchar4* pano, int eqrW, int eqrH) {
   const int padAbove = (eqrH - camH) / 2;
-  hipLaunchKernelGGL(k_assemble_pano, dim3(cdiv(eqrW, 256), eqrH), dim3(256), 0, st, strips_eye, P, camH, stripW, offset,
+  hipLaunchKernelGGL(k_assemble_pano, dim3(cdiv(cdiv(eqrW, 4), 256), eqrH), dim3(256), 0, st, strips_eye, P, camH, stripW, offset,
                      pano, eqrW, eqrH, padAbove);
 }
 void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h) {
@@ -520,15 +641,21 @@ void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha,
 }
 void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
                       const PoleWarpParams& pw, const DevTables& T) {
-  hipLaunchKernelGGL(k_pole_warp, dim3(cdiv(pw.extW, 256), pw.rows), dim3(256), 0, st, extFisheye, flow, warpedExt, pw,
-                     T.bicubic_i);
+  MapFromPoleFlow mf{flow, pw};
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromPoleFlow>), dim3(cdiv(pw.extW, RT_W), cdiv(pw.rows, RT_H)),
+                     dim3(RT_W, RT_H), 0, st, extFisheye, pw.extW, pw.rows, mf, warpedExt, pw.extW, pw.rows, T.bicubic_i, 0,
+                     0, 1);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   hipLaunchKernelGGL(k_pole_finish, dim3(cdiv(pw.cols, 256), eqrH), dim3(256), 0, st, warpedExt, out, eqrH, pw);
 }
 void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar4* out, int w, int h, int flip_top,
                     const DevTables& T) {
-  hipLaunchKernelGGL(k_flatten, dim3(cdiv(w, 256), h), dim3(256), 0, st, base, top, out, w, h, flip_top, T);
+  if ((w & 3) == 0)
+    hipLaunchKernelGGL(k_flatten_v4, dim3(cdiv(w / 4, 256), h), dim3(256), 0, st, reinterpret_cast<const uint4*>(base),
+                       reinterpret_cast<const uint4*>(top), reinterpret_cast<uint4*>(out), w / 4, h, flip_top, T);
+  else
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(w, 256), h), dim3(256), 0, st, base, top, out, w, h, flip_top, T);
 }
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst) {
   const size_t n = (size_t)w * h;
