@@ -135,21 +135,33 @@ def main():
             dist.barrier()
 
     # ---- timed region: every rank renders K whole frames, up to F in flight (independent frames: no collective) ----
+    # One host thread per context: a frame is ~1500 kernel launches, and a single submitting thread caps the node
+    # at ~27 frames/s whatever the GPU does (ctypes releases the GIL inside libs360, the HIP runtime locks per stream).
+    from concurrent.futures import ThreadPoolExecutor
+    pools = [ThreadPoolExecutor(max_workers=1) for _ in range(F)]
     counter = [0]
+    futures = []
 
     def step():
-        ctxs[counter[0] % F].render(False)  # asynchronous enqueue on that context's stream
+        k = counter[0] % F
+        futures.append(pools[k].submit(ctxs[k].render, False))  # asynchronous enqueue on that context's stream
         counter[0] += 1
+
+    def drain():
+        for f in futures:
+            f.result()
+        del futures[:]
+        sync()
 
     for _ in range(args.warmup):
         step()
-    sync()
+    drain()
     for c in ctxs:
         c.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync()
+    drain()
     dt = time.perf_counter() - t0
     prof = {}
     for c in ctxs:

@@ -207,6 +207,11 @@ int s360_set_keep_intermediates(s360_ctx* ctx, int on);
 int s360_debug_flow_levels(s360_ctx* ctx, const char* alg, const uint8_t* i0_bgra, const uint8_t* i1_bgra, int w, int h,
                            int hint, float* levels_out, size_t cap_floats, int* n_levels);
 
+/* Which sweep kernel PixFlow's propagation uses: "latency" (default) finishes ONE flow soonest; "throughput"
+ * spends ~4x fewer instructions per pixel and is the right choice when several frames / contexts are in flight on
+ * the GPU. Results are bit-identical. */
+int s360_set_sweep_mode(s360_ctx* ctx, const char* mode);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Per-kernel-family device time of the last frame/flow call measured with HIP events on the context
  * stream, when enabled. names_out receives a ';'-separated list matching ms_out entries. */

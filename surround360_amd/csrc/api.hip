@@ -158,7 +158,7 @@ int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams,
     c->top_idx = c->rig.find_by_direction(up);
     c->bottom_idx = c->rig.find_by_direction(down);
     if (c->bottom_idx >= 0) c->ramp = pole_ramp(c->rig);
-    c->flow.reset(new FlowEngine(&c->prof));
+    { c->flow.reset(new FlowEngine(&c->prof)); c->flow->set_sweep_mode(c->sweep_mode); }
   });
   if (rc != S360_OK) {
     delete c;
@@ -377,7 +377,7 @@ int s360_pole_to_side_flow(s360_ctx* c, const uint8_t* side, const uint8_t* pole
     uchar4* ext = c->op_c.as<uchar4>();
     dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), W, pole_rows, ext, extW);
     launch_extend_wrap(c->st, c->op_b.as<uchar4>(), nullptr, W, pole_rows, ext + xn, extW);
-    if (!c->flow_pole) c->flow_pole.reset(new FlowEngine(&c->prof));
+    if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
     FlowIdx idx;
     std::memset(&idx, 0, sizeof(idx));
     idx.i0[0] = 0; idx.i1[0] = 1;
@@ -568,6 +568,18 @@ int s360_frame_get_f32(s360_ctx* c, const char* name, int idx, int whc[3], float
     }
     whc[0] = w; whc[1] = h; whc[2] = 2;
     if (dst) d2h(c, dst, src, (size_t)w * h * sizeof(float2));
+  });
+}
+
+int s360_set_sweep_mode(s360_ctx* c, const char* mode) {
+  return guard(c, [&] {
+    need(c && mode, "bad argument");
+    const std::string m(mode);
+    if (m == "latency") c->sweep_mode = 2;
+    else if (m == "throughput") c->sweep_mode = 3;
+    else throw Error(S360_ERR_INVALID_ARG, "sweep mode must be \"latency\" or \"throughput\"");
+    if (c->flow) c->flow->set_sweep_mode(c->sweep_mode);
+    if (c->flow_pole) c->flow_pole->set_sweep_mode(c->sweep_mode);
   });
 }
 

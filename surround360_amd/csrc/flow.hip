@@ -84,14 +84,16 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   full_.ensure((size_t)B * w * h * sizeof(float2));
   if (sweep_mode_ < 0) {
     const char* e = std::getenv("S360_SWEEP");  // debugging/A-B knob: "diag" = v1 kernel, "hex" = v2 hex16 kernel
-    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : 2;
+    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : (e && std::string(e) == "quad") ? 3 : 2;
+    sweep_env_forced_ = e != nullptr;
     const char* n = std::getenv("S360_SWEEP_NW");
     sweep_nw_ = (n && std::atoi(n) == 8) ? 8 : 4;
     const char* d = std::getenv("S360_SWEEP_DIV");  // "ieee" disables the verified fast division / sqrt
     sweep_fast_ = !(d && std::string(d) == "ieee");
   }
+  if (!sweep_env_forced_ && requested_mode_ >= 0) sweep_mode_ = requested_mode_;
   bool fastOk = false;
-  if (sweep_mode_ == 2 && sweep_fast_) {
+  if (sweep_mode_ >= 2 && sweep_fast_) {
     std::vector<float> divs;
     divs.push_back(0.001f);
     for (int l = 0; l < L; ++l) {
@@ -102,7 +104,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   }
   if (sweep_mode_ >= 1) {
     rec_.ensure(B * n0 * sizeof(float4));
-    handoff_.ensure(std::max(sweep_handoff_bytes(dw_, dh_, B), sweep_lock_handoff_bytes(dw_, dh_, B, 4)));
+    handoff_.ensure(std::max(std::max(sweep_handoff_bytes(dw_, dh_, B), sweep_lock_handoff_bytes(dw_, dh_, B, 4)),
+                             sweep_quad_handoff_bytes(dw_, dh_, B)));
     if (!err_.p) {
       err_.ensure(sizeof(unsigned));
       S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
@@ -186,9 +189,14 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       ProfScope ps(P, "flow_records");
       launch_make_records(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), rec_.as<float4>(), nl, B, idx);
     }
+    static const bool skipSweep = std::getenv("S360_DEBUG_SKIP_SWEEP") != nullptr;  // timing experiments only
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
-      if (sweep_mode_ == 2)
+      if (skipSweep) return;
+      if (sweep_mode_ == 3)
+        launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B, idx,
+                          dir, pc, fastOk);
+      else if (sweep_mode_ == 2)
         launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
                           idx, dir, pc, sweep_nw_, fastOk);
       else if (sweep_mode_ == 1)

@@ -47,11 +47,15 @@ class FlowEngine {
   int dw_ = 0, dh_ = 0;
   DevBuf down_, prevdown_, gray_, pyrI_, pyrA_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
       motionPyr_, I1eq_, rec_, handoff_, err_;
-  int sweep_mode_ = -1;  // 0: v1 one-workgroup diagonal kernel, 1: v2 hex16 banded kernel, 2: lockstep kernel (default)
+  int sweep_mode_ = -1;  // 0: v1 diagonal kernel, 1: v2 hex16 kernel, 2: lockstep kernel (latency, default), 3: quad (throughput)
+  bool sweep_env_forced_ = false;
   int sweep_nw_ = 4;     // compute waves per workgroup of the lockstep kernel
   bool sweep_fast_ = true;
+  int requested_mode_ = -1;
 
  public:
+  // 2 = lockstep (lowest latency of one flow), 3 = quad (highest chip-wide rate); ignored when S360_SWEEP is set
+  void set_sweep_mode(int m) { requested_mode_ = m; }
   // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag
   unsigned take_error(hipStream_t st);
 

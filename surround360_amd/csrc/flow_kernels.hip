@@ -251,28 +251,36 @@ __global__ __launch_bounds__(256) void k_sobel(const float* __restrict__ I, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// medianBlur(5) on CV_32FC2, replicate border (PixFlow.h:398,411): exact per-channel median of
-// 25 by forgetful selection (drop min and max of a shrinking working set).
+// medianBlur(5) on CV_32FC2, replicate border (PixFlow.h:398,411): exact per-channel median of 25.
 __device__ __forceinline__ void mnmx(float& a, float& b) {
   const float lo = fminf(a, b), hi = fmaxf(a, b);
   a = lo;
   b = hi;
 }
-__device__ __forceinline__ float median25(const float* v) {
-  // Forgetful selection: a working set of 14 can never contain the median as its min or max;
-  // drop both, insert the next sample into the freed slot, repeat until 3 remain.
-  float ws[14];
+// Exact median of 25 with the 99-comparator selection network of Devillard's "Fast median search" (after Paeth,
+// Graphics Gems): verified for all 2^25 0/1 inputs (0-1 principle), tools/verify_median_network.py. Comparators
+// whose outputs are never read again are removed by the compiler.
+__device__ __forceinline__ float median25(const float* in) {
+  float p[25];
 #pragma unroll
-  for (int i = 0; i < 14; ++i) ws[i] = v[i];
-#pragma unroll
-  for (int n = 14; n >= 3; --n) {
-#pragma unroll
-    for (int i = 1; i < n; ++i) mnmx(ws[0], ws[i]);
-#pragma unroll
-    for (int i = 1; i < n - 1; ++i) mnmx(ws[i], ws[n - 1]);
-    if (n > 3) ws[0] = v[14 + (14 - n)];
-  }
-  return ws[1];
+  for (int i = 0; i < 25; ++i) p[i] = in[i];
+#define S360_CE(a, b) mnmx(p[a], p[b])
+  S360_CE(0, 1); S360_CE(3, 4); S360_CE(2, 4); S360_CE(2, 3); S360_CE(6, 7); S360_CE(5, 7); S360_CE(5, 6); S360_CE(9, 10);
+  S360_CE(8, 10); S360_CE(8, 9); S360_CE(12, 13); S360_CE(11, 13); S360_CE(11, 12); S360_CE(15, 16); S360_CE(14, 16);
+  S360_CE(14, 15); S360_CE(18, 19); S360_CE(17, 19); S360_CE(17, 18); S360_CE(21, 22); S360_CE(20, 22); S360_CE(20, 21);
+  S360_CE(23, 24); S360_CE(2, 5); S360_CE(3, 6); S360_CE(0, 6); S360_CE(0, 3); S360_CE(4, 7); S360_CE(1, 7); S360_CE(1, 4);
+  S360_CE(11, 14); S360_CE(8, 14); S360_CE(8, 11); S360_CE(12, 15); S360_CE(9, 15); S360_CE(9, 12); S360_CE(13, 16);
+  S360_CE(10, 16); S360_CE(10, 13); S360_CE(20, 23); S360_CE(17, 23); S360_CE(17, 20); S360_CE(21, 24); S360_CE(18, 24);
+  S360_CE(18, 21); S360_CE(19, 22); S360_CE(8, 17); S360_CE(9, 18); S360_CE(0, 18); S360_CE(0, 9); S360_CE(10, 19);
+  S360_CE(1, 19); S360_CE(1, 10); S360_CE(11, 20); S360_CE(2, 20); S360_CE(2, 11); S360_CE(12, 21); S360_CE(3, 21);
+  S360_CE(3, 12); S360_CE(13, 22); S360_CE(4, 22); S360_CE(4, 13); S360_CE(14, 23); S360_CE(5, 23); S360_CE(5, 14);
+  S360_CE(15, 24); S360_CE(6, 24); S360_CE(6, 15); S360_CE(7, 16); S360_CE(7, 19); S360_CE(13, 21); S360_CE(15, 23);
+  S360_CE(7, 13); S360_CE(7, 15); S360_CE(1, 9); S360_CE(3, 11); S360_CE(5, 17); S360_CE(11, 17); S360_CE(9, 17);
+  S360_CE(4, 10); S360_CE(6, 12); S360_CE(7, 14); S360_CE(4, 6); S360_CE(4, 7); S360_CE(12, 14); S360_CE(10, 14);
+  S360_CE(6, 7); S360_CE(10, 12); S360_CE(6, 10); S360_CE(6, 17); S360_CE(12, 17); S360_CE(7, 17); S360_CE(7, 10);
+  S360_CE(12, 18); S360_CE(7, 12); S360_CE(10, 18); S360_CE(12, 20); S360_CE(10, 20); S360_CE(10, 12);
+#undef S360_CE
+  return p[12];
 }
 __global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ src, float2* __restrict__ dst, int w,
                                                     int h, size_t bs) {

@@ -247,7 +247,7 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
     // NovelViewGeneratorAsymmetricFlow::prepare (NovelView.cpp:270-299): flowLtoR = flow(I0=L, I1=R, LEFT),
     // flowRtoL = flow(I0=R, I1=L, RIGHT). Both hints only matter for pixflow_search_20; the batch is split by
     // hint in that case.
-    if (!c->flow) c->flow.reset(new FlowEngine(&c->prof));
+    if (!c->flow) { c->flow.reset(new FlowEngine(&c->prof)); c->flow->set_sweep_mode(c->sweep_mode); }
     const PixFlowConsts pc = pixflow_consts_by_name(c->P.side_flow_alg);
     FlowIdx idx;
     std::memset(&idx, 0, sizeof(idx));
@@ -396,7 +396,7 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
     }
     {
       // computeOpticalFlow(extendedSide, extendedFisheye, ..., DOWN) for every enabled unit (TRSP:438-448)
-      if (!c->flow_pole) c->flow_pole.reset(new FlowEngine(&c->prof));
+      if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
       const PixFlowConsts pc = pixflow_consts_by_name(c->P.polar_flow_alg);
       int u = 0;
       while (u < 4) {

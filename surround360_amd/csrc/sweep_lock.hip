@@ -86,61 +86,6 @@ __device__ __forceinline__ float from_row_above(float old, float v) {
                                                               0x142, 0xE, BANKS, false));
 }
 
-// Correctly rounded x / c for a divisor known in advance (Markstein's sequence): q = RN(x*rc), r = x - q*c (exact
-// in one FMA), q' = RN(q + r*rc), with rc = RN(1/c). For the (c, rc) pairs this kernel is launched with, the
-// result has been checked on the device against the IEEE division for every float significand
-// (k_verify_div below); that covers every x whose intermediates stay normal, i.e. x == 0 or |x| >= 2^-96 —
-// smaller non-zero numerators take the IEEE path (see `tiny`).
-__device__ __forceinline__ float fdiv_m(float x, float c, float rc) {
-  const float q = x * rc;
-  const float r = __builtin_fmaf(-q, c, x);
-  return __builtin_fmaf(r, rc, q);
-}
-// Correctly rounded sqrtf for x == 0 or x >= 2^-96: v_sqrt_f32 (1 ulp) + the two-sided residual fix-up that the
-// compiler's own IEEE expansion uses, without its denormal pre-scaling.
-__device__ __forceinline__ float sqrt_cr(float x) {
-  float s = __builtin_amdgcn_sqrtf(x);
-  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
-  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
-  s = (rm <= 0.0f) ? sm : s;
-  s = (rp > 0.0f) ? sp : s;
-  return s;
-}
-// key for the "tiny non-zero" test of a non-negative float: bits - 1 (0 wraps to 0xFFFFFFFF, NaN/inf are large)
-__device__ __forceinline__ unsigned tiny_key(float v) { return __float_as_uint(v) - 1u; }
-constexpr unsigned kTinyBits = 0x0F800000u;  // 2^-96
-
-struct SweepFast {  // reciprocals of the three divisors of the sweep, verified on the device
-  float rcCols, rcRows, rcEps;
-  int dbg;  // timing experiments only (results invalid when non-zero): 1 no granule polls, 2 no publish, 4 no prefetch,
-            // 8 no bulk events, 16 no compute body
-};
-
-// errorFunction (PixFlow.h:493-534) with the verified fast divisions / square roots. Sets tinyFlag when an
-// operand falls outside their proven range (the caller then re-evaluates with the IEEE expansion).
-__device__ __forceinline__ float error_fast(const Texels& t, float xR, float yR, float g0x, float g0y, float bfx,
-                                            float bfy, float fdx, float fdy, const SweepConst& c, const SweepFast& fc,
-                                            bool& tinyFlag) {
-  float i1x, i1y;
-  {
-    const float a1 = t.r0.x, a2 = t.r0.z - t.r0.x, a3 = t.r1.x - t.r0.x, a4 = t.r0.x + t.r1.z - t.r0.z - t.r1.x;
-    i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
-  }
-  {
-    const float a1 = t.r0.y, a2 = t.r0.w - t.r0.y, a3 = t.r1.y - t.r0.y, a4 = t.r0.y + t.r1.w - t.r0.w - t.r1.y;
-    i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
-  }
-  const float dfx = bfx - fdx, dfy = bfy - fdy;
-  const float sm2 = dfx * dfx + dfy * dfy;
-  const float smoothness = sqrt_cr(sm2);
-  const float ex = g0x - i1x, ey = g0y - i1y;
-  const float d2 = ex * ex + ey * ey;
-  const float vn = c.vertCoef * fabsf(fdy), hn = c.horizCoef * fabsf(fdx);
-  const unsigned key = min(min(tiny_key(sm2), tiny_key(d2)), min(tiny_key(vn), tiny_key(hn)));
-  tinyFlag = key < kTinyBits - 1u;
-  return sqrt_cr(d2) + smoothness * c.smoothnessCoef + fdiv_m(vn, c.fcols, fc.rcCols) + fdiv_m(hn, c.frows, fc.rcRows);
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_verify_div(const float* __restrict__ cs, unsigned* __restrict__ bad) {

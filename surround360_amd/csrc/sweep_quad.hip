@@ -1,0 +1,240 @@
+// sweep_quad.hip — throughput-oriented PixFlow propagation sweep for gfx950 ("quad").
+//
+// Same recurrence and same results as sweep_lock.hip (PixFlow.h:388-410), arranged for many flows / frames in
+// flight instead of for the latency of one flow. The sweeps are VALU-issue bound when the chip is full (rocprofv3:
+// the lockstep kernel spends ~42 VALU instructions per pixel update, 16 lanes per pixel, 9 speculative
+// evaluations), so this variant minimises instructions per pixel:
+//   * 4 lanes per pixel, 16 rows per wave (row r handles column s - r at step s);
+//   * the reference's two dependent rounds are kept: round 1 evaluates the current / left / up proposals in lanes
+//     0..2 of the quad, round 2 the two finite-difference probes of the winner in lanes 0..1 — 5 evaluations instead
+//     of 9, ~11 VALU instructions per pixel;
+//   * no service waves, no barriers: a workgroup is ONE wave that loads its own inputs one step ahead and stores its
+//     own results; other resident waves cover its memory latency. Left neighbour = registers, up neighbour = DPP
+//     (row_shr:4 / row_bcast:15), a band's first row takes the last row of the band above from 8-byte {fx,fy}
+//     granules in global memory (all-ones = not written; bands are ticketed in band-major order, spins are bounded).
+// A step is two gather rounds deep, so a single flow runs ~2x slower than with sweep_lock.hip; the chip-wide rate
+// is what improves. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+#include "devmath.hpp"
+#include "sweep_common.hpp"
+
+namespace s360 {
+
+namespace {
+
+constexpr unsigned long long kEmptyGranuleQ = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kQRows = 16;   // rows per wave
+constexpr int kUpRing = 64;  // columns of the band above kept in LDS
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {  // value of lane K of this lane's quad
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true));
+}
+// previous result of the row above: lane - 4. Inside a 16-lane DPP row that is row_shr:4 (banks 1..3); the first
+// quad of DPP rows 1..3 takes lane 15 of the previous DPP row (row_bcast:15, bank 0); the first quad of the wave
+// (row 0 of the band) keeps `old` = the granule-fed value.
+__device__ __forceinline__ float from_row_above_q(float old, float v) {
+  int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x114, 0xF, 0xE, false);
+  r = __builtin_amdgcn_update_dpp(r, __builtin_bit_cast(int, v), 0x142, 0xE, 0x1, false);
+  return __builtin_bit_cast(float, r);
+}
+
+}  // namespace
+
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ rec, const float2* __restrict__ G,
+                                                   float2* __restrict__ flow, unsigned long long* __restrict__ H,
+                                                   unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
+                                                   int dir, SweepConst c, SweepFast fc, int nb, int B,
+                                                   unsigned* __restrict__ errflag) {
+  __shared__ float2 s_up[kUpRing];
+  __shared__ unsigned s_ticket;
+  const int lane = threadIdx.x;
+  if (lane == 0) s_ticket = atomicAdd(hdr, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
+  __syncthreads();
+  const unsigned tk = s_ticket;
+  const int band = (int)(tk / (unsigned)B), b = (int)(tk - (unsigned)band * (unsigned)B);
+  if (band >= nb) return;
+  const float2* __restrict__ G1 = G + bs * idx.i1[b];
+  const char* __restrict__ G1b0 = reinterpret_cast<const char*>(G1);
+  const char* __restrict__ G1b1 = reinterpret_cast<const char*>(G1 + w);
+  rec += bs * b;
+  flow += bs * b;
+  H += (size_t)b * nb * w;
+  const unsigned long long* Hin = H + (size_t)band * w;
+  unsigned long long* Hout = H + (size_t)(band + 1) * w;
+  const int r = lane >> 2, q = lane & 3;
+  const int yi = band * kQRows + r;
+  const bool rowValid = yi < h;
+  const int yic = rowValid ? yi : h - 1;
+  const int y = dir > 0 ? yic : h - 1 - yic;
+  const bool hasUp = yi > 0;
+  const bool hasUpBand = band > 0;
+  const bool publishLane = band + 1 < nb && r == kQRows - 1 && q == 0;
+  const float4* __restrict__ recRow = rec + (size_t)y * w;
+  float2* __restrict__ flowRow = flow + (size_t)y * w;
+  const float fy = (float)y;
+  const float kEps = 0.001f, kInf = __int_as_float(0x7f800000);
+  const int nsteps = w + kQRows - 1;
+  auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
+
+  // errorFunction at (x + ax, y + ay) for this lane's pixel (PixFlow.h:493-534)
+  auto evaluate = [&](int x, float4 rc, float ax, float ay) -> float {
+    const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
+    const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
+    const int x0 = (int)mx, y0 = (int)my;
+    const float xR = __builtin_amdgcn_fractf(mx), yR = __builtin_amdgcn_fractf(my);
+    const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+    const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
+    const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
+    Texels tt;
+    tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+    tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+    Foot ft;
+    ft.off = 0; ft.xR = xR; ft.yR = yR;
+    float e;
+    if (FAST) {
+      bool tiny;
+      e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
+      if (__builtin_expect(__ballot(tiny) != 0ull, 0)) e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+    } else {
+      e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+    }
+    return e;
+  };
+
+  // ---- granules of the band above -> s_up ring (columns [upFilled - kUpRing, upFilled) are valid) ----
+  int upFilled = hasUpBand ? 0 : 0x3fffffff, pendS = -100;
+  bool pending = false, dead = false;
+  unsigned long long pv = kEmptyGranuleQ;
+  auto issue = [&](int s) {
+    const int xi = upFilled + lane;
+    pv = kEmptyGranuleQ;
+    if (xi < w) pv = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pending = true;
+    pendS = s;
+  };
+  auto process = [&](int s) {  // leading run of written granules; never overwrites columns >= s that are still needed
+    const int xi = upFilled + lane;
+    const unsigned long long bad = __ballot(xi >= w || (pv == kEmptyGranuleQ && !dead));
+    int n = bad ? (int)__ffsll((long long)bad) - 1 : 64;
+    n = min(n, s + kUpRing - upFilled);
+    if (n > 0) {
+      if (lane < n)
+        s_up[xi & (kUpRing - 1)] = make_float2(__uint_as_float((unsigned)pv), __uint_as_float((unsigned)(pv >> 32)));
+      upFilled = __builtin_amdgcn_readfirstlane(upFilled + n);
+    }
+    pending = false;
+  };
+
+  float2 fl = make_float2(0.f, 0.f);  // result of the previous pixel of this row (same in the 4 lanes of the quad)
+  float4 nrc;
+  float2 nfo;
+  {
+    const int x0c = col(0 - r);
+    nrc = recRow[x0c];
+    nfo = flowRow[x0c];
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const float4 rc = nrc;
+    const float2 fo = nfo;
+    {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
+      const int xn = col(s + 1 - r);
+      nrc = recRow[xn];
+      nfo = flowRow[xn];
+    }
+    if (hasUpBand && s < w) {
+      if (pending && (s - pendS >= 2 || upFilled <= s)) process(s);
+      unsigned spins = 0;
+      while (upFilled <= s) {  // row 0 needs column s now
+        if (!pending) issue(s);
+        process(s);
+        if (upFilled <= s) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 21) ||
+              ((spins & 1023u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
+            if (lane == 0) atomicExch(errflag, 1u);
+          }
+        }
+      }
+      if (!pending && upFilled < w && upFilled - s < 40) issue(s);
+    }
+    const float2 upl = s_up[s & (kUpRing - 1)];
+    const int xi = s - r;
+    const bool active = rowValid && xi >= 0 && xi < w;
+    const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
+    const bool upd = rc.x == rc.x;
+    float2 up;
+    up.x = from_row_above_q(upl.x, fl.x);
+    up.y = from_row_above_q(upl.y, fl.y);
+    // round 1: the three proposals (PixFlow.h:390-393 / 403-406), lanes 0..2 of the quad
+    const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
+    const float e = evaluate(x, rc, cand.x + 0.0f, cand.y + 0.0f);
+    const float e0 = quad_bcast<0>(e);
+    float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
+    if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column
+    if (!hasUp) e2 = kInf;     // no up proposal in the first row
+    float2 f = fo;
+    float cur = e0;
+    if (e1 < cur) { f = fl; cur = e1; }
+    if (e2 < cur) { f = up; cur = e2; }
+    // round 2: errorGradient's probes of the winner (PixFlow.h:195-217), lanes 0..1
+    const float pe = evaluate(x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f));
+    const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
+    const float nx = ex - cur, ny = ey - cur;
+    float ggx, ggy;
+    if (FAST) {
+      ggx = fdiv_m(nx, kEps, fc.rcEps);
+      ggy = fdiv_m(ny, kEps, fc.rcEps);
+      const bool tiny = min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
+      if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
+        ggx = nx / kEps;
+        ggy = ny / kEps;
+      }
+    } else {
+      ggx = nx / kEps;
+      ggy = ny / kEps;
+    }
+    float2 res;
+    res.x = f.x - c.gradStep * ggx;
+    res.y = f.y - c.gradStep * ggy;
+    const bool take = active && upd;
+    const float2 alt = active ? fo : fl;
+    res.x = take ? res.x : alt.x;
+    res.y = take ? res.y : alt.y;
+    fl = res;
+    if (active && q == 0) flowRow[x] = res;
+    if (publishLane && active)
+      __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(res.y) << 32) | __float_as_uint(res.x),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ==========================================================================================
+int sweep_quad_num_bands(int h) { return (h + kQRows - 1) / kQRows; }
+size_t sweep_quad_handoff_bytes(int w, int h, int B) {
+  return 256 + (size_t)B * sweep_quad_num_bands(h) * w * sizeof(unsigned long long);
+}
+void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
+                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
+                       const PixFlowConsts& pc, bool fast) {
+  const SweepConst c = make_sweep_const(pc, w, h);
+  SweepFast fc;
+  fc.rcCols = 1.0f / c.fcols;
+  fc.rcRows = 1.0f / c.frows;
+  fc.rcEps = 1.0f / 0.001f;
+  fc.dbg = 0;
+  const int nb = sweep_quad_num_bands(h);
+  (void)hipMemsetAsync(handoff, 0xFF, sweep_quad_handoff_bytes(w, h, B), st);
+  unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
+  unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
+  if (fast)
+    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(nb * B), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+                       fc, nb, B, errflag);
+  else
+    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(nb * B), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+                       fc, nb, B, errflag);
+}
+
+}  // namespace s360

@@ -245,6 +245,10 @@ class Context:
         self._ck(lib().s360_frame_download_equirect(self.h, _p(out)))
         return out
 
+    def set_sweep_mode(self, mode):
+        """'latency' (default) or 'throughput' — which sweep kernel PixFlow uses (bit-identical results)."""
+        self._ck(lib().s360_set_sweep_mode(self.h, mode.encode()))
+
     def keep_intermediates(self, on=True):
         self._ck(lib().s360_set_keep_intermediates(self.h, int(on)))
 

@@ -77,3 +77,34 @@ def test_identical_images_near_zero_flow(ctx):
     i0, _ = synth.flow_pair(192, 192, seed=9)
     f = ctx.compute_optical_flow(i0, i0)
     assert np.abs(f).max() < 0.5
+
+
+@pytest.mark.parametrize("mode", ["throughput", "latency"])
+def test_sweep_modes_bit_exact(gpu_rig, oracle, mode):
+    """Both sweep kernels (lockstep = latency, quad = throughput) reproduce the raster-order sweeps exactly,
+    including sizes that are not multiples of the band height and the temporal path."""
+    c = R.Context(gpu_rig, R.make_params(eqr_width=1008, eqr_height=504))
+    c.set_sweep_mode(mode)
+    try:
+        for (w, h, seed) in [(297, 444, 2), (333, 257, 5), (160, 130, 9)]:
+            i0, i1 = synth.flow_pair(w, h, seed=seed)
+            got = c.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+            want = oracle.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+            assert np.array_equal(bits(got), bits(want)), "%s %dx%d: max abs diff %g" % (mode, w, h, np.abs(got - want).max())
+        with pytest.raises(R.S360Error):
+            c.set_sweep_mode("fastest")
+    finally:
+        c.close()
+
+
+def test_ieee_division_path_bit_exact(gpu_rig, oracle, monkeypatch):
+    """S360_SWEEP_DIV=ieee disables the verified fast division / sqrt of the sweep kernels: same bits."""
+    monkeypatch.setenv("S360_SWEEP_DIV", "ieee")
+    c = R.Context(gpu_rig, R.make_params(eqr_width=1008, eqr_height=504))
+    try:
+        i0, i1 = synth.flow_pair(200, 168, seed=3)
+        got = c.compute_optical_flow(i0, i1, "pixflow_low", "RIGHT")
+        want = oracle.compute_optical_flow(i0, i1, "pixflow_low", "RIGHT")
+        assert np.array_equal(bits(got), bits(want))
+    finally:
+        c.close()

@@ -11,6 +11,7 @@
 
 #include "../surround360_amd/csrc/flow_kernels.hip"
 #include "../surround360_amd/csrc/sweep_lock.hip"
+#include "../surround360_amd/csrc/sweep_quad.hip"
 
 using namespace s360;
 
@@ -95,7 +96,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<void*> hand(NS);
   std::vector<unsigned*> err(NS);
   std::vector<hipStream_t> st(NS);
-  const size_t hb = std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4));
+  const size_t hb = std::max(std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4)), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
     CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
@@ -110,7 +111,9 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<float> d{0.001f, (float)w, (float)h};
   sweep_verify_divisors(st[0], d);
   auto once = [&](int k, int dir) {
-    if (mode == 2)
+    if (mode == 3)
+      launch_sweep_quad(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+    else if (mode == 2)
       launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, 4, true);
     else
       launch_sweep_band(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc);
@@ -127,14 +130,19 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 5 && std::string(argv[1]) == "tp1") {  // one configuration (for rocprofv3 --pmc runs): w h B streams
+    const int w = atoi(argv[2]), h = atoi(argv[3]), B = atoi(argv[4]), ns = atoi(argv[5]);
+    printf("lock %dx%d B=%d streams=%d: %.2f Gpx/s\n", w, h, B, ns, throughput(w, h, B, 2, ns, 4));
+    return 0;
+  }
   if (argc > 1 && std::string(argv[1]) == "tp") {
     printf("saturated sweep throughput, Gpx/s (one px = one pixel update of one sweep)\n");
     struct C2 { int w, h, B; const char* name; };
     const C2 cs[] = {{5040, 1052, 4, "polar L0"}, {607, 884, 28, "side L0"}, {1153, 240, 4, "polar L14"}, {140, 203, 28, "side L14"}};
     for (const C2& c : cs)
       for (int ns : {1, 2, 4, 8}) {
-        printf("%-10s B=%2d streams=%d : hex16 %7.2f   lock %7.2f\n", c.name, c.B, ns, throughput(c.w, c.h, c.B, 1, ns, 4),
-               throughput(c.w, c.h, c.B, 2, ns, 4));
+        printf("%-10s B=%2d streams=%d : hex16 %7.2f   lock %7.2f   quad %7.2f\n", c.name, c.B, ns, throughput(c.w, c.h, c.B, 1, ns, 4),
+               throughput(c.w, c.h, c.B, 2, ns, 4), throughput(c.w, c.h, c.B, 3, ns, 4));
         fflush(stdout);
       }
     return 0;
