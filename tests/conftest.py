@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch (test plumbing only) must load its HIP runtime before libs360.so does, or torch.cuda finds no device
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -118,3 +118,33 @@ def test_sharded_pairs_equal_single(setup):
     c2.finish(15)
     _cmp("sharded output", c2.download_equirect(), setup["got"])
     c2.close()
+
+
+def test_strip_buffer_view_for_the_gather(setup):
+    """parallel.strips_tensor aliases the context's strip buffers (zero copy): what the RCCL strip gather writes
+    into is what s360_frame_finish assembles. Checked by zeroing one pair's strips through the torch view."""
+    import torch
+    from surround360_amd import parallel
+    rig = R.RigDescription(setup["path"])
+    c2 = R.Context(rig, R.make_params(**setup["flags"]))
+    try:
+        c2.upload_frame(setup["side"], setup["top"], setup["bottom"])
+        c2.render_pairs(0, 14)
+        c2.synchronize()
+        dev = torch.device("cuda", 0)
+        strips = parallel.strips_tensor(c2, dev)
+        g = c2.geometry
+        assert tuple(strips.shape) == (2, 14, g.cam_image_height, setup["flags"]["eqr_width"] // 14, 4)
+        ptr, _ = c2.strip_ptr(0)
+        assert strips.data_ptr() == ptr
+        ext = torch.cuda.ExternalStream(c2.stream, device=dev)
+        with torch.cuda.stream(ext):
+            strips[:, 3].zero_()
+        c2.finish(15)
+        out = c2.download_equirect()
+        ref = setup["got"]
+        assert out.shape == ref.shape
+        assert (out != ref).any(), "zeroing a pair's strips through the torch view must change the panorama"
+        # and with nothing touched the sharded path reproduces the single-GPU frame (test_sharded_pairs_equal_single)
+    finally:
+        c2.close()

@@ -131,8 +131,8 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
 
 int main(int argc, char** argv) {
   if (argc > 5 && std::string(argv[1]) == "tp1") {  // one configuration (for rocprofv3 --pmc runs): w h B streams
-    const int w = atoi(argv[2]), h = atoi(argv[3]), B = atoi(argv[4]), ns = atoi(argv[5]);
-    printf("lock %dx%d B=%d streams=%d: %.2f Gpx/s\n", w, h, B, ns, throughput(w, h, B, 2, ns, 4));
+    const int w = atoi(argv[2]), h = atoi(argv[3]), B = atoi(argv[4]), ns = atoi(argv[5]), md = argc > 6 ? atoi(argv[6]) : 2;
+    printf("mode %d %dx%d B=%d streams=%d: %.2f Gpx/s\n", md, w, h, B, ns, throughput(w, h, B, md, ns, 4));
     return 0;
   }
   if (argc > 1 && std::string(argv[1]) == "tp") {
