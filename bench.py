@@ -91,15 +91,15 @@ WARP_BLEND_MB = {"project_side": 176 + 180, "project_pole": 2 * 12.6 + 141, "nov
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", default="8k", choices=["8k", "2k"], help="2k is a debugging aid, not a bench config")
-    ap.add_argument("--inflight", type=int, default=8,
+    ap.add_argument("--inflight", type=int, default=16,
                     help="independent frames in flight per GPU (one context + HIP stream each); 1 = one frame at a time")
     args = ap.parse_args()
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per in-flight frame (read at HIP init)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # hardware queues for the in-flight frames (read at HIP init)
     import torch
     from surround360_amd import parallel, render as R, synth
 

@@ -84,7 +84,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   full_.ensure((size_t)B * w * h * sizeof(float2));
   if (sweep_mode_ < 0) {
     const char* e = std::getenv("S360_SWEEP");  // debugging/A-B knob: "diag" = v1 kernel, "hex" = v2 hex16 kernel
-    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : (e && std::string(e) == "quad") ? 3 : 2;
+    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : (e && std::string(e) == "quad") ? 3 : (e && std::string(e) == "tile") ? 4 : 2;
     sweep_env_forced_ = e != nullptr;
     const char* n = std::getenv("S360_SWEEP_NW");
     sweep_nw_ = (n && std::atoi(n) == 8) ? 8 : 4;
@@ -101,6 +101,10 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       divs.push_back((float)lv_.h[l]);
     }
     fastOk = sweep_verify_divisors(st, divs);
+  }
+  if (sweep_mode_ == 4) {
+    recS_.ensure(sweep_tile_rec_bytes(dw_, dh_, B));
+    outS_.ensure(sweep_tile_out_bytes(dw_, dh_, B));
   }
   if (sweep_mode_ >= 1) {
     rec_.ensure(B * n0 * sizeof(float4));
@@ -185,7 +189,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       ProfScope ps(P, "flow_blur15");
       launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
     }
-    if (sweep_mode_ >= 1) {
+    if (sweep_mode_ >= 1 && sweep_mode_ != 4) {
       ProfScope ps(P, "flow_records");
       launch_make_records(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), rec_.as<float4>(), nl, B, idx);
     }
@@ -193,7 +197,10 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       if (skipSweep) return;
-      if (sweep_mode_ == 3)
+      if (sweep_mode_ == 4)
+        launch_sweep_tile(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), fl, recS_.p, outS_.p, handoff_.p,
+                          err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc, fastOk);
+      else if (sweep_mode_ == 3)
         launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B, idx,
                           dir, pc, fastOk);
       else if (sweep_mode_ == 2)

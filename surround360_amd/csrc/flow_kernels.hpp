@@ -66,6 +66,13 @@ size_t sweep_quad_handoff_bytes(int w, int h, int B);
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast);
+// "tile" sweep (sweep_tile.hip): skewed streaming inputs/outputs + LDS window for the I1-gradient gathers
+size_t sweep_tile_rec_bytes(int w, int h, int B);
+size_t sweep_tile_out_bytes(int w, int h, int B);
+size_t sweep_tile_handoff_bytes(int w, int h, int B);
+void launch_sweep_tile(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow,
+                       void* recS, void* outS, void* handoff, unsigned* errflag, int w, int h, size_t bs, int B,
+                       const FlowIdx& idx, int dir, const PixFlowConsts& pc, bool fast);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

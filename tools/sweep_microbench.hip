@@ -12,6 +12,7 @@
 #include "../surround360_amd/csrc/flow_kernels.hip"
 #include "../surround360_amd/csrc/sweep_lock.hip"
 #include "../surround360_amd/csrc/sweep_quad.hip"
+#include "../surround360_amd/csrc/sweep_tile.hip"
 
 using namespace s360;
 
@@ -92,14 +93,22 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
     hrec[4 * i + 2] = 2.0f * U(rng); hrec[4 * i + 3] = 1.0f * U(rng);
     hflow[2 * i + 0] = hrec[4 * i + 2] + 0.3f * U(rng); hflow[2 * i + 1] = hrec[4 * i + 3] + 0.3f * U(rng);
   }
-  std::vector<float*> dG(NS), drec(NS), dflow(NS);
-  std::vector<void*> hand(NS);
+  std::vector<float*> dG(NS), drec(NS), dflow(NS), dA(NS), dbl(NS);
+  std::vector<void*> hand(NS), dRecS(NS), dOutS(NS);
   std::vector<unsigned*> err(NS);
   std::vector<hipStream_t> st(NS);
   const size_t hb = std::max(std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4)), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
     CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
+    CK(hipMalloc(&dA[k], 2 * B * n * 4)); CK(hipMalloc(&dbl[k], B * n * 8));
+    {
+      std::vector<float> ones(2 * B * n, 1.0f), bl(B * n * 2);
+      for (size_t i = 0; i < (size_t)B * n; ++i) { bl[2 * i] = hrec[4 * i + 2]; bl[2 * i + 1] = hrec[4 * i + 3]; }
+      CK(hipMemcpy(dA[k], ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(dbl[k], bl.data(), bl.size() * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&dRecS[k], sweep_tile_rec_bytes(w, h, B))); CK(hipMalloc(&dOutS[k], sweep_tile_out_bytes(w, h, B)));
     CK(hipMemcpy(dG[k], hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(drec[k], hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dflow[k], hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
@@ -111,7 +120,9 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<float> d{0.001f, (float)w, (float)h};
   sweep_verify_divisors(st[0], d);
   auto once = [&](int k, int dir) {
-    if (mode == 3)
+    if (mode == 4)
+      launch_sweep_tile(st[k], (const float2*)dG[k], dA[k], (const float2*)dbl[k], (float2*)dflow[k], dRecS[k], dOutS[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+    else if (mode == 3)
       launch_sweep_quad(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
     else if (mode == 2)
       launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, 4, true);
@@ -125,7 +136,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
     for (int k = 0; k < NS; ++k) once(k, r & 1 ? -1 : 1);
   CK(hipDeviceSynchronize());
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  for (int k = 0; k < NS; ++k) { hipFree(dG[k]); hipFree(drec[k]); hipFree(dflow[k]); hipFree(hand[k]); hipFree(err[k]); hipStreamDestroy(st[k]); }
+  for (int k = 0; k < NS; ++k) { hipFree(dG[k]); hipFree(drec[k]); hipFree(dflow[k]); hipFree(hand[k]); hipFree(err[k]); hipFree(dA[k]); hipFree(dbl[k]); hipFree(dRecS[k]); hipFree(dOutS[k]); hipStreamDestroy(st[k]); }
   return (float)((double)NS * reps * B * n / sec / 1e9);
 }
 
@@ -141,8 +152,8 @@ int main(int argc, char** argv) {
     const C2 cs[] = {{5040, 1052, 4, "polar L0"}, {607, 884, 28, "side L0"}, {1153, 240, 4, "polar L14"}, {140, 203, 28, "side L14"}};
     for (const C2& c : cs)
       for (int ns : {1, 2, 4, 8}) {
-        printf("%-10s B=%2d streams=%d : hex16 %7.2f   lock %7.2f   quad %7.2f\n", c.name, c.B, ns, throughput(c.w, c.h, c.B, 1, ns, 4),
-               throughput(c.w, c.h, c.B, 2, ns, 4), throughput(c.w, c.h, c.B, 3, ns, 4));
+        printf("%-10s B=%2d streams=%d : lock %7.2f   quad %7.2f   tile %7.2f\n", c.name, c.B, ns,
+               throughput(c.w, c.h, c.B, 2, ns, 4), throughput(c.w, c.h, c.B, 3, ns, 4), throughput(c.w, c.h, c.B, 4, ns, 4));
         fflush(stdout);
       }
     return 0;
