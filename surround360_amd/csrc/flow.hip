@@ -74,8 +74,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
 
   down_.ensure(N * n0 * sizeof(uchar4));
   gray_.ensure(N * n0 * sizeof(float));
-  pyrI_.ensure(N * lv_.total * sizeof(float));
-  pyrA_.ensure(N * lv_.total * sizeof(float));
+  pyrI_.ensure(2 * N * lv_.total * sizeof(float));  // per level: N grey planes, then N alpha planes
   G_.ensure(N * n0 * sizeof(float2));
   Gtmp_.ensure(N * n0 * sizeof(float2));
   flowA_.ensure(B * n0 * sizeof(float2));
@@ -116,9 +115,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     }
   }
   float* pyrI = pyrI_.as<float>();
-  float* pyrA = pyrA_.as<float>();
-  auto LI = [&](int l) { return pyrI + (size_t)N * lv_.off[l]; };
-  auto LA = [&](int l) { return pyrA + (size_t)N * lv_.off[l]; };
+  auto LI = [&](int l) { return pyrI + (size_t)2 * N * lv_.off[l]; };
+  auto LA = [&](int l) { return pyrI + (size_t)2 * N * lv_.off[l] + (size_t)N * lv_.w[l] * lv_.h[l]; };
 
   const BlurTaps tPre = gaussian_taps(5, 0.25f), tGrad = gaussian_taps(3, 0.5f), tFlow = gaussian_taps(15, 8.0f),
                  tFinal = gaussian_taps(3, 1.0f);
@@ -132,9 +130,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     ProfScope ps(P, "flow_pyramid");
     for (int l = 1; l < L; ++l) {
       const size_t ns = (size_t)lv_.w[l - 1] * lv_.h[l - 1], nd = (size_t)lv_.w[l] * lv_.h[l];
-      launch_resize_linear_f32(st, LI(l - 1), lv_.w[l - 1], lv_.h[l - 1], ns, LI(l), lv_.w[l], lv_.h[l], nd, 1, N, 1.f,
-                               0);
-      launch_resize_linear_f32(st, LA(l - 1), lv_.w[l - 1], lv_.h[l - 1], ns, LA(l), lv_.w[l], lv_.h[l], nd, 1, N, 1.f,
+      // grey and alpha planes of a level are adjacent: one launch resizes all 2N planes
+      launch_resize_linear_f32(st, LI(l - 1), lv_.w[l - 1], lv_.h[l - 1], ns, LI(l), lv_.w[l], lv_.h[l], nd, 1, 2 * N, 1.f,
                                0);
     }
   }
@@ -173,8 +170,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     const size_t nl = (size_t)wl * hl;
     {
       ProfScope ps(P, "flow_gradients");
-      launch_sobel(st, LI(l), wl, hl, nl, Gtmp_.as<float2>(), N);
-      launch_sepblur(st, Gtmp_.as<float>(), G_.as<float>(), wl, hl, 2, nl, N, tGrad);
+      launch_gradients(st, LI(l), G_.as<float2>(), wl, hl, nl, N, tGrad);
     }
     if (l == L - 1) {
       S360_HIP(hipMemsetAsync(cur, 0, B * nl * sizeof(float2), st));
@@ -187,11 +183,10 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     }
     {
       ProfScope ps(P, "flow_blur15");
-      launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
-    }
-    if (sweep_mode_ >= 1 && sweep_mode_ != 4) {
-      ProfScope ps(P, "flow_records");
-      launch_make_records(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), rec_.as<float4>(), nl, B, idx);
+      if (sweep_mode_ >= 1 && sweep_mode_ != 4)  // the blurred flow goes straight into the sweep records
+        launch_blur_to_records(st, cur, rec_.as<float4>(), wl, hl, nl, B, tFlow, G_.as<float2>(), LA(l), idx);
+      else
+        launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
     }
     static const bool skipSweep = std::getenv("S360_DEBUG_SKIP_SWEEP") != nullptr;  // timing experiments only
     auto sweep = [&](float2* fl, int dir) {

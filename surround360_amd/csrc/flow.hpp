@@ -33,8 +33,6 @@ class FlowEngine {
                int h, const uchar4* prev_images, const float2* prev_flow, int hint, float2* out);
   // debugging taps for parity tests (valid after compute() + stream sync)
   const uchar4* dbg_down() const { return down_.as<uchar4>(); }
-  const float* dbg_pyr_I() const { return pyrI_.as<float>(); }
-  const float* dbg_pyr_A() const { return pyrA_.as<float>(); }
   const FlowLevels& levels() const { return lv_; }
   int dw() const { return dw_; }
   int dh() const { return dh_; }
@@ -45,7 +43,7 @@ class FlowEngine {
   Profiler* prof_;
   FlowLevels lv_;
   int dw_ = 0, dh_ = 0;
-  DevBuf down_, prevdown_, gray_, pyrI_, pyrA_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
+  DevBuf down_, prevdown_, gray_, pyrI_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
       motionPyr_, I1eq_, rec_, handoff_, err_, recS_, outS_;
   int sweep_mode_ = -1;  // 0: v1 diagonal kernel, 1: v2 hex16 kernel, 2: lockstep kernel (latency, default), 3: quad (throughput)
   bool sweep_env_forced_ = false;

@@ -89,58 +89,96 @@ __global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, 
 // order k[c]*x[c] + sum_j k[c+j]*(x[c+j] + x[c-j]) (GaussianBlur; PixFlow.h:137-138, 363-366,
 // 379-383, 439-443, 178-182). One LDS tile with halo per workgroup; the row-pass result is
 // rounded to float in LDS exactly like the intermediate image of the two-pass reference.
-// EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453).
+// Both passes are register-blocked: a thread produces 4 consecutive outputs along the filter axis from one
+// sliding window of 4 + 2R inputs (the wide 15x15 kernels are LDS-bandwidth bound otherwise).
+// SRC 0: the source is the image itself. SRC 1 (CN = 2): the source is Sobel(ksize 1, BORDER_REPLICATE) of a
+//        single-channel plane, computed while the tile is loaded (PixFlow.h:356-366 without the intermediate image).
+// EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453). EPI 2: store the sweep record
+//        {I0x | NaN when the pixel is not updated, I0y, blurred.x, blurred.y} instead of the blurred flow.
 constexpr int SB_TW = 64, SB_TH = 16;
-template <int R, int CN, int EPI>
+template <int R, int CN, int EPI, int SRC>
 __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                  size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
-                                                 const float* __restrict__ A, FlowIdx idx) {
+                                                 const float* __restrict__ A, FlowIdx idx,
+                                                 const float2* __restrict__ Gp, float4* __restrict__ rec) {
   constexpr int IW = SB_TW + 2 * R, IH = SB_TH + 2 * R;
-  __shared__ float s_in[IH][IW][CN];
-  __shared__ float s_mid[IH][SB_TW][CN];
+  constexpr int IWP = IW | 1;  // odd row stride: the 4-wide row tasks of consecutive rows fall into different banks
+  __shared__ float s_in[IH][IWP][CN];
+  __shared__ float s_mid[IH][SB_TW + 1][CN];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
-  src += bs * CN * blockIdx.z;
-  dst += bs * CN * blockIdx.z;
+  src += bs * (SRC == 1 ? 1 : CN) * blockIdx.z;
   for (int i = tid; i < IH * IW; i += 256) {
     const int ly = i / IW, lx = i - ly * IW;
     const int gy = reflect101(ty0 - R + ly, h), gx = reflect101(tx0 - R + lx, w);
-    const float* p = src + ((size_t)gy * w + gx) * CN;
+    if (SRC == 1) {  // Sobel ksize=1: [-1 0 +1], BORDER_REPLICATE, no scale
+      const float* r0 = src + (size_t)gy * w;
+      s_in[ly][lx][0] = r0[min(gx + 1, w - 1)] - r0[max(gx - 1, 0)];
+      s_in[ly][lx][CN - 1] = src[(size_t)min(gy + 1, h - 1) * w + gx] - src[(size_t)max(gy - 1, 0) * w + gx];
+    } else {
+      const float* p = src + ((size_t)gy * w + gx) * CN;
 #pragma unroll
-    for (int k = 0; k < CN; ++k) s_in[ly][lx][k] = p[k];
-  }
-  __syncthreads();
-  for (int i = tid; i < IH * SB_TW; i += 256) {
-    const int ly = i / SB_TW, lx = i - ly * SB_TW;
-#pragma unroll
-    for (int k = 0; k < CN; ++k) {
-      float s = taps.k[0] * s_in[ly][lx + R][k];
-#pragma unroll
-      for (int j = 1; j <= R; ++j) s += taps.k[j] * (s_in[ly][lx + R + j][k] + s_in[ly][lx + R - j][k]);
-      s_mid[ly][lx][k] = s;
+      for (int k = 0; k < CN; ++k) s_in[ly][lx][k] = p[k];
     }
   }
   __syncthreads();
-  for (int i = tid; i < SB_TH * SB_TW; i += 256) {
-    const int ly = i / SB_TW, lx = i - ly * SB_TW;
-    const int gx = tx0 + lx, gy = ty0 + ly;
-    if (gx >= w || gy >= h) continue;
-    float out[CN];
+  // row pass: task = (row ly, group of 4 consecutive x)
+  for (int t = tid; t < IH * (SB_TW / 4); t += 256) {
+    const int ly = t % IH, lx0 = (t / IH) * 4;
 #pragma unroll
     for (int k = 0; k < CN; ++k) {
-      float s = taps.k[0] * s_mid[ly + R][lx][k];
+      float v[4 + 2 * R];
 #pragma unroll
-      for (int j = 1; j <= R; ++j) s += taps.k[j] * (s_mid[ly + R + j][lx][k] + s_mid[ly + R - j][lx][k]);
-      out[k] = s;
+      for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_in[ly][lx0 + j][k];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float acc = taps.k[0] * v[o + R];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
+        s_mid[ly][lx0 + o][k] = acc;
+      }
     }
-    const size_t o = (size_t)gy * w + gx;
-    if (EPI == 1) {
-      const float c = 1.0f - A[bs * idx.i0[blockIdx.z] + o] * A[bs * idx.i1[blockIdx.z] + o];
+  }
+  __syncthreads();
+  // column pass: task = (column lx, group of 4 consecutive y)
+  dst += bs * CN * blockIdx.z;
+  for (int t = tid; t < SB_TW * (SB_TH / 4); t += 256) {
+    const int lx = t % SB_TW, ly0 = (t / SB_TW) * 4;
+    const int gx = tx0 + lx;
+    float outv[4][CN];
 #pragma unroll
-      for (int k = 0; k < CN; ++k) out[k] = c * out[k] + (1.0f - c) * s_in[ly + R][lx + R][k];
+    for (int k = 0; k < CN; ++k) {
+      float v[4 + 2 * R];
+#pragma unroll
+      for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_mid[ly0 + j][lx][k];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float acc = taps.k[0] * v[o + R];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
+        outv[o][k] = acc;
+      }
     }
+    if (gx >= w) continue;
 #pragma unroll
-    for (int k = 0; k < CN; ++k) dst[o * CN + k] = out[k];
+    for (int o = 0; o < 4; ++o) {
+      const int gy = ty0 + ly0 + o;
+      if (gy >= h) continue;
+      const size_t off = (size_t)gy * w + gx;
+      if (EPI == 1) {
+        const float cc = 1.0f - A[bs * idx.i0[blockIdx.z] + off] * A[bs * idx.i1[blockIdx.z] + off];
+#pragma unroll
+        for (int k = 0; k < CN; ++k) outv[o][k] = cc * outv[o][k] + (1.0f - cc) * s_in[ly0 + o + R][lx + R][k];
+      }
+      if (EPI == 2) {
+        const float2 g = Gp[bs * idx.i0[blockIdx.z] + off];
+        const bool upd = A[bs * idx.i0[blockIdx.z] + off] > 0.9f && A[bs * idx.i1[blockIdx.z] + off] > 0.9f;
+        rec[bs * blockIdx.z + off] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, outv[o][0], outv[o][CN - 1]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < CN; ++k) dst[off * CN + k] = outv[o][k];
+      }
+    }
   }
 }
 
@@ -739,25 +777,37 @@ void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t
   hipLaunchKernelGGL(k_motion, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, cur, prev, n, sbs, motion,
                      pbs);
 }
-template <int R, int CN, int EPI>
+template <int R, int CN, int EPI, int SRC>
 static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w, int h, size_t bs, int B,
-                             const BlurTaps& t, const float* A, const FlowIdx& idx) {
+                             const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float4* rec) {
   dim3 blk(64, 4);
   dim3 grd((w + SB_TW - 1) / SB_TW, (h + SB_TH - 1) / SB_TH, B);
-  hipLaunchKernelGGL((k_sepblur<R, CN, EPI>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx);
+  hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
 }
 void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
                     const BlurTaps& t) {
   static const FlowIdx none = {};
-  if (t.r == 1 && cn == 1) launch_sepblur_t<1, 1, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
-  else if (t.r == 1 && cn == 2) launch_sepblur_t<1, 2, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
-  else if (t.r == 2 && cn == 1) launch_sepblur_t<2, 1, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
-  else if (t.r == 7 && cn == 2) launch_sepblur_t<7, 2, 0>(st, src, dst, w, h, bs, B, t, nullptr, none);
+  if (t.r == 1 && cn == 1) launch_sepblur_t<1, 1, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
+  else if (t.r == 1 && cn == 2) launch_sepblur_t<1, 2, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
+  else if (t.r == 2 && cn == 1) launch_sepblur_t<2, 1, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
+  else if (t.r == 7 && cn == 2) launch_sepblur_t<7, 2, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
   else throw std::runtime_error("launch_sepblur: unsupported radius/channels");
 }
 void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
                       const BlurTaps& t, const float* A, const FlowIdx& idx) {
-  launch_sepblur_t<7, 2, 1>(st, (const float*)flow, (float*)dst, w, h, bs, B, t, A, idx);
+  launch_sepblur_t<7, 2, 1, 0>(st, (const float*)flow, (float*)dst, w, h, bs, B, t, A, idx, nullptr, nullptr);
+}
+// Sobel + 3x3 Gaussian of a float plane in one pass -> packed (Ix, Iy) (PixFlow.h:353-366)
+void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t) {
+  static const FlowIdx none = {};
+  if (t.r != 1) throw std::runtime_error("launch_gradients: 3x3 kernel expected");
+  launch_sepblur_t<1, 2, 0, 1>(st, I, (float*)G, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
+}
+// 15x15 Gaussian of the flow written straight into the sweep records (blurredFlow is only read by the sweep)
+void launch_blur_to_records(hipStream_t st, const float2* flow, float4* rec, int w, int h, size_t bs, int B,
+                            const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx) {
+  if (t.r != 7) throw std::runtime_error("launch_blur_to_records: 15x15 kernel expected");
+  launch_sepblur_t<7, 2, 2, 0>(st, (const float*)flow, nullptr, w, h, bs, B, t, A, idx, G, rec);
 }
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale) {

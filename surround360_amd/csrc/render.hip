@@ -295,14 +295,10 @@ void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano, int cols, int row
   const size_t n = (size_t)cols * rows;
   F.a8a.ensure(n);
   F.a8b.ensure(n);
-  F.gtmp.ensure(n * sizeof(int));
   const int e = c->P.std_alpha_feather_size;
-  launch_extract_alpha(st, pano, cols, rows, F.a8a.as<uint8_t>());
-  launch_erode_cross(st, F.a8a.as<uint8_t>(), F.a8b.as<uint8_t>(), cols, rows, e);
+  launch_erode_alpha(st, pano, F.a8b.as<uint8_t>(), cols, rows, e);
   if (F.tab.gauss_ksize > 1) {
-    const int r = F.tab.gauss_ksize / 2;
-    launch_gauss_u8_rows(st, F.a8b.as<uint8_t>(), F.gtmp.as<int>(), cols, rows, F.tab.gik.as<int>(), r);
-    launch_gauss_u8_cols(st, F.gtmp.as<int>(), F.a8a.as<uint8_t>(), cols, rows, F.tab.gik.as<int>(), r);
+    launch_gauss_u8(st, F.a8b.as<uint8_t>(), F.a8a.as<uint8_t>(), cols, rows, F.tab.gik.as<int>(), F.tab.gauss_ksize / 2);
     launch_extend_wrap(st, pano, F.a8a.as<uint8_t>(), cols, rows, ext, extW);
   } else {
     launch_extend_wrap(st, pano, F.a8b.as<uint8_t>(), cols, rows, ext, extW);

@@ -8,6 +8,8 @@
 // SR/util/CvUtil.cpp:93-115, 140-157, 224-260, SR/util/Filter.h:40-127.
 #include "render_kernels.hpp"
 
+#include <stdexcept>
+
 #include "devmath.hpp"
 
 namespace s360 {
@@ -377,49 +379,123 @@ __global__ __launch_bounds__(256) void k_flip_both(const uchar4* __restrict__ sr
   dst[(size_t)(h - 1 - y) * w + (w - 1 - x)] = src[(size_t)y * w + x];
 }
 
-// ---- featherAlphaChannel ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_extract_alpha(const uchar4* __restrict__ img, int w, int rows,
-                                                       uint8_t* __restrict__ a) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  a[(size_t)y * w + x] = img[(size_t)y * w + x].w;
-}
-// erode with MORPH_CROSS (2e+1)^2, outside treated as +inf. Horizontal arm through LDS, vertical arm direct.
-__global__ __launch_bounds__(256) void k_erode_cross(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, int w,
-                                                     int h, int e) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  uint8_t* row = reinterpret_cast<uint8_t*>(smem_raw);  // [blockDim.x + 2e]
-  const int x0 = blockIdx.x * blockDim.x, y = blockIdx.y;
-  for (int i = threadIdx.x; i < (int)blockDim.x + 2 * e; i += blockDim.x) {
-    const int gx = x0 - e + i;
-    row[i] = (gx >= 0 && gx < w) ? a[(size_t)y * w + gx] : 255;
+// ---- featherAlphaChannel (CvUtil.cpp:140-157) ---------------------------------------------------
+// erode with MORPH_CROSS (2e+1)^2 of the alpha channel (outside treated as +inf = 255), then an 8-bit Gaussian.
+// Both are LDS-tiled: the erosion runs the two arms of the cross as log-step (doubling) window minima, the Gaussian
+// does its row and column passes inside one tile.
+constexpr int ER_TW = 128, ER_TH = 32, ER_MAXE = 32;
+// Window minimum of length len = 2e+1 by van Herk / Gil-Werman: per segment of len elements a running prefix
+// minimum g and a running suffix minimum hh; min over [i, i+len) = min(hh[i], g[i+len-1]). ~3 operations per
+// element whatever the window length. Words (not bytes) in LDS: no sub-dword traffic.
+__global__ __launch_bounds__(256) void k_erode_cross_tiled(const uchar4* __restrict__ img, uint8_t* __restrict__ out,
+                                                           int w, int h, int e) {
+  constexpr int HWMAX = ER_TW + 2 * ER_MAXE, VHMAX = ER_TH + 2 * ER_MAXE;
+  __shared__ unsigned char s_src_h[ER_TH][HWMAX + 4];
+  __shared__ unsigned char s_g_h[ER_TH][HWMAX + 4];
+  __shared__ unsigned char s_s_h[ER_TH][HWMAX + 4];
+  __shared__ unsigned char s_src_v[VHMAX][ER_TW];
+  __shared__ unsigned char s_g_v[VHMAX][ER_TW];
+  __shared__ unsigned char s_s_v[VHMAX][ER_TW];
+  const int tx = threadIdx.x & (ER_TW - 1), ty = threadIdx.x >> 7;  // 128 x 2 threads
+  const int x0 = blockIdx.x * ER_TW, y0 = blockIdx.y * ER_TH;
+  const int len = 2 * e + 1;
+  const int HW = ER_TW + 2 * e, VH = ER_TH + 2 * e;
+  for (int ly = ty; ly < ER_TH; ly += 2)
+    for (int lx = tx; lx < HW; lx += ER_TW) {
+      const int gx = x0 - e + lx, gy = y0 + ly;
+      s_src_h[ly][lx] = (gx >= 0 && gx < w && gy < h) ? img[(size_t)gy * w + gx].w : 255;
+    }
+  for (int ly = ty; ly < VH; ly += 2) {
+    const int gx = x0 + tx, gy = y0 - e + ly;
+    s_src_v[ly][tx] = (gx < w && gy >= 0 && gy < h) ? img[(size_t)gy * w + gx].w : 255;
   }
   __syncthreads();
-  const int x = x0 + threadIdx.x;
-  if (x >= w) return;
-  int m = 255;
-  for (int i = 0; i <= 2 * e; ++i) m = min(m, (int)row[threadIdx.x + i]);
-  const int ylo = max(0, y - e), yhi = min(h - 1, y + e);
-  for (int yy = ylo; yy <= yhi; ++yy) m = min(m, (int)a[(size_t)yy * w + x]);
-  out[(size_t)y * w + x] = (uint8_t)m;
+  // horizontal arm: task = (row, segment); segments of `len` elements tile the row [0, HW)
+  const int nsegH = (HW + len - 1) / len;
+  for (int t = threadIdx.x; t < ER_TH * nsegH; t += 256) {
+    const int ly = t % ER_TH, seg = t / ER_TH;
+    const int b0 = seg * len, b1 = min(b0 + len, HW);
+    unsigned char m = 255;
+    for (int i = b0; i < b1; ++i) { m = min(m, s_src_h[ly][i]); s_g_h[ly][i] = m; }
+    m = 255;
+    for (int i = b1 - 1; i >= b0; --i) { m = min(m, s_src_h[ly][i]); s_s_h[ly][i] = m; }
+  }
+  // vertical arm: task = (column, segment)
+  const int nsegV = (VH + len - 1) / len;
+  for (int t = threadIdx.x; t < ER_TW * nsegV; t += 256) {
+    const int lx = t & (ER_TW - 1), seg = t >> 7;
+    const int b0 = seg * len, b1 = min(b0 + len, VH);
+    unsigned char m = 255;
+    for (int i = b0; i < b1; ++i) { m = min(m, s_src_v[i][lx]); s_g_v[i][lx] = m; }
+    m = 255;
+    for (int i = b1 - 1; i >= b0; --i) { m = min(m, s_src_v[i][lx]); s_s_v[i][lx] = m; }
+  }
+  __syncthreads();
+  // output (x, y): horizontal window [lx, lx + len) of the haloed row, vertical window [ly, ly + len) of the column
+  const int gx = x0 + tx;
+  if (gx < w)
+    for (int ly = ty; ly < ER_TH; ly += 2) {
+      const int gy = y0 + ly;
+      if (gy >= h) continue;
+      const unsigned char mh = min(s_s_h[ly][tx], s_g_h[ly][tx + len - 1]);
+      const unsigned char mv = min(s_s_v[ly][tx], s_g_v[ly + len - 1][tx]);
+      out[(size_t)gy * w + gx] = min(mh, mv);
+    }
 }
-__global__ __launch_bounds__(256) void k_gauss_u8_rows(const uint8_t* __restrict__ a, int* __restrict__ tmp, int w,
-                                                       int h, const int* __restrict__ ik, int r) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  const uint8_t* S = a + (size_t)y * w;
-  int s = ik[r] * S[x];
-  for (int j = 1; j <= r; ++j) s += ik[r + j] * ((int)S[reflect101(x + j, w)] + (int)S[reflect101(x - j, w)]);
-  tmp[(size_t)y * w + x] = s;
-}
-__global__ __launch_bounds__(256) void k_gauss_u8_cols(const int* __restrict__ tmp, uint8_t* __restrict__ out, int w,
-                                                       int h, const int* __restrict__ ik, int r) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  int s = ik[r] * tmp[(size_t)y * w + x];
-  for (int j = 1; j <= r; ++j)
-    s += ik[r + j] * (tmp[(size_t)reflect101(y + j, h) * w + x] + tmp[(size_t)reflect101(y - j, h) * w + x]);
-  out[(size_t)y * w + x] = (uint8_t)sat_u8((s + (1 << 15)) >> 16);
+
+// GaussianBlur on CV_8U (ksize x ksize, fixed-point taps ik scaled by 256, BORDER_REFLECT_101): row pass to int,
+// column pass, (sum + 2^15) >> 16 — both inside one LDS tile, 4 outputs per thread along the filter axis.
+constexpr int GU_TW = 64, GU_TH = 32, GU_MAXR = 16;
+__global__ __launch_bounds__(256) void k_gauss_u8_tiled(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, int w,
+                                                        int h, const int* __restrict__ ik, int r) {
+  constexpr int IWMAX = GU_TW + 2 * GU_MAXR, IHMAX = GU_TH + 2 * GU_MAXR;
+  __shared__ int s_a[IHMAX][IWMAX + 1];
+  __shared__ int s_row[IHMAX][GU_TW + 1];
+  __shared__ int s_k[2 * GU_MAXR + 1];
+  const int tx = threadIdx.x & (GU_TW - 1), ty = threadIdx.x >> 6;  // 64 x 4 threads
+  const int x0 = blockIdx.x * GU_TW, y0 = blockIdx.y * GU_TH;
+  const int IW = GU_TW + 2 * r, IH = GU_TH + 2 * r;
+  if ((int)threadIdx.x <= 2 * r) s_k[threadIdx.x] = ik[threadIdx.x];
+  for (int ly = ty; ly < IH; ly += 4) {
+    const uint8_t* row = a + (size_t)reflect101(y0 - r + ly, h) * w;
+    for (int lx = tx; lx < IW; lx += GU_TW) s_a[ly][lx] = row[reflect101(x0 - r + lx, w)];
+  }
+  __syncthreads();
+  // row pass: task = (row, group of 4 consecutive x); sums are integers: any order gives the same result
+  for (int t = threadIdx.x; t < IH * (GU_TW / 4); t += 256) {
+    const int ly = t % IH, lx0 = (t / IH) * 4;
+    int acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    for (int j = 0; j < 2 * r + 4; ++j) {
+      const int v = s_a[ly][lx0 + j];
+      // tap index of input j for output o is j - o (valid 0..2r)
+      if (j <= 2 * r) acc0 += s_k[j] * v;
+      if (j >= 1 && j - 1 <= 2 * r) acc1 += s_k[j - 1] * v;
+      if (j >= 2 && j - 2 <= 2 * r) acc2 += s_k[j - 2] * v;
+      if (j >= 3) acc3 += s_k[j - 3] * v;
+    }
+    s_row[ly][lx0] = acc0; s_row[ly][lx0 + 1] = acc1; s_row[ly][lx0 + 2] = acc2; s_row[ly][lx0 + 3] = acc3;
+  }
+  __syncthreads();
+  // column pass: task = (column, group of 4 consecutive y)
+  for (int t = threadIdx.x; t < GU_TW * (GU_TH / 4); t += 256) {
+    const int lx = t & (GU_TW - 1), ly0 = (t >> 6) * 4;
+    int acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    for (int j = 0; j < 2 * r + 4; ++j) {
+      const int v = s_row[ly0 + j][lx];
+      if (j <= 2 * r) acc0 += s_k[j] * v;
+      if (j >= 1 && j - 1 <= 2 * r) acc1 += s_k[j - 1] * v;
+      if (j >= 2 && j - 2 <= 2 * r) acc2 += s_k[j - 2] * v;
+      if (j >= 3) acc3 += s_k[j - 3] * v;
+    }
+    const int gx = x0 + lx;
+    if (gx >= w) continue;
+    const int acc[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int gy = y0 + ly0 + o;
+      if (gy < h) out[(size_t)gy * w + gx] = (uint8_t)sat_u8((acc[o] + (1 << 15)) >> 16);
+    }
+  }
 }
 __global__ __launch_bounds__(256) void k_extend_wrap(const uchar4* __restrict__ img, const uint8_t* __restrict__ alpha,
                                                      int cols, int rows, uchar4* __restrict__ ext, int extW) {
@@ -623,17 +699,14 @@ void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int c
 void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h) {
   hipLaunchKernelGGL(k_flip_both, dim3(cdiv(w, 256), h), dim3(256), 0, st, src, dst, w, h);
 }
-void launch_extract_alpha(hipStream_t st, const uchar4* img, int w, int rows, uint8_t* a) {
-  hipLaunchKernelGGL(k_extract_alpha, dim3(cdiv(w, 256), rows), dim3(256), 0, st, img, w, rows, a);
+// featherAlphaChannel's erode (alpha of a BGRA image -> eroded 8-bit plane) and Gaussian
+void launch_erode_alpha(hipStream_t st, const uchar4* img, uint8_t* out, int w, int h, int e) {
+  if (e > ER_MAXE) throw std::runtime_error("featherAlphaChannel: erode size above 32 is not supported");
+  hipLaunchKernelGGL(k_erode_cross_tiled, dim3(cdiv(w, ER_TW), cdiv(h, ER_TH)), dim3(256), 0, st, img, out, w, h, e);
 }
-void launch_erode_cross(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, int e) {
-  hipLaunchKernelGGL(k_erode_cross, dim3(cdiv(w, 256), h), dim3(256), 256 + 2 * e, st, a, out, w, h, e);
-}
-void launch_gauss_u8_rows(hipStream_t st, const uint8_t* a, int* tmp, int w, int h, const int* ik, int r) {
-  hipLaunchKernelGGL(k_gauss_u8_rows, dim3(cdiv(w, 256), h), dim3(256), 0, st, a, tmp, w, h, ik, r);
-}
-void launch_gauss_u8_cols(hipStream_t st, const int* tmp, uint8_t* out, int w, int h, const int* ik, int r) {
-  hipLaunchKernelGGL(k_gauss_u8_cols, dim3(cdiv(w, 256), h), dim3(256), 0, st, tmp, out, w, h, ik, r);
+void launch_gauss_u8(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, const int* ik, int r) {
+  if (r > GU_MAXR) throw std::runtime_error("featherAlphaChannel: Gaussian radius above 16 is not supported");
+  hipLaunchKernelGGL(k_gauss_u8_tiled, dim3(cdiv(w, GU_TW), cdiv(h, GU_TH)), dim3(256), 0, st, a, out, w, h, ik, r);
 }
 void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha, int cols, int rows, uchar4* ext,
                         int extW) {

@@ -53,10 +53,8 @@ void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int c
                           uchar4* pano, int eqrW, int eqrH);
 void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h);
 // featherAlphaChannel pieces (CvUtil.cpp:140-157) on the top `rows` rows of a pano
-void launch_extract_alpha(hipStream_t st, const uchar4* img, int w, int rows, uint8_t* a);
-void launch_erode_cross(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, int e);
-void launch_gauss_u8_rows(hipStream_t st, const uint8_t* a, int* tmp, int w, int h, const int* ik, int r);
-void launch_gauss_u8_cols(hipStream_t st, const int* tmp, uint8_t* out, int w, int h, const int* ik, int r);
+void launch_erode_alpha(hipStream_t st, const uchar4* img, uint8_t* out, int w, int h, int e);
+void launch_gauss_u8(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, const int* ik, int r);
 // extended (x % cols wrapped) flow inputs (TRSP:399-411): side image takes the feathered alpha plane
 void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha /*nullable*/, int cols, int rows,
                         uchar4* ext, int extW);
