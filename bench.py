@@ -219,6 +219,7 @@ def main():
     bytes_per_launch = bytes_per_frame / max(launches_per_frame, 1)
     avg_launch_ms = sweep_ms / max(sweep_launches, 1)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    agg = bytes_per_frame * args.steps / dt / 1e9
     s1_ms, s1_launches = prof1.get("flow_sweep", (0.0, 0))
     n_side_flows_1 = 2 * (p1 - p0)
     bytes_1 = sweep_algorithmic_bytes(g, n_side_flows_1, 4, flags["eqr_width"]) * n_single
@@ -250,13 +251,16 @@ def main():
                    "frames_in_flight": F},
         "roofline": {"bound": "hbm", "kernel": "%s (PixFlow propagation sweeps, PixFlow.h:388-410)" %
                                ("k_sweep_quad" if F > 1 else "k_sweep_lock"),
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "achieved": agg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
                      "traffic": None,
                      "avg_launch_ms": avg_launch_ms, "launches_per_frame": launches_per_frame,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "aggregate_GBps_all_streams": bytes_per_frame * args.steps / dt / 1e9,
-                     "note": "dependency-latency-bound wavefront kernel (DESIGN.md §5); launches of up to %d frames "
-                             "overlap in the timed region, durations are per launch" % F},
+                     "per_launch_GBps_while_overlapped": achieved,
+                     "note": "dependency-latency-bound wavefront kernel (DESIGN.md §5). Launches of up to %d frames overlap "
+                             "in the timed region, so `achieved` = algorithmic bytes of ALL sweep launches / wall time of "
+                             "the region (bytes per launch / average launch duration, times the average number of "
+                             "launches running at once); the un-overlapped per-launch figure is "
+                             "single_frame.sweep_roofline_frac" % F},
         "single_frame": {"mode": "one frame at a time, all pairs on 1 GPU" if world == 1 else
                                  "one frame at a time, 14 pairs sharded over %d GPUs + one RCCL strip gather, pole units "
                                  "and composite on rank 0" % world,
@@ -270,7 +274,9 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
     if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
         try:
-            out["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+            tj = json.load(open(traffic_file))
+            kname = "k_sweep_quad" if F > 1 else "k_sweep_lock"
+            out["roofline"]["traffic"] = tj.get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
     if world == 1 and not args.no_cpu_baseline:
