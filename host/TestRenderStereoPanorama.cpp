@@ -5,7 +5,7 @@
 //
 // Kept on the host, as in the reference: flag parsing, the rig loader (inside libs360: rig.cpp), directory
 // scanning, PNG decode/encode (png_io.hpp instead of cv::imread/imwrite) and the flow-state files.
-// Not supported here (out of scope): --output_cubemap_path, --enable_pole_removal, --save_debug_images.
+// Not supported here (out of scope): --enable_pole_removal, --save_debug_images.
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -153,7 +153,6 @@ int main(int argc, char** argv) {
   require_arg(F.s("frame_number"), "frame_number");
   require_arg(F.s("output_data_dir"), "output_data_dir");
   require_arg(F.s("output_equirect_path"), "output_equirect_path");
-  if (!F.s("output_cubemap_path").empty()) std::fprintf(stderr, "WARNING: --output_cubemap_path is not supported by this build; ignored\n");
   if (F.b("enable_pole_removal")) std::fprintf(stderr, "WARNING: --enable_pole_removal is not supported by this build; ignored\n");
   const int verbose = F.i("v");
   const double startTime = now_sec();
@@ -293,6 +292,14 @@ int main(int argc, char** argv) {
     }
   }
   const double stateEnd = now_sec();
+  // optional stereo cubemap (TRSP:917-935)
+  if (F.i("cubemap_width") > 0 && F.i("cubemap_height") > 0 && !F.s("output_cubemap_path").empty()) {
+    int whc[3];
+    ck(s360_frame_cubemap(ctx, F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, nullptr), ctx);
+    std::vector<uint8_t> cube((size_t)whc[0] * whc[1] * 3);
+    ck(s360_frame_cubemap(ctx, F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cube.data()), ctx);
+    save_png(F.s("output_cubemap_path"), cube.data(), whc[0], whc[1], 3);
+  }
   save_png(F.s("output_equirect_path"), equirect.data(), g.out_width, g.out_height, 3);  // TRSP:961
   const double endTime = now_sec();
   if (verbose >= 1) {  // the reference's VLOG(1) runtime breakdown, TRSP:964-971

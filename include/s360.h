@@ -180,6 +180,10 @@ int s360_frame_finish(s360_ctx* ctx, int pole_mask, int use_prev);
 /* Stacked stereo equirect (left eye over right eye), BGR, out_width x out_height (host / device). */
 int s360_frame_download_equirect(s360_ctx* ctx, uint8_t* out_bgr);
 int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* Stereo cubemap of the last rendered frame (convertSphericalToCubemapBicubicRemap + stackOutputCubemapFaces,
+ * SR/render/ImageWarper.cpp:95-141, SR/util/CvUtil.cpp:117-138, TRSP:917-935): format "video" (3 x 2 faces per eye,
+ * flipped) or "photo" (6 faces stacked). whc receives width/height/3; out_bgr may be NULL for a size query. */
+int s360_frame_cubemap(s360_ctx* ctx, int face_width, int face_height, const char* format, int whc[3], uint8_t* out_bgr);
 /* Intermediates for stage-by-stage parity tests and for the reference's on-disk state
  * (overlap_<i>_{L,R}.png, flow{LtoR,RtoL}_<i>.bin, extended*Spherical_<eye>.png, flow_<eye>.bin).
  * Names: "projection"(idx cam) "overlap_l" "overlap_r" "side_pano_l" "side_pano_r" "top_spherical"

@@ -343,6 +343,38 @@ static inline ImgU8 remapCubicU8(const ImgU8& src, const ImgF& map) {
   return dst;
 }
 
+// remap INTER_CUBIC, BORDER_WRAP, 8-bit source (ImageWarper.cpp:131-138: equirect -> cubemap face). Taps whose
+// 4x4 window leaves the image are fetched at borderInterpolate(p, len, BORDER_WRAP) in x and in y.
+static inline int borderWrap(int p, int len) {
+  if (p < 0) p -= ((p - len + 1) / len) * len;
+  if (p >= len) p %= len;
+  return p;
+}
+static inline ImgU8 remapCubicU8Wrap(const ImgU8& src, const ImgF& map) {
+  assert(map.c == 2);
+  const BicubicTab& T = bicubicTab();
+  const int cn = src.c, sw = src.w, sh = src.h;
+  ImgU8 dst(map.w, map.h, cn);
+  for (int y = 0; y < map.h; ++y) {
+    const float* M = map.row(y);
+    uint8_t* D = dst.row(y);
+    for (int x = 0; x < map.w; ++x, D += cn) {
+      int sx, sy, fxy;
+      remapCoord(M[2 * x], M[2 * x + 1], &sx, &sy, &fxy);
+      const short* w = T.i[fxy];
+      int xs[4], ys[4];
+      for (int q = 0; q < 4; ++q) { xs[q] = borderWrap(sx + q, sw); ys[q] = borderWrap(sy + q, sh); }
+      for (int k = 0; k < cn; ++k) {
+        int sum = 0;
+        for (int r = 0; r < 4; ++r)
+          for (int q = 0; q < 4; ++q) sum += src.at(ys[r], xs[q], k) * w[r * 4 + q];
+        D[k] = satU8((sum + (1 << 14)) >> 15);
+      }
+    }
+  }
+  return dst;
+}
+
 // remap INTER_CUBIC, BORDER_CONSTANT(0), float source (flow field remap in
 // renderLazyNovelView, NovelView.cpp:191). Float weights and accumulate;
 // interior: sum = row0(4-term) ; sum += row1 ; ... ; border: sequential adds.

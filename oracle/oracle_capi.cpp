@@ -336,6 +336,20 @@ int orc_frame_get_f32(orc_frame* f, const char* name, int idx, int* whc3, float*
   return 0;
 }
 
+// Stereo cubemap of the last rendered frame (TRSP:917-935). Query dims with dst == nullptr. -1: no frame / bad format.
+int orc_frame_cubemap(orc_frame* f, int face_w, int face_h, const char* format, int* whc3, uint8_t* dst) {
+  const std::string fmt(format);
+  if ((fmt != "video" && fmt != "photo") || f->dbg.eyeL.w == 0) return -1;
+  whc3[0] = fmt == "video" ? 3 * face_w : face_w;
+  whc3[1] = fmt == "video" ? 4 * face_h : 12 * face_h;
+  whc3[2] = 3;
+  if (dst) {
+    const ImgU8 c = stereoCubemap(f->dbg.eyeL, f->dbg.eyeR, face_w, face_h, fmt);
+    std::memcpy(dst, c.d.data(), c.bytes());
+  }
+  return 0;
+}
+
 // NovelViewGeneratorLazyFlow::combineLazyNovelViews for one pair (NovelView.cpp:226-268) using the frame geometry.
 void orc_frame_combine_lazy_novel_views(orc_frame* f, const uint8_t* imgL, const uint8_t* imgR, const float* flowLtoR,
                                         const float* flowRtoL, uint8_t* chunkL, uint8_t* chunkR) {

@@ -618,4 +618,79 @@ static inline ImgU8 renderStereoPanorama(const RigDescription& rig, const Render
   return out;
 }
 
+// ---- cubemap output (ImageWarper.cpp:26-141, CvUtil.cpp:117-138, TRSP:917-935) --------------------------------
+// Faces in the reference's order: RIGHT, LEFT, TOP, BOTTOM, BACK, FRONT (enum CubemapFace values 0..5 are
+// BACK, LEFT, TOP, BOTTOM, FRONT, RIGHT in ImageWarper.h; only the switch below depends on them).
+enum CubeFace { CUBE_BACK = 0, CUBE_LEFT, CUBE_TOP, CUBE_BOTTOM, CUBE_FRONT, CUBE_RIGHT };
+static inline void cubemapIndexToVec3(float x, float y, int face, float out[3]) {  // ImageWarper.cpp:26-61
+  const float dir[3] = {x, y, 0.5f};
+  out[0] = dir[0]; out[1] = dir[1]; out[2] = dir[2];
+  switch (face) {
+    case CUBE_BACK: out[0] = dir[0]; out[1] = dir[2]; out[2] = -dir[1]; break;
+    case CUBE_LEFT: out[0] = -dir[2]; out[1] = dir[0]; out[2] = -dir[1]; break;
+    case CUBE_TOP: break;
+    case CUBE_BOTTOM: out[0] = dir[0]; out[1] = -dir[1]; out[2] = -dir[2]; break;
+    case CUBE_FRONT: out[0] = -dir[0]; out[1] = -dir[2]; out[2] = -dir[1]; break;
+    case CUBE_RIGHT: out[0] = dir[2]; out[1] = -dir[0]; out[2] = -dir[1]; break;
+  }
+}
+static inline void mapEquirectToCubemapCoordinate(float x, float y, int face, int srcCols, int srcRows,
+                                                  float fisheyeFovRadians, float* srcX, float* srcY) {  // :63-93
+  float dir[3];
+  cubemapIndexToVec3(x, y, face, dir);
+  const float r = sqrtf(dir[0] * dir[0] + dir[1] * dir[1]);
+  // cv::norm(Vec3f): float accumulation of the squares, sqrt, returned as double
+  float s2 = 0.f;
+  for (int i = 0; i < 3; ++i) s2 += dir[i] * dir[i];
+  const double nrm = (double)std::sqrt(s2);
+  const float phi = acosf((float)((double)dir[2] / nrm));
+  float theta = r > 0.0f ? acosf(std::fabs(dir[0] / r)) : 0.0f;
+  if (dir[0] > 0 && dir[1] > 0) {
+  } else if (dir[0] <= 0 && dir[1] > 0) {
+    theta = (float)(M_PI - theta);
+  } else if (dir[0] <= 0 && dir[1] <= 0) {
+    theta = (float)(M_PI + theta);
+  } else {
+    theta = (float)(2 * M_PI - theta);
+  }
+  const float phiPrime = std::min(std::max(phi, 0.0f), fisheyeFovRadians);
+  const float thetaPrime = std::min(std::max(theta, 0.0f), float(2.0f * M_PI));
+  *srcX = (float)(float(srcCols) * thetaPrime / (2.0f * M_PI));
+  *srcY = float(srcRows) * phiPrime / fisheyeFovRadians;
+}
+static inline ImgF cubemapWarpMap(int face, int srcCols, int srcRows, float fov, int faceW, int faceH) {  // :111-128
+  const float dy = 1.0f / float(faceW), dx = 1.0f / float(faceH);
+  ImgF m(faceW, faceH, 2);
+  for (int j = 0; j < faceH; ++j)
+    for (int i = 0; i < faceW; ++i)
+      mapEquirectToCubemapCoordinate(float(i) * dy - 0.5f, float(j) * dx - 0.5f, face, srcCols, srcRows, fov,
+                                     &m.at(j, i, 0), &m.at(j, i, 1));
+  return m;
+}
+static inline ImgU8 flipHorizontal(const ImgU8& s) {
+  ImgU8 d(s.w, s.h, s.c);
+  for (int y = 0; y < s.h; ++y)
+    for (int x = 0; x < s.w; ++x)
+      for (int k = 0; k < s.c; ++k) d.at(y, x, k) = s.at(y, s.w - 1 - x, k);
+  return d;
+}
+// convertSphericalToCubemapBicubicRemap + stackOutputCubemapFaces for one eye (format "video" or "photo")
+static inline ImgU8 cubemapOfEye(const ImgU8& eyeBGR, int faceW, int faceH, const std::string& format) {
+  static const int faces[6] = {CUBE_RIGHT, CUBE_LEFT, CUBE_TOP, CUBE_BOTTOM, CUBE_BACK, CUBE_FRONT};
+  std::vector<ImgU8> img(6);
+  for (int f = 0; f < 6; ++f)
+    img[f] = remapCubicU8Wrap(eyeBGR, cubemapWarpMap(faces[f], eyeBGR.w, eyeBGR.h, (float)M_PI, faceW, faceH));
+  if (format == "video") {
+    const ImgU8 a = stackHorizontal({flipHorizontal(img[1]), flipHorizontal(img[0]), flipHorizontal(img[2])});
+    const ImgU8 b = stackHorizontal({flipHorizontal(img[3]), flipHorizontal(img[4]), flipHorizontal(img[5])});
+    return stackVertical2(a, b);
+  }
+  ImgU8 d = img[0];
+  for (int f = 1; f < 6; ++f) d = stackVertical2(d, img[f]);
+  return d;
+}
+static inline ImgU8 stereoCubemap(const ImgU8& eyeL, const ImgU8& eyeR, int faceW, int faceH, const std::string& format) {
+  return stackVertical2(cubemapOfEye(eyeL, faceW, faceH, format), cubemapOfEye(eyeR, faceW, faceH, format));
+}
+
 }  // namespace orc

@@ -495,6 +495,22 @@ int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
   });
 }
 
+int s360_frame_cubemap(s360_ctx* c, int face_w, int face_h, const char* format, int whc[3], uint8_t* out_bgr) {
+  return guard(c, [&] {
+    need(c && format && whc, "bad argument");
+    const std::string f(format);
+    if (f != "video" && f != "photo")  // CvUtil.cpp:134-137
+      throw Error(S360_ERR_INVALID_ARG, "unexpected cubemap format: " + f + ". valid formats are: video,photo");
+    need(face_w > 0 && face_h > 0, "cubemap face size must be positive");
+    whc[0] = f == "video" ? 3 * face_w : face_w;
+    whc[1] = f == "video" ? 4 * face_h : 12 * face_h;
+    whc[2] = 3;
+    if (!out_bgr) return;
+    int ow = 0, oh = 0;
+    frame_cubemap(c, face_w, face_h, f == "video", &ow, &oh);
+    d2h(c, out_bgr, frame_state(c).cubeOut.p, (size_t)ow * oh * 3);
+  });
+}
 int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_t* dst) {
   return guard(c, [&] {
     need(c && name && whc, "bad argument");

@@ -3,6 +3,7 @@
 // with no host round trips; buffers are persistent (sized once from rig + eqr size).
 #include "render.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -460,6 +461,75 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
       launch_pack_bgr(st, eye, outW, eyeH, F.outBGR.as<uint8_t>() + (size_t)e * outW * eyeH * 3);
     }
   }
+}
+
+// ---- cubemap output (TRSP:917-935) -------------------------------------------------------------------------------
+// Face warp maps of convertSphericalToCubemapBicubicRemap (ImageWarper.cpp:26-128): float arithmetic with the host's
+// acosf / sqrt exactly as the reference evaluates it; depends only on the sizes, so it is built once and cached.
+namespace {
+enum CubeFace { CUBE_BACK = 0, CUBE_LEFT, CUBE_TOP, CUBE_BOTTOM, CUBE_FRONT, CUBE_RIGHT };
+void cube_index_to_vec3(float x, float y, int face, float out[3]) {
+  const float dir[3] = {x, y, 0.5f};
+  out[0] = dir[0]; out[1] = dir[1]; out[2] = dir[2];
+  switch (face) {
+    case CUBE_BACK: out[0] = dir[0]; out[1] = dir[2]; out[2] = -dir[1]; break;
+    case CUBE_LEFT: out[0] = -dir[2]; out[1] = dir[0]; out[2] = -dir[1]; break;
+    case CUBE_TOP: break;
+    case CUBE_BOTTOM: out[0] = dir[0]; out[1] = -dir[1]; out[2] = -dir[2]; break;
+    case CUBE_FRONT: out[0] = -dir[0]; out[1] = -dir[2]; out[2] = -dir[1]; break;
+    case CUBE_RIGHT: out[0] = dir[2]; out[1] = -dir[0]; out[2] = -dir[1]; break;
+  }
+}
+void cube_map_entry(float x, float y, int face, int srcCols, int srcRows, float fov, float* srcX, float* srcY) {
+  float dir[3];
+  cube_index_to_vec3(x, y, face, dir);
+  const float r = sqrtf(dir[0] * dir[0] + dir[1] * dir[1]);
+  float s2 = 0.f;  // cv::norm(Vec3f): float accumulation, sqrt, returned as double
+  for (int i = 0; i < 3; ++i) s2 += dir[i] * dir[i];
+  const double nrm = (double)std::sqrt(s2);
+  const float phi = acosf((float)((double)dir[2] / nrm));
+  float theta = r > 0.0f ? acosf(std::fabs(dir[0] / r)) : 0.0f;
+  if (dir[0] > 0 && dir[1] > 0) {
+  } else if (dir[0] <= 0 && dir[1] > 0) {
+    theta = (float)(M_PI - theta);
+  } else if (dir[0] <= 0 && dir[1] <= 0) {
+    theta = (float)(M_PI + theta);
+  } else {
+    theta = (float)(2 * M_PI - theta);
+  }
+  const float phiPrime = std::min(std::max(phi, 0.0f), fov);
+  const float thetaPrime = std::min(std::max(theta, 0.0f), float(2.0f * M_PI));
+  *srcX = (float)(float(srcCols) * thetaPrime / (2.0f * M_PI));
+  *srcY = float(srcRows) * phiPrime / fov;
+}
+}  // namespace
+
+void frame_cubemap(s360_ctx* c, int fw, int fh, bool video, int* ow, int* oh) {
+  FrameState& F = frame_state(c);
+  if (fw <= 0 || fh <= 0) throw Error(S360_ERR_INVALID_ARG, "cubemap face size must be positive");
+  if (!F.pano[0].p || !F.pano[1].p || !F.outBGR.p) throw Error(S360_ERR_STATE, "no frame rendered yet");
+  const int W = c->P.eqr_width, H = c->P.eqr_height;
+  if (F.cubeW != fw || F.cubeH != fh || F.cubeSrcW != W || F.cubeSrcH != H) {
+    static const int faces[6] = {CUBE_RIGHT, CUBE_LEFT, CUBE_TOP, CUBE_BOTTOM, CUBE_BACK, CUBE_FRONT};
+    std::vector<float> m((size_t)6 * fw * fh * 2);
+    const float dy = 1.0f / float(fw), dx = 1.0f / float(fh);
+    for (int f = 0; f < 6; ++f)
+      for (int j = 0; j < fh; ++j)
+        for (int i = 0; i < fw; ++i) {
+          float* e = &m[(((size_t)f * fh + j) * fw + i) * 2];
+          cube_map_entry(float(i) * dy - 0.5f, float(j) * dx - 0.5f, faces[f], W, H, (float)M_PI, e, e + 1);
+        }
+    F.cubeMaps.ensure(m.size() * sizeof(float));
+    S360_HIP(hipMemcpyAsync(F.cubeMaps.p, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice, c->st));
+    S360_HIP(hipStreamSynchronize(c->st));  // `m` is freed on return
+    F.cubeW = fw; F.cubeH = fh; F.cubeSrcW = W; F.cubeSrcH = H;
+  }
+  *ow = video ? 3 * fw : fw;
+  *oh = video ? 4 * fh : 12 * fh;
+  F.cubeOut.ensure((size_t)*ow * *oh * 3);
+  ProfScope ps(c->prof, "cubemap");
+  launch_cubemap(c->st, F.pano[0].as<uchar4>(), F.pano[1].as<uchar4>(), W, H, F.cubeMaps.as<float2>(), fw, fh, video ? 1 : 0,
+                 F.cubeOut.as<uint8_t>(), F.tab.dev);
 }
 
 }  // namespace s360

@@ -42,6 +42,8 @@ struct FrameState {
   bool keep_intermediates = false;  // copy panoramas before the pole composite (parity tests)
   DevBuf panoDbg[2];
   int extW = 0, poleRows = 0;
+  DevBuf cubeMaps, cubeOut;  // cached face warp maps [6][fh][fw] float2 and the stacked BGR cubemap
+  int cubeW = 0, cubeH = 0, cubeSrcW = 0, cubeSrcH = 0;
 };
 
 FrameState& frame_state(s360_ctx* c);
@@ -49,6 +51,8 @@ void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, i
 void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h);
 void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev);
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev);
+// stereo cubemap of the last finished frame into F.cubeOut; returns its width/height through ow/oh
+void frame_cubemap(s360_ctx* c, int face_w, int face_h, bool video, int* ow, int* oh);
 
 // operator-level helpers on device buffers
 void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano_top_rows, int cols, int rows, uchar4* ext, int extW);

@@ -577,6 +577,60 @@ __global__ __launch_bounds__(256) void k_flatten_v4(const uint4* __restrict__ ba
   out[(size_t)y * w4 + x4] = o;
 }
 
+// ---- cubemap output (ImageWarper.cpp:95-141 + CvUtil.cpp:117-138) ------------------------------------------------
+// One thread per pixel of the stacked stereo cubemap: picks (eye, face, i, j) from the output position (faces are
+// flipped horizontally in the "video" layout), reads the cached face warp map and does remap INTER_CUBIC /
+// BORDER_WRAP from the eye panorama (taps wrap in x and in y). Output is packed BGR.
+__device__ __forceinline__ int border_wrap(int p, int len) {
+  if (p < 0) p -= ((p - len + 1) / len) * len;
+  if (p >= len) p %= len;
+  return p;
+}
+__global__ __launch_bounds__(256) void k_cubemap(const uchar4* __restrict__ eyeL, const uchar4* __restrict__ eyeR, int sw,
+                                                 int sh, const float2* __restrict__ maps /*[6][fh][fw]*/, int fw, int fh,
+                                                 int video, uint8_t* __restrict__ out, int ow, int oh,
+                                                 const short* __restrict__ tab) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= ow) return;
+  const int eyeH = oh / 2;
+  const int eye = y >= eyeH, ye = y - eye * eyeH;
+  int face, i, j;
+  if (video) {  // rows of three faces: {LEFT, RIGHT, TOP}, {BOTTOM, BACK, FRONT} = list indices {1,0,2},{3,4,5}; flipped
+    const int col = x / fw, row = ye / fh;
+    const int order[6] = {1, 0, 2, 3, 4, 5};
+    face = order[row * 3 + col];
+    i = fw - 1 - (x - col * fw);
+    j = ye - row * fh;
+  } else {  // "photo": the six faces stacked vertically in list order
+    face = ye / fh;
+    i = x;
+    j = ye - face * fh;
+  }
+  const float2 m = maps[((size_t)face * fh + j) * fw + i];
+  int sx, sy, fxy;
+  remap_coord(m.x, m.y, &sx, &sy, &fxy);
+  const short* w = tab + fxy * 16;
+  const uchar4* src = eye ? eyeR : eyeL;
+  int xs[4], ys[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { xs[q] = border_wrap(sx + q, sw); ys[q] = border_wrap(sy + q, sh); }
+  int s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uchar4* S = src + (size_t)ys[r] * sw;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uchar4 p = S[xs[q]];
+      const int ww = w[r * 4 + q];
+      s0 += p.x * ww; s1 += p.y * ww; s2 += p.z * ww;
+    }
+  }
+  uint8_t* o = out + ((size_t)y * ow + x) * 3;
+  o[0] = (uint8_t)sat_u8((s0 + (1 << 14)) >> 15);
+  o[1] = (uint8_t)sat_u8((s1 + (1 << 14)) >> 15);
+  o[2] = (uint8_t)sat_u8((s2 + (1 << 14)) >> 15);
+}
+
 __global__ __launch_bounds__(256) void k_pack_bgr(const uchar4* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -729,6 +783,12 @@ void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar
                        reinterpret_cast<const uint4*>(top), reinterpret_cast<uint4*>(out), w / 4, h, flip_top, T);
   else
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(w, 256), h), dim3(256), 0, st, base, top, out, w, h, flip_top, T);
+}
+void launch_cubemap(hipStream_t st, const uchar4* eyeL, const uchar4* eyeR, int sw, int sh, const float2* maps, int fw,
+                    int fh, int video, uint8_t* out, const DevTables& T) {
+  const int ow = video ? 3 * fw : fw, oh = video ? 4 * fh : 12 * fh;
+  hipLaunchKernelGGL(k_cubemap, dim3(cdiv(ow, 256), oh), dim3(256), 0, st, eyeL, eyeR, sw, sh, maps, fw, fh, video, out, ow,
+                     oh, T.bicubic_i);
 }
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst) {
   const size_t n = (size_t)w * h;

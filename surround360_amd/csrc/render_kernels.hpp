@@ -67,6 +67,9 @@ void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, in
 void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar4* out, int w, int h, int flip_top,
                     const DevTables& T);
 // BGRA rows -> packed BGR at row offset (stackVertical + BGRA2BGR, TRSP:890-894, 960)
+// stereo cubemap from the two eye panoramas through cached face warp maps (TRSP:917-935)
+void launch_cubemap(hipStream_t st, const uchar4* eyeL, const uchar4* eyeR, int sw, int sh, const float2* maps, int fw,
+                    int fh, int video, uint8_t* out, const DevTables& T);
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst);
 // sharpen (Filter.h:40-127) on BGRA in place, lp scratch same size
 void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount);

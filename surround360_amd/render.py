@@ -249,6 +249,14 @@ class Context:
         """'latency' (default) or 'throughput' — which sweep kernel PixFlow uses (bit-identical results)."""
         self._ck(lib().s360_set_sweep_mode(self.h, mode.encode()))
 
+    def cubemap(self, face_width, face_height, fmt="video"):
+        """Stereo cubemap of the last rendered frame (TestRenderStereoPanorama.cpp:917-935), BGR."""
+        whc = (C.c_int * 3)()
+        self._ck(lib().s360_frame_cubemap(self.h, int(face_width), int(face_height), fmt.encode(), whc, None))
+        out = np.empty((whc[1], whc[0], 3), np.uint8)
+        self._ck(lib().s360_frame_cubemap(self.h, int(face_width), int(face_height), fmt.encode(), whc, _p(out)))
+        return out
+
     def keep_intermediates(self, on=True):
         self._ck(lib().s360_set_keep_intermediates(self.h, int(on)))
 

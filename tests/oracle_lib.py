@@ -334,6 +334,14 @@ class Frame:
         lib().orc_frame_get_u8(self.h, name.encode(), idx, whc, _p(d))
         return d
 
+    def cubemap(self, face_w, face_h, fmt="video"):
+        whc = (C.c_int * 3)()
+        if lib().orc_frame_cubemap(self.h, face_w, face_h, fmt.encode(), whc, None) != 0:
+            raise ValueError("no frame rendered or unexpected cubemap format")
+        d = np.empty((whc[1], whc[0], 3), np.uint8)
+        lib().orc_frame_cubemap(self.h, face_w, face_h, fmt.encode(), whc, _p(d))
+        return d
+
     def get_f32(self, name, idx=0):
         whc = (C.c_int * 3)()
         if lib().orc_frame_get_f32(self.h, name.encode(), idx, whc, None) != 0:

@@ -148,3 +148,20 @@ def test_strip_buffer_view_for_the_gather(setup):
         # and with nothing touched the sharded path reproduces the single-GPU frame (test_sharded_pairs_equal_single)
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("fmt,fw,fh", [("video", 96, 80), ("photo", 64, 64)])
+def test_cubemap(setup, fmt, fw, fh):
+    """Stereo cubemap of the rendered frame (convertSphericalToCubemapBicubicRemap + stackOutputCubemapFaces,
+    ImageWarper.cpp:95-141, CvUtil.cpp:117-138, TRSP:917-935): byte-exact, both layouts, non-square faces."""
+    ctx = setup["ctx"]
+    ctx.upload_frame(setup["side"], setup["top"], setup["bottom"])
+    ctx.render()
+    setup["of"].render(setup["side"], setup["top"], setup["bottom"])
+    got = ctx.cubemap(fw, fh, fmt)
+    want = setup["of"].cubemap(fw, fh, fmt)
+    assert got.shape == ((4 * fh, 3 * fw, 3) if fmt == "video" else (12 * fh, fw, 3))
+    _cmp("cubemap " + fmt, got, want)
+    assert got.std() > 5
+    with pytest.raises(R.S360Error):
+        ctx.cubemap(fw, fh, "cross")

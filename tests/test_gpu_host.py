@@ -51,6 +51,10 @@ def test_two_frames_through_the_binary(tmp_path, rig_json, oracle, s360lib):
                "--final_eqr_height=960", "--side_flow_alg", "pixflow_low", "--polar_flow_alg", "pixflow_low",
                "--sharpening", "0.0", "--logbuflevel", "-1", "--stderrthreshold", "0", "--v", "1",
                "--log_dir", out]  # the glog flags batch_process_video.py passes
+        cube = os.path.join(out, "cube_%s.png" % f)
+        if f == "000001":
+            cmd += ["--output_cubemap_path", cube, "--cubemap_width", "96", "--cubemap_height", "96",
+                    "--cubemap_format", "video"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert "Runtime breakdown" in r.stderr
@@ -60,6 +64,10 @@ def test_two_frames_through_the_binary(tmp_path, rig_json, oracle, s360lib):
         assert got.shape == want.shape == (960, 960, 3)
         d = got.astype(np.int32) - want.astype(np.int32)
         assert not d.any(), "frame %s: %d mismatching bytes" % (f, int((d != 0).sum()))
+        if f == "000001":  # TRSP:917-935
+            got_c = np.asarray(Image.open(cube))[:, :, ::-1]
+            want_c = of.cubemap(96, 96, "video")
+            assert got_c.shape == want_c.shape == (384, 288, 3) and np.array_equal(got_c, want_c)
         # the state files the next frame (or a --resume) needs, under the reference's names
         for i in (0, 13):
             assert os.path.exists(os.path.join(out, "flow", f, "flowLtoR_%d.bin" % i))
