@@ -5,7 +5,7 @@
 //
 // Kept on the host, as in the reference: flag parsing, the rig loader (inside libs360: rig.cpp), directory
 // scanning, PNG decode/encode (png_io.hpp instead of cv::imread/imwrite) and the flow-state files.
-// Not supported here (out of scope): --enable_pole_removal, --save_debug_images.
+// Not supported here: --save_debug_images (debug PNGs only).
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -153,7 +153,6 @@ int main(int argc, char** argv) {
   require_arg(F.s("frame_number"), "frame_number");
   require_arg(F.s("output_data_dir"), "output_data_dir");
   require_arg(F.s("output_equirect_path"), "output_equirect_path");
-  if (F.b("enable_pole_removal")) std::fprintf(stderr, "WARNING: --enable_pole_removal is not supported by this build; ignored\n");
   const int verbose = F.i("v");
   const double startTime = now_sec();
 
@@ -181,6 +180,9 @@ int main(int argc, char** argv) {
   prm.final_eqr_height = F.i("final_eqr_height");
   std::strncpy(prm.side_flow_alg, F.s("side_flow_alg").c_str(), sizeof(prm.side_flow_alg) - 1);
   std::strncpy(prm.polar_flow_alg, F.s("polar_flow_alg").c_str(), sizeof(prm.polar_flow_alg) - 1);
+  prm.enable_pole_removal = F.b("enable_pole_removal") && F.b("enable_bottom");
+  std::strncpy(prm.poleremoval_flow_alg, F.s("poleremoval_flow_alg").c_str(), sizeof(prm.poleremoval_flow_alg) - 1);
+  if (prm.enable_pole_removal) require_arg(F.s("bottom_pole_masks_dir"), "bottom_pole_masks_dir");  // TRSP:571
 
   s360_ctx* ctx = nullptr;
   if (s360_create(&ctx, F.i("device"), cams.data(), ncams, &prm) < 0) die(s360_last_error(nullptr));
@@ -211,6 +213,16 @@ int main(int argc, char** argv) {
     if (bi < 0) die("no bottom camera in the rig");
     const pngio::Image im = load_png(imgs + "/" + cams[bi].id + "/" + frame + ".png", false);  // TRSP:602
     ck(s360_frame_upload_bottom(ctx, im.px.data(), im.w, im.h), ctx);
+    if (prm.enable_pole_removal) {  // PoleRemoval.cpp:48-66
+      const int b2 = s360_rig_find_bottom2(cams.data(), ncams);
+      const std::string masks = F.s("bottom_pole_masks_dir");
+      const pngio::Image im2 = load_png(imgs + "/" + cams[b2].id + "/" + frame + ".png", false);
+      const pngio::Image m1 = load_png(masks + "/" + cams[bi].id + ".png", false);
+      const pngio::Image m2 = load_png(masks + "/" + cams[b2].id + ".png", false);
+      if (im2.w != im.w || im2.h != im.h || m1.w != im.w || m1.h != im.h || m2.w != im.w || m2.h != im.h)
+        die("missing or bad pole mask:" + masks + "/" + cams[bi].id + ".png," + masks + "/" + cams[b2].id + ".png");
+      ck(s360_frame_upload_pole_removal(ctx, im2.px.data(), m1.px.data(), m2.px.data(), im.w, im.h), ctx);
+    }
   }
   const double loadTime = now_sec();
 
@@ -236,6 +248,18 @@ int main(int argc, char** argv) {
       if (L.c != 4 || R.c != 4 || L.w != g.overlap_image_width || L.h != g.cam_image_height || R.w != L.w || R.h != L.h)
         die("previous overlap images have the wrong size/channels");
       ck(s360_frame_set_prev_side(ctx, i, fl.data(), fr.data(), L.px.data(), R.px.data()), ctx);
+    }
+    if (prm.enable_pole_removal) {  // PoleRemoval.cpp:95-110
+      int w = 0, h = 0;
+      if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), nullptr, &w, &h, 0) < 0)
+        die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
+      std::vector<float> pf((size_t)w * h * 2);
+      if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), pf.data(), &w, &h, pf.size()) < 0)
+        die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
+      const pngio::Image b1 = load_png(imgPrevDir + "/bottomImage.png", true), b2 = load_png(imgPrevDir + "/bottomImage2.png", true);
+      if (b1.c != 4 || b2.c != 4 || b1.w != w || b1.h != h || b2.w != w || b2.h != h)
+        die("previous bottomImage / bottomImage2 have the wrong size/channels");
+      ck(s360_frame_set_prev_pole_removal(ctx, pf.data(), b1.px.data(), b2.px.data(), w, h), ctx);
     }
     for (int u = 0; u < 4; ++u) {
       if ((u < 2 && !prm.enable_top) || (u >= 2 && !prm.enable_bottom)) continue;
@@ -277,6 +301,17 @@ int main(int argc, char** argv) {
       ck(s360_save_flow_to_file((flowDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
       ck(s360_frame_get_f32(ctx, "flow_r_to_l", i, whc, fl.data()), ctx);
       ck(s360_save_flow_to_file((flowDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
+    }
+    if (prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
+      ck(s360_frame_get_u8(ctx, "bottom_image", 0, whc, nullptr), ctx);
+      std::vector<uint8_t> bimg((size_t)whc[0] * whc[1] * 4);
+      std::vector<float> bfl((size_t)whc[0] * whc[1] * 2);
+      ck(s360_frame_get_u8(ctx, "bottom_image", 0, whc, bimg.data()), ctx);
+      save_png(flowImagesDir + "/bottomImage.png", bimg.data(), whc[0], whc[1], 4);
+      ck(s360_frame_get_u8(ctx, "bottom_image2", 0, whc, bimg.data()), ctx);
+      save_png(flowImagesDir + "/bottomImage2.png", bimg.data(), whc[0], whc[1], 4);
+      ck(s360_frame_get_f32(ctx, "flow_bottom_secondary", 0, whc, bfl.data()), ctx);
+      ck(s360_save_flow_to_file((flowDir + "/flow_bottom_secondary.bin").c_str(), bfl.data(), whc[0], whc[1]), nullptr);
     }
     for (int u = 0; u < 4; ++u) {
       if ((u < 2 && !prm.enable_top) || (u >= 2 && !prm.enable_bottom)) continue;

@@ -66,6 +66,9 @@ typedef struct s360_params {
   int32_t final_eqr_width, final_eqr_height;
   char side_flow_alg[32];  /* "pixflow_low" | "pixflow_search_20" */
   char polar_flow_alg[32];
+  int32_t enable_pole_removal;    /* TRSP:58: merge the two bottom cameras to erase the tripod pole (needs the secondary
+                                     bottom image and the red pole masks: s360_frame_upload_pole_removal) */
+  char poleremoval_flow_alg[32];  /* "" = "pixflow_low" */
 } s360_params;
 
 /* Derived sizes (SR/test/TestRenderStereoPanorama.cpp:153-173, 309-348, 656-659). */
@@ -100,6 +103,10 @@ double s360_camera_get_fov(const s360_camera* cam);
 /* RigDescription::findCameraByDirection(+Z / -Z) (SR/render/RigDescription.cpp:33-47); index or <0. */
 int s360_rig_find_top(const s360_camera* cams, int n);
 int s360_rig_find_bottom(const s360_camera* cams, int n);
+/* RigDescription::findLargestDistCamAxisToRigCenter (RigDescription.cpp:46-54): the secondary bottom camera. */
+int s360_rig_find_bottom2(const s360_camera* cams, int n);
+/* Camera::approximateUsablePixelsRadius (SR/render/Camera.h:201-212). */
+float s360_camera_usable_pixels_radius(const s360_camera* cam);
 
 /* Derived panorama geometry for a rig + flag set (host only; what s360_create computes and caches). */
 int s360_derive_geometry(const s360_camera* cams, int n_cams, const s360_params* params, s360_geometry* out);
@@ -165,6 +172,10 @@ int s360_sharpen(s360_ctx* ctx, uint8_t* bgr, int w, int h, float sharpening);
 int s360_frame_upload_side(s360_ctx* ctx, int side_idx, const uint8_t* img, int w, int h, int channels);
 int s360_frame_upload_top(s360_ctx* ctx, const uint8_t* bgr, int w, int h);
 int s360_frame_upload_bottom(s360_ctx* ctx, const uint8_t* bgr, int w, int h);
+/* --enable_pole_removal inputs (combineBottomImagesWithPoleRemoval, SR/render/PoleRemoval.cpp:32-188): the secondary
+ * bottom camera's image and the red masks of both bottom cameras (pure BGR red (0,0,255) = pole), all BGR w x h. */
+int s360_frame_upload_pole_removal(s360_ctx* ctx, const uint8_t* bottom2_bgr, const uint8_t* mask_bgr,
+                                   const uint8_t* mask2_bgr, int w, int h);
 /* Enqueue the whole frame on the context stream (asynchronous). use_prev != 0 applies the
  * temporal regularisation against the previous s360_frame_render's device-resident state
  * (the reference's --prev_frame_data_dir, TRSP:215-235, 421-436). */
@@ -187,10 +198,11 @@ int s360_frame_cubemap(s360_ctx* ctx, int face_width, int face_height, const cha
 /* Intermediates for stage-by-stage parity tests and for the reference's on-disk state
  * (overlap_<i>_{L,R}.png, flow{LtoR,RtoL}_<i>.bin, extended*Spherical_<eye>.png, flow_<eye>.bin).
  * Names: "projection"(idx cam) "overlap_l" "overlap_r" "side_pano_l" "side_pano_r" "top_spherical"
- * "bottom_spherical" "pole_warped"(idx 0..3) "extended_side" "extended_fisheye" "eye_l" "eye_r".
+ * "bottom_spherical" "pole_warped"(idx 0..3) "extended_side" "extended_fisheye" "eye_l" "eye_r"
+ * "bottom_image" "bottom_image2" (pole removal's flow inputs).
  * whc receives width/height/channels; dst may be NULL for a size query. */
 int s360_frame_get_u8(s360_ctx* ctx, const char* name, int idx, int whc[3], uint8_t* dst);
-/* "flow_l_to_r" "flow_r_to_l" (idx pair) "flow_pole" (idx 0..3). */
+/* "flow_l_to_r" "flow_r_to_l" (idx pair) "flow_pole" (idx 0..3) "flow_bottom_secondary". */
 int s360_frame_get_f32(s360_ctx* ctx, const char* name, int idx, int whc[3], float* dst);
 
 /* Temporal state from a previous process (the reference's --prev_frame_data_dir files, TRSP:215-235, 421-436):
@@ -202,6 +214,10 @@ int s360_frame_set_prev_side(s360_ctx* ctx, int pair_idx, const float* flow_l_to
                              const uint8_t* overlap_l_bgra, const uint8_t* overlap_r_bgra);
 int s360_frame_set_prev_pole(s360_ctx* ctx, int unit, const float* flow, const uint8_t* extended_side_bgra,
                              const uint8_t* extended_fisheye_bgra);
+/* flow_bottom_secondary.bin + flow_images/bottomImage.png, bottomImage2.png (PoleRemoval.cpp:95-110), w x h of the
+ * bottom cameras. */
+int s360_frame_set_prev_pole_removal(s360_ctx* ctx, const float* flow, const uint8_t* bottom_image_bgra,
+                                     const uint8_t* bottom_image2_bgra, int w, int h);
 
 /* Keep copies of the eye panoramas as they are before the pole composite ("side_pano_l/r"); costs two
  * device copies per frame, off by default. */

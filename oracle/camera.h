@@ -6,6 +6,7 @@
 // Known answers: Camera::unitTest (Camera.cpp:291-410) is replayed by
 // tests/test_camera.py through oracle_capi.cpp.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -194,6 +195,21 @@ static inline float approximateFov(const std::vector<Camera>& rig, bool vertical
   return result;
 }
 
+// Camera.h:201-212
+static inline float approximateUsablePixelsRadius(const Camera& camera) {
+  const double fov = camera.getFov();
+  const double kStep = 2 * M_PI / 10.0;
+  double result = std::sqrt(camera.resolution.x * camera.resolution.x + camera.resolution.y * camera.resolution.y);
+  for (double a = 0; a < 2 * M_PI; a += kStep) {
+    const V3 ortho = camera.right() * std::cos(a) + camera.up() * std::sin(a);
+    const V3 direction = camera.forward() * std::cos(fov) + ortho * std::sin(fov);
+    const V2 pixel = camera.pixel(camera.position + direction);
+    const double dx = pixel.x - camera.resolution.x / 2.0, dy = pixel.y - camera.resolution.y / 2.0;
+    result = std::min(result, std::sqrt(dx * dx + dy * dy));
+  }
+  return (float)result;
+}
+
 struct RigDescription {
   std::vector<Camera> rig, rigSideOnly;
   // RigDescription.cpp:18-31 (construction from an already-parsed camera list)
@@ -215,6 +231,13 @@ struct RigDescription {
     for (const Camera& c : rig)
       if (best == nullptr || best->forward().dot(dir) < c.forward().dot(dir))
         if (distCamAxisToRigCenter(c) <= maxDist) best = &c;
+    return *best;
+  }
+  // RigDescription.cpp:46-54: the camera whose optical axis passes farthest from the rig centre (secondary bottom)
+  const Camera& findLargestDistCamAxisToRigCenter() const {
+    const Camera* best = &rig.back();
+    for (const Camera& c : rig)
+      if (distCamAxisToRigCenter(c) > distCamAxisToRigCenter(*best)) best = &c;
     return *best;
   }
   float getRingRadius() const { return (float)rigSideOnly[0].position.norm(); }

@@ -31,6 +31,7 @@ struct orc_params_c {
   int enable_top, enable_bottom;
   int eqr_width, eqr_height, final_eqr_width, final_eqr_height;
   int side_flow_search20, polar_flow_search20;
+  int enable_pole_removal, poleremoval_flow_search20;
 };
 }
 
@@ -61,6 +62,8 @@ static RenderParams makeParams(const orc_params_c& p) {
   P.final_eqr_width = p.final_eqr_width; P.final_eqr_height = p.final_eqr_height;
   P.side_flow_alg = p.side_flow_search20 ? "pixflow_search_20" : "pixflow_low";
   P.polar_flow_alg = p.polar_flow_search20 ? "pixflow_search_20" : "pixflow_low";
+  P.enable_pole_removal = p.enable_pole_removal;
+  P.poleremoval_flow_alg = p.poleremoval_flow_search20 ? "pixflow_search_20" : "pixflow_low";
   return P;
 }
 static ImgU8 wrapU8(const uint8_t* p, int w, int h, int c) {
@@ -251,6 +254,8 @@ struct orc_frame {
   ImgU8 out;
   double stage[5] = {0, 0, 0, 0, 0};
   std::map<std::string, const ImgU8*> named;
+  PoleRemovalInput poleRemoval;
+  bool havePoleRemoval = false;
 };
 
 orc_frame* orc_frame_create(const orc_camera_c* cams, int ncams, const orc_params_c* p) {
@@ -287,11 +292,26 @@ double orc_frame_render(orc_frame* f, const uint8_t* const* side, int w, int h, 
   const FrameState* prev = (use_prev && f->havePrev) ? &f->state[f->cur ^ 1] : nullptr;
   FrameState* st = &f->state[f->cur];
   *st = FrameState();
-  f->out = renderStereoPanorama(f->rig, f->P, imgs, t, b, prev, st, &f->dbg, threaded != 0, f->stage);
+  f->out = renderStereoPanorama(f->rig, f->P, imgs, t, b, prev, st, &f->dbg, threaded != 0, f->stage,
+                                f->havePoleRemoval ? &f->poleRemoval : nullptr);
   f->havePrev = true;
   f->cur ^= 1;
   return f->stage[4];
 }
+// Secondary bottom camera image + the two red pole masks (BGR, same size) for --enable_pole_removal (TRSP:569-597).
+void orc_frame_set_pole_removal(orc_frame* f, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w,
+                                int h) {
+  f->poleRemoval.bottom2 = wrapU8(bottom2, w, h, 3);
+  f->poleRemoval.mask = wrapU8(mask, w, h, 3);
+  f->poleRemoval.mask2 = wrapU8(mask2, w, h, 3);
+  f->havePoleRemoval = true;
+}
+// Index (in rig order) of RigDescription::findLargestDistCamAxisToRigCenter and Camera::approximateUsablePixelsRadius.
+int orc_frame_bottom2_index(orc_frame* f) {
+  const Camera& c = f->rig.findLargestDistCamAxisToRigCenter();
+  return (int)(&c - &f->rig.rig[0]);
+}
+float orc_frame_usable_pixels_radius(orc_frame* f, int cam_idx) { return approximateUsablePixelsRadius(f->rig.rig[cam_idx]); }
 void orc_frame_stage_seconds(orc_frame* f, double* out5) { std::memcpy(out5, f->stage, sizeof(f->stage)); }
 
 static const ImgU8* frameImage(orc_frame* f, const char* name, int idx) {
@@ -310,6 +330,8 @@ static const ImgU8* frameImage(orc_frame* f, const char* name, int idx) {
   if (n == "overlap_r") return &st.overlapR[idx];
   if (n == "extended_side") return &st.pole[idx].extendedSide;
   if (n == "extended_fisheye") return &st.pole[idx].extendedFisheye;
+  if (n == "bottom_image") return &st.poleRemoval.bottomImage;
+  if (n == "bottom_image2") return &st.poleRemoval.bottomImage2;
   return nullptr;
 }
 static const ImgF* frameFlow(orc_frame* f, const char* name, int idx) {
@@ -318,6 +340,7 @@ static const ImgF* frameFlow(orc_frame* f, const char* name, int idx) {
   if (n == "flow_l_to_r") return &st.flowLtoR[idx];
   if (n == "flow_r_to_l") return &st.flowRtoL[idx];
   if (n == "flow_pole") return &st.pole[idx].flow;
+  if (n == "flow_bottom_secondary") return &st.poleRemoval.flow;
   return nullptr;
 }
 // Query dims (whc3) then copy (dst may be null for a dims-only query). Returns 0 ok, -1 unknown name.

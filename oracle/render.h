@@ -36,6 +36,8 @@ struct RenderParams {
   double zero_parallax_dist = 10000.0;
   int eqr_width = 256, eqr_height = 128;
   int final_eqr_width = 3480, final_eqr_height = 960;
+  int enable_pole_removal = 0;
+  std::string poleremoval_flow_alg = "pixflow_low";
 };
 
 // ---------------------------------------------------------------------------
@@ -297,6 +299,86 @@ static inline ImgU8 flattenLayersDeghostPreferBase(const ImgU8& bottomLayer, con
 }
 
 // ---------------------------------------------------------------------------
+// flow_bottom_secondary.bin + flow_images/bottomImage{,2}.png (PoleRemoval.cpp:95-126)
+struct PoleRemovalState {
+  ImgF flow;
+  ImgU8 bottomImage, bottomImage2;
+  bool valid = false;
+};
+// the secondary bottom camera's image and the two red pole masks (PoleRemoval.cpp:48-66)
+struct PoleRemovalInput {
+  ImgU8 bottom2, mask, mask2;  // BGR
+};
+
+// CvUtil.cpp:201-211
+static inline void circleAlphaCut(ImgU8& imageBGRA, float radius) {
+  for (int y = 0; y < imageBGRA.h; ++y)
+    for (int x = 0; x < imageBGRA.w; ++x) {
+      const float dx = float(x) - float(imageBGRA.w) / 2.0f;
+      const float dy = float(y) - float(imageBGRA.h) / 2.0f;
+      const float r = sqrtf(dx * dx + dy * dy);
+      const float alpha = r < radius ? 1.0f : 0.0f;
+      imageBGRA.at(y, x, 3) = (unsigned char)(alpha * 255.0f);
+    }
+}
+// CvUtil.cpp:213-222
+static inline void cutRedMaskOutOfAlphaChannel(ImgU8& destBGRA, const ImgU8& redMaskBGR) {
+  assert(destBGRA.w == redMaskBGR.w && destBGRA.h == redMaskBGR.h);
+  for (int y = 0; y < redMaskBGR.h; ++y)
+    for (int x = 0; x < redMaskBGR.w; ++x)
+      if (redMaskBGR.at(y, x, 0) == 0 && redMaskBGR.at(y, x, 1) == 0 && redMaskBGR.at(y, x, 2) == 255)
+        destBGRA.at(y, x, 3) = 0;
+}
+// combineBottomImagesWithPoleRemoval (PoleRemoval.cpp:32-188) on decoded images; returns the merged BGRA bottom image.
+static inline ImgU8 combineBottomImagesWithPoleRemoval(const RigDescription& rig, const RenderParams& P,
+                                                       const ImgU8& bottomBGR, const PoleRemovalInput& in,
+                                                       const PoleRemovalState* prev, PoleRemovalState* state) {
+  const Camera& cam = rig.findCameraByDirection(V3(0, 0, -1));  // TRSP:576-580
+  const Camera& cam2 = rig.findLargestDistCamAxisToRigCenter();
+  const float radius = approximateUsablePixelsRadius(cam), radius2 = approximateUsablePixelsRadius(cam2);
+  const bool flip180 = cam.up().dot(cam2.up()) < 0;
+  ImgU8 bottomImage = bgr2bgra(bottomBGR), bottomImage2 = bgr2bgra(in.bottom2);
+  circleAlphaCut(bottomImage, radius);
+  circleAlphaCut(bottomImage2, radius2);
+  cutRedMaskOutOfAlphaChannel(bottomImage, in.mask);
+  cutRedMaskOutOfAlphaChannel(bottomImage2, in.mask2);
+  bottomImage = featherAlphaChannel(bottomImage, P.std_alpha_feather_size);
+  bottomImage2 = featherAlphaChannel(bottomImage2, P.std_alpha_feather_size);
+  if (flip180) bottomImage2 = flipBoth(bottomImage2);
+  PixFlowParams fp;
+  pixflowParamsByName(P.poleremoval_flow_alg, &fp);
+  PixFlow pf(fp);
+  ImgF flow;
+  if (prev && prev->valid)
+    pf.computeOpticalFlow(bottomImage, bottomImage2, prev->flow, prev->bottomImage, prev->bottomImage2, flow, HINT_DOWN);
+  else
+    pf.computeOpticalFlow(bottomImage, bottomImage2, ImgF(), ImgU8(), ImgU8(), flow, HINT_DOWN);
+  if (state) { state->flow = flow; state->bottomImage = bottomImage; state->bottomImage2 = bottomImage2; state->valid = true; }
+  ImgF warp(bottomImage.w, bottomImage.h, 2);
+  for (int y = 0; y < warp.h; ++y)
+    for (int x = 0; x < warp.w; ++x) {
+      warp.at(y, x, 0) = float(x) + flow.at(y, x, 0);
+      warp.at(y, x, 1) = float(y) + flow.at(y, x, 1);
+    }
+  const ImgU8 warped2 = remapCubicU8(bottomImage2, warp);
+  for (int y = 0; y < bottomImage.h; ++y)
+    for (int x = 0; x < bottomImage.w; ++x) {
+      uint8_t* p1 = bottomImage.px(y, x);
+      const uint8_t* p2 = warped2.px(y, x);
+      const float alpha = p1[3] / 255.0f, alpha2 = p2[3] / 255.0f;
+      if (alpha < 1.0f && alpha2 > 0.0f) {
+        const float a1 = alpha, a2 = 1.0f - alpha;
+        const float r1 = p1[2], g1 = p1[1], b1 = p1[0], r2 = p2[2], g2 = p2[1], b2 = p2[0];
+        p1[0] = (unsigned char)(a1 * b1 + a2 * b2);
+        p1[1] = (unsigned char)(a1 * g1 + a2 * g2);
+        p1[2] = (unsigned char)(a1 * r1 + a2 * r2);
+        p1[3] = 255;
+      }
+    }
+  circleAlphaCut(bottomImage, radius);
+  return featherAlphaChannel(bottomImage, P.std_alpha_feather_size);
+}
+
 // TRSP:647-685 / 564-644 (no pole removal): pole camera -> spherical BGRA with
 // the bottom-rows alpha feather.
 static inline ImgU8 preparePoleImage(const ImgU8& img, const Camera& cam, const RenderParams& P, bool isTop) {
@@ -306,9 +388,9 @@ static inline ImgU8 preparePoleImage(const ImgU8& img, const Camera& cam, const 
     sph = bicubicRemapToSpherical(P.eqr_width, rows, 3, img, cam, (float)(2.0f * M_PI), 0.f, (float)(M_PI / 2.0f),
                                   (float)(M_PI / 2.0f - cam.getFov()));
   else
-    sph = bicubicRemapToSpherical(P.eqr_width, rows, 3, img, cam, 0.f, (float)(2.0f * M_PI), (float)(-(M_PI / 2.0f)),
+    sph = bicubicRemapToSpherical(P.eqr_width, rows, img.c, img, cam, 0.f, (float)(2.0f * M_PI), (float)(-(M_PI / 2.0f)),
                                   (float)(-(M_PI / 2.0f - cam.getFov())));
-  sph = bgr2bgra(sph);
+  if (sph.c != 4) sph = bgr2bgra(sph);  // TRSP:621-623: the pole-removal result already has an alpha channel
   const int yFeatherStart = sph.h - 1 - P.std_alpha_feather_size;
   for (int y = yFeatherStart; y < sph.h; ++y)
     for (int x = 0; x < sph.w; ++x) {
@@ -460,6 +542,7 @@ static inline void sharpen(ImgU8& img /*BGR*/, float sharpening) {
 // Temporal state the reference writes under output_data_dir for the next frame
 // (TRSP:201-255, 413-452).
 struct FrameState {
+  PoleRemovalState poleRemoval;
   std::vector<ImgU8> overlapL, overlapR;
   std::vector<ImgF> flowLtoR, flowRtoL;
   PoleFlowState pole[4];  // top_left, top_right, bottom_left, bottom_right
@@ -480,7 +563,8 @@ struct FrameDebug {  // intermediates exposed for stage-by-stage parity tests
 static inline ImgU8 renderStereoPanorama(const RigDescription& rig, const RenderParams& P,
                                          const std::vector<ImgU8>& sideImages, const ImgU8& topImage,
                                          const ImgU8& bottomImage, const FrameState* prev, FrameState* state,
-                                         FrameDebug* dbg, bool threaded, double* stageSec /*[5] or null*/) {
+                                         FrameDebug* dbg, bool threaded, double* stageSec /*[5] or null*/,
+                                         const PoleRemovalInput* poleRemoval = nullptr) {
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const int numCams = (int)rig.rigSideOnly.size();
   const SideGeometry g = sideGeometry(rig, P);
@@ -489,7 +573,16 @@ static inline ImgU8 renderStereoPanorama(const RigDescription& rig, const Render
   ImgU8 topSph, botSph;
   std::thread topThread, botThread;
   if (P.enable_bottom) {
-    auto f = [&] { botSph = preparePoleImage(bottomImage, rig.findCameraByDirection(V3(0, 0, -1)), P, false); };
+    auto f = [&] {
+      if (P.enable_pole_removal && poleRemoval) {  // TRSP:569-597
+        const ImgU8 merged = combineBottomImagesWithPoleRemoval(rig, P, bottomImage, *poleRemoval,
+                                                                prev ? &prev->poleRemoval : nullptr,
+                                                                state ? &state->poleRemoval : nullptr);
+        botSph = preparePoleImage(merged, rig.findCameraByDirection(V3(0, 0, -1)), P, false);
+      } else {
+        botSph = preparePoleImage(bottomImage, rig.findCameraByDirection(V3(0, 0, -1)), P, false);
+      }
+    };
     if (threaded) botThread = std::thread(f); else f();
   }
   if (P.enable_top) {

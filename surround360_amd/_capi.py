@@ -29,6 +29,7 @@ class Params(C.Structure):
         ("eqr_width", C.c_int32), ("eqr_height", C.c_int32),
         ("final_eqr_width", C.c_int32), ("final_eqr_height", C.c_int32),
         ("side_flow_alg", C.c_char * 32), ("polar_flow_alg", C.c_char * 32),
+        ("enable_pole_removal", C.c_int32), ("poleremoval_flow_alg", C.c_char * 32),
     ]
 
 
@@ -45,13 +46,13 @@ class Geometry(C.Structure):
 # every symbol include/s360.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "s360_version", "s360_device_count", "s360_last_error", "s360_rig_load_json", "s360_camera_init",
-    "s360_camera_pixel", "s360_camera_get_fov", "s360_rig_find_top", "s360_rig_find_bottom", "s360_derive_geometry",
+    "s360_camera_pixel", "s360_camera_get_fov", "s360_rig_find_top", "s360_rig_find_bottom", "s360_rig_find_bottom2", "s360_camera_usable_pixels_radius", "s360_derive_geometry",
     "s360_pole_ramp", "s360_create",
     "s360_destroy", "s360_get_geometry", "s360_stream", "s360_synchronize", "s360_compute_optical_flow",
     "s360_compute_optical_flow_batch", "s360_bicubic_remap_to_spherical", "s360_spherical_warp_map",
     "s360_combine_lazy_novel_views", "s360_flatten_layers_deghost_prefer_base", "s360_offset_horizontal_wrap",
     "s360_feather_alpha_channel", "s360_pole_to_side_flow", "s360_sharpen", "s360_frame_upload_side",
-    "s360_frame_upload_top", "s360_frame_upload_bottom", "s360_frame_render", "s360_frame_render_pairs",
+    "s360_frame_upload_top", "s360_frame_upload_bottom", "s360_frame_upload_pole_removal", "s360_frame_set_prev_pole_removal", "s360_frame_render", "s360_frame_render_pairs",
     "s360_frame_set_prev_side", "s360_frame_set_prev_pole", "s360_frame_strip_ptr", "s360_frame_finish", "s360_frame_download_equirect", "s360_frame_equirect_dev",
     "s360_frame_cubemap", "s360_frame_get_u8", "s360_frame_get_f32", "s360_set_keep_intermediates", "s360_set_sweep_mode", "s360_debug_flow_levels",
     "s360_profile_enable", "s360_profile_get", "s360_save_flow_to_file", "s360_read_flow_from_file",
@@ -72,6 +73,7 @@ def lib():
         L.s360_last_error.restype = C.c_char_p
         L.s360_last_error.argtypes = [C.c_void_p]
         L.s360_camera_get_fov.restype = C.c_double
+        L.s360_camera_usable_pixels_radius.restype = C.c_float
         L.s360_stream.restype = C.c_void_p
         L.s360_stream.argtypes = [C.c_void_p]
         for name in ("s360_destroy", "s360_synchronize", "s360_get_geometry"):

@@ -39,6 +39,7 @@ static void check_sweep_error(s360_ctx* c) {
   unsigned e = 0;
   if (c->flow) e |= c->flow->take_error(c->st);
   if (c->flow_pole) e |= c->flow_pole->take_error(c->st);
+  if (c->flow_pr) e |= c->flow_pr->take_error(c->st);
   if (e) throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
 }
 static void d2h(s360_ctx* c, void* h, const void* d, size_t n) {
@@ -107,6 +108,13 @@ static int find_dir(const s360_camera* cams, int n, double z) {
 }
 int s360_rig_find_top(const s360_camera* cams, int n) { return find_dir(cams, n, 1.0); }
 int s360_rig_find_bottom(const s360_camera* cams, int n) { return find_dir(cams, n, -1.0); }
+int s360_rig_find_bottom2(const s360_camera* cams, int n) {
+  if (!cams || n <= 0) return -1;
+  Rig r;
+  r.all.assign(cams, cams + n);
+  return r.find_largest_axis_dist();
+}
+float s360_camera_usable_pixels_radius(const s360_camera* cam) { return cam ? approximate_usable_pixels_radius(cam) : 0.f; }
 
 int s360_derive_geometry(const s360_camera* cams, int n_cams, const s360_params* params, s360_geometry* out) {
   return guard(nullptr, [&] {
@@ -411,6 +419,29 @@ int s360_frame_upload_top(s360_ctx* c, const uint8_t* bgr, int w, int h) {
 int s360_frame_upload_bottom(s360_ctx* c, const uint8_t* bgr, int w, int h) {
   return guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, false, bgr, w, h); });
 }
+int s360_frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w,
+                                   int h) {
+  return guard(c, [&] {
+    need(c && bottom2 && mask && mask2 && w > 0 && h > 0, "bad argument");
+    frame_upload_pole_removal(c, bottom2, mask, mask2, w, h);
+  });
+}
+int s360_frame_set_prev_pole_removal(s360_ctx* c, const float* flow, const uint8_t* bottom_image, const uint8_t* bottom_image2,
+                                     int w, int h) {
+  return guard(c, [&] {
+    need(c && flow && bottom_image && bottom_image2 && w > 0 && h > 0, "bad argument");
+    FrameState& F = frame_state(c);
+    const size_t n = (size_t)w * h;
+    const int prv = F.cur_pr ^ 1;
+    F.prImgs[prv].ensure(2 * n * sizeof(uchar4));
+    F.prFlow[prv].ensure(n * sizeof(float2));
+    h2d(c, F.prImgs[prv].as<uchar4>(), bottom_image, n * sizeof(uchar4));
+    h2d(c, F.prImgs[prv].as<uchar4>() + n, bottom_image2, n * sizeof(uchar4));
+    h2d(c, F.prFlow[prv].p, flow, n * sizeof(float2));
+    S360_HIP(hipStreamSynchronize(c->st));
+    F.have_prev_pr = true;
+  });
+}
 int s360_frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
   return guard(c, [&] { need(c, "null ctx"); frame_render_pairs(c, p0, p1, use_prev); });
 }
@@ -545,6 +576,10 @@ int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_
       w = F.extW; h = F.poleRows;
       const int slot = n == "extended_side" ? idx : (idx < 2 ? 4 : 5);
       src = F.extImgs[F.last_pole].as<uchar4>() + (size_t)w * h * slot;
+    } else if (n == "bottom_image" || n == "bottom_image2") {
+      need(F.prImgs[F.last_pr].p && F.have_prev_pr, "not available (pole removal not run)");
+      w = F.poleW; h = F.poleH;
+      src = F.prImgs[F.last_pr].as<uchar4>() + (n == "bottom_image2" ? (size_t)w * h : 0);
     } else if (n == "eye_l" || n == "eye_r") {
       const int e = n == "eye_r";
       need(F.pano[e].p, "not available");
@@ -575,6 +610,10 @@ int s360_frame_get_f32(s360_ctx* c, const char* name, int idx, int whc[3], float
       w = g.overlap_image_width; h = g.cam_image_height;
       const int j = idx - F.side_p0 + (n == "flow_r_to_l" ? nloc : 0);
       src = F.sideFlows[F.last_side].as<float2>() + (size_t)w * h * j;
+    } else if (n == "flow_bottom_secondary") {
+      need(F.prFlow[F.last_pr].p && F.have_prev_pr, "not available (pole removal not run)");
+      w = F.poleW; h = F.poleH;
+      src = F.prFlow[F.last_pr].p;
     } else if (n == "flow_pole") {
       need(idx >= 0 && idx < 4 && F.poleFlows[F.last_pole].p, "flow not available");
       w = F.extW; h = F.poleRows;
@@ -596,6 +635,7 @@ int s360_set_sweep_mode(s360_ctx* c, const char* mode) {
     else throw Error(S360_ERR_INVALID_ARG, "sweep mode must be \"latency\" or \"throughput\"");
     if (c->flow) c->flow->set_sweep_mode(c->sweep_mode);
     if (c->flow_pole) c->flow_pole->set_sweep_mode(c->sweep_mode);
+    if (c->flow_pr) c->flow_pr->set_sweep_mode(c->sweep_mode);
   });
 }
 

@@ -23,6 +23,7 @@ struct s360_ctx {
   s360::Profiler prof;
   std::unique_ptr<s360::FlowEngine> flow;       // operator-level calls + side flows
   std::unique_ptr<s360::FlowEngine> flow_pole;  // pole flows (different sizes: keeps both buffer sets resident)
+  std::unique_ptr<s360::FlowEngine> flow_pr;    // pole-removal flow between the two bottom cameras
   int sweep_mode = -1;  // -1 default (lockstep), 2 latency, 3 throughput (s360_set_sweep_mode)
   std::string err;
   // scratch for operator-level calls

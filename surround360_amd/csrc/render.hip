@@ -178,6 +178,96 @@ void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) 
   (top ? F.have_top : F.have_bottom) = true;
 }
 
+void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w, int h) {
+  FrameState& F = frame_state(c);
+  if (F.have_bottom && (w != F.poleW || h != F.poleH))
+    throw Error(S360_ERR_INVALID_ARG, "the secondary bottom image and the pole masks must have the bottom camera's size");
+  const size_t n = (size_t)w * h;
+  F.botSrc2.ensure(n * sizeof(uchar4));
+  F.staging.ensure(n * 4);
+  S360_HIP(hipMemcpyAsync(F.staging.p, bottom2, n * 3, hipMemcpyHostToDevice, c->st));
+  launch_bgr_to_bgra(c->st, F.staging.as<uint8_t>(), 3, F.botSrc2.as<uchar4>(), n);
+  const uint8_t* masks[2] = {mask, mask2};
+  for (int k = 0; k < 2; ++k) {
+    S360_HIP(hipStreamSynchronize(c->st));  // staging is reused
+    F.prRed[k].ensure(n);
+    S360_HIP(hipMemcpyAsync(F.staging.p, masks[k], n * 3, hipMemcpyHostToDevice, c->st));
+    launch_red_mask(c->st, F.staging.as<uint8_t>(), F.prRed[k].as<uint8_t>(), n);
+  }
+  S360_HIP(hipStreamSynchronize(c->st));
+  F.have_pr_inputs = true;
+}
+
+// featherAlphaChannel (CvUtil.cpp:140-157) of a whole BGRA image, in place.
+static void dev_feather_in_place(s360_ctx* c, uchar4* img, int w, int h) {
+  FrameState& F = frame_state(c);
+  const size_t n = (size_t)w * h;
+  F.a8a.ensure(n);
+  F.a8b.ensure(n);
+  launch_erode_alpha(c->st, img, F.a8b.as<uint8_t>(), w, h, c->P.std_alpha_feather_size);
+  const uint8_t* alpha = F.a8b.as<uint8_t>();
+  if (F.tab.gauss_ksize > 1) {
+    launch_gauss_u8(c->st, F.a8b.as<uint8_t>(), F.a8a.as<uint8_t>(), w, h, F.tab.gik.as<int>(), F.tab.gauss_ksize / 2);
+    alpha = F.a8a.as<uint8_t>();
+  }
+  launch_extend_wrap(c->st, img, alpha, w, h, img, w);  // extW == cols: every thread rewrites its own pixel
+}
+
+// combineBottomImagesWithPoleRemoval (PoleRemoval.cpp:32-188): merged BGRA bottom image in F.prMerged.
+static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
+  if (!F.have_pr_inputs) throw Error(S360_ERR_STATE, "enable_pole_removal: secondary bottom image / pole masks not uploaded");
+  hipStream_t st = c->st;
+  const int w = F.poleW, h = F.poleH;
+  const size_t n = (size_t)w * h;
+  const int bi = c->bottom_idx, b2 = c->rig.find_largest_axis_dist();
+  const s360_camera& cam = c->rig.all[bi];
+  const s360_camera& cam2 = c->rig.all[b2];
+  const float radius = approximate_usable_pixels_radius(&cam), radius2 = approximate_usable_pixels_radius(&cam2);
+  const double* up1 = cam.rotation + 3;
+  const double* up2 = cam2.rotation + 3;
+  const bool flip180 = up1[0] * up2[0] + up1[1] * up2[1] + up1[2] * up2[2] < 0;  // TRSP:580
+  const int cur = F.cur_pr, prv = cur ^ 1;
+  const bool usePrev = use_prev && F.have_prev_pr;
+  F.prImgs[cur].ensure(2 * n * sizeof(uchar4));
+  F.prFlow[cur].ensure(n * sizeof(float2));
+  F.prTmp.ensure(n * sizeof(uchar4));
+  F.prWarp.ensure(n * sizeof(uchar4));
+  F.prMerged.ensure(n * sizeof(uchar4));
+  uchar4* img1 = F.prImgs[cur].as<uchar4>();
+  uchar4* img2 = img1 + n;
+  {
+    ProfScope ps(c->prof, "pole_removal_prepare");
+    launch_circle_alpha(st, F.botSrc.as<uchar4>(), F.prRed[0].as<uint8_t>(), img1, w, h, radius);
+    dev_feather_in_place(c, img1, w, h);
+    uchar4* t2 = flip180 ? F.prTmp.as<uchar4>() : img2;
+    launch_circle_alpha(st, F.botSrc2.as<uchar4>(), F.prRed[1].as<uint8_t>(), t2, w, h, radius2);
+    dev_feather_in_place(c, t2, w, h);
+    if (flip180) launch_flip_both(st, t2, img2, w, h);
+  }
+  {
+    if (!c->flow_pr) { c->flow_pr.reset(new FlowEngine(&c->prof)); c->flow_pr->set_sweep_mode(c->sweep_mode); }
+    const std::string alg = c->P.poleremoval_flow_alg[0] ? c->P.poleremoval_flow_alg : "pixflow_low";
+    FlowIdx idx;
+    std::memset(&idx, 0, sizeof(idx));
+    idx.i0[0] = 0;
+    idx.i1[0] = 1;
+    c->flow_pr->compute(st, pixflow_consts_by_name(alg), 2, 1, idx, img1, w, h,
+                        usePrev ? F.prImgs[prv].as<uchar4>() : nullptr, usePrev ? F.prFlow[prv].as<float2>() : nullptr,
+                        S360_HINT_DOWN, F.prFlow[cur].as<float2>());
+  }
+  {
+    ProfScope ps(c->prof, "pole_removal_merge");
+    launch_remap_by_flow(st, img2, w, h, F.prFlow[cur].as<float2>(), F.prWarp.as<uchar4>(), F.tab.dev);
+    S360_HIP(hipMemcpyAsync(F.prMerged.p, img1, n * sizeof(uchar4), hipMemcpyDeviceToDevice, st));
+    launch_pole_removal_combine(st, F.prMerged.as<uchar4>(), F.prWarp.as<uchar4>(), n);
+    launch_circle_alpha(st, F.prMerged.as<uchar4>(), nullptr, F.prMerged.as<uchar4>(), w, h, radius);
+    dev_feather_in_place(c, F.prMerged.as<uchar4>(), w, h);
+  }
+  F.have_prev_pr = true;
+  F.last_pr = cur;
+  F.cur_pr ^= 1;
+}
+
 static void ensure_maps(s360_ctx* c, FrameState& F) {
   if (F.maps_ready) return;
   const s360_geometry& g = c->g;
@@ -372,8 +462,14 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
         if (!F.have_bottom) throw Error(S360_ERR_STATE, "bottom image not uploaded");
         F.botSph.ensure((size_t)W * rowsB * sizeof(uchar4));
         const int yfs = rowsB - 1 - c->P.std_alpha_feather_size;
-        launch_remap_cubic_u8c4(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, F.botMap.as<float2>(),
-                                F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
+        if (c->P.enable_pole_removal) {  // TRSP:569-597: the bottom source is the merge of the two bottom cameras
+          dev_pole_removal(c, F, use_prev != 0);
+          launch_remap_cubic_u8c4(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, F.botMap.as<float2>(),
+                                  F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 2, yfs, c->P.std_alpha_feather_size);
+        } else {
+          launch_remap_cubic_u8c4(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, F.botMap.as<float2>(),
+                                  F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
+        }
         launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xn, extW);
       }
     }

@@ -42,6 +42,10 @@ struct FrameState {
   bool keep_intermediates = false;  // copy panoramas before the pole composite (parity tests)
   DevBuf panoDbg[2];
   int extW = 0, poleRows = 0;
+  // pole removal: secondary bottom source (BGRA), red-mask planes, flow inputs [cur/prev][2][n], flow [cur/prev][n]
+  DevBuf botSrc2, prRed[2], prImgs[2], prFlow[2], prTmp, prWarp, prMerged;
+  bool have_pr_inputs = false, have_prev_pr = false;
+  int cur_pr = 0, last_pr = 0;
   DevBuf cubeMaps, cubeOut;  // cached face warp maps [6][fh][fw] float2 and the stacked BGR cubemap
   int cubeW = 0, cubeH = 0, cubeSrcW = 0, cubeSrcH = 0;
 };
@@ -49,6 +53,7 @@ struct FrameState {
 FrameState& frame_state(s360_ctx* c);
 void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, int ch);
 void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h);
+void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w, int h);
 void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev);
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev);
 // stereo cubemap of the last finished frame into F.cubeOut; returns its width/height through ow/oh

@@ -176,6 +176,15 @@ struct MapFromPoleFlow {  // poleToSideFlowThread's ramped warp (TRSP:483-503)
   }
 };
 
+struct MapFromFlowAdd {  // PoleRemoval.cpp:128-133: warp = (x, y) + flow
+  const float2* flow;
+  int w;
+  __device__ __forceinline__ float2 operator()(int x, int y) const {
+    const float2 f = flow[(size_t)y * w + x];
+    return make_float2((float)x + f.x, (float)y + f.y);
+  }
+};
+
 template <class MapFn>
 __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uchar4* __restrict__ src, int sw, int sh,
                                                                        MapFn mapfn, uchar4* __restrict__ dst, int dw,
@@ -247,8 +256,57 @@ __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uch
       a = (int)(unsigned char)(255.0f * alpha);
     }
     o.w = (unsigned char)a;
+  } else if (alpha_mode == 2) {
+    // 4-channel source (pole removal result): the interpolated alpha is kept, the feather rows take the minimum
+    // (TRSP:625-634)
+    if (y >= yFeatherStart) {
+      const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
+      const unsigned char a = (unsigned char)(255.0f * alpha);
+      o.w = o.w < a ? o.w : a;
+    }
   }
   dst[(size_t)y * dw + x] = o;
+}
+
+// ---- pole removal (PoleRemoval.cpp:32-188) -------------------------------------------------------------------
+// "is pure red" plane of a BGR mask image (cutRedMaskOutOfAlphaChannel's test, CvUtil.cpp:213-222)
+__global__ __launch_bounds__(256) void k_red_mask(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ red, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = bgr + i * 3;
+  red[i] = (p[0] == 0 && p[1] == 0 && p[2] == 255) ? 1 : 0;
+}
+// circleAlphaCut (CvUtil.cpp:201-211) [+ cutRedMaskOutOfAlphaChannel when red != nullptr]; colours copied from src
+__global__ __launch_bounds__(256) void k_circle_alpha(const uchar4* __restrict__ src, const uint8_t* __restrict__ red,
+                                                      uchar4* __restrict__ dst, int w, int h, float radius) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t i = (size_t)y * w + x;
+  const float dx = (float)x - (float)w / 2.0f;
+  const float dy = (float)y - (float)h / 2.0f;
+  const float r = sqrtf(dx * dx + dy * dy);
+  const float alpha = r < radius ? 1.0f : 0.0f;
+  uchar4 p = src[i];
+  p.w = (unsigned char)(alpha * 255.0f);
+  if (red && red[i]) p.w = 0;
+  dst[i] = p;
+}
+// the alpha-weighted merge of the primary bottom image with the warped secondary one (PoleRemoval.cpp:153-180)
+__global__ __launch_bounds__(256) void k_pole_removal_combine(uchar4* __restrict__ bottom, const uchar4* __restrict__ warped2,
+                                                              size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uchar4 p1 = bottom[i];
+  const uchar4 p2 = warped2[i];
+  const float alpha = (float)p1.w / 255.0f, alpha2 = (float)p2.w / 255.0f;
+  if (alpha < 1.0f && alpha2 > 0.0f) {
+    const float a1 = alpha, a2 = 1.0f - alpha;
+    p1.x = (unsigned char)(a1 * (float)p1.x + a2 * (float)p2.x);
+    p1.y = (unsigned char)(a1 * (float)p1.y + a2 * (float)p2.y);
+    p1.z = (unsigned char)(a1 * (float)p1.z + a2 * (float)p2.z);
+    p1.w = 255;
+    bottom[i] = p1;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_crop_overlaps(const uchar4* __restrict__ proj, int camW, int camH, int P,
@@ -730,6 +788,21 @@ void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, 
   MapFromBuffer mf{map, dw};
   hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromBuffer>), dim3(cdiv(dw, RT_W), cdiv(dh, RT_H)), dim3(RT_W, RT_H), 0,
                      st, src, sw, sh, mf, dst, dw, dh, T.bicubic_i, alpha_mode, yFeatherStart, featherSize);
+}
+void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
+                          const DevTables& T) {
+  MapFromFlowAdd mf{flow, w};
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromFlowAdd>), dim3(cdiv(w, RT_W), cdiv(h, RT_H)), dim3(RT_W, RT_H), 0, st,
+                     src, w, h, mf, dst, w, h, T.bicubic_i, 0, 0, 1);
+}
+void launch_red_mask(hipStream_t st, const uint8_t* bgr, uint8_t* red, size_t n) {
+  hipLaunchKernelGGL(k_red_mask, dim3(cdiv(n, 256)), dim3(256), 0, st, bgr, red, n);
+}
+void launch_circle_alpha(hipStream_t st, const uchar4* src, const uint8_t* red, uchar4* dst, int w, int h, float radius) {
+  hipLaunchKernelGGL(k_circle_alpha, dim3(cdiv(w, 256), h), dim3(256), 0, st, src, red, dst, w, h, radius);
+}
+void launch_pole_removal_combine(hipStream_t st, uchar4* bottom, const uchar4* warped2, size_t n) {
+  hipLaunchKernelGGL(k_pole_removal_combine, dim3(cdiv(n, 256)), dim3(256), 0, st, bottom, warped2, n);
 }
 void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH, int P, int overlapW, uchar4* out,
                           int p0, int p1) {

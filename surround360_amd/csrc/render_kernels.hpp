@@ -70,6 +70,13 @@ void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar
 // stereo cubemap from the two eye panoramas through cached face warp maps (TRSP:917-935)
 void launch_cubemap(hipStream_t st, const uchar4* eyeL, const uchar4* eyeR, int sw, int sh, const float2* maps, int fw,
                     int fh, int video, uint8_t* out, const DevTables& T);
+// pole removal pieces (SR/render/PoleRemoval.cpp:32-188, SR/util/CvUtil.cpp:201-222)
+void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
+                          const DevTables& T);
+void launch_red_mask(hipStream_t st, const uint8_t* bgr, uint8_t* red, size_t n);
+void launch_circle_alpha(hipStream_t st, const uchar4* src, const uint8_t* red /*nullable*/, uchar4* dst, int w, int h,
+                         float radius);
+void launch_pole_removal_combine(hipStream_t st, uchar4* bottom, const uchar4* warped2, size_t n);
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst);
 // sharpen (Filter.h:40-127) on BGRA in place, lp scratch same size
 void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount);

@@ -2,6 +2,7 @@
 #include "rig.hpp"
 
 #include <cctype>
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -165,6 +166,30 @@ int Rig::find_by_direction(const double dir[3], double maxd) const {  // RigDesc
     if (best < 0 || fdot(all[best]) < fdot(all[i]))
       if (axis_dist_to_centre(all[i]) <= maxd) best = (int)i;
   return best;
+}
+int Rig::find_largest_axis_dist() const {  // RigDescription.cpp:46-54
+  int best = (int)all.size() - 1;
+  for (size_t i = 0; i < all.size(); ++i)
+    if (axis_dist_to_centre(all[i]) > axis_dist_to_centre(all[best])) best = (int)i;
+  return best;
+}
+float approximate_usable_pixels_radius(const s360_camera* c) {  // Camera.h:201-212
+  const double fov = camera_get_fov(c);
+  const double kStep = 2 * M_PI / 10.0;
+  double result = std::sqrt(c->resolution[0] * c->resolution[0] + c->resolution[1] * c->resolution[1]);
+  double fwd[3];
+  camera_forward(c, fwd);
+  const double* right = c->rotation;
+  const double* up = c->rotation + 3;
+  for (double a = 0; a < 2 * M_PI; a += kStep) {
+    double ortho[3], p[3], pix[2];
+    for (int i = 0; i < 3; ++i) ortho[i] = right[i] * std::cos(a) + up[i] * std::sin(a);
+    for (int i = 0; i < 3; ++i) p[i] = c->position[i] + (fwd[i] * std::cos(fov) + ortho[i] * std::sin(fov));
+    camera_pixel(c, p, pix);
+    const double dx = pix[0] - c->resolution[0] / 2.0, dy = pix[1] - c->resolution[1] / 2.0;
+    result = std::min(result, std::sqrt(dx * dx + dy * dy));
+  }
+  return (float)result;
 }
 float Rig::ring_radius() const {
   const double* p = side[0].position;

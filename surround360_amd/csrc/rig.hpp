@@ -32,7 +32,10 @@ struct Rig {
   void finalize();  // split "side" group
   int find_by_direction(const double dir[3], double max_axis_dist = 1.0) const;  // index into all, -1 if none
   float ring_radius() const;
+  int find_largest_axis_dist() const;  // RigDescription::findLargestDistCamAxisToRigCenter (secondary bottom camera)
 };
+// Camera::approximateUsablePixelsRadius (SR/render/Camera.h:201-212)
+float approximate_usable_pixels_radius(const s360_camera* c);
 // Parses the rig JSON text (RIG_JSON.md). Throws Error on malformed input.
 std::vector<s360_camera> parse_rig_json(const std::string& text);
 

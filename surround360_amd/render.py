@@ -56,6 +56,9 @@ class RigDescription:
     def get_top_camera_id(self):
         return self.rig[self.top_index].id.decode()
 
+    def get_bottom_camera2_id(self):
+        return self.rig[lib().s360_rig_find_bottom2(self.rig, len(self.rig))].id.decode()
+
     def get_bottom_camera_id(self):
         return self.rig[self.bottom_index].id.decode()
 
@@ -82,6 +85,8 @@ def make_params(**kw):
     p.final_eqr_height = 960
     p.side_flow_alg = b"pixflow_low"
     p.polar_flow_alg = b"pixflow_low"
+    p.enable_pole_removal = 0
+    p.poleremoval_flow_alg = b"pixflow_low"
     for k, v in kw.items():
         if not hasattr(p, k):
             raise TypeError("unknown flag: " + k)
@@ -217,6 +222,12 @@ class Context:
         if bottom is not None:
             b = _u8(bottom)
             self._ck(lib().s360_frame_upload_bottom(self.h, _p(b), b.shape[1], b.shape[0]))
+
+    def upload_pole_removal(self, bottom2, mask, mask2):
+        """Secondary bottom camera image + the two red pole masks (BGR) for enable_pole_removal (PoleRemoval.cpp:48-66)."""
+        b2, m1, m2 = _u8(bottom2), _u8(mask), _u8(mask2)
+        assert b2.shape == m1.shape == m2.shape and b2.shape[2] == 3
+        self._ck(lib().s360_frame_upload_pole_removal(self.h, _p(b2), _p(m1), _p(m2), b2.shape[1], b2.shape[0]))
 
     def render(self, use_prev=False):
         self._ck(lib().s360_frame_render(self.h, int(use_prev)))

@@ -129,11 +129,12 @@ def _camera_rays(cam, res):
     return unit @ R  # R^T * unit per pixel
 
 
-def rig_frame(rig_json_path, size=2048, world_h=2048, seed=360, yaw_deg=0.0):
+def rig_frame(rig_json_path, size=2048, world_h=2048, seed=360, yaw_deg=0.0, return_all=False):
     """Render every camera of the rig from the seeded world. Returns (list of side BGR images in
     rigSideOnly order, top BGR, bottom BGR). One fixed-point iteration places each ray's hit
     point at the world depth seen from the rig centre, which gives consistent parallax between
-    adjacent cameras."""
+    adjacent cameras. return_all=True also returns the dict {camera id: image} of every camera of the rig (the
+    secondary bottom camera of pole removal is not one of the three standard outputs)."""
     with open(rig_json_path) as f:
         cams = json.load(f)["cameras"]
     tex, depth = world_texture(world_h, seed)
@@ -166,4 +167,6 @@ def rig_frame(rig_json_path, size=2048, world_h=2048, seed=360, yaw_deg=0.0):
     ok = [c for c in cams if axis_dist(c) <= 1.0]
     top = max(ok, key=lambda c: c["forward"][2])
     bottom = max(ok, key=lambda c: -c["forward"][2])
+    if return_all:
+        return side, imgs[top["id"]], imgs[bottom["id"]], imgs
     return side, imgs[top["id"]], imgs[bottom["id"]]

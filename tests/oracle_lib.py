@@ -30,6 +30,7 @@ class ParamsC(C.Structure):
         ("enable_top", C.c_int), ("enable_bottom", C.c_int),
         ("eqr_width", C.c_int), ("eqr_height", C.c_int), ("final_eqr_width", C.c_int), ("final_eqr_height", C.c_int),
         ("side_flow_search20", C.c_int), ("polar_flow_search20", C.c_int),
+        ("enable_pole_removal", C.c_int), ("poleremoval_flow_search20", C.c_int),
     ]
 
 
@@ -50,6 +51,7 @@ def lib():
         _LIB.orc_camera_get_fov.restype = C.c_double
         _LIB.orc_camera_undistort_distort.restype = C.c_double
         _LIB.orc_approximate_fov.restype = C.c_float
+        _LIB.orc_frame_usable_pixels_radius.restype = C.c_float
     return _LIB
 
 
@@ -333,6 +335,18 @@ class Frame:
         d = np.empty((whc[1], whc[0], whc[2]), np.uint8)
         lib().orc_frame_get_u8(self.h, name.encode(), idx, whc, _p(d))
         return d
+
+    def set_pole_removal(self, bottom2, mask, mask2):
+        """Secondary bottom camera image + red pole masks (BGR) for enable_pole_removal."""
+        b2, m1, m2 = (np.ascontiguousarray(a, np.uint8) for a in (bottom2, mask, mask2))
+        assert b2.shape == m1.shape == m2.shape and b2.shape[2] == 3
+        lib().orc_frame_set_pole_removal(self.h, _p(b2), _p(m1), _p(m2), b2.shape[1], b2.shape[0])
+
+    def bottom2_index(self):
+        return lib().orc_frame_bottom2_index(self.h)
+
+    def usable_pixels_radius(self, cam_idx):
+        return float(lib().orc_frame_usable_pixels_radius(self.h, cam_idx))
 
     def cubemap(self, face_w, face_h, fmt="video"):
         whc = (C.c_int * 3)()

@@ -1,5 +1,7 @@
 """Full-frame parity: renderStereoPanorama (TestRenderStereoPanorama.cpp:716-972) on the GPU vs the oracle,
 stage by stage, on a scaled 17-camera rig. Byte/flow results must be bit-exact."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -165,3 +167,35 @@ def test_cubemap(setup, fmt, fw, fh):
     assert got.std() > 5
     with pytest.raises(R.S360Error):
         ctx.cubemap(fw, fh, "cross")
+
+
+def test_pole_removal_two_frames(tmp_path, rig_json, oracle, s360lib):
+    """--enable_pole_removal (combineBottomImagesWithPoleRemoval, PoleRemoval.cpp:32-188 + TRSP:569-634): the two
+    bottom cameras merged through a flow, red masks, circle cuts and feathers; second frame with temporal state."""
+    path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_small.json"), CAM / 2048.0)
+    flags = dict(eqr_width=EQR_W, eqr_height=EQR_H, enable_top=0, enable_bottom=1, enable_pole_removal=1,
+                 final_eqr_width=0, final_eqr_height=0)
+    rig = R.RigDescription(path)
+    ctx = R.Context(rig, R.make_params(**flags))
+    cams, ids = oracle.load_rig(path)
+    of = oracle.Frame(cams, oracle.make_params(**flags))
+    b2 = of.bottom2_index()
+    assert rig.get_bottom_camera2_id() == ids[b2] != rig.get_bottom_camera_id()
+    assert np.float32(s360lib.s360_camera_usable_pixels_radius(C.byref(rig.rig[b2]))) == np.float32(of.usable_pixels_radius(b2))
+    try:
+        for k, yaw in enumerate((0.0, 1.5)):
+            side, top, bottom, imgs, m1, m2 = rigutil.pole_removal_inputs(path, CAM, yaw_deg=yaw)
+            of.set_pole_removal(imgs[ids[b2]], m1, m2)
+            want, _ = of.render(side, None, bottom, use_prev=k > 0)
+            ctx.upload_frame(side, None, bottom)
+            ctx.upload_pole_removal(imgs[ids[b2]], m1, m2)
+            ctx.render(use_prev=k > 0)
+            got = ctx.download_equirect()
+            _cmp("bottom_image f%d" % k, ctx.get_u8("bottom_image"), of.get_u8("bottom_image"))
+            _cmp("bottom_image2 f%d" % k, ctx.get_u8("bottom_image2"), of.get_u8("bottom_image2"))
+            _cmp("flow_bottom_secondary f%d" % k, ctx.get_f32("flow_bottom_secondary"), of.get_f32("flow_bottom_secondary"))
+            _cmp("bottom_spherical f%d" % k, ctx.get_u8("bottom_spherical"), of.get_u8("bottom_spherical"))
+            _cmp("pole removal frame %d" % k, got, want)
+        assert np.abs(ctx.get_f32("flow_bottom_secondary")).max() > 0.5
+    finally:
+        ctx.close()
