@@ -192,96 +192,145 @@ def main():
             if rank == 0:
                 ctx.finish(15, False)
 
-    ctx.set_sweep_mode("latency")  # one frame at a time: the kernel with the shortest dependent chain
-    single()
-    sync()
-    ctx.profile_enable(True)
-    n_single = 3
-    t1 = time.perf_counter()
-    for _ in range(n_single):
-        single()
-    sync()
-    dt1 = time.perf_counter() - t1
-    prof1 = ctx.profile_get()
-    if dist is not None:
-        t = torch.tensor([dt1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt1 = float(t.item())
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+    def emit(prof1, video, dt1, n_single, error):
+        prof1 = prof1 or {}
+        g = ctx.geometry
+        sweep_ms, sweep_launches = prof.get("flow_sweep", (0.0, 0))
+        bytes_per_frame = sweep_algorithmic_bytes(g, 2 * P, 4, flags["eqr_width"])
+        launches_per_frame = sweep_launches / max(args.steps, 1)
+        bytes_per_launch = bytes_per_frame / max(launches_per_frame, 1)
+        avg_launch_ms = sweep_ms / max(sweep_launches, 1)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        agg = bytes_per_frame * args.steps / dt / 1e9
+        s1_ms, s1_launches = prof1.get("flow_sweep", (0.0, 0))
+        n_side_flows_1 = 2 * (p1 - p0)
+        bytes_1 = sweep_algorithmic_bytes(g, n_side_flows_1, 4, flags["eqr_width"]) * n_single
+        wb = {}
+        if world == 1:
+            for k, mb in WARP_BLEND_MB.items():
+                ms = prof1.get(k, (0.0, 0))[0] / n_single
+                if ms > 0:
+                    gbs = mb * 1e6 / (ms * 1e-3) / 1e9
+                    wb[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        out = {
+            "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
+            "value": world * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo 8192x8192, "
+                                   "top+bottom poles, pixflow_low, sharpening 0" if args.size == "8k" else
+                                   "DEBUG 2K frame (not a bench config)",
+                       "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
+                                      "(one context + HIP stream each), no data-path collective" % (world, F),
+                       "frames_in_flight": F},
+            "roofline": {"bound": "hbm", "kernel": "%s (PixFlow propagation sweeps, PixFlow.h:388-410)" %
+                                   ("k_sweep_quad" if F > 1 else "k_sweep_lock"),
+                         "achieved": agg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "avg_launch_ms": avg_launch_ms, "launches_per_frame": launches_per_frame,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "per_launch_GBps_while_overlapped": achieved,
+                         "note": "dependency-latency-bound wavefront kernel (DESIGN.md §5). Launches of up to %d frames overlap "
+                                 "in the timed region, so `achieved` = algorithmic bytes of ALL sweep launches / wall time of "
+                                 "the region (bytes per launch / average launch duration, times the average number of "
+                                 "launches running at once); the un-overlapped per-launch figure is "
+                                 "single_frame.sweep_roofline_frac" % F},
+            "single_frame": {"mode": "one frame at a time, all pairs on 1 GPU" if world == 1 else
+                                     "one frame at a time, 14 pairs sharded over %d GPUs + one RCCL strip gather, pole units "
+                                     "and composite on rank 0" % world,
+                             "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9),
+                             "sweep_roofline_frac": (bytes_1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s1_ms > 0 else None,
+                             "kernel_ms_per_frame": {k: round(v[0] / n_single, 3)
+                                                     for k, v in sorted(prof1.items(), key=lambda kv: -kv[1][0])},
+                             "warp_blend_roofline": wb},
+            "kernel_ms_per_frame": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        }
+        if error is not None:
+            out["single_frame"] = {"error": error}
+        if video:
+            out["video_stream"] = video
+        traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+        if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+            try:
+                tj = json.load(open(traffic_file))
+                kname = "k_sweep_quad" if F > 1 else "k_sweep_lock"
+                out["roofline"]["traffic"] = tj.get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(side, top, bottom)
+        print(json.dumps(out))
+        sys.stdout.flush()
 
-    g = ctx.geometry
-    sweep_ms, sweep_launches = prof.get("flow_sweep", (0.0, 0))
-    bytes_per_frame = sweep_algorithmic_bytes(g, 2 * P, 4, flags["eqr_width"])
-    launches_per_frame = sweep_launches / max(args.steps, 1)
-    bytes_per_launch = bytes_per_frame / max(launches_per_frame, 1)
-    avg_launch_ms = sweep_ms / max(sweep_launches, 1)
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    agg = bytes_per_frame * args.steps / dt / 1e9
-    s1_ms, s1_launches = prof1.get("flow_sweep", (0.0, 0))
-    n_side_flows_1 = 2 * (p1 - p0)
-    bytes_1 = sweep_algorithmic_bytes(g, n_side_flows_1, 4, flags["eqr_width"]) * n_single
-    wb = {}
-    if world == 1:
-        for k, mb in WARP_BLEND_MB.items():
-            ms = prof1.get(k, (0.0, 0))[0] / n_single
-            if ms > 0:
-                gbs = mb * 1e6 / (ms * 1e-3) / 1e9
-                wb[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-    out = {
-        "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
-        "value": world * args.steps / dt,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo 8192x8192, "
-                               "top+bottom poles, pixflow_low, sharpening 0" if args.size == "8k" else
-                               "DEBUG 2K frame (not a bench config)",
-                   "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
-                                  "(one context + HIP stream each), no data-path collective" % (world, F),
-                   "frames_in_flight": F},
-        "roofline": {"bound": "hbm", "kernel": "%s (PixFlow propagation sweeps, PixFlow.h:388-410)" %
-                               ("k_sweep_quad" if F > 1 else "k_sweep_lock"),
-                     "achieved": agg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
-                     "traffic": None,
-                     "avg_launch_ms": avg_launch_ms, "launches_per_frame": launches_per_frame,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "per_launch_GBps_while_overlapped": achieved,
-                     "note": "dependency-latency-bound wavefront kernel (DESIGN.md §5). Launches of up to %d frames overlap "
-                             "in the timed region, so `achieved` = algorithmic bytes of ALL sweep launches / wall time of "
-                             "the region (bytes per launch / average launch duration, times the average number of "
-                             "launches running at once); the un-overlapped per-launch figure is "
-                             "single_frame.sweep_roofline_frac" % F},
-        "single_frame": {"mode": "one frame at a time, all pairs on 1 GPU" if world == 1 else
-                                 "one frame at a time, 14 pairs sharded over %d GPUs + one RCCL strip gather, pole units "
-                                 "and composite on rank 0" % world,
-                         "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / dt1,
-                         "sweep_roofline_frac": (bytes_1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s1_ms > 0 else None,
-                         "kernel_ms_per_frame": {k: round(v[0] / n_single, 3)
-                                                 for k, v in sorted(prof1.items(), key=lambda kv: -kv[1][0])},
-                         "warp_blend_roofline": wb},
-        "kernel_ms_per_frame": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-    }
-    traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
-    if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-        try:
-            tj = json.load(open(traffic_file))
-            kname = "k_sweep_quad" if F > 1 else "k_sweep_lock"
-            out["roofline"]["traffic"] = tj.get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(side, top, bottom)
-    print(json.dumps(out))
+    # A hang or failure in this phase (the only one with a data-path collective) must not cost the bench line: the
+    # timed region above is complete, so a watchdog reports it without the single-frame figures.
+    import threading
+    state = {"emitted": False}
+    lock = threading.Lock()
+
+    def bail(reason):
+        with lock:
+            if state["emitted"]:
+                return
+            state["emitted"] = True
+            if rank == 0:
+                emit(None, None, 0.0, 1, reason)
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = threading.Timer(240.0, bail, args=("single-frame phase timed out",))
+    watchdog.daemon = True
+    watchdog.start()
+    n_single = 3
+    video = None
+    prof1, dt1 = None, 0.0
+    try:
+        ctx.set_sweep_mode("latency")  # one frame at a time: the kernel with the shortest dependent chain
+        single()
+        sync()
+        ctx.profile_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(n_single):
+            single()
+        sync()
+        dt1 = time.perf_counter() - t1
+        prof1 = ctx.profile_get()
+        ctx.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([dt1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = float(t.item())
+        if world == 1:
+            # BASELINE configs[4]: ONE video stream with temporal regularisation. Frame k+1 needs frame k's flows, so
+            # the frames of one stream run back to back (independent streams overlap like the timed region above).
+            ctx.render(False)
+            ctx.render(True)
+            sync()
+            n_video = 4
+            t2 = time.perf_counter()
+            for _ in range(n_video):
+                ctx.render(True)
+            sync()
+            ms = 1e3 * (time.perf_counter() - t2) / n_video
+            video = {"mode": "one stream; frame k regularised toward frame k-1's flows (use_prev)", "frames": n_video,
+                     "ms_per_frame": ms, "frames_per_s": 1e3 / ms}
+    except Exception as e:  # noqa: BLE001 - reported in the JSON line
+        bail("single-frame phase failed: %r" % (e,))
+    watchdog.cancel()
+    with lock:
+        if state["emitted"]:
+            return
+        state["emitted"] = True
+    if rank == 0:
+        emit(prof1, video, dt1, n_single, None)
     if dist is not None:
         dist.destroy_process_group()
 

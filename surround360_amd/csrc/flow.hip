@@ -76,7 +76,6 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   gray_.ensure(N * n0 * sizeof(float));
   pyrI_.ensure(2 * N * lv_.total * sizeof(float));  // per level: N grey planes, then N alpha planes
   G_.ensure(N * n0 * sizeof(float2));
-  Gtmp_.ensure(N * n0 * sizeof(float2));
   flowA_.ensure(B * n0 * sizeof(float2));
   flowB_.ensure(B * n0 * sizeof(float2));
   blurred_.ensure(B * n0 * sizeof(float2));

@@ -43,7 +43,7 @@ class FlowEngine {
   Profiler* prof_;
   FlowLevels lv_;
   int dw_ = 0, dh_ = 0;
-  DevBuf down_, prevdown_, gray_, pyrI_, G_, Gtmp_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
+  DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
       motionPyr_, I1eq_, rec_, handoff_, err_, recS_, outS_;
   int sweep_mode_ = -1;  // 0: v1 diagonal kernel, 1: v2 hex16 kernel, 2: lockstep kernel (latency, default), 3: quad (throughput)
   bool sweep_env_forced_ = false;

@@ -273,21 +273,6 @@ __global__ __launch_bounds__(256) void k_adjust_toward_prev(float2* __restrict__
   flow[o] = f;
 }
 
-// Sobel ksize=1 on I -> packed (Ix, Iy), BORDER_REPLICATE, no scale (PixFlow.h:356-359).
-__global__ __launch_bounds__(256) void k_sobel(const float* __restrict__ I, int w, int h, size_t bs,
-                                               float2* __restrict__ G) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
-  I += bs * blockIdx.z;
-  G += bs * blockIdx.z;
-  const float* r = I + (size_t)y * w;
-  float2 g;
-  g.x = r[min(x + 1, w - 1)] - r[max(x - 1, 0)];
-  g.y = I[(size_t)min(y + 1, h - 1) * w + x] - I[(size_t)max(y - 1, 0) * w + x];
-  G[(size_t)y * w + x] = g;
-}
-
 // ------------------------------------------------------------------------------------------
 // medianBlur(5) on CV_32FC2, replicate border (PixFlow.h:398,411): exact per-channel median of 25.
 __device__ __forceinline__ void mnmx(float& a, float& b) {
@@ -456,18 +441,6 @@ __global__ __launch_bounds__(1024) void k_sweep_diag(const float2* __restrict__ 
 // {I0x, I0y, blurredFlow.x, blurredFlow.y}; I0x = NaN marks "alpha0 <= 0.9 || alpha1 <= 0.9" (not updated).
 constexpr unsigned long long kHandoffEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBandRows = 4, kPoll = 8;
-
-__global__ __launch_bounds__(256) void k_make_records(const float2* __restrict__ G, const float* __restrict__ A,
-                                                      const float2* __restrict__ blurred, float4* __restrict__ rec,
-                                                      size_t n, size_t bs, FlowIdx idx) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int b = blockIdx.z;
-  const float2 g = G[bs * idx.i0[b] + i];
-  const float2 bf = blurred[bs * b + i];
-  const bool upd = A[bs * idx.i0[b] + i] > 0.9f && A[bs * idx.i1[b] + i] > 0.9f;
-  rec[bs * b + i] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, bf.x, bf.y);
-}
 
 template <int K>
 __device__ __forceinline__ float row_get(float v) {  // value of lane K of this lane's 16-lane row
@@ -835,10 +808,6 @@ void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev,
   hipLaunchKernelGGL(k_adjust_toward_prev, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, flow, prev,
                      motion, n, bs, idx);
 }
-void launch_sobel(hipStream_t st, const float* I, int w, int h, size_t bs, float2* G, int B) {
-  dim3 blk(64, 4);
-  hipLaunchKernelGGL(k_sobel, grid2d(w, h, B, blk), blk, 0, st, I, w, h, bs, G);
-}
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B) {
   dim3 blk(64, 4);
   hipLaunchKernelGGL(k_median5_c2, grid2d(w, h, B, blk), blk, 0, st, src, dst, w, h, bs);
@@ -859,11 +828,6 @@ void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2*
   if (threads > 1024) threads = 1024;
   const size_t lds = (size_t)2 * h * sizeof(float2);
   hipLaunchKernelGGL(k_sweep_diag, dim3(B), dim3(threads), lds, st, G, A, blurred, flow, w, h, bs, idx, dir, c);
-}
-void launch_make_records(hipStream_t st, const float2* G, const float* A, const float2* blurred, float4* rec, size_t n,
-                         int B, const FlowIdx& idx) {
-  hipLaunchKernelGGL(k_make_records, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, G, A, blurred, rec, n, n,
-                     idx);
 }
 int sweep_num_bands(int h) { return (h + kBandRows - 1) / kBandRows; }
 size_t sweep_handoff_bytes(int w, int h, int B) {

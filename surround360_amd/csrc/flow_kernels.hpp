@@ -44,13 +44,10 @@ void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh
 void launch_scale_f32(hipStream_t st, float* p, size_t n, float s);
 void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
                                size_t bs, int B, const FlowIdx& idx);
-void launch_sobel(hipStream_t st, const float* I, int w, int h, size_t bs, float2* G, int B);
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
 void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow, int w, int h,
                   size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc);
 // banded "hex16" sweep (see flow_kernels.hip): records = {I0x|NaN mask, I0y, blurred.x, blurred.y}
-void launch_make_records(hipStream_t st, const float2* G, const float* A, const float2* blurred, float4* rec, size_t n,
-                         int B, const FlowIdx& idx);
 int sweep_num_bands(int h);
 size_t sweep_handoff_bytes(int w, int h, int B);
 void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
