@@ -14,6 +14,8 @@
 //     granules in global memory (all-ones = not written; bands are ticketed in band-major order, spins are bounded).
 // A step is two gather rounds deep, so a single flow runs ~2x slower than with sweep_lock.hip; the chip-wide rate
 // is what improves. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+#include <type_traits>
+
 #include "devmath.hpp"
 #include "sweep_common.hpp"
 
@@ -41,6 +43,13 @@ __device__ __forceinline__ float from_row_above_q(float old, float v) {
 
 }  // namespace
 
+// Steps per chunk. Everything that is not the pixel update itself happens once per chunk, with wave-uniform control:
+// the poll of the band above, the write-back of the results (through an LDS ring, so that no global store sits in
+// front of the next step's gathers — loads and stores retire in order through one counter on gfx950) and the
+// publication of the last row's granules.
+constexpr int kQChunk = 16;
+constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
+
 template <bool FAST>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ rec, const float2* __restrict__ G,
                                                    float2* __restrict__ flow, unsigned long long* __restrict__ H,
@@ -48,6 +57,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
                                                    unsigned* __restrict__ errflag) {
   __shared__ float2 s_up[kUpRing];
+  __shared__ float2 s_res[kQRows][kQResRing];
   __shared__ unsigned s_ticket;
   const int lane = threadIdx.x;
   if (lane == 0) s_ticket = atomicAdd(hdr, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const int y = dir > 0 ? yic : h - 1 - yic;
   const bool hasUp = yi > 0;
   const bool hasUpBand = band > 0;
-  const bool publishLane = band + 1 < nb && r == kQRows - 1 && q == 0;
+  const bool publishes = band + 1 < nb;
   const float4* __restrict__ recRow = rec + (size_t)y * w;
   float2* __restrict__ flowRow = flow + (size_t)y * w;
   const float fy = (float)y;
@@ -78,8 +88,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const int nsteps = w + kQRows - 1;
   auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
 
-  // errorFunction at (x + ax, y + ay) for this lane's pixel (PixFlow.h:493-534)
-  auto evaluate = [&](int x, float4 rc, float ax, float ay) -> float {
+  // errorFunction at (x + ax, y + ay) for this lane's pixel (PixFlow.h:493-534). `tiny` collects the lanes whose
+  // operands leave the proven range of the fast division / square root.
+  auto evaluate = [&](auto ieee, int x, float4 rc, float ax, float ay, bool& tiny) -> float {
     const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
     const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
     const int x0 = (int)mx, y0 = (int)my;
@@ -90,40 +101,65 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     Texels tt;
     tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
     tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-    Foot ft;
-    ft.off = 0; ft.xR = xR; ft.yR = yR;
-    float e;
-    if (FAST) {
-      bool tiny;
-      e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
-      if (__builtin_expect(__ballot(tiny) != 0ull, 0)) e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
-    } else {
-      e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+    if (decltype(ieee)::value) {
+      Foot ft;
+      ft.off = 0; ft.xR = xR; ft.yR = yR;
+      return error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
     }
+    bool t1;
+    const float e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, t1);
+    tiny = tiny || t1;
     return e;
   };
+  // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
+  // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
+  auto update = [&](auto ieee, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool& tiny) -> float2 {
+    const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
+    const float e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
+    const float e0 = quad_bcast<0>(e);
+    float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
+    if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column
+    if (!hasUp) e2 = kInf;     // no up proposal in the first row
+    float2 f = fo;
+    float cur = e0;
+    if (e1 < cur) { f = fl; cur = e1; }
+    if (e2 < cur) { f = up; cur = e2; }
+    const float pe = evaluate(ieee, x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f), tiny);
+    const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
+    const float nx = ex - cur, ny = ey - cur;
+    float ggx, ggy;
+    if (decltype(ieee)::value) {
+      ggx = nx / kEps;
+      ggy = ny / kEps;
+    } else {
+      ggx = fdiv_m(nx, kEps, fc.rcEps);
+      ggy = fdiv_m(ny, kEps, fc.rcEps);
+      tiny = tiny || min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
+    }
+    float2 res;
+    res.x = f.x - c.gradStep * ggx;
+    res.y = f.y - c.gradStep * ggy;
+    return res;
+  };
 
-  // ---- granules of the band above -> s_up ring (columns [upFilled - kUpRing, upFilled) are valid) ----
-  int upFilled = hasUpBand ? 0 : 0x3fffffff, pendS = -100;
+  // ---- granules of the band above -> s_up ring. Wave-uniform state; columns [.., upFilled) have been taken ----
+  int upFilled = hasUpBand ? 0 : 0x3fffffff;
   bool pending = false, dead = false;
   unsigned long long pv = kEmptyGranuleQ;
-  auto issue = [&](int s) {
+  auto issue = [&]() {
     const int xi = upFilled + lane;
     pv = kEmptyGranuleQ;
     if (xi < w) pv = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pending = true;
-    pendS = s;
   };
-  auto process = [&](int s) {  // leading run of written granules; never overwrites columns >= s that are still needed
+  auto process = [&](int limit) {  // takes the leading run of written granules, never beyond column `limit`
     const int xi = upFilled + lane;
     const unsigned long long bad = __ballot(xi >= w || (pv == kEmptyGranuleQ && !dead));
     int n = bad ? (int)__ffsll((long long)bad) - 1 : 64;
-    n = min(n, s + kUpRing - upFilled);
-    if (n > 0) {
-      if (lane < n)
-        s_up[xi & (kUpRing - 1)] = make_float2(__uint_as_float((unsigned)pv), __uint_as_float((unsigned)(pv >> 32)));
-      upFilled = __builtin_amdgcn_readfirstlane(upFilled + n);
-    }
+    n = min(n, limit - upFilled);
+    if (lane < n)
+      s_up[xi & (kUpRing - 1)] = make_float2(__uint_as_float((unsigned)pv), __uint_as_float((unsigned)(pv >> 32)));
+    upFilled = __builtin_amdgcn_readfirstlane(upFilled + max(n, 0));
     pending = false;
   };
 
@@ -135,79 +171,74 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     nrc = recRow[x0c];
     nfo = flowRow[x0c];
   }
-  for (int s = 0; s < nsteps; ++s) {
-    const float4 rc = nrc;
-    const float2 fo = nfo;
-    {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
-      const int xn = col(s + 1 - r);
-      nrc = recRow[xn];
-      nfo = flowRow[xn];
-    }
-    if (hasUpBand && s < w) {
-      if (pending && (s - pendS >= 2 || upFilled <= s)) process(s);
+  for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
+    if (hasUpBand && s0 < w) {  // row 0 needs columns [s0, s0 + kQChunk) of the band above during this chunk
+      const int need = min(s0 + kQChunk, w), limit = s0 + kUpRing;
+      if (!pending) issue();
+      process(limit);
       unsigned spins = 0;
-      while (upFilled <= s) {  // row 0 needs column s now
-        if (!pending) issue(s);
-        process(s);
-        if (upFilled <= s) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21) ||
-              ((spins & 1023u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
-            if (lane == 0) atomicExch(errflag, 1u);
-          }
+      while (upFilled < need) {
+        __builtin_amdgcn_s_sleep(4);
+        issue();
+        process(limit);
+        if (++spins > (1u << 20) ||
+            ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
+          if (lane == 0) atomicExch(errflag, 1u);
         }
       }
-      if (!pending && upFilled < w && upFilled - s < 40) issue(s);
+      if (upFilled < w) issue();  // taken at the next chunk boundary
     }
-    const float2 upl = s_up[s & (kUpRing - 1)];
-    const int xi = s - r;
-    const bool active = rowValid && xi >= 0 && xi < w;
-    const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
-    const bool upd = rc.x == rc.x;
-    float2 up;
-    up.x = from_row_above_q(upl.x, fl.x);
-    up.y = from_row_above_q(upl.y, fl.y);
-    // round 1: the three proposals (PixFlow.h:390-393 / 403-406), lanes 0..2 of the quad
-    const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
-    const float e = evaluate(x, rc, cand.x + 0.0f, cand.y + 0.0f);
-    const float e0 = quad_bcast<0>(e);
-    float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
-    if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column
-    if (!hasUp) e2 = kInf;     // no up proposal in the first row
-    float2 f = fo;
-    float cur = e0;
-    if (e1 < cur) { f = fl; cur = e1; }
-    if (e2 < cur) { f = up; cur = e2; }
-    // round 2: errorGradient's probes of the winner (PixFlow.h:195-217), lanes 0..1
-    const float pe = evaluate(x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f));
-    const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
-    const float nx = ex - cur, ny = ey - cur;
-    float ggx, ggy;
-    if (FAST) {
-      ggx = fdiv_m(nx, kEps, fc.rcEps);
-      ggy = fdiv_m(ny, kEps, fc.rcEps);
-      const bool tiny = min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
-      if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
-        ggx = nx / kEps;
-        ggy = ny / kEps;
+    const int send = min(s0 + kQChunk, nsteps);
+    for (int s = s0; s < send; ++s) {
+      const float4 rc = nrc;
+      const float2 fo = nfo;
+      {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
+        const int xn = col(s + 1 - r);
+        nrc = recRow[xn];
+        nfo = flowRow[xn];
       }
-    } else {
-      ggx = nx / kEps;
-      ggy = ny / kEps;
+      const float2 upl = s_up[s & (kUpRing - 1)];
+      const int xi = s - r;
+      const bool active = rowValid && xi >= 0 && xi < w;
+      const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
+      const bool upd = rc.x == rc.x;
+      float2 up;
+      up.x = from_row_above_q(upl.x, fl.x);
+      up.y = from_row_above_q(upl.y, fl.y);
+      float2 res;
+      if (FAST) {
+        bool tiny = false;
+        res = update(std::false_type{}, x, xi, rc, fo, fl, up, tiny);
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
+      } else {
+        bool tiny = false;
+        res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
+      }
+      const bool take = active && upd;
+      const float2 alt = active ? fo : fl;
+      res.x = take ? res.x : alt.x;
+      res.y = take ? res.y : alt.y;
+      fl = res;
+      if (q == 0) s_res[r][xi & (kQResRing - 1)] = res;
     }
-    float2 res;
-    res.x = f.x - c.gradStep * ggx;
-    res.y = f.y - c.gradStep * ggy;
-    const bool take = active && upd;
-    const float2 alt = active ? fo : fl;
-    res.x = take ? res.x : alt.x;
-    res.y = take ? res.y : alt.y;
-    fl = res;
-    if (active && q == 0) flowRow[x] = res;
-    if (publishLane && active)
-      __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(res.y) << 32) | __float_as_uint(res.x),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
+    {
+      const int base = s0 - r + q;
+#pragma unroll
+      for (int k = 0; k < kQChunk / 4; ++k) {
+        const int xi = base + 4 * k;
+        if (rowValid && xi >= 0 && xi < w && xi < send - r) flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][xi & (kQResRing - 1)];
+      }
+      if (publishes && lane < kQChunk) {  // the last row's granules for the band below
+        const int xi = s0 - (kQRows - 1) + lane;
+        if (xi >= 0 && xi < w && xi < send - (kQRows - 1)) {
+          const float2 v = s_res[kQRows - 1][xi & (kQResRing - 1)];
+          __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
   }
 }
 

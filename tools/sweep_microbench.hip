@@ -2,6 +2,7 @@
 // parity lives in tests/). Build: make -C tools   Run on the GPU box: tools/sweep_microbench
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <string>
@@ -140,7 +141,58 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   return (float)((double)NS * reps * B * n / sec / 1e9);
 }
 
+
+// Where do 1-wave workgroups land? Every workgroup records HW_ID / XCC_ID and then idles ~spin shader cycles so that
+// the workgroups of all concurrent dispatches are resident together.
+__global__ __launch_bounds__(256) void k_place(unsigned* out, long long spin) {
+  unsigned a, b;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(a));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(b));
+  const long long t0 = __builtin_readcyclecounter();
+  while ((long long)__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    out[2 * i] = a; out[2 * i + 1] = b;
+  }
+}
+static void placement(int G0, int NS, int wavesPerWg) {
+  const int G = G0 * wavesPerWg;  // waves per dispatch
+  std::vector<unsigned*> d(NS);
+  std::vector<hipStream_t> st(NS);
+  for (int k = 0; k < NS; ++k) { CK(hipMalloc(&d[k], G * 8)); CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking)); }
+  for (int k = 0; k < NS; ++k) hipLaunchKernelGGL(k_place, dim3(G0), dim3(64 * wavesPerWg), 0, st[k], d[k], 2000000LL);
+  CK(hipDeviceSynchronize());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < NS; ++k) hipLaunchKernelGGL(k_place, dim3(G0), dim3(64 * wavesPerWg), 0, st[k], d[k], 2000000LL);
+  CK(hipDeviceSynchronize());
+  printf("wall time of %d concurrent spin dispatches (2M cycles each): %.3f ms\n", NS,
+         1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  std::vector<int> perSimd(8 * 128 * 4, 0), perCu(8 * 128, 0), perXcc(8, 0);
+  std::vector<unsigned> h(2 * G);
+  for (int k = 0; k < NS; ++k) {
+    CK(hipMemcpy(h.data(), d[k], G * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < G; ++i) {
+      const unsigned id = h[2 * i], xcc = h[2 * i + 1] & 7;
+      const unsigned simd = (id >> 4) & 3, cu = (id >> 8) & 15, sh = (id >> 12) & 1, se = (id >> 13) & 7;
+      const unsigned cuIdx = ((se & 3) * 2 + sh) * 16 + cu;  // 0..127
+      perXcc[xcc]++; perCu[xcc * 128 + cuIdx]++; perSimd[(xcc * 128 + cuIdx) * 4 + simd]++;
+    }
+  }
+  auto stats = [](const std::vector<int>& v, const char* name) {
+    int used = 0, mx = 0; long tot = 0;
+    std::vector<int> hist(64, 0);
+    for (int x : v) { if (x) ++used; mx = std::max(mx, x); tot += x; hist[std::min(x, 63)]++; }
+    printf("%-8s slots used %d, max %d, total %ld; histogram(count:slots):", name, used, mx, tot);
+    for (int i = 0; i < 64; ++i) if (hist[i] && i) printf(" %d:%d", i, hist[i]);
+    printf("\n");
+  };
+  printf("placement of %d dispatches x %d workgroups of %d wave(s)\n", NS, G0, wavesPerWg);
+  printf("per XCC:"); for (int x : perXcc) printf(" %d", x); printf("\n");
+  stats(perCu, "per CU"); stats(perSimd, "per SIMD");
+}
+
 int main(int argc, char** argv) {
+  if (argc > 3 && std::string(argv[1]) == "place") { placement(atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 1); return 0; }
   if (argc > 5 && std::string(argv[1]) == "tp1") {  // one configuration (for rocprofv3 --pmc runs): w h B streams
     const int w = atoi(argv[2]), h = atoi(argv[3]), B = atoi(argv[4]), ns = atoi(argv[5]), md = argc > 6 ? atoi(argv[6]) : 2;
     printf("mode %d %dx%d B=%d streams=%d: %.2f Gpx/s\n", md, w, h, B, ns, throughput(w, h, B, md, ns, 4));
