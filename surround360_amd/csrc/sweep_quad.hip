@@ -1,19 +1,27 @@
 // sweep_quad.hip — throughput-oriented PixFlow propagation sweep for gfx950 ("quad").
 //
 // Same recurrence and same results as sweep_lock.hip (PixFlow.h:388-410), arranged for many flows / frames in
-// flight instead of for the latency of one flow. The sweeps are VALU-issue bound when the chip is full (rocprofv3:
-// the lockstep kernel spends ~42 VALU instructions per pixel update, 16 lanes per pixel, 9 speculative
-// evaluations), so this variant minimises instructions per pixel:
+// flight instead of for the latency of one flow. With the chip full of sweeps the limit is instruction issue (all
+// types: tools/issue_rate shows ~0.4 instructions per cycle per SIMD for VALU/SALU mixes however many waves share
+// the SIMD), so this variant minimises instructions per pixel update:
 //   * 4 lanes per pixel, 16 rows per wave (row r handles column s - r at step s);
 //   * the reference's two dependent rounds are kept: round 1 evaluates the current / left / up proposals in lanes
 //     0..2 of the quad, round 2 the two finite-difference probes of the winner in lanes 0..1 — 5 evaluations instead
-//     of 9, ~11 VALU instructions per pixel;
-//   * no service waves, no barriers: a workgroup is ONE wave that loads its own inputs one step ahead and stores its
-//     own results; other resident waves cover its memory latency. Left neighbour = registers, up neighbour = DPP
-//     (row_shr:4 / row_bcast:15), a band's first row takes the last row of the band above from 8-byte {fx,fy}
-//     granules in global memory (all-ones = not written; bands are ticketed in band-major order, spins are bounded).
-// A step is two gather rounds deep, so a single flow runs ~2x slower than with sweep_lock.hip; the chip-wide rate
-// is what improves. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+//     of the lockstep kernel's 9;
+//   * the step itself is ~250 instructions (202 VALU); everything else is amortised: the band above is checked every
+//     4 steps with wave-uniform control (a poll returns up to 64 granules), results go to an LDS ring and are written
+//     back once per 16 steps (loads and stores retire in order through one counter on gfx950 — a global store per step
+//     sat in front of every gather), the last row's granules are published every 4 steps, and the rare operands
+//     outside the proven range of the fast division / square root re-run the whole update with the IEEE expansions
+//     (one branch per step instead of three). Per step this is 253 instructions against 484 before;
+//   * no service waves, no barriers: a workgroup is ONE wave; other resident waves cover its memory latency. Left
+//     neighbour = registers, up neighbour = DPP (row_shr:4 / row_bcast:15), a band's first row takes the last row of
+//     the band above from 8-byte {fx,fy} granules in global memory (all-ones = not written; bands are ticketed in
+//     band-major order, spins are bounded).
+// Measured (tools/sweep_microbench tp1, 32 pole-level flows x 2 streams): 20.5 Gpx/s against 13.8 for the previous
+// per-step control flow; a single flow still runs ~1.25x slower than with sweep_lock.hip. FlowEngine picks this
+// kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+#include <cstdlib>
 #include <type_traits>
 
 #include "devmath.hpp"
@@ -49,6 +57,8 @@ __device__ __forceinline__ float from_row_above_q(float old, float v) {
 // publication of the last row's granules.
 constexpr int kQChunk = 16;
 constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
+constexpr int kQNeed = 4;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
+constexpr int kQPub = 4;   // the last row publishes its granules every kQPub steps
 
 template <bool FAST>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ rec, const float2* __restrict__ G,
@@ -95,7 +105,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
     const int x0 = (int)mx, y0 = (int)my;
     const float xR = __builtin_amdgcn_fractf(mx), yR = __builtin_amdgcn_fractf(my);
-    const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+    unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+    if (fc.dbg & 1) boff = (unsigned)lane << 4;  // timing experiment (results invalid): gathers that always hit
     const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
     const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
     Texels tt;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 
   // ---- granules of the band above -> s_up ring. Wave-uniform state; columns [.., upFilled) have been taken ----
   int upFilled = hasUpBand ? 0 : 0x3fffffff;
-  bool pending = false, dead = false;
+  bool pending = false, dead = (fc.dbg & 2) != 0;  // (dbg 2: timing experiment without the band-to-band wait)
   unsigned long long pv = kEmptyGranuleQ;
   auto issue = [&]() {
     const int xi = upFilled + lane;
@@ -172,25 +183,24 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     nfo = flowRow[x0c];
   }
   for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
-    if (hasUpBand && s0 < w) {  // row 0 needs columns [s0, s0 + kQChunk) of the band above during this chunk
-      const int need = min(s0 + kQChunk, w), limit = s0 + kUpRing;
-      if (!pending) issue();
-      process(limit);
-      unsigned spins = 0;
-      while (upFilled < need) {
-        __builtin_amdgcn_s_sleep(4);
-        issue();
-        process(limit);
-        if (++spins > (1u << 20) ||
-            ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-          dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
-          if (lane == 0) atomicExch(errflag, 1u);
-        }
-      }
-      if (upFilled < w) issue();  // taken at the next chunk boundary
-    }
     const int send = min(s0 + kQChunk, nsteps);
     for (int s = s0; s < send; ++s) {
+      if (hasUpBand && (s & (kQNeed - 1)) == 0 && s < w) {  // row 0 needs columns [s, s + kQNeed) of the band above
+        const int need = min(s + kQNeed, w), limit = s + kUpRing;
+        if (pending) process(limit);
+        unsigned spins = 0;
+        while (upFilled < need) {
+          if (spins) __builtin_amdgcn_s_sleep(2);
+          issue();
+          process(limit);
+          if (++spins > (1u << 20) ||
+              ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
+            if (lane == 0) atomicExch(errflag, 1u);
+          }
+        }
+        if (upFilled < w && upFilled - s < 2 * kQNeed + 8) issue();  // running low: taken at the next check
+      }
       const float4 rc = nrc;
       const float2 fo = nfo;
       {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
@@ -221,6 +231,14 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       res.y = take ? res.y : alt.y;
       fl = res;
       if (q == 0) s_res[r][xi & (kQResRing - 1)] = res;
+      if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
+        const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
+        if (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1)) {
+          const float2 v = s_res[kQRows - 1][xi0 & (kQResRing - 1)];
+          __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
     // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
     {
@@ -228,15 +246,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #pragma unroll
       for (int k = 0; k < kQChunk / 4; ++k) {
         const int xi = base + 4 * k;
-        if (rowValid && xi >= 0 && xi < w && xi < send - r) flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][xi & (kQResRing - 1)];
-      }
-      if (publishes && lane < kQChunk) {  // the last row's granules for the band below
-        const int xi = s0 - (kQRows - 1) + lane;
-        if (xi >= 0 && xi < w && xi < send - (kQRows - 1)) {
-          const float2 v = s_res[kQRows - 1][xi & (kQResRing - 1)];
-          __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (rowValid && xi >= 0 && xi < w && xi < send - r && !(fc.dbg & 4)) flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][xi & (kQResRing - 1)];
       }
     }
   }
@@ -255,7 +265,10 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   fc.rcCols = 1.0f / c.fcols;
   fc.rcRows = 1.0f / c.frows;
   fc.rcEps = 1.0f / 0.001f;
-  fc.dbg = 0;
+  {
+    const char* e = std::getenv("S360_SWEEP_DBG");  // timing experiments only
+    fc.dbg = e ? std::atoi(e) : 0;
+  }
   const int nb = sweep_quad_num_bands(h);
   (void)hipMemsetAsync(handoff, 0xFF, sweep_quad_handoff_bytes(w, h, B), st);
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
