@@ -242,7 +242,7 @@ static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
     uchar4* t2 = flip180 ? F.prTmp.as<uchar4>() : img2;
     launch_circle_alpha(st, F.botSrc2.as<uchar4>(), F.prRed[1].as<uint8_t>(), t2, w, h, radius2);
     dev_feather_in_place(c, t2, w, h);
-    if (flip180) launch_flip_both(st, t2, img2, w, h);
+    if (flip180) launch_flip_both(st, t2, img2, w, h, h);
   }
   {
     if (!c->flow_pr) { c->flow_pr.reset(new FlowEngine(&c->prof)); c->flow_pr->set_sweep_mode(c->sweep_mode); }
@@ -478,7 +478,7 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
       if (pole_mask & 12) {
         for (int e = 0; e < 2; ++e) {
           F.panoFlip[e].ensure(en * sizeof(uchar4));
-          launch_flip_both(st, F.pano[e].as<uchar4>(), F.panoFlip[e].as<uchar4>(), W, H);  // TRSP:842-843
+          launch_flip_both(st, F.pano[e].as<uchar4>(), F.panoFlip[e].as<uchar4>(), W, H, rows);  // TRSP:842-843 (only the rows the pole unit reads)
         }
       }
       for (int u = 0; u < 4; ++u)

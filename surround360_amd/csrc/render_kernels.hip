@@ -431,10 +431,10 @@ __global__ __launch_bounds__(256) void k_assemble_pano(const uchar4* __restrict_
   }
 }
 __global__ __launch_bounds__(256) void k_flip_both(const uchar4* __restrict__ src, uchar4* __restrict__ dst, int w,
-                                                   int h) {
+                                                   int h) {  // grid.y = number of leading rows of the flipped image
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= w) return;
-  dst[(size_t)(h - 1 - y) * w + (w - 1 - x)] = src[(size_t)y * w + x];
+  dst[(size_t)y * w + x] = src[(size_t)(h - 1 - y) * w + (w - 1 - x)];
 }
 
 // ---- featherAlphaChannel (CvUtil.cpp:140-157) ---------------------------------------------------
@@ -501,6 +501,89 @@ __global__ __launch_bounds__(256) void k_erode_cross_tiled(const uchar4* __restr
     }
 }
 
+// The same erosion for a compile-time radius E, all window minima in registers. Window minimum of length 2E+1 by
+// doubling: m2[i] = min(a[i], a[i+1]), m4[i] = min(m2[i], m2[i+2]) ... up to the largest power of two P <= 2E+1, then
+// min(mP[i], mP[i + 2E+1 - P]). A thread owns a strip of 32 outputs (32 + 2E inputs) of TWO rows (horizontal arm) or
+// TWO columns (vertical arm) at once, the two packed as the 16-bit halves of a register (v_pk_min_u16): ~7 VALU
+// operations per pixel and arm, no serial dependence on the window length, no LDS traffic beyond one read of the tile.
+constexpr int ERF_TW = 128, ERF_TH = 64, ERF_OUT = 32;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+template <int N, int LEN>
+__device__ __forceinline__ void window_min_strip(us2 (&a)[N]) {  // a[i] <- min(a[i .. i+LEN-1]) for i < N - LEN + 1
+  int span = 1;
+#pragma unroll
+  for (int d = 1; 2 * d <= LEN; d *= 2) {
+#pragma unroll
+    for (int i = 0; i + d < N; ++i) a[i] = __builtin_elementwise_min(a[i], a[i + d]);
+    span = 2 * d;
+  }
+  if (span < LEN) {
+#pragma unroll
+    for (int i = 0; i + LEN - span < N; ++i) a[i] = __builtin_elementwise_min(a[i], a[i + LEN - span]);
+  }
+}
+template <int E>
+__global__ __launch_bounds__(256) void k_erode_cross_fixed(const uchar4* __restrict__ img, uint8_t* __restrict__ out,
+                                                           int w, int h) {
+  constexpr int LEN = 2 * E + 1, NIN = ERF_OUT + 2 * E, HW = ERF_TW + 2 * E, VH = ERF_TH + 2 * E;
+  constexpr int HWP = (HW + 3) & ~3;
+  __shared__ unsigned s_h[ERF_TH / 2][HWP];       // row pairs: alpha(2j, c) | alpha(2j+1, c) << 16
+  __shared__ unsigned char s_v[VH][ERF_TW];       // alpha with the vertical halo
+  __shared__ unsigned char s_o[ERF_TH][ERF_TW];   // horizontal-arm result
+  const int x0 = blockIdx.x * ERF_TW, y0 = blockIdx.y * ERF_TH;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < (ERF_TH / 2) * HW; t += 256) {
+    const int j = t / HW, lx = t - j * HW;
+    const int gx = x0 - E + lx, gy = y0 + 2 * j;
+    const bool cx = gx >= 0 && gx < w;
+    const unsigned a0 = (cx && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
+    const unsigned a1 = (cx && gy + 1 < h) ? img[(size_t)(gy + 1) * w + gx].w : 255u;
+    s_h[j][lx] = a0 | (a1 << 16);
+  }
+  for (int t = tid; t < VH * ERF_TW; t += 256) {
+    const int ly = t >> 7, lx = t & (ERF_TW - 1);
+    const int gx = x0 + lx, gy = y0 - E + ly;
+    s_v[ly][lx] = (gx < w && gy >= 0 && gy < h) ? img[(size_t)gy * w + gx].w : 255;
+  }
+  __syncthreads();
+  us2 a[NIN];
+  if (tid < 128) {  // horizontal arm: row pair j, strip k of 32 columns
+    const int j = tid >> 2, k = tid & 3;
+    const unsigned* row = &s_h[j][k * ERF_OUT];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) a[i] = __builtin_bit_cast(us2, row[i]);
+    window_min_strip<NIN, LEN>(a);
+#pragma unroll
+    for (int i = 0; i < ERF_OUT; ++i) {
+      s_o[2 * j][k * ERF_OUT + i] = (unsigned char)a[i].x;
+      s_o[2 * j + 1][k * ERF_OUT + i] = (unsigned char)a[i].y;
+    }
+  } else {  // vertical arm: column pair c, strip k of 32 rows
+    const int t = tid - 128, c = t & 63, k = t >> 6;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const unsigned short two = *reinterpret_cast<const unsigned short*>(&s_v[k * ERF_OUT + i][2 * c]);
+      a[i] = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, (unsigned)two, 0x0c010c00u));
+    }
+    window_min_strip<NIN, LEN>(a);
+  }
+  __syncthreads();
+  if (tid >= 128) {
+    const int t = tid - 128, c = t & 63, k = t >> 6;
+    const int gx = x0 + 2 * c;
+#pragma unroll
+    for (int i = 0; i < ERF_OUT; ++i) {
+      const int ly = k * ERF_OUT + i, gy = y0 + ly;
+      const unsigned short hh = *reinterpret_cast<const unsigned short*>(&s_o[ly][2 * c]);
+      const unsigned m0 = min((unsigned)a[i].x, (unsigned)(hh & 0xff)), m1 = min((unsigned)a[i].y, (unsigned)(hh >> 8));
+      if (gy < h) {
+        if (gx + 1 < w) *reinterpret_cast<unsigned short*>(out + (size_t)gy * w + gx) = (unsigned short)(m0 | (m1 << 8));
+        else if (gx < w) out[(size_t)gy * w + gx] = (uint8_t)m0;
+      }
+    }
+  }
+}
+
 // GaussianBlur on CV_8U (ksize x ksize, fixed-point taps ik scaled by 256, BORDER_REFLECT_101): row pass to int,
 // column pass, (sum + 2^15) >> 16 — both inside one LDS tile, 4 outputs per thread along the filter axis.
 constexpr int GU_TW = 64, GU_TH = 32, GU_MAXR = 16;
@@ -526,10 +609,10 @@ __global__ __launch_bounds__(256) void k_gauss_u8_tiled(const uint8_t* __restric
     for (int j = 0; j < 2 * r + 4; ++j) {
       const int v = s_a[ly][lx0 + j];
       // tap index of input j for output o is j - o (valid 0..2r)
-      if (j <= 2 * r) acc0 += s_k[j] * v;
-      if (j >= 1 && j - 1 <= 2 * r) acc1 += s_k[j - 1] * v;
-      if (j >= 2 && j - 2 <= 2 * r) acc2 += s_k[j - 2] * v;
-      if (j >= 3) acc3 += s_k[j - 3] * v;
+      if (j <= 2 * r) acc0 += (int)__umul24((unsigned)s_k[j], (unsigned)v);
+      if (j >= 1 && j - 1 <= 2 * r) acc1 += (int)__umul24((unsigned)s_k[j - 1], (unsigned)v);
+      if (j >= 2 && j - 2 <= 2 * r) acc2 += (int)__umul24((unsigned)s_k[j - 2], (unsigned)v);
+      if (j >= 3) acc3 += (int)__umul24((unsigned)s_k[j - 3], (unsigned)v);
     }
     s_row[ly][lx0] = acc0; s_row[ly][lx0 + 1] = acc1; s_row[ly][lx0 + 2] = acc2; s_row[ly][lx0 + 3] = acc3;
   }
@@ -540,14 +623,67 @@ __global__ __launch_bounds__(256) void k_gauss_u8_tiled(const uint8_t* __restric
     int acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
     for (int j = 0; j < 2 * r + 4; ++j) {
       const int v = s_row[ly0 + j][lx];
-      if (j <= 2 * r) acc0 += s_k[j] * v;
-      if (j >= 1 && j - 1 <= 2 * r) acc1 += s_k[j - 1] * v;
-      if (j >= 2 && j - 2 <= 2 * r) acc2 += s_k[j - 2] * v;
-      if (j >= 3) acc3 += s_k[j - 3] * v;
+      if (j <= 2 * r) acc0 += (int)__umul24((unsigned)s_k[j], (unsigned)v);
+      if (j >= 1 && j - 1 <= 2 * r) acc1 += (int)__umul24((unsigned)s_k[j - 1], (unsigned)v);
+      if (j >= 2 && j - 2 <= 2 * r) acc2 += (int)__umul24((unsigned)s_k[j - 2], (unsigned)v);
+      if (j >= 3) acc3 += (int)__umul24((unsigned)s_k[j - 3], (unsigned)v);
     }
     const int gx = x0 + lx;
     if (gx >= w) continue;
     const int acc[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int gy = y0 + ly0 + o;
+      if (gy < h) out[(size_t)gy * w + gx] = (uint8_t)sat_u8((acc[o] + (1 << 15)) >> 16);
+    }
+  }
+}
+// The same filter for a compile-time radius R: every loop unrolled, tap index known at compile time.
+template <int R>
+__global__ __launch_bounds__(256) void k_gauss_u8_fixed(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, int w,
+                                                        int h, const int* __restrict__ ik) {
+  constexpr int IW = GU_TW + 2 * R, IH = GU_TH + 2 * R, NT = 2 * R + 1;
+  __shared__ int s_a[IH][IW + 1];
+  __shared__ int s_row[IH][GU_TW + 1];
+  const int tx = threadIdx.x & (GU_TW - 1), ty = threadIdx.x >> 6;  // 64 x 4 threads
+  const int x0 = blockIdx.x * GU_TW, y0 = blockIdx.y * GU_TH;
+  int k[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) k[j] = ik[j];  // uniform: scalar registers
+  for (int ly = ty; ly < IH; ly += 4) {
+    const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
+    for (int lx = tx; lx < IW; lx += GU_TW) s_a[ly][lx] = row[reflect101(x0 - R + lx, w)];
+  }
+  __syncthreads();
+  // row pass: task = (row, group of 4 consecutive x)
+  for (int t = threadIdx.x; t < IH * (GU_TW / 4); t += 256) {
+    const int g = t / IH, ly = t - g * IH, lx0 = g * 4;
+    int acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+    for (int j = 0; j < NT + 3; ++j) {
+      const int v = s_a[ly][lx0 + j];
+      if (j < NT) acc0 += (int)__umul24((unsigned)k[j], (unsigned)v);
+      if (j >= 1 && j - 1 < NT) acc1 += (int)__umul24((unsigned)k[j - 1], (unsigned)v);
+      if (j >= 2 && j - 2 < NT) acc2 += (int)__umul24((unsigned)k[j - 2], (unsigned)v);
+      if (j >= 3) acc3 += (int)__umul24((unsigned)k[j - 3], (unsigned)v);
+    }
+    s_row[ly][lx0] = acc0; s_row[ly][lx0 + 1] = acc1; s_row[ly][lx0 + 2] = acc2; s_row[ly][lx0 + 3] = acc3;
+  }
+  __syncthreads();
+  // column pass: task = (column, group of 4 consecutive y)
+  for (int t = threadIdx.x; t < GU_TW * (GU_TH / 4); t += 256) {
+    const int lx = t & (GU_TW - 1), ly0 = (t >> 6) * 4;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NT + 3; ++j) {
+      const int v = s_row[ly0 + j][lx];
+      if (j < NT) acc[0] += (int)__umul24((unsigned)k[j], (unsigned)v);
+      if (j >= 1 && j - 1 < NT) acc[1] += (int)__umul24((unsigned)k[j - 1], (unsigned)v);
+      if (j >= 2 && j - 2 < NT) acc[2] += (int)__umul24((unsigned)k[j - 2], (unsigned)v);
+      if (j >= 3) acc[3] += (int)__umul24((unsigned)k[j - 3], (unsigned)v);
+    }
+    const int gx = x0 + lx;
+    if (gx >= w) continue;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int gy = y0 + ly0 + o;
@@ -823,17 +959,23 @@ void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int c
   hipLaunchKernelGGL(k_assemble_pano, dim3(cdiv(cdiv(eqrW, 4), 256), eqrH), dim3(256), 0, st, strips_eye, P, camH, stripW, offset,
                      pano, eqrW, eqrH, padAbove);
 }
-void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h) {
-  hipLaunchKernelGGL(k_flip_both, dim3(cdiv(w, 256), h), dim3(256), 0, st, src, dst, w, h);
+void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h, int rows) {
+  hipLaunchKernelGGL(k_flip_both, dim3(cdiv(w, 256), rows), dim3(256), 0, st, src, dst, w, h);
 }
 // featherAlphaChannel's erode (alpha of a BGRA image -> eroded 8-bit plane) and Gaussian
 void launch_erode_alpha(hipStream_t st, const uchar4* img, uint8_t* out, int w, int h, int e) {
   if (e > ER_MAXE) throw std::runtime_error("featherAlphaChannel: erode size above 32 is not supported");
-  hipLaunchKernelGGL(k_erode_cross_tiled, dim3(cdiv(w, ER_TW), cdiv(h, ER_TH)), dim3(256), 0, st, img, out, w, h, e);
+  if (e == 31 && (w & 1) == 0)  // the reference's default std_alpha_feather_size; (even width: 2-byte stores)
+    hipLaunchKernelGGL((k_erode_cross_fixed<31>), dim3(cdiv(w, ERF_TW), cdiv(h, ERF_TH)), dim3(256), 0, st, img, out, w, h);
+  else
+    hipLaunchKernelGGL(k_erode_cross_tiled, dim3(cdiv(w, ER_TW), cdiv(h, ER_TH)), dim3(256), 0, st, img, out, w, h, e);
 }
 void launch_gauss_u8(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, const int* ik, int r) {
   if (r > GU_MAXR) throw std::runtime_error("featherAlphaChannel: Gaussian radius above 16 is not supported");
-  hipLaunchKernelGGL(k_gauss_u8_tiled, dim3(cdiv(w, GU_TW), cdiv(h, GU_TH)), dim3(256), 0, st, a, out, w, h, ik, r);
+  if (r == 15)  // ksize 31: the reference's default std_alpha_feather_size
+    hipLaunchKernelGGL((k_gauss_u8_fixed<15>), dim3(cdiv(w, GU_TW), cdiv(h, GU_TH)), dim3(256), 0, st, a, out, w, h, ik);
+  else
+    hipLaunchKernelGGL(k_gauss_u8_tiled, dim3(cdiv(w, GU_TW), cdiv(h, GU_TH)), dim3(256), 0, st, a, out, w, h, ik, r);
 }
 void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha, int cols, int rows, uchar4* ext,
                         int extW) {

@@ -51,7 +51,8 @@ void launch_novel_view(hipStream_t st, const uchar4* overlaps, const float2* flo
 // stackHorizontal + offsetHorizontalWrap + padToheight (TRSP:380-384, 806-807) for one eye
 void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int camH, int stripW, float offset,
                           uchar4* pano, int eqrW, int eqrH);
-void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h);
+// first `rows` rows of the image flipped around both axes (flip(img, img, -1))
+void launch_flip_both(hipStream_t st, const uchar4* src, uchar4* dst, int w, int h, int rows);
 // featherAlphaChannel pieces (CvUtil.cpp:140-157) on the top `rows` rows of a pano
 void launch_erode_alpha(hipStream_t st, const uchar4* img, uint8_t* out, int w, int h, int e);
 void launch_gauss_u8(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int h, const int* ik, int r);
