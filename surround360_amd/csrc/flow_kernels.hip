@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restr
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uchar4 p = S[clip_idx(sx - 1 + q, sw)];
-      hx += p.x * ax[q]; hy += p.y * ax[q]; hz += p.z * ax[q]; hw += p.w * ax[q];
+      hx += __mul24((int)p.x, ax[q]); hy += __mul24((int)p.y, ax[q]); hz += __mul24((int)p.z, ax[q]); hw += __mul24((int)p.w, ax[q]);
     }
-    vx += hx * ay[r]; vy += hy * ay[r]; vz += hz * ay[r]; vw += hw * ay[r];
+    vx += __mul24(hx, ay[r]); vy += __mul24(hy, ay[r]); vz += __mul24(hz, ay[r]); vw += __mul24(hw, ay[r]);  // |h| < 2^20, |a| < 2^12
   }
   uchar4 o;
   o.x = (unsigned char)sat_u8((vx + (1 << 21)) >> 22);
@@ -280,29 +280,34 @@ __device__ __forceinline__ void mnmx(float& a, float& b) {
   a = lo;
   b = hi;
 }
+// Sort of three: v_min3 / v_med3 / v_max3 — three instructions where three compare-exchanges take six.
+__device__ __forceinline__ void sort3(float& a, float& b, float& c) {
+  const float lo = fminf(fminf(a, b), c), hi = fmaxf(fmaxf(a, b), c), md = __builtin_amdgcn_fmed3f(a, b, c);
+  a = lo;
+  b = md;
+  c = hi;
+}
 // Exact median of 25 with the 99-comparator selection network of Devillard's "Fast median search" (after Paeth,
-// Graphics Gems): verified for all 2^25 0/1 inputs (0-1 principle), tools/verify_median_network.py. Comparators
-// whose outputs are never read again are removed by the compiler.
+// Graphics Gems): verified for all 2^25 0/1 inputs (0-1 principle), tools/verify_median_network.py. 66 of its
+// comparators form 22 runs of three that sort three wires; those are S360_S3 (same function, half the instructions).
+// Comparators whose outputs are never read again are removed by the compiler.
 __device__ __forceinline__ float median25(const float* in) {
   float p[25];
 #pragma unroll
   for (int i = 0; i < 25; ++i) p[i] = in[i];
 #define S360_CE(a, b) mnmx(p[a], p[b])
-  S360_CE(0, 1); S360_CE(3, 4); S360_CE(2, 4); S360_CE(2, 3); S360_CE(6, 7); S360_CE(5, 7); S360_CE(5, 6); S360_CE(9, 10);
-  S360_CE(8, 10); S360_CE(8, 9); S360_CE(12, 13); S360_CE(11, 13); S360_CE(11, 12); S360_CE(15, 16); S360_CE(14, 16);
-  S360_CE(14, 15); S360_CE(18, 19); S360_CE(17, 19); S360_CE(17, 18); S360_CE(21, 22); S360_CE(20, 22); S360_CE(20, 21);
-  S360_CE(23, 24); S360_CE(2, 5); S360_CE(3, 6); S360_CE(0, 6); S360_CE(0, 3); S360_CE(4, 7); S360_CE(1, 7); S360_CE(1, 4);
-  S360_CE(11, 14); S360_CE(8, 14); S360_CE(8, 11); S360_CE(12, 15); S360_CE(9, 15); S360_CE(9, 12); S360_CE(13, 16);
-  S360_CE(10, 16); S360_CE(10, 13); S360_CE(20, 23); S360_CE(17, 23); S360_CE(17, 20); S360_CE(21, 24); S360_CE(18, 24);
-  S360_CE(18, 21); S360_CE(19, 22); S360_CE(8, 17); S360_CE(9, 18); S360_CE(0, 18); S360_CE(0, 9); S360_CE(10, 19);
-  S360_CE(1, 19); S360_CE(1, 10); S360_CE(11, 20); S360_CE(2, 20); S360_CE(2, 11); S360_CE(12, 21); S360_CE(3, 21);
-  S360_CE(3, 12); S360_CE(13, 22); S360_CE(4, 22); S360_CE(4, 13); S360_CE(14, 23); S360_CE(5, 23); S360_CE(5, 14);
-  S360_CE(15, 24); S360_CE(6, 24); S360_CE(6, 15); S360_CE(7, 16); S360_CE(7, 19); S360_CE(13, 21); S360_CE(15, 23);
-  S360_CE(7, 13); S360_CE(7, 15); S360_CE(1, 9); S360_CE(3, 11); S360_CE(5, 17); S360_CE(11, 17); S360_CE(9, 17);
-  S360_CE(4, 10); S360_CE(6, 12); S360_CE(7, 14); S360_CE(4, 6); S360_CE(4, 7); S360_CE(12, 14); S360_CE(10, 14);
-  S360_CE(6, 7); S360_CE(10, 12); S360_CE(6, 10); S360_CE(6, 17); S360_CE(12, 17); S360_CE(7, 17); S360_CE(7, 10);
-  S360_CE(12, 18); S360_CE(7, 12); S360_CE(10, 18); S360_CE(12, 20); S360_CE(10, 20); S360_CE(10, 12);
+#define S360_S3(a, b, c) sort3(p[a], p[b], p[c])
+  S360_CE(0, 1); S360_S3(2, 3, 4); S360_S3(5, 6, 7); S360_S3(8, 9, 10); S360_S3(11, 12, 13); S360_S3(14, 15, 16);
+  S360_S3(17, 18, 19); S360_S3(20, 21, 22); S360_CE(23, 24); S360_CE(2, 5); S360_S3(0, 3, 6); S360_S3(1, 4, 7);
+  S360_S3(8, 11, 14); S360_S3(9, 12, 15); S360_S3(10, 13, 16); S360_S3(17, 20, 23); S360_S3(18, 21, 24);
+  S360_CE(19, 22); S360_CE(8, 17); S360_S3(0, 9, 18); S360_S3(1, 10, 19); S360_S3(2, 11, 20); S360_S3(3, 12, 21);
+  S360_S3(4, 13, 22); S360_S3(5, 14, 23); S360_S3(6, 15, 24); S360_CE(7, 16); S360_CE(7, 19); S360_CE(13, 21);
+  S360_CE(15, 23); S360_CE(7, 13); S360_CE(7, 15); S360_CE(1, 9); S360_CE(3, 11); S360_CE(5, 17); S360_CE(11, 17);
+  S360_CE(9, 17); S360_CE(4, 10); S360_CE(6, 12); S360_CE(7, 14); S360_CE(4, 6); S360_CE(4, 7); S360_CE(12, 14);
+  S360_CE(10, 14); S360_CE(6, 7); S360_CE(10, 12); S360_CE(6, 10); S360_CE(6, 17); S360_CE(12, 17); S360_CE(7, 17);
+  S360_CE(7, 10); S360_CE(12, 18); S360_CE(7, 12); S360_CE(10, 18); S360_S3(10, 12, 20);
 #undef S360_CE
+#undef S360_S3
   return p[12];
 }
 __global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ src, float2* __restrict__ dst, int w,

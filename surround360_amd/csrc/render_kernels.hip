@@ -95,7 +95,7 @@ __device__ __forceinline__ uchar4 remap_cubic_u8c4_at(const uchar4* __restrict__
       if (xi < 0 || xi >= sw) continue;
       const uchar4 p = S[xi];
       const int ww = w[r * 4 + q];
-      s0 += p.x * ww; s1 += p.y * ww; s2 += p.z * ww; s3 += p.w * ww;
+      s0 += __mul24((int)p.x, ww); s1 += __mul24((int)p.y, ww); s2 += __mul24((int)p.z, ww); s3 += __mul24((int)p.w, ww);  // 8-bit x 16-bit
     }
   }
   return make_uchar4((unsigned char)sat_u8((s0 + (1 << 14)) >> 15), (unsigned char)sat_u8((s1 + (1 << 14)) >> 15),
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uch
         for (int q = 0; q < 4; ++q) {
           const uchar4 p = T[r * bw + q];
           const int ww = w[r * 4 + q];
-          s0 += p.x * ww; s1 += p.y * ww; s2 += p.z * ww; s3 += p.w * ww;
+          s0 += __mul24((int)p.x, ww); s1 += __mul24((int)p.y, ww); s2 += __mul24((int)p.z, ww); s3 += __mul24((int)p.w, ww);  // 8-bit x 16-bit
         }
       }
       o = make_uchar4((unsigned char)sat_u8((s0 + (1 << 14)) >> 15), (unsigned char)sat_u8((s1 + (1 << 14)) >> 15),

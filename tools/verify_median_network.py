@@ -15,9 +15,27 @@ n = np.arange(N, dtype=np.uint32)
 v = n - ((n >> 1) & 0x55555555); v = (v & 0x33333333) + ((v >> 2) & 0x33333333); pc = (((v + (v >> 4)) & 0x0F0F0F0F) * 0x01010101) >> 24
 maj = np.packbits((pc >= 13).astype(np.uint8), bitorder='little').view(np.uint64)
 wires = [np.packbits(((n >> i) & 1).astype(np.uint8), bitorder='little').view(np.uint64) for i in range(25)]
-for a, b in pairs:
-    lo = wires[a] & wires[b]; hi = wires[a] | wires[b]
-    wires[a], wires[b] = lo, hi
+# The kernel runs the 22 runs of three comparators that sort three wires as sort3 (min3 / med3 / max3); group them
+# the same way here (a run (b,c),(a,c),(a,b) over wires a<b<c) and apply the 3-sort as one operation.
+ops, i = [], 0
+while i < len(pairs):
+    if i + 2 < len(pairs):
+        (p0, p1), (q0, q1), (r0, r1) = pairs[i], pairs[i + 1], pairs[i + 2]
+        ws = sorted({p0, p1, q0, q1, r0, r1})
+        if len(ws) == 3 and (p0, p1) == (ws[1], ws[2]) and (q0, q1) == (ws[0], ws[2]) and (r0, r1) == (ws[0], ws[1]):
+            ops.append(tuple(ws)); i += 3; continue
+    ops.append(tuple(pairs[i])); i += 1
+print(sum(len(o) == 3 for o in ops), "sort3 +", sum(len(o) == 2 for o in ops), "compare-exchange")
+for o in ops:
+    if len(o) == 2:
+        a, b = o
+        lo = wires[a] & wires[b]; hi = wires[a] | wires[b]
+        wires[a], wires[b] = lo, hi
+    else:
+        a, b, c = o
+        lo = wires[a] & wires[b] & wires[c]; hi = wires[a] | wires[b] | wires[c]
+        md = (wires[a] & wires[b]) | (wires[a] & wires[c]) | (wires[b] & wires[c])
+        wires[a], wires[b], wires[c] = lo, md, hi
 ok = np.array_equal(wires[12], maj)
 print("median network correct for all 2^25 0/1 inputs:", ok)
 if not ok:
