@@ -320,10 +320,14 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
     ProfScope ps(prof, "project_side");
     std::vector<char> need(P, 0);
     for (int p = p0; p < p1; ++p) need[p] = need[(p + 1) % P] = 1;
-    for (int i = 0; i < P; ++i)
-      if (need[i])
-        launch_remap_cubic_u8c4(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, F.sideMaps.as<float2>() + pn * i,
-                                F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1);
+    for (int i = 0; i < P;) {  // one launch per run of consecutive cameras (all of them unless the frame is sharded)
+      if (!need[i]) { ++i; continue; }
+      int j = i;
+      while (j < P && need[j]) ++j;
+      launch_remap_cubic_u8c4(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, F.sideMaps.as<float2>() + pn * i,
+                              F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
+      i = j;
+    }
   }
   const bool repartition = (F.side_p0 != p0 || F.side_p1 != p1);
   const bool usePrev = use_prev && F.have_prev_side && !repartition;

@@ -148,6 +148,7 @@ __device__ __forceinline__ float2 remap_cubic_f32c2_at(const float2* __restrict_
 // need no bounds checks), and the 16 taps per pixel are LDS reads. Tiles whose box does not fit fall back to the
 // per-tap global gather. Integer arithmetic: the result does not depend on the summation order.
 constexpr int RT_W = 64, RT_H = 8, RT_CAP = 4608;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -164,6 +165,7 @@ struct MapFromBuffer {  // bicubicRemapToSpherical: cached warp map (ImageWarper
   const float2* map;
   int dw;
   __device__ __forceinline__ float2 operator()(int x, int y) const { return map[(size_t)y * dw + x]; }
+  __device__ __forceinline__ void advance(size_t n) { map += n; }
 };
 struct MapFromPoleFlow {  // poleToSideFlowThread's ramped warp (TRSP:483-503)
   const float2* flow;
@@ -174,6 +176,7 @@ struct MapFromPoleFlow {  // poleToSideFlowThread's ramped warp (TRSP:483-503)
     const float2 f = flow[(size_t)y * pw.extW + x];
     return make_float2((float)x + (1.0f - alpha) * f.x, (float)y + (1.0f - alpha) * f.y);
   }
+  __device__ __forceinline__ void advance(size_t n) { flow += n; }
 };
 
 struct MapFromFlowAdd {  // PoleRemoval.cpp:128-133: warp = (x, y) + flow
@@ -183,6 +186,7 @@ struct MapFromFlowAdd {  // PoleRemoval.cpp:128-133: warp = (x, y) + flow
     const float2 f = flow[(size_t)y * w + x];
     return make_float2((float)x + f.x, (float)y + f.y);
   }
+  __device__ __forceinline__ void advance(size_t n) { flow += n; }
 };
 
 template <class MapFn>
@@ -190,7 +194,11 @@ __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uch
                                                                        MapFn mapfn, uchar4* __restrict__ dst, int dw,
                                                                        int dh, const short* __restrict__ tab,
                                                                        int alpha_mode, int yFeatherStart,
-                                                                       int featherSize) {
+                                                                       int featherSize, size_t sbs, size_t dbs) {
+  // blockIdx.z = image of a batch with identical geometry (the side cameras): sources sbs, maps / outputs dbs apart
+  src += sbs * blockIdx.z;
+  dst += dbs * blockIdx.z;
+  mapfn.advance(dbs * blockIdx.z);
   __shared__ uchar4 s_tile[RT_CAP];
   __shared__ int s_box[4];
   const int x = blockIdx.x * RT_W + threadIdx.x, y = blockIdx.y * RT_H + threadIdx.y;
@@ -229,20 +237,28 @@ __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uch
     }
     __syncthreads();
     if (live) {
-      const short* w = tab + fxy * 16;
-      const uchar4* T = s_tile + (sy - by0) * bw + (sx - bx0);
-      int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      // 16 taps x 4 channels as v_dot2_i32_i16: the table already holds the weights of two neighbouring taps in one
+      // dword; v_perm_b32 puts one channel of two neighbouring pixels into the halves of the other operand.
+      const uint4* w4 = reinterpret_cast<const uint4*>(tab + fxy * 16);
+      const uint4 wa = w4[0], wb = w4[1];
+      const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+      const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + (sy - by0) * bw + (sx - bx0);
+      int acc[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        const unsigned p0 = T[r * bw], p1 = T[r * bw + 1], p2 = T[r * bw + 2], p3 = T[r * bw + 3];
+        const s16x2 w01 = __builtin_bit_cast(s16x2, wq[2 * r]), w23 = __builtin_bit_cast(s16x2, wq[2 * r + 1]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uchar4 p = T[r * bw + q];
-          const int ww = w[r * 4 + q];
-          s0 += __mul24((int)p.x, ww); s1 += __mul24((int)p.y, ww); s2 += __mul24((int)p.z, ww); s3 += __mul24((int)p.w, ww);  // 8-bit x 16-bit
+        for (int ch = 0; ch < 4; ++ch) {
+          const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
+          const s16x2 lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p1, p0, sel));
+          const s16x2 hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p3, p2, sel));
+          acc[ch] = __builtin_amdgcn_sdot2(lo, w01, acc[ch], false);
+          acc[ch] = __builtin_amdgcn_sdot2(hi, w23, acc[ch], false);
         }
       }
-      o = make_uchar4((unsigned char)sat_u8((s0 + (1 << 14)) >> 15), (unsigned char)sat_u8((s1 + (1 << 14)) >> 15),
-                      (unsigned char)sat_u8((s2 + (1 << 14)) >> 15), (unsigned char)sat_u8((s3 + (1 << 14)) >> 15));
+      o = make_uchar4((unsigned char)sat_u8((acc[0] + (1 << 14)) >> 15), (unsigned char)sat_u8((acc[1] + (1 << 14)) >> 15),
+                      (unsigned char)sat_u8((acc[2] + (1 << 14)) >> 15), (unsigned char)sat_u8((acc[3] + (1 << 14)) >> 15));
     }
   } else if (live) {
     o = remap_cubic_u8c4_at(src, sw, sh, m.x, m.y, tab);
@@ -920,16 +936,17 @@ void launch_spherical_map(hipStream_t st, float2* map, int dw, int dh, const Dev
                      sinY);
 }
 void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, uchar4* dst, int dw,
-                             int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize) {
+                             int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize, int batch) {
   MapFromBuffer mf{map, dw};
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromBuffer>), dim3(cdiv(dw, RT_W), cdiv(dh, RT_H)), dim3(RT_W, RT_H), 0,
-                     st, src, sw, sh, mf, dst, dw, dh, T.bicubic_i, alpha_mode, yFeatherStart, featherSize);
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromBuffer>), dim3(cdiv(dw, RT_W), cdiv(dh, RT_H), batch),
+                     dim3(RT_W, RT_H), 0, st, src, sw, sh, mf, dst, dw, dh, T.bicubic_i, alpha_mode, yFeatherStart,
+                     featherSize, (size_t)sw * sh, (size_t)dw * dh);
 }
 void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
                           const DevTables& T) {
   MapFromFlowAdd mf{flow, w};
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromFlowAdd>), dim3(cdiv(w, RT_W), cdiv(h, RT_H)), dim3(RT_W, RT_H), 0, st,
-                     src, w, h, mf, dst, w, h, T.bicubic_i, 0, 0, 1);
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromFlowAdd>), dim3(cdiv(w, RT_W), cdiv(h, RT_H), 1), dim3(RT_W, RT_H), 0, st,
+                     src, w, h, mf, dst, w, h, T.bicubic_i, 0, 0, 1, (size_t)0, (size_t)0);
 }
 void launch_red_mask(hipStream_t st, const uint8_t* bgr, uint8_t* red, size_t n) {
   hipLaunchKernelGGL(k_red_mask, dim3(cdiv(n, 256)), dim3(256), 0, st, bgr, red, n);
@@ -984,9 +1001,9 @@ void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha,
 void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
                       const PoleWarpParams& pw, const DevTables& T) {
   MapFromPoleFlow mf{flow, pw};
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromPoleFlow>), dim3(cdiv(pw.extW, RT_W), cdiv(pw.rows, RT_H)),
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromPoleFlow>), dim3(cdiv(pw.extW, RT_W), cdiv(pw.rows, RT_H), 1),
                      dim3(RT_W, RT_H), 0, st, extFisheye, pw.extW, pw.rows, mf, warpedExt, pw.extW, pw.rows, T.bicubic_i, 0,
-                     0, 1);
+                     0, 1, (size_t)0, (size_t)0);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   hipLaunchKernelGGL(k_pole_finish, dim3(cdiv(pw.cols, 256), eqrH), dim3(256), 0, st, warpedExt, out, eqrH, pw);

@@ -40,7 +40,8 @@ void launch_spherical_map(hipStream_t st, float2* map, int dw, int dh, const Dev
 // remap INTER_CUBIC / BORDER_CONSTANT(0) of a BGRA image through a float2 map. alpha_mode 0: keep interpolated
 // alpha; 1: pole rule (alpha = 255 above yFeatherStart, 255*ramp below; TRSP:669-678, 629-637).
 void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, uchar4* dst, int dw,
-                             int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize);
+                             int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize,
+                             int batch = 1 /* images of identical geometry: sources sw*sh, maps and outputs dw*dh apart */);
 // overlap crops (TRSP:196-198) for pairs [p0,p1): out[j] = right part of proj p0+j, out[n+j] = left part of
 // proj (p0+j+1)%P, n = p1-p0
 void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH, int P, int overlapW, uchar4* out,
