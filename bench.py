@@ -15,7 +15,10 @@ gathering the strips on rank 0, which runs the pole units and the composite.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
 (measured live with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle = an OpenCV-free
-port of the reference, timed on a bounded sample on the host cores; N=1 only).
+port of the reference, timed on a bounded sample on the host cores; N=1 only). `video_stream` is one stream with
+temporal regularisation (frame k uses frame k-1's flows: BASELINE configs[4] on one GPU). `host` reports the
+submission side: enqueue time per frame and the untimed settle batches that precede the warm-up (see the comment at
+the settle loop).
 """
 import argparse
 import json
