@@ -154,10 +154,11 @@ int s360_combine_lazy_novel_views(s360_ctx* ctx, const uint8_t* image_l, const u
 /* flattenLayersDeghostPreferBase (SR/util/CvUtil.cpp:224-260). BGRA in, BGRA out. */
 int s360_flatten_layers_deghost_prefer_base(s360_ctx* ctx, const uint8_t* bottom_layer, const uint8_t* top_layer, int w,
                                             int h, uint8_t* out);
-/* offsetHorizontalWrap (SR/util/CvUtil.cpp:93-115). */
+/* offsetHorizontalWrap (SR/util/CvUtil.cpp:93-115). channels 3 (BGR) or 4 (BGRA). */
 int s360_offset_horizontal_wrap(s360_ctx* ctx, const uint8_t* src, int w, int h, int channels, float offset,
                                 uint8_t* out);
-/* featherAlphaChannel (SR/util/CvUtil.cpp:140-157). BGRA. */
+/* featherAlphaChannel (SR/util/CvUtil.cpp:140-157). BGRA. erode_size odd (it is also the GaussianBlur kernel size)
+ * and <= 31; the context's std_alpha_feather_size uses the cached taps and the fixed-radius kernels. */
 int s360_feather_alpha_channel(s360_ctx* ctx, const uint8_t* src, int w, int h, int erode_size, uint8_t* out);
 /* poleToSideFlowThread (SR/test/TestRenderStereoPanorama.cpp:388-561) without temporal state:
  * side: eqr_width x eqr_height BGRA eye panorama, pole: eqr_width x pole_rows BGRA.

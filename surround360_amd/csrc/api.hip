@@ -349,23 +349,42 @@ int s360_offset_horizontal_wrap(s360_ctx* c, const uint8_t* src, int w, int h, i
                                 uint8_t* out) {
   return guard(c, [&] {
     need(c && src && out && w > 0 && h > 0, "bad argument");
-    need(channels == 4, "only BGRA panoramas are shifted on this path");
+    need(channels == 3 || channels == 4, "channels must be 3 or 4");
     const size_t n = (size_t)w * h;
     c->op_a.ensure(n * 4); c->op_b.ensure(n * 4);
-    h2d(c, c->op_a.p, src, n * 4);
+    if (channels == 4) {
+      h2d(c, c->op_a.p, src, n * 4);
+    } else {  // BGR: through the BGRA kernels, alpha dropped again
+      c->op_c.ensure(n * 3);
+      h2d(c, c->op_c.p, src, n * 3);
+      launch_bgr_to_bgra(c->st, c->op_c.as<uint8_t>(), 3, c->op_a.as<uchar4>(), n);
+    }
     // one "strip" of the full width, no padding: pure offsetHorizontalWrap
     launch_assemble_pano(c->st, c->op_a.as<uchar4>(), 1, h, w, offset, c->op_b.as<uchar4>(), w, h);
-    d2h(c, out, c->op_b.p, n * 4);
+    if (channels == 4) {
+      d2h(c, out, c->op_b.p, n * 4);
+    } else {
+      launch_pack_bgr(c->st, c->op_b.as<uchar4>(), w, h, c->op_c.as<uint8_t>());
+      d2h(c, out, c->op_c.p, n * 3);
+    }
   });
 }
 int s360_feather_alpha_channel(s360_ctx* c, const uint8_t* src, int w, int h, int erode_size, uint8_t* out) {
   return guard(c, [&] {
     need(c && src && out && w > 0 && h > 0, "bad argument");
-    need(erode_size == c->P.std_alpha_feather_size, "erode_size must equal the context's std_alpha_feather_size");
+    need(erode_size >= 1 && erode_size <= 32, "erode_size must be in 1..32");
+    need(erode_size % 2 == 1, "erode_size must be odd (it is the GaussianBlur kernel size, CvUtil.cpp:151)");
     const size_t n = (size_t)w * h;
     c->op_a.ensure(n * 4); c->op_b.ensure(n * 4);
     h2d(c, c->op_a.p, src, n * 4);
-    dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), w, h, c->op_b.as<uchar4>(), w);
+    if (erode_size == c->P.std_alpha_feather_size) {
+      dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), w, h, c->op_b.as<uchar4>(), w);
+    } else {
+      const std::vector<int> taps = feather_gauss_taps(erode_size);
+      c->op_e.ensure(taps.size() * sizeof(int));
+      h2d(c, c->op_e.p, taps.data(), taps.size() * sizeof(int));
+      dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), w, h, c->op_b.as<uchar4>(), w, erode_size, c->op_e.as<int>());
+    }
     d2h(c, out, c->op_b.p, n * 4);
   });
 }

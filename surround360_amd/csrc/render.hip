@@ -15,6 +15,26 @@ namespace s360 {
 // Host-built lookup tables (the host's libm is the reference's libm: tanhf / exp of NovelView.cpp:138-141
 // and CvUtil.cpp:239-246 are evaluated here for every possible 8-bit input, so the device needs no
 // transcendental for them).
+// 8-bit Gaussian of featherAlphaChannel (CvUtil.cpp:140-157): ksize = erodeSize, sigma = erodeSize / 2.0f, taps
+// round(k*256) (the fixed-point row/column filter of GaussianBlur on CV_8U)
+std::vector<int> feather_gauss_taps(int erode_size) {
+  const int n = erode_size;
+  std::vector<int> ik(std::max(n, 1));
+  std::vector<float> k(std::max(n, 1));
+  const double sigma = erode_size / 2.0f;
+  const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  const double scale2X = -0.5 / (sigmaX * sigmaX);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    k[i] = (float)std::exp(scale2X * x * x);
+    sum += k[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) ik[i] = cv_round((float)(k[i] * sum) * 256.f);
+  return ik;
+}
+
 void Tables::build(hipStream_t st, int std_feather) {
   // OpenCV initInterTab2D(INTER_CUBIC, fixpt) — see SURVEY App. A.2
   std::vector<float> tf(1024 * 16);
@@ -59,24 +79,8 @@ void Tables::build(hipStream_t st, int std_feather) {
     const double sumExp = expL + expR + 0.00001;
     fs[a] = float(expL / sumExp);
   }
-  // 8-bit Gaussian of featherAlphaChannel: ksize = erodeSize, sigma = erodeSize / 2.0f, taps round(k*256)
   gauss_ksize = std_feather;
-  std::vector<int> ik(std::max(gauss_ksize, 1));
-  {
-    const int n = gauss_ksize;
-    std::vector<float> k(n);
-    const double sigma = std_feather / 2.0f;
-    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
-    const double scale2X = -0.5 / (sigmaX * sigmaX);
-    double sum = 0;
-    for (int i = 0; i < n; ++i) {
-      const double x = i - (n - 1) * 0.5;
-      k[i] = (float)std::exp(scale2X * x * x);
-      sum += k[i];
-    }
-    sum = 1. / sum;
-    for (int i = 0; i < n; ++i) ik[i] = cv_round((float)(k[i] * sum) * 256.f);
-  }
+  const std::vector<int> ik = feather_gauss_taps(std_feather);
   bi.ensure(ti.size() * sizeof(short));
   bf.ensure(tf.size() * sizeof(float));
   this->t10.ensure(766 * sizeof(float));
@@ -384,16 +388,19 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
 }
 
 // featherAlphaChannel (CvUtil.cpp:140-157) on `rows` rows of a pano, then the x % cols extension (TRSP:399-411).
-void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano, int cols, int rows, uchar4* ext, int extW) {
+void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano, int cols, int rows, uchar4* ext, int extW, int erode_size,
+                              const int* taps) {
   FrameState& F = frame_state(c);
   hipStream_t st = c->st;
   const size_t n = (size_t)cols * rows;
   F.a8a.ensure(n);
   F.a8b.ensure(n);
-  const int e = c->P.std_alpha_feather_size;
+  const int e = erode_size >= 0 ? erode_size : c->P.std_alpha_feather_size;
+  const int ksize = erode_size >= 0 ? erode_size : F.tab.gauss_ksize;
+  const int* gik = erode_size >= 0 ? taps : F.tab.gik.as<int>();
   launch_erode_alpha(st, pano, F.a8b.as<uint8_t>(), cols, rows, e);
-  if (F.tab.gauss_ksize > 1) {
-    launch_gauss_u8(st, F.a8b.as<uint8_t>(), F.a8a.as<uint8_t>(), cols, rows, F.tab.gik.as<int>(), F.tab.gauss_ksize / 2);
+  if (ksize > 1) {
+    launch_gauss_u8(st, F.a8b.as<uint8_t>(), F.a8a.as<uint8_t>(), cols, rows, gik, ksize / 2);
     launch_extend_wrap(st, pano, F.a8a.as<uint8_t>(), cols, rows, ext, extW);
   } else {
     launch_extend_wrap(st, pano, F.a8b.as<uint8_t>(), cols, rows, ext, extW);

@@ -60,7 +60,10 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev);
 void frame_cubemap(s360_ctx* c, int face_w, int face_h, bool video, int* ow, int* oh);
 
 // operator-level helpers on device buffers
-void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano_top_rows, int cols, int rows, uchar4* ext, int extW);
+// erode_size < 0: the context's std_alpha_feather_size and its cached Gaussian taps; otherwise `taps` (device, erode_size ints)
+void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano_top_rows, int cols, int rows, uchar4* ext, int extW,
+                              int erode_size = -1, const int* taps = nullptr);
+std::vector<int> feather_gauss_taps(int erode_size);
 void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flow, int cols, int rows, int extW,
                         uchar4* warped_out /*cols x eqrH*/, int eqrH);
 
