@@ -369,6 +369,19 @@ def main():
             ms = 1e3 * (time.perf_counter() - t2) / n_video
             video = {"mode": "one stream; frame k regularised toward frame k-1's flows (use_prev)", "frames": n_video,
                      "ms_per_frame": ms, "frames_per_s": 1e3 / ms}
+            # the same stream with frame pipelining: the pole stage of frame k (second HIP stream) overlaps the side
+            # stage of frame k+1; the temporal chains side(k)->side(k+1) and pole(k)->pole(k+1) are kept
+            ctx.set_frame_pipelining(True)
+            ctx.render(True)
+            sync()
+            n_pipe = 6
+            t3 = time.perf_counter()
+            for _ in range(n_pipe):
+                ctx.render(True)
+            sync()
+            ms = 1e3 * (time.perf_counter() - t3) / n_pipe
+            ctx.set_frame_pipelining(False)
+            video["pipelined"] = {"frames": n_pipe, "ms_per_frame": ms, "frames_per_s": 1e3 / ms}
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         bail("single-frame phase failed: %r" % (e,))
     watchdog.cancel()

@@ -232,6 +232,13 @@ int s360_debug_flow_levels(s360_ctx* ctx, const char* alg, const uint8_t* i0_bgr
  * spends ~4x fewer instructions per pixel and is the right choice when several frames / contexts are in flight on
  * the GPU. Results are bit-identical. */
 int s360_set_sweep_mode(s360_ctx* ctx, const char* mode);
+/* Frame pipelining for ONE video stream (BASELINE configs[4]: "temporal-flow reuse and frame pipelining"). With it on,
+ * s360_frame_finish (pole units, composite: TRSP:811-960) is enqueued on a second HIP stream and overlaps the side
+ * stage (s360_frame_render_pairs: projection, flows, novel views, TRSP:320-384) of the NEXT frame; the three buffers
+ * the two stages share are ordered by events inside the library. Results are unchanged. Calls that return data
+ * (download, get_*, cubemap) and s360_synchronize wait for both streams. Not meant for the sharded (multi-GPU) frame,
+ * whose strip gather runs on s360_stream(). */
+int s360_set_frame_pipelining(s360_ctx* ctx, int on);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Per-kernel-family device time of the last frame/flow call measured with HIP events on the context

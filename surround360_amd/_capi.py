@@ -54,7 +54,7 @@ SYMBOLS = [
     "s360_feather_alpha_channel", "s360_pole_to_side_flow", "s360_sharpen", "s360_frame_upload_side",
     "s360_frame_upload_top", "s360_frame_upload_bottom", "s360_frame_upload_pole_removal", "s360_frame_set_prev_pole_removal", "s360_frame_render", "s360_frame_render_pairs",
     "s360_frame_set_prev_side", "s360_frame_set_prev_pole", "s360_frame_strip_ptr", "s360_frame_finish", "s360_frame_download_equirect", "s360_frame_equirect_dev",
-    "s360_frame_cubemap", "s360_frame_get_u8", "s360_frame_get_f32", "s360_set_keep_intermediates", "s360_set_sweep_mode", "s360_debug_flow_levels",
+    "s360_frame_cubemap", "s360_frame_get_u8", "s360_frame_get_f32", "s360_set_keep_intermediates", "s360_set_sweep_mode", "s360_set_frame_pipelining", "s360_debug_flow_levels",
     "s360_profile_enable", "s360_profile_get", "s360_save_flow_to_file", "s360_read_flow_from_file",
 ]
 

@@ -43,6 +43,7 @@ static void check_sweep_error(s360_ctx* c) {
   if (e) throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
 }
 static void d2h(s360_ctx* c, void* h, const void* d, size_t n) {
+  if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));  // frame pipelining: the data may come from the finish stream
   S360_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->st));
   S360_HIP(hipStreamSynchronize(c->st));
   check_sweep_error(c);
@@ -179,10 +180,18 @@ void s360_destroy(s360_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
+  if (c->st2) (void)hipStreamSynchronize(c->st2);
   c->frame.reset();
   c->flow.reset();
   c->flow_pole.reset();
+  c->flow_pr.reset();
   if (c->st) (void)hipStreamDestroy(c->st);
+  if (c->st2) {
+    (void)hipStreamDestroy(c->st2);
+    (void)hipEventDestroy(c->evSideDone);
+    (void)hipEventDestroy(c->evStripsFree);
+    (void)hipEventDestroy(c->evPoleSrcFree);
+  }
   delete c;
 }
 int s360_get_geometry(const s360_ctx* c, s360_geometry* out) {
@@ -192,7 +201,28 @@ int s360_get_geometry(const s360_ctx* c, s360_geometry* out) {
 }
 void* s360_stream(s360_ctx* c) { return c ? (void*)c->st : nullptr; }
 int s360_synchronize(s360_ctx* c) {
-  return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); check_sweep_error(c); });
+  return guard(c, [&] {
+    need(c, "null ctx");
+    S360_HIP(hipStreamSynchronize(c->st));
+    if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));
+    check_sweep_error(c);
+  });
+}
+int s360_set_frame_pipelining(s360_ctx* c, int on) {
+  return guard(c, [&] {
+    need(c, "null ctx");
+    c->make_current();
+    S360_HIP(hipStreamSynchronize(c->st));
+    if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));
+    if (on && !c->st2) {
+      S360_HIP(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+      S360_HIP(hipEventCreateWithFlags(&c->evSideDone, hipEventDisableTiming));
+      S360_HIP(hipEventCreateWithFlags(&c->evStripsFree, hipEventDisableTiming));
+      S360_HIP(hipEventCreateWithFlags(&c->evPoleSrcFree, hipEventDisableTiming));
+    }
+    c->pipeline = on != 0;
+    c->haveStripsFree = c->havePoleSrcFree = false;
+  });
 }
 int s360_set_keep_intermediates(s360_ctx* c, int on) {
   return guard(c, [&] { need(c, "null ctx"); frame_state(c).keep_intermediates = on != 0; });

@@ -15,6 +15,13 @@ struct FrameState;  // render.hip
 struct s360_ctx {
   int device = 0;
   hipStream_t st = nullptr;
+  // Frame pipelining (s360_set_frame_pipelining): the pole stage / composite (frame_finish) runs on st2 so that it
+  // overlaps the side stage (frame_render_pairs) of the NEXT frame of a video stream. The two stages share three
+  // things, each guarded by an event: the strips, the pole source images, and the order side(k) -> finish(k).
+  hipStream_t st2 = nullptr;
+  bool pipeline = false;
+  hipEvent_t evSideDone = nullptr, evStripsFree = nullptr, evPoleSrcFree = nullptr;
+  bool haveStripsFree = false, havePoleSrcFree = false;
   s360::Rig rig;
   s360_params P;
   s360_geometry g;

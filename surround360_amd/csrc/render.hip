@@ -176,6 +176,7 @@ void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) 
   DevBuf& dst = top ? F.topSrc : F.botSrc;
   dst.ensure(n * sizeof(uchar4));
   F.staging.ensure(n * 4);
+  if (c->pipeline && c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->st, c->evPoleSrcFree, 0));
   S360_HIP(hipMemcpyAsync(F.staging.p, bgr, n * 3, hipMemcpyHostToDevice, c->st));
   launch_bgr_to_bgra(c->st, F.staging.as<uint8_t>(), 3, dst.as<uchar4>(), n);
   S360_HIP(hipStreamSynchronize(c->st));
@@ -189,6 +190,7 @@ void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_
   const size_t n = (size_t)w * h;
   F.botSrc2.ensure(n * sizeof(uchar4));
   F.staging.ensure(n * 4);
+  if (c->pipeline && c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->st, c->evPoleSrcFree, 0));
   S360_HIP(hipMemcpyAsync(F.staging.p, bottom2, n * 3, hipMemcpyHostToDevice, c->st));
   launch_bgr_to_bgra(c->st, F.staging.as<uint8_t>(), 3, F.botSrc2.as<uchar4>(), n);
   const uint8_t* masks[2] = {mask, mask2};
@@ -377,9 +379,12 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
     nv.numPairs = P; nv.numLocal = n;
     nv.camImageWidthHalf = float(camW) * 0.5f;
     nv.disp = g.verge_at_infinity_slab_displacement;
+    // pipelined video stream: the previous frame's panoramas must have been assembled from the strips
+    if (c->pipeline && c->haveStripsFree) S360_HIP(hipStreamWaitEvent(st, c->evStripsFree, 0));
     launch_novel_view(st, F.overlaps[cur].as<uchar4>(), F.sideFlows[cur].as<float2>(), F.strips.as<uchar4>(), nv, p0,
                       p1, F.tab.dev);
   }
+  if (c->pipeline) S360_HIP(hipEventRecord(c->evSideDone, st));
   F.side_p0 = p0;
   F.side_p1 = p1;
   F.have_prev_side = true;
@@ -422,10 +427,30 @@ void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flo
   launch_pole_finish(c->st, F.warpedExt.as<uchar4>(), warped_out, eqrH, pw);
 }
 
+namespace {
+// Frame pipelining: everything frame_finish enqueues (its helpers read c->st) goes to the second stream.
+struct FinishStream {
+  s360_ctx* c;
+  hipStream_t saved, savedProf;
+  explicit FinishStream(s360_ctx* c_) : c(c_), saved(c_->st), savedProf(c_->prof.st) {
+    if (c->pipeline) {
+      c->st = c->st2;
+      c->prof.st = c->st2;
+      S360_HIP(hipStreamWaitEvent(c->st2, c->evSideDone, 0));  // the side stage of THIS frame
+    }
+  }
+  ~FinishStream() {
+    c->st = saved;
+    c->prof.st = savedProf;
+  }
+};
+}  // namespace
+
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
   FrameState& F = frame_state(c);
   const s360_geometry& g = c->g;
   Profiler& prof = c->prof;
+  FinishStream finishStream(c);
   hipStream_t st = c->st;
   const int P = F.P, W = c->P.eqr_width, H = c->P.eqr_height, camH = g.cam_image_height, stripW = W / P;
   const size_t en = (size_t)W * H;
@@ -439,6 +464,10 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
     launch_assemble_pano(st, F.strips.as<uchar4>(), P, camH, stripW, sh, F.pano[0].as<uchar4>(), W, H);
     launch_assemble_pano(st, F.strips.as<uchar4>() + (size_t)P * camH * stripW, P, camH, stripW, -sh,
                          F.pano[1].as<uchar4>(), W, H);
+    if (c->pipeline) {  // the next frame's novel views may overwrite the strips from here on
+      S360_HIP(hipEventRecord(c->evStripsFree, st));
+      c->haveStripsFree = true;
+    }
   }
   if (F.keep_intermediates)
     for (int e = 0; e < 2; ++e) {
@@ -482,6 +511,10 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
                                   F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         }
         launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xn, extW);
+      }
+      if (c->pipeline) {  // the next frame's pole images may be uploaded from here on
+        S360_HIP(hipEventRecord(c->evPoleSrcFree, st));
+        c->havePoleSrcFree = true;
       }
     }
     {

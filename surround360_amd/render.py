@@ -260,6 +260,10 @@ class Context:
         """'latency' (default) or 'throughput' — which sweep kernel PixFlow uses (bit-identical results)."""
         self._ck(lib().s360_set_sweep_mode(self.h, mode.encode()))
 
+    def set_frame_pipelining(self, on=True):
+        """One video stream: overlap the pole stage of frame k with the side stage of frame k+1 (same results)."""
+        self._ck(lib().s360_set_frame_pipelining(self.h, 1 if on else 0))
+
     def cubemap(self, face_width, face_height, fmt="video"):
         """Stereo cubemap of the last rendered frame (TestRenderStereoPanorama.cpp:917-935), BGR."""
         whc = (C.c_int * 3)()

@@ -199,3 +199,24 @@ def test_pole_removal_two_frames(tmp_path, rig_json, oracle, s360lib):
         assert np.abs(ctx.get_f32("flow_bottom_secondary")).max() > 0.5
     finally:
         ctx.close()
+
+
+def test_frame_pipelining_equals_sequential(setup, oracle):
+    """s360_set_frame_pipelining: three frames of a video stream (different inputs, temporal regularisation) enqueued
+    back to back with the pole stage on the second stream must give the bytes of the one-stream sequence."""
+    frames = [rigutil.frame_inputs(setup["path"], CAM, yaw_deg=0.4 * k) for k in range(3)]  # the world turns slowly
+    rig = R.RigDescription(setup["path"])
+    outs = []
+    for pipelined in (False, True):
+        ctx = R.Context(rig, R.make_params(**setup["flags"]))
+        ctx.set_frame_pipelining(pipelined)
+        for k, (side, top, bottom) in enumerate(frames):
+            ctx.upload_frame(side, top, bottom)
+            ctx.render(use_prev=k > 0)  # no synchronisation between the frames
+        last = ctx.download_equirect()
+        flows = [ctx.get_f32("flow_pole", u) for u in range(4)] + [ctx.get_f32("flow_l_to_r", 3)]
+        outs.append((last, flows))
+        ctx.close()
+    _cmp("pipelined equirect", outs[1][0], outs[0][0])
+    for a, b in zip(outs[1][1], outs[0][1]):
+        _cmp("pipelined temporal flow", a, b)
