@@ -132,11 +132,11 @@ def main():
         if F > 1:
             c.set_sweep_mode("throughput")  # several frames in flight: the kernel with the fewest instructions per pixel
 
-    def sync():
+    def sync(barrier=True):
         for c in ctxs:
             c.synchronize()
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None and barrier:
             dist.barrier()
 
     # ---- timed region: every rank renders K whole frames, up to F in flight (independent frames: no collective) ----
@@ -159,37 +159,39 @@ def main():
         futures.append(pools[k].submit(enqueue, k))
         counter[0] += 1
 
-    def drain():
+    def drain(barrier=True):
         for f in futures:
             f.result()
         del futures[:]
-        sync()
+        sync(barrier)
 
     # Untimed set-up before the W warm-up steps: every context renders once (allocations, cached maps), then — only
     # if launches are being held up — frames are rendered until the host-side enqueue time per frame is back to a
-    # small multiple of the uncontended one. Observed on shared boxes: for some tens of seconds after another GPU
+    # small multiple of the uncontended one. Observed on shared boxes: for the first seconds after another GPU
     # process has exited, enqueueing a frame takes ~8x longer (300 ms instead of 39 ms summed over the threads) and
     # the GPU starves. Bounded at 60 s; not part of the warm-up or of the timed steps.
     settle = {"batches": 0, "seconds": 0.0}
     if F > 1:
+        # (rank-local synchronisation inside this block: the ranks may need different numbers of settle batches)
         for _ in range(F):
             step()
-        drain()
+        drain(barrier=False)
         t = time.perf_counter()
         ctxs[0].render(False)
         base_enqueue = time.perf_counter() - t  # one thread, idle GPU queues
-        sync()
+        sync(barrier=False)
         t_settle = time.perf_counter()
         while time.perf_counter() - t_settle < 60.0:
             for k in range(F):
                 enqueue_s[k] = 0.0
             for _ in range(F):
                 step()
-            drain()
+            drain(barrier=False)
             settle["batches"] += 1
             if sum(enqueue_s) / F < 6.0 * base_enqueue:
                 break
         settle["seconds"] = time.perf_counter() - t_settle
+        sync()  # all ranks settled
     for _ in range(args.warmup):
         step()
     drain()
