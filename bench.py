@@ -112,12 +112,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    # Debugging aids for a box with fewer GPUs than ranks (NOT a bench configuration): S360_BENCH_BACKEND=gloo and
+    # S360_BENCH_DEVICE=0 run the multi-process control flow with every rank on one device.
+    backend = os.environ.get("S360_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("S360_BENCH_DEVICE", local_rank))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks timing tensors live
 
     flags = dict(FLAGS_8K) if args.size == "8k" else dict(eqr_width=2058, eqr_height=1029, enable_top=1,
                                                            enable_bottom=1, final_eqr_width=0, final_eqr_height=0)
@@ -211,7 +219,7 @@ def main():
             prof[k] = (a[0] + v[0], a[1] + v[1])
         c.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -354,7 +362,7 @@ def main():
         prof1 = ctx.profile_get()
         ctx.profile_enable(False)
         if dist is not None:
-            t = torch.tensor([dt1], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt1], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt1 = float(t.item())
         if world == 1:
