@@ -51,10 +51,10 @@ __device__ __forceinline__ float from_row_above_q(float old, float v) {
 
 }  // namespace
 
-// Steps per chunk. Everything that is not the pixel update itself happens once per chunk, with wave-uniform control:
-// the poll of the band above, the write-back of the results (through an LDS ring, so that no global store sits in
-// front of the next step's gathers — loads and stores retire in order through one counter on gfx950) and the
-// publication of the last row's granules.
+// Everything that is not the pixel update itself is amortised over several steps, with wave-uniform control: the
+// results of kQChunk steps are written back together (through an LDS ring, so that no global store sits in front of
+// the next step's gathers — loads and stores retire in order through one counter on gfx950), the band above is
+// checked every kQNeed steps and the last row's granules are published every kQPub steps.
 constexpr int kQChunk = 16;
 constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
 constexpr int kQNeed = 4;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
@@ -266,7 +266,9 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   fc.rcRows = 1.0f / c.frows;
   fc.rcEps = 1.0f / 0.001f;
   {
-    const char* e = std::getenv("S360_SWEEP_DBG");  // timing experiments only
+    // timing experiments only (results invalid when set): 1 gathers always hit, 2 no waiting on the band above,
+    // 4 no write-back of the results
+    const char* e = std::getenv("S360_SWEEP_DBG");
     fc.dbg = e ? std::atoi(e) : 0;
   }
   const int nb = sweep_quad_num_bands(h);
