@@ -22,7 +22,8 @@ def test_png_codec_round_trip(tmp_path):
     src = tmp_path / "rt.cpp"
     src.write_text(SNIPPET)
     exe = str(tmp_path / "rt")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz"])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz",
+                           "-lpthread"])
     rng = np.random.default_rng(5)
     for mode, ch in (("RGB", 3), ("RGBA", 4), ("L", 1), ("P", 1)):
         a = rng.integers(0, 256, (37, 53, ch), dtype=np.uint8)
@@ -38,6 +39,44 @@ def test_png_codec_round_trip(tmp_path):
             got = np.asarray(Image.open(p_out))
             want = np.asarray(img.convert("RGBA" if want_c == 4 else "RGB"))
             assert np.array_equal(got, want), (mode, keep)
+
+
+BANDS_SNIPPET = r'''
+#include "png_io.hpp"
+int main(int argc, char** argv) {  // argv: in.png out.png threads
+  pngio::Image im = pngio::read(argv[1], true);
+  pngio::write(argv[2], im.px.data(), im.w, im.h, im.c, 1, std::atoi(argv[3]));
+  return 0;
+}
+'''
+
+
+def test_png_writer_parallel_bands(tmp_path):
+    """The writer deflates bands of ~2 MB of scanlines independently (sync-flushed raw deflate streams concatenated
+    into one zlib stream, Adler-32 combined): images of several bands, a ragged last band, 1 / 3 / many threads must
+    all decode (PIL = libpng/zlib, and our own reader) to the source pixels."""
+    src = tmp_path / "bands.cpp"
+    src.write_text(BANDS_SNIPPET)
+    exe = str(tmp_path / "bands")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz",
+                           "-lpthread"])
+    rng = np.random.default_rng(9)
+    for (h, w, ch) in ((1500, 1601, 3), (1111, 1203, 4), (3, 5, 3)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = ((np.sin(xx * 0.013)[..., None] * np.cos(yy * 0.007)[..., None] * 90 + 128) +
+             rng.integers(-9, 10, (h, w, ch))).clip(0, 255).astype(np.uint8)
+        p_in = str(tmp_path / ("big_%d.png" % ch))
+        Image.fromarray(a, "RGB" if ch == 3 else "RGBA").save(p_in)
+        outs = []
+        for threads in ("1", "3", "0"):
+            p_out = str(tmp_path / ("big_%d_%s.png" % (ch, threads)))
+            subprocess.check_call([exe, p_in, p_out, threads])
+            got = np.asarray(Image.open(p_out))
+            assert np.array_equal(got, a), (h, w, ch, threads)
+            outs.append(open(p_out, "rb").read())
+            subprocess.check_call([exe, p_out, str(tmp_path / "again.png"), "1"])  # our reader accepts its own output
+            assert np.array_equal(np.asarray(Image.open(str(tmp_path / "again.png"))), a)
+        assert outs[0] == outs[1] == outs[2]  # the file does not depend on the number of threads
 
 
 def test_required_flags_and_unknown_flags():
