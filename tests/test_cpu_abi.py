@@ -127,3 +127,13 @@ def test_flow_file_round_trip(s360lib, tmp_path):
                                             C.c_size_t(out.size)) == 0
     assert (w.value, h.value) == (53, 37) and np.array_equal(out, f)
     assert s360lib.s360_read_flow_from_file(b"/nonexistent/x.bin", None, C.byref(w), C.byref(h), C.c_size_t(0)) < 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/s360.h must compile as C99 and as C++11 on its own (no torch / HIP types)."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "s360.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)  # comments may mention where pointers come from
+    assert "torch" not in code and "hip/" not in code and "hipStream" not in code and "#include <std" in code
