@@ -7,9 +7,13 @@
 // PARITY UNPINNED: OpenCV (pinned by the reference at git f109c01, WITH_IPP=OFF,
 // surround360_render/README.md:144-153) is not available in this environment and
 // the reference ships no golden vectors for this path. Each
-// primitive below restates the published OpenCV algorithm (scalar, non-SIMD
-// code path) as specified in SURVEY.md Appendix A; where OpenCV's behaviour is
-// ambiguous, THIS FILE IS THE DEFINITION the HIP kernels are tested against.
+// primitive below restates the published OpenCV 3.1 algorithm as the reference's
+// x86-64 build executes it: SSE2 is part of the x86-64 baseline, so where OpenCV's
+// SSE2 code path rounds differently from its scalar tail loop (8-bit cubic resize,
+// 8-bit Gaussian column pass) BOTH are restated, each on the elements it covers.
+// DESIGN.md §2 lists, per primitive, what is restated and how sure that is; where
+// OpenCV's behaviour is ambiguous, THIS FILE IS THE DEFINITION the HIP kernels are
+// tested against.
 //
 // Build with -ffp-contract=off: the reference's x86 build has no FMA
 // (surround360_render/CMakeLists.txt:33-35), and float op order matters.
@@ -98,8 +102,9 @@ static inline double resizeScale(int srcN, int dstN) {
 
 // ---------------------------------------------------------------------------
 // resize INTER_CUBIC, 8-bit, any channel count (fixed point):
-// short weights = saturate(round(w*2048)); H pass -> int32; V pass ->
-// (sum + (1<<21)) >> 22, saturate. Taps clamped (replicate).
+// short weights = saturate(round(w*2048)); H pass -> int32 (HResizeCubic, no SIMD);
+// V pass: float arithmetic on the SSE2-covered elements, (sum + (1<<21)) >> 22 on the
+// scalar tail (see below), saturate. Taps clamped (replicate).
 // Used by PixFlow entry downscale (PixFlow.h:98-107) and the final equirect
 // resize (TestRenderStereoPanorama.cpp:938-957).
 static inline ImgU8 resizeCubicU8(const ImgU8& src, int dw, int dh) {
@@ -143,7 +148,21 @@ static inline ImgU8 resizeCubicU8(const ImgU8& src, int dw, int dh) {
     const int* S2 = hbuf.data() + size_t(clipIdx(sy + 1, 0, sh)) * dw * cn;
     const int* S3 = hbuf.data() + size_t(clipIdx(sy + 2, 0, sh)) * dw * cn;
     uint8_t* D = dst.row(dy);
-    for (int x = 0; x < dw * cn; ++x) {
+    // VResizeCubicVec_32s8u (the SSE2 path, taken for whole groups of 8 elements of the row): the taps become
+    // floats b*2^-22, the int32 row sums are converted to float, multiplied and added left to right in float,
+    // and the sum is converted back with cvtps2dq (round-half-even) and saturated.
+    const int wc = dw * cn, vecEnd = (wc / 8) * 8;
+    const float scale = 1.f / (2048 * 2048);
+    const float fb0 = b[0] * scale, fb1 = b[1] * scale, fb2 = b[2] * scale, fb3 = b[3] * scale;
+    for (int x = 0; x < vecEnd; ++x) {
+      float s = (float)S0[x] * fb0;
+      s = s + (float)S1[x] * fb1;
+      s = s + (float)S2[x] * fb2;
+      s = s + (float)S3[x] * fb3;
+      D[x] = satU8(cvRoundF(s));
+    }
+    // scalar tail: FixedPtCast<int, uchar, 22>
+    for (int x = vecEnd; x < wc; ++x) {
       int v = S0[x] * b[0] + S1[x] * b[1] + S2[x] * b[2] + S3[x] * b[3];
       D[x] = satU8((v + (1 << 21)) >> 22);
     }
@@ -428,10 +447,14 @@ static inline ImgF remapCubicF32(const ImgF& src, const ImgF& map) {
 }
 
 // ---------------------------------------------------------------------------
-// GaussianBlur. Kernel: exp in double, stored float,
-// normalised by the (double) sum of the float taps. BORDER_REFLECT_101,
-// row pass then column pass, symmetric evaluation order
-//   k[c]*x[c] + sum_j k[c+j]*(x[c+j] + x[c-j]).
+// GaussianBlur on CV_32F. Kernel: exp in double, stored float, normalised by the (double) sum
+// of the float taps (getGaussianKernel). BORDER_REFLECT_101, row pass then column pass (sepFilter2D).
+//  * row pass, ksize <= 5: SymmRowSmallFilter — k[c]*x[c] + k[c+1]*(x[c+1] + x[c-1]) (+ k[c+2]*(x[c+2] + x[c-2]));
+//  * row pass, ksize  > 5: the generic RowFilter<float,float,RowVec_32f> — taps accumulated LEFT TO RIGHT,
+//    s = k[0]*x[0]; s += k[1]*x[1]; ...; the SSE2 loop (whole groups of 8 elements of the row) starts from +0
+//    instead (only the sign of an all-minus-zero sum can differ);
+//  * column pass: SymmColumnFilter / SymmColumnSmallFilter — k[c]*x[c] + delta (delta = +0), then
+//    += k[c+j]*(x[c+j] + x[c-j]).
 static inline std::vector<float> gaussianKernel(int n, double sigma) {
   std::vector<float> k(n);
   const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
@@ -461,20 +484,27 @@ static inline ImgF gaussianBlurF32(const ImgF& src, int ksize, double sigma) {
   ImgF tmp(w, h, cn), dst(w, h, cn);
   std::vector<int> xi(w + 2 * r);
   for (int i = 0; i < w + 2 * r; ++i) xi[i] = reflect101(i - r, w);
+  const int vecEnd = ((w * cn) / 8) * 8;
   for (int y = 0; y < h; ++y) {
     const float* S = src.row(y);
     float* D = tmp.row(y);
     for (int x = 0; x < w; ++x)
       for (int k = 0; k < cn; ++k) {
-        float s = kc[0] * S[xi[x + r] * cn + k];
-        for (int j = 1; j <= r; ++j) s += kc[j] * (S[xi[x + r + j] * cn + k] + S[xi[x + r - j] * cn + k]);
+        float s;
+        if (ksize <= 5) {
+          s = kc[0] * S[xi[x + r] * cn + k];
+          for (int j = 1; j <= r; ++j) s += kc[j] * (S[xi[x + r + j] * cn + k] + S[xi[x + r - j] * cn + k]);
+        } else {
+          s = (x * cn + k < vecEnd) ? 0.0f : -0.0f;  // (-0) + p == p for every p
+          for (int j = 0; j < ksize; ++j) s += kern[j] * S[xi[x + j] * cn + k];
+        }
         D[x * cn + k] = s;
       }
   }
   for (int y = 0; y < h; ++y) {
     float* D = dst.row(y);
     const float* Sc = tmp.row(y);
-    for (int x = 0; x < w * cn; ++x) D[x] = kc[0] * Sc[x];
+    for (int x = 0; x < w * cn; ++x) D[x] = kc[0] * Sc[x] + 0.0f;
     for (int j = 1; j <= r; ++j) {
       const float* Sp = tmp.row(reflect101(y + j, h));
       const float* Sm = tmp.row(reflect101(y - j, h));
@@ -484,14 +514,21 @@ static inline ImgF gaussianBlurF32(const ImgF& src, int ksize, double sigma) {
   return dst;
 }
 
-// 8-bit GaussianBlur on a single-channel image (alpha feather, CvUtil.cpp:152).
-// Fixed point: taps = round(k*256) per pass, final (sum + (1<<15)) >> 16.
+// 8-bit GaussianBlur on a single-channel image (alpha feather, CvUtil.cpp:152). createSeparableLinearFilter's
+// fixed-point branch: taps = round(k*256) per pass, int32 row pass (RowVec_8u32s, exact). Column pass:
+//  * SymmColumnVec_32s8u (the SSE2 path, whole groups of 4 columns): taps as floats ik*2^-16, the int32 row sums
+//    (pairs added as integers first) converted to float, accumulated centre first then outwards in float, converted
+//    back with cvtps2dq (round-half-even) and saturated;
+//  * scalar tail (the last w % 4 columns): FixedPtCastEx — (sum + (1<<15)) >> 16.
+// The two differ only on exact .5 ties (and when a float partial sum needs more than 24 bits).
 static inline ImgU8 gaussianBlurU8C1(const ImgU8& src, int ksize, double sigma) {
   assert(src.c == 1);
   const std::vector<float> kern = gaussianKernel(ksize, sigma);
   std::vector<int> ik(ksize);
   for (int i = 0; i < ksize; ++i) ik[i] = cvRoundF(kern[i] * 256.f);
   const int r = ksize / 2, w = src.w, h = src.h;
+  std::vector<float> fk(r + 1);
+  for (int j = 0; j <= r; ++j) fk[j] = (float)ik[r + j] * (float)(1. / 65536);
   std::vector<int> tmp(size_t(w) * h);
   for (int y = 0; y < h; ++y) {
     const uint8_t* S = src.row(y);
@@ -502,13 +539,21 @@ static inline ImgU8 gaussianBlurU8C1(const ImgU8& src, int ksize, double sigma) 
     }
   }
   ImgU8 dst(w, h, 1);
-  for (int y = 0; y < h; ++y)
-    for (int x = 0; x < w; ++x) {
+  const int vecEnd = (w / 4) * 4;
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < vecEnd; ++x) {
+      float s = (float)tmp[size_t(y) * w + x] * fk[0] + 0.0f;
+      for (int j = 1; j <= r; ++j)
+        s = s + (float)(tmp[size_t(reflect101(y + j, h)) * w + x] + tmp[size_t(reflect101(y - j, h)) * w + x]) * fk[j];
+      dst.at(y, x) = satU8(cvRoundF(s));
+    }
+    for (int x = vecEnd; x < w; ++x) {
       int s = ik[r] * tmp[size_t(y) * w + x];
       for (int j = 1; j <= r; ++j)
         s += ik[r + j] * (tmp[size_t(reflect101(y + j, h)) * w + x] + tmp[size_t(reflect101(y - j, h)) * w + x]);
       dst.at(y, x) = satU8((s + (1 << 15)) >> 16);
     }
+  }
   return dst;
 }
 

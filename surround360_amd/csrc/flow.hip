@@ -78,20 +78,13 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
   G_.ensure(N * n0 * sizeof(float2));
   flowA_.ensure(B * n0 * sizeof(float2));
   flowB_.ensure(B * n0 * sizeof(float2));
-  blurred_.ensure(B * n0 * sizeof(float2));
   full_.ensure((size_t)B * w * h * sizeof(float2));
-  if (sweep_mode_ < 0) {
-    const char* e = std::getenv("S360_SWEEP");  // debugging/A-B knob: "diag" = v1 kernel, "hex" = v2 hex16 kernel
-    sweep_mode_ = (e && std::string(e) == "diag") ? 0 : (e && std::string(e) == "hex") ? 1 : (e && std::string(e) == "quad") ? 3 : (e && std::string(e) == "tile") ? 4 : 2;
-    sweep_env_forced_ = e != nullptr;
-    const char* n = std::getenv("S360_SWEEP_NW");
-    sweep_nw_ = (n && std::atoi(n) == 8) ? 8 : 4;
-    const char* d = std::getenv("S360_SWEEP_DIV");  // "ieee" disables the verified fast division / sqrt
+  if (sweep_fast_ < 0) {
+    const char* d = std::getenv("S360_SWEEP_DIV");  // "ieee": IEEE division / sqrt expansions instead of the verified fast ones (same bits)
     sweep_fast_ = !(d && std::string(d) == "ieee");
   }
-  if (!sweep_env_forced_ && requested_mode_ >= 0) sweep_mode_ = requested_mode_;
   bool fastOk = false;
-  if (sweep_mode_ >= 2 && sweep_fast_) {
+  if (sweep_fast_) {
     std::vector<float> divs;
     divs.push_back(0.001f);
     for (int l = 0; l < L; ++l) {
@@ -100,18 +93,21 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     }
     fastOk = sweep_verify_divisors(st, divs);
   }
-  if (sweep_mode_ == 4) {
-    recS_.ensure(sweep_tile_rec_bytes(dw_, dh_, B));
-    outS_.ensure(sweep_tile_out_bytes(dw_, dh_, B));
-  }
-  if (sweep_mode_ >= 1) {
-    rec_.ensure(B * n0 * sizeof(float4));
-    handoff_.ensure(std::max(std::max(sweep_handoff_bytes(dw_, dh_, B), sweep_lock_handoff_bytes(dw_, dh_, B, 4)),
-                             sweep_quad_handoff_bytes(dw_, dh_, B)));
-    if (!err_.p) {
-      err_.ensure(sizeof(unsigned));
-      S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
-    }
+  rec_.ensure(B * n0 * sizeof(float4));
+  // Band hand-off granules + ticket counters of every sweep launch of this call (2 per level): one arena, reset to
+  // all-ones ("not written") by ONE memset instead of one per launch.
+  auto handoff_bytes = [&](int l) {
+    const size_t b = sweep_mode_ == 3 ? sweep_quad_handoff_bytes(lv_.w[l], lv_.h[l], B)
+                                      : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, 4);
+    return (b + 255) & ~(size_t)255;
+  };
+  std::vector<size_t> hoff(L + 1, 0);
+  for (int l = 0; l < L; ++l) hoff[l + 1] = hoff[l] + 2 * handoff_bytes(l);
+  handoff_.ensure(hoff[L]);
+  S360_HIP(hipMemsetAsync(handoff_.p, 0xFF, hoff[L], st));
+  if (!err_.p) {
+    err_.ensure(sizeof(unsigned));
+    S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
   }
   float* pyrI = pyrI_.as<float>();
   auto LI = [&](int l) { return pyrI + (size_t)2 * N * lv_.off[l]; };
@@ -181,30 +177,18 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       }
     }
     {
-      ProfScope ps(P, "flow_blur15");
-      if (sweep_mode_ >= 1 && sweep_mode_ != 4)  // the blurred flow goes straight into the sweep records
-        launch_blur_to_records(st, cur, rec_.as<float4>(), wl, hl, nl, B, tFlow, G_.as<float2>(), LA(l), idx);
-      else
-        launch_sepblur(st, (const float*)cur, blurred_.as<float>(), wl, hl, 2, nl, B, tFlow);
+      ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweep records
+      launch_blur_to_records(st, cur, rec_.as<float4>(), wl, hl, nl, B, tFlow, G_.as<float2>(), LA(l), idx);
     }
-    static const bool skipSweep = std::getenv("S360_DEBUG_SKIP_SWEEP") != nullptr;  // timing experiments only
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
-      if (skipSweep) return;
-      if (sweep_mode_ == 4)
-        launch_sweep_tile(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), fl, recS_.p, outS_.p, handoff_.p,
-                          err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc, fastOk);
-      else if (sweep_mode_ == 3)
-        launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B, idx,
-                          dir, pc, fastOk);
-      else if (sweep_mode_ == 2)
-        launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
-                          idx, dir, pc, sweep_nw_, fastOk);
-      else if (sweep_mode_ == 1)
-        launch_sweep_band(st, rec_.as<float4>(), G_.as<float2>(), fl, handoff_.p, err_.as<unsigned>(), wl, hl, nl, B,
-                          idx, dir, pc);
+      void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
+      if (sweep_mode_ == 3)
+        launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+                          fastOk);
       else
-        launch_sweep(st, G_.as<float2>(), LA(l), blurred_.as<float2>(), fl, wl, hl, nl, B, idx, dir, pc);
+        launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+                          fastOk);
     };
     sweep(cur, +1);
     {

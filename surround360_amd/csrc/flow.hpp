@@ -43,17 +43,14 @@ class FlowEngine {
   Profiler* prof_;
   FlowLevels lv_;
   int dw_ = 0, dh_ = 0;
-  DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, blurred_, full_, prevFlowDown_, prevPyr_,
-      motionPyr_, I1eq_, rec_, handoff_, err_, recS_, outS_;
-  int sweep_mode_ = -1;  // 0: v1 diagonal kernel, 1: v2 hex16 kernel, 2: lockstep kernel (latency, default), 3: quad (throughput)
-  bool sweep_env_forced_ = false;
-  int sweep_nw_ = 4;     // compute waves per workgroup of the lockstep kernel
-  bool sweep_fast_ = true;
-  int requested_mode_ = -1;
+  DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, full_, prevFlowDown_, prevPyr_, motionPyr_, I1eq_, rec_,
+      handoff_, err_;
+  int sweep_mode_ = 2;      // 2: lockstep kernel (latency, default), 3: quad kernel (throughput)
+  int sweep_fast_ = -1;     // verified fast division / sqrt in the sweeps; S360_SWEEP_DIV=ieee selects the IEEE expansions (same bits)
 
  public:
-  // 2 = lockstep (lowest latency of one flow), 3 = quad (highest chip-wide rate); ignored when S360_SWEEP is set
-  void set_sweep_mode(int m) { requested_mode_ = m; }
+  // 2 = lockstep (lowest latency of one flow), 3 = quad (highest chip-wide rate)
+  void set_sweep_mode(int m) { sweep_mode_ = (m == 3) ? 3 : 2; }
   // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag
   unsigned take_error(hipStream_t st);
 

@@ -13,13 +13,15 @@
 #include <stdexcept>
 
 #include "devmath.hpp"
-#include "sweep_common.hpp"
 
 namespace s360 {
 
 // ------------------------------------------------------------------------------------------
 // resize INTER_CUBIC 8UC4 (PixFlow.h:98-107 entry downscale; TRSP:938-957 final resize).
-// OpenCV fixed point: short taps = round(w*2048); H pass int; V pass (sum + 2^21) >> 22.
+// OpenCV fixed point: short taps = round(w*2048); H pass int (HResizeCubic). V pass as the reference's x86-64 build
+// runs it: VResizeCubicVec_32s8u (SSE2) covers whole groups of 8 row elements = 2 BGRA pixels and works in float —
+// taps b*2^-22, float(int row sum) * tap added left to right, cvtps2dq (round-half-even), saturate; the scalar tail
+// (the last pixel of an odd-width row) is FixedPtCast: (sum + 2^21) >> 22.
 __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restrict__ src, int sw, int sh,
                                                            size_t sbs, uchar4* __restrict__ dst, int dw, int dh,
                                                            size_t dbs, double scx, double scy) {
@@ -39,23 +41,36 @@ __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restr
   cubic_coeffs(fy, cb);
 #pragma unroll
   for (int k = 0; k < 4; ++k) ay[k] = sat_s16(cv_round(cb[k] * 2048.f));
-  int vx = 0, vy = 0, vz = 0, vw = 0;
+  int hx[4], hy[4], hz[4], hw[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uchar4* S = src + (size_t)clip_idx(sy - 1 + r, sh) * sw;
-    int hx = 0, hy = 0, hz = 0, hw = 0;
+    hx[r] = hy[r] = hz[r] = hw[r] = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uchar4 p = S[clip_idx(sx - 1 + q, sw)];
-      hx += __mul24((int)p.x, ax[q]); hy += __mul24((int)p.y, ax[q]); hz += __mul24((int)p.z, ax[q]); hw += __mul24((int)p.w, ax[q]);
+      hx[r] += __mul24((int)p.x, ax[q]); hy[r] += __mul24((int)p.y, ax[q]); hz[r] += __mul24((int)p.z, ax[q]); hw[r] += __mul24((int)p.w, ax[q]);
     }
-    vx += __mul24(hx, ay[r]); vy += __mul24(hy, ay[r]); vz += __mul24(hz, ay[r]); vw += __mul24(hw, ay[r]);  // |h| < 2^20, |a| < 2^12
   }
   uchar4 o;
-  o.x = (unsigned char)sat_u8((vx + (1 << 21)) >> 22);
-  o.y = (unsigned char)sat_u8((vy + (1 << 21)) >> 22);
-  o.z = (unsigned char)sat_u8((vz + (1 << 21)) >> 22);
-  o.w = (unsigned char)sat_u8((vw + (1 << 21)) >> 22);
+  if (dx < (dw & ~1)) {  // SSE2-covered elements
+    const float scale = 1.f / (2048 * 2048);
+    const float b0 = (float)ay[0] * scale, b1 = (float)ay[1] * scale, b2 = (float)ay[2] * scale, b3 = (float)ay[3] * scale;
+    auto vf = [&](const int* hh) {
+      float s = (float)hh[0] * b0;
+      s = s + (float)hh[1] * b1;
+      s = s + (float)hh[2] * b2;
+      s = s + (float)hh[3] * b3;
+      return (unsigned char)sat_u8(cv_round(s));
+    };
+    o.x = vf(hx); o.y = vf(hy); o.z = vf(hz); o.w = vf(hw);
+  } else {
+    auto vi = [&](const int* hh) {  // |h| < 2^20, |a| < 2^12
+      const int v = __mul24(hh[0], ay[0]) + __mul24(hh[1], ay[1]) + __mul24(hh[2], ay[2]) + __mul24(hh[3], ay[3]);
+      return (unsigned char)sat_u8((v + (1 << 21)) >> 22);
+    };
+    o.x = vi(hx); o.y = vi(hy); o.z = vi(hz); o.w = vi(hw);
+  }
   dst[(size_t)dy * dw + dx] = o;
 }
 
@@ -85,9 +100,10 @@ __global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Separable symmetric Gaussian, BORDER_REFLECT_101, row pass then column pass, evaluation
-// order k[c]*x[c] + sum_j k[c+j]*(x[c+j] + x[c-j]) (GaussianBlur; PixFlow.h:137-138, 363-366,
-// 379-383, 439-443, 178-182). One LDS tile with halo per workgroup; the row-pass result is
+// Separable symmetric Gaussian on CV_32F, BORDER_REFLECT_101, row pass then column pass (GaussianBlur;
+// PixFlow.h:137-138, 363-366, 379-383, 439-443, 178-182). Evaluation order as OpenCV 3.1's filter engine has it:
+// row pass of the 3- and 5-tap kernels k[c]*x[c] + sum_j k[c+j]*(x[c+j] + x[c-j]) (SymmRowSmallFilter), row pass of
+// the 15-tap kernel left to right (generic RowFilter), column pass k[c]*x[c] + 0, then the symmetric pairs. One LDS tile with halo per workgroup; the row-pass result is
 // rounded to float in LDS exactly like the intermediate image of the two-pass reference.
 // Both passes are register-blocked: a thread produces 4 consecutive outputs along the filter axis from one
 // sliding window of 4 + 2R inputs (the wide 15x15 kernels are LDS-bandwidth bound otherwise).
@@ -108,6 +124,7 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
   __shared__ float s_mid[IH][SB_TW + 1][CN];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
+  const int vecEnd = ((w * CN) / 8) * 8;
   src += bs * (SRC == 1 ? 1 : CN) * blockIdx.z;
   for (int i = tid; i < IH * IW; i += 256) {
     const int ly = i / IW, lx = i - ly * IW;
@@ -133,9 +150,16 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
       for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_in[ly][lx0 + j][k];
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        float acc = taps.k[0] * v[o + R];
+        float acc;
+        if (R <= 2) {  // SymmRowSmallFilter: centre, then symmetric pairs
+          acc = taps.k[0] * v[o + R];
 #pragma unroll
-        for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
+          for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
+        } else {  // generic RowFilter: left to right; its SSE2 loop (whole groups of 8 row elements) starts from +0
+          acc = ((tx0 + lx0 + o) * CN + k < vecEnd) ? 0.0f : -0.0f;
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) acc += taps.k[j < R ? R - j : j - R] * v[o + j];
+        }
         s_mid[ly][lx0 + o][k] = acc;
       }
     }
@@ -154,7 +178,7 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
       for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_mid[ly0 + j][lx][k];
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        float acc = taps.k[0] * v[o + R];
+        float acc = taps.k[0] * v[o + R] + 0.0f;  // SymmColumnFilter: centre + delta (= +0), then symmetric pairs
 #pragma unroll
         for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
         outv[o][k] = acc;
@@ -335,332 +359,6 @@ __global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ s
   dst[(size_t)y * w + x] = o;
 }
 
-// ------------------------------------------------------------------------------------------
-// The propagation sweeps (PixFlow.h:388-410). errorFunction (PixFlow.h:493-534, no directional
-// term), getPixBilinear32FExtend (:457-475), proposeFlowUpdate (:415-435), errorGradient (:195-217).
-__device__ __forceinline__ float2 bilinear_g1(const float2* __restrict__ G1, int w, float x, float y,
-                                              const SweepConst& c) {
-  x = (0.0f < x) ? x : 0.0f;
-  x = (x < c.wm2) ? x : c.wm2;
-  y = (0.0f < y) ? y : 0.0f;
-  y = (y < c.hm2) ? y : c.hm2;
-  const int x0 = (int)x, y0 = (int)y;
-  const float xR = x - (float)x0, yR = y - (float)y0;
-  const float2* p = G1 + (size_t)y0 * w + x0;
-  const float2 f00 = p[0], f10 = p[1], f01 = p[w], f11 = p[w + 1];
-  float2 r;
-  {
-    const float a1 = f00.x, a2 = f10.x - f00.x, a3 = f01.x - f00.x, a4 = f00.x + f11.x - f10.x - f01.x;
-    r.x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
-  }
-  {
-    const float a1 = f00.y, a2 = f10.y - f00.y, a3 = f01.y - f00.y, a4 = f00.y + f11.y - f10.y - f01.y;
-    r.y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
-  }
-  return r;
-}
-
-__device__ __forceinline__ float error_fn(const float2* __restrict__ G1, int w, int x, int y, float2 g0, float2 bf,
-                                          float fdx, float fdy, const SweepConst& c) {
-  const float matchX = (float)x + fdx;
-  const float matchY = (float)y + fdy;
-  const float2 g1 = bilinear_g1(G1, w, matchX, matchY, c);
-  const float dfx = bf.x - fdx, dfy = bf.y - fdy;
-  const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
-  const float ex = g0.x - g1.x, ey = g0.y - g1.y;
-  float err = sqrtf(ex * ex + ey * ey) + smoothness * c.smoothnessCoef + c.vertCoef * fabsf(fdy) / c.fcols +
-              c.horizCoef * fabsf(fdx) / c.frows;
-  return err;
-}
-
-// v1: one workgroup per flow, anti-diagonal wavefront, one barrier per diagonal. The previous
-// diagonal's flow lives in LDS indexed by row, so left = diag[prev][yi], up = diag[prev][yi-1].
-// dir=+1: top-left sweep; dir=-1: bottom-right sweep expressed through mirrored virtual coordinates.
-__global__ __launch_bounds__(1024) void k_sweep_diag(const float2* __restrict__ G, const float* __restrict__ A,
-                                                     const float2* __restrict__ blurred, float2* __restrict__ flow,
-                                                     int w, int h, size_t bs, FlowIdx idx, int dir, SweepConst c) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float2* diag = reinterpret_cast<float2*>(smem_raw);  // [2][h]
-  const int b = blockIdx.x;
-  const float2* __restrict__ G0 = G + bs * idx.i0[b];
-  const float2* __restrict__ G1 = G + bs * idx.i1[b];
-  const float* __restrict__ A0 = A + bs * idx.i0[b];
-  const float* __restrict__ A1 = A + bs * idx.i1[b];
-  blurred += bs * b;
-  flow += bs * b;
-  const float kEps = 0.001f, kThr = 0.9f;
-  const int nd = w + h - 1;
-  for (int d = 0; d < nd; ++d) {
-    const int cur = d & 1, prv = cur ^ 1;
-    const int ylo = max(0, d - (w - 1)), yhi = min(h - 1, d);
-    for (int yi = ylo + (int)threadIdx.x; yi <= yhi; yi += blockDim.x) {
-      const int xi = d - yi;
-      const int x = dir > 0 ? xi : w - 1 - xi;
-      const int y = dir > 0 ? yi : h - 1 - yi;
-      const size_t idx = (size_t)y * w + x;
-      float2 f = flow[idx];
-      if (A0[idx] > kThr && A1[idx] > kThr) {
-        const float2 g0 = G0[idx], bf = blurred[idx];
-        float currErr = error_fn(G1, w, x, y, g0, bf, f.x, f.y, c);
-        if (xi > 0) {
-          const float2 p = diag[prv * h + yi];
-          const float e = error_fn(G1, w, x, y, g0, bf, p.x, p.y, c);
-          if (e < currErr) { f = p; currErr = e; }
-        }
-        if (yi > 0) {
-          const float2 p = diag[prv * h + yi - 1];
-          const float e = error_fn(G1, w, x, y, g0, bf, p.x, p.y, c);
-          if (e < currErr) { f = p; currErr = e; }
-        }
-        const float ex = error_fn(G1, w, x, y, g0, bf, f.x + kEps, f.y + 0.0f, c);
-        const float ey = error_fn(G1, w, x, y, g0, bf, f.x + 0.0f, f.y + kEps, c);
-        const float gx = (ex - currErr) / kEps, gy = (ey - currErr) / kEps;
-        f.x = f.x - c.gradStep * gx;
-        f.y = f.y - c.gradStep * gy;
-        flow[idx] = f;
-      }
-      diag[cur * h + yi] = f;
-    }
-    __syncthreads();
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Banded wavefront sweep ("hex16"): the production kernel for PixFlow.h:388-410.
-//
-// Geometry. A wave owns a band of 4 consecutive rows; each row gets 16 lanes. Row r of the band handles
-// column s - r at step s (skewed), so inside the wave the raster-order dependencies are register hand-offs:
-// left neighbour = the row's own previous result (every lane of the row holds it), up neighbour = the row
-// above's previous result (DPP row_bcast:15). Bands of one flow are separate workgroups on different CUs;
-// band k+1 receives the final flow of band k's last row through one 8-byte {fx,fy} granule per column
-// (agent-scope relaxed atomic store/load; all-ones = "not written yet" — MI355X_MICROARCH.md: the data IS
-// the flag). Bands take their (band, flow) from a ticket counter in band-major order, so a band's
-// predecessor has always started before it: no co-residency assumption. Every spin is bounded.
-//
-// Latency. One pixel update needs 5 errorFunction evaluations in 2 dependent rounds (3 proposals, then 2
-// finite-difference probes of the winner). The 16 lanes of a row evaluate all 9 possible ones at once —
-// lanes 0-2: current / left / up flow; lanes 3-8: the +eps probes of each of them — and exchange the 9
-// scalars with DPP row broadcasts; every lane then replays the reference's sequential selection. A step is
-// therefore ONE gather round + ONE evaluation deep instead of two rounds and five evaluations.
-// Per-pixel inputs that are constant during a sweep come packed as one 16-byte record
-// {I0x, I0y, blurredFlow.x, blurredFlow.y}; I0x = NaN marks "alpha0 <= 0.9 || alpha1 <= 0.9" (not updated).
-constexpr unsigned long long kHandoffEmpty = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kBandRows = 4, kPoll = 8;
-
-template <int K>
-__device__ __forceinline__ float row_get(float v) {  // value of lane K of this lane's 16-lane row
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float from_row_above(float v) {  // lane 15 of the previous row (rows 1..3)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xE, 0xF, false));
-}
-
-// LDS rings between the compute wave (wave 0) and the service wave (wave 1) of a band, indexed by step.
-// On gfx950 a wave's loads AND stores retire in order through one counter (vmcnt), so a compute wave that
-// also stored its results or polled granules would wait for L2/HBM round trips every step. The service wave
-// owns all of that traffic: it streams the per-pixel inputs in (16 steps x 4 rows per load instruction),
-// polls the up-row granules, writes results back and publishes the band's last row. The compute wave's
-// memory queue then only ever holds the bilinear gathers (L1 hits).
-constexpr int kRing = 64;  // steps (power of two)
-struct __attribute__((aligned(16))) InSlot {
-  float4 rec;
-  float2 flow;
-  float2 pad;
-};
-enum { C_IN = 0, C_UP = 1, C_DONE = 2, C_FLUSHED = 3, C_TICKET = 4, C_ABORT = 5 };
-
-__device__ __forceinline__ unsigned lds_acquire(unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_release(unsigned* p, unsigned v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__global__ __launch_bounds__(128) void k_sweep_hex(const float4* __restrict__ rec, const float2* __restrict__ G,
-                                                   float2* __restrict__ flow, unsigned long long* __restrict__ H,
-                                                   unsigned* __restrict__ ticket, int w, int h, size_t bs, FlowIdx idx,
-                                                   int dir, SweepConst c, int nb, int B,
-                                                   unsigned* __restrict__ errflag) {
-  __shared__ InSlot s_in[kRing][kBandRows];
-  __shared__ unsigned long long s_up[kRing];
-  __shared__ float2 s_out[kRing][kBandRows];
-  __shared__ unsigned s_ctr[8];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) {
-    s_ctr[C_TICKET] = atomicAdd(ticket, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
-    s_ctr[C_IN] = 0; s_ctr[C_UP] = 0; s_ctr[C_DONE] = 0; s_ctr[C_FLUSHED] = 0; s_ctr[C_ABORT] = 0;
-  }
-  __syncthreads();
-  const unsigned t = s_ctr[C_TICKET];
-  const int band = (int)(t / (unsigned)B), b = (int)(t - (unsigned)band * (unsigned)B);
-  if (band >= nb) return;
-  const float2* __restrict__ G1 = G + bs * idx.i1[b];
-  rec += bs * b;
-  flow += bs * b;
-  H += (size_t)b * nb * w;
-  const unsigned long long* Hin = H + (size_t)band * w;
-  unsigned long long* Hout = H + (size_t)(band + 1) * w;
-  const int lastRow = min(kBandRows - 1, h - 1 - band * kBandRows);
-  const int nsteps = w + lastRow;
-  auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
-
-  if (wave == 1) {
-    // ------------------------------ service wave ------------------------------
-    const int st = lane & 15, rr = lane >> 4;
-    const int yi = band * kBandRows + rr;
-    const bool rowValid = yi < h;
-    const int yic = rowValid ? yi : h - 1;
-    const int y = dir > 0 ? yic : h - 1 - yic;
-    const float4* __restrict__ recRow = rec + (size_t)y * w;
-    float2* __restrict__ flowRow = flow + (size_t)y * w;
-    const bool produceRow = (band + 1 < nb) && rr == lastRow;
-    int filled = 0, upFilled = 0, flushed = 0;
-    const int upNeed = band > 0 ? w : 0;
-    unsigned idle = 0;
-    while (flushed < nsteps) {
-      bool progress = false;
-      const int done = (int)lds_acquire(&s_ctr[C_DONE]);
-      while (flushed < done) {  // results of steps [flushed, done) -> global flow (+ granules of the last row)
-        const int n = min(16, done - flushed);
-        const int sidx = flushed + st;
-        const int xi = sidx - rr;
-        if (st < n && rowValid && xi >= 0 && xi < w) {
-          const float2 v = s_out[sidx & (kRing - 1)][rr];
-          flowRow[col(xi)] = v;
-          if (produceRow)
-            __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        flushed += n;
-        progress = true;
-      }
-      lds_release(&s_ctr[C_FLUSHED], (unsigned)flushed);
-      if (filled < nsteps && filled + 16 <= done + kRing) {  // inputs of steps [filled, filled+16)
-        const int sidx = filled + st;
-        const int x = col(sidx - rr);
-        InSlot v;
-        v.rec = recRow[x];
-        v.flow = flowRow[x];
-        v.pad = make_float2(0.f, 0.f);
-        s_in[sidx & (kRing - 1)][rr] = v;
-        filled += 16;
-        lds_release(&s_ctr[C_IN], (unsigned)filled);
-        progress = true;
-      }
-      if (upFilled < upNeed && upFilled + 16 <= done + kRing) {  // granules of columns [upFilled, upFilled+16)
-        const int xi = upFilled + lane;
-        const bool want = lane < 16 && xi < w;
-        unsigned long long v = kHandoffEmpty;
-        if (want) v = __hip_atomic_load(Hin + xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long bad = __ballot(lane < 16 && (xi >= w || v == kHandoffEmpty));
-        const int nvalid = bad ? (int)__ffsll((long long)bad) - 1 : 16;  // leading run of written granules
-        if (nvalid > 0) {
-          if (lane < nvalid) s_up[xi & (kRing - 1)] = v;
-          upFilled += nvalid;
-          lds_release(&s_ctr[C_UP], (unsigned)upFilled);
-          progress = true;
-        }
-      }
-      if (progress) {
-        idle = 0;
-      } else {
-        __builtin_amdgcn_s_sleep(1);
-        ++idle;
-        if ((idle & 1023u) == 0 &&
-            (__hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || lds_acquire(&s_ctr[C_ABORT]))) {
-          lds_release(&s_ctr[C_ABORT], 1u);
-          return;
-        }
-        if (idle > (1u << 22)) {  // seconds without progress: a neighbour band is gone (results invalid)
-          if (lane == 0) atomicExch(errflag, 1u);
-          lds_release(&s_ctr[C_ABORT], 1u);
-          return;
-        }
-      }
-    }
-    return;
-  }
-
-  // ------------------------------ compute wave ------------------------------
-  const int r = lane >> 4, k = lane & 15;
-  const int yi = band * kBandRows + r;
-  const bool rowValid = yi < h;
-  const int yic = rowValid ? yi : h - 1;
-  const int y = dir > 0 ? yic : h - 1 - yic;
-  const bool hasUp = yi > 0;
-  const float kEps = 0.001f;
-  const bool evalLane = k < 9;
-  const int ci = k < 3 ? k : (k - 3) >> 1;  // which candidate: 0 current, 1 left, 2 up
-  const float ox = (k >= 3 && k < 9 && ((k - 3) & 1) == 0) ? kEps : 0.0f;
-  const float oy = (k >= 3 && k < 9 && ((k - 3) & 1) == 1) ? kEps : 0.0f;
-  const float fy = (float)y;
-  const float kInf = __int_as_float(0x7f800000);
-  float2 fl = make_float2(0.f, 0.f);  // final flow of the previous pixel of this row (same in all 16 lanes)
-  int inAvail = 0, upAvail = band > 0 ? 0 : 0x7fffffff, flushedSeen = 0;
-  auto wait_ctr = [&](unsigned* ctr, int need) -> int {  // spin (bounded) until *ctr >= need; returns value or -1
-    unsigned spins = 0;
-    for (;;) {
-      const int v = (int)lds_acquire(ctr);
-      if (v >= need) return v;
-      __builtin_amdgcn_s_sleep(0);
-      if ((++spins & 4095u) == 0 && lds_acquire(&s_ctr[C_ABORT])) return -1;
-    }
-  };
-  for (int s = 0; s < nsteps; ++s) {
-    if (inAvail <= s) { inAvail = wait_ctr(&s_ctr[C_IN], s + 1); if (inAvail < 0) return; }
-    if (s < w && upAvail <= s) { upAvail = wait_ctr(&s_ctr[C_UP], s + 1); if (upAvail < 0) return; }
-    if (s - flushedSeen >= kRing - 2) { flushedSeen = wait_ctr(&s_ctr[C_FLUSHED], s - (kRing - 2) + 1); if (flushedSeen < 0) return; }
-    const int slot = s & (kRing - 1);
-    const InSlot in = s_in[slot][r];
-    const unsigned long long hg = s_up[slot];
-    const int xi = s - r;
-    const bool active = rowValid && xi >= 0 && xi < w;
-    // up neighbour: previous result of the row above; row 0 takes the granule of column xi == s
-    float2 up;
-    up.x = from_row_above(fl.x);
-    up.y = from_row_above(fl.y);
-    if (r == 0) { up.x = __uint_as_float((unsigned)hg); up.y = __uint_as_float((unsigned)(hg >> 32)); }
-    const float4 rc = in.rec;
-    const float2 fo = in.flow;
-    const int x = col(xi);
-    const bool upd = active && (rc.x == rc.x);
-    const float2 cand = ci == 0 ? fo : (ci == 1 ? fl : up);
-    const float ax = cand.x + ox, ay = cand.y + oy;
-    float e = kInf;
-    if (evalLane && upd) {
-      const Foot ft = footprint(w, (float)x + ax, fy + ay, c);
-      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1 + ft.off);
-      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1 + ft.off + w);
-      Texels tt;
-      tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
-      tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-      e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
-    }
-    const float e0 = row_get<0>(e);
-    float e1 = row_get<1>(e), e2 = row_get<2>(e);
-    const float e3 = row_get<3>(e), e4 = row_get<4>(e), e5 = row_get<5>(e), e6 = row_get<6>(e), e7 = row_get<7>(e),
-                e8 = row_get<8>(e);
-    if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column (PixFlow.h:392 / :405)
-    if (!hasUp) e2 = kInf;     // no up proposal in the first row (:393 / :406)
-    // proposeFlowUpdate x2 in the reference's order, then the gradient step on the winner
-    float2 f = fo;
-    float cur = e0, ex = e3, ey = e4;
-    if (e1 < cur) { f = fl; cur = e1; ex = e5; ey = e6; }
-    if (e2 < cur) { f = up; cur = e2; ex = e7; ey = e8; }
-    const float ggx = (ex - cur) / kEps, ggy = (ey - cur) / kEps;
-    float2 res;
-    res.x = f.x - c.gradStep * ggx;
-    res.y = f.y - c.gradStep * ggy;
-    if (active) {
-      if (!upd) res = fo;
-      if (k == 0) s_out[slot][r] = res;
-      fl = res;
-    }
-    if (lane == 0) lds_release(&s_ctr[C_DONE], (unsigned)(s + 1));
-  }
-}
-
 // ---- pixflow_search_20 only: adjustInitialFlow at the coarsest level (PixFlow.h:219-342) ----
 __global__ void k_search_init(const float* __restrict__ I, const float* __restrict__ A, int w, int h, size_t pbs,
                               FlowIdx idx, float2* __restrict__ flow, int hint, int dist, float* __restrict__ I1eq) {
@@ -828,47 +526,6 @@ void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev,
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B) {
   dim3 blk(64, 4);
   hipLaunchKernelGGL(k_median5_c2, grid2d(w, h, B, blk), blk, 0, st, src, dst, w, h, bs);
-}
-void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow, int w, int h,
-                  size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc) {
-  SweepConst c;
-  c.smoothnessCoef = pc.smoothnessCoef;
-  c.vertCoef = pc.verticalRegularizationCoef;
-  c.horizCoef = pc.horizontalRegularizationCoef;
-  c.gradStep = pc.gradientStepSize;
-  c.fcols = (float)w;
-  c.frows = (float)h;
-  c.wm2 = (float)w - 2.0f;
-  c.hm2 = (float)h - 2.0f;
-  const int md = w < h ? w : h;
-  int threads = ((md + 63) / 64) * 64;
-  if (threads > 1024) threads = 1024;
-  const size_t lds = (size_t)2 * h * sizeof(float2);
-  hipLaunchKernelGGL(k_sweep_diag, dim3(B), dim3(threads), lds, st, G, A, blurred, flow, w, h, bs, idx, dir, c);
-}
-int sweep_num_bands(int h) { return (h + kBandRows - 1) / kBandRows; }
-size_t sweep_handoff_bytes(int w, int h, int B) {
-  return 256 + (size_t)B * sweep_num_bands(h) * w * sizeof(unsigned long long);
-}
-void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
-                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc) {
-  SweepConst c;
-  c.smoothnessCoef = pc.smoothnessCoef;
-  c.vertCoef = pc.verticalRegularizationCoef;
-  c.horizCoef = pc.horizontalRegularizationCoef;
-  c.gradStep = pc.gradientStepSize;
-  c.fcols = (float)w;
-  c.frows = (float)h;
-  c.wm2 = (float)w - 2.0f;
-  c.hm2 = (float)h - 2.0f;
-  const int nb = sweep_num_bands(h);
-  // ticket counter (first 256 bytes) and every granule start as all-ones
-  hipMemsetAsync(handoff, 0xFF, sweep_handoff_bytes(w, h, B), st);
-  unsigned* ticket = reinterpret_cast<unsigned*>(handoff);
-  unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  hipLaunchKernelGGL(k_sweep_hex, dim3(nb * B), dim3(128), 0, st, rec, G, flow, H, ticket, w, h, bs, idx, dir, c, nb, B,
-                     errflag);
 }
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq) {

@@ -45,20 +45,12 @@ void launch_scale_f32(hipStream_t st, float* p, size_t n, float s);
 void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
                                size_t bs, int B, const FlowIdx& idx);
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
-void launch_sweep(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow, int w, int h,
-                  size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc);
-// banded "hex16" sweep (see flow_kernels.hip): records = {I0x|NaN mask, I0y, blurred.x, blurred.y}
-int sweep_num_bands(int h);
-size_t sweep_handoff_bytes(int w, int h, int B);
-void launch_sweep_band(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
-                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc);
 // lockstep banded sweep (sweep_lock.hip): nw compute waves (4 rows each) + 2 service waves per workgroup
 int sweep_lock_num_wgs(int h, int nw);
 size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw);
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, int nw, bool fast);
+                       const PixFlowConsts& pc, bool fast);
 // true when the kernel's fast exact division may be used for all of these divisors (checked on the device, cached)
 bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& divisors);
 // throughput-oriented sweep (sweep_quad.hip): one wave per workgroup, 16 rows x 4 lanes per pixel, two rounds
@@ -66,13 +58,6 @@ size_t sweep_quad_handoff_bytes(int w, int h, int B);
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast);
-// "tile" sweep (sweep_tile.hip): skewed streaming inputs/outputs + LDS window for the I1-gradient gathers
-size_t sweep_tile_rec_bytes(int w, int h, int B);
-size_t sweep_tile_out_bytes(int w, int h, int B);
-size_t sweep_tile_handoff_bytes(int w, int h, int B);
-void launch_sweep_tile(hipStream_t st, const float2* G, const float* A, const float2* blurred, float2* flow,
-                       void* recS, void* outS, void* handoff, unsigned* errflag, int w, int h, size_t bs, int B,
-                       const FlowIdx& idx, int dir, const PixFlowConsts& pc, bool fast);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

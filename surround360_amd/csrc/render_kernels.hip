@@ -600,8 +600,26 @@ __global__ __launch_bounds__(256) void k_erode_cross_fixed(const uchar4* __restr
   }
 }
 
-// GaussianBlur on CV_8U (ksize x ksize, fixed-point taps ik scaled by 256, BORDER_REFLECT_101): row pass to int,
-// column pass, (sum + 2^15) >> 16 — both inside one LDS tile, 4 outputs per thread along the filter axis.
+// GaussianBlur on CV_8U (ksize x ksize, fixed-point taps ik scaled by 256, BORDER_REFLECT_101): row pass to int32
+// (exact), column pass — both inside one LDS tile, 4 outputs per thread along the filter axis. The column pass of the
+// reference's x86-64 build is SymmColumnVec_32s8u (SSE2) on whole groups of 4 columns: float taps ik*2^-16,
+// float(centre)*k0 + 0, += float(pair sum)*kj outwards, cvtps2dq (round-half-even), saturate; the last w % 4 columns
+// take the scalar FixedPtCastEx, (sum + 2^15) >> 16. When sum(ik) <= 256 every float partial sum is an exact multiple
+// of 2^-16 below 2^8 (24 bits), so the SSE2 result is the integer sum rounded half-even; otherwise the float
+// accumulation is replayed literally.
+__device__ __forceinline__ int gauss_u8_round(int acc, bool vec) {
+  if (!vec) return sat_u8((acc + (1 << 15)) >> 16);
+  const int q = acc >> 16, rem = acc & 0xFFFF;
+  return sat_u8(q + ((rem > 0x8000 || (rem == 0x8000 && (q & 1))) ? 1 : 0));
+}
+// literal SymmColumnVec_32s8u accumulation for one output: rows[c - r .. c + r] of the int32 row pass
+template <typename RowAt, typename TapAt>
+__device__ __forceinline__ int gauss_u8_float_column(RowAt rowAt, TapAt tapAt, int r) {
+  const float sc = (float)(1. / 65536);
+  float s = (float)rowAt(0) * ((float)tapAt(0) * sc) + 0.0f;
+  for (int j = 1; j <= r; ++j) s = s + (float)(rowAt(j) + rowAt(-j)) * ((float)tapAt(j) * sc);
+  return sat_u8(cv_round(s));
+}
 constexpr int GU_TW = 64, GU_TH = 32, GU_MAXR = 16;
 __global__ __launch_bounds__(256) void k_gauss_u8_tiled(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, int w,
                                                         int h, const int* __restrict__ ik, int r) {
@@ -613,6 +631,9 @@ __global__ __launch_bounds__(256) void k_gauss_u8_tiled(const uint8_t* __restric
   const int x0 = blockIdx.x * GU_TW, y0 = blockIdx.y * GU_TH;
   const int IW = GU_TW + 2 * r, IH = GU_TH + 2 * r;
   if ((int)threadIdx.x <= 2 * r) s_k[threadIdx.x] = ik[threadIdx.x];
+  int ksum = 0;
+  for (int j = 0; j <= 2 * r; ++j) ksum += ik[j];
+  const bool exact = ksum <= 256;
   for (int ly = ty; ly < IH; ly += 4) {
     const uint8_t* row = a + (size_t)reflect101(y0 - r + ly, h) * w;
     for (int lx = tx; lx < IW; lx += GU_TW) s_a[ly][lx] = row[reflect101(x0 - r + lx, w)];
@@ -647,10 +668,15 @@ __global__ __launch_bounds__(256) void k_gauss_u8_tiled(const uint8_t* __restric
     const int gx = x0 + lx;
     if (gx >= w) continue;
     const int acc[4] = {acc0, acc1, acc2, acc3};
+    const bool vec = gx < (w & ~3);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int gy = y0 + ly0 + o;
-      if (gy < h) out[(size_t)gy * w + gx] = (uint8_t)sat_u8((acc[o] + (1 << 15)) >> 16);
+      if (gy >= h) continue;
+      int v;
+      if (exact || !vec) v = gauss_u8_round(acc[o], vec);
+      else v = gauss_u8_float_column([&](int j) { return s_row[ly0 + o + r + j][lx]; }, [&](int j) { return s_k[r + j]; }, r);
+      out[(size_t)gy * w + gx] = (uint8_t)v;
     }
   }
 }
@@ -666,6 +692,10 @@ __global__ __launch_bounds__(256) void k_gauss_u8_fixed(const uint8_t* __restric
   int k[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) k[j] = ik[j];  // uniform: scalar registers
+  int ksum = 0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) ksum += k[j];
+  const bool exact = ksum <= 256;
   for (int ly = ty; ly < IH; ly += 4) {
     const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
     for (int lx = tx; lx < IW; lx += GU_TW) s_a[ly][lx] = row[reflect101(x0 - R + lx, w)];
@@ -700,10 +730,15 @@ __global__ __launch_bounds__(256) void k_gauss_u8_fixed(const uint8_t* __restric
     }
     const int gx = x0 + lx;
     if (gx >= w) continue;
+    const bool vec = gx < (w & ~3);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int gy = y0 + ly0 + o;
-      if (gy < h) out[(size_t)gy * w + gx] = (uint8_t)sat_u8((acc[o] + (1 << 15)) >> 16);
+      if (gy >= h) continue;
+      int v;
+      if (exact || !vec) v = gauss_u8_round(acc[o], vec);
+      else v = gauss_u8_float_column([&](int j) { return s_row[ly0 + o + R + j][lx]; }, [&](int j) { return ik[R + j]; }, R);
+      out[(size_t)gy * w + gx] = (uint8_t)v;
     }
   }
 }

@@ -74,9 +74,18 @@ constexpr unsigned kTinyBits = 0x0F800000u;  // 2^-96
 
 struct SweepFast {  // reciprocals of the three divisors of the sweep, verified on the device
   float rcCols, rcRows, rcEps;
-  int dbg;  // timing experiments only (results invalid when non-zero): 1 no granule polls, 2 no publish, 4 no prefetch,
-            // 8 no bulk events, 16 no compute body
+  int dbg;  // always 0 in the product library (see S360_DBG)
 };
+// Timing experiments that invalidate the results (skip polls / publishes / gathers ...) exist only in the developer
+// tools: tools/Makefile builds the sweep sources with -DS360_TIMING_EXPERIMENTS, the product library never does, and
+// there S360_DBG() is the constant 0 — no environment variable can switch a result-changing path on.
+#ifdef S360_TIMING_EXPERIMENTS
+#define S360_DBG(fc, bits) ((fc).dbg & (bits))
+#define S360_DBG_FROM_ENV() (std::getenv("S360_SWEEP_DBG") ? std::atoi(std::getenv("S360_SWEEP_DBG")) : 0)
+#else
+#define S360_DBG(fc, bits) 0
+#define S360_DBG_FROM_ENV() 0
+#endif
 
 // errorFunction (PixFlow.h:493-534) with the verified fast divisions / square roots. Sets tinyFlag when an
 // operand falls outside their proven range (the caller then re-evaluates with the IEEE expansion).

@@ -126,7 +126,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
   if (wave < NW) {
     // ------------------------------------ compute waves ------------------------------------
     const int j = wave;
-    if (!(fc.dbg & 128)) __builtin_amdgcn_s_setprio(3);  // the update chain outranks the service waves on its SIMD
+    if (!S360_DBG(fc, 128)) __builtin_amdgcn_s_setprio(3);  // the update chain outranks the service waves on its SIMD
     const int rr = lane >> 4, k = lane & 15, bank = k >> 2, role = k & 3;
     const int yi = rows0 + j * 4 + rr;
     const bool rowValid = yi < h;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     for (int t = -1; t < T; ++t) {
       TS(0);
       const int s = t - kLag * j;
-      const bool run = s >= 0 && s < nsteps && !(fc.dbg & 16);
+      const bool run = s >= 0 && s < nsteps && !S360_DBG(fc, 16);
       const LkIn in = nin;
       const float2 upl = nup;
       const int xi = s - rr;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         xR = __builtin_amdgcn_fractf(mx);
         yR = __builtin_amdgcn_fractf(my);
         const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
-        if (!(fc.dbg & 64)) {  // (timing experiment: 64 = no gathers)
+        if (!S360_DBG(fc, 64)) {  // (timing experiment: 64 = no gathers)
           ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
           tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
         } else {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     return;
   }
 
-  if (wave >= NW && (fc.dbg & 32)) return;  // timing experiment: compute waves alone
+  if (wave >= NW && S360_DBG(fc, 32)) return;  // timing experiment: compute waves alone
   if (wave == NW) {
     // ------------------------------------ bulk service wave ------------------------------------
     // One event per compute wave every 16 steps (staggered by kLag). An event first consumes what was issued at
@@ -312,7 +312,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     auto event = [&](int j, int cc) {
       sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // previous prefetch round (long since landed)
       int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-      if (fc.dbg & 8) return;
+      if (S360_DBG(fc, 8)) return;
       const bool wr = cc + 1 < nchunks;
       if (wr) {
         // Where the pixels of chunk cc+1 will sample I1's gradients, predicted by the blurred flow and by the
@@ -328,7 +328,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       __builtin_amdgcn_sched_barrier(0);
       if (cc >= 1) flush_chunk(j, cc - 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (wr && !(fc.dbg & 4)) {
+      if (wr && !S360_DBG(fc, 4)) {
         pf0 = G1w[o0]; pf1 = G1w[o1]; pf2 = G1w[o2]; pf3 = G1w[o3];
       }
     };
@@ -363,8 +363,8 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
   // behind what the next step needs, (3) publish the finished columns of this band's last row, (4) issue the next
   // poll. Everything waited on is two steps old.
   {
-    const bool hasUpWg = wgband > 0 && !(fc.dbg & 1);
-    const bool publishes = wgband + 1 < nwg && !(fc.dbg & 2);
+    const bool hasUpWg = wgband > 0 && !S360_DBG(fc, 1);
+    const bool publishes = wgband + 1 < nwg && !S360_DBG(fc, 2);
     const unsigned long long* Hin = H + (size_t)wgband * w;
     unsigned long long* Hout = H + (size_t)(wgband + 1) * w;
     constexpr int jl = NW - 1;
@@ -502,26 +502,21 @@ static void launch_lock_t(hipStream_t st, const float4* rec, const float2* G, fl
 
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, int nw, bool fast) {
+                       const PixFlowConsts& pc, bool fast) {
+  constexpr int nw = 4;
   const SweepConst c = make_sweep_const(pc, w, h);
   SweepFast fc;
   fc.rcCols = 1.0f / c.fcols;
   fc.rcRows = 1.0f / c.frows;
   fc.rcEps = 1.0f / 0.001f;
-  const char* dbgEnv = std::getenv("S360_SWEEP_DBG");
-  fc.dbg = dbgEnv ? std::atoi(dbgEnv) : 0;
+  fc.dbg = S360_DBG_FROM_ENV();  // developer tools only
   const int nwg = sweep_lock_num_wgs(h, nw);
-  // ticket counter (first 256 bytes) and every granule start as all-ones
-  (void)hipMemsetAsync(handoff, 0xFF, sweep_lock_handoff_bytes(w, h, B, nw), st);
+  // `handoff` must be all-ones: ticket counter (first 256 bytes) and every granule start as "not written"
+  // (FlowEngine resets the hand-off arena of all its sweep launches with one memset)
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  if (nw == 4) {
-    if (fast) launch_lock_t<4, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
-    else launch_lock_t<4, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
-  } else {
-    if (fast) launch_lock_t<8, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
-    else launch_lock_t<8, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
-  }
+  if (fast) launch_lock_t<nw, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
+  else launch_lock_t<nw, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
 }
 
 }  // namespace s360

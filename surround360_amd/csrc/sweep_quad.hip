@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const int x0 = (int)mx, y0 = (int)my;
     const float xR = __builtin_amdgcn_fractf(mx), yR = __builtin_amdgcn_fractf(my);
     unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
-    if (fc.dbg & 1) boff = (unsigned)lane << 4;  // timing experiment (results invalid): gathers that always hit
+    if (S360_DBG(fc, 1)) boff = (unsigned)lane << 4;  // timing experiment (results invalid): gathers that always hit
     const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
     const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
     Texels tt;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 
   // ---- granules of the band above -> s_up ring. Wave-uniform state; columns [.., upFilled) have been taken ----
   int upFilled = hasUpBand ? 0 : 0x3fffffff;
-  bool pending = false, dead = (fc.dbg & 2) != 0;  // (dbg 2: timing experiment without the band-to-band wait)
+  bool pending = false, dead = S360_DBG(fc, 2) != 0;  // (dbg 2: timing experiment without the band-to-band wait)
   unsigned long long pv = kEmptyGranuleQ;
   auto issue = [&]() {
     const int xi = upFilled + lane;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #pragma unroll
       for (int k = 0; k < kQChunk / 4; ++k) {
         const int xi = base + 4 * k;
-        if (rowValid && xi >= 0 && xi < w && xi < send - r && !(fc.dbg & 4)) flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][xi & (kQResRing - 1)];
+        if (rowValid && xi >= 0 && xi < w && xi < send - r && !S360_DBG(fc, 4)) flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][xi & (kQResRing - 1)];
       }
     }
   }
@@ -265,14 +265,10 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   fc.rcCols = 1.0f / c.fcols;
   fc.rcRows = 1.0f / c.frows;
   fc.rcEps = 1.0f / 0.001f;
-  {
-    // timing experiments only (results invalid when set): 1 gathers always hit, 2 no waiting on the band above,
-    // 4 no write-back of the results
-    const char* e = std::getenv("S360_SWEEP_DBG");
-    fc.dbg = e ? std::atoi(e) : 0;
-  }
+  fc.dbg = S360_DBG_FROM_ENV();  // developer tools only: 1 gathers always hit, 2 no waiting on the band above, 4 no write-back
   const int nb = sweep_quad_num_bands(h);
-  (void)hipMemsetAsync(handoff, 0xFF, sweep_quad_handoff_bytes(w, h, B), st);
+  // `handoff` must be all-ones (ticket counter in the first 256 bytes, then the granules): FlowEngine resets the
+  // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
   if (fast)

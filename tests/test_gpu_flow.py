@@ -108,19 +108,3 @@ def test_ieee_division_path_bit_exact(gpu_rig, oracle, monkeypatch):
         assert np.array_equal(bits(got), bits(want))
     finally:
         c.close()
-
-
-def test_tile_sweep_bit_exact(gpu_rig, oracle, monkeypatch):
-    """S360_SWEEP=tile: the experimental sweep with skewed streaming inputs/outputs and an LDS window for the
-    I1-gradient gathers (sweep_tile.hip), including flows that leave the window (global-gather fallback)."""
-    monkeypatch.setenv("S360_SWEEP", "tile")
-    c = R.Context(gpu_rig, R.make_params(eqr_width=1008, eqr_height=504))
-    try:
-        for (w, h, seed, disp) in [(297, 444, 2, None), (333, 257, 5, None), (400, 200, 7, 90.0)]:
-            i0, i1 = synth.flow_pair(w, h, seed=seed, max_disp=disp)
-            for hint, a, b in (("LEFT", i0, i1), ("RIGHT", i1, i0)):
-                got = c.compute_optical_flow(a, b, "pixflow_low", hint)
-                want = oracle.compute_optical_flow(a, b, "pixflow_low", hint)
-                assert np.array_equal(bits(got), bits(want)), "%dx%d %s: max abs diff %g" % (w, h, hint, np.abs(got - want).max())
-    finally:
-        c.close()
