@@ -1,6 +1,6 @@
 // png_io.hpp — minimal PNG codec on zlib for the host binary (the reference uses cv::imread / cv::imwrite,
-// RigDescription.cpp:87-105, TRSP:961). Reads 8-bit grey / grey+alpha / RGB / RGBA / palette, non-interlaced;
-// writes 8-bit RGB / RGBA. Pixel order at this interface is OpenCV's: B,G,R(,A).
+// RigDescription.cpp:87-105, TRSP:961). Reads every PNG colour type and bit depth (1..16 bits, Adam7 interlace) into
+// 8-bit B,G,R(,A) like imread's 8-bit decode; writes 8-bit RGB / RGBA and fails loudly on a short write. Pixel order at this interface is OpenCV's: B,G,R(,A).
 #pragma once
 #include <zlib.h>
 
@@ -30,6 +30,9 @@ inline int paeth(int a, int b, int c) {
 }
 
 // keep_alpha == false mirrors CV_LOAD_IMAGE_COLOR (3 channels); true mirrors flag -1 (unchanged: 3 or 4 channels).
+// Every PNG the format defines is accepted, converted the way cv::imread's 8-bit decode does (grfmt_png.cpp):
+// bit depths 1/2/4 are expanded (grey scaled to 0..255, palette looked up), 16-bit samples keep their high byte
+// (png_set_strip_16), grey becomes B=G=R, Adam7-interlaced files are de-interlaced.
 inline Image read(const std::string& path, bool keep_alpha) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) throw std::runtime_error("failed to load image: " + path);
@@ -41,86 +44,139 @@ inline Image read(const std::string& path, bool keep_alpha) {
   static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
   if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw std::runtime_error("not a PNG file: " + path);
   size_t pos = 8;
-  int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+  int w = 0, h = 0, depth = 0, ctype = -1, interlace = 0;
+  bool have_ihdr = false;
   std::vector<uint8_t> idat, plte, trns;
   while (pos + 12 <= file.size()) {
     const uint32_t len = be32(&file[pos]);
     const char* type = (const char*)&file[pos + 4];
     const uint8_t* data = &file[pos + 8];
-    if (pos + 12 + len > file.size()) break;
+    if (len > file.size() || pos + 12 + len > file.size()) break;
     if (!std::memcmp(type, "IHDR", 4)) {
-      w = (int)be32(data); h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
+      if (len < 13) throw std::runtime_error("corrupt PNG header: " + path);
+      const uint32_t uw = be32(data), uh = be32(data + 4);
+      if (uw == 0 || uh == 0 || uw > 65535u || uh > 65535u) throw std::runtime_error("unsupported PNG dimensions: " + path);
+      w = (int)uw; h = (int)uh; depth = data[8]; ctype = data[9]; interlace = data[12];
+      if (data[10] != 0 || data[11] != 0 || interlace > 1) throw std::runtime_error("unsupported PNG coding: " + path);
+      have_ihdr = true;
     } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
     else if (!std::memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
     else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
     else if (!std::memcmp(type, "IEND", 4)) break;
     pos += 12 + len;
   }
-  if (w <= 0 || h <= 0 || depth != 8 || interlace != 0)
-    throw std::runtime_error("unsupported PNG (need 8-bit, non-interlaced): " + path);
-  const int sc = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-  if (!sc) throw std::runtime_error("unsupported PNG colour type: " + path);
-  const size_t stride = (size_t)w * sc;
-  std::vector<uint8_t> raw((stride + 1) * h);
-  uLongf rawlen = raw.size();
-  if (uncompress(raw.data(), &rawlen, idat.data(), idat.size()) != Z_OK || rawlen != raw.size())
+  if (!have_ihdr) throw std::runtime_error("corrupt PNG (no header): " + path);
+  const int sc = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;  // samples per pixel
+  const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                        (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                        ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+  if (!sc || !depth_ok) throw std::runtime_error("unsupported PNG colour type / bit depth: " + path);
+  const int bpp_bits = sc * depth, fbpp = std::max(1, bpp_bits / 8);  // filter distance in bytes
+  auto row_bytes = [&](int pw) { return ((size_t)pw * bpp_bits + 7) / 8; };
+  // passes: {x0, y0, dx, dy}; non-interlaced = one pass covering everything
+  static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const int whole[1][4] = {{0, 0, 1, 1}};
+  const int (*passes)[4] = interlace ? adam7 : whole;
+  const int npass = interlace ? 7 : 1;
+  size_t total = 0;
+  for (int p = 0; p < npass; ++p) {
+    const int pw = (w - passes[p][0] + passes[p][2] - 1) / passes[p][2], ph = (h - passes[p][1] + passes[p][3] - 1) / passes[p][3];
+    if (pw > 0 && ph > 0) total += (row_bytes(pw) + 1) * ph;
+  }
+  std::vector<uint8_t> raw(total);
+  uLongf rawlen = (uLongf)raw.size();
+  if (idat.empty() || uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size())
     throw std::runtime_error("corrupt PNG data: " + path);
-  std::vector<uint8_t> prev(stride, 0), cur(stride);
   const bool has_alpha = ctype == 4 || ctype == 6 || (ctype == 3 && !trns.empty());
   Image im;
   im.w = w; im.h = h; im.c = (keep_alpha && has_alpha) ? 4 : 3;
   im.px.resize((size_t)w * h * im.c);
-  for (int y = 0; y < h; ++y) {
-    const uint8_t* in = &raw[(stride + 1) * y];
-    const int ft = in[0];
-    ++in;
-    for (size_t i = 0; i < stride; ++i) {
-      const int a = i >= (size_t)sc ? cur[i - sc] : 0, b = prev[i], c = i >= (size_t)sc ? prev[i - sc] : 0;
-      int v = in[i];
-      switch (ft) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += b; break;
-        case 3: v += (a + b) >> 1; break;
-        case 4: v += paeth(a, b, c); break;
-        default: throw std::runtime_error("corrupt PNG filter: " + path);
+  const uint8_t* in = raw.data();
+  for (int p = 0; p < npass; ++p) {
+    const int x0 = passes[p][0], y0 = passes[p][1], dx = passes[p][2], dy = passes[p][3];
+    const int pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+    if (pw <= 0 || ph <= 0) continue;
+    const size_t stride = row_bytes(pw);
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    for (int py = 0; py < ph; ++py) {
+      const int ft = *in++;
+      for (size_t i = 0; i < stride; ++i) {
+        const int a = i >= (size_t)fbpp ? cur[i - fbpp] : 0, b = prev[i], c = i >= (size_t)fbpp ? prev[i - fbpp] : 0;
+        int v = in[i];
+        switch (ft) {
+          case 0: break;
+          case 1: v += a; break;
+          case 2: v += b; break;
+          case 3: v += (a + b) >> 1; break;
+          case 4: v += paeth(a, b, c); break;
+          default: throw std::runtime_error("corrupt PNG filter: " + path);
+        }
+        cur[i] = (uint8_t)v;
       }
-      cur[i] = (uint8_t)v;
-    }
-    uint8_t* o = &im.px[(size_t)y * w * im.c];
-    for (int x = 0; x < w; ++x) {
-      uint8_t r, g, b, a = 255;
-      const uint8_t* s = &cur[(size_t)x * sc];
-      if (ctype == 0) { r = g = b = s[0]; }
-      else if (ctype == 4) { r = g = b = s[0]; a = s[1]; }
-      else if (ctype == 2) { r = s[0]; g = s[1]; b = s[2]; }
-      else if (ctype == 6) { r = s[0]; g = s[1]; b = s[2]; a = s[3]; }
-      else {
-        const size_t k = s[0];
-        if (3 * k + 2 >= plte.size()) throw std::runtime_error("corrupt PNG palette: " + path);
-        r = plte[3 * k]; g = plte[3 * k + 1]; b = plte[3 * k + 2];
-        if (k < trns.size()) a = trns[k];
+      in += stride;
+      auto sample = [&](int px, int k) -> int {  // sample k of pixel px as 8 bits (16-bit: high byte; <8-bit grey: scaled)
+        if (depth == 8) return cur[(size_t)px * sc + k];
+        if (depth == 16) return cur[((size_t)px * sc + k) * 2];
+        const int bit = px * depth, v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+        return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+      };
+      uint8_t* orow = &im.px[(size_t)(y0 + py * dy) * w * im.c];
+      for (int px = 0; px < pw; ++px) {
+        uint8_t r, g, b, a = 255;
+        if (ctype == 0) { r = g = b = (uint8_t)sample(px, 0); }
+        else if (ctype == 4) { r = g = b = (uint8_t)sample(px, 0); a = (uint8_t)sample(px, 1); }
+        else if (ctype == 2) { r = (uint8_t)sample(px, 0); g = (uint8_t)sample(px, 1); b = (uint8_t)sample(px, 2); }
+        else if (ctype == 6) { r = (uint8_t)sample(px, 0); g = (uint8_t)sample(px, 1); b = (uint8_t)sample(px, 2); a = (uint8_t)sample(px, 3); }
+        else {
+          const size_t k = (size_t)sample(px, 0);
+          if (3 * k + 2 >= plte.size()) throw std::runtime_error("corrupt PNG palette: " + path);
+          r = plte[3 * k]; g = plte[3 * k + 1]; b = plte[3 * k + 2];
+          if (k < trns.size()) a = trns[k];
+        }
+        uint8_t* o = orow + (size_t)(x0 + px * dx) * im.c;
+        o[0] = b; o[1] = g; o[2] = r;
+        if (im.c == 4) o[3] = a;
       }
-      o[0] = b; o[1] = g; o[2] = r;
-      if (im.c == 4) o[3] = a;
-      o += im.c;
+      prev.swap(cur);
     }
-    prev.swap(cur);
   }
   return im;
 }
 
-inline void chunk(FILE* f, const char* type, const uint8_t* data, size_t len) {
+// Output file that remembers the first failed write: a full disk must not leave a truncated PNG behind a zero exit
+// code (the reference's imwriteExceptionOnFail aborts, CvUtil.h).
+struct OutFile {
+  FILE* f;
+  bool ok = true;
+  std::string path;
+  explicit OutFile(const std::string& p) : f(std::fopen(p.c_str(), "wb")), path(p) {
+    if (!f) throw std::runtime_error("failed to write image: " + p);
+  }
+  void put(const void* d, size_t n) {
+    if (n && std::fwrite(d, 1, n, f) != n) ok = false;
+  }
+  void close() {
+    const bool closed = std::fclose(f) == 0;
+    f = nullptr;
+    if (!ok || !closed) {
+      std::remove(path.c_str());
+      throw std::runtime_error("failed to write image (short write): " + path);
+    }
+  }
+  ~OutFile() { if (f) std::fclose(f); }
+};
+
+inline void chunk(OutFile& f, const char* type, const uint8_t* data, size_t len) {
   uint8_t hdr[8];
   put32(hdr, (uint32_t)len);
   std::memcpy(hdr + 4, type, 4);
-  std::fwrite(hdr, 1, 8, f);
-  if (len) std::fwrite(data, 1, len, f);
+  f.put(hdr, 8);
+  f.put(data, len);
   uLong crc = crc32(0L, (const Bytef*)type, 4);
   if (len) crc = crc32(crc, data, (uInt)len);
   uint8_t c[4];
   put32(c, (uint32_t)crc);
-  std::fwrite(c, 1, 4, f);
+  f.put(c, 4);
 }
 
 // px: B,G,R(,A) rows. Filter "up"/"sub" is skipped (type 0) — encode speed matters more than size here: the 8192x8192
@@ -182,10 +238,9 @@ inline void write(const std::string& path, const uint8_t* px, int w, int h, int 
   }
   for (const Band& B : bands)
     if (!B.ok) throw std::runtime_error("png write: deflate failed");
-  FILE* f = std::fopen(path.c_str(), "wb");
-  if (!f) throw std::runtime_error("failed to write image: " + path);
+  OutFile f(path);
   static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
-  std::fwrite(sig, 1, 8, f);
+  f.put(sig, 8);
   uint8_t ihdr[13];
   put32(ihdr, (uint32_t)w); put32(ihdr + 4, (uint32_t)h);
   ihdr[8] = 8; ihdr[9] = c == 3 ? 2 : 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
@@ -199,16 +254,16 @@ inline void write(const std::string& path, const uint8_t* px, int w, int h, int 
     put32(hdr, (uint32_t)B.z.size());
     std::memcpy(hdr + 4, "IDAT", 4);
     put32(crc, (uint32_t)B.crc);
-    std::fwrite(hdr, 1, 8, f);
-    std::fwrite(B.z.data(), 1, B.z.size(), f);
-    std::fwrite(crc, 1, 4, f);
+    f.put(hdr, 8);
+    f.put(B.z.data(), B.z.size());
+    f.put(crc, 4);
     adler = adler32_combine(adler, B.adler, (z_off_t)B.raw);
   }
   uint8_t tail[4];
   put32(tail, (uint32_t)adler);
   chunk(f, "IDAT", tail, 4);
   chunk(f, "IEND", nullptr, 0);
-  std::fclose(f);
+  f.close();
 }
 
 }  // namespace pngio

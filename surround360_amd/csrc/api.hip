@@ -42,6 +42,11 @@ static void check_sweep_error(s360_ctx* c) {
   if (c->flow_pr) e |= c->flow_pr->take_error(c->st);
   if (e) throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
 }
+// Frame pipelining: frame_finish runs on st2. Anything enqueued on st that READS what frame_finish writes (panoramas,
+// warped poles, extended pole images, the stacked equirect) must be ordered after it: the host waits for st2 first.
+static void wait_finish_stream(s360_ctx* c) {
+  if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));
+}
 static void d2h(s360_ctx* c, void* h, const void* d, size_t n) {
   if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));  // frame pipelining: the data may come from the finish stream
   S360_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->st));
@@ -162,6 +167,7 @@ int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams,
     c->P = *params;
     pixflow_consts_by_name(c->P.side_flow_alg);   // validate early (throws S360_ERR_UNKNOWN_ALG)
     pixflow_consts_by_name(c->P.polar_flow_alg);
+    if (c->P.enable_pole_removal && c->P.poleremoval_flow_alg[0]) pixflow_consts_by_name(c->P.poleremoval_flow_alg);
     c->g = derive_geometry(c->rig, c->P);
     const double up[3] = {0, 0, 1}, down[3] = {0, 0, -1};
     c->top_idx = c->rig.find_by_direction(up);
@@ -521,6 +527,7 @@ int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, co
     h2d(c, F.overlaps[prv].as<uchar4>() + on * (P + pair), overlap_r, on * sizeof(uchar4));
     h2d(c, F.sideFlows[prv].as<float2>() + on * pair, flow_l_to_r, on * sizeof(float2));
     h2d(c, F.sideFlows[prv].as<float2>() + on * (P + pair), flow_r_to_l, on * sizeof(float2));
+    S360_HIP(hipStreamSynchronize(c->st));  // the caller's buffers may be reused as soon as this returns
     F.side_p0 = 0;
     F.side_p1 = P;
     F.have_prev_side = true;
@@ -541,6 +548,7 @@ int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uin
     h2d(c, F.extImgs[prv].as<uchar4>() + xn * unit, ext_side, xn * sizeof(uchar4));
     h2d(c, F.extImgs[prv].as<uchar4>() + xn * (unit < 2 ? 4 : 5), ext_fisheye, xn * sizeof(uchar4));
     h2d(c, F.poleFlows[prv].as<float2>() + xn * unit, flow, xn * sizeof(float2));
+    S360_HIP(hipStreamSynchronize(c->st));  // the caller's buffers may be reused as soon as this returns
     F.extW = extW;
     F.poleRows = rows;
     F.have_prev_pole = true;
@@ -587,6 +595,7 @@ int s360_frame_cubemap(s360_ctx* c, int face_w, int face_h, const char* format, 
     whc[2] = 3;
     if (!out_bgr) return;
     int ow = 0, oh = 0;
+    wait_finish_stream(c);  // the cubemap kernel reads the composited panoramas
     frame_cubemap(c, face_w, face_h, f == "video", &ow, &oh);
     d2h(c, out_bgr, frame_state(c).cubeOut.p, (size_t)ow * oh * 3);
   });
@@ -635,6 +644,7 @@ int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_
       w = W; h = H; ch = 3;
       if (dst) {
         c->op_f.ensure((size_t)w * h * 3);
+        wait_finish_stream(c);  // the pack kernel reads the composited panorama
         launch_pack_bgr(c->st, F.pano[e].as<uchar4>(), w, h, c->op_f.as<uint8_t>());
         src = c->op_f.p;
       }

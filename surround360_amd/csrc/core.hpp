@@ -70,9 +70,12 @@ struct Profiler {
     recs.push_back(r);
     return (int)recs.size() - 1;
   }
-  void end(int h) {
-    if (h >= 0) S360_HIP(hipEventRecord(recs[h].b, st));
+  // Called from ~ProfScope (implicitly noexcept): never throws; a failed record marks the profile invalid and the
+  // error surfaces at the next checked HIP call on the stream.
+  void end(int h) noexcept {
+    if (h >= 0 && hipEventRecord(recs[h].b, st) != hipSuccess) broken = true;
   }
+  bool broken = false;
   void clear() {
     for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
     recs.clear();
@@ -81,6 +84,7 @@ struct Profiler {
   void collect(std::vector<float>& ms, std::vector<int>& cnt) {
     ms.assign(names.size(), 0.f);
     cnt.assign(names.size(), 0);
+    if (broken) { broken = false; clear(); throw Error(-3, "profiler: an event could not be recorded"); }
     if (!recs.empty()) S360_HIP(hipEventSynchronize(recs.back().b));
     for (auto& r : recs) {
       float t = 0;

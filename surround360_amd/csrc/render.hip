@@ -157,6 +157,7 @@ void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, i
   if (idx < 0 || idx >= F.P) throw Error(S360_ERR_INVALID_ARG, "side_idx out of range");
   if (ch != 3 && ch != 4) throw Error(S360_ERR_INVALID_ARG, "side image must have 3 or 4 channels");
   if (F.have_side && (w != F.srcW || h != F.srcH)) throw Error(S360_ERR_INVALID_ARG, "side image size changed");
+  if (F.P > 64) throw Error(S360_ERR_INVALID_ARG, "more than 64 side cameras");
   F.srcW = w;
   F.srcH = h;
   const size_t n = (size_t)w * h;
@@ -167,11 +168,11 @@ void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, i
                           c->P.side_alpha_feather_size);
   S360_HIP(hipStreamSynchronize(c->st));  // staging is reused by the next upload
   F.have_side = true;
+  F.side_uploaded |= 1ull << idx;
 }
 void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) {
   FrameState& F = frame_state(c);
-  F.poleW = w;
-  F.poleH = h;
+  if (top) { F.topW = w; F.topH = h; } else { F.poleW = w; F.poleH = h; }
   const size_t n = (size_t)w * h;
   DevBuf& dst = top ? F.topSrc : F.botSrc;
   dst.ensure(n * sizeof(uchar4));
@@ -308,6 +309,10 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
   const int P = F.P;
   if (!F.have_side) throw Error(S360_ERR_STATE, "side images not uploaded");
   if (p0 < 0 || p1 > P || p1 < p0) throw Error(S360_ERR_INVALID_ARG, "bad pair range");
+  for (int p = p0; p < p1; ++p)
+    if (!((F.side_uploaded >> p) & 1) || !((F.side_uploaded >> ((p + 1) % P)) & 1))
+      throw Error(S360_ERR_STATE, "side image of camera " + std::to_string(((F.side_uploaded >> p) & 1) ? (p + 1) % P : p) +
+                                      " not uploaded (needed by pair " + std::to_string(p) + ")");
   if (c->P.eqr_width % P != 0)
     throw Error(S360_ERR_INVALID_ARG, "eqr_width must be evenly divisible by the number of cameras");  // TRSP:729-738
   if (g.num_novel_views != c->P.eqr_width / P)
@@ -494,7 +499,7 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
         if (!F.have_top) throw Error(S360_ERR_STATE, "top image not uploaded");
         F.topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
         const int yfs = rowsT - 1 - c->P.std_alpha_feather_size;
-        launch_remap_cubic_u8c4(st, F.topSrc.as<uchar4>(), F.poleW, F.poleH, F.topMap.as<float2>(),
+        launch_remap_cubic_u8c4(st, F.topSrc.as<uchar4>(), F.topW, F.topH, F.topMap.as<float2>(),
                                 F.topSph.as<uchar4>(), W, rowsT, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xn, extW);
       }

@@ -23,7 +23,9 @@ void build_spherical_map(s360_ctx* c, float2* map, int dw, int dh, const s360_ca
 struct FrameState {
   Tables tab;
   int P = 0;                       // number of side cameras / pairs
-  int srcW = 0, srcH = 0, poleW = 0, poleH = 0;
+  int srcW = 0, srcH = 0;
+  int topW = 0, topH = 0, poleW = 0, poleH = 0;  // top camera image; bottom camera image (poleW/poleH: also pole removal)
+  unsigned long long side_uploaded = 0;          // bit i: side camera i has an image (cleared by nothing: images persist)
   bool have_side = false, have_top = false, have_bottom = false, maps_ready = false;
   DevBuf staging, sideSrc, topSrc, botSrc;
   DevBuf sideMaps, topMap, botMap;

@@ -41,6 +41,75 @@ def test_png_codec_round_trip(tmp_path):
             assert np.array_equal(got, want), (mode, keep)
 
 
+def test_png_reader_bit_depths_and_interlace(tmp_path):
+    """Inputs the reference's imread accepts beyond 8-bit non-interlaced: 16-bit (high byte kept), 1/2/4-bit grey and
+    palette, Adam7 interlace. Files are written by PIL (libpng) / by hand-built chunks and read back by our codec."""
+    import struct
+    import zlib
+    src = tmp_path / "rt.cpp"
+    src.write_text(SNIPPET)
+    exe = str(tmp_path / "rt")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz",
+                           "-lpthread"])
+    rng = np.random.default_rng(6)
+
+    def png(w, h, depth, ctype, rows, interlace=0, extra=b""):
+        def ch(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+        raw = b"".join(b"\0" + r for r in rows)
+        return (b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) + extra +
+                ch(b"IDAT", zlib.compress(raw)) + ch(b"IEND", b""))
+
+    def run(path):
+        out = str(path) + ".out.png"
+        dims = subprocess.check_output([exe, str(path), "0", out], text=True).split()
+        return [int(v) for v in dims], np.asarray(Image.open(out))
+
+    # 16-bit RGB: high byte is kept
+    a16 = rng.integers(0, 65536, (9, 13, 3), dtype=np.uint16)
+    p = tmp_path / "rgb16.png"
+    p.write_bytes(png(13, 9, 16, 2, [a16[y].astype(">u2").tobytes() for y in range(9)]))
+    dims, got = run(p)
+    assert dims == [13, 9, 3] and np.array_equal(got, (a16 >> 8).astype(np.uint8))
+    # 16-bit grey
+    g16 = rng.integers(0, 65536, (7, 10), dtype=np.uint16)
+    p = tmp_path / "g16.png"
+    p.write_bytes(png(10, 7, 16, 0, [g16[y].astype(">u2").tobytes() for y in range(7)]))
+    dims, got = run(p)
+    assert np.array_equal(got, np.repeat((g16 >> 8).astype(np.uint8)[..., None], 3, 2))
+    # 1/2/4-bit grey (scaled to 0..255) through PIL for the 1-bit case and by hand for 2/4
+    for depth in (1, 2, 4):
+        v = rng.integers(0, 1 << depth, (6, 11))
+        rows = []
+        for y in range(6):
+            bits = "".join(format(int(x), "0%db" % depth) for x in v[y])
+            bits += "0" * (-len(bits) % 8)
+            rows.append(int(bits, 2).to_bytes(len(bits) // 8, "big"))
+        p = tmp_path / ("g%d.png" % depth)
+        p.write_bytes(png(11, 6, depth, 0, rows))
+        dims, got = run(p)
+        want = (v * 255 // ((1 << depth) - 1)).astype(np.uint8)
+        assert np.array_equal(got, np.repeat(want[..., None], 3, 2)), depth
+        assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), got), depth  # libpng agrees
+    # Adam7-interlaced RGBA, written by hand: pass p holds the pixels (x0 + i*dx, y0 + j*dy)
+    a = rng.integers(0, 256, (11, 13, 4), dtype=np.uint8)
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    rows = []
+    for (x0, y0, dx, dy) in passes:
+        sub = a[y0::dy, x0::dx]
+        if sub.size:
+            rows += [sub[j].tobytes() for j in range(sub.shape[0])]
+    p = tmp_path / "adam7.png"
+    p.write_bytes(png(13, 11, 8, 6, rows, interlace=1))
+    assert np.array_equal(np.asarray(Image.open(p)), a)  # the hand-built file is a valid interlaced PNG
+    dims, got = run(p)
+    assert dims == [13, 11, 3] and np.array_equal(got, a[..., :3])
+    # truncated / lying headers are rejected, not trusted
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\n" + struct.pack(">I", 4) + b"IHDR" + b"\0\0\0\1" + b"\0\0\0\0")
+    assert subprocess.run([exe, str(bad), "0", str(tmp_path / "x.png")], capture_output=True).returncode != 0
+
+
 BANDS_SNIPPET = r'''
 #include "png_io.hpp"
 int main(int argc, char** argv) {  // argv: in.png out.png threads
