@@ -6,19 +6,29 @@ PixFlow flows, novel-view strips, panorama assembly, 4 pole flows + warps, compo
 8192x8192 — everything renderStereoPanorama does between decoded inputs and the stacked equirect
 (TestRenderStereoPanorama.cpp:716-972). Inputs are uploaded to HBM before the timed region.
 
-Timed region: every rank renders K independent frames of BASELINE.json configs[2] with up to `--inflight` frames
-in flight on its GPU (one context + HIP stream each; a single frame is latency-bound by PixFlow's raster-order
-sweeps and leaves most of the chip idle). Per-GPU work is fixed => "scaling": "weak"; `value` is
-the aggregate over all ranks. The same run then measures ONE frame at a time ("single_frame"): on 1 GPU that is
-configs[2] as a latency; on N GPUs it is configs[3] — the 14 side pairs sharded over the ranks, one RCCL exchange
-gathering the strips on rank 0, which runs the pole units and the composite.
+Timed region (`value`): every rank renders K independent frames of BASELINE.json configs[2] with up to `--inflight`
+frames in flight on its GPU (one context + HIP stream each, every context holds a DIFFERENT frame of the synthetic
+stream; a single frame is latency-bound by PixFlow's raster-order sweeps and leaves most of the chip idle, DESIGN.md
+§5/§7). Per-GPU work is fixed => "scaling": "weak"; `value` is the aggregate over all ranks. After the timed region
+every context's equirect is downloaded and byte-compared with the render of the same inputs by one context alone
+(`checked`).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(measured live with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle = an OpenCV-free
-port of the reference, timed on a bounded sample on the host cores; N=1 only). `video_stream` is one stream with
-temporal regularisation (frame k uses frame k-1's flows: BASELINE configs[4] on one GPU). `host` reports the
-submission side: enqueue time per frame and the untimed settle batches that precede the warm-up (see the comment at
-the settle loop).
+Then, one context alone on the GPU (nothing else in flight, so kernel durations are isolated):
+  * `roofline`: the dominant kernel of the timed region (the throughput-mode sweep) — algorithmic bytes per launch
+    (48 B per pixel-level-sweep) / its average ISOLATED launch duration from HIP events on the library's
+    stream / 8 TB/s; `aggregate_frac` is the same bytes over the wall time of the timed region (launches of up to
+    `inflight` frames overlapping);
+  * `single_frame`: configs[2] as a latency (on N GPUs: configs[3] — 14 pairs sharded over the ranks, one RCCL strip
+    gather, poles + composite on rank 0), per-kernel-family milliseconds, the warp/blend and flow-stencil kernels
+    against the HBM roofline, and the same frame with the reference presets' sharpening 0.25;
+  * `config2_flow_pair`: BASELINE configs[1], one 2048x2048 pair, both directions, GPU vs the CPU oracle;
+  * `video_stream`: configs[4] on one GPU — >= 32 DISTINCT frames of a rotating world with a moving disc, every frame
+    regularised toward its predecessor's device-resident flows, inputs fed from host memory through the upload stream
+    while the previous frame renders; with and without frame pipelining;
+  * `cpu_baseline`: the CPU oracle (an OpenCV-free port of the reference, kind "port") rendering the SAME 8K frame once
+    with the reference's thread shape (14 pair threads, then 4 pole threads), timed on the host cores (N=1 only).
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -35,7 +45,7 @@ RIG = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
 FLAGS_8K = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192,
                 final_eqr_height=8192)  # the reference's "8k" preset, batch_process_video.py:194-199
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-SWEEP_BYTES_PER_PX = 48  # sweep reads 40 B + writes 8 B per pixel-level
+SWEEP_BYTES_PER_PX = 48  # a sweep reads 40 B + writes 8 B per pixel-level
 
 
 def pyramid_levels(w, h):
@@ -52,43 +62,43 @@ def pyramid_levels(w, h):
     return out
 
 
-def sweep_algorithmic_bytes(geom, n_side_flows, n_pole_flows, eqr_w):
+def flow_px_levels(geom, eqr_w):
     side = sum(w * h for w, h in pyramid_levels(geom.overlap_image_width, geom.cam_image_height))
-    ext_w = int(np.float32(eqr_w) * np.float32(1.2))
-    pole = sum(w * h for w, h in pyramid_levels(ext_w, geom.top_rows)) if n_pole_flows else 0
-    # two sweeps (forward, backward) per level per flow
-    return 2 * SWEEP_BYTES_PER_PX * (n_side_flows * side + n_pole_flows * pole)
+    pole = sum(w * h for w, h in pyramid_levels(int(np.float32(eqr_w) * np.float32(1.2)), geom.top_rows))
+    return side, pole
 
 
-def cpu_baseline(side, top, bottom):
-    """The oracle (kind "port") with the reference's thread shape on a bounded sample: the same 17-camera
-    frame rendered at eqr 2058x1029 (2K). Converted to 8K-equivalent frames/s by the ratio of flow
-    pixel-levels (flow is >95 % of the CPU time at both sizes)."""
+def sweep_algorithmic_bytes(geom, n_side_flows, n_pole_flows, eqr_w):
+    side, pole = flow_px_levels(geom, eqr_w)
+    return 2 * SWEEP_BYTES_PER_PX * (n_side_flows * side + n_pole_flows * pole)  # forward + backward sweep per level
+
+
+def cpu_baseline_8k(side, top, bottom):
+    """The oracle (kind "port") on the bench's own 8K frame, once, with the reference's thread shape."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # test infrastructure: used here only as the timed CPU baseline
     cams, _ = O.load_rig(RIG)
-    f = O.Frame(cams, O.make_params(eqr_width=2058, eqr_height=1029, enable_top=1, enable_bottom=1,
-                                    final_eqr_width=0, final_eqr_height=0))
+    f = O.Frame(cams, O.make_params(**FLAGS_8K))
     t0 = time.time()
-    f.render(side, top, bottom, threaded=True)
-    sec_2k = time.time() - t0
-
-    def px_levels(fr, eqr_w):
-        s = sum(w * h for w, h in pyramid_levels(fr.overlap_image_width, fr.cam_image_height))
-        p = sum(w * h for w, h in pyramid_levels(int(np.float32(eqr_w) * np.float32(1.2)), fr.top_rows))
-        return 28 * s + 4 * p
-    f8 = O.Frame(cams, O.make_params(**FLAGS_8K))
-    ratio = px_levels(f8, 8400) / px_levels(f, 2058)
-    cores = os.cpu_count() or 1
-    return {"value": 1.0 / (sec_2k * ratio), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "CPU restatement of Surround360 (OpenCV-free), reference thread shape (14 pair threads + 4 "
-                      "pole threads on %d cores): one 17-cam frame at eqr 2058x1029 took %.2f s; scaled to 8K by "
-                      "the flow pixel-level ratio %.1fx" % (cores, sec_2k, ratio)}
+    out, _ = f.render(side, top, bottom, threaded=True)
+    sec = time.time() - t0
+    st = f.stage_seconds()
+    return out, {"value": 1.0 / sec, "unit": "frames/s", "cores": 18, "kind": "port",
+                 "host_cores_available": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
+                 "stage_seconds": {k: round(v, 2) for k, v in st.items()},
+                 "sample": "CPU restatement of Surround360 (OpenCV-free oracle, -O3, no FMA): ONE full 8K frame of the bench "
+                           "workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low), reference thread shape = 14 "
+                           "camera/pair threads for projection, flow and novel views, then 4 pole-unit threads, "
+                           "single-threaded inside every operator (TestRenderStereoPanorama.cpp:153-175, 320-372, 811-860); "
+                           "cores = peak threads in use"}
 
 
 # SURVEY.md §8(d): compulsory bytes per 8K frame of the warp/blend kernel families (MB)
 WARP_BLEND_MB = {"project_side": 176 + 180, "project_pole": 2 * 12.6 + 141, "novel_view": 840, "assemble_pano": 400,
                  "pole_warp": 1600, "flatten": 1650}
+# compulsory bytes per pixel-level of the flow stencil families (SURVEY.md §8d pass list, reference dtypes)
+FLOW_STENCIL_B_PER_PXLEVEL = {"flow_gradients": 24, "flow_blur15": 16, "flow_median": 32, "flow_diffusion": 48,
+                              "flow_upscale": 16}
 
 
 def main():
@@ -97,9 +107,10 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--size", default="8k", choices=["8k", "2k"], help="2k is a debugging aid, not a bench config")
+    ap.add_argument("--no-extras", action="store_true", help="timed region + check + roofline only (profiling runs)")
     ap.add_argument("--inflight", type=int, default=16,
                     help="independent frames in flight per GPU (one context + HIP stream each); 1 = one frame at a time")
+    ap.add_argument("--video-frames", type=int, default=32)
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # hardware queues for the in-flight frames (read at HIP init)
@@ -127,16 +138,24 @@ def main():
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks timing tensors live
 
-    flags = dict(FLAGS_8K) if args.size == "8k" else dict(eqr_width=2058, eqr_height=1029, enable_top=1,
-                                                           enable_bottom=1, final_eqr_width=0, final_eqr_height=0)
-    side, top, bottom = synth.rig_frame(RIG, size=2048, world_h=1024, seed=360)
+    flags = dict(FLAGS_8K)
     rig = R.RigDescription(RIG)
+    P = rig.get_side_camera_count()
     F = max(1, args.inflight)
+    # ---- synthetic stream: one seeded equirect world (noise + near objects at 2 m / 5 m), rendered
+    # through the 17 rig cameras on the GPU; frame k = world rotated by 0.2 deg * k, one disc moving 0.5 deg per frame.
+    # (The world is 8192x4096: the 16384x8192 of §8d needs 3 GB for the texture + depth alone; stated in `data`.)
+    n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 2)
+    wtex = synth.World(4096, seed=360 + rank, device=dev)
+    rr = synth.RigRenderer(RIG, wtex, 2048)
+    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F, n_video))]
+    del rr, wtex
+    torch.cuda.empty_cache()
+
     ctxs = [R.Context(rig, R.make_params(**flags), device=local_rank) for _ in range(F)]
     ctx = ctxs[0]
-    P = rig.get_side_camera_count()
-    for c in ctxs:
-        c.upload_frame(side, top, bottom)  # inputs resident in HBM before the timed region
+    for k, c in enumerate(ctxs):
+        c.upload_frame(*frames[k])  # inputs resident in HBM before the timed region
         if F > 1:
             c.set_sweep_mode("throughput")  # several frames in flight: the kernel with the fewest instructions per pixel
 
@@ -148,14 +167,13 @@ def main():
             dist.barrier()
 
     # ---- timed region: every rank renders K whole frames, up to F in flight (independent frames: no collective) ----
-    # One host thread per context: a frame is ~1500 kernel launches, and a single submitting thread caps the node
+    # One host thread per context: a frame is ~1000 kernel launches, and a single submitting thread caps the node
     # at ~27 frames/s whatever the GPU does (ctypes releases the GIL inside libs360, the HIP runtime locks per stream).
     from concurrent.futures import ThreadPoolExecutor
     pools = [ThreadPoolExecutor(max_workers=1) for _ in range(F)]
     counter = [0]
     futures = []
-
-    enqueue_s = [0.0] * F  # host time spent inside s360_frame_render (enqueueing ~800 launches), per context
+    enqueue_s = [0.0] * F  # host time spent inside s360_frame_render, per context
 
     def enqueue(k):
         t = time.perf_counter()
@@ -176,11 +194,10 @@ def main():
     # Untimed set-up before the W warm-up steps: every context renders once (allocations, cached maps), then — only
     # if launches are being held up — frames are rendered until the host-side enqueue time per frame is back to a
     # small multiple of the uncontended one. Observed on shared boxes: for the first seconds after another GPU
-    # process has exited, enqueueing a frame takes ~8x longer (300 ms instead of 39 ms summed over the threads) and
-    # the GPU starves. Bounded at 60 s; not part of the warm-up or of the timed steps.
+    # process has exited, enqueueing a frame takes ~8x longer and the GPU starves. Bounded at 60 s; not part of the
+    # warm-up or of the timed steps.
     settle = {"batches": 0, "seconds": 0.0}
     if F > 1:
-        # (rank-local synchronisation inside this block: the ranks may need different numbers of settle batches)
         for _ in range(F):
             step()
         drain(barrier=False)
@@ -222,109 +239,114 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    enqueue_ms_per_frame = 1e3 * sum(enqueue_s) / max(args.steps, 1)
 
-    # ---- one frame at a time (BASELINE configs[2] on 1 GPU; configs[3] = pairs sharded + strip gather on N GPUs) ----
-    bounds = parallel.partition_pairs(P, world)
-    p0, p1 = bounds[rank], bounds[rank + 1]
-    ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    strips = parallel.strips_tensor(ctx, dev) if world > 1 else None
+    # ---- check of the timed region: every in-flight context against ONE context rendering the same inputs alone ----
+    inflight_out = [c.download_equirect() for c in ctxs]
+    for c in ctxs[1:]:
+        c.close()
+    del ctxs[1:]
+    ctx.set_sweep_mode("latency")
+    mism = []
+    single0 = None
+    for k in range(F):
+        ctx.upload_frame(*frames[k])
+        ctx.render(False)
+        alone = ctx.download_equirect()
+        if k == 0:
+            single0 = alone
+        if not np.array_equal(alone, inflight_out[k]):
+            mism.append(k)
+    checked = {"checked": not mism, "checked_contexts": F, "mismatching_contexts": mism,
+               "check": "equirect of every in-flight context (throughput sweep kernel) byte-compared with one context "
+                        "rendering the same inputs alone (latency sweep kernel)"}
+    del inflight_out
+    ctx.upload_frame(*frames[0])
 
-    def single():
-        if world == 1:
+    g = ctx.geometry
+    side_px, pole_px = flow_px_levels(g, flags["eqr_width"])
+    bytes_per_frame = sweep_algorithmic_bytes(g, 2 * P, 4, flags["eqr_width"])
+
+    def isolated(mode, n):
+        """n frames one at a time on the otherwise idle GPU: wall ms per frame + per-family (ms, launches) per frame."""
+        ctx.set_sweep_mode(mode)
+        ctx.render(False)
+        sync(barrier=False)
+        ctx.profile_enable(True)
+        t1 = time.perf_counter()
+        enq = 0.0
+        for _ in range(n):
+            te = time.perf_counter()
             ctx.render(False)
-        else:
-            ctx.render_pairs(p0, p1, False)
-            with torch.cuda.stream(ext):
-                parallel.gather_strips(strips, bounds, rank, world, 0)
-            if rank == 0:
-                ctx.finish(15, False)
+            enq += time.perf_counter() - te
+        sync(barrier=False)
+        ms = 1e3 * (time.perf_counter() - t1) / n
+        pr = {k: (v[0] / n, v[1] / n) for k, v in ctx.profile_get().items()}
+        ctx.profile_enable(False)
+        return ms, pr, 1e3 * enq / n
 
-    def emit(prof1, video, dt1, n_single, error):
-        prof1 = prof1 or {}
-        g = ctx.geometry
-        sweep_ms, sweep_launches = prof.get("flow_sweep", (0.0, 0))
-        bytes_per_frame = sweep_algorithmic_bytes(g, 2 * P, 4, flags["eqr_width"])
-        launches_per_frame = sweep_launches / max(args.steps, 1)
-        bytes_per_launch = bytes_per_frame / max(launches_per_frame, 1)
-        avg_launch_ms = sweep_ms / max(sweep_launches, 1)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        agg = bytes_per_frame * args.steps / dt / 1e9
-        s1_ms, s1_launches = prof1.get("flow_sweep", (0.0, 0))
-        n_side_flows_1 = 2 * (p1 - p0)
-        bytes_1 = sweep_algorithmic_bytes(g, n_side_flows_1, 4, flags["eqr_width"]) * n_single
-        wb = {}
-        if world == 1:
-            for k, mb in WARP_BLEND_MB.items():
-                ms = prof1.get(k, (0.0, 0))[0] / n_single
-                if ms > 0:
-                    gbs = mb * 1e6 / (ms * 1e-3) / 1e9
-                    wb[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        out = {
-            "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
-            "value": world * args.steps / dt,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo 8192x8192, "
-                                   "top+bottom poles, pixflow_low, sharpening 0" if args.size == "8k" else
-                                   "DEBUG 2K frame (not a bench config)",
-                       "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
-                                      "(one context + HIP stream each), no data-path collective" % (world, F),
-                       "frames_in_flight": F},
-            "roofline": {"bound": "hbm", "kernel": "%s (PixFlow propagation sweeps, PixFlow.h:388-410)" %
-                                   ("k_sweep_quad" if F > 1 else "k_sweep_lock"),
-                         "achieved": agg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "avg_launch_ms": avg_launch_ms, "launches_per_frame": launches_per_frame,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "per_launch_GBps_while_overlapped": achieved,
-                         "note": "dependency-latency-bound wavefront kernel (DESIGN.md §5). Launches of up to %d frames overlap "
-                                 "in the timed region, so `achieved` = algorithmic bytes of ALL sweep launches / wall time of "
-                                 "the region (bytes per launch / average launch duration, times the average number of "
-                                 "launches running at once); the un-overlapped per-launch figure is "
-                                 "single_frame.sweep_roofline_frac" % F},
-            "single_frame": {"mode": "one frame at a time, all pairs on 1 GPU" if world == 1 else
-                                     "one frame at a time, 14 pairs sharded over %d GPUs + one RCCL strip gather, pole units "
-                                     "and composite on rank 0" % world,
-                             "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9),
-                             "sweep_roofline_frac": (bytes_1 / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s1_ms > 0 else None,
-                             "kernel_ms_per_frame": {k: round(v[0] / n_single, 3)
-                                                     for k, v in sorted(prof1.items(), key=lambda kv: -kv[1][0])},
-                             "warp_blend_roofline": wb},
-            "kernel_ms_per_frame": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-        }
-        out["host"] = {"submit_threads": F, "enqueue_ms_per_frame": 1e3 * sum(enqueue_s) / max(args.steps, 1),
-                       "settle_batches_before_warmup": settle["batches"], "settle_seconds": round(settle["seconds"], 2),
-                       "note": "wall time inside s360_frame_render per frame, summed over the submitting threads "
-                               "(includes waiting on a full hardware queue)"}
-        if error is not None:
-            out["single_frame"] = {"error": error}
-        else:
-            out["single_frame"]["enqueue_ms"] = single_enqueue_ms[0]  # host time to enqueue one frame (one thread)
-        if video:
-            out["video_stream"] = video
-        traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
-        if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-            try:
-                tj = json.load(open(traffic_file))
-                kname = "k_sweep_quad" if F > 1 else "k_sweep_lock"
-                out["roofline"]["traffic"] = tj.get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(side, top, bottom)
-        print(json.dumps(out))
-        sys.stdout.flush()
+    def sweep_roofline(pr, kernel, note):
+        ms, launches = pr.get("flow_sweep", (0.0, 0))
+        per_launch_bytes = bytes_per_frame / max(launches, 1)
+        avg_ms = ms / max(launches, 1)
+        ach = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_frame": launches,
+                "algorithmic_bytes_per_launch": per_launch_bytes, "note": note}
 
-    # A hang or failure in this phase (the only one with a data-path collective) must not cost the bench line: the
-    # timed region above is complete, so a watchdog reports it without the single-frame figures.
+    # ---- isolated kernels: one context alone, throughput-mode kernel (the timed region's) and latency-mode kernel ----
+    tp_ms, tp_prof, _ = isolated("throughput", 2)
+    roofline = sweep_roofline(
+        tp_prof, "k_sweep_quad (PixFlow propagation sweeps, PixFlow.h:388-410)",
+        "dominant kernel of the timed region, measured with ONE frame alone on the GPU (HIP events on the library's "
+        "stream, launches do not overlap): algorithmic bytes per launch (48 B per pixel-level-sweep x the pixel-levels "
+        "of the launch's 28 side or 4 pole flows) / average launch duration. A dependency-latency-bound wavefront "
+        "kernel (DESIGN.md §5): one launch is a serial chain of w+h diagonal steps; `aggregate_frac` is the same bytes "
+        "over the wall time of the timed region, where launches of up to %d frames overlap" % F)
+    roofline["aggregate_frac"] = bytes_per_frame * args.steps / dt / 1e9 / HBM_PEAK_GBS
+    roofline["aggregate_GBps"] = bytes_per_frame * args.steps / dt / 1e9
+    roofline["us_per_diagonal_step"] = None
+    traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+    if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+        try:
+            tj = json.load(open(traffic_file))
+            roofline["traffic"] = tj.get("kernels", {}).get("k_sweep_quad", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    out = {
+        "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
+        "value": world * args.steps / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded 8192x4096 equirect world through the 17-camera rig, 2048x2048 inputs; every in-flight "
+                "context holds a different frame of the stream)",
+        "config": {"workload": "BASELINE configs[2]: full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo "
+                               "8192x8192, top+bottom poles, pixflow_low, sharpening 0",
+                   "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
+                                  "(one context + HIP stream each), no data-path collective" % (world, F),
+                   "frames_in_flight": F, "rccl_ranks": world},
+        "roofline": roofline,
+        "kernel_ms_per_frame_in_flight": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "host": {"submit_threads": F, "enqueue_ms_per_frame": enqueue_ms_per_frame,
+                 "settle_batches_before_warmup": settle["batches"], "settle_seconds": round(settle["seconds"], 2)},
+    }
+    out.update(checked)
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+
+    # A hang or failure past this point must not cost the bench line: the timed region is complete, so a watchdog
+    # prints what has been measured so far.
     import threading
     state = {"emitted": False}
     lock = threading.Lock()
@@ -334,74 +356,163 @@ def main():
             if state["emitted"]:
                 return
             state["emitted"] = True
-            if rank == 0:
-                emit(None, None, 0.0, 1, reason)
-        sys.stdout.flush()
+            out.setdefault("errors", []).append(reason)
+            emit()
         os._exit(0)
 
-    single_enqueue_ms = [None]
-    watchdog = threading.Timer(240.0, bail, args=("single-frame phase timed out",))
+    watchdog = threading.Timer(900.0, bail, args=("post-timed-region phases timed out",))
     watchdog.daemon = True
     watchdog.start()
-    n_single = 3
-    video = None
-    prof1, dt1 = None, 0.0
     try:
-        ctx.set_sweep_mode("latency")  # one frame at a time: the kernel with the shortest dependent chain
-        single()
-        sync()
-        ctx.profile_enable(True)
-        t1 = time.perf_counter()
-        enq1 = 0.0
-        for _ in range(n_single):
-            te = time.perf_counter()
-            single()
-            enq1 += time.perf_counter() - te
-        sync()
-        dt1 = time.perf_counter() - t1
-        prof1 = ctx.profile_get()
-        ctx.profile_enable(False)
-        if dist is not None:
+        # ---- one frame at a time (configs[2] on 1 GPU; configs[3] = pairs sharded + strip gather on N GPUs) ----
+        bounds = parallel.partition_pairs(P, world)
+        p0, p1 = bounds[rank], bounds[rank + 1]
+        if world == 1:
+            lat_ms, lat_prof, lat_enq = isolated("latency", 3)
+            n_diag = 2 * (sum(w + h - 1 for w, h in pyramid_levels(g.overlap_image_width, g.cam_image_height)) +
+                          sum(w + h - 1 for w, h in pyramid_levels(int(np.float32(flags["eqr_width"]) * np.float32(1.2)), g.top_rows)))
+            lock_roof = sweep_roofline(lat_prof, "k_sweep_lock", "latency-mode sweep kernel, one frame alone")
+            wb = {}
+            for k, mb in WARP_BLEND_MB.items():
+                ms = lat_prof.get(k, (0.0, 0))[0]
+                if ms > 0:
+                    gbs = mb * 1e6 / (ms * 1e-3) / 1e9
+                    wb[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            fs = {}
+            pxl = 28 * side_px + 4 * pole_px
+            for k, b in FLOW_STENCIL_B_PER_PXLEVEL.items():
+                ms = lat_prof.get(k, (0.0, 0))[0]
+                if ms > 0:
+                    # gradients are per image (28 side images, 6 pole images: 4 B read + 8 B written each)
+                    nbytes = 12 * (28 * side_px + 6 * pole_px) if k == "flow_gradients" else b * pxl
+                    gbs = nbytes / (ms * 1e-3) / 1e9
+                    fs[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            non_sweep = sum(v[0] for k, v in lat_prof.items() if k != "flow_sweep")
+            out["single_frame"] = {
+                "mode": "configs[2]: one frame at a time, all pairs on 1 GPU, latency sweep kernel",
+                "ms": lat_ms, "frames_per_s": 1e3 / lat_ms, "enqueue_ms": lat_enq,
+                "sweep": {"kernel": "k_sweep_lock", "ms_per_frame": lat_prof.get("flow_sweep", (0, 0))[0],
+                          "roofline_frac": lock_roof["frac"], "avg_launch_ms": lock_roof["avg_launch_ms"],
+                          "serial_diagonal_steps_per_frame": n_diag,
+                          "us_per_diagonal_step": 1e3 * lat_prof.get("flow_sweep", (0, 0))[0] / n_diag},
+                "kernel_ms_non_sweep": round(non_sweep, 3),
+                "kernel_ms_per_frame": {k: round(v[0], 3) for k, v in sorted(lat_prof.items(), key=lambda kv: -kv[1][0])},
+                "warp_blend_roofline": wb, "flow_stencil_roofline": fs,
+                "throughput_kernel_alone_ms": tp_ms}
+        else:
+            ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+            strips = parallel.strips_tensor(ctx, dev)
+            ctx.set_sweep_mode("latency")
+
+            def sharded():
+                ctx.render_pairs(p0, p1, False)
+                with torch.cuda.stream(ext):
+                    parallel.gather_strips(strips, bounds, rank, world, 0)
+                if rank == 0:
+                    ctx.finish(15, False)
+            sharded()
+            sync()
+            n_single = 3
+            t1 = time.perf_counter()
+            for _ in range(n_single):
+                sharded()
+            sync()
+            dt1 = time.perf_counter() - t1
             t = torch.tensor([dt1], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt1 = float(t.item())
-        if world == 1:
-            # BASELINE configs[4]: ONE video stream with temporal regularisation. Frame k+1 needs frame k's flows, so
-            # the frames of one stream run back to back (independent streams overlap like the timed region above).
-            ctx.render(False)
-            ctx.render(True)
-            sync()
-            n_video = 4
-            t2 = time.perf_counter()
-            for _ in range(n_video):
+            ok = None
+            if rank == 0:
+                ok = bool(np.array_equal(ctx.download_equirect(), single0))
+            out["single_frame"] = {
+                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), ONE RCCL exchange gathering the "
+                        "strips on rank 0, which runs the 4 pole units and the composite" % (world, bounds),
+                "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9), "rccl_ranks": world,
+                "equals_single_gpu_frame": ok}
+
+        if world == 1 and not args.no_extras:
+            # ---- the reference presets' sharpening 0.25 (batch_process_video.py:176-199) ----
+            cs = R.Context(rig, R.make_params(sharpening=0.25, **flags), device=local_rank)
+            cs.upload_frame(*frames[0])
+            cs.render(False)
+            cs.synchronize()
+            cs.profile_enable(True)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                cs.render(False)
+            cs.synchronize()
+            ms = 1e3 * (time.perf_counter() - t1) / 3
+            pr = cs.profile_get()
+            cs.close()
+            out["single_frame"]["with_sharpening_0.25"] = {"ms": ms, "finish_ms": pr.get("finish", (0, 0))[0] / 3,
+                                                           "finish_ms_without": out["single_frame"]["kernel_ms_per_frame"].get("finish")}
+
+            # ---- BASELINE configs[1]: one 2048x2048 pair, both directions (TestOpticalFlow.cpp:50-143) ----
+            i0, i1 = synth.flow_pair(2048, 2048, seed=360)
+            cf = R.Context(rig, R.make_params(), device=local_rank)
+            cf.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+            t1 = time.perf_counter()
+            gl = cf.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+            gr = cf.compute_optical_flow(i1, i0, "pixflow_low", "RIGHT")
+            gpu_s = time.perf_counter() - t1
+            cf.close()
+            c2 = {"workload": "BASELINE configs[1]: one 2048x2048 BGRA pair, pixflow_low, flowLtoR + flowRtoL",
+                  "gpu_runtime_sec": gpu_s, "gpu_note": "host buffers in and out (PCIe both ways), latency sweep kernel"}
+            if not args.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                with ThreadPoolExecutor(2) as ex:
+                    t1 = time.perf_counter()
+                    fl = ex.submit(O.compute_optical_flow, i0, i1, "pixflow_low", "LEFT")
+                    fr = ex.submit(O.compute_optical_flow, i1, i0, "pixflow_low", "RIGHT")
+                    wl, wr = fl.result(), fr.result()
+                    c2["cpu_runtime_sec"] = time.perf_counter() - t1
+                c2["cpu_note"] = "oracle, the two directions on two threads (NovelView.cpp:282-297 runs them back to back)"
+                c2["checked"] = bool(np.array_equal(gl.view(np.uint32), wl.view(np.uint32)) and
+                                     np.array_equal(gr.view(np.uint32), wr.view(np.uint32)))
+            out["config2_flow_pair"] = c2
+
+            # ---- BASELINE configs[4] on one GPU: one video stream, distinct frames, temporal regularisation ----
+            def stream(pipelined):
+                ctx.set_frame_pipelining(pipelined)
+                ctx.upload_frame(*frames[0])
+                ctx.render(False)
+                ctx.upload_frame(*frames[1])
                 ctx.render(True)
-            sync()
-            ms = 1e3 * (time.perf_counter() - t2) / n_video
-            video = {"mode": "one stream; frame k regularised toward frame k-1's flows (use_prev)", "frames": n_video,
-                     "ms_per_frame": ms, "frames_per_s": 1e3 / ms}
-            # the same stream with frame pipelining: the pole stage of frame k (second HIP stream) overlaps the side
-            # stage of frame k+1; the temporal chains side(k)->side(k+1) and pole(k)->pole(k+1) are kept
-            ctx.set_frame_pipelining(True)
-            ctx.render(True)
-            sync()
-            n_pipe = 6
-            t3 = time.perf_counter()
-            for _ in range(n_pipe):
-                ctx.render(True)
-            sync()
-            ms = 1e3 * (time.perf_counter() - t3) / n_pipe
-            ctx.set_frame_pipelining(False)
-            video["pipelined"] = {"frames": n_pipe, "ms_per_frame": ms, "frames_per_s": 1e3 / ms}
+                sync(barrier=False)
+                up = 0.0
+                t2 = time.perf_counter()
+                for k in range(2, n_video):
+                    tu = time.perf_counter()
+                    ctx.upload_frame(*frames[k])  # host memory -> pinned ring -> upload stream; overlaps frame k-1
+                    up += time.perf_counter() - tu
+                    ctx.render(True)
+                sync(barrier=False)
+                ms = 1e3 * (time.perf_counter() - t2) / (n_video - 2)
+                ctx.set_frame_pipelining(False)
+                return {"frames": n_video - 2, "ms_per_frame": ms, "frames_per_s": 1e3 / ms,
+                        "host_upload_ms_per_frame": 1e3 * up / (n_video - 2)}
+            ctx.set_sweep_mode("latency")
+            video = {"mode": "one stream of %d distinct frames (world rotating 0.2 deg/frame, one moving disc); frame k regularised "
+                             "toward frame k-1's device-resident flows and images; inputs uploaded from host memory while the "
+                             "previous frame renders" % n_video}
+            video.update(stream(False))
+            video["pipelined"] = stream(True)
+            out["video_stream"] = video
+
+            if not args.no_cpu_baseline:
+                want, cb = cpu_baseline_8k(*frames[0])
+                cb["checked_against_gpu"] = bool(np.array_equal(want, single0))
+                out["cpu_baseline"] = cb
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
-        bail("single-frame phase failed: %r" % (e,))
+        import traceback
+        bail("post-timed-region phase failed: %r %s" % (e, traceback.format_exc()[-600:]))
     watchdog.cancel()
     with lock:
         if state["emitted"]:
             return
         state["emitted"] = True
-    if rank == 0:
-        single_enqueue_ms[0] = 1e3 * enq1 / n_single
-        emit(prof1, video, dt1, n_single, None)
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -185,6 +185,7 @@ int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams,
 void s360_destroy(s360_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stUp) (void)hipStreamSynchronize(c->stUp);
   if (c->st) (void)hipStreamSynchronize(c->st);
   if (c->st2) (void)hipStreamSynchronize(c->st2);
   c->frame.reset();
@@ -196,7 +197,16 @@ void s360_destroy(s360_ctx* c) {
     (void)hipStreamDestroy(c->st2);
     (void)hipEventDestroy(c->evSideDone);
     (void)hipEventDestroy(c->evStripsFree);
-    (void)hipEventDestroy(c->evPoleSrcFree);
+  }
+  if (c->evPoleSrcFree) (void)hipEventDestroy(c->evPoleSrcFree);
+  if (c->stUp) {
+    (void)hipStreamDestroy(c->stUp);
+    (void)hipEventDestroy(c->evUploaded);
+    (void)hipEventDestroy(c->evSideSrcFree);
+    for (int i = 0; i < s360_ctx::kPinChunks; ++i) {
+      if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+      if (c->pinEv[i]) (void)hipEventDestroy(c->pinEv[i]);
+    }
   }
   delete c;
 }
@@ -209,6 +219,7 @@ void* s360_stream(s360_ctx* c) { return c ? (void*)c->st : nullptr; }
 int s360_synchronize(s360_ctx* c) {
   return guard(c, [&] {
     need(c, "null ctx");
+    if (c->stUp) S360_HIP(hipStreamSynchronize(c->stUp));
     S360_HIP(hipStreamSynchronize(c->st));
     if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));
     check_sweep_error(c);
@@ -224,10 +235,10 @@ int s360_set_frame_pipelining(s360_ctx* c, int on) {
       S360_HIP(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
       S360_HIP(hipEventCreateWithFlags(&c->evSideDone, hipEventDisableTiming));
       S360_HIP(hipEventCreateWithFlags(&c->evStripsFree, hipEventDisableTiming));
-      S360_HIP(hipEventCreateWithFlags(&c->evPoleSrcFree, hipEventDisableTiming));
+      if (!c->evPoleSrcFree) S360_HIP(hipEventCreateWithFlags(&c->evPoleSrcFree, hipEventDisableTiming));
     }
     c->pipeline = on != 0;
-    c->haveStripsFree = c->havePoleSrcFree = false;
+    c->haveStripsFree = false;
   });
 }
 int s360_set_keep_intermediates(s360_ctx* c, int on) {

@@ -22,6 +22,19 @@ struct s360_ctx {
   bool pipeline = false;
   hipEvent_t evSideDone = nullptr, evStripsFree = nullptr, evPoleSrcFree = nullptr;
   bool haveStripsFree = false, havePoleSrcFree = false;
+  // Uploads (s360_frame_upload_*) never touch the render streams: the caller's buffer is copied through a small ring
+  // of library-owned pinned chunks and sent on stUp, so a host thread can feed frame k+1 while frame k renders. Three
+  // events order the two sides: evUploaded (render waits for the inputs), evSideSrcFree / evPoleSrcFree (the upload's
+  // conversion kernels wait until the previous frame's projections have read the source images).
+  hipStream_t stUp = nullptr;
+  static constexpr int kPinChunks = 4;
+  static constexpr size_t kPinChunkBytes = (size_t)8 << 20;
+  void* pin[kPinChunks] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pinEv[kPinChunks] = {nullptr, nullptr, nullptr, nullptr};
+  bool pinUsed[kPinChunks] = {false, false, false, false};
+  int pinNext = 0;
+  hipEvent_t evUploaded = nullptr, evSideSrcFree = nullptr;
+  bool haveUploaded = false, haveSideSrcFree = false;
   s360::Rig rig;
   s360_params P;
   s360_geometry g;

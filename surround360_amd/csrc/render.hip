@@ -152,35 +152,74 @@ FrameState& frame_state(s360_ctx* c) {
   return *c->frame;
 }
 
+// ---- uploads: pinned chunk ring + upload stream (see ctx.hpp) ----------------------------------------------------
+static void ensure_upload_stream(s360_ctx* c) {
+  if (c->stUp) return;
+  S360_HIP(hipStreamCreateWithFlags(&c->stUp, hipStreamNonBlocking));
+  S360_HIP(hipEventCreateWithFlags(&c->evUploaded, hipEventDisableTiming));
+  S360_HIP(hipEventCreateWithFlags(&c->evSideSrcFree, hipEventDisableTiming));
+  if (!c->evPoleSrcFree) S360_HIP(hipEventCreateWithFlags(&c->evPoleSrcFree, hipEventDisableTiming));
+  for (int i = 0; i < s360_ctx::kPinChunks; ++i) {
+    S360_HIP(hipHostMalloc(&c->pin[i], s360_ctx::kPinChunkBytes, hipHostMallocDefault));
+    S360_HIP(hipEventCreateWithFlags(&c->pinEv[i], hipEventDisableTiming));
+  }
+}
+// host -> device through the pinned ring on stUp; `src` may be reused as soon as this returns
+static void upload_bytes(s360_ctx* c, void* dst, const void* src, size_t bytes) {
+  const char* s = static_cast<const char*>(src);
+  char* d = static_cast<char*>(dst);
+  for (size_t off = 0; off < bytes; off += s360_ctx::kPinChunkBytes) {
+    const size_t len = std::min(s360_ctx::kPinChunkBytes, bytes - off);
+    const int i = c->pinNext;
+    c->pinNext = (i + 1) % s360_ctx::kPinChunks;
+    if (c->pinUsed[i]) S360_HIP(hipEventSynchronize(c->pinEv[i]));  // the chunk's previous copy has left the host
+    std::memcpy(c->pin[i], s + off, len);
+    S360_HIP(hipMemcpyAsync(d + off, c->pin[i], len, hipMemcpyHostToDevice, c->stUp));
+    S360_HIP(hipEventRecord(c->pinEv[i], c->stUp));
+    c->pinUsed[i] = true;
+  }
+}
+static void uploads_done(s360_ctx* c) {
+  S360_HIP(hipEventRecord(c->evUploaded, c->stUp));
+  c->haveUploaded = true;
+}
+// called by the render stages before they read the source images / after they have read them
+static void wait_for_uploads(s360_ctx* c, hipStream_t st) {
+  if (c->haveUploaded) S360_HIP(hipStreamWaitEvent(st, c->evUploaded, 0));
+}
+
 void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, int ch) {
   FrameState& F = frame_state(c);
   if (idx < 0 || idx >= F.P) throw Error(S360_ERR_INVALID_ARG, "side_idx out of range");
   if (ch != 3 && ch != 4) throw Error(S360_ERR_INVALID_ARG, "side image must have 3 or 4 channels");
   if (F.have_side && (w != F.srcW || h != F.srcH)) throw Error(S360_ERR_INVALID_ARG, "side image size changed");
   if (F.P > 64) throw Error(S360_ERR_INVALID_ARG, "more than 64 side cameras");
+  ensure_upload_stream(c);
   F.srcW = w;
   F.srcH = h;
   const size_t n = (size_t)w * h;
   F.sideSrc.ensure(F.P * n * sizeof(uchar4));
   F.staging.ensure(n * 4);
-  S360_HIP(hipMemcpyAsync(F.staging.p, img, n * ch, hipMemcpyHostToDevice, c->st));
-  launch_prepare_side_src(c->st, F.staging.as<uint8_t>(), ch, F.sideSrc.as<uchar4>() + n * idx, w, h,
+  upload_bytes(c, F.staging.p, img, n * ch);  // stUp is in order: the previous image's conversion has read the staging buffer
+  if (c->haveSideSrcFree) S360_HIP(hipStreamWaitEvent(c->stUp, c->evSideSrcFree, 0));  // the previous frame's projections
+  launch_prepare_side_src(c->stUp, F.staging.as<uint8_t>(), ch, F.sideSrc.as<uchar4>() + n * idx, w, h,
                           c->P.side_alpha_feather_size);
-  S360_HIP(hipStreamSynchronize(c->st));  // staging is reused by the next upload
+  uploads_done(c);
   F.have_side = true;
   F.side_uploaded |= 1ull << idx;
 }
 void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) {
   FrameState& F = frame_state(c);
+  ensure_upload_stream(c);
   if (top) { F.topW = w; F.topH = h; } else { F.poleW = w; F.poleH = h; }
   const size_t n = (size_t)w * h;
   DevBuf& dst = top ? F.topSrc : F.botSrc;
   dst.ensure(n * sizeof(uchar4));
   F.staging.ensure(n * 4);
-  if (c->pipeline && c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->st, c->evPoleSrcFree, 0));
-  S360_HIP(hipMemcpyAsync(F.staging.p, bgr, n * 3, hipMemcpyHostToDevice, c->st));
-  launch_bgr_to_bgra(c->st, F.staging.as<uint8_t>(), 3, dst.as<uchar4>(), n);
-  S360_HIP(hipStreamSynchronize(c->st));
+  upload_bytes(c, F.staging.p, bgr, n * 3);
+  if (c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->stUp, c->evPoleSrcFree, 0));  // the previous frame's pole projections
+  launch_bgr_to_bgra(c->stUp, F.staging.as<uint8_t>(), 3, dst.as<uchar4>(), n);
+  uploads_done(c);
   (top ? F.have_top : F.have_bottom) = true;
 }
 
@@ -188,20 +227,20 @@ void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_
   FrameState& F = frame_state(c);
   if (F.have_bottom && (w != F.poleW || h != F.poleH))
     throw Error(S360_ERR_INVALID_ARG, "the secondary bottom image and the pole masks must have the bottom camera's size");
+  ensure_upload_stream(c);
   const size_t n = (size_t)w * h;
   F.botSrc2.ensure(n * sizeof(uchar4));
   F.staging.ensure(n * 4);
-  if (c->pipeline && c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->st, c->evPoleSrcFree, 0));
-  S360_HIP(hipMemcpyAsync(F.staging.p, bottom2, n * 3, hipMemcpyHostToDevice, c->st));
-  launch_bgr_to_bgra(c->st, F.staging.as<uint8_t>(), 3, F.botSrc2.as<uchar4>(), n);
+  for (int k = 0; k < 2; ++k) F.prRed[k].ensure(n);
+  upload_bytes(c, F.staging.p, bottom2, n * 3);
+  if (c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->stUp, c->evPoleSrcFree, 0));
+  launch_bgr_to_bgra(c->stUp, F.staging.as<uint8_t>(), 3, F.botSrc2.as<uchar4>(), n);
   const uint8_t* masks[2] = {mask, mask2};
   for (int k = 0; k < 2; ++k) {
-    S360_HIP(hipStreamSynchronize(c->st));  // staging is reused
-    F.prRed[k].ensure(n);
-    S360_HIP(hipMemcpyAsync(F.staging.p, masks[k], n * 3, hipMemcpyHostToDevice, c->st));
-    launch_red_mask(c->st, F.staging.as<uint8_t>(), F.prRed[k].as<uint8_t>(), n);
+    upload_bytes(c, F.staging.p, masks[k], n * 3);
+    launch_red_mask(c->stUp, F.staging.as<uint8_t>(), F.prRed[k].as<uint8_t>(), n);
   }
-  S360_HIP(hipStreamSynchronize(c->st));
+  uploads_done(c);
   F.have_pr_inputs = true;
 }
 
@@ -327,6 +366,7 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
   F.proj.ensure(P * pn * sizeof(uchar4));
   F.strips.ensure((size_t)2 * P * camH * stripW * sizeof(uchar4));
   if (n == 0) return;
+  wait_for_uploads(c, st);
   {
     ProfScope ps(prof, "project_side");
     std::vector<char> need(P, 0);
@@ -339,6 +379,10 @@ void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
                               F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
       i = j;
     }
+  }
+  if (c->evSideSrcFree) {  // the next frame's side images may be converted into sideSrc from here on
+    S360_HIP(hipEventRecord(c->evSideSrcFree, st));
+    c->haveSideSrcFree = true;
   }
   const bool repartition = (F.side_p0 != p0 || F.side_p1 != p1);
   const bool usePrev = use_prev && F.have_prev_side && !repartition;
@@ -493,6 +537,7 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
     F.extImgs[cur].ensure(6 * xn * sizeof(uchar4));
     F.poleFlows[cur].ensure(4 * xn * sizeof(float2));
     uchar4* ext = F.extImgs[cur].as<uchar4>();
+    wait_for_uploads(c, st);
     {
       ProfScope ps(prof, "project_pole");
       if (pole_mask & 3) {
@@ -517,7 +562,7 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
         }
         launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xn, extW);
       }
-      if (c->pipeline) {  // the next frame's pole images may be uploaded from here on
+      if (c->evPoleSrcFree) {  // the next frame's pole images may be converted into topSrc / botSrc from here on
         S360_HIP(hipEventRecord(c->evPoleSrcFree, st));
         c->havePoleSrcFree = true;
       }

@@ -170,3 +170,118 @@ def rig_frame(rig_json_path, size=2048, world_h=2048, seed=360, yaw_deg=0.0, ret
     if return_all:
         return side, imgs[top["id"]], imgs[bottom["id"]], imgs
     return side, imgs[top["id"]], imgs[bottom["id"]]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# torch versions of the generators above for the full-size configurations (17 x 2048^2 cameras per frame, a 190-frame
+# stream): the numpy ray caster takes minutes per frame, this one milliseconds on the GPU (it also runs on CPU
+# tensors). Same construction — seeded band-limited world texture + depth, rays through the rig's camera model, one
+# fixed-point iteration for parallax — but NOT bit-identical to the numpy path; inputs only have to be the same for
+# the two sides of a comparison, which get the same arrays.
+class World:
+    """Seeded equirect world (2h x h BGR float texture + depth in cm) resident on `device`; `disc` adds one moving
+    high-contrast disc (BASELINE configs[4]: "one disc translating")."""
+
+    def __init__(self, h=4096, seed=360, device="cpu"):
+        import torch
+        import torch.nn.functional as F
+        self.torch, self.F = torch, F
+        self.h, self.w, self.device = h, 2 * h, torch.device(device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+
+        def smooth(octaves, base, ch):
+            out = torch.zeros(ch, h, 2 * h, device=self.device)
+            amp = 1.0
+            for o in range(octaves):
+                gh, gw = base * (2 ** o) + 1, 2 * base * (2 ** o) + 1
+                grid = torch.rand(1, ch, gh, gw, generator=g)
+                grid[..., -1] = grid[..., 0]  # periodic in azimuth: no seam where the equirect wraps
+                grid = grid.to(self.device)
+                out += amp * F.interpolate(grid, size=(h, 2 * h), mode="bilinear", align_corners=True)[0]
+                amp *= 0.5
+            out -= out.amin(dim=(1, 2), keepdim=True)
+            out /= out.amax(dim=(1, 2), keepdim=True).clamp_min(1e-6)
+            return out
+
+        tex = (smooth(7, 8, 3) * 255.0).clamp(0, 255)
+        blobs = smooth(2, 3, 1)[0]
+        depth = torch.where(blobs > 0.72, 200.0, torch.where(blobs > 0.6, 500.0, 1.0e6))
+        near = depth < 1e5
+        mark = torch.tensor([40.0, 10.0, 60.0], device=self.device)[:, None, None]
+        tex = torch.where(near[None], (tex * 0.75 + mark).clamp(0, 255), tex)
+        self.tex, self.depth = tex.contiguous(), depth.contiguous()
+
+
+def _rays_torch(cam, size, device, torch):
+    sx = cam["resolution"][0] / size
+    fwd, up, right = (np.asarray(cam[k], np.float64) for k in ("forward", "up", "right"))
+    Rm = np.stack([right, up, -fwd])
+    u, _, vt = np.linalg.svd(Rm)
+    Rm = torch.tensor(u @ vt, dtype=torch.float32, device=device)
+    p = (torch.arange(size, device=device, dtype=torch.float32) + 0.5) * sx
+    Y, X = torch.meshgrid(p, p, indexing="ij")
+    pr = cam.get("principal", [cam["resolution"][0] / 2, cam["resolution"][1] / 2])
+    sxn = (X - pr[0]) / cam["focal"][0]
+    syn = (Y - pr[1]) / cam["focal"][1]
+    r = torch.sqrt(sxn * sxn + syn * syn) + 1e-12
+    ang = r if cam["type"] == "FTHETA" else torch.atan(r)
+    s = torch.sin(ang) / r
+    unit = torch.stack([s * sxn, s * syn, -torch.cos(ang)], dim=-1)
+    return unit @ Rm
+
+
+class RigRenderer:
+    """Renders the cameras of a rig JSON from a World; rays are cached per camera. frame(yaw_deg, disc_deg) returns
+    ([side BGR uint8 HxWx3 ...], top, bottom) as tensors on the world's device."""
+
+    def __init__(self, rig_json_path, world, size=2048):
+        self.world, self.size = world, size
+        torch = world.torch
+        with open(rig_json_path) as f:
+            self.cams = json.load(f)["cameras"]
+        self.rays = [_rays_torch(c, size, world.device, torch) for c in self.cams]
+        self.org = [torch.tensor(c["origin"], dtype=torch.float32, device=world.device) for c in self.cams]
+
+        def axis_dist(c):
+            fw = np.asarray(c["forward"], np.float64)
+            o = np.asarray(c["origin"], np.float64)
+            return np.linalg.norm(-o - fw * np.dot(fw, -o))
+        ok = [i for i, c in enumerate(self.cams) if axis_dist(c) <= 1.0]
+        self.top = max(ok, key=lambda i: self.cams[i]["forward"][2])
+        self.bottom = max(ok, key=lambda i: -self.cams[i]["forward"][2])
+        self.side = [i for i, c in enumerate(self.cams) if "side" in c.get("group", "")]
+
+    def _camera(self, i, yaw_deg, disc_deg):
+        W = self.world
+        torch, F = W.torch, W.F
+        rays, org = self.rays[i], self.org[i]
+        p = org + rays * 1.0e6
+        for _ in range(2):
+            n = p / p.norm(dim=-1, keepdim=True)
+            th = torch.atan2(n[..., 1], n[..., 0]) + float(np.deg2rad(yaw_deg))
+            ph = torch.acos(n[..., 2].clamp(-1, 1))
+            u = torch.remainder(-th, 2 * np.pi) / (2 * np.pi) * W.w
+            v = ph / np.pi * W.h
+            d = W.depth[v.long().clamp(0, W.h - 1), u.long().clamp(0, W.w - 1)]
+            b = (rays * org).sum(-1)
+            c = (org * org).sum() - d * d
+            t = -b + torch.sqrt((b * b - c).clamp_min(0))
+            p = org + rays * t[..., None]
+        # bilinear, wrapping in x: grid_sample on a texture padded by one column
+        tex = torch.cat([W.tex, W.tex[:, :, :1]], dim=2)[None]
+        gx = (u / W.w) * 2 - 1  # align_corners=True over W.w + 1 columns: x in [0, W.w] -> [-1, 1]
+        gy = (v.clamp(0, W.h - 1.001) / (W.h - 1)) * 2 - 1
+        img = F.grid_sample(tex, torch.stack([gx, gy], -1)[None], mode="bilinear", padding_mode="border", align_corners=True)[0]
+        if disc_deg is not None:  # a dark disc with a bright rim, 3 degrees across, on the horizon at azimuth disc_deg
+            az = torch.remainder(th - float(np.deg2rad(disc_deg)) + np.pi, 2 * np.pi) - np.pi
+            rr = torch.sqrt(az * az + (ph - np.pi / 2) ** 2) / float(np.deg2rad(1.5))
+            img = torch.where((rr < 1.0)[None], torch.where((rr < 0.8)[None], img * 0.2, img * 0 + 250.0), img)
+        return img.clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous()
+
+    def frame(self, yaw_deg=0.0, disc_deg=None):
+        imgs = [self._camera(i, yaw_deg, disc_deg) for i in range(len(self.cams))]
+        return [imgs[i] for i in self.side], imgs[self.top], imgs[self.bottom]
+
+    def frame_numpy(self, yaw_deg=0.0, disc_deg=None):
+        side, top, bottom = self.frame(yaw_deg, disc_deg)
+        return [s.cpu().numpy() for s in side], top.cpu().numpy(), bottom.cpu().numpy()

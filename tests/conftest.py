@@ -17,6 +17,8 @@ RIG_JSON = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullsize: the subset of the gpu tests that runs at the BASELINE.json sizes "
+                                       "(2048^2 pair, full 8K frame); minutes of oracle time on the host cores")
 
 
 @pytest.fixture(scope="session")

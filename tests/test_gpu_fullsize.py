@@ -1,0 +1,167 @@
+"""Parity at the BENCHMARK sizes (BASELINE.json configs[1] and configs[2]; `-m gpu`, also selectable as `-m fullsize`).
+
+Everything else in tests/ runs at sizes the oracle finishes in seconds (eqr 1008, flows <= 333x444). The paths below
+only exist at full size: 64-band hand-off chains on 1024-wide levels (config 2: one 2048x2048 pair), 66 bands on
+5040-wide pole levels, the gather fallback of the pole remap at 8400x2104, the double-precision device trigonometry of
+the spherical maps over 45 Mpx, and several 8K contexts in flight under the throughput sweep kernel (what bench.py times).
+
+The oracle runs with the reference's thread shape (one thread per pair / pole unit); on the GPU box's host cores one 8K
+frame takes about a minute."""
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from surround360_amd import render as R, synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.fullsize]
+
+FLAGS_8K = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192,
+                final_eqr_height=8192)  # the reference's 8k preset (batch_process_video.py:194-199)
+
+
+def _cmp(name, got, want):
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+    if got.dtype == np.float32:
+        a, b = got.view(np.uint32), want.view(np.uint32)
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError("%s: %d of %d values differ, max abs %g, first at %s" % (
+                name, len(bad), a.size, np.abs(got - want).max(), bad[0].tolist()))
+    elif not np.array_equal(got, want):
+        d = got.astype(np.int16) - want.astype(np.int16)
+        bad = np.argwhere(d != 0)
+        raise AssertionError("%s: %d of %d bytes differ, max |d| %d, first at %s" % (
+            name, len(bad), d.size, int(np.abs(d).max()), bad[0].tolist()))
+
+
+# ---- BASELINE configs[1]: one adjacent side-camera pair, 2048x2048, PixFlow only (TestOpticalFlow.cpp:50-143) ----
+@pytest.mark.parametrize("mode", ["latency", "throughput"])
+def test_config2_flow_pair_2048(gpu_rig, oracle, mode):
+    """Both directions of one 2048^2 pair like TestOpticalFlow's `test` mode (flowLtoR with hint LEFT, flowRtoL with
+    hint RIGHT): 1024^2 after the x0.5 downscale, 36 pyramid levels, 64 sweep bands on the finest."""
+    i0, i1 = synth.flow_pair(2048, 2048, seed=360)
+    with ThreadPoolExecutor(2) as ex:  # the oracle's two flows side by side (ctypes releases the GIL)
+        fl = ex.submit(oracle.compute_optical_flow, i0, i1, "pixflow_low", "LEFT")
+        fr = ex.submit(oracle.compute_optical_flow, i1, i0, "pixflow_low", "RIGHT")
+        ctx = R.Context(gpu_rig, R.make_params())
+        try:
+            ctx.set_sweep_mode(mode)
+            ctx.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")  # allocations, divisor verification
+            t0 = time.perf_counter()
+            got_l = ctx.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+            got_r = ctx.compute_optical_flow(i1, i0, "pixflow_low", "RIGHT")
+            print("config 2 (%s): RUNTIME (sec) = %.4f incl. PCIe both ways" % (mode, time.perf_counter() - t0))
+        finally:
+            ctx.close()
+        _cmp("flowLtoR 2048^2 (%s)" % mode, got_l, fl.result())
+        _cmp("flowRtoL 2048^2 (%s)" % mode, got_r, fr.result())
+    assert np.abs(got_l).max() > 4.0  # a real disparity field, not zeros
+
+
+# ---- BASELINE configs[2]: the full 17-camera frame at the 8k preset, stage by stage ----
+@pytest.fixture(scope="module")
+def frame8k(rig_json, oracle, s360lib, gpu_rig):
+    world = synth.World(4096, seed=360, device="cuda")
+    rr = synth.RigRenderer(rig_json, world, 2048)
+    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(2)]
+    del rr, world
+    import torch
+    torch.cuda.empty_cache()
+    side, top, bottom = frames[0]
+    cams, _ = oracle.load_rig(rig_json)
+    of = oracle.Frame(cams, oracle.make_params(**FLAGS_8K))
+    t0 = time.perf_counter()
+    want, _ = of.render(side, top, bottom, threaded=True)
+    print("oracle 8K frame: %.1f s, stages %s" % (time.perf_counter() - t0, of.stage_seconds()))
+    ctx = R.Context(gpu_rig, R.make_params(**FLAGS_8K))
+    ctx.keep_intermediates(True)
+    ctx.upload_frame(side, top, bottom)
+    ctx.render()
+    got = ctx.download_equirect()
+    yield dict(ctx=ctx, of=of, got=got, want=want, frames=frames)
+    ctx.close()
+
+
+def test_config3_geometry(frame8k):
+    g = frame8k["ctx"].geometry
+    assert (g.cam_image_width, g.cam_image_height, g.overlap_image_width, g.num_novel_views) == (1814, 1769, 1214, 600)
+    assert (g.top_rows, g.bottom_rows) == (2104, 2104)  # SURVEY.md §8 size table
+
+
+def test_config3_projections_and_overlaps(frame8k):
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    for i in range(14):
+        _cmp("projection %d" % i, ctx.get_u8("projection", i), of.get_u8("projection", i))
+    for i in (0, 6, 13):
+        _cmp("overlap_l %d" % i, ctx.get_u8("overlap_l", i), of.get_u8("overlap_l", i))
+        _cmp("overlap_r %d" % i, ctx.get_u8("overlap_r", i), of.get_u8("overlap_r", i))
+    _cmp("top_spherical", ctx.get_u8("top_spherical"), of.get_u8("top_spherical"))
+    _cmp("bottom_spherical", ctx.get_u8("bottom_spherical"), of.get_u8("bottom_spherical"))
+
+
+def test_config3_side_flows(frame8k):
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    for i in range(14):
+        _cmp("flow_l_to_r %d" % i, ctx.get_f32("flow_l_to_r", i), of.get_f32("flow_l_to_r", i))
+        _cmp("flow_r_to_l %d" % i, ctx.get_f32("flow_r_to_l", i), of.get_f32("flow_r_to_l", i))
+
+
+def test_config3_side_panoramas(frame8k):
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    _cmp("side_pano_l", ctx.get_u8("side_pano_l"), of.get_u8("side_pano_l"))
+    _cmp("side_pano_r", ctx.get_u8("side_pano_r"), of.get_u8("side_pano_r"))
+
+
+def test_config3_pole_units(frame8k):
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    for u in range(4):
+        _cmp("extended_side %d" % u, ctx.get_u8("extended_side", u), of.get_u8("extended_side", u))
+        _cmp("extended_fisheye %d" % u, ctx.get_u8("extended_fisheye", u), of.get_u8("extended_fisheye", u))
+        _cmp("flow_pole %d" % u, ctx.get_f32("flow_pole", u), of.get_f32("flow_pole", u))
+        _cmp("pole_warped %d" % u, ctx.get_u8("pole_warped", u), of.get_u8("pole_warped", u))
+
+
+def test_config3_eyes_and_equirect(frame8k):
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    _cmp("eye_l", ctx.get_u8("eye_l"), of.get_u8("eye_l"))
+    _cmp("eye_r", ctx.get_u8("eye_r"), of.get_u8("eye_r"))
+    assert frame8k["got"].shape == (8192, 8192, 3)
+    _cmp("stereo equirect 8192x8192", frame8k["got"], frame8k["want"])
+    assert frame8k["got"].std() > 5
+
+
+def test_config3_contexts_in_flight_equal_single(frame8k, gpu_rig):
+    """What bench.py's timed region does: several 8K contexts fed by one host thread each, throughput sweep kernel
+    (inter-workgroup spin-waits under oversubscription). Every context must produce the single-context bytes."""
+    side, top, bottom = frame8k["frames"][0]
+    n = 4
+    ctxs = [R.Context(gpu_rig, R.make_params(**FLAGS_8K)) for _ in range(n)]
+    try:
+        for c in ctxs:
+            c.set_sweep_mode("throughput")
+            c.upload_frame(side, top, bottom)
+        with ThreadPoolExecutor(n) as ex:
+            for _ in range(2):  # two rounds back to back on every context, no synchronisation in between
+                list(ex.map(lambda c: c.render(False), ctxs))
+        for k, c in enumerate(ctxs):
+            _cmp("context %d of %d in flight" % (k, n), c.download_equirect(), frame8k["got"])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_config5_second_frame_temporal(frame8k):
+    """BASELINE configs[4] shape: frame k+1 (world rotated 0.2 deg, the disc moved) regularised toward frame k's
+    device-resident flows and images (--prev_frame_data_dir semantics), at 8K."""
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    side, top, bottom = frame8k["frames"][1]
+    want, _ = of.render(side, top, bottom, use_prev=True, threaded=True)
+    ctx.upload_frame(side, top, bottom)
+    ctx.render(use_prev=True)
+    for i in (0, 9):
+        _cmp("flow_l_to_r t1 %d" % i, ctx.get_f32("flow_l_to_r", i), of.get_f32("flow_l_to_r", i))
+    for u in (0, 3):
+        _cmp("flow_pole t1 %d" % u, ctx.get_f32("flow_pole", u), of.get_f32("flow_pole", u))
+    _cmp("frame 2 (temporal)", ctx.download_equirect(), want)
