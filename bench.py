@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=16,
                     help="independent frames in flight per GPU (one context + HIP stream each); 1 = one frame at a time")
     ap.add_argument("--video-frames", type=int, default=32)
+    ap.add_argument("--throughput-mode", default="throughput", help="sweep mode of the in-flight contexts (A/B runs)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # hardware queues for the in-flight frames (read at HIP init)
@@ -157,7 +158,7 @@ def main():
     for k, c in enumerate(ctxs):
         c.upload_frame(*frames[k])  # inputs resident in HBM before the timed region
         if F > 1:
-            c.set_sweep_mode("throughput")  # several frames in flight: the kernel with the fewest instructions per pixel
+            c.set_sweep_mode(args.throughput_mode)  # several frames in flight: the kernel with the fewest instructions per pixel
 
     def sync(barrier=True):
         for c in ctxs:
@@ -295,7 +296,7 @@ def main():
                 "algorithmic_bytes_per_launch": per_launch_bytes, "note": note}
 
     # ---- isolated kernels: one context alone, throughput-mode kernel (the timed region's) and latency-mode kernel ----
-    tp_ms, tp_prof, _ = isolated("throughput", 2)
+    tp_ms, tp_prof, _ = isolated(args.throughput_mode, 2)
     roofline = sweep_roofline(
         tp_prof, "k_sweep_quad (PixFlow propagation sweeps, PixFlow.h:388-410)",
         "dominant kernel of the timed region, measured with ONE frame alone on the GPU (HIP events on the library's "

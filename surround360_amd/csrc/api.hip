@@ -466,7 +466,7 @@ int s360_sharpen(s360_ctx* c, uint8_t* bgr, int w, int h, float sharpening) {
   return guard(c, [&] {
     need(c && bgr && w > 1 && h > 1, "bad argument");
     const size_t n = (size_t)w * h;
-    c->op_a.ensure(n * 3); c->op_b.ensure(n * 4); c->op_c.ensure(n * 4); c->op_d.ensure(n * 3 * sizeof(float));
+    c->op_a.ensure(n * 3); c->op_b.ensure(n * 4); c->op_c.ensure(n * 4); c->op_d.ensure(sharpen_scratch_bytes(w, h));
     h2d(c, c->op_a.p, bgr, n * 3);
     launch_bgr_to_bgra(c->st, c->op_a.as<uint8_t>(), 3, c->op_b.as<uchar4>(), n);
     launch_sharpen(c->st, c->op_b.as<uchar4>(), c->op_c.as<uchar4>(), c->op_d.as<float>(), w, h, 1.0f + sharpening);
@@ -702,6 +702,7 @@ int s360_set_sweep_mode(s360_ctx* c, const char* mode) {
     const std::string m(mode);
     if (m == "latency") c->sweep_mode = 2;
     else if (m == "throughput") c->sweep_mode = 3;
+    else if (m == "throughput-mono") c->sweep_mode = 5;  // A/B while the one-lane-per-pixel kernel is being measured
     else throw Error(S360_ERR_INVALID_ARG, "sweep mode must be \"latency\" or \"throughput\"");
     if (c->flow) c->flow->set_sweep_mode(c->sweep_mode);
     if (c->flow_pole) c->flow_pole->set_sweep_mode(c->sweep_mode);

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, 
 //        single-channel plane, computed while the tile is loaded (PixFlow.h:356-366 without the intermediate image).
 // EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453). EPI 2: store the sweep record
 //        {I0x | NaN when the pixel is not updated, I0y, blurred.x, blurred.y} instead of the blurred flow.
-// Tile: 64x16 outputs by default. SB_TW x SB_TH = 32x32 is selectable for the 15x15 kernels (S360_SEPBLUR_TILE=32, an
-// A/B switch for the next measurement round): 29 KB of LDS instead of 35 KB and 1.44x instead of 1.9x row-pass halo work.
+// Tile: 64x16 outputs for the 3- and 5-tap kernels, 32x32 for the 15-tap ones (29 KB of LDS instead of 35 KB and 1.44x
+// instead of 1.9x row-pass halo work: blur15 + diffusion 100 -> 69 ms of summed kernel time per frame with 16 frames in flight).
 template <int R, int CN, int EPI, int SRC, int SB_TW = 64, int SB_TH = 16>
 __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                  size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
@@ -458,19 +458,13 @@ template <int R, int CN, int EPI, int SRC>
 static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w, int h, size_t bs, int B,
                              const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float4* rec) {
   dim3 blk(64, 4);
-  static const bool square = [] {
-    const char* e = std::getenv("S360_SEPBLUR_TILE");
-    return e && std::string(e) == "32";
-  }();
-  if constexpr (R == 7) {
-    if (square) {
-      dim3 grd((w + 31) / 32, (h + 31) / 32, B);
-      hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
-      return;
-    }
+  if constexpr (R == 7) {  // 15x15: 32x32 tile — 29 KB of LDS, 1.44x row-pass halo work (64x16: 35 KB, 1.9x; measured 30 % slower)
+    dim3 grd((w + 31) / 32, (h + 31) / 32, B);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
+  } else {
+    dim3 grd((w + 63) / 64, (h + 15) / 16, B);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
   }
-  dim3 grd((w + 63) / 64, (h + 15) / 16, B);
-  hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
 }
 void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
                     const BlurTaps& t) {

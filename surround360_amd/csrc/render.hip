@@ -640,7 +640,7 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
       uchar4* eye = F.pano[e].as<uchar4>();
       if (c->P.sharpening > 0.0) {
         F.sharpLp.ensure(en * sizeof(uchar4));
-        F.sharpBuf.ensure(en * 3 * sizeof(float));
+        F.sharpBuf.ensure(sharpen_scratch_bytes(W, H));
         launch_sharpen(st, eye, F.sharpLp.as<uchar4>(), F.sharpBuf.as<float>(), W, H, 1.0f + (float)c->P.sharpening);
       }
       if (resize) {

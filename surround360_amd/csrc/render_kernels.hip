@@ -8,6 +8,8 @@
 // SR/util/CvUtil.cpp:93-115, 140-157, 224-260, SR/util/Filter.h:40-127.
 #include "render_kernels.hpp"
 
+#include <algorithm>
+
 #include <stdexcept>
 
 #include "devmath.hpp"
@@ -889,70 +891,165 @@ __global__ __launch_bounds__(256) void k_pack_bgr(const uchar4* __restrict__ src
 __device__ __forceinline__ int wrap_i(int x, int r) { return x < 0 ? r + x : x >= r ? x - r : x; }
 __device__ __forceinline__ int refl_i(int x, int r) { return x < 0 ? -x : x >= r ? 2 * r - x - 2 : x; }
 __device__ __forceinline__ float clamp255(float v) { return v < 0.0f ? 0.0f : v > 255.0f ? 255.0f : v; }
-__global__ __launch_bounds__(64) void k_iir_rows(const uchar4* __restrict__ img, uchar4* __restrict__ lp,
-                                                 float* __restrict__ buf, int w, int h, float alpha) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= h) return;
-  const uchar4* R = img + (size_t)i * w;
-  float* B = buf + (size_t)i * w * 3;
-  uchar4 p = R[0];
-  float v0 = p.x, v1 = p.y, v2 = p.z;
-  for (int j = 1; j <= w; ++j) {
-    p = R[wrap_i(j, w)];
-    v0 = (float)p.x * (1.0f - alpha) + v0 * alpha;
-    v1 = (float)p.y * (1.0f - alpha) + v1 * alpha;
-    v2 = (float)p.z * (1.0f - alpha) + v2 * alpha;
-    float* b = B + (size_t)wrap_i(j - 1, w) * 3;
-    b[0] = v0; b[1] = v1; b[2] = v2;
-  }
-  for (int j = w - 2; j >= -1; --j) {
-    const float* b = B + (size_t)wrap_i(j, w) * 3;
-    v0 = b[0] * (1.0f - alpha) + v0 * alpha;
-    v1 = b[1] * (1.0f - alpha) + v1 * alpha;
-    v2 = b[2] * (1.0f - alpha) + v2 * alpha;
-    lp[(size_t)i * w + j + 1] = make_uchar4((unsigned char)clamp255(v0), (unsigned char)clamp255(v1),
-                                            (unsigned char)clamp255(v2), 255);
-  }
+// iirLowPass is a first-order recurrence v = ip*(1-alpha) + v*alpha along every row (then every column), forwards
+// and backwards: bit-exactness forbids re-associating it, so the parallelism is one chain per (row, channel) — 16 384
+// chains for the row pass of a 4096-row eye — and each chain is 2 x 8400 dependent steps. The kernels below keep a
+// chain in one lane (a wave = 16 chains x 4 channels; the alpha lane computes a value nobody reads), move the data in
+// tiles of 64 positions through LDS so that global memory is only touched with coalesced row segments (row pass) or
+// whole 64/256-byte runs per lane (column pass), and prefetch the next tile while the current one is computed. The
+// causal pass writes its float results (float4 per pixel) and each chain's final state; the anticausal pass reads them
+// back in reverse and writes the clamped 8-bit low pass — or, for the last pass, the sharpened pixel itself
+// (sharpenWithIirLowPass, Filter.h:93-127, fused: the low pass is only ever used there).
+constexpr int IIR_CH = 16;   // chains per wave
+constexpr int IIR_T = 64;    // positions per tile
+constexpr int IIR_LD = IIR_T + 1;  // padded LDS row: 16 chains hit 16 different banks
+struct IirGeom {
+  int n;        // chain length (ROWS: w, columns: h)
+  int nchains;  // ROWS: h, columns: w
+  int w;        // image row pitch in pixels
+};
+template <bool ROWS>
+__device__ __forceinline__ int iir_bnd(int x, int n) { return ROWS ? wrap_i(x, n) : refl_i(x, n); }
+template <bool ROWS>
+__device__ __forceinline__ size_t iir_px(const IirGeom& g, int chain, int pos) {
+  return ROWS ? (size_t)chain * g.w + pos : (size_t)pos * g.w + chain;
 }
-__global__ __launch_bounds__(64) void k_iir_cols(uchar4* __restrict__ lp, float* __restrict__ buf, int w, int h,
-                                                 float alpha) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= w) return;
-  uchar4 p = lp[j];
-  float v0 = p.x, v1 = p.y, v2 = p.z;
-  for (int i = 1; i <= h; ++i) {
-    p = lp[(size_t)refl_i(i, h) * w + j];
-    v0 = (float)p.x * (1.0f - alpha) + v0 * alpha;
-    v1 = (float)p.y * (1.0f - alpha) + v1 * alpha;
-    v2 = (float)p.z * (1.0f - alpha) + v2 * alpha;
-    float* b = buf + ((size_t)refl_i(i - 1, h) * w + j) * 3;
-    b[0] = v0; b[1] = v1; b[2] = v2;
-  }
-  for (int i = h - 2; i >= -1; --i) {
-    const float* b = buf + ((size_t)refl_i(i, h) * w + j) * 3;
-    v0 = b[0] * (1.0f - alpha) + v0 * alpha;
-    v1 = b[1] * (1.0f - alpha) + v1 * alpha;
-    v2 = b[2] * (1.0f - alpha) + v2 * alpha;
-    lp[(size_t)(i + 1) * w + j] = make_uchar4((unsigned char)clamp255(v0), (unsigned char)clamp255(v1),
-                                              (unsigned char)clamp255(v2), 255);
-  }
-}
-__global__ __launch_bounds__(256) void k_unsharp(uchar4* __restrict__ img, const uchar4* __restrict__ lp, size_t n,
-                                                 float amount) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uchar4 p = img[i];
-  const uchar4 l = lp[i];
-  auto f = [&](unsigned char pc, unsigned char lc) -> unsigned char {
-    const float lf = (float)lc;
-    const float hp = (float)pc - lf;
-    // noise coring: 1 - expf(-(hp^2 * 100)). hp is an integer: the factor is exactly 0 for hp == 0 and
-    // exactly 1.0f otherwise (expf(-100) < 2^-24), so no transcendental is needed on the device.
-    const float ng = hp == 0.0f ? 0.0f : 1.0f;
-    return (unsigned char)clamp255(lf + hp * ng * amount);
+
+// Causal half: B[e] = v after consuming X[bnd(e+1)], e = 0..n-1, v0 = X[0]; carry[chain] = final v.
+template <bool ROWS>
+__global__ __launch_bounds__(64) void k_iir_causal(const uchar4* __restrict__ X, float4* __restrict__ Bf,
+                                                   float4* __restrict__ carry, IirGeom g, float alpha) {
+  __shared__ unsigned s_in[IIR_CH * IIR_LD];
+  __shared__ float s_out[IIR_CH * IIR_LD * 4];
+  const int lane = threadIdx.x, k = lane >> 2, c = lane & 3;
+  const int chain0 = blockIdx.x * IIR_CH;
+  const int ntiles = (g.n + IIR_T - 1) / IIR_T;
+  unsigned pre[IIR_CH];
+  auto load_tile = [&](int t) {  // X at positions bnd(e + 1), e = 64 t + lane (ROWS) / e = 64 t + lane for all 16 chains (columns)
+    const int e = min(t * IIR_T + lane, g.n - 1);
+    const int pos = iir_bnd<ROWS>(e + 1, g.n);
+    if (ROWS) {
+#pragma unroll
+      for (int kk = 0; kk < IIR_CH; ++kk)
+        pre[kk] = reinterpret_cast<const unsigned*>(X)[iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos)];
+    } else {
+      const unsigned* row = reinterpret_cast<const unsigned*>(X) + (size_t)pos * g.w;
+#pragma unroll
+      for (int kk = 0; kk < IIR_CH; ++kk) pre[kk] = row[min(chain0 + kk, g.nchains - 1)];
+    }
   };
-  p.x = f(p.x, l.x); p.y = f(p.y, l.y); p.z = f(p.z, l.z);
-  img[i] = p;
+  const float am = 1.0f - alpha;
+  float v;
+  {
+    const uchar4 p0 = X[iir_px<ROWS>(g, min(chain0 + k, g.nchains - 1), 0)];
+    v = c == 0 ? (float)p0.x : c == 1 ? (float)p0.y : c == 2 ? (float)p0.z : (float)p0.w;
+  }
+  load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+    for (int kk = 0; kk < IIR_CH; ++kk) s_in[kk * IIR_LD + lane] = pre[kk];
+    if (t + 1 < ntiles) load_tile(t + 1);
+    const int cnt = min(IIR_T, g.n - t * IIR_T);
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(s_in) + (size_t)k * IIR_LD * 4 + c;
+    float* so = s_out + (size_t)k * IIR_LD * 4 + c;
+    int j = 0;
+    for (; j + 8 <= cnt; j += 8) {  // 8 inputs fetched together: the dependent chain is then 2 VALU ops per step
+      float ip[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ip[q] = (float)sb[(j + q) * 4] * am;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v = ip[q] + v * alpha;  // lerp(ip, v, alpha) = ip*(1-alpha) + v*alpha, MathUtil.h
+        so[(j + q) * 4] = v;
+      }
+    }
+    for (; j < cnt; ++j) {
+      v = (float)sb[j * 4] * am + v * alpha;
+      so[j * 4] = v;
+    }
+    // store the tile's float results: ROWS: 1 KB per chain row; columns: 256 B per position
+    const int e = t * IIR_T + lane;
+    if (e < g.n) {
+#pragma unroll
+      for (int kk = 0; kk < IIR_CH; ++kk) {
+        if (chain0 + kk < g.nchains) {
+          const float4 o = *reinterpret_cast<const float4*>(s_out + ((size_t)kk * IIR_LD + lane) * 4);
+          Bf[iir_px<ROWS>(g, chain0 + kk, e)] = o;
+        }
+      }
+    }
+  }
+  if (chain0 + k < g.nchains) reinterpret_cast<float*>(carry)[(size_t)(chain0 + k) * 4 + c] = v;
+}
+
+// Anticausal half: for e = n-1 .. 0: v = lerp(B[bnd(e-1)], v); OUT[e] = clamp(v). FUSE: OUT is the unsharp mask of
+// `img` against that low-pass value, written in place.
+template <bool ROWS, bool FUSE>
+__global__ __launch_bounds__(64) void k_iir_anticausal(const float4* __restrict__ Bf, const float4* __restrict__ carry,
+                                                       uchar4* __restrict__ out, IirGeom g, float alpha, float amount) {
+  __shared__ float s_in[IIR_CH * IIR_LD * 4];
+  __shared__ unsigned s_out[IIR_CH * IIR_LD];
+  const int lane = threadIdx.x, k = lane >> 2, c = lane & 3;
+  const int chain0 = blockIdx.x * IIR_CH;
+  const int ntiles = (g.n + IIR_T - 1) / IIR_T;
+  float4 pre[IIR_CH];
+  auto load_tile = [&](int t) {  // B at positions bnd(e - 1)
+    const int e = min(t * IIR_T + lane, g.n - 1);
+    const int pos = iir_bnd<ROWS>(e - 1, g.n);
+#pragma unroll
+    for (int kk = 0; kk < IIR_CH; ++kk) pre[kk] = Bf[iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos)];
+  };
+  const float am = 1.0f - alpha;
+  float v = reinterpret_cast<const float*>(carry)[(size_t)min(chain0 + k, g.nchains - 1) * 4 + c];
+  load_tile(ntiles - 1);
+  for (int t = ntiles - 1; t >= 0; --t) {
+#pragma unroll
+    for (int kk = 0; kk < IIR_CH; ++kk) *reinterpret_cast<float4*>(s_in + ((size_t)kk * IIR_LD + lane) * 4) = pre[kk];
+    if (t > 0) load_tile(t - 1);
+    const int cnt = min(IIR_T, g.n - t * IIR_T);
+    const float* si = s_in + (size_t)k * IIR_LD * 4 + c;
+    unsigned char* so = reinterpret_cast<unsigned char*>(s_out) + (size_t)k * IIR_LD * 4 + c;
+    int j = cnt - 1;
+    for (; j >= 7; j -= 8) {
+      float ip[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ip[q] = si[(j - q) * 4] * am;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v = ip[q] + v * alpha;
+        so[(j - q) * 4] = c == 3 ? (unsigned char)255 : (unsigned char)clamp255(v);
+      }
+    }
+    for (; j >= 0; --j) {
+      v = si[j * 4] * am + v * alpha;
+      so[j * 4] = c == 3 ? (unsigned char)255 : (unsigned char)clamp255(v);
+    }
+    const int e = t * IIR_T + lane;
+    if (e < g.n) {
+#pragma unroll
+      for (int kk = 0; kk < IIR_CH; ++kk) {
+        if (chain0 + kk < g.nchains) {
+          const unsigned lw = s_out[kk * IIR_LD + lane];
+          const size_t o = iir_px<ROWS>(g, chain0 + kk, e);
+          if (FUSE) {
+            uchar4 p = out[o];
+            auto f = [&](unsigned char pc, unsigned lc) -> unsigned char {
+              const float lf = (float)lc;
+              const float hp = (float)pc - lf;
+              // noise coring: 1 - expf(-(hp^2 * 100)). hp is an integer: the factor is exactly 0 for hp == 0 and
+              // exactly 1.0f otherwise (expf(-100) < 2^-24), so no transcendental is needed on the device.
+              const float ng = hp == 0.0f ? 0.0f : 1.0f;
+              return (unsigned char)clamp255(lf + hp * ng * amount);
+            };
+            p.x = f(p.x, lw & 255u); p.y = f(p.y, (lw >> 8) & 255u); p.z = f(p.z, (lw >> 16) & 255u);
+            out[o] = p;
+          } else {
+            reinterpret_cast<unsigned*>(out)[o] = lw;
+          }
+        }
+      }
+    }
+  }
 }
 
 // ==========================================================================================
@@ -1061,12 +1158,18 @@ void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* d
   const size_t n = (size_t)w * h;
   hipLaunchKernelGGL(k_pack_bgr, dim3(cdiv(n, 256)), dim3(256), 0, st, src, n, dst);
 }
+// iirLowPass (wrap horizontally, reflect vertically) + sharpenWithIirLowPass on one eye, in place (TRSP:688-696).
+// scratch: w*h float4 + max(w,h) float4 (the chains' carried state).
+size_t sharpen_scratch_bytes(int w, int h) { return ((size_t)w * h + (size_t)std::max(w, h)) * sizeof(float4); }
 void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount) {
   const float alpha = powf(0.25f, 1.0f / 4.0f);  // host libm, Filter.h:49
-  hipLaunchKernelGGL(k_iir_rows, dim3(cdiv(h, 64)), dim3(64), 0, st, img, lp, scratch, w, h, alpha);
-  hipLaunchKernelGGL(k_iir_cols, dim3(cdiv(w, 64)), dim3(64), 0, st, lp, scratch, w, h, alpha);
-  const size_t n = (size_t)w * h;
-  hipLaunchKernelGGL(k_unsharp, dim3(cdiv(n, 256)), dim3(256), 0, st, img, lp, n, amount);
+  float4* buf = reinterpret_cast<float4*>(scratch);
+  float4* carry = buf + (size_t)w * h;
+  const IirGeom gr{w, h, w}, gc{h, w, w};
+  hipLaunchKernelGGL((k_iir_causal<true>), dim3(cdiv(h, IIR_CH)), dim3(64), 0, st, img, buf, carry, gr, alpha);
+  hipLaunchKernelGGL((k_iir_anticausal<true, false>), dim3(cdiv(h, IIR_CH)), dim3(64), 0, st, buf, carry, lp, gr, alpha, amount);
+  hipLaunchKernelGGL((k_iir_causal<false>), dim3(cdiv(w, IIR_CH)), dim3(64), 0, st, lp, buf, carry, gc, alpha);
+  hipLaunchKernelGGL((k_iir_anticausal<false, true>), dim3(cdiv(w, IIR_CH)), dim3(64), 0, st, buf, carry, img, gc, alpha, amount);
 }
 
 }  // namespace s360

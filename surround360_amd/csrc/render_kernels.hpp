@@ -81,6 +81,7 @@ void launch_circle_alpha(hipStream_t st, const uchar4* src, const uint8_t* red /
 void launch_pole_removal_combine(hipStream_t st, uchar4* bottom, const uchar4* warped2, size_t n);
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst);
 // sharpen (Filter.h:40-127) on BGRA in place, lp scratch same size
+size_t sharpen_scratch_bytes(int w, int h);
 void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount);
 
 }  // namespace s360

@@ -79,14 +79,14 @@ def test_identical_images_near_zero_flow(ctx):
     assert np.abs(f).max() < 0.5
 
 
-@pytest.mark.parametrize("mode", ["throughput", "latency"])
+@pytest.mark.parametrize("mode", ["throughput", "throughput-mono", "latency"])
 def test_sweep_modes_bit_exact(gpu_rig, oracle, mode):
     """Both sweep kernels (lockstep = latency, quad = throughput) reproduce the raster-order sweeps exactly,
     including sizes that are not multiples of the band height and the temporal path."""
     c = R.Context(gpu_rig, R.make_params(eqr_width=1008, eqr_height=504))
     c.set_sweep_mode(mode)
     try:
-        for (w, h, seed) in [(297, 444, 2), (333, 257, 5), (160, 130, 9)]:
+        for (w, h, seed) in [(297, 444, 2), (333, 257, 5), (160, 130, 9), (520, 300, 12)]:
             i0, i1 = synth.flow_pair(w, h, seed=seed)
             got = c.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
             want = oracle.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")

@@ -135,10 +135,12 @@ def test_feather_alpha_channel(env, oracle, w, h, e):
     _same("featherAlphaChannel e=%d" % e, env["ctx"].feather_alpha_channel(img, e), oracle.feather_alpha_channel(img, e))
 
 
-@pytest.mark.parametrize("amount", [0.25, 1.0])
-def test_sharpen(env, oracle, amount):
+@pytest.mark.parametrize("amount,h,w", [(0.25, 96, 200), (1.0, 96, 200), (0.25, 131, 203), (0.25, 70, 61)])
+def test_sharpen(env, oracle, amount, h, w):
+    """iirLowPass + sharpenWithIirLowPass (Filter.h:40-127); sizes that are not multiples of the kernels' 64-position
+    tiles, 8-step groups and 16-chain waves."""
     rng = np.random.default_rng(5)
-    img = _noise(rng, 96, 200, 3)
+    img = _noise(rng, h, w, 3)
     _same("sharpen", env["ctx"].sharpen(img, amount), oracle.sharpen(img, amount))
 
 

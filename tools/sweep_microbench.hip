@@ -13,14 +13,14 @@
 #include "../surround360_amd/csrc/flow_kernels.hip"
 #include "../surround360_amd/csrc/sweep_lock.hip"
 #include "../surround360_amd/csrc/sweep_quad.hip"
-#include "../surround360_amd/csrc/sweep_tile.hip"
+#include "../surround360_amd/csrc/sweep_mono.hip"
 
 using namespace s360;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 static unsigned long long g_ts[8];
-static float run(int w, int h, int B, int nw, bool fast, int mode /*2 lock, 1 hex*/, int reps) {
+static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad, 5 mono*/, int reps) {
   const size_t n = (size_t)w * h;
   std::mt19937 rng(1234);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -40,7 +40,7 @@ static float run(int w, int h, int B, int nw, bool fast, int mode /*2 lock, 1 he
   CK(hipMalloc(&dG, hG.size() * 4));
   CK(hipMalloc(&drec, hrec.size() * 4));
   CK(hipMalloc(&dflow, hflow.size() * 4));
-  const size_t hb = std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4));
+  const size_t hb = std::max(std::max(sweep_mono_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4)), sweep_quad_handoff_bytes(w, h, B));
   CK(hipMalloc(&hand, hb));
   CK(hipMalloc(&err, 8));
   CK(hipMemset(err, 0, 8));
@@ -60,10 +60,13 @@ static float run(int w, int h, int B, int nw, bool fast, int mode /*2 lock, 1 he
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b2));
   auto once = [&](int dir) {
+    CK(hipMemsetAsync(hand, 0xFF, hb, st));  // (the library resets one arena per flow call instead)
     if (mode == 2)
-      launch_sweep_lock(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, nw, fast);
+      launch_sweep_lock(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
+    else if (mode == 3)
+      launch_sweep_quad(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
     else
-      launch_sweep_band(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc);
+      launch_sweep_mono(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
   };
   once(1);
   CK(hipStreamSynchronize(st));
@@ -95,10 +98,10 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
     hflow[2 * i + 0] = hrec[4 * i + 2] + 0.3f * U(rng); hflow[2 * i + 1] = hrec[4 * i + 3] + 0.3f * U(rng);
   }
   std::vector<float*> dG(NS), drec(NS), dflow(NS), dA(NS), dbl(NS);
-  std::vector<void*> hand(NS), dRecS(NS), dOutS(NS);
+  std::vector<void*> hand(NS);
   std::vector<unsigned*> err(NS);
   std::vector<hipStream_t> st(NS);
-  const size_t hb = std::max(std::max(sweep_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4)), sweep_quad_handoff_bytes(w, h, B));
+  const size_t hb = std::max(std::max(sweep_mono_handoff_bytes(w, h, B), sweep_lock_handoff_bytes(w, h, B, 4)), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
     CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
@@ -109,7 +112,6 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
       CK(hipMemcpy(dA[k], ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dbl[k], bl.data(), bl.size() * 4, hipMemcpyHostToDevice));
     }
-    CK(hipMalloc(&dRecS[k], sweep_tile_rec_bytes(w, h, B))); CK(hipMalloc(&dOutS[k], sweep_tile_out_bytes(w, h, B)));
     CK(hipMemcpy(dG[k], hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(drec[k], hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dflow[k], hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
@@ -121,14 +123,13 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<float> d{0.001f, (float)w, (float)h};
   sweep_verify_divisors(st[0], d);
   auto once = [&](int k, int dir) {
-    if (mode == 4)
-      launch_sweep_tile(st[k], (const float2*)dG[k], dA[k], (const float2*)dbl[k], (float2*)dflow[k], dRecS[k], dOutS[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+    CK(hipMemsetAsync(hand[k], 0xFF, hb, st[k]));
+    if (mode == 5)
+      launch_sweep_mono(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
     else if (mode == 3)
       launch_sweep_quad(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
-    else if (mode == 2)
-      launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, 4, true);
     else
-      launch_sweep_band(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc);
+      launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
   };
   for (int k = 0; k < NS; ++k) once(k, 1);
   CK(hipDeviceSynchronize());
@@ -137,7 +138,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
     for (int k = 0; k < NS; ++k) once(k, r & 1 ? -1 : 1);
   CK(hipDeviceSynchronize());
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  for (int k = 0; k < NS; ++k) { hipFree(dG[k]); hipFree(drec[k]); hipFree(dflow[k]); hipFree(hand[k]); hipFree(err[k]); hipFree(dA[k]); hipFree(dbl[k]); hipFree(dRecS[k]); hipFree(dOutS[k]); hipStreamDestroy(st[k]); }
+  for (int k = 0; k < NS; ++k) { hipFree(dG[k]); hipFree(drec[k]); hipFree(dflow[k]); hipFree(hand[k]); hipFree(err[k]); hipFree(dA[k]); hipFree(dbl[k]); hipStreamDestroy(st[k]); }
   return (float)((double)NS * reps * B * n / sec / 1e9);
 }
 
@@ -203,9 +204,9 @@ int main(int argc, char** argv) {
     struct C2 { int w, h, B; const char* name; };
     const C2 cs[] = {{5040, 1052, 4, "polar L0"}, {607, 884, 28, "side L0"}, {1153, 240, 4, "polar L14"}, {140, 203, 28, "side L14"}};
     for (const C2& c : cs)
-      for (int ns : {1, 2, 4, 8}) {
-        printf("%-10s B=%2d streams=%d : lock %7.2f   quad %7.2f   tile %7.2f\n", c.name, c.B, ns,
-               throughput(c.w, c.h, c.B, 2, ns, 4), throughput(c.w, c.h, c.B, 3, ns, 4), throughput(c.w, c.h, c.B, 4, ns, 4));
+      for (int ns : {1, 4, 16}) {
+        printf("%-10s B=%2d streams=%d : lock %7.2f   quad %7.2f   mono %7.2f\n", c.name, c.B, ns,
+               throughput(c.w, c.h, c.B, 2, ns, 4), throughput(c.w, c.h, c.B, 3, ns, 4), throughput(c.w, c.h, c.B, 5, ns, 4));
         fflush(stdout);
       }
     return 0;
@@ -213,37 +214,12 @@ int main(int argc, char** argv) {
   struct Cfg { int w, h, B; const char* name; };
   const Cfg cfgs[] = {{127, 27, 4, "polar L35"}, {613, 128, 4, "polar L20"}, {5040, 1052, 4, "polar L0"},
                       {27, 38, 28, "side L30"}, {140, 203, 28, "side L14"}, {607, 884, 28, "side L0"}};
-  const int dbgs[] = {0, 128, 3, 15, 47, 31};
-  printf("%-10s %6s %6s %3s | %8s |", "config", "w", "h", "B", "hex16");
-  for (int d : dbgs) printf(" lock d%-2d |", d);
-  printf(" lock ieee | lock nw8 |  (us per launch; steps = w+3+15)\n");
+  printf("%-10s %6s %6s %3s | %9s | %9s | %9s | %9s |  us per launch of one flow batch alone\n", "config", "w", "h", "B", "lock", "lock ieee", "quad", "mono");
   for (const Cfg& c : cfgs) {
     const int reps = c.w > 1000 ? 6 : 20;
-    printf("%-10s %6d %6d %3d |", c.name, c.w, c.h, c.B);
-    unsetenv("S360_SWEEP_DBG");
-    printf(" %8.1f |", run(c.w, c.h, c.B, 4, true, 1, reps));
-    for (int d : dbgs) {
-      char buf[16];
-      snprintf(buf, sizeof buf, "%d", d);
-      setenv("S360_SWEEP_DBG", buf, 1);
-      printf(" %8.1f |", run(c.w, c.h, c.B, 4, true, 2, reps));
-    }
-    unsetenv("S360_SWEEP_DBG");
-    printf(" %9.1f |", run(c.w, c.h, c.B, 4, false, 2, reps));
-    printf(" %8.1f |", run(c.w, c.h, c.B, 8, true, 2, reps));
-    printf("  us/step(d0) %.3f\n", run(c.w, c.h, c.B, 4, true, 2, reps) / (c.w + 18));
-#ifdef S360_SWEEP_TIMING
-    for (int d : {0, 47, 111}) {
-      char buf[16];
-      snprintf(buf, sizeof buf, "%d", d);
-      setenv("S360_SWEEP_DBG", buf, 1);
-      run(c.w, c.h, c.B, 4, true, 2, 1);
-      const double st = c.w + 3;
-      printf("    d%-2d cycles/step of wave 0: loop-top %.0f | pre-gather %.0f | barrier %.0f | preload+gather wait %.0f | error %.0f | select+grad %.0f\n", d,
-             g_ts[0] / st, g_ts[1] / st, g_ts[2] / st, g_ts[3] / st, g_ts[4] / st, g_ts[5] / st);
-    }
-#endif
-    unsetenv("S360_SWEEP_DBG");
+    printf("%-10s %6d %6d %3d | %9.1f | %9.1f | %9.1f | %9.1f |  lock us/step %.3f\n", c.name, c.w, c.h, c.B,
+           run(c.w, c.h, c.B, true, 2, reps), run(c.w, c.h, c.B, false, 2, reps), run(c.w, c.h, c.B, true, 3, reps),
+           run(c.w, c.h, c.B, true, 5, reps), run(c.w, c.h, c.B, true, 2, reps) / (c.w + 18));
     fflush(stdout);
   }
   return 0;
