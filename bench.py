@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="timed region + check + roofline only (profiling runs)")
     ap.add_argument("--inflight", type=int, default=16,
                     help="independent frames in flight per GPU (one context + HIP stream each); 1 = one frame at a time")
+    ap.add_argument("--slots", type=int, default=1,
+                    help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
+                         "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
     ap.add_argument("--video-frames", type=int, default=32)
     ap.add_argument("--throughput-mode", default="throughput", help="sweep mode of the in-flight contexts (A/B runs)")
     args = ap.parse_args()
@@ -143,21 +146,27 @@ def main():
     rig = R.RigDescription(RIG)
     P = rig.get_side_camera_count()
     F = max(1, args.inflight)
+    S = max(1, args.slots)
     # ---- synthetic stream: one seeded equirect world (noise + near objects at 2 m / 5 m), rendered
     # through the 17 rig cameras on the GPU; frame k = world rotated by 0.2 deg * k, one disc moving 0.5 deg per frame.
     # (The world is 8192x4096: the 16384x8192 of §8d needs 3 GB for the texture + depth alone; stated in `data`.)
     n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 2)
     wtex = synth.World(4096, seed=360 + rank, device=dev)
     rr = synth.RigRenderer(RIG, wtex, 2048)
-    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F, n_video))]
+    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_video))]
     del rr, wtex
     torch.cuda.empty_cache()
 
     ctxs = [R.Context(rig, R.make_params(**flags), device=local_rank) for _ in range(F)]
     ctx = ctxs[0]
     for k, c in enumerate(ctxs):
-        c.upload_frame(*frames[k])  # inputs resident in HBM before the timed region
-        if F > 1:
+        if S > 1:
+            c.set_frame_slots(S)
+        for j in range(S):
+            if S > 1:
+                c.select_frame_slot(j)
+            c.upload_frame(*frames[k * S + j])  # inputs resident in HBM before the timed region
+        if F * S > 1:
             c.set_sweep_mode(args.throughput_mode)  # several frames in flight: the kernel with the fewest instructions per pixel
 
     def sync(barrier=True):
@@ -178,7 +187,10 @@ def main():
 
     def enqueue(k):
         t = time.perf_counter()
-        ctxs[k].render(False)  # asynchronous enqueue on that context's stream
+        if S > 1:
+            ctxs[k].render_batch(False)  # S frames, one launch sequence
+        else:
+            ctxs[k].render(False)  # asynchronous enqueue on that context's stream
         enqueue_s[k] += time.perf_counter() - t
 
     def step():
@@ -203,7 +215,7 @@ def main():
             step()
         drain(barrier=False)
         t = time.perf_counter()
-        ctxs[0].render(False)
+        enqueue(0)
         base_enqueue = time.perf_counter() - t  # one thread, idle GPU queues
         sync(barrier=False)
         t_settle = time.perf_counter()
@@ -240,17 +252,36 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    enqueue_ms_per_frame = 1e3 * sum(enqueue_s) / max(args.steps, 1)
+    enqueue_ms_per_frame = 1e3 * sum(enqueue_s) / max(args.steps * S, 1)
 
-    # ---- check of the timed region: every in-flight context against ONE context rendering the same inputs alone ----
-    inflight_out = [c.download_equirect() for c in ctxs]
+    # ---- check of the timed region: every in-flight frame against ONE context rendering the same inputs alone ----
+    inflight_out = []
+    for c in ctxs:
+        for j in range(S):
+            if S > 1:
+                c.select_frame_slot(j)
+            inflight_out.append(c.download_equirect())
     for c in ctxs[1:]:
         c.close()
     del ctxs[1:]
+    batched_alone = None
+    if S > 1:  # one batched context alone on the GPU: isolated durations of launches that hold S frames' flows
+        ctx.render_batch(False)
+        sync(barrier=False)
+        ctx.profile_enable(True)
+        tb = time.perf_counter()
+        for _ in range(2):
+            ctx.render_batch(False)
+        sync(barrier=False)
+        batched_alone = {"ms_per_batch": 1e3 * (time.perf_counter() - tb) / 2,
+                         "prof": {k: (v[0] / 2, v[1] / 2) for k, v in ctx.profile_get().items()}}
+        ctx.profile_enable(False)
+        ctx.select_frame_slot(0)
+        ctx.set_frame_slots(1)
     ctx.set_sweep_mode("latency")
     mism = []
     single0 = None
-    for k in range(F):
+    for k in range(F * S):
         ctx.upload_frame(*frames[k])
         ctx.render(False)
         alone = ctx.download_equirect()
@@ -258,9 +289,9 @@ def main():
             single0 = alone
         if not np.array_equal(alone, inflight_out[k]):
             mism.append(k)
-    checked = {"checked": not mism, "checked_contexts": F, "mismatching_contexts": mism,
-               "check": "equirect of every in-flight context (throughput sweep kernel) byte-compared with one context "
-                        "rendering the same inputs alone (latency sweep kernel)"}
+    checked = {"checked": not mism, "checked_frames": F * S, "mismatching_frames": mism,
+               "check": "equirect of every in-flight frame (throughput sweep kernel; %d context(s) x %d slot(s)) byte-compared "
+                        "with one context rendering the same inputs alone (latency sweep kernel)" % (F, S)}
     del inflight_out
     ctx.upload_frame(*frames[0])
 
@@ -304,9 +335,18 @@ def main():
         "of the launch's 28 side or 4 pole flows) / average launch duration. A dependency-latency-bound wavefront "
         "kernel (DESIGN.md §5): one launch is a serial chain of w+h diagonal steps; `aggregate_frac` is the same bytes "
         "over the wall time of the timed region, where launches of up to %d frames overlap" % F)
-    roofline["aggregate_frac"] = bytes_per_frame * args.steps / dt / 1e9 / HBM_PEAK_GBS
-    roofline["aggregate_GBps"] = bytes_per_frame * args.steps / dt / 1e9
-    roofline["us_per_diagonal_step"] = None
+    roofline["aggregate_frac"] = bytes_per_frame * args.steps * S / dt / 1e9 / HBM_PEAK_GBS
+    roofline["aggregate_GBps"] = bytes_per_frame * args.steps * S / dt / 1e9
+    if batched_alone:
+        bms, bl = batched_alone["prof"].get("flow_sweep", (0.0, 0))
+        per_launch = S * bytes_per_frame / max(bl, 1)
+        ach = per_launch / (bms / max(bl, 1) * 1e-3) / 1e9 if bms > 0 else 0.0
+        roofline.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": bms / max(bl, 1),
+                         "launches_per_frame": bl / S, "algorithmic_bytes_per_launch": per_launch,
+                         "frames_per_launch": S, "batch_alone_ms": batched_alone["ms_per_batch"],
+                         "batch_alone_ms_per_frame": batched_alone["ms_per_batch"] / S,
+                         "batch_alone_kernel_ms_per_frame": {k: round(v[0] / S, 3) for k, v in sorted(
+                             batched_alone["prof"].items(), key=lambda kv: -kv[1][0])}})
     traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
     if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
         try:
@@ -317,7 +357,7 @@ def main():
 
     out = {
         "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
-        "value": world * args.steps / dt,
+        "value": world * args.steps * S / dt,
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -333,9 +373,10 @@ def main():
                                "8192x8192, top+bottom poles, pixflow_low, sharpening 0",
                    "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
                                   "(one context + HIP stream each), no data-path collective" % (world, F),
-                   "frames_in_flight": F, "rccl_ranks": world},
+                   "frames_in_flight": F * S, "contexts": F, "slots_per_context": S, "frames_per_step": S,
+                   "rccl_ranks": world},
         "roofline": roofline,
-        "kernel_ms_per_frame_in_flight": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "kernel_ms_per_frame_in_flight": {k: round(v[0] / (args.steps * S), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         "host": {"submit_threads": F, "enqueue_ms_per_frame": enqueue_ms_per_frame,
                  "settle_batches_before_warmup": settle["batches"], "settle_seconds": round(settle["seconds"], 2)},
     }
@@ -401,14 +442,15 @@ def main():
                 "warp_blend_roofline": wb, "flow_stencil_roofline": fs,
                 "throughput_kernel_alone_ms": tp_ms}
         else:
-            ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-            strips = parallel.strips_tensor(ctx, dev)
+            # the library's own RCCL communicator: rank 0 creates the id, torch.distributed only carries the 128 bytes
+            ids = [R.Context.comm_get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init_rank(ids[0], rank, world)
             ctx.set_sweep_mode("latency")
 
             def sharded():
                 ctx.render_pairs(p0, p1, False)
-                with torch.cuda.stream(ext):
-                    parallel.gather_strips(strips, bounds, rank, world, 0)
+                ctx.gather_strips(bounds, 0)  # grouped ncclSend/ncclRecv on the context stream (comm.cpp)
                 if rank == 0:
                     ctx.finish(15, False)
             sharded()
@@ -426,8 +468,9 @@ def main():
             if rank == 0:
                 ok = bool(np.array_equal(ctx.download_equirect(), single0))
             out["single_frame"] = {
-                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), ONE RCCL exchange gathering the "
-                        "strips on rank 0, which runs the 4 pole units and the composite" % (world, bounds),
+                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), ONE native RCCL exchange (grouped "
+                        "ncclSend/ncclRecv, s360_frame_gather_strips) gathering the strips on rank 0, which runs the 4 pole "
+                        "units and the composite" % (world, bounds),
                 "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9), "rccl_ranks": world,
                 "equals_single_gpu_frame": ok}
 

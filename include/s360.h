@@ -220,6 +220,41 @@ int s360_frame_set_prev_pole(s360_ctx* ctx, int unit, const float* flow, const u
 int s360_frame_set_prev_pole_removal(s360_ctx* ctx, const float* flow, const uint8_t* bottom_image_bgra,
                                      const uint8_t* bottom_image2_bgra, int w, int h);
 
+/* ---- frame slots: several independent frames through ONE launch sequence ----------------------------
+ * The reference renders one frame per process and scales out by running processes side by side. On one MI355X a single
+ * frame cannot fill the chip (PixFlow's sweeps are raster-order recurrences), so independent frames — the streams of a
+ * multi-stream job, or the segments of an offline batch — are given to one context as slots: s360_set_frame_slots(n),
+ * then per slot s360_select_frame_slot(k) + the usual uploads (and later getters / downloads), and ONE
+ * s360_frame_render_batch renders all of them: per-frame kernels slot by slot, the side flows of every slot in one
+ * batch of the flow kernels (n x 28 flows per launch), the pole flows of every slot in another (n x 4). Every slot's
+ * result equals s360_frame_render on it. use_prev applies each slot's own device-resident temporal state (a batch
+ * uses it only if every slot has one). */
+int s360_set_frame_slots(s360_ctx* ctx, int n);
+int s360_select_frame_slot(s360_ctx* ctx, int k);
+int s360_frame_render_batch(s360_ctx* ctx, int use_prev);
+
+/* ---- multi-GPU: one frame sharded by side pairs, ONE RCCL exchange ------------------
+ * Replaces the per-pair thread fan-out + join + stackHorizontal of TRSP:320-335, 354-384 when the pairs of a frame are
+ * rendered on several GPUs: rank r renders the contiguous block of pairs [bounds[r], bounds[r+1]) with
+ * s360_frame_render_pairs, s360_frame_gather_strips moves every block into the root's strip buffers (grouped
+ * ncclSend/ncclRecv over xGMI, enqueued on s360_stream(): no host synchronisation), the root runs s360_frame_finish.
+ * One context per rank and per GPU. Either one process per GPU (rank 0 calls s360_comm_get_unique_id, the host
+ * distributes the 128 bytes, every rank calls s360_comm_init_rank) or one process driving all GPUs
+ * (s360_comm_init_all over one context per device, then one host thread per context for the collective call). */
+#define S360_COMM_ID_BYTES 128
+int s360_comm_get_unique_id(void* id_out /* S360_COMM_ID_BYTES */);
+int s360_comm_init_rank(s360_ctx* ctx, const void* id, int rank, int nranks);
+int s360_comm_init_all(s360_ctx* const* ctxs, int n);
+int s360_comm_destroy(s360_ctx* ctx);
+/* bounds: nranks + 1 non-decreasing pair indices from 0 to n_side. */
+int s360_frame_gather_strips(s360_ctx* ctx, const int* bounds, int root);
+/* Self-test for single-GPU boxes: one grouped ncclSend + ncclRecv of this rank to itself, eye-0 strip of pair
+ * src_pair into the slot of dst_pair, on s360_stream(). */
+int s360_comm_loopback(s360_ctx* ctx, int src_pair, int dst_pair);
+/* Declares the block of pairs [pair_begin, pair_end) this context renders BEFORE previous-frame state is handed in with
+ * s360_frame_set_prev_side (which then only accepts pairs of the block). Default: all pairs. */
+int s360_frame_set_partition(s360_ctx* ctx, int pair_begin, int pair_end);
+
 /* Keep copies of the eye panoramas as they are before the pole composite ("side_pano_l/r"); costs two
  * device copies per frame, off by default. */
 int s360_set_keep_intermediates(s360_ctx* ctx, int on);

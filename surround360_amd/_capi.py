@@ -56,6 +56,9 @@ SYMBOLS = [
     "s360_frame_set_prev_side", "s360_frame_set_prev_pole", "s360_frame_strip_ptr", "s360_frame_finish", "s360_frame_download_equirect", "s360_frame_equirect_dev",
     "s360_frame_cubemap", "s360_frame_get_u8", "s360_frame_get_f32", "s360_set_keep_intermediates", "s360_set_sweep_mode", "s360_set_frame_pipelining", "s360_debug_flow_levels",
     "s360_profile_enable", "s360_profile_get", "s360_save_flow_to_file", "s360_read_flow_from_file",
+    "s360_comm_get_unique_id", "s360_comm_init_rank", "s360_comm_init_all", "s360_comm_destroy",
+    "s360_frame_gather_strips", "s360_comm_loopback", "s360_frame_set_partition",
+    "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch",
 ]
 
 _lib = None

@@ -1,5 +1,6 @@
 // api.hip — the C ABI of libs360 (include/s360.h). Thin: argument checks, host<->device copies for
 // the operator-level calls, exception -> error-code translation. No CPU fallback anywhere.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -188,7 +189,8 @@ void s360_destroy(s360_ctx* c) {
   if (c->stUp) (void)hipStreamSynchronize(c->stUp);
   if (c->st) (void)hipStreamSynchronize(c->st);
   if (c->st2) (void)hipStreamSynchronize(c->st2);
-  c->frame.reset();
+  comm_destroy(c);
+  c->slots.clear();
   c->flow.reset();
   c->flow_pole.reset();
   c->flow_pr.reset();
@@ -272,11 +274,11 @@ int s360_compute_optical_flow_batch(s360_ctx* c, const char* alg, int batch, con
       pimg = c->op_c.as<uchar4>();
       pflow = c->op_d.as<float2>();
     }
-    FlowIdx idx;
-    std::memset(&idx, 0, sizeof(idx));
-    for (int b = 0; b < batch; ++b) { idx.i0[b] = b; idx.i1[b] = batch + b; }
-    c->flow->compute(c->st, pc, 2 * batch, batch, idx, c->op_a.as<uchar4>(), w, h, pimg, pflow, hint,
-                     c->op_b.as<float2>());
+    FlowBatch fb;
+    fb.add_images(c->op_a.as<uchar4>(), 2 * batch, n);
+    if (pimg) fb.add_prev_images(pimg, 2 * batch, n);
+    for (int b = 0; b < batch; ++b) fb.add_flow(b, batch + b, c->op_b.as<float2>() + n * b, pflow ? pflow + n * b : nullptr);
+    c->flow->compute(c->st, pc, fb, w, h, hint);
     d2h(c, flow_out, c->op_b.p, B * n * sizeof(float2));
   });
 }
@@ -296,13 +298,13 @@ int s360_debug_flow_levels(s360_ctx* c, const char* alg, const uint8_t* i0, cons
     c->op_b.ensure(n * sizeof(float2));
     h2d(c, c->op_a.p, i0, n * 4);
     h2d(c, c->op_a.as<uint8_t>() + n * 4, i1, n * 4);
-    FlowIdx idx;
-    std::memset(&idx, 0, sizeof(idx));
-    idx.i0[0] = 0; idx.i1[0] = 1;
+    FlowBatch fb;
+    fb.add_images(c->op_a.as<uchar4>(), 2, n);
+    fb.add_flow(0, 1, c->op_b.as<float2>());
     std::vector<std::vector<float>> lv;
     c->flow->capture_levels = &lv;
     try {
-      c->flow->compute(c->st, pc, 2, 1, idx, c->op_a.as<uchar4>(), w, h, nullptr, nullptr, hint, c->op_b.as<float2>());
+      c->flow->compute(c->st, pc, fb, w, h, hint);
     } catch (...) {
       c->flow->capture_levels = nullptr;
       throw;
@@ -452,11 +454,10 @@ int s360_pole_to_side_flow(s360_ctx* c, const uint8_t* side, const uint8_t* pole
     dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), W, pole_rows, ext, extW);
     launch_extend_wrap(c->st, c->op_b.as<uchar4>(), nullptr, W, pole_rows, ext + xn, extW);
     if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
-    FlowIdx idx;
-    std::memset(&idx, 0, sizeof(idx));
-    idx.i0[0] = 0; idx.i1[0] = 1;
-    c->flow_pole->compute(c->st, pixflow_consts_by_name(c->P.polar_flow_alg), 2, 1, idx, ext, extW, pole_rows, nullptr,
-                          nullptr, S360_HINT_DOWN, c->op_d.as<float2>());
+    FlowBatch fb;
+    fb.add_images(ext, 2, xn);
+    fb.add_flow(0, 1, c->op_d.as<float2>());
+    c->flow_pole->compute(c->st, pixflow_consts_by_name(c->P.polar_flow_alg), fb, extW, pole_rows, S360_HINT_DOWN);
     dev_pole_unit_post(c, ext + xn, c->op_d.as<float2>(), W, pole_rows, extW, c->op_e.as<uchar4>(), H);
     d2h(c, warped_out, c->op_e.p, en * 4);
     if (flow_out) d2h(c, flow_out, c->op_d.p, xn * sizeof(float2));
@@ -521,6 +522,19 @@ int s360_frame_render(s360_ctx* c, int use_prev) {
     frame_finish(c, 15, use_prev);
   });
 }
+int s360_set_frame_slots(s360_ctx* c, int n) {
+  return guard(c, [&] { need(c, "null ctx"); set_frame_slots(c, n); });
+}
+int s360_select_frame_slot(s360_ctx* c, int k) {
+  return guard(c, [&] {
+    need(c, "null ctx");
+    need(k >= 0 && k < (int)std::max<size_t>(c->slots.size(), 1), "frame slot out of range");
+    c->slot = k;
+  });
+}
+int s360_frame_render_batch(s360_ctx* c, int use_prev) {
+  return guard(c, [&] { need(c, "null ctx"); frame_render_batch(c, use_prev); });
+}
 int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, const float* flow_r_to_l,
                              const uint8_t* overlap_l, const uint8_t* overlap_r) {
   return guard(c, [&] {
@@ -529,18 +543,21 @@ int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, co
     const int P = F.P;
     need(pair >= 0 && pair < P, "pair_idx out of range");
     const size_t on = (size_t)c->g.overlap_image_width * c->g.cam_image_height;
-    // previous-frame slot of the double buffer, laid out for the full partition [0, P): L images / LtoR flows
-    // first, then R images / RtoL flows (frame_render_pairs)
+    // previous-frame slot of the double buffer, laid out like frame_render_pairs lays out the block [p0, p1) this
+    // context renders (s360_frame_set_partition; default all pairs): L images / LtoR flows of the block first, then
+    // R images / RtoL flows
+    if (!F.partition_declared) { F.side_p0 = 0; F.side_p1 = P; }
+    const int p0 = F.side_p0, n = F.side_p1 - F.side_p0;
+    need(pair >= p0 && pair < F.side_p1, "pair_idx outside the block declared with s360_frame_set_partition");
+    const int j = pair - p0;
     const int prv = F.cur_side ^ 1;
-    F.overlaps[prv].ensure(2 * P * on * sizeof(uchar4));
-    F.sideFlows[prv].ensure(2 * P * on * sizeof(float2));
-    h2d(c, F.overlaps[prv].as<uchar4>() + on * pair, overlap_l, on * sizeof(uchar4));
-    h2d(c, F.overlaps[prv].as<uchar4>() + on * (P + pair), overlap_r, on * sizeof(uchar4));
-    h2d(c, F.sideFlows[prv].as<float2>() + on * pair, flow_l_to_r, on * sizeof(float2));
-    h2d(c, F.sideFlows[prv].as<float2>() + on * (P + pair), flow_r_to_l, on * sizeof(float2));
+    F.overlaps[prv].ensure(2 * n * on * sizeof(uchar4));
+    F.sideFlows[prv].ensure(2 * n * on * sizeof(float2));
+    h2d(c, F.overlaps[prv].as<uchar4>() + on * j, overlap_l, on * sizeof(uchar4));
+    h2d(c, F.overlaps[prv].as<uchar4>() + on * (n + j), overlap_r, on * sizeof(uchar4));
+    h2d(c, F.sideFlows[prv].as<float2>() + on * j, flow_l_to_r, on * sizeof(float2));
+    h2d(c, F.sideFlows[prv].as<float2>() + on * (n + j), flow_r_to_l, on * sizeof(float2));
     S360_HIP(hipStreamSynchronize(c->st));  // the caller's buffers may be reused as soon as this returns
-    F.side_p0 = 0;
-    F.side_p1 = P;
     F.have_prev_side = true;
   });
 }
@@ -551,18 +568,49 @@ int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uin
     FrameState& F = frame_state(c);
     const int extW = int(float(c->P.eqr_width) * 1.2f);
     const int rows = unit < 2 ? c->g.top_rows : c->g.bottom_rows;
-    need(F.poleRows == 0 || F.poleRows == rows || !F.have_prev_pole, "pole units of different height");
-    const size_t xn = (size_t)extW * rows;
+    const size_t xn = (size_t)extW * rows;                                       // one image / flow of this unit
+    const size_t xs = (size_t)extW * std::max(c->g.top_rows, c->g.bottom_rows);  // slot stride (frame_finish)
     const int prv = F.cur_pole ^ 1;
-    F.extImgs[prv].ensure(6 * xn * sizeof(uchar4));
-    F.poleFlows[prv].ensure(4 * xn * sizeof(float2));
-    h2d(c, F.extImgs[prv].as<uchar4>() + xn * unit, ext_side, xn * sizeof(uchar4));
-    h2d(c, F.extImgs[prv].as<uchar4>() + xn * (unit < 2 ? 4 : 5), ext_fisheye, xn * sizeof(uchar4));
-    h2d(c, F.poleFlows[prv].as<float2>() + xn * unit, flow, xn * sizeof(float2));
+    F.extImgs[prv].ensure(6 * xs * sizeof(uchar4));
+    F.poleFlows[prv].ensure(4 * xs * sizeof(float2));
+    h2d(c, F.extImgs[prv].as<uchar4>() + xs * unit, ext_side, xn * sizeof(uchar4));
+    h2d(c, F.extImgs[prv].as<uchar4>() + xs * (unit < 2 ? 4 : 5), ext_fisheye, xn * sizeof(uchar4));
+    h2d(c, F.poleFlows[prv].as<float2>() + xs * unit, flow, xn * sizeof(float2));
     S360_HIP(hipStreamSynchronize(c->st));  // the caller's buffers may be reused as soon as this returns
     F.extW = extW;
-    F.poleRows = rows;
+    F.extStride = xs;
+    F.poleRowsT = c->g.top_rows;
+    F.poleRowsB = c->g.bottom_rows;
     F.have_prev_pole = true;
+  });
+}
+int s360_comm_get_unique_id(void* id_out) {
+  return guard(nullptr, [&] { need(id_out, "null argument"); comm_unique_id(id_out); });
+}
+int s360_comm_init_rank(s360_ctx* c, const void* id, int rank, int nranks) {
+  return guard(c, [&] { need(c && id, "null argument"); comm_init_rank(c, id, rank, nranks); });
+}
+int s360_comm_init_all(s360_ctx* const* ctxs, int n) {
+  return guard(nullptr, [&] { need(ctxs && n > 0, "bad argument"); comm_init_all(ctxs, n); });
+}
+int s360_comm_destroy(s360_ctx* c) {
+  return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); comm_destroy(c); });
+}
+int s360_frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
+  return guard(c, [&] { need(c && bounds, "null argument"); frame_gather_strips(c, bounds, root); });
+}
+int s360_comm_loopback(s360_ctx* c, int src_pair, int dst_pair) {
+  return guard(c, [&] { need(c, "null ctx"); comm_loopback(c, src_pair, dst_pair); });
+}
+int s360_frame_set_partition(s360_ctx* c, int p0, int p1) {
+  return guard(c, [&] {
+    need(c, "null ctx");
+    FrameState& F = frame_state(c);
+    need(p0 >= 0 && p1 <= F.P && p0 <= p1, "bad pair range");
+    if (F.side_p0 != p0 || F.side_p1 != p1) F.have_prev_side = false;  // state of another block is of no use
+    F.side_p0 = p0;
+    F.side_p1 = p1;
+    F.partition_declared = true;
   });
 }
 int s360_frame_strip_ptr(s360_ctx* c, int eye, void** dev_ptr, size_t* bytes_per_pair) {
@@ -642,9 +690,9 @@ int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_
       need(idx >= 0 && idx < 4 && F.poleWarped[idx].p, "not available"); w = W; h = H; src = F.poleWarped[idx].p;
     } else if (n == "extended_side" || n == "extended_fisheye") {
       need(idx >= 0 && idx < 4 && F.extImgs[F.last_pole].p, "not available");
-      w = F.extW; h = F.poleRows;
+      w = F.extW; h = idx < 2 ? F.poleRowsT : F.poleRowsB;
       const int slot = n == "extended_side" ? idx : (idx < 2 ? 4 : 5);
-      src = F.extImgs[F.last_pole].as<uchar4>() + (size_t)w * h * slot;
+      src = F.extImgs[F.last_pole].as<uchar4>() + F.extStride * slot;
     } else if (n == "bottom_image" || n == "bottom_image2") {
       need(F.prImgs[F.last_pr].p && F.have_prev_pr, "not available (pole removal not run)");
       w = F.poleW; h = F.poleH;
@@ -686,8 +734,8 @@ int s360_frame_get_f32(s360_ctx* c, const char* name, int idx, int whc[3], float
       src = F.prFlow[F.last_pr].p;
     } else if (n == "flow_pole") {
       need(idx >= 0 && idx < 4 && F.poleFlows[F.last_pole].p, "flow not available");
-      w = F.extW; h = F.poleRows;
-      src = F.poleFlows[F.last_pole].as<float2>() + (size_t)w * h * idx;
+      w = F.extW; h = idx < 2 ? F.poleRowsT : F.poleRowsB;
+      src = F.poleFlows[F.last_pole].as<float2>() + F.extStride * idx;
     } else {
       throw Error(S360_ERR_INVALID_ARG, "unknown intermediate name: " + n);
     }

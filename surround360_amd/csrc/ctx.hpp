@@ -35,6 +35,9 @@ struct s360_ctx {
   int pinNext = 0;
   hipEvent_t evUploaded = nullptr, evSideSrcFree = nullptr;
   bool haveUploaded = false, haveSideSrcFree = false;
+  // RCCL communicator of the sharded frame (comm.cpp); opaque here so that only comm.cpp needs rccl.h
+  void* comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
   s360::Rig rig;
   s360_params P;
   s360_geometry g;
@@ -48,6 +51,13 @@ struct s360_ctx {
   std::string err;
   // scratch for operator-level calls
   s360::DevBuf op_a, op_b, op_c, op_d, op_e, op_f;
-  std::shared_ptr<s360::FrameState> frame;
+  // Frame slots: slot 0 always exists; s360_set_frame_slots(n) adds more so that n independent frames (n streams of a
+  // multi-stream job) are rendered by ONE launch sequence with the flows of all of them in the same batched kernels
+  // (s360_frame_render_batch). Uploads / getters / downloads act on the selected slot.
+  std::vector<std::shared_ptr<s360::FrameState>> slots;
+  int slot = 0;
+  // warp maps of bicubicRemapToSpherical per rig camera: depend only on rig + sizes, shared by all slots
+  s360::DevBuf sideMaps, topMap, botMap;
+  bool maps_ready = false;
   void make_current() const { S360_HIP(hipSetDevice(device)); }
 };

@@ -60,17 +60,59 @@ void FlowLevels::build(int dw, int dh, float pyrScale) {
   }
 }
 
-void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, const FlowIdx& idx,
-                         const uchar4* images, int w, int h, const uchar4* prev_images, const float2* prev_flow,
-                         int hint, float2* out) {
-  if (B > kMaxFlows) throw Error(-1, "FlowEngine: batch too large");
+// Layout of the uploaded table (8-byte words): [N][B][images N][prev_images N][prev_flow B][out B][int i0[B], int i1[B]]
+const unsigned long long* FlowEngine::batch_tables(hipStream_t st, const FlowBatch& b) {
+  const size_t N = b.images.size(), B = b.out.size();
+  std::vector<unsigned long long> key;
+  key.reserve(2 * N + 3 * B + 2);
+  key.push_back(N);
+  key.push_back(B);
+  for (size_t k = 0; k < N; ++k) key.push_back((unsigned long long)b.images[k]);
+  for (size_t k = 0; k < N; ++k) key.push_back(b.prev_images.empty() ? 0ull : (unsigned long long)b.prev_images[k]);
+  for (size_t k = 0; k < B; ++k) key.push_back(b.prev_flow.empty() ? 0ull : (unsigned long long)b.prev_flow[k]);
+  for (size_t k = 0; k < B; ++k) key.push_back((unsigned long long)b.out[k]);
+  {
+    std::vector<int> ints(2 * B);
+    for (size_t k = 0; k < B; ++k) { ints[k] = b.i0[k]; ints[B + k] = b.i1[k]; }
+    const size_t at = key.size();
+    key.resize(at + B);
+    std::memcpy(&key[at], ints.data(), 2 * B * sizeof(int));
+  }
+  for (TabSlot& t : tabs_)
+    if (t.key == key) return t.buf.as<unsigned long long>() + 2;
+  TabSlot& t = tabs_[tab_next_];
+  tab_next_ = (tab_next_ + 1) % 4;
+  S360_HIP(hipStreamSynchronize(st));  // earlier launches may still read the slot that is being replaced
+  t.key = key;
+  t.buf.ensure(key.size() * sizeof(unsigned long long));
+  S360_HIP(hipMemcpyAsync(t.buf.p, t.key.data(), key.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+  S360_HIP(hipStreamSynchronize(st));
+  return t.buf.as<unsigned long long>() + 2;
+}
+
+void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatch& batch, int w, int h, int hint) {
+  const int N = (int)batch.images.size(), B = (int)batch.out.size();
+  if (B < 1 || B > kMaxFlows || (int)batch.i0.size() != B || (int)batch.i1.size() != B)
+    throw Error(-1, "FlowEngine: bad batch");
+  if (!batch.prev_flow.empty() && ((int)batch.prev_flow.size() != B || (int)batch.prev_images.size() != N))
+    throw Error(-1, "FlowEngine: previous-frame state must cover the whole batch");
+  for (int b = 0; b < B; ++b)
+    if (batch.i0[b] < 0 || batch.i0[b] >= N || batch.i1[b] < 0 || batch.i1[b] >= N) throw Error(-1, "FlowEngine: image index out of range");
   Profiler& P = *prof_;
   dw_ = int(w * pc.downscaleFactor);
   dh_ = int(h * pc.downscaleFactor);
   const size_t n0 = (size_t)dw_ * dh_;
   lv_.build(dw_, dh_, pc.pyrScaleFactor);
   const int L = (int)lv_.w.size();
-  const bool usePrev = prev_flow != nullptr;
+  const bool usePrev = !batch.prev_flow.empty();
+  const unsigned long long* tab = batch_tables(st, batch);
+  const uchar4* const* imageTab = reinterpret_cast<const uchar4* const*>(tab);
+  const uchar4* const* prevImageTab = reinterpret_cast<const uchar4* const*>(tab + N);
+  const float2* const* prevFlowTab = reinterpret_cast<const float2* const*>(tab + 2 * N);
+  float* const* outTab = reinterpret_cast<float* const*>(tab + 2 * N + B);
+  FlowIdx idx;
+  idx.i0 = reinterpret_cast<const int*>(tab + 2 * N + 2 * B);
+  idx.i1 = idx.i0 + B;
 
   down_.ensure(N * n0 * sizeof(uchar4));
   gray_.ensure(N * n0 * sizeof(float));
@@ -118,7 +160,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
                  tFinal = gaussian_taps(3, 1.0f);
   {
     ProfScope ps(P, "flow_entry");
-    launch_resize_cubic_u8c4(st, images, w, h, (size_t)w * h, down_.as<uchar4>(), dw_, dh_, n0, N);
+    launch_resize_cubic_u8c4(st, nullptr, w, h, 0, down_.as<uchar4>(), dw_, dh_, n0, N, imageTab);
     launch_gray_alpha(st, down_.as<uchar4>(), n0, n0, gray_.as<float>(), LA(0), n0, N);
     launch_sepblur(st, gray_.as<float>(), LI(0), dw_, dh_, 1, n0, N, tPre);
   }
@@ -140,10 +182,10 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
     motionPyr_.ensure(N * lv_.total * sizeof(float));
     prevPyr = prevPyr_.as<float2>();
     motionPyr = motionPyr_.as<float>();
-    launch_resize_cubic_u8c4(st, prev_images, w, h, (size_t)w * h, prevdown_.as<uchar4>(), dw_, dh_, n0, N);
+    launch_resize_cubic_u8c4(st, nullptr, w, h, 0, prevdown_.as<uchar4>(), dw_, dh_, n0, N, prevImageTab);
     launch_motion(st, down_.as<uchar4>(), prevdown_.as<uchar4>(), n0, n0, motionPyr, n0, N);
     // prevFlowDownscaled = resize(prevFlow) * (rows_down / rows_full)  (PixFlow.h:103-104)
-    launch_resize_cubic_f32c2(st, prev_flow, w, h, (size_t)w * h, prevPyr, dw_, dh_, n0, B, float(dh_) / float(h));
+    launch_resize_cubic_f32c2(st, nullptr, w, h, 0, prevPyr, dw_, dh_, n0, B, float(dh_) / float(h), prevFlowTab);
     for (int l = 1; l < L; ++l) {
       const size_t ns = (size_t)lv_.w[l - 1] * lv_.h[l - 1], nd = (size_t)lv_.w[l] * lv_.h[l];
       launch_resize_linear_f32(st, (const float*)(prevPyr + (size_t)B * lv_.off[l - 1]), lv_.w[l - 1], lv_.h[l - 1], ns,
@@ -227,7 +269,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, 
       ProfScope ps(P, "flow_final");
       launch_resize_linear_f32(st, (const float*)oth, wl, hl, nl, full_.as<float>(), w, h, (size_t)w * h, 2, B,
                                1.0f / pc.downscaleFactor, 1);
-      launch_sepblur(st, full_.as<float>(), (float*)out, w, h, 2, (size_t)w * h, B, tFinal);
+      launch_sepblur(st, full_.as<float>(), nullptr, w, h, 2, (size_t)w * h, B, tFinal, outTab);
     }
   }
 }

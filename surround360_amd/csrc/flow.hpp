@@ -24,13 +24,27 @@ struct FlowLevels {
   void build(int dw, int dh, float pyrScale);
 };
 
+// Which flows a batch computes and where its data lives. Flow b matches image i0[b] (I0) against i1[b] (I1). Images,
+// previous flows and outputs are given per item as device pointers, so a batch may span buffers of several frames
+// (s360_frame_render_batch); `contiguous` helpers cover the common one-allocation case.
+struct FlowBatch {
+  std::vector<int> i0, i1;                    // B entries
+  std::vector<const uchar4*> images;          // N entries, each [h][w] uchar4
+  std::vector<const uchar4*> prev_images;     // N entries or empty (no previous frame)
+  std::vector<const float2*> prev_flow;       // B entries or empty
+  std::vector<float2*> out;                   // B entries, each [h][w] float2
+  void add_images(const uchar4* base, int n, size_t stride) { for (int k = 0; k < n; ++k) images.push_back(base + stride * k); }
+  void add_prev_images(const uchar4* base, int n, size_t stride) { for (int k = 0; k < n; ++k) prev_images.push_back(base + stride * k); }
+  void add_flow(int a, int b, float2* o, const float2* prev = nullptr) {
+    i0.push_back(a); i1.push_back(b); out.push_back(o);
+    if (prev) prev_flow.push_back(prev);
+  }
+};
+
 class FlowEngine {
  public:
   explicit FlowEngine(Profiler* prof) : prof_(prof) {}
-  // images: device [N][h][w] uchar4. prev_images (nullable): previous frame's same packing;
-  // prev_flow (nullable): device [B][h][w] float2. out: device [B][h][w] float2.
-  void compute(hipStream_t st, const PixFlowConsts& pc, int N, int B, const FlowIdx& idx, const uchar4* images, int w,
-               int h, const uchar4* prev_images, const float2* prev_flow, int hint, float2* out);
+  void compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatch& batch, int w, int h, int hint);
   // debugging taps for parity tests (valid after compute() + stream sync)
   const uchar4* dbg_down() const { return down_.as<uchar4>(); }
   const FlowLevels& levels() const { return lv_; }
@@ -43,6 +57,12 @@ class FlowEngine {
   Profiler* prof_;
   FlowLevels lv_;
   int dw_ = 0, dh_ = 0;
+  // device copies of a batch's index arrays and pointer tables, cached by content (a video stream alternates between
+  // the two halves of its double-buffered temporal state, so a few slots make the steady state upload-free)
+  struct TabSlot { std::vector<unsigned long long> key; DevBuf buf; };
+  TabSlot tabs_[4];
+  int tab_next_ = 0;
+  const unsigned long long* batch_tables(hipStream_t st, const FlowBatch& b);
   DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, full_, prevFlowDown_, prevPyr_, motionPyr_, I1eq_, rec_,
       handoff_, err_;
   int sweep_mode_ = 2;      // 2: lockstep kernel (latency, default), 3: quad kernel, 5: mono kernel (throughput)

@@ -24,11 +24,12 @@ namespace s360 {
 // (the last pixel of an odd-width row) is FixedPtCast: (sum + 2^21) >> 22.
 __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restrict__ src, int sw, int sh,
                                                            size_t sbs, uchar4* __restrict__ dst, int dw, int dh,
-                                                           size_t dbs, double scx, double scy) {
+                                                           size_t dbs, double scx, double scy,
+                                                           const uchar4* const* __restrict__ src_tab) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x;
   const int dy = blockIdx.y * blockDim.y + threadIdx.y;
   if (dx >= dw || dy >= dh) return;
-  src += sbs * blockIdx.z;
+  src = src_tab ? src_tab[blockIdx.z] : src + sbs * blockIdx.z;
   dst += dbs * blockIdx.z;
   int sx, sy;
   float fx, fy, cb[4];
@@ -117,7 +118,8 @@ template <int R, int CN, int EPI, int SRC, int SB_TW = 64, int SB_TH = 16>
 __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                  size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
                                                  const float* __restrict__ A, FlowIdx idx,
-                                                 const float2* __restrict__ Gp, float4* __restrict__ rec) {
+                                                 const float2* __restrict__ Gp, float4* __restrict__ rec,
+                                                 float* const* __restrict__ dst_tab) {
   constexpr int IW = SB_TW + 2 * R, IH = SB_TH + 2 * R;
   constexpr int IWP = IW | 1;  // odd row stride: the 4-wide row tasks of consecutive rows fall into different banks
   __shared__ float s_in[IH][IWP][CN];
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
   }
   __syncthreads();
   // column pass: task = (column lx, group of 4 consecutive y)
-  dst += bs * CN * blockIdx.z;
+  dst = dst_tab ? dst_tab[blockIdx.z] : dst + bs * CN * blockIdx.z;
   for (int t = tid; t < SB_TW * (SB_TH / 4); t += 256) {
     const int lx = t % SB_TW, ly0 = (t / SB_TW) * 4;
     const int gx = tx0 + lx;
@@ -249,11 +251,12 @@ __global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restri
 // followed by the scalar multiply.
 __global__ __launch_bounds__(256) void k_resize_cubic_f32c2(const float2* __restrict__ src, int sw, int sh,
                                                             size_t sbs, float2* __restrict__ dst, int dw, int dh,
-                                                            size_t dbs, double scx, double scy, float post_scale) {
+                                                            size_t dbs, double scx, double scy, float post_scale,
+                                                            const float2* const* __restrict__ src_tab) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x;
   const int dy = blockIdx.y * blockDim.y + threadIdx.y;
   if (dx >= dw || dy >= dh) return;
-  src += sbs * blockIdx.z;
+  src = src_tab ? src_tab[blockIdx.z] : src + sbs * blockIdx.z;
   dst += dbs * blockIdx.z;
   int sx, sy;
   float fx, fy, ax[4], ay[4];
@@ -438,11 +441,11 @@ __global__ void k_search_init(const float* __restrict__ I, const float* __restri
 static inline dim3 grid2d(int w, int h, int B, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y, B); }
 
 void launch_resize_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, size_t sbs, uchar4* dst, int dw,
-                              int dh, size_t dbs, int B) {
+                              int dh, size_t dbs, int B, const uchar4* const* src_tab) {
   const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
   dim3 blk(32, 8);
   hipLaunchKernelGGL(k_resize_cubic_u8c4, grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx,
-                     scy);
+                     scy, src_tab);
 }
 void launch_gray_alpha(hipStream_t st, const uchar4* src, size_t n, size_t sbs, float* gray, float* alpha, size_t pbs,
                        int B) {
@@ -456,21 +459,22 @@ void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t
 }
 template <int R, int CN, int EPI, int SRC>
 static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w, int h, size_t bs, int B,
-                             const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float4* rec) {
+                             const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float4* rec,
+                             float* const* dst_tab = nullptr) {
   dim3 blk(64, 4);
   if constexpr (R == 7) {  // 15x15: 32x32 tile — 29 KB of LDS, 1.44x row-pass halo work (64x16: 35 KB, 1.9x; measured 30 % slower)
     dim3 grd((w + 31) / 32, (h + 31) / 32, B);
-    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab);
   } else {
     dim3 grd((w + 63) / 64, (h + 15) / 16, B);
-    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab);
   }
 }
 void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
-                    const BlurTaps& t) {
-  static const FlowIdx none = {};
+                    const BlurTaps& t, float* const* dst_tab) {
+  static const FlowIdx none = {nullptr, nullptr};
   if (t.r == 1 && cn == 1) launch_sepblur_t<1, 1, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
-  else if (t.r == 1 && cn == 2) launch_sepblur_t<1, 2, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
+  else if (t.r == 1 && cn == 2) launch_sepblur_t<1, 2, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr, dst_tab);
   else if (t.r == 2 && cn == 1) launch_sepblur_t<2, 1, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
   else if (t.r == 7 && cn == 2) launch_sepblur_t<7, 2, 0, 0>(st, src, dst, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
   else throw std::runtime_error("launch_sepblur: unsupported radius/channels");
@@ -481,7 +485,7 @@ void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, in
 }
 // Sobel + 3x3 Gaussian of a float plane in one pass -> packed (Ix, Iy) (PixFlow.h:353-366)
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t) {
-  static const FlowIdx none = {};
+  static const FlowIdx none = {nullptr, nullptr};
   if (t.r != 1) throw std::runtime_error("launch_gradients: 3x3 kernel expected");
   launch_sepblur_t<1, 2, 0, 1>(st, I, (float*)G, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
 }
@@ -503,11 +507,11 @@ void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, 
                        scx, scy, post_scale, do_scale);
 }
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
-                               int dh, size_t dbs, int B, float post_scale) {
+                               int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab) {
   const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
   dim3 blk(32, 8);
   hipLaunchKernelGGL(k_resize_cubic_f32c2, grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx,
-                     scy, post_scale);
+                     scy, post_scale, src_tab);
 }
 void launch_scale_f32(hipStream_t st, float* p, size_t n, float s) {
   hipLaunchKernelGGL(k_scale_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, s);

@@ -12,11 +12,12 @@ struct BlurTaps {  // centre tap k[0] and the r symmetric taps k[1..r]
   float k[8];
 };
 // Which image planes a flow of the batch uses: flow b matches image i0[b] (I0) against i1[b] (I1).
-// The 14 side pairs need only 28 image pyramids for 28 flows (LtoR and RtoL share them).
-constexpr int kMaxFlows = 32;
+// The 14 side pairs need only 28 image pyramids for 28 flows (LtoR and RtoL share them). Device arrays of B ints
+// (a batch can hold the flows of many frames).
+constexpr int kMaxFlows = 1024;
 struct FlowIdx {
-  int i0[kMaxFlows];
-  int i1[kMaxFlows];
+  const int* i0;
+  const int* i1;
 };
 struct PixFlowConsts {  // OpticalFlowFactory.h:26-41 / :45-60
   float pyrScaleFactor, smoothnessCoef, verticalRegularizationCoef, horizontalRegularizationCoef;
@@ -24,14 +25,16 @@ struct PixFlowConsts {  // OpticalFlowFactory.h:26-41 / :45-60
   int maxPercentage;
 };
 
+// src_tab (optional): device array of B source pointers used instead of src + sbs * b (images of a batch that do not
+// live in one allocation); likewise dst_tab / src_tab of the other launchers that take one.
 void launch_resize_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, size_t sbs, uchar4* dst, int dw,
-                              int dh, size_t dbs, int B);
+                              int dh, size_t dbs, int B, const uchar4* const* src_tab = nullptr);
 void launch_gray_alpha(hipStream_t st, const uchar4* src, size_t n, size_t sbs, float* gray, float* alpha, size_t pbs,
                        int B);
 void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t n, size_t sbs, float* motion,
                    size_t pbs, int B);
 void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
-                    const BlurTaps& t);
+                    const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
                       const BlurTaps& t, const float* A, const FlowIdx& idx);
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t);
@@ -40,7 +43,7 @@ void launch_blur_to_records(hipStream_t st, const float2* flow, float4* rec, int
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale);
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
-                               int dh, size_t dbs, int B, float post_scale);
+                               int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab = nullptr);
 void launch_scale_f32(hipStream_t st, float* p, size_t n, float s);
 void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
                                size_t bs, int B, const FlowIdx& idx);

@@ -144,13 +144,32 @@ void build_spherical_map(s360_ctx* c, float2* map, int dw, int dh, const s360_ca
 
 // ------------------------------------------------------------------------------------------
 FrameState& frame_state(s360_ctx* c) {
-  if (!c->frame) {
-    c->frame = std::make_shared<FrameState>();
-    c->frame->P = (int)c->rig.side.size();
-    c->frame->tab.build(c->st, c->P.std_alpha_feather_size);
+  if (c->slots.empty()) c->slots.resize(1);
+  if (c->slot < 0 || c->slot >= (int)c->slots.size()) throw Error(S360_ERR_STATE, "bad frame slot");
+  std::shared_ptr<FrameState>& f = c->slots[c->slot];
+  if (!f) {
+    f = std::make_shared<FrameState>();
+    f->P = (int)c->rig.side.size();
+    f->tab.build(c->st, c->P.std_alpha_feather_size);
   }
-  return *c->frame;
+  return *f;
 }
+void set_frame_slots(s360_ctx* c, int n) {
+  if (n < 1 || n > 64) throw Error(S360_ERR_INVALID_ARG, "frame slots must be 1..64");
+  S360_HIP(hipStreamSynchronize(c->st));
+  if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));
+  if (c->stUp) S360_HIP(hipStreamSynchronize(c->stUp));
+  c->slots.resize(n);
+  if (c->slot >= n) c->slot = 0;
+}
+namespace {
+struct SlotScope {  // the helpers below find their scratch buffers through frame_state(c): select the slot they work on
+  s360_ctx* c;
+  int saved;
+  SlotScope(s360_ctx* c_, int k) : c(c_), saved(c_->slot) { c->slot = k; }
+  ~SlotScope() { c->slot = saved; }
+};
+}  // namespace
 
 // ---- uploads: pinned chunk ring + upload stream (see ctx.hpp) ----------------------------------------------------
 static void ensure_upload_stream(s360_ctx* c) {
@@ -293,13 +312,11 @@ static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
   {
     if (!c->flow_pr) { c->flow_pr.reset(new FlowEngine(&c->prof)); c->flow_pr->set_sweep_mode(c->sweep_mode); }
     const std::string alg = c->P.poleremoval_flow_alg[0] ? c->P.poleremoval_flow_alg : "pixflow_low";
-    FlowIdx idx;
-    std::memset(&idx, 0, sizeof(idx));
-    idx.i0[0] = 0;
-    idx.i1[0] = 1;
-    c->flow_pr->compute(st, pixflow_consts_by_name(alg), 2, 1, idx, img1, w, h,
-                        usePrev ? F.prImgs[prv].as<uchar4>() : nullptr, usePrev ? F.prFlow[prv].as<float2>() : nullptr,
-                        S360_HINT_DOWN, F.prFlow[cur].as<float2>());
+    FlowBatch fb;
+    fb.add_images(img1, 2, n);
+    if (usePrev) fb.add_prev_images(F.prImgs[prv].as<uchar4>(), 2, n);
+    fb.add_flow(0, 1, F.prFlow[cur].as<float2>(), usePrev ? F.prFlow[prv].as<float2>() : nullptr);
+    c->flow_pr->compute(st, pixflow_consts_by_name(alg), fb, w, h, S360_HINT_DOWN);
   }
   {
     ProfScope ps(c->prof, "pole_removal_merge");
@@ -314,132 +331,152 @@ static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
   F.cur_pr ^= 1;
 }
 
-static void ensure_maps(s360_ctx* c, FrameState& F) {
-  if (F.maps_ready) return;
+static void ensure_maps(s360_ctx* c) {
+  if (c->maps_ready) return;
   const s360_geometry& g = c->g;
+  const int P = (int)c->rig.side.size();
   const size_t mn = (size_t)g.cam_image_width * g.cam_image_height;
-  F.sideMaps.ensure(F.P * mn * sizeof(float2));
-  for (int i = 0; i < F.P; ++i) {
+  c->sideMaps.ensure(P * mn * sizeof(float2));
+  for (int i = 0; i < P; ++i) {
     float l, r, t, b;
-    side_camera_angles(g, i, F.P, &l, &r, &t, &b);
-    build_spherical_map(c, F.sideMaps.as<float2>() + mn * i, g.cam_image_width, g.cam_image_height, c->rig.side[i], l, r,
+    side_camera_angles(g, i, P, &l, &r, &t, &b);
+    build_spherical_map(c, c->sideMaps.as<float2>() + mn * i, g.cam_image_width, g.cam_image_height, c->rig.side[i], l, r,
                         t, b);
   }
   if (c->P.enable_top && c->top_idx >= 0) {  // TRSP:655-667
     const s360_camera& cam = c->rig.all[c->top_idx];
-    F.topMap.ensure((size_t)c->P.eqr_width * g.top_rows * sizeof(float2));
-    build_spherical_map(c, F.topMap.as<float2>(), c->P.eqr_width, g.top_rows, cam, (float)(2.0f * M_PI), 0.f,
+    c->topMap.ensure((size_t)c->P.eqr_width * g.top_rows * sizeof(float2));
+    build_spherical_map(c, c->topMap.as<float2>(), c->P.eqr_width, g.top_rows, cam, (float)(2.0f * M_PI), 0.f,
                         (float)(M_PI / 2.0f), (float)(M_PI / 2.0f - camera_get_fov(&cam)));
   }
   if (c->P.enable_bottom && c->bottom_idx >= 0) {  // TRSP:606-618
     const s360_camera& cam = c->rig.all[c->bottom_idx];
-    F.botMap.ensure((size_t)c->P.eqr_width * g.bottom_rows * sizeof(float2));
-    build_spherical_map(c, F.botMap.as<float2>(), c->P.eqr_width, g.bottom_rows, cam, 0.f, (float)(2.0f * M_PI),
+    c->botMap.ensure((size_t)c->P.eqr_width * g.bottom_rows * sizeof(float2));
+    build_spherical_map(c, c->botMap.as<float2>(), c->P.eqr_width, g.bottom_rows, cam, 0.f, (float)(2.0f * M_PI),
                         (float)(-(M_PI / 2.0f)), (float)(-(M_PI / 2.0f - camera_get_fov(&cam))));
   }
-  F.maps_ready = true;
+  c->maps_ready = true;
 }
 
-// Side stage for pairs [p0,p1): projections of the cameras those pairs touch, overlap crops, the two flows
-// per pair, and the fused novel-view/blend into the strip buffers.
-void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
-  FrameState& F = frame_state(c);
+// Side stage for pairs [p0,p1) of a set of frame slots: per slot the projections of the cameras those pairs touch and
+// the overlap crops; then the two flows per pair of ALL slots in one FlowEngine batch; then per slot the fused
+// novel-view/blend into the strip buffers. One slot = the classic single frame.
+static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int p1, int use_prev) {
   const s360_geometry& g = c->g;
-  const int P = F.P;
-  if (!F.have_side) throw Error(S360_ERR_STATE, "side images not uploaded");
+  const int P = (int)c->rig.side.size();
   if (p0 < 0 || p1 > P || p1 < p0) throw Error(S360_ERR_INVALID_ARG, "bad pair range");
-  for (int p = p0; p < p1; ++p)
-    if (!((F.side_uploaded >> p) & 1) || !((F.side_uploaded >> ((p + 1) % P)) & 1))
-      throw Error(S360_ERR_STATE, "side image of camera " + std::to_string(((F.side_uploaded >> p) & 1) ? (p + 1) % P : p) +
-                                      " not uploaded (needed by pair " + std::to_string(p) + ")");
   if (c->P.eqr_width % P != 0)
     throw Error(S360_ERR_INVALID_ARG, "eqr_width must be evenly divisible by the number of cameras");  // TRSP:729-738
   if (g.num_novel_views != c->P.eqr_width / P)
     throw Error(S360_ERR_INVALID_ARG, "numNovelViews != eqr_width / numCams for this rig");
-  ensure_maps(c, F);
   Profiler& prof = c->prof;
   hipStream_t st = c->st;
   const int camW = g.cam_image_width, camH = g.cam_image_height, ow = g.overlap_image_width;
   const int stripW = c->P.eqr_width / P;
-  const size_t pn = (size_t)camW * camH, sn = (size_t)F.srcW * F.srcH, on = (size_t)ow * camH;
+  const size_t pn = (size_t)camW * camH, on = (size_t)ow * camH;
   const int n = p1 - p0;
-  F.proj.ensure(P * pn * sizeof(uchar4));
-  F.strips.ensure((size_t)2 * P * camH * stripW * sizeof(uchar4));
+  std::vector<FrameState*> Fs;
+  for (int k : slotIds) {
+    SlotScope ss(c, k);
+    FrameState& F = frame_state(c);
+    if (!F.have_side) throw Error(S360_ERR_STATE, "side images not uploaded");
+    for (int p = p0; p < p1; ++p)
+      if (!((F.side_uploaded >> p) & 1) || !((F.side_uploaded >> ((p + 1) % P)) & 1))
+        throw Error(S360_ERR_STATE, "side image of camera " + std::to_string(((F.side_uploaded >> p) & 1) ? (p + 1) % P : p) +
+                                        " not uploaded (needed by pair " + std::to_string(p) + ")");
+    F.proj.ensure(P * pn * sizeof(uchar4));
+    F.strips.ensure((size_t)2 * P * camH * stripW * sizeof(uchar4));
+    Fs.push_back(&F);
+  }
+  ensure_maps(c);
   if (n == 0) return;
+  if (2 * n * (int)Fs.size() > kMaxFlows) throw Error(S360_ERR_INVALID_ARG, "too many flows for one batch");
   wait_for_uploads(c, st);
-  {
-    ProfScope ps(prof, "project_side");
-    std::vector<char> need(P, 0);
-    for (int p = p0; p < p1; ++p) need[p] = need[(p + 1) % P] = 1;
-    for (int i = 0; i < P;) {  // one launch per run of consecutive cameras (all of them unless the frame is sharded)
-      if (!need[i]) { ++i; continue; }
-      int j = i;
-      while (j < P && need[j]) ++j;
-      launch_remap_cubic_u8c4(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, F.sideMaps.as<float2>() + pn * i,
-                              F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
-      i = j;
+  // temporal state is used only if every slot of the batch has it (one FlowEngine batch = one setting)
+  bool usePrev = use_prev != 0;
+  for (FrameState* F : Fs) usePrev = usePrev && F->have_prev_side && F->side_p0 == p0 && F->side_p1 == p1;
+  for (FrameState* Fp : Fs) {
+    FrameState& F = *Fp;
+    const size_t sn = (size_t)F.srcW * F.srcH;
+    {
+      ProfScope ps(prof, "project_side");
+      std::vector<char> need(P, 0);
+      for (int p = p0; p < p1; ++p) need[p] = need[(p + 1) % P] = 1;
+      for (int i = 0; i < P;) {  // one launch per run of consecutive cameras (all of them unless the frame is sharded)
+        if (!need[i]) { ++i; continue; }
+        int j = i;
+        while (j < P && need[j]) ++j;
+        launch_remap_cubic_u8c4(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, c->sideMaps.as<float2>() + pn * i,
+                                F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
+        i = j;
+      }
+    }
+    const int cur = F.cur_side;
+    F.overlaps[cur].ensure(2 * n * on * sizeof(uchar4));
+    F.sideFlows[cur].ensure(2 * n * on * sizeof(float2));
+    {
+      ProfScope ps(prof, "crop_overlaps");
+      launch_crop_overlaps(st, F.proj.as<uchar4>(), camW, camH, P, ow, F.overlaps[cur].as<uchar4>(), p0, p1);
     }
   }
   if (c->evSideSrcFree) {  // the next frame's side images may be converted into sideSrc from here on
     S360_HIP(hipEventRecord(c->evSideSrcFree, st));
     c->haveSideSrcFree = true;
   }
-  const bool repartition = (F.side_p0 != p0 || F.side_p1 != p1);
-  const bool usePrev = use_prev && F.have_prev_side && !repartition;
-  const int cur = F.cur_side, prv = cur ^ 1;
-  F.overlaps[cur].ensure(2 * n * on * sizeof(uchar4));
-  F.sideFlows[cur].ensure(2 * n * on * sizeof(float2));
-  {
-    ProfScope ps(prof, "crop_overlaps");
-    launch_crop_overlaps(st, F.proj.as<uchar4>(), camW, camH, P, ow, F.overlaps[cur].as<uchar4>(), p0, p1);
-  }
   {
     // NovelViewGeneratorAsymmetricFlow::prepare (NovelView.cpp:270-299): flowLtoR = flow(I0=L, I1=R, LEFT),
     // flowRtoL = flow(I0=R, I1=L, RIGHT). Both hints only matter for pixflow_search_20; the batch is split by
-    // hint in that case.
+    // hint in that case. Per slot: images [L_0..L_{n-1}, R_0..R_{n-1}], flows [LtoR_0.., RtoL_0..].
     if (!c->flow) { c->flow.reset(new FlowEngine(&c->prof)); c->flow->set_sweep_mode(c->sweep_mode); }
     const PixFlowConsts pc = pixflow_consts_by_name(c->P.side_flow_alg);
-    FlowIdx idx;
-    std::memset(&idx, 0, sizeof(idx));
-    if (2 * n > kMaxFlows) throw Error(S360_ERR_INVALID_ARG, "too many pairs for one batch");
-    for (int j = 0; j < n; ++j) {
-      idx.i0[j] = j; idx.i1[j] = n + j;          // LtoR
-      idx.i0[n + j] = n + j; idx.i1[n + j] = j;  // RtoL
-    }
-    const uchar4* prevImgs = usePrev ? F.overlaps[prv].as<uchar4>() : nullptr;
-    const float2* prevFlow = usePrev ? F.sideFlows[prv].as<float2>() : nullptr;
+    auto build = [&](bool ltor, bool rtol) {
+      FlowBatch fb;
+      for (size_t k = 0; k < Fs.size(); ++k) {
+        FrameState& F = *Fs[k];
+        const int cur = F.cur_side, prv = cur ^ 1;
+        const int base = (int)fb.images.size();
+        fb.add_images(F.overlaps[cur].as<uchar4>(), 2 * n, on);
+        if (usePrev) fb.add_prev_images(F.overlaps[prv].as<uchar4>(), 2 * n, on);
+        float2* out = F.sideFlows[cur].as<float2>();
+        const float2* pf = usePrev ? F.sideFlows[prv].as<float2>() : nullptr;
+        if (ltor)
+          for (int j = 0; j < n; ++j) fb.add_flow(base + j, base + n + j, out + on * j, pf ? pf + on * j : nullptr);
+        if (rtol)
+          for (int j = 0; j < n; ++j) fb.add_flow(base + n + j, base + j, out + on * (n + j), pf ? pf + on * (n + j) : nullptr);
+      }
+      return fb;
+    };
     if (pc.maxPercentage == 0) {
-      c->flow->compute(st, pc, 2 * n, 2 * n, idx, F.overlaps[cur].as<uchar4>(), ow, camH, prevImgs, prevFlow,
-                       S360_HINT_LEFT, F.sideFlows[cur].as<float2>());
+      c->flow->compute(st, pc, build(true, true), ow, camH, S360_HINT_LEFT);
     } else {
-      FlowIdx a = idx, b;
-      std::memset(&b, 0, sizeof(b));
-      for (int j = 0; j < n; ++j) { b.i0[j] = idx.i0[n + j]; b.i1[j] = idx.i1[n + j]; }
-      c->flow->compute(st, pc, 2 * n, n, a, F.overlaps[cur].as<uchar4>(), ow, camH, prevImgs, prevFlow, S360_HINT_LEFT,
-                       F.sideFlows[cur].as<float2>());
-      c->flow->compute(st, pc, 2 * n, n, b, F.overlaps[cur].as<uchar4>(), ow, camH, prevImgs,
-                       prevFlow ? prevFlow + n * on : nullptr, S360_HINT_RIGHT, F.sideFlows[cur].as<float2>() + n * on);
+      c->flow->compute(st, pc, build(true, false), ow, camH, S360_HINT_LEFT);
+      c->flow->compute(st, pc, build(false, true), ow, camH, S360_HINT_RIGHT);
     }
   }
-  {
-    ProfScope ps(prof, "novel_view");
-    NovelViewParams nv;
-    nv.overlapW = ow; nv.camH = camH; nv.stripW = stripW; nv.numNovelViews = g.num_novel_views;
-    nv.numPairs = P; nv.numLocal = n;
-    nv.camImageWidthHalf = float(camW) * 0.5f;
-    nv.disp = g.verge_at_infinity_slab_displacement;
-    // pipelined video stream: the previous frame's panoramas must have been assembled from the strips
-    if (c->pipeline && c->haveStripsFree) S360_HIP(hipStreamWaitEvent(st, c->evStripsFree, 0));
-    launch_novel_view(st, F.overlaps[cur].as<uchar4>(), F.sideFlows[cur].as<float2>(), F.strips.as<uchar4>(), nv, p0,
-                      p1, F.tab.dev);
+  for (FrameState* Fp : Fs) {
+    FrameState& F = *Fp;
+    const int cur = F.cur_side;
+    {
+      ProfScope ps(prof, "novel_view");
+      NovelViewParams nv;
+      nv.overlapW = ow; nv.camH = camH; nv.stripW = stripW; nv.numNovelViews = g.num_novel_views;
+      nv.numPairs = P; nv.numLocal = n;
+      nv.camImageWidthHalf = float(camW) * 0.5f;
+      nv.disp = g.verge_at_infinity_slab_displacement;
+      // pipelined video stream: the previous frame's panoramas must have been assembled from the strips
+      if (c->pipeline && c->haveStripsFree) S360_HIP(hipStreamWaitEvent(st, c->evStripsFree, 0));
+      launch_novel_view(st, F.overlaps[cur].as<uchar4>(), F.sideFlows[cur].as<float2>(), F.strips.as<uchar4>(), nv, p0,
+                        p1, F.tab.dev);
+    }
+    F.side_p0 = p0;
+    F.side_p1 = p1;
+    F.have_prev_side = true;
+    F.last_side = cur;
+    F.cur_side ^= 1;
   }
   if (c->pipeline) S360_HIP(hipEventRecord(c->evSideDone, st));
-  F.side_p0 = p0;
-  F.side_p1 = p1;
-  F.have_prev_side = true;
-  F.last_side = cur;
-  F.cur_side ^= 1;
 }
+void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) { side_stage(c, {c->slot}, p0, p1, use_prev); }
 
 // featherAlphaChannel (CvUtil.cpp:140-157) on `rows` rows of a pano, then the x % cols extension (TRSP:399-411).
 void dev_feather_alpha_to_ext(s360_ctx* c, const uchar4* pano, int cols, int rows, uchar4* ext, int extW, int erode_size,
@@ -495,47 +532,52 @@ struct FinishStream {
 };
 }  // namespace
 
-void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
-  FrameState& F = frame_state(c);
+// Pole stage + composite of a set of frame slots: per slot panorama assembly, pole projections and the flow inputs of
+// the enabled pole units; then the pole flows of ALL slots in one FlowEngine batch (two when the top and bottom pole
+// projections differ in height); then per slot warp, composite, sharpen / final resize / stacking.
+static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_mask, int use_prev) {
   const s360_geometry& g = c->g;
   Profiler& prof = c->prof;
   FinishStream finishStream(c);
   hipStream_t st = c->st;
-  const int P = F.P, W = c->P.eqr_width, H = c->P.eqr_height, camH = g.cam_image_height, stripW = W / P;
+  const int P = (int)c->rig.side.size(), W = c->P.eqr_width, H = c->P.eqr_height, camH = g.cam_image_height, stripW = W / P;
   const size_t en = (size_t)W * H;
   if (!c->P.enable_top) pole_mask &= ~3;
   if (!c->P.enable_bottom) pole_mask &= ~12;
-  for (int e = 0; e < 2; ++e) F.pano[e].ensure(en * sizeof(uchar4));
-  F.panoTmp.ensure(en * sizeof(uchar4));
-  {
-    ProfScope ps(prof, "assemble_pano");  // TRSP:380-384, 806-807
-    const float sh = g.zero_parallax_novel_view_shift_pixels;
-    launch_assemble_pano(st, F.strips.as<uchar4>(), P, camH, stripW, sh, F.pano[0].as<uchar4>(), W, H);
-    launch_assemble_pano(st, F.strips.as<uchar4>() + (size_t)P * camH * stripW, P, camH, stripW, -sh,
-                         F.pano[1].as<uchar4>(), W, H);
-    if (c->pipeline) {  // the next frame's novel views may overwrite the strips from here on
-      S360_HIP(hipEventRecord(c->evStripsFree, st));
-      c->haveStripsFree = true;
-    }
+  const int rowsT = g.top_rows, rowsB = g.bottom_rows;
+  const int extW = int(float(W) * 1.2f);  // TRSP:400-401
+  const size_t xs = (size_t)extW * std::max(rowsT, rowsB);  // slot stride of the extended images / pole flows
+  auto rowsOf = [&](int u) { return u < 2 ? rowsT : rowsB; };
+  if (pole_mask) ensure_maps(c);
+  bool usePrev = use_prev != 0 && pole_mask != 0;
+  for (int k : slotIds) {
+    SlotScope ss(c, k);
+    FrameState& F = frame_state(c);
+    usePrev = usePrev && F.have_prev_pole && F.extW == extW && F.poleRowsT == rowsT && F.poleRowsB == rowsB;
   }
-  if (F.keep_intermediates)
-    for (int e = 0; e < 2; ++e) {
-      F.panoDbg[e].ensure(en * sizeof(uchar4));
-      S360_HIP(hipMemcpyAsync(F.panoDbg[e].p, F.pano[e].p, en * sizeof(uchar4), hipMemcpyDeviceToDevice, st));
+  for (int k : slotIds) {
+    SlotScope ss(c, k);
+    FrameState& F = frame_state(c);
+    if (!F.strips.p) throw Error(S360_ERR_STATE, "no strips rendered for this frame");
+    for (int e = 0; e < 2; ++e) F.pano[e].ensure(en * sizeof(uchar4));
+    F.panoTmp.ensure(en * sizeof(uchar4));
+    {
+      ProfScope ps(prof, "assemble_pano");  // TRSP:380-384, 806-807
+      const float sh = g.zero_parallax_novel_view_shift_pixels;
+      launch_assemble_pano(st, F.strips.as<uchar4>(), P, camH, stripW, sh, F.pano[0].as<uchar4>(), W, H);
+      launch_assemble_pano(st, F.strips.as<uchar4>() + (size_t)P * camH * stripW, P, camH, stripW, -sh,
+                           F.pano[1].as<uchar4>(), W, H);
     }
-  // ---- pole units (TRSP:811-860): 0 top_left, 1 top_right, 2 bottom_left, 3 bottom_right ----
-  if (pole_mask) {
-    ensure_maps(c, F);
-    const int rowsT = g.top_rows, rowsB = g.bottom_rows;
-    const int rows = (pole_mask & 3) ? rowsT : rowsB;
-    if ((pole_mask & 3) && (pole_mask & 12) && rowsT != rowsB)
-      throw Error(S360_ERR_INVALID_ARG, "top and bottom pole projections of different height are not batched yet");
-    const int extW = int(float(W) * 1.2f);  // TRSP:400-401
-    const size_t xn = (size_t)extW * rows;
-    const int cur = F.cur_pole, prv = cur ^ 1;
-    const bool usePrev = use_prev && F.have_prev_pole && F.extW == extW && F.poleRows == rows;
-    F.extImgs[cur].ensure(6 * xn * sizeof(uchar4));
-    F.poleFlows[cur].ensure(4 * xn * sizeof(float2));
+    if (F.keep_intermediates)
+      for (int e = 0; e < 2; ++e) {
+        F.panoDbg[e].ensure(en * sizeof(uchar4));
+        S360_HIP(hipMemcpyAsync(F.panoDbg[e].p, F.pano[e].p, en * sizeof(uchar4), hipMemcpyDeviceToDevice, st));
+      }
+    if (!pole_mask) continue;
+    // ---- pole units (TRSP:811-860): 0 top_left, 1 top_right, 2 bottom_left, 3 bottom_right ----
+    const int cur = F.cur_pole;
+    F.extImgs[cur].ensure(6 * xs * sizeof(uchar4));
+    F.poleFlows[cur].ensure(4 * xs * sizeof(float2));
     uchar4* ext = F.extImgs[cur].as<uchar4>();
     wait_for_uploads(c, st);
     {
@@ -544,9 +586,9 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
         if (!F.have_top) throw Error(S360_ERR_STATE, "top image not uploaded");
         F.topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
         const int yfs = rowsT - 1 - c->P.std_alpha_feather_size;
-        launch_remap_cubic_u8c4(st, F.topSrc.as<uchar4>(), F.topW, F.topH, F.topMap.as<float2>(),
+        launch_remap_cubic_u8c4(st, F.topSrc.as<uchar4>(), F.topW, F.topH, c->topMap.as<float2>(),
                                 F.topSph.as<uchar4>(), W, rowsT, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
-        launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xn, extW);
+        launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xs, extW);
       }
       if (pole_mask & 12) {
         if (!F.have_bottom) throw Error(S360_ERR_STATE, "bottom image not uploaded");
@@ -554,17 +596,13 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
         const int yfs = rowsB - 1 - c->P.std_alpha_feather_size;
         if (c->P.enable_pole_removal) {  // TRSP:569-597: the bottom source is the merge of the two bottom cameras
           dev_pole_removal(c, F, use_prev != 0);
-          launch_remap_cubic_u8c4(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, F.botMap.as<float2>(),
+          launch_remap_cubic_u8c4(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
                                   F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 2, yfs, c->P.std_alpha_feather_size);
         } else {
-          launch_remap_cubic_u8c4(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, F.botMap.as<float2>(),
+          launch_remap_cubic_u8c4(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
                                   F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         }
-        launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xn, extW);
-      }
-      if (c->evPoleSrcFree) {  // the next frame's pole images may be converted into topSrc / botSrc from here on
-        S360_HIP(hipEventRecord(c->evPoleSrcFree, st));
-        c->havePoleSrcFree = true;
+        launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xs, extW);
       }
     }
     {
@@ -572,85 +610,135 @@ void frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
       if (pole_mask & 12) {
         for (int e = 0; e < 2; ++e) {
           F.panoFlip[e].ensure(en * sizeof(uchar4));
-          launch_flip_both(st, F.pano[e].as<uchar4>(), F.panoFlip[e].as<uchar4>(), W, H, rows);  // TRSP:842-843 (only the rows the pole unit reads)
+          launch_flip_both(st, F.pano[e].as<uchar4>(), F.panoFlip[e].as<uchar4>(), W, H, rowsB);  // TRSP:842-843 (only the rows the pole unit reads)
         }
       }
       for (int u = 0; u < 4; ++u)
         if (pole_mask & (1 << u)) {
           const uchar4* side = (u < 2) ? F.pano[u & 1].as<uchar4>() : F.panoFlip[u & 1].as<uchar4>();
-          dev_feather_alpha_to_ext(c, side, W, rows, ext + u * xn, extW);
+          dev_feather_alpha_to_ext(c, side, W, rowsOf(u), ext + u * xs, extW);
         }
     }
-    {
-      // computeOpticalFlow(extendedSide, extendedFisheye, ..., DOWN) for every enabled unit (TRSP:438-448)
-      if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
-      const PixFlowConsts pc = pixflow_consts_by_name(c->P.polar_flow_alg);
-      int u = 0;
-      while (u < 4) {
-        if (!(pole_mask & (1 << u))) { ++u; continue; }
-        int u1 = u;
-        while (u1 < 4 && (pole_mask & (1 << u1))) ++u1;
-        FlowIdx idx;
-        std::memset(&idx, 0, sizeof(idx));
-        for (int k = u; k < u1; ++k) { idx.i0[k - u] = k; idx.i1[k - u] = k < 2 ? 4 : 5; }
-        c->flow_pole->compute(st, pc, 6, u1 - u, idx, ext, extW, rows, usePrev ? F.extImgs[prv].as<uchar4>() : nullptr,
-                              usePrev ? F.poleFlows[prv].as<float2>() + u * xn : nullptr, S360_HINT_DOWN,
-                              F.poleFlows[cur].as<float2>() + u * xn);
-        u = u1;
-      }
+  }
+  if (c->pipeline) {  // the next frame's novel views may overwrite the strips from here on
+    S360_HIP(hipEventRecord(c->evStripsFree, st));
+    c->haveStripsFree = true;
+  }
+  if (pole_mask) {
+    if (c->evPoleSrcFree) {  // the next frame's pole images may be converted into topSrc / botSrc from here on
+      S360_HIP(hipEventRecord(c->evPoleSrcFree, st));
+      c->havePoleSrcFree = true;
     }
-    {
-      ProfScope ps(prof, "pole_warp");
-      for (int u = 0; u < 4; ++u)
-        if (pole_mask & (1 << u)) {
-          F.poleWarped[u].ensure(en * sizeof(uchar4));
-          dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xn, F.poleFlows[cur].as<float2>() + u * xn, W, rows, extW,
-                             F.poleWarped[u].as<uchar4>(), H);
+    // computeOpticalFlow(extendedSide, extendedFisheye, ..., DOWN) for every enabled unit (TRSP:438-448)
+    if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
+    const PixFlowConsts pc = pixflow_consts_by_name(c->P.polar_flow_alg);
+    auto run = [&](int mask, int rows) {
+      if (!mask) return;
+      FlowBatch fb;
+      for (int k : slotIds) {
+        SlotScope ss(c, k);
+        FrameState& F = frame_state(c);
+        const int cur = F.cur_pole, prv = cur ^ 1;
+        const uchar4* ext = F.extImgs[cur].as<uchar4>();
+        const uchar4* pext = usePrev ? F.extImgs[prv].as<uchar4>() : nullptr;
+        int fishIdx[2] = {-1, -1};
+        for (int u = 0; u < 4; ++u) {
+          if (!(mask & (1 << u))) continue;
+          const int pole = u >> 1;  // 0 top, 1 bottom
+          if (fishIdx[pole] < 0) {
+            fishIdx[pole] = (int)fb.images.size();
+            fb.images.push_back(ext + (4 + pole) * xs);
+            if (usePrev) fb.prev_images.push_back(pext + (4 + pole) * xs);
+          }
+          const int sideIdx = (int)fb.images.size();
+          fb.images.push_back(ext + u * xs);
+          if (usePrev) fb.prev_images.push_back(pext + u * xs);
+          fb.add_flow(sideIdx, fishIdx[pole], F.poleFlows[cur].as<float2>() + u * xs,
+                      usePrev ? F.poleFlows[prv].as<float2>() + u * xs : nullptr);
         }
-    }
-    F.extW = extW;
-    F.poleRows = rows;
-    F.have_prev_pole = true;
-    F.last_pole = cur;
-    F.cur_pole ^= 1;
-  }
-  {
-    ProfScope ps(prof, "flatten");  // TRSP:864-885
-    for (int e = 0; e < 2; ++e) {
-      if (pole_mask & (1 << e)) {
-        launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 0,
-                       F.tab.dev);
-        std::swap(F.pano[e].p, F.panoTmp.p);
-        std::swap(F.pano[e].cap, F.panoTmp.cap);
       }
-      if (pole_mask & (4 << e)) {
-        launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[2 + e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 1,
-                       F.tab.dev);
-        std::swap(F.pano[e].p, F.panoTmp.p);
-        std::swap(F.pano[e].cap, F.panoTmp.cap);
-      }
+      c->flow_pole->compute(st, pc, fb, extW, rows, S360_HINT_DOWN);
+    };
+    if (rowsT == rowsB) {
+      run(pole_mask, rowsT);
+    } else {
+      run(pole_mask & 3, rowsT);
+      run(pole_mask & 12, rowsB);
     }
   }
-  {
-    ProfScope ps(prof, "finish");  // TRSP:890-961
-    const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
-    F.outBGR.ensure((size_t)outW * outH * 3);
-    const bool resize = (outW != W) || (eyeH != H);
-    for (int e = 0; e < 2; ++e) {
-      uchar4* eye = F.pano[e].as<uchar4>();
-      if (c->P.sharpening > 0.0) {
-        F.sharpLp.ensure(en * sizeof(uchar4));
-        F.sharpBuf.ensure(sharpen_scratch_bytes(W, H));
-        launch_sharpen(st, eye, F.sharpLp.as<uchar4>(), F.sharpBuf.as<float>(), W, H, 1.0f + (float)c->P.sharpening);
+  for (int k : slotIds) {
+    SlotScope ss(c, k);
+    FrameState& F = frame_state(c);
+    if (pole_mask) {
+      const int cur = F.cur_pole;
+      const uchar4* ext = F.extImgs[cur].as<uchar4>();
+      {
+        ProfScope ps(prof, "pole_warp");
+        for (int u = 0; u < 4; ++u)
+          if (pole_mask & (1 << u)) {
+            F.poleWarped[u].ensure(en * sizeof(uchar4));
+            dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xs, F.poleFlows[cur].as<float2>() + u * xs, W, rowsOf(u), extW,
+                               F.poleWarped[u].as<uchar4>(), H);
+          }
       }
-      if (resize) {
-        F.eyeFinal[e].ensure((size_t)outW * eyeH * sizeof(uchar4));
-        launch_resize_cubic_u8c4(st, eye, W, H, en, F.eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);
-        eye = F.eyeFinal[e].as<uchar4>();
+      F.extW = extW;
+      F.extStride = xs;
+      F.poleRowsT = rowsT;
+      F.poleRowsB = rowsB;
+      F.have_prev_pole = true;
+      F.last_pole = cur;
+      F.cur_pole ^= 1;
+    }
+    {
+      ProfScope ps(prof, "flatten");  // TRSP:864-885
+      for (int e = 0; e < 2; ++e) {
+        if (pole_mask & (1 << e)) {
+          launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 0,
+                         F.tab.dev);
+          std::swap(F.pano[e].p, F.panoTmp.p);
+          std::swap(F.pano[e].cap, F.panoTmp.cap);
+        }
+        if (pole_mask & (4 << e)) {
+          launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[2 + e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 1,
+                         F.tab.dev);
+          std::swap(F.pano[e].p, F.panoTmp.p);
+          std::swap(F.pano[e].cap, F.panoTmp.cap);
+        }
       }
-      launch_pack_bgr(st, eye, outW, eyeH, F.outBGR.as<uint8_t>() + (size_t)e * outW * eyeH * 3);
+    }
+    {
+      ProfScope ps(prof, "finish");  // TRSP:890-961
+      const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
+      F.outBGR.ensure((size_t)outW * outH * 3);
+      const bool resize = (outW != W) || (eyeH != H);
+      for (int e = 0; e < 2; ++e) {
+        uchar4* eye = F.pano[e].as<uchar4>();
+        if (c->P.sharpening > 0.0) {
+          F.sharpLp.ensure(en * sizeof(uchar4));
+          F.sharpBuf.ensure(sharpen_scratch_bytes(W, H));
+          launch_sharpen(st, eye, F.sharpLp.as<uchar4>(), F.sharpBuf.as<float>(), W, H, 1.0f + (float)c->P.sharpening);
+        }
+        if (resize) {
+          F.eyeFinal[e].ensure((size_t)outW * eyeH * sizeof(uchar4));
+          launch_resize_cubic_u8c4(st, eye, W, H, en, F.eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);
+          eye = F.eyeFinal[e].as<uchar4>();
+        }
+        launch_pack_bgr(st, eye, outW, eyeH, F.outBGR.as<uint8_t>() + (size_t)e * outW * eyeH * 3);
+      }
     }
   }
+}
+void frame_finish(s360_ctx* c, int pole_mask, int use_prev) { finish_stage(c, {c->slot}, pole_mask, use_prev); }
+
+// Every slot at once (independent frames of a multi-stream job): one launch sequence, the 28 side flows of every slot
+// in ONE batch of the flow kernels, the 4 pole flows of every slot in another. Results per slot are those of
+// s360_frame_render on that slot.
+void frame_render_batch(s360_ctx* c, int use_prev) {
+  if (c->pipeline) throw Error(S360_ERR_STATE, "frame pipelining and batched slots are separate modes");
+  std::vector<int> ids;
+  for (int k = 0; k < (int)std::max<size_t>(c->slots.size(), 1); ++k) ids.push_back(k);
+  side_stage(c, ids, 0, (int)c->rig.side.size(), use_prev);
+  finish_stage(c, ids, 15, use_prev);
 }
 
 // ---- cubemap output (TRSP:917-935) -------------------------------------------------------------------------------

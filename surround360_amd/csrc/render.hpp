@@ -26,12 +26,12 @@ struct FrameState {
   int srcW = 0, srcH = 0;
   int topW = 0, topH = 0, poleW = 0, poleH = 0;  // top camera image; bottom camera image (poleW/poleH: also pole removal)
   unsigned long long side_uploaded = 0;          // bit i: side camera i has an image (cleared by nothing: images persist)
-  bool have_side = false, have_top = false, have_bottom = false, maps_ready = false;
+  bool have_side = false, have_top = false, have_bottom = false;
   DevBuf staging, sideSrc, topSrc, botSrc;
-  DevBuf sideMaps, topMap, botMap;
   DevBuf proj;
   DevBuf overlaps[2], sideFlows[2];  // [cur/prev] temporal double buffer
   int side_p0 = 0, side_p1 = 0;       // pairs held by overlaps/sideFlows (local partition)
+  bool partition_declared = false;    // s360_frame_set_partition was called (set_prev_side then fills that block)
   DevBuf strips;                      // [2][P][camH][stripW]
   DevBuf pano[2], panoFlip[2], panoTmp;
   DevBuf topSph, botSph;
@@ -43,7 +43,8 @@ struct FrameState {
   bool have_prev_side = false, have_prev_pole = false;
   bool keep_intermediates = false;  // copy panoramas before the pole composite (parity tests)
   DevBuf panoDbg[2];
-  int extW = 0, poleRows = 0;
+  int extW = 0, poleRowsT = 0, poleRowsB = 0;  // geometry the pole temporal state was produced with
+  size_t extStride = 0;                        // pixels between the slots of extImgs / poleFlows (extW * max rows)
   // pole removal: secondary bottom source (BGRA), red-mask planes, flow inputs [cur/prev][2][n], flow [cur/prev][n]
   DevBuf botSrc2, prRed[2], prImgs[2], prFlow[2], prTmp, prWarp, prMerged;
   bool have_pr_inputs = false, have_prev_pr = false;
@@ -58,8 +59,20 @@ void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h);
 void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w, int h);
 void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev);
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev);
+// all slots at once: per-frame kernels slot by slot, the side flows of all slots in one FlowEngine batch, the pole
+// flows of all slots in another
+void frame_render_batch(s360_ctx* c, int use_prev);
+void set_frame_slots(s360_ctx* c, int n);
 // stereo cubemap of the last finished frame into F.cubeOut; returns its width/height through ow/oh
 void frame_cubemap(s360_ctx* c, int face_w, int face_h, bool video, int* ow, int* oh);
+
+// RCCL strip gather of the sharded frame (comm.cpp)
+void comm_unique_id(void* id128);
+void comm_init_rank(s360_ctx* c, const void* id128, int rank, int nranks);
+void comm_init_all(s360_ctx* const* ctxs, int n);
+void comm_destroy(s360_ctx* c);
+void frame_gather_strips(s360_ctx* c, const int* bounds, int root);
+void comm_loopback(s360_ctx* c, int src_pair, int dst_pair);
 
 // operator-level helpers on device buffers
 // erode_size < 0: the context's std_alpha_feather_size and its cached Gaussian taps; otherwise `taps` (device, erode_size ints)

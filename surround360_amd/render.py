@@ -229,6 +229,16 @@ class Context:
         assert b2.shape == m1.shape == m2.shape and b2.shape[2] == 3
         self._ck(lib().s360_frame_upload_pole_removal(self.h, _p(b2), _p(m1), _p(m2), b2.shape[1], b2.shape[0]))
 
+    # ---- frame slots: several independent frames through one launch sequence ----
+    def set_frame_slots(self, n):
+        self._ck(lib().s360_set_frame_slots(self.h, int(n)))
+
+    def select_frame_slot(self, k):
+        self._ck(lib().s360_select_frame_slot(self.h, int(k)))
+
+    def render_batch(self, use_prev=False):
+        self._ck(lib().s360_frame_render_batch(self.h, int(use_prev)))
+
     def render(self, use_prev=False):
         self._ck(lib().s360_frame_render(self.h, int(use_prev)))
 
@@ -237,6 +247,29 @@ class Context:
 
     def finish(self, pole_mask=15, use_prev=False):
         self._ck(lib().s360_frame_finish(self.h, pole_mask, int(use_prev)))
+
+    # ---- multi-GPU: sharded frame + native RCCL strip gather (s360.h, "multi-GPU") ----
+    @staticmethod
+    def comm_get_unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().s360_comm_get_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, unique_id, rank, nranks):
+        self._ck(lib().s360_comm_init_rank(self.h, C.c_char_p(unique_id), int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        self._ck(lib().s360_comm_destroy(self.h))
+
+    def gather_strips(self, bounds, root=0):
+        arr = (C.c_int * len(bounds))(*bounds)
+        self._ck(lib().s360_frame_gather_strips(self.h, arr, int(root)))
+
+    def comm_loopback(self, src_pair, dst_pair):
+        self._ck(lib().s360_comm_loopback(self.h, int(src_pair), int(dst_pair)))
+
+    def set_partition(self, p0, p1):
+        self._ck(lib().s360_frame_set_partition(self.h, int(p0), int(p1)))
 
     def strip_ptr(self, eye):
         p = C.c_void_p()

@@ -152,6 +152,109 @@ def test_strip_buffer_view_for_the_gather(setup):
         c2.close()
 
 
+def test_frame_slots_batch_equals_single(setup):
+    """s360_frame_render_batch: three different frames in three slots of one context — the 84 side flows in one batch
+    of the flow kernels, the 12 pole flows in another — must give, slot by slot, the bytes of s360_frame_render; a
+    second batch with use_prev continues three independent temporal chains."""
+    rig = R.RigDescription(setup["path"])
+    yaws = (0.0, 0.7, 1.4)
+    f0 = [rigutil.frame_inputs(setup["path"], CAM, yaw_deg=y) for y in yaws]
+    f1 = [rigutil.frame_inputs(setup["path"], CAM, yaw_deg=y + 0.3) for y in yaws]
+    want = []
+    for a, b in zip(f0, f1):
+        c1 = R.Context(rig, R.make_params(**setup["flags"]))
+        c1.upload_frame(*a)
+        c1.render()
+        first = c1.download_equirect()
+        c1.upload_frame(*b)
+        c1.render(use_prev=True)
+        want.append((first, c1.download_equirect(), c1.get_f32("flow_pole", 1), c1.get_f32("flow_r_to_l", 6)))
+        c1.close()
+    cb = R.Context(rig, R.make_params(**setup["flags"]))
+    try:
+        cb.set_frame_slots(3)
+        cb.set_sweep_mode("throughput")
+        for k in range(3):
+            cb.select_frame_slot(k)
+            cb.upload_frame(*f0[k])
+        cb.render_batch()
+        for k in range(3):
+            cb.select_frame_slot(k)
+            _cmp("batched slot %d" % k, cb.download_equirect(), want[k][0])
+            cb.upload_frame(*f1[k])
+        cb.render_batch(use_prev=True)
+        for k in range(3):
+            cb.select_frame_slot(k)
+            _cmp("batched temporal slot %d" % k, cb.download_equirect(), want[k][1])
+            _cmp("batched temporal flow_pole slot %d" % k, cb.get_f32("flow_pole", 1), want[k][2])
+            _cmp("batched temporal flow_r_to_l slot %d" % k, cb.get_f32("flow_r_to_l", 6), want[k][3])
+        with pytest.raises(R.S360Error):
+            cb.select_frame_slot(3)
+    finally:
+        cb.close()
+
+
+def test_native_rccl_gather_single_rank(setup):
+    """The native strip gather (comm.cpp: grouped ncclSend/ncclRecv on the context stream) on the one GPU there is:
+    a one-rank communicator, the gather as a no-op between render_pairs and finish, and one real RCCL send+recv of
+    the rank to itself between two strip slots (checked through the torch view of the strip buffer)."""
+    import torch
+    from surround360_amd import parallel
+    rig = R.RigDescription(setup["path"])
+    c2 = R.Context(rig, R.make_params(**setup["flags"]))
+    try:
+        c2.comm_init_rank(R.Context.comm_get_unique_id(), 0, 1)
+        c2.upload_frame(setup["side"], setup["top"], setup["bottom"])
+        c2.render_pairs(0, 14)
+        c2.gather_strips([0, 14], 0)
+        c2.finish(15)
+        _cmp("one-rank sharded frame", c2.download_equirect(), setup["got"])
+        strips = parallel.strips_tensor(c2, torch.device("cuda", 0))
+        before = strips[0, 3].clone()
+        assert not torch.equal(strips[0, 3], strips[0, 9])
+        c2.comm_loopback(3, 9)
+        c2.synchronize()
+        assert torch.equal(strips[0, 9], before) and torch.equal(strips[0, 3], before)
+        with pytest.raises(R.S360Error):
+            c2.gather_strips([0, 7, 14], 0)  # bounds for two ranks on a one-rank communicator
+        c2.comm_destroy()
+        with pytest.raises(R.S360Error):
+            c2.gather_strips([0, 14], 0)
+    finally:
+        c2.close()
+
+
+def test_partitioned_temporal_state(setup, oracle):
+    """s360_frame_set_partition + s360_frame_set_prev_side for a block of pairs: what a rank of the sharded frame
+    does when the previous frame's state comes from files. The block's flows must equal the full frame's."""
+    side, top, bottom = rigutil.frame_inputs(setup["path"], CAM, yaw_deg=1.5)
+    ctx = setup["ctx"]
+    ctx.upload_frame(setup["side"], setup["top"], setup["bottom"])
+    ctx.render()
+    prev = {i: (ctx.get_f32("flow_l_to_r", i), ctx.get_f32("flow_r_to_l", i), ctx.get_u8("overlap_l", i),
+                ctx.get_u8("overlap_r", i)) for i in range(4, 9)}
+    ctx.upload_frame(side, top, bottom)
+    ctx.render(use_prev=True)
+    want = {i: (ctx.get_f32("flow_l_to_r", i), ctx.get_f32("flow_r_to_l", i)) for i in range(4, 9)}
+    rig = R.RigDescription(setup["path"])
+    c2 = R.Context(rig, R.make_params(**setup["flags"]))
+    try:
+        c2.set_partition(4, 9)
+        for i, (fl, fr, ol, orr) in prev.items():
+            check = R._capi.check
+            check(R.lib().s360_frame_set_prev_side(c2.h, i, R._p(fl), R._p(fr), R._p(ol), R._p(orr)), c2.h)
+        with pytest.raises(R.S360Error):
+            R._capi.check(R.lib().s360_frame_set_prev_side(c2.h, 2, R._p(prev[4][0]), R._p(prev[4][1]), R._p(prev[4][2]),
+                                                           R._p(prev[4][3])), c2.h)
+        c2.upload_frame(side, top, bottom)
+        c2.render_pairs(4, 9, use_prev=True)
+        for i in range(4, 9):
+            _cmp("partitioned temporal flow_l_to_r %d" % i, c2.get_f32("flow_l_to_r", i), want[i][0])
+            _cmp("partitioned temporal flow_r_to_l %d" % i, c2.get_f32("flow_r_to_l", i), want[i][1])
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("fmt,fw,fh", [("video", 96, 80), ("photo", 64, 64)])
 def test_cubemap(setup, fmt, fw, fh):
     """Stereo cubemap of the rendered frame (convertSphericalToCubemapBicubicRemap + stackOutputCubemapFaces,
@@ -167,6 +270,28 @@ def test_cubemap(setup, fmt, fw, fh):
     assert got.std() > 5
     with pytest.raises(R.S360Error):
         ctx.cubemap(fw, fh, "cross")
+
+
+def test_pipelined_readers_wait_for_finish(setup):
+    """With frame pipelining on, s360_frame_cubemap and the eye getters launch kernels that read the panoramas the
+    finish stream composites: they must be ordered after it (they used to read a half-composited image)."""
+    rig = R.RigDescription(setup["path"])
+    ref = R.Context(rig, R.make_params(**setup["flags"]))
+    pip = R.Context(rig, R.make_params(**setup["flags"]))
+    try:
+        pip.set_frame_pipelining(True)
+        for c in (ref, pip):
+            c.upload_frame(setup["side"], setup["top"], setup["bottom"])
+        for _ in range(3):
+            ref.render()
+            want_cube, want_eye = ref.cubemap(96, 80, "video"), ref.get_u8("eye_r")
+            pip.render()  # no synchronisation before the readers
+            _cmp("pipelined cubemap", pip.cubemap(96, 80, "video"), want_cube)
+            pip.render()
+            _cmp("pipelined eye_r", pip.get_u8("eye_r"), want_eye)
+    finally:
+        ref.close()
+        pip.close()
 
 
 def test_pole_removal_two_frames(tmp_path, rig_json, oracle, s360lib):

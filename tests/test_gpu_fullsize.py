@@ -152,6 +152,32 @@ def test_config3_contexts_in_flight_equal_single(frame8k, gpu_rig):
             c.close()
 
 
+def test_config3_frame_slots_batch(frame8k, gpu_rig):
+    """Two different 8K frames in two slots of one context (56 side flows / 8 pole flows per batched launch) equal
+    the frames rendered one by one."""
+    cb = R.Context(gpu_rig, R.make_params(**FLAGS_8K))
+    c1 = R.Context(gpu_rig, R.make_params(**FLAGS_8K))
+    try:
+        cb.set_frame_slots(2)
+        cb.set_sweep_mode("throughput")
+        for k in range(2):
+            cb.select_frame_slot(k)
+            cb.upload_frame(*frame8k["frames"][k])
+        cb.render_batch()
+        for k in range(2):
+            cb.select_frame_slot(k)
+            if k == 0:
+                want = frame8k["got"]
+            else:
+                c1.upload_frame(*frame8k["frames"][1])
+                c1.render()
+                want = c1.download_equirect()
+            _cmp("8K batched slot %d" % k, cb.download_equirect(), want)
+    finally:
+        cb.close()
+        c1.close()
+
+
 def test_config5_second_frame_temporal(frame8k):
     """BASELINE configs[4] shape: frame k+1 (world rotated 0.2 deg, the disc moved) regularised toward frame k's
     device-resident flows and images (--prev_frame_data_dir semantics), at 8K."""

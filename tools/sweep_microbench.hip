@@ -20,6 +20,14 @@ using namespace s360;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 static unsigned long long g_ts[8];
+static FlowIdx make_idx(int B) {  // flow b: image b against image (b + B) mod 2B (device arrays, leaked: a tool)
+  std::vector<int> h(2 * B);
+  for (int b = 0; b < B; ++b) { h[b] = b % (2 * B); h[B + b] = (b + B) % (2 * B); }
+  int* d = nullptr;
+  CK(hipMalloc(&d, h.size() * sizeof(int)));
+  CK(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  return FlowIdx{d, d + B};
+}
 static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad, 5 mono*/, int reps) {
   const size_t n = (size_t)w * h;
   std::mt19937 rng(1234);
@@ -47,8 +55,7 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad, 5 mo
   CK(hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(drec, hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dflow, hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
-  FlowIdx idx;
-  for (int b = 0; b < kMaxFlows; ++b) { idx.i0[b] = b % (2 * B); idx.i1[b] = (b + B) % (2 * B); }
+  FlowIdx idx = make_idx(B);
   PixFlowConsts pc{0.9f, 0.001f, 0.01f, 0.01f, 0.5f, 0.5f, 0};
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -117,8 +124,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
     CK(hipMemcpy(dflow[k], hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
     CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
   }
-  FlowIdx idx;
-  for (int b = 0; b < kMaxFlows; ++b) { idx.i0[b] = b % (2 * B); idx.i1[b] = (b + B) % (2 * B); }
+  FlowIdx idx = make_idx(B);
   PixFlowConsts pc{0.9f, 0.001f, 0.01f, 0.01f, 0.5f, 0.5f, 0};
   std::vector<float> d{0.001f, (float)w, (float)h};
   sweep_verify_divisors(st[0], d);
