@@ -114,7 +114,6 @@ def main():
                     help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
                          "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
     ap.add_argument("--video-frames", type=int, default=32)
-    ap.add_argument("--throughput-mode", default="throughput", help="sweep mode of the in-flight contexts (A/B runs)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # hardware queues for the in-flight frames (read at HIP init)
@@ -167,7 +166,7 @@ def main():
                 c.select_frame_slot(j)
             c.upload_frame(*frames[k * S + j])  # inputs resident in HBM before the timed region
         if F * S > 1:
-            c.set_sweep_mode(args.throughput_mode)  # several frames in flight: the kernel with the fewest instructions per pixel
+            c.set_sweep_mode("throughput")  # several frames in flight: the kernel with the fewest instructions per pixel
 
     def sync(barrier=True):
         for c in ctxs:
@@ -327,7 +326,7 @@ def main():
                 "algorithmic_bytes_per_launch": per_launch_bytes, "note": note}
 
     # ---- isolated kernels: one context alone, throughput-mode kernel (the timed region's) and latency-mode kernel ----
-    tp_ms, tp_prof, _ = isolated(args.throughput_mode, 2)
+    tp_ms, tp_prof, _ = isolated("throughput", 2)
     roofline = sweep_roofline(
         tp_prof, "k_sweep_quad (PixFlow propagation sweeps, PixFlow.h:388-410)",
         "dominant kernel of the timed region, measured with ONE frame alone on the GPU (HIP events on the library's "

@@ -6,6 +6,8 @@
 // Kept on the host, as in the reference: flag parsing, the rig loader (inside libs360: rig.cpp), directory
 // scanning, PNG decode/encode (png_io.hpp instead of cv::imread/imwrite) and the flow-state files.
 // Not supported here: --save_debug_images (debug PNGs only).
+// Opt-in additions: --num_gpus G (one frame sharded over G GPUs, native RCCL strip gather) and --num_frames N (a
+// stream of N consecutive frames in one process: device-resident temporal state, overlapped I/O).
 #include <dirent.h>
 #include <sys/stat.h>
 
@@ -40,7 +42,13 @@ struct Flags {
          {"log_dir", ""}, {"stderrthreshold", "0"}, {"v", "0"}, {"logbuflevel", "0"}, {"logtostderr", "false"},
          {"alsologtostderr", "false"},
          // additions of this implementation (opt-in)
-         {"device", "0"}, {"write_state", "true"}};
+         {"device", "0"}, {"write_state", "true"},
+         // --num_gpus G: the 14 side pairs of the frame sharded over G GPUs, one RCCL strip gather
+         {"num_gpus", "1"},
+         // --num_frames N: frames frame_number .. +N-1 as ONE stream in this process (temporal state stays on the
+         // device, decode/upload/render/download/encode overlapped); output_equirect_path must contain %s or {frame}
+         // (the state files are written after the LAST frame only: that is what a later run resumes from)
+         {"num_frames", "1"}};
   }
   static bool is_bool(const std::string& k) {
     static const char* b[] = {"save_debug_images", "enable_top", "enable_bottom", "enable_pole_removal", "logtostderr",
@@ -143,10 +151,217 @@ void save_png(const std::string& path, const uint8_t* px, int w, int h, int c) {
   }
 }
 
+// One decoded frame of the rig (rig.loadSideCameraImages: one thread per camera, RigDescription.cpp:80-108)
+struct FrameInputs {
+  std::string frame;
+  std::vector<pngio::Image> side;
+  pngio::Image top, bottom, bottom2, mask1, mask2;
+};
+
+struct Job {
+  Flags F;
+  std::vector<s360_camera> cams;
+  std::vector<int> sideIdx;
+  int P = 0, ncams = 0, ti = -1, bi = -1, b2 = -1;
+  s360_params prm;
+  s360_geometry g;
+  std::vector<s360_ctx*> ctx;  // one per GPU; ctx[0] is the root (poles, composite, output)
+  std::vector<int> bounds;     // pairs [bounds[r], bounds[r+1]) are rendered by ctx[r]
+  int extW = 0;
+};
+
+FrameInputs load_frame(const Job& J, const std::string& frame) {
+  FrameInputs in;
+  in.frame = frame;
+  in.side.resize(J.P);
+  const std::string imgs = J.F.s("imgs_dir");
+  std::vector<std::thread> th;
+  for (int k = 0; k < J.P; ++k)
+    th.emplace_back([&, k] {
+      const std::string dir = imgs + "/" + J.cams[J.sideIdx[k]].id;
+      in.side[k] = load_png(dir + "/" + frame + image_extension(dir), false);
+    });
+  if (J.prm.enable_top) th.emplace_back([&] { in.top = load_png(imgs + "/" + J.cams[J.ti].id + "/" + frame + ".png", false); });  // TRSP:652
+  if (J.prm.enable_bottom) {
+    th.emplace_back([&] { in.bottom = load_png(imgs + "/" + J.cams[J.bi].id + "/" + frame + ".png", false); });  // TRSP:602
+    if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:48-66
+      const std::string masks = J.F.s("bottom_pole_masks_dir");
+      th.emplace_back([&] { in.bottom2 = load_png(imgs + "/" + J.cams[J.b2].id + "/" + frame + ".png", false); });
+      th.emplace_back([&, masks] { in.mask1 = load_png(masks + "/" + J.cams[J.bi].id + ".png", false); });
+      th.emplace_back([&, masks] { in.mask2 = load_png(masks + "/" + J.cams[J.b2].id + ".png", false); });
+    }
+  }
+  for (auto& t : th) t.join();
+  if (J.prm.enable_pole_removal) {
+    const pngio::Image& im = in.bottom;
+    if (in.bottom2.w != im.w || in.bottom2.h != im.h || in.mask1.w != im.w || in.mask1.h != im.h || in.mask2.w != im.w || in.mask2.h != im.h)
+      die("missing or bad pole mask:" + J.F.s("bottom_pole_masks_dir") + "/" + J.cams[J.bi].id + ".png," + J.F.s("bottom_pole_masks_dir") + "/" + J.cams[J.b2].id + ".png");
+  }
+  return in;
+}
+
+// every GPU gets the side images its pairs touch; the root also gets the pole images (asynchronous: upload stream)
+void upload_frame(const Job& J, const FrameInputs& in) {
+  const int G = (int)J.ctx.size();
+  for (int r = 0; r < G; ++r) {
+    std::vector<char> need(J.P, 0);
+    for (int p = J.bounds[r]; p < J.bounds[r + 1]; ++p) need[p] = need[(p + 1) % J.P] = 1;
+    for (int k = 0; k < J.P; ++k)
+      if (need[k]) ck(s360_frame_upload_side(J.ctx[r], k, in.side[k].px.data(), in.side[k].w, in.side[k].h, in.side[k].c), J.ctx[r]);
+  }
+  s360_ctx* root = J.ctx[0];
+  if (J.prm.enable_top) ck(s360_frame_upload_top(root, in.top.px.data(), in.top.w, in.top.h), root);
+  if (J.prm.enable_bottom) {
+    ck(s360_frame_upload_bottom(root, in.bottom.px.data(), in.bottom.w, in.bottom.h), root);
+    if (J.prm.enable_pole_removal)
+      ck(s360_frame_upload_pole_removal(root, in.bottom2.px.data(), in.mask1.px.data(), in.mask2.px.data(), in.bottom.w, in.bottom.h), root);
+  }
+}
+
+const char* const kEyeNames[4] = {"top_left", "top_right", "bottom_left", "bottom_right"};
+
+// previous frame's state from files (TRSP:215-235, 421-436), each pair to the GPU that renders it
+void load_prev_state(const Job& J, const std::string& prev) {
+  const s360_geometry& g = J.g;
+  const std::string outData = J.F.s("output_data_dir");
+  const std::string flowPrevDir = outData + "/flow/" + prev, imgPrevDir = outData + "/debug/" + prev + "/flow_images/";
+  const size_t on = (size_t)g.overlap_image_width * g.cam_image_height;
+  std::vector<float> fl(on * 2), fr(on * 2);
+  for (size_t r = 0; r < J.ctx.size(); ++r) {
+    ck(s360_frame_set_partition(J.ctx[r], J.bounds[r], J.bounds[r + 1]), J.ctx[r]);
+    for (int i = J.bounds[r]; i < J.bounds[r + 1]; ++i) {
+      int w = 0, h = 0;
+      if (s360_read_flow_from_file((flowPrevDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), &w, &h, fl.size()) < 0 ||
+          w != g.overlap_image_width || h != g.cam_image_height)
+        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
+      if (s360_read_flow_from_file((flowPrevDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fr.data(), &w, &h, fr.size()) < 0 ||
+          w != g.overlap_image_width || h != g.cam_image_height)
+        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
+      const pngio::Image L = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_L.png", true);
+      const pngio::Image R = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_R.png", true);
+      if (L.c != 4 || R.c != 4 || L.w != g.overlap_image_width || L.h != g.cam_image_height || R.w != L.w || R.h != L.h)
+        die("previous overlap images have the wrong size/channels");
+      ck(s360_frame_set_prev_side(J.ctx[r], i, fl.data(), fr.data(), L.px.data(), R.px.data()), J.ctx[r]);
+    }
+  }
+  s360_ctx* root = J.ctx[0];
+  if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:95-110
+    int w = 0, h = 0;
+    if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), nullptr, &w, &h, 0) < 0)
+      die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
+    std::vector<float> pf((size_t)w * h * 2);
+    if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), pf.data(), &w, &h, pf.size()) < 0)
+      die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
+    const pngio::Image b1 = load_png(imgPrevDir + "/bottomImage.png", true), b2 = load_png(imgPrevDir + "/bottomImage2.png", true);
+    if (b1.c != 4 || b2.c != 4 || b1.w != w || b1.h != h || b2.w != w || b2.h != h)
+      die("previous bottomImage / bottomImage2 have the wrong size/channels");
+    ck(s360_frame_set_prev_pole_removal(root, pf.data(), b1.px.data(), b2.px.data(), w, h), root);
+  }
+  for (int u = 0; u < 4; ++u) {
+    if ((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom)) continue;
+    const int rows = u < 2 ? g.top_rows : g.bottom_rows;
+    std::vector<float> pf((size_t)J.extW * rows * 2);
+    int w = 0, h = 0;
+    if (s360_read_flow_from_file((flowPrevDir + "/flow_" + kEyeNames[u] + ".bin").c_str(), pf.data(), &w, &h, pf.size()) < 0 || w != J.extW || h != rows)
+      die(std::string("bad previous pole flow file: ") + kEyeNames[u]);
+    const pngio::Image S = load_png(imgPrevDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png", true);
+    const pngio::Image Fi = load_png(imgPrevDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png", true);
+    if (S.c != 4 || Fi.c != 4 || S.w != J.extW || S.h != rows || Fi.w != J.extW || Fi.h != rows)
+      die("previous extended pole images have the wrong size/channels");
+    ck(s360_frame_set_prev_pole(root, u, pf.data(), S.px.data(), Fi.px.data()), root);
+  }
+}
+
+// Enqueue one frame. One GPU: the whole frame on its stream. G GPUs (TRSP:320-385): every GPU renders its
+// block of pairs, ONE grouped RCCL exchange gathers the strips on the root, the root runs the pole units and the
+// composite. One host thread per GPU for the collective call (single-process RCCL).
+void render_frame(const Job& J, bool usePrev) {
+  const int G = (int)J.ctx.size();
+  if (G == 1) {
+    ck(s360_frame_render(J.ctx[0], usePrev ? 1 : 0), J.ctx[0]);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int r = 0; r < G; ++r)
+    th.emplace_back([&, r] {
+      ck(s360_frame_render_pairs(J.ctx[r], J.bounds[r], J.bounds[r + 1], usePrev ? 1 : 0), J.ctx[r]);
+      ck(s360_frame_gather_strips(J.ctx[r], J.bounds.data(), 0), J.ctx[r]);
+      if (r == 0) ck(s360_frame_finish(J.ctx[0], 15, usePrev ? 1 : 0), J.ctx[0]);
+    });
+  for (auto& t : th) t.join();
+}
+
+// state for the next frame: always written by the reference (TRSP:201-208, 247-255, 413-416, 451-452)
+void write_state(const Job& J, const std::string& frame) {
+  const s360_geometry& g = J.g;
+  const std::string outData = J.F.s("output_data_dir");
+  const std::string flowDir = outData + "/flow/" + frame, flowImagesDir = outData + "/debug/" + frame + "/flow_images";
+  mkdirs(flowDir);
+  mkdirs(flowImagesDir);
+  int whc[3];
+  const size_t on = (size_t)g.overlap_image_width * g.cam_image_height;
+  std::vector<uint8_t> img(on * 4);
+  std::vector<float> fl(on * 2);
+  for (size_t r = 0; r < J.ctx.size(); ++r) {
+    s360_ctx* c = J.ctx[r];
+    for (int i = J.bounds[r]; i < J.bounds[r + 1]; ++i) {
+      ck(s360_frame_get_u8(c, "overlap_l", i, whc, img.data()), c);
+      save_png(flowImagesDir + "/overlap_" + std::to_string(i) + "_L.png", img.data(), whc[0], whc[1], 4);
+      ck(s360_frame_get_u8(c, "overlap_r", i, whc, img.data()), c);
+      save_png(flowImagesDir + "/overlap_" + std::to_string(i) + "_R.png", img.data(), whc[0], whc[1], 4);
+      ck(s360_frame_get_f32(c, "flow_l_to_r", i, whc, fl.data()), c);
+      ck(s360_save_flow_to_file((flowDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
+      ck(s360_frame_get_f32(c, "flow_r_to_l", i, whc, fl.data()), c);
+      ck(s360_save_flow_to_file((flowDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
+    }
+  }
+  s360_ctx* root = J.ctx[0];
+  if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
+    ck(s360_frame_get_u8(root, "bottom_image", 0, whc, nullptr), root);
+    std::vector<uint8_t> bimg((size_t)whc[0] * whc[1] * 4);
+    std::vector<float> bfl((size_t)whc[0] * whc[1] * 2);
+    ck(s360_frame_get_u8(root, "bottom_image", 0, whc, bimg.data()), root);
+    save_png(flowImagesDir + "/bottomImage.png", bimg.data(), whc[0], whc[1], 4);
+    ck(s360_frame_get_u8(root, "bottom_image2", 0, whc, bimg.data()), root);
+    save_png(flowImagesDir + "/bottomImage2.png", bimg.data(), whc[0], whc[1], 4);
+    ck(s360_frame_get_f32(root, "flow_bottom_secondary", 0, whc, bfl.data()), root);
+    ck(s360_save_flow_to_file((flowDir + "/flow_bottom_secondary.bin").c_str(), bfl.data(), whc[0], whc[1]), nullptr);
+  }
+  for (int u = 0; u < 4; ++u) {
+    if ((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom)) continue;
+    const int rows = u < 2 ? g.top_rows : g.bottom_rows;
+    std::vector<uint8_t> e((size_t)J.extW * rows * 4);
+    std::vector<float> pf((size_t)J.extW * rows * 2);
+    ck(s360_frame_get_u8(root, "extended_side", u, whc, e.data()), root);
+    save_png(flowImagesDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
+    ck(s360_frame_get_u8(root, "extended_fisheye", u, whc, e.data()), root);
+    save_png(flowImagesDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
+    ck(s360_frame_get_f32(root, "flow_pole", u, whc, pf.data()), root);
+    ck(s360_save_flow_to_file((flowDir + "/flow_" + kEyeNames[u] + ".bin").c_str(), pf.data(), whc[0], whc[1]), nullptr);
+  }
+}
+
+// "000123" + 1 -> "000124" (same width); frame names of the reference's datasets are zero-padded decimal numbers
+std::string next_frame_name(const std::string& f) {
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%0*lld", (int)f.size(), std::atoll(f.c_str()) + 1);
+  return buf;
+}
+// output path of one frame in stream mode: "%s" (or "{frame}") in the flag value is replaced by the frame name
+std::string frame_path(const std::string& pattern, const std::string& frame) {
+  std::string out = pattern;
+  for (const char* key : {"%s", "{frame}"}) {
+    const size_t at = out.find(key);
+    if (at != std::string::npos) { out.replace(at, std::strlen(key), frame); return out; }
+  }
+  return out;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-  Flags F;
+  Job J;
+  Flags& F = J.F;
   F.parse(argc, argv);
   require_arg(F.s("rig_json_file"), "rig_json_file");  // TRSP:717-721
   require_arg(F.s("imgs_dir"), "imgs_dir");
@@ -156,16 +371,15 @@ int main(int argc, char** argv) {
   const int verbose = F.i("v");
   const double startTime = now_sec();
 
-  std::vector<s360_camera> cams(64);
-  const int ncams = s360_rig_load_json(F.s("rig_json_file").c_str(), cams.data(), (int)cams.size());
-  if (ncams < 0) die(s360_last_error(nullptr));
-  cams.resize(ncams);
-  std::vector<int> sideIdx;
-  for (int i = 0; i < ncams; ++i)
-    if (cams[i].is_side) sideIdx.push_back(i);
-  const int P = (int)sideIdx.size();
+  J.cams.resize(64);
+  J.ncams = s360_rig_load_json(F.s("rig_json_file").c_str(), J.cams.data(), (int)J.cams.size());
+  if (J.ncams < 0) die(s360_last_error(nullptr));
+  J.cams.resize(J.ncams);
+  for (int i = 0; i < J.ncams; ++i)
+    if (J.cams[i].is_side) J.sideIdx.push_back(i);
+  J.P = (int)J.sideIdx.size();
 
-  s360_params prm;
+  s360_params& prm = J.prm;
   std::memset(&prm, 0, sizeof prm);
   prm.interpupilary_dist = F.d("interpupilary_dist");
   prm.zero_parallax_dist = F.d("zero_parallax_dist");
@@ -183,169 +397,91 @@ int main(int argc, char** argv) {
   prm.enable_pole_removal = F.b("enable_pole_removal") && F.b("enable_bottom");
   std::strncpy(prm.poleremoval_flow_alg, F.s("poleremoval_flow_alg").c_str(), sizeof(prm.poleremoval_flow_alg) - 1);
   if (prm.enable_pole_removal) require_arg(F.s("bottom_pole_masks_dir"), "bottom_pole_masks_dir");  // TRSP:571
+  if (prm.enable_top && (J.ti = s360_rig_find_top(J.cams.data(), J.ncams)) < 0) die("no top camera in the rig");
+  if (prm.enable_bottom && (J.bi = s360_rig_find_bottom(J.cams.data(), J.ncams)) < 0) die("no bottom camera in the rig");
+  if (prm.enable_pole_removal) J.b2 = s360_rig_find_bottom2(J.cams.data(), J.ncams);
 
-  s360_ctx* ctx = nullptr;
-  if (s360_create(&ctx, F.i("device"), cams.data(), ncams, &prm) < 0) die(s360_last_error(nullptr));
-  s360_geometry g;
-  ck(s360_get_geometry(ctx, &g), ctx);
+  // ---- GPUs: --num_gpus G uses devices device .. device+G-1 (never more GPUs than pairs)
+  const int G = std::max(1, std::min(F.i("num_gpus"), J.P));
+  const int numFrames = std::max(1, F.i("num_frames"));
+  if (G > 1 && numFrames > 1) die("--num_gpus and --num_frames are separate modes (a stream keeps its temporal state on one GPU)");
+  if (G > s360_device_count() - F.i("device")) die("--num_gpus: not that many HIP devices");
+  J.ctx.resize(G, nullptr);
+  for (int r = 0; r < G; ++r)
+    if (s360_create(&J.ctx[r], F.i("device") + r, J.cams.data(), J.ncams, &prm) < 0) die(s360_last_error(nullptr));
+  ck(s360_get_geometry(J.ctx[0], &J.g), J.ctx[0]);
+  J.extW = int(float(prm.eqr_width) * 1.2f);
+  J.bounds.assign(1, 0);
+  for (int r = 0; r < G; ++r) J.bounds.push_back(J.bounds.back() + J.P / G + (r < J.P % G ? 1 : 0));  // 14 over 8 -> 2,2,2,2,2,2,1,1
+  if (G > 1) {
+    if (s360_comm_init_all(J.ctx.data(), G) < 0) die(s360_last_error(nullptr));
+    for (int r = 0; r < G; ++r) ck(s360_frame_set_partition(J.ctx[r], J.bounds[r], J.bounds[r + 1]), J.ctx[r]);
+  }
+  if (numFrames > 1) ck(s360_set_frame_pipelining(J.ctx[0], 1), J.ctx[0]);  // pole stage of frame k overlaps side stage of k+1
 
-  // ---- load + upload the camera images (rig.loadSideCameraImages: one thread per camera, RigDescription.cpp:80-108)
-  const std::string frame = F.s("frame_number"), imgs = F.s("imgs_dir");
-  std::vector<pngio::Image> sideImgs(P);
-  {
-    std::vector<std::thread> th;
-    for (int k = 0; k < P; ++k)
-      th.emplace_back([&, k] {
-        const std::string dir = imgs + "/" + cams[sideIdx[k]].id;
-        sideImgs[k] = load_png(dir + "/" + frame + image_extension(dir), false);
-      });
-    for (auto& t : th) t.join();
-  }
-  for (int k = 0; k < P; ++k) ck(s360_frame_upload_side(ctx, k, sideImgs[k].px.data(), sideImgs[k].w, sideImgs[k].h, sideImgs[k].c), ctx);
-  if (prm.enable_top) {
-    const int ti = s360_rig_find_top(cams.data(), ncams);
-    if (ti < 0) die("no top camera in the rig");
-    const pngio::Image im = load_png(imgs + "/" + cams[ti].id + "/" + frame + ".png", false);  // TRSP:652
-    ck(s360_frame_upload_top(ctx, im.px.data(), im.w, im.h), ctx);
-  }
-  if (prm.enable_bottom) {
-    const int bi = s360_rig_find_bottom(cams.data(), ncams);
-    if (bi < 0) die("no bottom camera in the rig");
-    const pngio::Image im = load_png(imgs + "/" + cams[bi].id + "/" + frame + ".png", false);  // TRSP:602
-    ck(s360_frame_upload_bottom(ctx, im.px.data(), im.w, im.h), ctx);
-    if (prm.enable_pole_removal) {  // PoleRemoval.cpp:48-66
-      const int b2 = s360_rig_find_bottom2(cams.data(), ncams);
-      const std::string masks = F.s("bottom_pole_masks_dir");
-      const pngio::Image im2 = load_png(imgs + "/" + cams[b2].id + "/" + frame + ".png", false);
-      const pngio::Image m1 = load_png(masks + "/" + cams[bi].id + ".png", false);
-      const pngio::Image m2 = load_png(masks + "/" + cams[b2].id + ".png", false);
-      if (im2.w != im.w || im2.h != im.h || m1.w != im.w || m1.h != im.h || m2.w != im.w || m2.h != im.h)
-        die("missing or bad pole mask:" + masks + "/" + cams[bi].id + ".png," + masks + "/" + cams[b2].id + ".png");
-      ck(s360_frame_upload_pole_removal(ctx, im2.px.data(), m1.px.data(), m2.px.data(), im.w, im.h), ctx);
-    }
-  }
+  const s360_geometry& g = J.g;
+  const std::string prev = F.s("prev_frame_data_dir");
+  const bool cube = F.i("cubemap_width") > 0 && F.i("cubemap_height") > 0 && !F.s("output_cubemap_path").empty();
+  if (numFrames > 1 && cube) die("--output_cubemap_path is not available with --num_frames > 1");
+
+  // ---- frame 0: decode, upload, previous-frame state from files, render
+  std::string frame = F.s("frame_number");
+  FrameInputs in = load_frame(J, frame);
+  upload_frame(J, in);
   const double loadTime = now_sec();
-
-  // ---- previous frame's state (TRSP:215-235, 421-436)
-  const std::string outData = F.s("output_data_dir"), prev = F.s("prev_frame_data_dir");
-  const bool usePrev = prev != "NONE";
-  static const char* eyeNames[4] = {"top_left", "top_right", "bottom_left", "bottom_right"};
-  const int extW = int(float(prm.eqr_width) * 1.2f);
-  if (usePrev) {
-    const std::string flowPrevDir = outData + "/flow/" + prev, imgPrevDir = outData + "/debug/" + prev + "/flow_images/";
-    const size_t on = (size_t)g.overlap_image_width * g.cam_image_height;
-    std::vector<float> fl(on * 2), fr(on * 2);
-    for (int i = 0; i < P; ++i) {
-      int w = 0, h = 0;
-      if (s360_read_flow_from_file((flowPrevDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), &w, &h, fl.size()) < 0 ||
-          w != g.overlap_image_width || h != g.cam_image_height)
-        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
-      if (s360_read_flow_from_file((flowPrevDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fr.data(), &w, &h, fr.size()) < 0 ||
-          w != g.overlap_image_width || h != g.cam_image_height)
-        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
-      const pngio::Image L = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_L.png", true);
-      const pngio::Image R = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_R.png", true);
-      if (L.c != 4 || R.c != 4 || L.w != g.overlap_image_width || L.h != g.cam_image_height || R.w != L.w || R.h != L.h)
-        die("previous overlap images have the wrong size/channels");
-      ck(s360_frame_set_prev_side(ctx, i, fl.data(), fr.data(), L.px.data(), R.px.data()), ctx);
-    }
-    if (prm.enable_pole_removal) {  // PoleRemoval.cpp:95-110
-      int w = 0, h = 0;
-      if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), nullptr, &w, &h, 0) < 0)
-        die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
-      std::vector<float> pf((size_t)w * h * 2);
-      if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), pf.data(), &w, &h, pf.size()) < 0)
-        die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
-      const pngio::Image b1 = load_png(imgPrevDir + "/bottomImage.png", true), b2 = load_png(imgPrevDir + "/bottomImage2.png", true);
-      if (b1.c != 4 || b2.c != 4 || b1.w != w || b1.h != h || b2.w != w || b2.h != h)
-        die("previous bottomImage / bottomImage2 have the wrong size/channels");
-      ck(s360_frame_set_prev_pole_removal(ctx, pf.data(), b1.px.data(), b2.px.data(), w, h), ctx);
-    }
-    for (int u = 0; u < 4; ++u) {
-      if ((u < 2 && !prm.enable_top) || (u >= 2 && !prm.enable_bottom)) continue;
-      const int rows = u < 2 ? g.top_rows : g.bottom_rows;
-      std::vector<float> pf((size_t)extW * rows * 2);
-      int w = 0, h = 0;
-      if (s360_read_flow_from_file((flowPrevDir + "/flow_" + eyeNames[u] + ".bin").c_str(), pf.data(), &w, &h, pf.size()) < 0 || w != extW || h != rows)
-        die(std::string("bad previous pole flow file: ") + eyeNames[u]);
-      const pngio::Image S = load_png(imgPrevDir + "/extendedSideSpherical_" + eyeNames[u] + ".png", true);
-      const pngio::Image Fi = load_png(imgPrevDir + "/extendedFisheyeSpherical_" + eyeNames[u] + ".png", true);
-      if (S.c != 4 || Fi.c != 4 || S.w != extW || S.h != rows || Fi.w != extW || Fi.h != rows)
-        die("previous extended pole images have the wrong size/channels");
-      ck(s360_frame_set_prev_pole(ctx, u, pf.data(), S.px.data(), Fi.px.data()), ctx);
-    }
-  }
-
-  // ---- render on the GPU
+  if (prev != "NONE") load_prev_state(J, prev);
   const double renderStart = now_sec();
-  ck(s360_frame_render(ctx, usePrev ? 1 : 0), ctx);
-  std::vector<uint8_t> equirect((size_t)g.out_width * g.out_height * 3);
-  ck(s360_frame_download_equirect(ctx, equirect.data()), ctx);
-  const double renderEnd = now_sec();
+  render_frame(J, prev != "NONE");
 
-  // ---- state for the next frame: always written by the reference (TRSP:201-208, 247-255, 413-416, 451-452)
-  if (F.b("write_state")) {
-    const std::string flowDir = outData + "/flow/" + frame, flowImagesDir = outData + "/debug/" + frame + "/flow_images";
-    mkdirs(flowDir);
-    mkdirs(flowImagesDir);
-    int whc[3];
-    const size_t on = (size_t)g.overlap_image_width * g.cam_image_height;
-    std::vector<uint8_t> img(on * 4);
-    std::vector<float> fl(on * 2);
-    for (int i = 0; i < P; ++i) {
-      ck(s360_frame_get_u8(ctx, "overlap_l", i, whc, img.data()), ctx);
-      save_png(flowImagesDir + "/overlap_" + std::to_string(i) + "_L.png", img.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_u8(ctx, "overlap_r", i, whc, img.data()), ctx);
-      save_png(flowImagesDir + "/overlap_" + std::to_string(i) + "_R.png", img.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_f32(ctx, "flow_l_to_r", i, whc, fl.data()), ctx);
-      ck(s360_save_flow_to_file((flowDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
-      ck(s360_frame_get_f32(ctx, "flow_r_to_l", i, whc, fl.data()), ctx);
-      ck(s360_save_flow_to_file((flowDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
+  std::vector<uint8_t> equirect((size_t)g.out_width * g.out_height * 3), pending;
+  std::thread encoder;  // PNG encode + write of frame k-1 while frame k renders
+  std::string pendingPath;
+  double renderEnd = renderStart, stateEnd = renderStart;
+  for (int k = 0; k < numFrames; ++k) {
+    const bool last = k + 1 == numFrames;
+    std::string nextName;
+    if (!last) {  // feed frame k+1 behind frame k: the GPU never waits for the host
+      nextName = next_frame_name(frame);
+      FrameInputs nin = load_frame(J, nextName);
+      upload_frame(J, nin);     // upload stream: overlaps frame k
+      render_frame(J, true);    // temporal state stays on the device
     }
-    if (prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
-      ck(s360_frame_get_u8(ctx, "bottom_image", 0, whc, nullptr), ctx);
-      std::vector<uint8_t> bimg((size_t)whc[0] * whc[1] * 4);
-      std::vector<float> bfl((size_t)whc[0] * whc[1] * 2);
-      ck(s360_frame_get_u8(ctx, "bottom_image", 0, whc, bimg.data()), ctx);
-      save_png(flowImagesDir + "/bottomImage.png", bimg.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_u8(ctx, "bottom_image2", 0, whc, bimg.data()), ctx);
-      save_png(flowImagesDir + "/bottomImage2.png", bimg.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_f32(ctx, "flow_bottom_secondary", 0, whc, bfl.data()), ctx);
-      ck(s360_save_flow_to_file((flowDir + "/flow_bottom_secondary.bin").c_str(), bfl.data(), whc[0], whc[1]), nullptr);
+    if (last) ck(s360_frame_download_equirect(J.ctx[0], equirect.data()), J.ctx[0]);
+    else ck(s360_frame_download_equirect_of(J.ctx[0], 1, equirect.data()), J.ctx[0]);  // frame k, while k+1 renders
+    renderEnd = now_sec();
+    // the reference writes the state of every frame; a stream only needs it to resume after its last frame
+    if (F.b("write_state") && last) write_state(J, frame);
+    stateEnd = now_sec();
+    if (last && cube) {  // optional stereo cubemap (TRSP:917-935)
+      int whc[3];
+      ck(s360_frame_cubemap(J.ctx[0], F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, nullptr), J.ctx[0]);
+      std::vector<uint8_t> cubeImg((size_t)whc[0] * whc[1] * 3);
+      ck(s360_frame_cubemap(J.ctx[0], F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cubeImg.data()), J.ctx[0]);
+      save_png(F.s("output_cubemap_path"), cubeImg.data(), whc[0], whc[1], 3);
     }
-    for (int u = 0; u < 4; ++u) {
-      if ((u < 2 && !prm.enable_top) || (u >= 2 && !prm.enable_bottom)) continue;
-      const int rows = u < 2 ? g.top_rows : g.bottom_rows;
-      std::vector<uint8_t> e((size_t)extW * rows * 4);
-      std::vector<float> pf((size_t)extW * rows * 2);
-      ck(s360_frame_get_u8(ctx, "extended_side", u, whc, e.data()), ctx);
-      save_png(flowImagesDir + "/extendedSideSpherical_" + eyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_u8(ctx, "extended_fisheye", u, whc, e.data()), ctx);
-      save_png(flowImagesDir + "/extendedFisheyeSpherical_" + eyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_f32(ctx, "flow_pole", u, whc, pf.data()), ctx);
-      ck(s360_save_flow_to_file((flowDir + "/flow_" + eyeNames[u] + ".bin").c_str(), pf.data(), whc[0], whc[1]), nullptr);
-    }
+    if (encoder.joinable()) encoder.join();
+    pending.swap(equirect);
+    equirect.resize(pending.size());
+    pendingPath = numFrames > 1 ? frame_path(F.s("output_equirect_path"), frame) : F.s("output_equirect_path");
+    encoder = std::thread([&pending, pendingPath, &g] { save_png(pendingPath, pending.data(), g.out_width, g.out_height, 3); });  // TRSP:961
+    if (last) encoder.join();
+    frame = nextName;
   }
-  const double stateEnd = now_sec();
-  // optional stereo cubemap (TRSP:917-935)
-  if (F.i("cubemap_width") > 0 && F.i("cubemap_height") > 0 && !F.s("output_cubemap_path").empty()) {
-    int whc[3];
-    ck(s360_frame_cubemap(ctx, F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, nullptr), ctx);
-    std::vector<uint8_t> cube((size_t)whc[0] * whc[1] * 3);
-    ck(s360_frame_cubemap(ctx, F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cube.data()), ctx);
-    save_png(F.s("output_cubemap_path"), cube.data(), whc[0], whc[1], 3);
-  }
-  save_png(F.s("output_equirect_path"), equirect.data(), g.out_width, g.out_height, 3);  // TRSP:961
   const double endTime = now_sec();
   if (verbose >= 1) {  // the reference's VLOG(1) runtime breakdown, TRSP:964-971
     std::fprintf(stderr, "--- Runtime breakdown (sec) ---\n");
     std::fprintf(stderr, "load + decode + upload:  %.3f\n", loadTime - startTime);
     std::fprintf(stderr, "previous-frame state:    %.3f\n", renderStart - loadTime);
-    std::fprintf(stderr, "GPU render + download:   %.3f\n", renderEnd - renderStart);
-    std::fprintf(stderr, "state files:             %.3f\n", stateEnd - renderEnd);
-    std::fprintf(stderr, "equirect PNG encode:     %.3f\n", endTime - stateEnd);
+    if (numFrames == 1) {
+      std::fprintf(stderr, "GPU render + download:   %.3f  (%d GPU%s)\n", renderEnd - renderStart, G, G > 1 ? "s, RCCL strip gather" : "");
+      std::fprintf(stderr, "state files:             %.3f\n", stateEnd - renderEnd);
+      std::fprintf(stderr, "equirect PNG encode:     %.3f\n", endTime - stateEnd);
+    } else {
+      std::fprintf(stderr, "stream of %d frames:      %.3f  (%.3f per frame: decode, upload, render, download, encode overlapped)\n",
+                   numFrames, endTime - renderStart, (endTime - renderStart) / numFrames);
+    }
     std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
   }
-  s360_destroy(ctx);
+  for (s360_ctx* c : J.ctx) s360_destroy(c);
   return 0;
 }

@@ -58,7 +58,7 @@ SYMBOLS = [
     "s360_profile_enable", "s360_profile_get", "s360_save_flow_to_file", "s360_read_flow_from_file",
     "s360_comm_get_unique_id", "s360_comm_init_rank", "s360_comm_init_all", "s360_comm_destroy",
     "s360_frame_gather_strips", "s360_comm_loopback", "s360_frame_set_partition",
-    "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch",
+    "s360_frame_download_equirect_of", "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch",
 ]
 
 _lib = None

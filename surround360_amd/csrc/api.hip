@@ -201,6 +201,7 @@ void s360_destroy(s360_ctx* c) {
     (void)hipEventDestroy(c->evStripsFree);
   }
   if (c->evPoleSrcFree) (void)hipEventDestroy(c->evPoleSrcFree);
+  if (c->stDown) (void)hipStreamDestroy(c->stDown);
   if (c->stUp) {
     (void)hipStreamDestroy(c->stUp);
     (void)hipEventDestroy(c->evUploaded);
@@ -628,8 +629,8 @@ int s360_frame_equirect_dev(s360_ctx* c, void** dev_ptr, size_t* bytes) {
   return guard(c, [&] {
     need(c && dev_ptr, "bad argument");
     FrameState& F = frame_state(c);
-    need(F.outBGR.p != nullptr, "no frame rendered yet");
-    *dev_ptr = F.outBGR.p;
+    need(F.frames_done > 0, "no frame rendered yet");
+    *dev_ptr = F.outBGR[F.out_cur].p;
     if (bytes) *bytes = (size_t)c->g.out_width * c->g.out_height * 3;
   });
 }
@@ -637,8 +638,23 @@ int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
   return guard(c, [&] {
     need(c && out_bgr, "bad argument");
     FrameState& F = frame_state(c);
-    need(F.outBGR.p != nullptr, "no frame rendered yet");
-    d2h(c, out_bgr, F.outBGR.p, (size_t)c->g.out_width * c->g.out_height * 3);
+    need(F.frames_done > 0, "no frame rendered yet");
+    d2h(c, out_bgr, F.outBGR[F.out_cur].p, (size_t)c->g.out_width * c->g.out_height * 3);
+  });
+}
+int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
+  return guard(c, [&] {
+    need(c && out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
+    FrameState& F = frame_state(c);
+    need(F.frames_done > age, "that frame has not been rendered");
+    const int b = age == 0 ? F.out_cur : F.out_cur ^ 1;
+    // wait for THAT frame only (its event sits behind its last kernel), then copy on a stream of its own so that the
+    // transfer does not queue behind the kernels of the frame enqueued after it
+    if (!c->stDown) S360_HIP(hipStreamCreateWithFlags(&c->stDown, hipStreamNonBlocking));
+    S360_HIP(hipStreamWaitEvent(c->stDown, F.outDone[b], 0));
+    S360_HIP(hipMemcpyAsync(out_bgr, F.outBGR[b].p, (size_t)c->g.out_width * c->g.out_height * 3, hipMemcpyDeviceToHost, c->stDown));
+    S360_HIP(hipStreamSynchronize(c->stDown));
+    if (c->flow) { /* sweep time-outs of that frame are reported by the next synchronising call */ }
   });
 }
 
@@ -750,7 +766,6 @@ int s360_set_sweep_mode(s360_ctx* c, const char* mode) {
     const std::string m(mode);
     if (m == "latency") c->sweep_mode = 2;
     else if (m == "throughput") c->sweep_mode = 3;
-    else if (m == "throughput-mono") c->sweep_mode = 5;  // A/B while the one-lane-per-pixel kernel is being measured
     else throw Error(S360_ERR_INVALID_ARG, "sweep mode must be \"latency\" or \"throughput\"");
     if (c->flow) c->flow->set_sweep_mode(c->sweep_mode);
     if (c->flow_pole) c->flow_pole->set_sweep_mode(c->sweep_mode);

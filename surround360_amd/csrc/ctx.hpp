@@ -27,6 +27,7 @@ struct s360_ctx {
   // events order the two sides: evUploaded (render waits for the inputs), evSideSrcFree / evPoleSrcFree (the upload's
   // conversion kernels wait until the previous frame's projections have read the source images).
   hipStream_t stUp = nullptr;
+  hipStream_t stDown = nullptr;  // s360_frame_download_equirect_of: device -> host copy of a finished frame
   static constexpr int kPinChunks = 4;
   static constexpr size_t kPinChunkBytes = (size_t)8 << 20;
   void* pin[kPinChunks] = {nullptr, nullptr, nullptr, nullptr};

@@ -139,9 +139,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   // Band hand-off granules + ticket counters of every sweep launch of this call (2 per level): one arena, reset to
   // all-ones ("not written") by ONE memset instead of one per launch.
   auto handoff_bytes = [&](int l) {
-    const size_t b = sweep_mode_ == 5   ? sweep_mono_handoff_bytes(lv_.w[l], lv_.h[l], B)
-                     : sweep_mode_ == 3 ? sweep_quad_handoff_bytes(lv_.w[l], lv_.h[l], B)
-                                        : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, 4);
+    const size_t b = sweep_mode_ == 3 ? sweep_quad_handoff_bytes(lv_.w[l], lv_.h[l], B)
+                                      : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, 4);
     return (b + 255) & ~(size_t)255;
   };
   std::vector<size_t> hoff(L + 1, 0);
@@ -226,10 +225,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
-      if (sweep_mode_ == 5)
-        launch_sweep_mono(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
-                          fastOk);
-      else if (sweep_mode_ == 3)
+      if (sweep_mode_ == 3)
         launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk);
       else

@@ -61,11 +61,6 @@ size_t sweep_quad_handoff_bytes(int w, int h, int B);
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast);
-// one lane per pixel, 64 rows per wave (sweep_mono.hip): fewest instructions per pixel, needs many flows in flight
-size_t sweep_mono_handoff_bytes(int w, int h, int B);
-void launch_sweep_mono(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
-                       unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, bool fast);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

@@ -709,7 +709,9 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     {
       ProfScope ps(prof, "finish");  // TRSP:890-961
       const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
-      F.outBGR.ensure((size_t)outW * outH * 3);
+      const int ob = F.out_cur ^ 1;  // the buffer the previous-but-one frame used
+      F.outBGR[ob].ensure((size_t)outW * outH * 3);
+      if (!F.outDone[ob]) S360_HIP(hipEventCreateWithFlags(&F.outDone[ob], hipEventDisableTiming));
       const bool resize = (outW != W) || (eyeH != H);
       for (int e = 0; e < 2; ++e) {
         uchar4* eye = F.pano[e].as<uchar4>();
@@ -723,8 +725,11 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
           launch_resize_cubic_u8c4(st, eye, W, H, en, F.eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);
           eye = F.eyeFinal[e].as<uchar4>();
         }
-        launch_pack_bgr(st, eye, outW, eyeH, F.outBGR.as<uint8_t>() + (size_t)e * outW * eyeH * 3);
+        launch_pack_bgr(st, eye, outW, eyeH, F.outBGR[ob].as<uint8_t>() + (size_t)e * outW * eyeH * 3);
       }
+      S360_HIP(hipEventRecord(F.outDone[ob], st));
+      F.out_cur = ob;
+      ++F.frames_done;
     }
   }
 }
@@ -785,7 +790,7 @@ void cube_map_entry(float x, float y, int face, int srcCols, int srcRows, float 
 void frame_cubemap(s360_ctx* c, int fw, int fh, bool video, int* ow, int* oh) {
   FrameState& F = frame_state(c);
   if (fw <= 0 || fh <= 0) throw Error(S360_ERR_INVALID_ARG, "cubemap face size must be positive");
-  if (!F.pano[0].p || !F.pano[1].p || !F.outBGR.p) throw Error(S360_ERR_STATE, "no frame rendered yet");
+  if (!F.pano[0].p || !F.pano[1].p || !F.frames_done) throw Error(S360_ERR_STATE, "no frame rendered yet");
   const int W = c->P.eqr_width, H = c->P.eqr_height;
   if (F.cubeW != fw || F.cubeH != fh || F.cubeSrcW != W || F.cubeSrcH != H) {
     static const int faces[6] = {CUBE_RIGHT, CUBE_LEFT, CUBE_TOP, CUBE_BOTTOM, CUBE_BACK, CUBE_FRONT};

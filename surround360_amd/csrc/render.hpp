@@ -38,7 +38,15 @@ struct FrameState {
   DevBuf a8a, a8b, gtmp;
   DevBuf extImgs[2], poleFlows[2];    // [cur/prev]; slots: ext 0-3 side units, 4 top fisheye, 5 bottom fisheye
   DevBuf warpedExt, poleWarped[4];
-  DevBuf eyeFinal[2], sharpLp, sharpBuf, outBGR;
+  DevBuf eyeFinal[2], sharpLp, sharpBuf;
+  // Stacked equirect of the last two frames (alternating): a streaming host downloads frame k from one buffer while
+  // frame k+1 is composited into the other (s360_frame_download_equirect_of). outDone[i] is recorded behind the
+  // kernels that fill outBGR[i].
+  DevBuf outBGR[2];
+  hipEvent_t outDone[2] = {nullptr, nullptr};
+  int out_cur = 0;           // buffer of the most recently ENQUEUED frame
+  long long frames_done = 0;  // frames enqueued so far
+  ~FrameState() { for (auto& e : outDone) if (e) (void)hipEventDestroy(e); }
   int cur_side = 0, cur_pole = 0, last_side = 0, last_pole = 0;
   bool have_prev_side = false, have_prev_pole = false;
   bool keep_intermediates = false;  // copy panoramas before the pole composite (parity tests)

@@ -289,6 +289,13 @@ class Context:
         self._ck(lib().s360_frame_download_equirect(self.h, _p(out)))
         return out
 
+    def download_equirect_of(self, age):
+        """age 0: the frame enqueued last; 1: the one before (fetched while the last one still renders)."""
+        g = self.geometry
+        out = np.empty((g.out_height, g.out_width, 3), np.uint8)
+        self._ck(lib().s360_frame_download_equirect_of(self.h, int(age), _p(out)))
+        return out
+
     def set_sweep_mode(self, mode):
         """'latency' (default) or 'throughput' — which sweep kernel PixFlow uses (bit-identical results)."""
         self._ck(lib().s360_set_sweep_mode(self.h, mode.encode()))

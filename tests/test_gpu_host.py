@@ -83,6 +83,56 @@ def test_two_frames_through_the_binary(tmp_path, rig_json, oracle, s360lib):
         prev = f
 
 
+def test_stream_mode_equals_chained_processes(tmp_path, rig_json, oracle, s360lib):
+    """--num_frames 3: one process renders three consecutive frames as a stream (device-resident temporal state, frame
+    pipelining, next frame decoded/uploaded and previous frame downloaded/encoded while the current one renders). Every
+    equirect must equal the oracle's frame-by-frame chain, and the state written after the last frame must let a
+    classic one-frame process continue the chain (--prev_frame_data_dir)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+    rig_path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_small.json"), CAM / 2048.0)
+    imgs, out = str(tmp_path / "rgb"), str(tmp_path / "out")
+    os.makedirs(out)
+    names = ["000007", "000008", "000009", "000010"]
+    frames = {f: rigutil.frame_inputs(rig_path, CAM, yaw_deg=0.6 * k) for k, f in enumerate(names)}
+    for f, (side, top, bottom) in frames.items():
+        _write_frame(imgs, rig_path, f, side, top, bottom)
+    flags = dict(eqr_width=EQR_W, eqr_height=EQR_H, enable_top=1, enable_bottom=1, final_eqr_width=960,
+                 final_eqr_height=960, sharpening=0.25)
+    cams, _ = oracle.load_rig(rig_path)
+    of = oracle.Frame(cams, oracle.make_params(**flags))
+    common = ["--rig_json_file", rig_path, "--imgs_dir", imgs, "--output_data_dir", out, "--enable_top", "--enable_bottom",
+              "--eqr_width", str(EQR_W), "--eqr_height", str(EQR_H), "--final_eqr_width", "960", "--final_eqr_height", "960",
+              "--sharpening", "0.25", "--v", "1"]
+    r = subprocess.run([exe, "--frame_number", names[0], "--num_frames", "3", "--output_equirect_path",
+                        os.path.join(out, "eqr_%s.png")] + common, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "stream of 3 frames" in r.stderr
+    for k, f in enumerate(names[:3]):
+        want, _ = of.render(*frames[f], use_prev=k > 0)
+        got = np.asarray(Image.open(os.path.join(out, "eqr_%s.png" % f)))[:, :, ::-1]
+        assert got.shape == want.shape and np.array_equal(got, want), "stream frame %s differs" % f
+    assert os.path.exists(os.path.join(out, "flow", names[2], "flow_top_left.bin"))
+    assert not os.path.exists(os.path.join(out, "flow", names[1]))  # state only after the last frame of the stream
+    # a one-frame process resumes from the stream's last frame
+    eqr = os.path.join(out, "resume.png")
+    r = subprocess.run([exe, "--frame_number", names[3], "--prev_frame_data_dir", names[2], "--output_equirect_path", eqr] +
+                       common, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want, _ = of.render(*frames[names[3]], use_prev=True)
+    assert np.array_equal(np.asarray(Image.open(eqr))[:, :, ::-1], want)
+    # --num_gpus beyond the box's GPUs is refused, not silently reduced
+    r = subprocess.run([exe, "--frame_number", names[0], "--num_gpus", "2", "--output_equirect_path", eqr] + common,
+                       capture_output=True, text=True)
+    import ctypes
+    if s360lib.s360_device_count() < 2:
+        assert r.returncode != 0 and "not that many HIP devices" in r.stderr
+    else:
+        assert r.returncode == 0, r.stderr
+        want0, _ = oracle.Frame(cams, oracle.make_params(**flags)).render(*frames[names[0]])
+        assert np.array_equal(np.asarray(Image.open(eqr))[:, :, ::-1], want0)
+
+
 def test_bad_command_lines(tmp_path):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
     exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
