@@ -108,9 +108,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="timed region + check + roofline only (profiling runs)")
-    ap.add_argument("--inflight", type=int, default=16,
-                    help="independent frames in flight per GPU (one context + HIP stream each); 1 = one frame at a time")
-    ap.add_argument("--slots", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="contexts in flight per GPU (one HIP stream + one submitting host thread each)")
+    ap.add_argument("--slots", type=int, default=8,
                     help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
                          "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
     ap.add_argument("--video-frames", type=int, default=32)
@@ -252,6 +252,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     enqueue_ms_per_frame = 1e3 * sum(enqueue_s) / max(args.steps * S, 1)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    hbm_used_gb = round((total_b - free_b) / 1e9, 1)
 
     # ---- check of the timed region: every in-flight frame against ONE context rendering the same inputs alone ----
     inflight_out = []
@@ -326,14 +328,18 @@ def main():
                 "algorithmic_bytes_per_launch": per_launch_bytes, "note": note}
 
     # ---- isolated kernels: one context alone, throughput-mode kernel (the timed region's) and latency-mode kernel ----
-    tp_ms, tp_prof, _ = isolated("throughput", 2)
+    if S > 1:
+        tp_ms, tp_prof = None, {"flow_sweep": (1.0, 1)}  # replaced below by the batched context's own launches
+    else:
+        tp_ms, tp_prof, _ = isolated("throughput", 2)
     roofline = sweep_roofline(
         tp_prof, "k_sweep_quad (PixFlow propagation sweeps, PixFlow.h:388-410)",
-        "dominant kernel of the timed region, measured with ONE frame alone on the GPU (HIP events on the library's "
+        "dominant kernel of the timed region, measured with ONE context alone on the GPU (HIP events on the library's "
         "stream, launches do not overlap): algorithmic bytes per launch (48 B per pixel-level-sweep x the pixel-levels "
-        "of the launch's 28 side or 4 pole flows) / average launch duration. A dependency-latency-bound wavefront "
-        "kernel (DESIGN.md §5): one launch is a serial chain of w+h diagonal steps; `aggregate_frac` is the same bytes "
-        "over the wall time of the timed region, where launches of up to %d frames overlap" % F)
+        "of the launch's flows: the 28 side or the 4 pole flows of each of the context's %d frame slots) / average launch "
+        "duration. A dependency-latency-bound wavefront kernel (DESIGN.md §5): one launch is a serial chain of w+h "
+        "diagonal steps; `aggregate_frac` is the same bytes over the wall time of the timed region, where the launches "
+        "of %d contexts overlap" % (S, F))
     roofline["aggregate_frac"] = bytes_per_frame * args.steps * S / dt / 1e9 / HBM_PEAK_GBS
     roofline["aggregate_GBps"] = bytes_per_frame * args.steps * S / dt / 1e9
     if batched_alone:
@@ -380,6 +386,7 @@ def main():
                  "settle_batches_before_warmup": settle["batches"], "settle_seconds": round(settle["seconds"], 2)},
     }
     out.update(checked)
+    out["hbm_used_GB_in_timed_region"] = hbm_used_gb
 
     def emit():
         if rank == 0:

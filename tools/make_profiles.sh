@@ -1,32 +1,44 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries under profiles/ on a GPU box (run from the repo root, e.g. through gpurun;
-# gpurun_out/ is scratch). Usage: tools/make_profiles.sh <tag>     e.g. tools/make_profiles.sh r02_v1
-#   1. kernel-trace summary of the default bench configuration (16 frames in flight + single-frame phases)
-#   2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (counters are never combined with other trace domains)
-#   3. profiles/sweep_traffic.json (HBM bytes per sweep launch, gfx950 FETCH_SIZE correction x2 on the read side)
+# gpurun_out/ is scratch). Usage: tools/make_profiles.sh <tag> [slots]     e.g. tools/make_profiles.sh r02_v1 8
+#   1. <tag>_kernel_stats.txt          kernel-trace summary of the DEFAULT bench command (contexts overlap: durations
+#                                      of launches that share the GPU are longer than isolated ones)
+#   2. <tag>_isolated_kernel_stats.txt the same workload with ONE context alone (--inflight 1): launches do not overlap,
+#                                      so the average duration of k_sweep_quad here is the bench line's
+#                                      roofline.avg_launch_ms (HIP events) measured a second way
+#   3. <tag>_pmc_fetch_write.txt       FETCH_SIZE and WRITE_SIZE in separate --pmc passes of the isolated command
+#                                      (counters are never combined with other trace domains)
+#   4. profiles/sweep_traffic.json     HBM bytes per sweep launch (gfx950: FETCH_SIZE x2 on the read side)
 set -e
 TAG=${1:?tag}
+SLOTS=${2:-8}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
-rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- python bench.py --steps 16 --warmup 16 --no-cpu-baseline > $OUT/ks.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f -o f -- python bench.py --steps 1 --warmup 1 --inflight 2 --no-cpu-baseline > $OUT/f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w -o w -- python bench.py --steps 1 --warmup 1 --inflight 2 --no-cpu-baseline > $OUT/w.log 2>&1
+ISO="python bench.py --inflight 1 --slots $SLOTS --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/ks.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/iso -o iso -- $ISO > $OUT/iso.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f -o f -- $ISO > $OUT/f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w -o w -- $ISO > $OUT/w.log 2>&1
+python tools/rocpd_kernel_stats.py $OUT/ks/ks_results.db \
+  "rocprofv3 --kernel-trace --stats summary ($TAG): python bench.py --steps 8 --warmup 2 --no-cpu-baseline (default: 2 contexts x 8 frame slots)" \
+  "durations from the rocpd kernel dispatch table; launches of the two contexts overlap, so these are NOT isolated durations" \
+  > profiles/${TAG}_kernel_stats.txt
+python tools/rocpd_kernel_stats.py $OUT/iso/iso_results.db \
+  "rocprofv3 --kernel-trace --stats summary ($TAG): $ISO" \
+  "ONE context alone: launches do not overlap. k_sweep_quad avg_us here = roofline.avg_launch_ms of the bench line; every k_sweep_quad launch holds the flows of $SLOTS frames" \
+  > profiles/${TAG}_isolated_kernel_stats.txt
+tail -1 $OUT/iso.log > profiles/${TAG}_isolated_bench.json || true
 {
-  echo "# rocprofv3 --kernel-trace --stats summary ($TAG): python bench.py --steps 16 --warmup 16 --no-cpu-baseline"
-  echo "# durations from the rocpd kernel dispatch table (launches of different frames overlap, so the sum exceeds wall time)"
-  python tools/rocpd_kernel_stats.py $OUT/ks/ks_results.db
-} > profiles/${TAG}_kernel_stats.txt
-{
-  echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) and --pmc WRITE_SIZE (pass 2) on: python bench.py --steps 1 --warmup 1 --inflight 2 --no-cpu-baseline ($TAG)"
+  echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) and --pmc WRITE_SIZE (pass 2) on: $ISO ($TAG)"
   echo "# Units: KB as reported by rocprofv3. gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at 1/2 of their bytes."
   python tools/rocpd_pmc.py $OUT/f/f_results.db FETCH_SIZE | head -24
   echo
   python tools/rocpd_pmc.py $OUT/w/w_results.db WRITE_SIZE | head -24
 } > profiles/${TAG}_pmc_fetch_write.txt
-python - "$TAG" <<'PY'
-import json, re, sys
-tag = sys.argv[1]
+python - "$TAG" "$SLOTS" <<'PY'
+import json, sys
+tag, slots = sys.argv[1], int(sys.argv[2])
 txt = open("profiles/%s_pmc_fetch_write.txt" % tag).read()
 fetch, write = txt.split("\n\n", 1)
 def per_launch(block, kernel):
@@ -35,15 +47,17 @@ def per_launch(block, kernel):
             f = line.split()
             return int(f[-3]), float(f[-1])
     return 0, 0.0
-d = json.load(open("profiles/sweep_traffic.json"))
-d["source"] = "profiles/%s_pmc_fetch_write.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 1 --warmup 1 --inflight 2)" % tag
+d = {"source": "profiles/%s_pmc_fetch_write.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --inflight 1 --slots %d --steps 2 --warmup 1 --no-extras)" % (tag, slots),
+     "correction": "gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM) -> read side doubled; WRITE_SIZE as reported",
+     "frames_per_launch": slots, "kernels": {}}
 for key, kname in (("k_sweep_lock", "k_sweep_lock<"), ("k_sweep_quad", "k_sweep_quad<")):
     n, f = per_launch(fetch, kname)
     _, w = per_launch(write, kname)
     if n:
-        d["kernels"][key].update({"launches_profiled": n, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
-                                  "hbm_bytes_per_launch_raw": (f + w) * 1024, "hbm_bytes_per_launch": (2 * f + w) * 1024})
-d["hbm_bytes_per_launch"] = d["kernels"]["k_sweep_quad"]["hbm_bytes_per_launch"]
+        d["kernels"][key] = {"launches_profiled": n, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+                             "hbm_bytes_per_launch_raw": (f + w) * 1024, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+if "k_sweep_quad" in d["kernels"]:
+    d["hbm_bytes_per_launch"] = d["kernels"]["k_sweep_quad"]["hbm_bytes_per_launch"]
 json.dump(d, open("profiles/sweep_traffic.json", "w"), indent=1)
 print("profiles written for", tag)
 PY
