@@ -356,7 +356,11 @@ def main():
     if os.path.exists(traffic_file):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
         try:
             tj = json.load(open(traffic_file))
-            roofline["traffic"] = tj.get("kernels", {}).get("k_sweep_quad", {}).get("hbm_bytes_per_launch")
+            t = tj.get("kernels", {}).get("k_sweep_quad", {}).get("hbm_bytes_per_launch")
+            fpl = tj.get("frames_per_launch", 1)
+            if t:  # measured with `fpl` frames per launch; a launch's traffic is proportional to the frames it holds
+                roofline["traffic"] = t * S / fpl
+                roofline["traffic_source"] = "profiles/sweep_traffic.json (%d frame(s) per launch when profiled)" % fpl
         except Exception:
             pass
 

@@ -120,7 +120,6 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   G_.ensure(N * n0 * sizeof(float2));
   flowA_.ensure(B * n0 * sizeof(float2));
   flowB_.ensure(B * n0 * sizeof(float2));
-  full_.ensure((size_t)B * w * h * sizeof(float2));
   if (sweep_fast_ < 0) {
     const char* d = std::getenv("S360_SWEEP_DIV");  // "ieee": IEEE division / sqrt expansions instead of the verified fast ones (same bits)
     sweep_fast_ = !(d && std::string(d) == "ieee");
@@ -263,9 +262,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
                                 (size_t)lv_.w[l - 1] * lv_.h[l - 1], B, invPyr);
     } else {
       ProfScope ps(P, "flow_final");
-      launch_resize_linear_f32(st, (const float*)oth, wl, hl, nl, full_.as<float>(), w, h, (size_t)w * h, 2, B,
-                               1.0f / pc.downscaleFactor, 1);
-      launch_sepblur(st, full_.as<float>(), nullptr, w, h, 2, (size_t)w * h, B, tFinal, outTab);
+      // final upscale + scalar + 3x3 blur fused: the upscaled flow is evaluated while the blur's tile is loaded
+      launch_upscale_blur(st, oth, wl, hl, nl, nullptr, w, h, (size_t)w * h, B, 1.0f / pc.downscaleFactor, tFinal, outTab);
     }
   }
 }

@@ -63,7 +63,7 @@ class FlowEngine {
   TabSlot tabs_[4];
   int tab_next_ = 0;
   const unsigned long long* batch_tables(hipStream_t st, const FlowBatch& b);
-  DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, full_, prevFlowDown_, prevPyr_, motionPyr_, I1eq_, rec_,
+  DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, prevFlowDown_, prevPyr_, motionPyr_, I1eq_, rec_,
       handoff_, err_;
   int sweep_mode_ = 2;      // 2: lockstep kernel (latency, default), 3: quad kernel (throughput)
   int sweep_fast_ = -1;     // verified fast division / sqrt in the sweeps; S360_SWEEP_DIV=ieee selects the IEEE expansions (same bits)

@@ -16,6 +16,8 @@
 
 namespace s360 {
 
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+
 // ------------------------------------------------------------------------------------------
 // resize INTER_CUBIC 8UC4 (PixFlow.h:98-107 entry downscale; TRSP:938-957 final resize).
 // OpenCV fixed point: short taps = round(w*2048); H pass int (HResizeCubic). V pass as the reference's x86-64 build
@@ -110,16 +112,24 @@ __global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, 
 // sliding window of 4 + 2R inputs (the wide 15x15 kernels are LDS-bandwidth bound otherwise).
 // SRC 0: the source is the image itself. SRC 1 (CN = 2): the source is Sobel(ksize 1, BORDER_REPLICATE) of a
 //        single-channel plane, computed while the tile is loaded (PixFlow.h:356-366 without the intermediate image).
+// SRC 2: the source is the INTER_LINEAR upscale (resize + scalar multiply, PixFlow.h:176-177) of a smaller image,
+//        evaluated while the tile is loaded: the full-resolution intermediate of the final flow blur never exists.
 // EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453). EPI 2: store the sweep record
 //        {I0x | NaN when the pixel is not updated, I0y, blurred.x, blurred.y} instead of the blurred flow.
 // Tile: 64x16 outputs for the 3- and 5-tap kernels, 32x32 for the 15-tap ones (29 KB of LDS instead of 35 KB and 1.44x
 // instead of 1.9x row-pass halo work: blur15 + diffusion 100 -> 69 ms of summed kernel time per frame with 16 frames in flight).
+struct UpSrc {  // SRC 2: geometry of the small source image and the scalar applied after the resize
+  int sw, sh;
+  size_t sbs;
+  double scx, scy;
+  float post_scale;
+};
 template <int R, int CN, int EPI, int SRC, int SB_TW = 64, int SB_TH = 16>
 __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                  size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
                                                  const float* __restrict__ A, FlowIdx idx,
                                                  const float2* __restrict__ Gp, float4* __restrict__ rec,
-                                                 float* const* __restrict__ dst_tab) {
+                                                 float* const* __restrict__ dst_tab, UpSrc up) {
   constexpr int IW = SB_TW + 2 * R, IH = SB_TH + 2 * R;
   constexpr int IWP = IW | 1;  // odd row stride: the 4-wide row tasks of consecutive rows fall into different banks
   __shared__ float s_in[IH][IWP][CN];
@@ -127,11 +137,36 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
-  src += bs * (SRC == 1 ? 1 : CN) * blockIdx.z;
+  src += (SRC == 2 ? up.sbs * CN : bs * (SRC == 1 ? 1 : CN)) * blockIdx.z;
   for (int i = tid; i < IH * IW; i += 256) {
     const int ly = i / IW, lx = i - ly * IW;
     const int gy = reflect101(ty0 - R + ly, h), gx = reflect101(tx0 - R + lx, w);
-    if (SRC == 1) {  // Sobel ksize=1: [-1 0 +1], BORDER_REPLICATE, no scale
+    if (SRC == 2) {  // k_resize_linear_f32's arithmetic at (gx, gy), then the scalar multiply
+      int sx, sy;
+      float fx, fy;
+      resize_coord(gx, up.scx, &sx, &fx);
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= up.sw - 1) { fx = 0; sx = up.sw - 1; }
+      resize_coord(gy, up.scy, &sy, &fy);
+      const float* S0 = src + (size_t)clip_idx(sy, up.sh) * up.sw * CN;
+      const float* S1 = src + (size_t)clip_idx(sy + 1, up.sh) * up.sw * CN;
+      const float b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+      for (int k = 0; k < CN; ++k) {
+        float h0, h1;
+        if (sx >= up.sw - 1) {
+          h0 = S0[sx * CN + k] * 1.0f;
+          h1 = S1[sx * CN + k] * 1.0f;
+        } else {
+          const float a0 = 1.f - fx, a1 = fx;
+          h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
+          h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
+        }
+        float v = h0 * b0 + h1 * b1;
+        v *= up.post_scale;
+        s_in[ly][lx][k] = v;
+      }
+    } else if (SRC == 1) {  // Sobel ksize=1: [-1 0 +1], BORDER_REPLICATE, no scale
       const float* r0 = src + (size_t)gy * w;
       s_in[ly][lx][0] = r0[min(gx + 1, w - 1)] - r0[max(gx - 1, 0)];
       s_in[ly][lx][CN - 1] = src[(size_t)min(gy + 1, h - 1) * w + gx] - src[(size_t)max(gy - 1, 0) * w + gx];
@@ -281,6 +316,72 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32c2(const float2* __rest
   dst[(size_t)dy * dw + dx] = o;
 }
 
+// The same resize for ratios <= 1 (the x1/0.9 upscale between pyramid levels, 190 M pixel-levels per frame) with the
+// source window of a 64x16 output tile staged in LDS: the per-column / per-row coordinates and cubic weights (double
+// precision coordinate arithmetic) are computed once per tile instead of once per pixel, the horizontal pass runs once
+// per source row of the window instead of four times per output, and global memory is read in coalesced rows.
+constexpr int UC_TW = 64, UC_TH = 16, UC_SW = 72, UC_SH = 24;
+__global__ __launch_bounds__(256) void k_resize_cubic_f32c2_tiled(const float2* __restrict__ src, int sw, int sh,
+                                                                  size_t sbs, float2* __restrict__ dst, int dw, int dh,
+                                                                  size_t dbs, double scx, double scy, float post_scale) {
+  __shared__ float2 s_src[UC_SH][UC_SW];
+  __shared__ float2 s_h[UC_SH][UC_TW];
+  __shared__ float s_ax[UC_TW][4], s_ay[UC_TH][4];
+  __shared__ int s_sx[UC_TW], s_sy[UC_TH];
+  const int tid = threadIdx.x;
+  const int dx0 = blockIdx.x * UC_TW, dy0 = blockIdx.y * UC_TH;
+  src += sbs * blockIdx.z;
+  dst += dbs * blockIdx.z;
+  if (tid < UC_TW) {
+    float f;
+    resize_coord(min(dx0 + tid, dw - 1), scx, &s_sx[tid], &f);
+    cubic_coeffs(f, s_ax[tid]);
+  } else if (tid < UC_TW + UC_TH) {
+    float f;
+    resize_coord(min(dy0 + tid - UC_TW, dh - 1), scy, &s_sy[tid - UC_TW], &f);
+    cubic_coeffs(f, s_ay[tid - UC_TW]);
+  }
+  __syncthreads();
+  const int X0 = clip_idx(s_sx[0] - 1, sw), X1 = clip_idx(s_sx[UC_TW - 1] + 2, sw);
+  const int Y0 = clip_idx(s_sy[0] - 1, sh), Y1 = clip_idx(s_sy[UC_TH - 1] + 2, sh);
+  const int W = X1 - X0 + 1, H = Y1 - Y0 + 1;  // <= UC_SW x UC_SH for ratios <= 1 (checked by the launcher)
+  for (int i = tid; i < H * W; i += 256) {
+    const int ly = i / W, lx = i - ly * W;
+    s_src[ly][lx] = src[(size_t)(Y0 + ly) * sw + X0 + lx];
+  }
+  __syncthreads();
+  for (int i = tid; i < H * UC_TW; i += 256) {  // horizontal pass of every source row of the window
+    const int ly = i >> 6, c = i & (UC_TW - 1);
+    const int sx = s_sx[c];
+    const float2 p0 = s_src[ly][clip_idx(sx - 1, sw) - X0], p1 = s_src[ly][clip_idx(sx, sw) - X0],
+                 p2 = s_src[ly][clip_idx(sx + 1, sw) - X0], p3 = s_src[ly][clip_idx(sx + 2, sw) - X0];
+    const float a0 = s_ax[c][0], a1 = s_ax[c][1], a2 = s_ax[c][2], a3 = s_ax[c][3];
+    float2 hv;
+    hv.x = p0.x * a0 + p1.x * a1 + p2.x * a2 + p3.x * a3;
+    hv.y = p0.y * a0 + p1.y * a1 + p2.y * a2 + p3.y * a3;
+    s_h[ly][c] = hv;
+  }
+  __syncthreads();
+  const int c = tid & (UC_TW - 1), r0 = (tid >> 6) * 4;
+  const int dx = dx0 + c;
+  if (dx >= dw) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + j, dy = dy0 + r;
+    if (dy >= dh) break;
+    const int sy = s_sy[r];
+    const float2 h0 = s_h[clip_idx(sy - 1, sh) - Y0][c], h1 = s_h[clip_idx(sy, sh) - Y0][c],
+                 h2 = s_h[clip_idx(sy + 1, sh) - Y0][c], h3 = s_h[clip_idx(sy + 2, sh) - Y0][c];
+    const float b0 = s_ay[r][0], b1 = s_ay[r][1], b2 = s_ay[r][2], b3 = s_ay[r][3];
+    float2 o;
+    o.x = h0.x * b0 + h1.x * b1 + h2.x * b2 + h3.x * b3;
+    o.y = h0.y * b0 + h1.y * b1 + h2.y * b2 + h3.y * b3;
+    o.x *= post_scale;
+    o.y *= post_scale;
+    dst[(size_t)dy * dw + dx] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_scale_f32(float* __restrict__ p, size_t n, float s) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] *= s;
@@ -360,6 +461,56 @@ __global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ s
   o.x = median25(vx);
   o.y = median25(vy);
   dst[(size_t)y * w + x] = o;
+}
+
+// The same medians for 8 horizontally adjacent pixels per thread from 12 shared columns: every column of 5 is sorted
+// once and used by 5 windows, aligned column pairs are merged once and used by 4, and the 6 median candidates of two
+// adjacent pairs are selected once and used by 2 — 79 min/max operations per median instead of 112 and 60 eight-byte
+// loads per 8 pixels instead of 200. The networks are generated and verified by tools/gen_median_network.py.
+#include "median_tile.inc"
+constexpr int MED_T = 8;
+__global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restrict__ src, float2* __restrict__ dst, int w,
+                                                         int h, size_t bs) {
+  const int x0 = (blockIdx.x * 64 + threadIdx.x) * MED_T;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (x0 >= w || y >= h) return;
+  src += bs * blockIdx.z;
+  dst += bs * blockIdx.z;
+  float inx[(MED_T + 4) * 5], iny[(MED_T + 4) * 5];
+  const bool interior = x0 >= 2 && x0 + MED_T + 2 <= w;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const float2* row = src + (size_t)clip_idx(y + r - 2, h) * w;
+    if (interior) {
+      const f4a8* v = reinterpret_cast<const f4a8*>(row + x0 - 2);  // 8-byte aligned 16-byte loads, two pixels each
+#pragma unroll
+      for (int c = 0; c < (MED_T + 4) / 2; ++c) {
+        const f4a8 p = v[c];
+        inx[(2 * c) * 5 + r] = p.x; iny[(2 * c) * 5 + r] = p.y;
+        inx[(2 * c + 1) * 5 + r] = p.z; iny[(2 * c + 1) * 5 + r] = p.w;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < MED_T + 4; ++c) {
+        const float2 p = row[clip_idx(x0 - 2 + c, w)];
+        inx[c * 5 + r] = p.x;
+        iny[c * 5 + r] = p.y;
+      }
+    }
+  }
+  float ox[MED_T], oy[MED_T];
+  median5x5_row8(inx, ox);
+  median5x5_row8(iny, oy);
+  float2* out = dst + (size_t)y * w + x0;
+  if (x0 + MED_T <= w) {
+#pragma unroll
+    for (int o = 0; o < MED_T; o += 2) {
+      f4a8 q = {ox[o], oy[o], ox[o + 1], oy[o + 1]};
+      *reinterpret_cast<f4a8*>(out + o) = q;
+    }
+  } else {
+    for (int o = 0; o < MED_T && x0 + o < w; ++o) out[o] = make_float2(ox[o], oy[o]);
+  }
 }
 
 // ---- pixflow_search_20 only: adjustInitialFlow at the coarsest level (PixFlow.h:219-342) ----
@@ -460,14 +611,14 @@ void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t
 template <int R, int CN, int EPI, int SRC>
 static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w, int h, size_t bs, int B,
                              const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float4* rec,
-                             float* const* dst_tab = nullptr) {
+                             float* const* dst_tab = nullptr, const UpSrc& up = UpSrc{}) {
   dim3 blk(64, 4);
   if constexpr (R == 7) {  // 15x15: 32x32 tile — 29 KB of LDS, 1.44x row-pass halo work (64x16: 35 KB, 1.9x; measured 30 % slower)
     dim3 grd((w + 31) / 32, (h + 31) / 32, B);
-    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab, up);
   } else {
     dim3 grd((w + 63) / 64, (h + 15) / 16, B);
-    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab, up);
   }
 }
 void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, int cn, size_t bs, int B,
@@ -482,6 +633,18 @@ void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, 
 void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
                       const BlurTaps& t, const float* A, const FlowIdx& idx) {
   launch_sepblur_t<7, 2, 1, 0>(st, (const float*)flow, (float*)dst, w, h, bs, B, t, A, idx, nullptr, nullptr);
+}
+// resize(flow, originalSize, INTER_LINEAR); flow *= s; GaussianBlur(flow, 3x3) in one pass (PixFlow.h:175-182)
+void launch_upscale_blur(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw, int dh,
+                         size_t dbs, int B, float post_scale, const BlurTaps& t, float* const* dst_tab) {
+  static const FlowIdx none = {nullptr, nullptr};
+  if (t.r != 1) throw std::runtime_error("launch_upscale_blur: 3x3 kernel expected");
+  UpSrc up;
+  up.sw = sw; up.sh = sh; up.sbs = sbs;
+  up.scx = 1.0 / ((double)dw / (double)sw);
+  up.scy = 1.0 / ((double)dh / (double)sh);
+  up.post_scale = post_scale;
+  launch_sepblur_t<1, 2, 0, 2>(st, (const float*)src, (float*)dst, dw, dh, dbs, B, t, nullptr, none, nullptr, nullptr, dst_tab, up);
 }
 // Sobel + 3x3 Gaussian of a float plane in one pass -> packed (Ix, Iy) (PixFlow.h:353-366)
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t) {
@@ -509,6 +672,11 @@ void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, 
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
                                int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab) {
   const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
+  if (!src_tab && scx <= 1.0 && scy <= 1.0) {  // upscale: a 64x16 tile reads at most (64 + 4) x (16 + 4) source pixels
+    hipLaunchKernelGGL(k_resize_cubic_f32c2_tiled, dim3((dw + UC_TW - 1) / UC_TW, (dh + UC_TH - 1) / UC_TH, B), dim3(256),
+                       0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx, scy, post_scale);
+    return;
+  }
   dim3 blk(32, 8);
   hipLaunchKernelGGL(k_resize_cubic_f32c2, grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx,
                      scy, post_scale, src_tab);
@@ -523,6 +691,11 @@ void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev,
 }
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B) {
   dim3 blk(64, 4);
+  if (w >= 64) {  // 8 pixels per thread; narrow levels keep one pixel per thread (more threads than the chip otherwise idles)
+    dim3 grd((w + 64 * MED_T - 1) / (64 * MED_T), (h + 3) / 4, B);
+    hipLaunchKernelGGL(k_median5_c2_row8, grd, blk, 0, st, src, dst, w, h, bs);
+    return;
+  }
   hipLaunchKernelGGL(k_median5_c2, grid2d(w, h, B, blk), blk, 0, st, src, dst, w, h, bs);
 }
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,

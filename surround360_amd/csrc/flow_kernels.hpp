@@ -37,6 +37,8 @@ void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, 
                     const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
                       const BlurTaps& t, const float* A, const FlowIdx& idx);
+void launch_upscale_blur(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw, int dh,
+                         size_t dbs, int B, float post_scale, const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t);
 void launch_blur_to_records(hipStream_t st, const float2* flow, float4* rec, int w, int h, size_t bs, int B,
                             const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx);
