@@ -500,7 +500,7 @@ int s360_frame_set_prev_pole_removal(s360_ctx* c, const float* flow, const uint8
     need(c && flow && bottom_image && bottom_image2 && w > 0 && h > 0, "bad argument");
     FrameState& F = frame_state(c);
     const size_t n = (size_t)w * h;
-    const int prv = F.cur_pr ^ 1;
+    const int prv = F.last_pr;  // becomes "the previous frame" of the next render
     F.prImgs[prv].ensure(2 * n * sizeof(uchar4));
     F.prFlow[prv].ensure(n * sizeof(float2));
     h2d(c, F.prImgs[prv].as<uchar4>(), bottom_image, n * sizeof(uchar4));
@@ -551,7 +551,7 @@ int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, co
     const int p0 = F.side_p0, n = F.side_p1 - F.side_p0;
     need(pair >= p0 && pair < F.side_p1, "pair_idx outside the block declared with s360_frame_set_partition");
     const int j = pair - p0;
-    const int prv = F.cur_side ^ 1;
+    const int prv = F.last_side;  // becomes "the previous frame" of the next render
     F.overlaps[prv].ensure(2 * n * on * sizeof(uchar4));
     F.sideFlows[prv].ensure(2 * n * on * sizeof(float2));
     h2d(c, F.overlaps[prv].as<uchar4>() + on * j, overlap_l, on * sizeof(uchar4));
@@ -571,7 +571,7 @@ int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uin
     const int rows = unit < 2 ? c->g.top_rows : c->g.bottom_rows;
     const size_t xn = (size_t)extW * rows;                                       // one image / flow of this unit
     const size_t xs = (size_t)extW * std::max(c->g.top_rows, c->g.bottom_rows);  // slot stride (frame_finish)
-    const int prv = F.cur_pole ^ 1;
+    const int prv = F.last_pole;  // becomes "the previous frame" of the next render
     F.extImgs[prv].ensure(6 * xs * sizeof(uchar4));
     F.poleFlows[prv].ensure(4 * xs * sizeof(float2));
     h2d(c, F.extImgs[prv].as<uchar4>() + xs * unit, ext_side, xn * sizeof(uchar4));

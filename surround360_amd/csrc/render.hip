@@ -291,8 +291,9 @@ static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
   const double* up1 = cam.rotation + 3;
   const double* up2 = cam2.rotation + 3;
   const bool flip180 = up1[0] * up2[0] + up1[1] * up2[1] + up1[2] * up2[2] < 0;  // TRSP:580
-  const int cur = F.cur_pr, prv = cur ^ 1;
   const bool usePrev = use_prev && F.have_prev_pr;
+  // temporal double buffer: the previous state is only kept apart when this frame reads it
+  const int prv = F.last_pr, cur = usePrev ? prv ^ 1 : prv;
   F.prImgs[cur].ensure(2 * n * sizeof(uchar4));
   F.prFlow[cur].ensure(n * sizeof(float2));
   F.prTmp.ensure(n * sizeof(uchar4));
@@ -328,7 +329,6 @@ static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
   }
   F.have_prev_pr = true;
   F.last_pr = cur;
-  F.cur_pr ^= 1;
 }
 
 static void ensure_maps(s360_ctx* c) {
@@ -395,6 +395,9 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
   // temporal state is used only if every slot of the batch has it (one FlowEngine batch = one setting)
   bool usePrev = use_prev != 0;
   for (FrameState* F : Fs) usePrev = usePrev && F->have_prev_side && F->side_p0 == p0 && F->side_p1 == p1;
+  // temporal double buffer: frame k's overlaps / flows are kept apart from frame k-1's only when frame k reads them
+  // (independent frames keep writing the same half: 1.4 GB less per frame slot at 8K)
+  for (FrameState* F : Fs) F->cur_side = usePrev ? F->last_side ^ 1 : F->last_side;
   for (FrameState* Fp : Fs) {
     FrameState& F = *Fp;
     const size_t sn = (size_t)F.srcW * F.srcH;
@@ -472,7 +475,6 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
     F.side_p1 = p1;
     F.have_prev_side = true;
     F.last_side = cur;
-    F.cur_side ^= 1;
   }
   if (c->pipeline) S360_HIP(hipEventRecord(c->evSideDone, st));
 }
@@ -554,6 +556,11 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     SlotScope ss(c, k);
     FrameState& F = frame_state(c);
     usePrev = usePrev && F.have_prev_pole && F.extW == extW && F.poleRowsT == rowsT && F.poleRowsB == rowsB;
+  }
+  for (int k : slotIds) {
+    SlotScope ss(c, k);
+    FrameState& F = frame_state(c);
+    F.cur_pole = usePrev ? F.last_pole ^ 1 : F.last_pole;
   }
   for (int k : slotIds) {
     SlotScope ss(c, k);
@@ -687,7 +694,6 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       F.poleRowsB = rowsB;
       F.have_prev_pole = true;
       F.last_pole = cur;
-      F.cur_pole ^= 1;
     }
     {
       ProfScope ps(prof, "flatten");  // TRSP:864-885
@@ -713,13 +719,19 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       F.outBGR[ob].ensure((size_t)outW * outH * 3);
       if (!F.outDone[ob]) S360_HIP(hipEventCreateWithFlags(&F.outDone[ob], hipEventDisableTiming));
       const bool resize = (outW != W) || (eyeH != H);
+      if (c->P.sharpening > 0.0) {  // both eyes in one set of launches (TRSP:901-915 runs them on two threads)
+        uchar4* imgs[2];
+        uchar4* lps[2];
+        float* scr[2];
+        for (int e = 0; e < 2; ++e) {
+          F.sharpLp[e].ensure(en * sizeof(uchar4));
+          F.sharpBuf[e].ensure(sharpen_scratch_bytes(W, H));
+          imgs[e] = F.pano[e].as<uchar4>(); lps[e] = F.sharpLp[e].as<uchar4>(); scr[e] = F.sharpBuf[e].as<float>();
+        }
+        launch_sharpen_many(st, imgs, lps, scr, 2, W, H, 1.0f + (float)c->P.sharpening);
+      }
       for (int e = 0; e < 2; ++e) {
         uchar4* eye = F.pano[e].as<uchar4>();
-        if (c->P.sharpening > 0.0) {
-          F.sharpLp.ensure(en * sizeof(uchar4));
-          F.sharpBuf.ensure(sharpen_scratch_bytes(W, H));
-          launch_sharpen(st, eye, F.sharpLp.as<uchar4>(), F.sharpBuf.as<float>(), W, H, 1.0f + (float)c->P.sharpening);
-        }
         if (resize) {
           F.eyeFinal[e].ensure((size_t)outW * eyeH * sizeof(uchar4));
           launch_resize_cubic_u8c4(st, eye, W, H, en, F.eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);

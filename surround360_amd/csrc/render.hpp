@@ -38,7 +38,7 @@ struct FrameState {
   DevBuf a8a, a8b, gtmp;
   DevBuf extImgs[2], poleFlows[2];    // [cur/prev]; slots: ext 0-3 side units, 4 top fisheye, 5 bottom fisheye
   DevBuf warpedExt, poleWarped[4];
-  DevBuf eyeFinal[2], sharpLp, sharpBuf;
+  DevBuf eyeFinal[2], sharpLp[2], sharpBuf[2];
   // Stacked equirect of the last two frames (alternating): a streaming host downloads frame k from one buffer while
   // frame k+1 is composited into the other (s360_frame_download_equirect_of). outDone[i] is recorded behind the
   // kernels that fill outBGR[i].
@@ -56,7 +56,7 @@ struct FrameState {
   // pole removal: secondary bottom source (BGRA), red-mask planes, flow inputs [cur/prev][2][n], flow [cur/prev][n]
   DevBuf botSrc2, prRed[2], prImgs[2], prFlow[2], prTmp, prWarp, prMerged;
   bool have_pr_inputs = false, have_prev_pr = false;
-  int cur_pr = 0, last_pr = 0;
+  int last_pr = 0;
   DevBuf cubeMaps, cubeOut;  // cached face warp maps [6][fh][fw] float2 and the stacked BGR cubemap
   int cubeW = 0, cubeH = 0, cubeSrcW = 0, cubeSrcH = 0;
 };

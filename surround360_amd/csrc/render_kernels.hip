@@ -908,6 +908,12 @@ struct IirGeom {
   int nchains;  // ROWS: h, columns: w
   int w;        // image row pitch in pixels
 };
+constexpr int IIR_MAX_IMGS = 16;  // images per launch (blockIdx.y): the two eyes of every frame slot of a batch
+struct IirImgs {
+  const uchar4* x[IIR_MAX_IMGS];  // input of the pass
+  uchar4* out[IIR_MAX_IMGS];      // 8-bit output of the anticausal half
+  float4* buf[IIR_MAX_IMGS];      // float results of the causal half (+ carried state behind them)
+};
 template <bool ROWS>
 __device__ __forceinline__ int iir_bnd(int x, int n) { return ROWS ? wrap_i(x, n) : refl_i(x, n); }
 template <bool ROWS>
@@ -917,8 +923,10 @@ __device__ __forceinline__ size_t iir_px(const IirGeom& g, int chain, int pos) {
 
 // Causal half: B[e] = v after consuming X[bnd(e+1)], e = 0..n-1, v0 = X[0]; carry[chain] = final v.
 template <bool ROWS>
-__global__ __launch_bounds__(64) void k_iir_causal(const uchar4* __restrict__ X, float4* __restrict__ Bf,
-                                                   float4* __restrict__ carry, IirGeom g, float alpha) {
+__global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t npix, float alpha) {
+  const uchar4* __restrict__ X = im.x[blockIdx.y];
+  float4* __restrict__ Bf = im.buf[blockIdx.y];
+  float4* __restrict__ carry = Bf + npix;
   __shared__ unsigned s_in[IIR_CH * IIR_LD];
   __shared__ float s_out[IIR_CH * IIR_LD * 4];
   const int lane = threadIdx.x, k = lane >> 2, c = lane & 3;
@@ -985,8 +993,10 @@ __global__ __launch_bounds__(64) void k_iir_causal(const uchar4* __restrict__ X,
 // Anticausal half: for e = n-1 .. 0: v = lerp(B[bnd(e-1)], v); OUT[e] = clamp(v). FUSE: OUT is the unsharp mask of
 // `img` against that low-pass value, written in place.
 template <bool ROWS, bool FUSE>
-__global__ __launch_bounds__(64) void k_iir_anticausal(const float4* __restrict__ Bf, const float4* __restrict__ carry,
-                                                       uchar4* __restrict__ out, IirGeom g, float alpha, float amount) {
+__global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, size_t npix, float alpha, float amount) {
+  const float4* __restrict__ Bf = im.buf[blockIdx.y];
+  const float4* __restrict__ carry = Bf + npix;
+  uchar4* __restrict__ out = im.out[blockIdx.y];
   __shared__ float s_in[IIR_CH * IIR_LD * 4];
   __shared__ unsigned s_out[IIR_CH * IIR_LD];
   const int lane = threadIdx.x, k = lane >> 2, c = lane & 3;
@@ -1161,15 +1171,27 @@ void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* d
 // iirLowPass (wrap horizontally, reflect vertically) + sharpenWithIirLowPass on one eye, in place (TRSP:688-696).
 // scratch: w*h float4 + max(w,h) float4 (the chains' carried state).
 size_t sharpen_scratch_bytes(int w, int h) { return ((size_t)w * h + (size_t)std::max(w, h)) * sizeof(float4); }
-void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount) {
+// n images of the same size in one set of launches (the chains of one image cannot fill the chip: 16 384 of them for
+// the row pass of a 4096-row eye, each 2 x 8400 dependent steps).
+void launch_sharpen_many(hipStream_t st, uchar4* const* imgs, uchar4* const* lps, float* const* scratch, int n, int w,
+                         int h, float amount) {
+  if (n < 1 || n > IIR_MAX_IMGS) throw std::runtime_error("launch_sharpen_many: 1..16 images per launch");
   const float alpha = powf(0.25f, 1.0f / 4.0f);  // host libm, Filter.h:49
-  float4* buf = reinterpret_cast<float4*>(scratch);
-  float4* carry = buf + (size_t)w * h;
+  const size_t npix = (size_t)w * h;
   const IirGeom gr{w, h, w}, gc{h, w, w};
-  hipLaunchKernelGGL((k_iir_causal<true>), dim3(cdiv(h, IIR_CH)), dim3(64), 0, st, img, buf, carry, gr, alpha);
-  hipLaunchKernelGGL((k_iir_anticausal<true, false>), dim3(cdiv(h, IIR_CH)), dim3(64), 0, st, buf, carry, lp, gr, alpha, amount);
-  hipLaunchKernelGGL((k_iir_causal<false>), dim3(cdiv(w, IIR_CH)), dim3(64), 0, st, lp, buf, carry, gc, alpha);
-  hipLaunchKernelGGL((k_iir_anticausal<false, true>), dim3(cdiv(w, IIR_CH)), dim3(64), 0, st, buf, carry, img, gc, alpha, amount);
+  IirImgs rows, cols;
+  for (int i = 0; i < IIR_MAX_IMGS; ++i) {
+    const int k = i < n ? i : 0;
+    rows.x[i] = imgs[k]; rows.out[i] = lps[k]; rows.buf[i] = reinterpret_cast<float4*>(scratch[k]);
+    cols.x[i] = lps[k]; cols.out[i] = imgs[k]; cols.buf[i] = reinterpret_cast<float4*>(scratch[k]);
+  }
+  hipLaunchKernelGGL((k_iir_causal<true>), dim3(cdiv(h, IIR_CH), n), dim3(64), 0, st, rows, gr, npix, alpha);
+  hipLaunchKernelGGL((k_iir_anticausal<true, false>), dim3(cdiv(h, IIR_CH), n), dim3(64), 0, st, rows, gr, npix, alpha, amount);
+  hipLaunchKernelGGL((k_iir_causal<false>), dim3(cdiv(w, IIR_CH), n), dim3(64), 0, st, cols, gc, npix, alpha);
+  hipLaunchKernelGGL((k_iir_anticausal<false, true>), dim3(cdiv(w, IIR_CH), n), dim3(64), 0, st, cols, gc, npix, alpha, amount);
+}
+void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount) {
+  launch_sharpen_many(st, &img, &lp, &scratch, 1, w, h, amount);
 }
 
 }  // namespace s360

@@ -82,6 +82,8 @@ void launch_pole_removal_combine(hipStream_t st, uchar4* bottom, const uchar4* w
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst);
 // sharpen (Filter.h:40-127) on BGRA in place, lp scratch same size
 size_t sharpen_scratch_bytes(int w, int h);
+void launch_sharpen_many(hipStream_t st, uchar4* const* imgs, uchar4* const* lps, float* const* scratch, int n, int w,
+                         int h, float amount);
 void launch_sharpen(hipStream_t st, uchar4* img, uchar4* lp, float* scratch, int w, int h, float amount);
 
 }  // namespace s360
