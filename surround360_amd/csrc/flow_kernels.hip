@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
                                                  float* const* __restrict__ dst_tab, UpSrc up) {
   constexpr int IW = SB_TW + 2 * R, IH = SB_TH + 2 * R;
   constexpr int IWP = IW | 1;  // odd row stride: the 4-wide row tasks of consecutive rows fall into different banks
-  __shared__ float s_in[IH][IWP][CN];
-  __shared__ float s_mid[IH][SB_TW + 1][CN];
+  __shared__ __attribute__((aligned(8))) float s_in[IH][IWP][CN];
+  __shared__ __attribute__((aligned(8))) float s_mid[IH][SB_TW + 1][CN];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
@@ -170,35 +170,45 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
       const float* r0 = src + (size_t)gy * w;
       s_in[ly][lx][0] = r0[min(gx + 1, w - 1)] - r0[max(gx - 1, 0)];
       s_in[ly][lx][CN - 1] = src[(size_t)min(gy + 1, h - 1) * w + gx] - src[(size_t)max(gy - 1, 0) * w + gx];
+    } else if (CN == 2) {
+      *reinterpret_cast<float2*>(&s_in[ly][lx][0]) = *reinterpret_cast<const float2*>(src + ((size_t)gy * w + gx) * CN);
     } else {
-      const float* p = src + ((size_t)gy * w + gx) * CN;
-#pragma unroll
-      for (int k = 0; k < CN; ++k) s_in[ly][lx][k] = p[k];
+      s_in[ly][lx][0] = src[(size_t)gy * w + gx];
     }
   }
   __syncthreads();
-  // row pass: task = (row ly, group of 4 consecutive x)
+  // row pass: task = (row ly, group of 4 consecutive x). Two-channel images move through LDS as 8-byte pairs (one
+  // ds_read_b64 per tap for both channels: half the LDS instructions and all banks in use).
   for (int t = tid; t < IH * (SB_TW / 4); t += 256) {
     const int ly = t % IH, lx0 = (t / IH) * 4;
+    float v[CN][4 + 2 * R];
 #pragma unroll
-    for (int k = 0; k < CN; ++k) {
-      float v[4 + 2 * R];
-#pragma unroll
-      for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_in[ly][lx0 + j][k];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        float acc;
-        if (R <= 2) {  // SymmRowSmallFilter: centre, then symmetric pairs
-          acc = taps.k[0] * v[o + R];
-#pragma unroll
-          for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
-        } else {  // generic RowFilter: left to right; its SSE2 loop (whole groups of 8 row elements) starts from +0
-          acc = ((tx0 + lx0 + o) * CN + k < vecEnd) ? 0.0f : -0.0f;
-#pragma unroll
-          for (int j = 0; j <= 2 * R; ++j) acc += taps.k[j < R ? R - j : j - R] * v[o + j];
-        }
-        s_mid[ly][lx0 + o][k] = acc;
+    for (int j = 0; j < 4 + 2 * R; ++j) {
+      if (CN == 2) {
+        const float2 p = *reinterpret_cast<const float2*>(&s_in[ly][lx0 + j][0]);
+        v[0][j] = p.x;
+        v[CN - 1][j] = p.y;
+      } else {
+        v[0][j] = s_in[ly][lx0 + j][0];
       }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float acc[CN];
+#pragma unroll
+      for (int k = 0; k < CN; ++k) {
+        if (R <= 2) {  // SymmRowSmallFilter: centre, then symmetric pairs
+          acc[k] = taps.k[0] * v[k][o + R];
+#pragma unroll
+          for (int j = 1; j <= R; ++j) acc[k] += taps.k[j] * (v[k][o + R + j] + v[k][o + R - j]);
+        } else {  // generic RowFilter: left to right; its SSE2 loop (whole groups of 8 row elements) starts from +0
+          acc[k] = ((tx0 + lx0 + o) * CN + k < vecEnd) ? 0.0f : -0.0f;
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) acc[k] += taps.k[j < R ? R - j : j - R] * v[k][o + j];
+        }
+      }
+      if (CN == 2) *reinterpret_cast<float2*>(&s_mid[ly][lx0 + o][0]) = make_float2(acc[0], acc[CN - 1]);
+      else s_mid[ly][lx0 + o][0] = acc[0];
     }
   }
   __syncthreads();
@@ -208,18 +218,27 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
     const int lx = t % SB_TW, ly0 = (t / SB_TW) * 4;
     const int gx = tx0 + lx;
     float outv[4][CN];
+    {
+      float v[CN][4 + 2 * R];
 #pragma unroll
-    for (int k = 0; k < CN; ++k) {
-      float v[4 + 2 * R];
-#pragma unroll
-      for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_mid[ly0 + j][lx][k];
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        float acc = taps.k[0] * v[o + R] + 0.0f;  // SymmColumnFilter: centre + delta (= +0), then symmetric pairs
-#pragma unroll
-        for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[o + R + j] + v[o + R - j]);
-        outv[o][k] = acc;
+      for (int j = 0; j < 4 + 2 * R; ++j) {
+        if (CN == 2) {
+          const float2 p = *reinterpret_cast<const float2*>(&s_mid[ly0 + j][lx][0]);
+          v[0][j] = p.x;
+          v[CN - 1][j] = p.y;
+        } else {
+          v[0][j] = s_mid[ly0 + j][lx][0];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < CN; ++k)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float acc = taps.k[0] * v[k][o + R] + 0.0f;  // SymmColumnFilter: centre + delta (= +0), then symmetric pairs
+#pragma unroll
+          for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[k][o + R + j] + v[k][o + R - j]);
+          outv[o][k] = acc;
+        }
     }
     if (gx >= w) continue;
 #pragma unroll
@@ -468,48 +487,56 @@ __global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ s
 // adjacent pairs are selected once and used by 2 — 79 min/max operations per median instead of 112 and 60 eight-byte
 // loads per 8 pixels instead of 200. The networks are generated and verified by tools/gen_median_network.py.
 #include "median_tile.inc"
-constexpr int MED_T = 8;
+constexpr int MED_T = 8;                      // outputs per thread
+constexpr int MED_BX = 32, MED_BY = 8;        // threads per block: a block produces (32 * 8) x 8 pixels
+constexpr int MED_LW = MED_BX * MED_T + 4, MED_LH = MED_BY + 4;
+// The tile (with its 2-pixel replicate border) goes through LDS once, split into its two channels: a thread then reads
+// the 60 values of ONE channel at a time (three 16-byte LDS reads per window row), which keeps the generated network
+// at ~100 registers instead of the ~190 it needs with both channels' inputs live.
 __global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restrict__ src, float2* __restrict__ dst, int w,
                                                          int h, size_t bs) {
-  const int x0 = (blockIdx.x * 64 + threadIdx.x) * MED_T;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  if (x0 >= w || y >= h) return;
+  __shared__ __attribute__((aligned(16))) float s_p[2][MED_LH][MED_LW];
+  const int tid = threadIdx.x;
+  const int X0 = blockIdx.x * (MED_BX * MED_T), Y0 = blockIdx.y * MED_BY;
   src += bs * blockIdx.z;
   dst += bs * blockIdx.z;
-  float inx[(MED_T + 4) * 5], iny[(MED_T + 4) * 5];
-  const bool interior = x0 >= 2 && x0 + MED_T + 2 <= w;
+  for (int i = tid; i < MED_LH * MED_LW; i += 256) {
+    const int ly = i / MED_LW, lx = i - ly * MED_LW;
+    const float2 p = src[(size_t)clip_idx(Y0 - 2 + ly, h) * w + clip_idx(X0 - 2 + lx, w)];
+    s_p[0][ly][lx] = p.x;
+    s_p[1][ly][lx] = p.y;
+  }
+  __syncthreads();
+  const int tx = tid & (MED_BX - 1), ty = tid >> 5;
+  const int x0 = X0 + tx * MED_T, y = Y0 + ty;
+  if (x0 >= w || y >= h) return;
+  float o[2][MED_T];
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const float2* row = src + (size_t)clip_idx(y + r - 2, h) * w;
-    if (interior) {
-      const f4a8* v = reinterpret_cast<const f4a8*>(row + x0 - 2);  // 8-byte aligned 16-byte loads, two pixels each
+  for (int ch = 0; ch < 2; ++ch) {
+    float in[(MED_T + 4) * 5];
 #pragma unroll
-      for (int c = 0; c < (MED_T + 4) / 2; ++c) {
-        const f4a8 p = v[c];
-        inx[(2 * c) * 5 + r] = p.x; iny[(2 * c) * 5 + r] = p.y;
-        inx[(2 * c + 1) * 5 + r] = p.z; iny[(2 * c + 1) * 5 + r] = p.w;
-      }
-    } else {
+    for (int r = 0; r < 5; ++r) {
+      const float4* row = reinterpret_cast<const float4*>(&s_p[ch][ty + r][tx * MED_T]);  // 32-byte aligned
 #pragma unroll
-      for (int c = 0; c < MED_T + 4; ++c) {
-        const float2 p = row[clip_idx(x0 - 2 + c, w)];
-        inx[c * 5 + r] = p.x;
-        iny[c * 5 + r] = p.y;
+      for (int q = 0; q < (MED_T + 4) / 4; ++q) {
+        const float4 v = row[q];
+        in[(4 * q) * 5 + r] = v.x;
+        in[(4 * q + 1) * 5 + r] = v.y;
+        in[(4 * q + 2) * 5 + r] = v.z;
+        in[(4 * q + 3) * 5 + r] = v.w;
       }
     }
+    median5x5_row8(in, o[ch]);
   }
-  float ox[MED_T], oy[MED_T];
-  median5x5_row8(inx, ox);
-  median5x5_row8(iny, oy);
   float2* out = dst + (size_t)y * w + x0;
   if (x0 + MED_T <= w) {
 #pragma unroll
-    for (int o = 0; o < MED_T; o += 2) {
-      f4a8 q = {ox[o], oy[o], ox[o + 1], oy[o + 1]};
-      *reinterpret_cast<f4a8*>(out + o) = q;
+    for (int k = 0; k < MED_T; k += 2) {
+      f4a8 q = {o[0][k], o[1][k], o[0][k + 1], o[1][k + 1]};
+      *reinterpret_cast<f4a8*>(out + k) = q;
     }
   } else {
-    for (int o = 0; o < MED_T && x0 + o < w; ++o) out[o] = make_float2(ox[o], oy[o]);
+    for (int k = 0; k < MED_T && x0 + k < w; ++k) out[k] = make_float2(o[0][k], o[1][k]);
   }
 }
 
@@ -692,8 +719,8 @@ void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev,
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B) {
   dim3 blk(64, 4);
   if (w >= 64) {  // 8 pixels per thread; narrow levels keep one pixel per thread (more threads than the chip otherwise idles)
-    dim3 grd((w + 64 * MED_T - 1) / (64 * MED_T), (h + 3) / 4, B);
-    hipLaunchKernelGGL(k_median5_c2_row8, grd, blk, 0, st, src, dst, w, h, bs);
+    dim3 grd((w + MED_BX * MED_T - 1) / (MED_BX * MED_T), (h + MED_BY - 1) / MED_BY, B);
+    hipLaunchKernelGGL(k_median5_c2_row8, grd, dim3(256), 0, st, src, dst, w, h, bs);
     return;
   }
   hipLaunchKernelGGL(k_median5_c2, grid2d(w, h, B, blk), blk, 0, st, src, dst, w, h, bs);

@@ -153,30 +153,10 @@ def build(T):
     ncols = T + 4
     assert T % 2 == 0
     E = Emitter()
-    cols = []
-    for c in range(ncols):
-        w = E.apply(s5, 5, {r: "in[%d]" % (c * 5 + r) for r in range(5)})
-        cols.append(w[:5])
-    pairs = []
-    for k in range(ncols // 2):
-        place = {}
-        for r in range(5):
-            place[m55_a[r]] = cols[2 * k][r]
-            place[m55_b[r]] = cols[2 * k + 1][r]
-        w = E.apply(m55, m55_n, place)
-        assert INF not in w[:10]
-        pairs.append(w[:10])
-    quads = []
-    for k in range(ncols // 2 - 1):
-        place = {}
-        for r in range(10):
-            place[q_a[r]] = pairs[k][r]
-            place[q_b[r]] = pairs[k + 1][r]
-        w = E.apply(qn, qn_n, place)
-        assert INF not in w[7:13]
-        quads.append(w[7:13])
-    outs = []
-    for o in range(T):
+    cols, pairs, quads = {}, {}, {}
+    outs = [None] * T
+
+    def final(o):
         if o % 2 == 0:
             X, Y = quads[o // 2], cols[o + 4]
         else:
@@ -185,7 +165,38 @@ def build(T):
         acc = X[5]
         for i in range(1, 6):
             acc = E.binop("fminf", acc, E.binop("fmaxf", X[i - 1], Y[5 - i]))
-        outs.append(acc)
+        outs[o] = acc
+
+    # streaming order, left to right: values die as early as possible (the register footprint of the generated code
+    # follows the order of this list closely)
+    for k in range(ncols // 2):
+        for c in (2 * k, 2 * k + 1):
+            w = E.apply(s5, 5, {r: "in[%d]" % (c * 5 + r) for r in range(5)})
+            cols[c] = w[:5]
+        place = {}
+        for r in range(5):
+            place[m55_a[r]] = cols[2 * k][r]
+            place[m55_b[r]] = cols[2 * k + 1][r]
+        w = E.apply(m55, m55_n, place)
+        assert INF not in w[:10]
+        pairs[k] = w[:10]
+        if k >= 1:
+            place = {}
+            for r in range(10):
+                place[q_a[r]] = pairs[k - 1][r]
+                place[q_b[r]] = pairs[k][r]
+            w = E.apply(qn, qn_n, place)
+            assert INF not in w[7:13]
+            quads[k - 1] = w[7:13]
+        # outputs whose quad and single column now exist
+        for o in range(T):
+            if outs[o] is not None:
+                continue
+            q = o // 2 if o % 2 == 0 else (o + 1) // 2
+            col = o + 4 if o % 2 == 0 else o
+            if q in quads and col in cols:
+                final(o)
+    assert all(o is not None for o in outs)
     ops = E.live_ops(outs)
     return ops, outs, dict(sort5=len(s5), merge55=len(m55), quad=len(qn))
 
