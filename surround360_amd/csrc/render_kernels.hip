@@ -84,6 +84,31 @@ __device__ __forceinline__ uchar4 remap_cubic_u8c4_at(const uchar4* __restrict__
   int sx, sy, fxy;
   remap_coord(mx, my, &sx, &sy, &fxy);
   if (sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0) return make_uchar4(0, 0, 0, 0);
+  if (sx >= 0 && sx + 4 <= sw && sy >= 0 && sy + 4 <= sh) {
+    // interior: four 16-byte row loads (4-byte aligned) and the 64 multiply-adds as v_perm_b32 + v_dot2_i32_i16 — the
+    // table holds the weights of two neighbouring taps per dword (integer sums: the order does not matter)
+    typedef unsigned u4a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef short s16x2_ __attribute__((ext_vector_type(2)));
+    const uint4* w4 = reinterpret_cast<const uint4*>(tab + fxy * 16);
+    const uint4 wa = w4[0], wb = w4[1];
+    const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u4a4 p = *reinterpret_cast<const u4a4*>(src + (size_t)(sy + r) * sw + sx);
+      const s16x2_ w01 = __builtin_bit_cast(s16x2_, wq[2 * r]), w23 = __builtin_bit_cast(s16x2_, wq[2 * r + 1]);
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
+        const s16x2_ lo = __builtin_bit_cast(s16x2_, __builtin_amdgcn_perm(p.y, p.x, sel));
+        const s16x2_ hi = __builtin_bit_cast(s16x2_, __builtin_amdgcn_perm(p.w, p.z, sel));
+        acc[ch] = __builtin_amdgcn_sdot2(lo, w01, acc[ch], false);
+        acc[ch] = __builtin_amdgcn_sdot2(hi, w23, acc[ch], false);
+      }
+    }
+    return make_uchar4((unsigned char)sat_u8((acc[0] + (1 << 14)) >> 15), (unsigned char)sat_u8((acc[1] + (1 << 14)) >> 15),
+                       (unsigned char)sat_u8((acc[2] + (1 << 14)) >> 15), (unsigned char)sat_u8((acc[3] + (1 << 14)) >> 15));
+  }
   const short* w = tab + fxy * 16;
   int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
@@ -113,16 +138,19 @@ __device__ __forceinline__ float2 remap_cubic_f32c2_at(const float2* __restrict_
   const unsigned width1 = sw - 3 > 0 ? sw - 3 : 0, height1 = sh - 3 > 0 ? sh - 3 : 0;
   float2 o;
   if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+    typedef float f4a8_ __attribute__((ext_vector_type(4), aligned(8)));
     const float2* S = src + (size_t)sy * sw + sx;
-    float2 a = S[0], b = S[1], c = S[2], d = S[3];
-    o.x = a.x * w[0] + b.x * w[1] + c.x * w[2] + d.x * w[3];
-    o.y = a.y * w[0] + b.y * w[1] + c.y * w[2] + d.y * w[3];
+    const f4a8_* V = reinterpret_cast<const f4a8_*>(S);  // two pixels per 16-byte load
+    f4a8_ ab = V[0], cd = V[1];
+    o.x = ab.x * w[0] + ab.z * w[1] + cd.x * w[2] + cd.z * w[3];
+    o.y = ab.y * w[0] + ab.w * w[1] + cd.y * w[2] + cd.w * w[3];
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
       S += sw;
-      a = S[0]; b = S[1]; c = S[2]; d = S[3];
-      o.x += a.x * w[r * 4] + b.x * w[r * 4 + 1] + c.x * w[r * 4 + 2] + d.x * w[r * 4 + 3];
-      o.y += a.y * w[r * 4] + b.y * w[r * 4 + 1] + c.y * w[r * 4 + 2] + d.y * w[r * 4 + 3];
+      V = reinterpret_cast<const f4a8_*>(S);
+      ab = V[0]; cd = V[1];
+      o.x += ab.x * w[r * 4] + ab.z * w[r * 4 + 1] + cd.x * w[r * 4 + 2] + cd.z * w[r * 4 + 3];
+      o.y += ab.y * w[r * 4] + ab.w * w[r * 4 + 1] + cd.y * w[r * 4 + 2] + cd.w * w[r * 4 + 3];
     }
   } else if (sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0) {
     o = make_float2(0.f, 0.f);
