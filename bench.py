@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="timed region + check + roofline only (profiling runs)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts in flight per GPU (one HIP stream + one submitting host thread each)")
-    ap.add_argument("--slots", type=int, default=8,
+    ap.add_argument("--slots", type=int, default=12,
                     help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
                          "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
     ap.add_argument("--video-frames", type=int, default=32)

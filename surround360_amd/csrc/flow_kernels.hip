@@ -124,8 +124,8 @@ struct UpSrc {  // SRC 2: geometry of the small source image and the scalar appl
   double scx, scy;
   float post_scale;
 };
-template <int R, int CN, int EPI, int SRC, int SB_TW = 64, int SB_TH = 16>
-__global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
+template <int R, int CN, int EPI, int SRC, int SB_TW = 64, int SB_TH = 16, int NT = 256>
+__global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                  size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
                                                  const float* __restrict__ A, FlowIdx idx,
                                                  const float2* __restrict__ Gp, float4* __restrict__ rec,
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
   const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
   src += (SRC == 2 ? up.sbs * CN : bs * (SRC == 1 ? 1 : CN)) * blockIdx.z;
-  for (int i = tid; i < IH * IW; i += 256) {
+  for (int i = tid; i < IH * IW; i += NT) {
     const int ly = i / IW, lx = i - ly * IW;
     const int gy = reflect101(ty0 - R + ly, h), gx = reflect101(tx0 - R + lx, w);
     if (SRC == 2) {  // k_resize_linear_f32's arithmetic at (gx, gy), then the scalar multiply
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
   __syncthreads();
   // row pass: task = (row ly, group of 4 consecutive x). Two-channel images move through LDS as 8-byte pairs (one
   // ds_read_b64 per tap for both channels: half the LDS instructions and all banks in use).
-  for (int t = tid; t < IH * (SB_TW / 4); t += 256) {
+  for (int t = tid; t < IH * (SB_TW / 4); t += NT) {
     const int ly = t % IH, lx0 = (t / IH) * 4;
     float v[CN][4 + 2 * R];
 #pragma unroll
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_sepblur(const float* __restrict__ src, 
   __syncthreads();
   // column pass: task = (column lx, group of 4 consecutive y)
   dst = dst_tab ? dst_tab[blockIdx.z] : dst + bs * CN * blockIdx.z;
-  for (int t = tid; t < SB_TW * (SB_TH / 4); t += 256) {
+  for (int t = tid; t < SB_TW * (SB_TH / 4); t += NT) {
     const int lx = t % SB_TW, ly0 = (t / SB_TW) * 4;
     const int gx = tx0 + lx;
     float outv[4][CN];
@@ -640,9 +640,10 @@ static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w
                              const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float4* rec,
                              float* const* dst_tab = nullptr, const UpSrc& up = UpSrc{}) {
   dim3 blk(64, 4);
-  if constexpr (R == 7) {  // 15x15: 32x32 tile — 29 KB of LDS, 1.44x row-pass halo work (64x16: 35 KB, 1.9x; measured 30 % slower)
+  if constexpr (R == 7) {  // 15x15: 32x32 tile — 29 KB of LDS, 1.44x row-pass halo work (64x16: 35 KB, 1.9x; measured 30 % slower);
+    // 384 threads: the row pass has 46 rows x 8 groups = 368 tasks (two rounds on 256 threads, the second 44 % full)
     dim3 grd((w + 31) / 32, (h + 31) / 32, B);
-    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab, up);
+    hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC, 32, 32, 384>), grd, dim3(64, 6), 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab, up);
   } else {
     dim3 grd((w + 63) / 64, (h + 15) / 16, B);
     hipLaunchKernelGGL((k_sepblur<R, CN, EPI, SRC>), grd, blk, 0, st, src, dst, w, h, bs, t, A, idx, Gp, rec, dst_tab, up);

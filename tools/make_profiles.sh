@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries under profiles/ on a GPU box (run from the repo root, e.g. through gpurun;
-# gpurun_out/ is scratch). Usage: tools/make_profiles.sh <tag> [slots]     e.g. tools/make_profiles.sh r02_v1 8
+# gpurun_out/ is scratch). Usage: tools/make_profiles.sh <tag> [slots]     e.g. tools/make_profiles.sh r02_v1 12
 #   1. <tag>_kernel_stats.txt          kernel-trace summary of the DEFAULT bench command (contexts overlap: durations
 #                                      of launches that share the GPU are longer than isolated ones)
 #   2. <tag>_isolated_kernel_stats.txt the same workload with ONE context alone (--inflight 1): launches do not overlap,
@@ -11,7 +11,7 @@
 #   4. profiles/sweep_traffic.json     HBM bytes per sweep launch (gfx950: FETCH_SIZE x2 on the read side)
 set -e
 TAG=${1:?tag}
-SLOTS=${2:-8}
+SLOTS=${2:-12}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/iso -o iso -- $ISO > $OUT/iso.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f -o f -- $ISO > $OUT/f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w -o w -- $ISO > $OUT/w.log 2>&1
 python tools/rocpd_kernel_stats.py $OUT/ks/ks_results.db \
-  "rocprofv3 --kernel-trace --stats summary ($TAG): python bench.py --steps 8 --warmup 2 --no-cpu-baseline (default: 2 contexts x 8 frame slots)" \
+  "rocprofv3 --kernel-trace --stats summary ($TAG): python bench.py --steps 8 --warmup 2 --no-cpu-baseline (default: 2 contexts x 12 frame slots)" \
   "durations from the rocpd kernel dispatch table; launches of the two contexts overlap, so these are NOT isolated durations" \
   > profiles/${TAG}_kernel_stats.txt
 python tools/rocpd_kernel_stats.py $OUT/iso/iso_results.db \
