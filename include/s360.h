@@ -194,8 +194,9 @@ int s360_frame_download_equirect(s360_ctx* ctx, uint8_t* out_bgr);
 int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
 /* Streaming hosts (one video stream, the reference's per-frame loop of scripts/batch_process_video.py:123-210 inside
  * one process): the stacked equirect of the last two frames is kept. age 0 = the frame enqueued last, age 1 = the one
- * before; the call waits for THAT frame only and copies on a stream of its own, so frame k can be fetched and encoded
- * while frame k+1 renders:  upload(k+1); render(k+1); download_equirect_of(age 1) -> frame k. */
+ * before (needs s360_set_frame_pipelining, which is what makes the library alternate between two output buffers); the
+ * call waits for THAT frame only and copies on a stream of its own, so frame k can be fetched and encoded while frame
+ * k+1 renders:  upload(k+1); render(k+1); download_equirect_of(age 1) -> frame k. */
 int s360_frame_download_equirect_of(s360_ctx* ctx, int age, uint8_t* out_bgr);
 /* Stereo cubemap of the last rendered frame (convertSphericalToCubemapBicubicRemap + stackOutputCubemapFaces,
  * SR/render/ImageWarper.cpp:95-141, SR/util/CvUtil.cpp:117-138, TRSP:917-935): format "video" (3 x 2 faces per eye,

@@ -647,6 +647,7 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     need(c && out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
     FrameState& F = frame_state(c);
     need(F.frames_done > age, "that frame has not been rendered");
+    need(age == 0 || (c->pipeline && F.outBGR[F.out_cur ^ 1].p), "age 1 needs s360_set_frame_pipelining (two output buffers)");
     const int b = age == 0 ? F.out_cur : F.out_cur ^ 1;
     // wait for THAT frame only (its event sits behind its last kernel), then copy on a stream of its own so that the
     // transfer does not queue behind the kernels of the frame enqueued after it

@@ -28,22 +28,33 @@ __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restr
                                                            size_t sbs, uchar4* __restrict__ dst, int dw, int dh,
                                                            size_t dbs, double scx, double scy,
                                                            const uchar4* const* __restrict__ src_tab) {
+  // the double-precision source coordinate and the four 11-bit taps depend on the column (row) only: computed once
+  // per block column / row instead of once per pixel
+  __shared__ int s_sx[32], s_sy[8];
+  __shared__ short s_ax[32][4], s_ay[8][4];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if (tid < 40) {
+    const bool col = tid < 32;
+    const int k = col ? tid : tid - 32;
+    const int d = col ? min((int)(blockIdx.x * 32 + k), dw - 1) : min((int)(blockIdx.y * 8 + k), dh - 1);
+    int s0;
+    float f, cb[4];
+    resize_coord(d, col ? scx : scy, &s0, &f);
+    cubic_coeffs(f, cb);
+    if (col) s_sx[k] = s0; else s_sy[k] = s0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) (col ? s_ax[k] : s_ay[k])[q] = (short)sat_s16(cv_round(cb[q] * 2048.f));
+  }
+  __syncthreads();
   const int dx = blockIdx.x * blockDim.x + threadIdx.x;
   const int dy = blockIdx.y * blockDim.y + threadIdx.y;
   if (dx >= dw || dy >= dh) return;
   src = src_tab ? src_tab[blockIdx.z] : src + sbs * blockIdx.z;
   dst += dbs * blockIdx.z;
-  int sx, sy;
-  float fx, fy, cb[4];
+  const int sx = s_sx[threadIdx.x], sy = s_sy[threadIdx.y];
   int ax[4], ay[4];
-  resize_coord(dx, scx, &sx, &fx);
-  cubic_coeffs(fx, cb);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ax[k] = sat_s16(cv_round(cb[k] * 2048.f));
-  resize_coord(dy, scy, &sy, &fy);
-  cubic_coeffs(fy, cb);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ay[k] = sat_s16(cv_round(cb[k] * 2048.f));
+  for (int k = 0; k < 4; ++k) { ax[k] = s_ax[threadIdx.x][k]; ay[k] = s_ay[threadIdx.y][k]; }
   int hx[4], hy[4], hz[4], hw[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

@@ -715,7 +715,9 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     {
       ProfScope ps(prof, "finish");  // TRSP:890-961
       const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
-      const int ob = F.out_cur ^ 1;  // the buffer the previous-but-one frame used
+      // frame pipelining (a streaming host fetches frame k while frame k+1 renders) alternates between two output
+      // buffers; otherwise the same one is reused
+      const int ob = c->pipeline ? F.out_cur ^ 1 : F.out_cur;
       F.outBGR[ob].ensure((size_t)outW * outH * 3);
       if (!F.outDone[ob]) S360_HIP(hipEventCreateWithFlags(&F.outDone[ob], hipEventDisableTiming));
       const bool resize = (outW != W) || (eyeH != H);
