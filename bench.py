@@ -150,7 +150,7 @@ def main():
     # through the 17 rig cameras on the GPU; frame k = world rotated by 0.2 deg * k, one disc moving 0.5 deg per frame.
     # (The world is 8192x4096: the 16384x8192 of §8d needs 3 GB for the texture + depth alone; stated in `data`.)
     n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 2)
-    wtex = synth.World(4096, seed=360 + rank, device=dev)
+    wtex = synth.World(4096, seed=360, device=dev)  # the same stream on every rank (the sharded frame needs identical inputs)
     rr = synth.RigRenderer(RIG, wtex, 2048)
     frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_video))]
     del rr, wtex

@@ -28,7 +28,7 @@ python tools/rocpd_kernel_stats.py $OUT/iso/iso_results.db \
   "rocprofv3 --kernel-trace --stats summary ($TAG): $ISO" \
   "ONE context alone: launches do not overlap. k_sweep_quad avg_us here = roofline.avg_launch_ms of the bench line; every k_sweep_quad launch holds the flows of $SLOTS frames" \
   > profiles/${TAG}_isolated_kernel_stats.txt
-tail -1 $OUT/iso.log > profiles/${TAG}_isolated_bench.json || true
+grep '^{"metric"' $OUT/iso.log | tail -1 > profiles/${TAG}_isolated_bench.json || true
 {
   echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) and --pmc WRITE_SIZE (pass 2) on: $ISO ($TAG)"
   echo "# Units: KB as reported by rocprofv3. gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at 1/2 of their bytes."
