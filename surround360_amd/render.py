@@ -342,6 +342,21 @@ class Context:
         return {ns[i]: (ms[i], cnt[i]) for i in range(n)}
 
 
+def save_flow_to_file(flow, filename):
+    """saveFlowToFile (CvUtil.cpp:159-177)."""
+    f = np.ascontiguousarray(flow, np.float32)
+    check(lib().s360_save_flow_to_file(str(filename).encode(), _p(f), f.shape[1], f.shape[0]))
+
+
+def read_flow_from_file(filename):
+    """readFlowFromFile (CvUtil.cpp:179-199) -> H x W x 2 float32."""
+    w, h = C.c_int(), C.c_int()
+    check(lib().s360_read_flow_from_file(str(filename).encode(), None, C.byref(w), C.byref(h), C.c_size_t(0)))
+    out = np.empty((h.value, w.value, 2), np.float32)
+    check(lib().s360_read_flow_from_file(str(filename).encode(), _p(out), C.byref(w), C.byref(h), C.c_size_t(out.size)))
+    return out
+
+
 # ---- reference-shaped operator objects ----------------------------------------------------------
 class OpticalFlow:
     """OpticalFlowInterface implementation returned by make_optical_flow_by_name."""

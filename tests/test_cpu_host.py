@@ -158,3 +158,21 @@ def test_required_flags_and_unknown_flags():
     assert r.returncode == 1 and "unknown command line flag" in r.stderr
     r = subprocess.run([exe, "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--eqr_width" in r.stdout and "--prev_frame_data_dir" in r.stdout
+
+
+def test_optical_flow_harness_flags(tmp_path):
+    """host/TestOpticalFlow: requireArg order and messages of TestOpticalFlow.cpp:226-244."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "surround360_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "TestOpticalFlow")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "missing required command line argument: mode" in r.stderr
+    r = subprocess.run([exe, "--mode", "video"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unrecongized mode" in r.stderr
+    r = subprocess.run([exe, "--mode", "test", "--test_dir", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "left_img" in r.stderr
+    r = subprocess.run([exe, "--mode", "test", "--test_dir", str(tmp_path), "--left_img", "l.png", "--right_img", "r.png",
+                        "--flow_alg", "pixflow_low"], capture_output=True, text=True)
+    assert r.returncode != 0 and "failed to load image" in r.stderr
+    r = subprocess.run([exe, "--nope", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown command line flag" in r.stderr

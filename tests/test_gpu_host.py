@@ -186,3 +186,24 @@ def test_pole_removal_through_the_binary(tmp_path, rig_json, oracle, s360lib):
     # --enable_pole_removal without masks is an error, like requireArg at TRSP:571
     r = subprocess.run([c for c in cmd if c not in ("--bottom_pole_masks_dir", masks)], capture_output=True, text=True)
     assert r.returncode != 0 and "bottom_pole_masks_dir" in r.stderr
+
+
+def test_optical_flow_harness(tmp_path, oracle, s360lib):
+    """host/TestOpticalFlow --mode test (TestOpticalFlow.cpp:50-143): both flow directions of one pair, bit-exact
+    against the oracle, "RUNTIME (sec)" logged per repetition, flows written in the reference's .bin format."""
+    from surround360_amd import synth, render as R
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "TestOpticalFlow")
+    i0, i1 = synth.flow_pair(300, 260, seed=11)
+    Image.fromarray(np.ascontiguousarray(i0[:, :, [2, 1, 0, 3]])).save(str(tmp_path / "left.png"))   # BGRA -> RGBA
+    Image.fromarray(np.ascontiguousarray(i1[:, :, [2, 1, 0]])).save(str(tmp_path / "right.png"))     # no alpha: 255 added
+    i1 = i1.copy()
+    i1[:, :, 3] = 255
+    r = subprocess.run([exe, "--mode", "test", "--test_dir", str(tmp_path), "--left_img", "left.png", "--right_img",
+                        "right.png", "--flow_alg", "pixflow_low", "--repetitions", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("RUNTIME (sec) = ") == 2
+    for name, a, b, hint in (("flowLtoR", i0, i1, "LEFT"), ("flowRtoL", i1, i0, "RIGHT")):
+        got = R.read_flow_from_file(str(tmp_path / "disparity" / (name + "_pixflow_low.bin")))
+        want = oracle.compute_optical_flow(a, b, "pixflow_low", hint)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
