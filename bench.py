@@ -232,26 +232,32 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    for c in ctxs:
-        c.profile_enable(True)
     for k in range(F):
         enqueue_s[k] = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):  # the timed region carries no event records: nothing but the frames' own launches
         step()
     drain()
     dt = time.perf_counter() - t0
-    prof = {}
-    for c in ctxs:
-        for k, v in c.profile_get().items():
-            a = prof.get(k, (0.0, 0))
-            prof[k] = (a[0] + v[0], a[1] + v[1])
-        c.profile_enable(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     enqueue_ms_per_frame = 1e3 * sum(enqueue_s) / max(args.steps * S, 1)
+    # Per-kernel-family breakdown: one more step per context with the same contexts in flight, untimed, with the
+    # library's per-family HIP events switched on (two event records per family scope perturb the launch stream,
+    # which is why the timed steps above run without them).
+    prof, prof_steps = {}, F
+    for c in ctxs:
+        c.profile_enable(True)
+    for _ in range(prof_steps):
+        step()
+    drain(barrier=False)
+    for c in ctxs:
+        for k, v in c.profile_get().items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + v[0], a[1] + v[1])
+        c.profile_enable(False)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)
 
@@ -269,12 +275,16 @@ def main():
     if S > 1:  # one batched context alone on the GPU: isolated durations of launches that hold S frames' flows
         ctx.render_batch(False)
         sync(barrier=False)
-        ctx.profile_enable(True)
         tb = time.perf_counter()
         for _ in range(2):
             ctx.render_batch(False)
         sync(barrier=False)
-        batched_alone = {"ms_per_batch": 1e3 * (time.perf_counter() - tb) / 2,
+        ms_per_batch = 1e3 * (time.perf_counter() - tb) / 2
+        ctx.profile_enable(True)
+        for _ in range(2):
+            ctx.render_batch(False)
+        sync(barrier=False)
+        batched_alone = {"ms_per_batch": ms_per_batch,
                          "prof": {k: (v[0] / 2, v[1] / 2) for k, v in ctx.profile_get().items()}}
         ctx.profile_enable(False)
         ctx.select_frame_slot(0)
@@ -305,15 +315,18 @@ def main():
         ctx.set_sweep_mode(mode)
         ctx.render(False)
         sync(barrier=False)
-        ctx.profile_enable(True)
         t1 = time.perf_counter()
         enq = 0.0
-        for _ in range(n):
+        for _ in range(n):  # wall time without event records
             te = time.perf_counter()
             ctx.render(False)
             enq += time.perf_counter() - te
         sync(barrier=False)
         ms = 1e3 * (time.perf_counter() - t1) / n
+        ctx.profile_enable(True)
+        for _ in range(n):  # the same frames again with the per-family HIP events
+            ctx.render(False)
+        sync(barrier=False)
         pr = {k: (v[0] / n, v[1] / n) for k, v in ctx.profile_get().items()}
         ctx.profile_enable(False)
         return ms, pr, 1e3 * enq / n
@@ -385,7 +398,7 @@ def main():
                    "frames_in_flight": F * S, "contexts": F, "slots_per_context": S, "frames_per_step": S,
                    "rccl_ranks": world},
         "roofline": roofline,
-        "kernel_ms_per_frame_in_flight": {k: round(v[0] / (args.steps * S), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "kernel_ms_per_frame_in_flight": {k: round(v[0] / (prof_steps * S), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         "host": {"submit_threads": F, "enqueue_ms_per_frame": enqueue_ms_per_frame,
                  "settle_batches_before_warmup": settle["batches"], "settle_seconds": round(settle["seconds"], 2)},
     }
@@ -490,12 +503,15 @@ def main():
             cs.upload_frame(*frames[0])
             cs.render(False)
             cs.synchronize()
-            cs.profile_enable(True)
             t1 = time.perf_counter()
             for _ in range(3):
                 cs.render(False)
             cs.synchronize()
             ms = 1e3 * (time.perf_counter() - t1) / 3
+            cs.profile_enable(True)
+            for _ in range(3):
+                cs.render(False)
+            cs.synchronize()
             pr = cs.profile_get()
             cs.close()
             out["single_frame"]["with_sharpening_0.25"] = {"ms": ms, "finish_ms": pr.get("finish", (0, 0))[0] / 3,

@@ -161,10 +161,15 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       const float4 rc = in.rec;
       const float2 fo = in.flow;
       const bool upd = rc.x == rc.x;
+      // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403). When none of the wave's 4 pixels is
+      // updated at this step (the upper ~60 % of the pole flows, which the side cameras do not cover) the gathers
+      // and the evaluation are skipped; workgroups made of such rows run at the speed of the empty iteration.
+      const bool take = active && upd;
+      const bool any = run && __ballot(take) != 0ull;
       float2 up = make_float2(0.f, 0.f);
       float ax = 0.f, ay = 0.f, xR = 0.f, yR = 0.f;
       f4a8 ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
-      if (run) {
+      if (any) {
         // up neighbour in every lane (needed by the selection below)
         up.x = from_row_above<0xF>(upl.x, fl.x);
         up.y = from_row_above<0xF>(upl.y, fl.y);
@@ -203,6 +208,12 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
       }
       if (!run) continue;
+      if (!any) {
+        const float2 keep = active ? fo : fl;
+        fl = keep;
+        if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = keep;
+        continue;
+      }
       TS_WAITV();
       TS(3);
       Texels tt;
@@ -253,7 +264,6 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       res.x = f.x - c.gradStep * ggx;
       res.y = f.y - c.gradStep * ggy;
       // not-updated pixels keep their flow; inactive lanes keep the previous result
-      const bool take = active && upd;
       const float2 alt = active ? fo : fl;
       res.x = take ? res.x : alt.x;
       res.y = take ? res.y : alt.y;
@@ -418,10 +428,20 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         pub += n;
       }
     };
+    // The band above is needed only where the workgroup's first row is updated (pixels below the alpha threshold
+    // keep their flow): column c is waited for iff its record is not NaN-masked, and columns the first row passed
+    // without needing them are dropped. Workgroups whose first row is never updated — most of a pole flow — wait
+    // for nobody.
     int pendT = -100;
+    bool wantPoll = false;
     if (hasUpWg) {
-      ensure(min(w, 2), 26);
-      if (upFilled < w) issue();
+      const int y0 = dir > 0 ? rows0 : h - 1 - rows0;
+      const float4* __restrict__ rec0 = rec + (size_t)y0 * w;
+      const float m0 = rec0[col(0)].x, m1 = rec0[col(1)].x;  // (the LDS ring is not filled yet)
+      if (m0 == m0 || m1 == m1) {
+        ensure(min(w, 2), 26);
+        if (upFilled < w) issue();
+      }
     }
     for (int t = -1; t < T; ++t) {
       wg_barrier();
@@ -429,13 +449,25 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       // Order per iteration: take in the poll issued two iterations ago, publish, issue the next poll — so that
       // whatever the next wait covers is two steps old.
       if (hasUpWg && upFilled < w) {
-        const int need = min(w, t + 3);
-        if (pending && (t - pendT >= 2 || upFilled < need)) process(t + 31);
-        if (upFilled < need) ensure(need, t + 31);
+        const int c = t + 2;  // the column that becomes necessary now; its record has been in the ring for >= 13 steps
+        wantPoll = false;
+        if (c < w) {
+          const float m = s_in[0][c & (kRingK - 1)][0].rec.x;
+          wantPoll = m == m;
+        }
+        if (wantPoll) {
+          if (upFilled < c) {
+            upFilled = c;
+            pending = false;
+          }
+          const int need = c + 1;
+          if (pending && (t - pendT >= 2 || upFilled < need)) process(t + 31);
+          if (upFilled < need) ensure(need, t + 31);
+        }
       }
       // columns of the band's last row that are complete and visible: wave jl finished local step t-1-kLag*jl
       if (publishes) publish(t - 1 - kLag * jl - 3);
-      if (hasUpWg && upFilled < w && !pending) {
+      if (hasUpWg && upFilled < w && !pending && wantPoll) {
         issue();
         pendT = t;
       }

@@ -57,8 +57,14 @@ __device__ __forceinline__ float from_row_above_q(float old, float v) {
 // checked every kQNeed steps and the last row's granules are published every kQPub steps.
 constexpr int kQChunk = 16;
 constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
-constexpr int kQNeed = 4;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
-constexpr int kQPub = 4;   // the last row publishes its granules every kQPub steps
+#ifndef S360_QNEED
+#define S360_QNEED 4
+#endif
+#ifndef S360_QPUB
+#define S360_QPUB 4
+#endif
+constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
+constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every kQPub steps
 
 template <bool FAST>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ rec, const float2* __restrict__ G,
@@ -185,8 +191,16 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
     const int send = min(s0 + kQChunk, nsteps);
     for (int s = s0; s < send; ++s) {
-      if (hasUpBand && (s & (kQNeed - 1)) == 0 && s < w) {  // row 0 needs columns [s, s + kQNeed) of the band above
+      // Row 0 needs column s of the band above only if its pixel is updated at this step (pixels below the alpha
+      // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
+      // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
+      // of steps that did not need the band above (the columns passed meanwhile are dropped).
+      if (hasUpBand && s < w && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
         const int need = min(s + kQNeed, w), limit = s + kUpRing;
+        if (upFilled < s) {
+          upFilled = s;
+          pending = false;
+        }
         if (pending) process(limit);
         unsigned spins = 0;
         while (upFilled < need) {
@@ -204,9 +218,18 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       const float4 rc = nrc;
       const float2 fo = nfo;
       {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
-        const int xn = col(s + 1 - r);
-        nrc = recRow[xn];
-        nfo = flowRow[xn];
+        const int xn = S360_DBG(fc, 8) ? col(-r) : col(s + 1 - r);  // (dbg 8: timing experiment, inputs that always hit)
+        if (S360_DBG(fc, 16)) {  // (dbg 16: inputs as streaming loads that do not allocate in L1; results unchanged)
+          typedef float f4n __attribute__((ext_vector_type(4)));
+          typedef float f2n __attribute__((ext_vector_type(2)));
+          const f4n a = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(recRow) + xn);
+          const f2n bq = __builtin_nontemporal_load(reinterpret_cast<const f2n*>(flowRow) + xn);
+          nrc = make_float4(a.x, a.y, a.z, a.w);
+          nfo = make_float2(bq.x, bq.y);
+        } else {
+          nrc = recRow[xn];
+          nfo = flowRow[xn];
+        }
       }
       const float2 upl = s_up[s & (kUpRing - 1)];
       const int xi = s - r;
@@ -216,19 +239,24 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       float2 up;
       up.x = from_row_above_q(upl.x, fl.x);
       up.y = from_row_above_q(upl.y, fl.y);
-      float2 res;
-      if (FAST) {
-        bool tiny = false;
-        res = update(std::false_type{}, x, xi, rc, fo, fl, up, tiny);
-        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
-      } else {
-        bool tiny = false;
-        res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
-      }
+      // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
+      // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
+      // two gather rounds and the evaluations are skipped.
       const bool take = active && upd;
       const float2 alt = active ? fo : fl;
-      res.x = take ? res.x : alt.x;
-      res.y = take ? res.y : alt.y;
+      float2 res = alt;
+      if (__ballot(take) != 0ull) {
+        if (FAST) {
+          bool tiny = false;
+          res = update(std::false_type{}, x, xi, rc, fo, fl, up, tiny);
+          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
+        } else {
+          bool tiny = false;
+          res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
+        }
+        res.x = take ? res.x : alt.x;
+        res.y = take ? res.y : alt.y;
+      }
       fl = res;
       if (q == 0) s_res[r][xi & (kQResRing - 1)] = res;
       if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
@@ -271,11 +299,19 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
+  // Occupancy cap: a wave's working set (17 gradient rows + its record / flow lines) is ~8 KB, and with the 28 waves
+  // per CU the 66 VGPRs allow, the 32 KB L1 thrashes: capping a CU at ~15 waves through an otherwise unused dynamic
+  // LDS allocation measured +19 % on saturated side levels and neutral elsewhere (tools/mb_experiment.sh).
+  // S360_QUAD_DYNLDS (bytes) tunes it; the results do not depend on it.
+  static const size_t dyn = [] {
+    const char* e = std::getenv("S360_QUAD_DYNLDS");
+    return e ? (size_t)std::atoi(e) : (size_t)5632;
+  }();
   if (fast)
-    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(nb * B), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(nb * B), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
                        fc, nb, B, errflag);
   else
-    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(nb * B), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(nb * B), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
                        fc, nb, B, errflag);
 }
 

@@ -41,6 +41,12 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, in
     hflow[2 * i + 0] = hrec[4 * i + 2] + 0.3f * U(rng);
     hflow[2 * i + 1] = hrec[4 * i + 3] + 0.3f * U(rng);
   }
+  if (const char* e = getenv("S360_MB_MASKROWS")) {  // the first fraction of the rows is below the alpha threshold
+    const int rows = (int)(atof(e) * h);
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < w; ++x) hrec[4 * ((size_t)b * n + (size_t)y * w + x)] = __builtin_nanf("");
+  }
   float *dG, *drec, *dflow;
   void* hand;
   unsigned* err;
@@ -100,6 +106,12 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
     hrec[4 * i + 0] = 0.05f * U(rng); hrec[4 * i + 1] = 0.05f * U(rng);
     hrec[4 * i + 2] = 2.0f * U(rng); hrec[4 * i + 3] = 1.0f * U(rng);
     hflow[2 * i + 0] = hrec[4 * i + 2] + 0.3f * U(rng); hflow[2 * i + 1] = hrec[4 * i + 3] + 0.3f * U(rng);
+  }
+  if (const char* e = getenv("S360_MB_MASKROWS")) {  // the first fraction of the rows is below the alpha threshold (like the pole flows)
+    const int rows = (int)(atof(e) * h);
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < w; ++x) hrec[4 * ((size_t)b * n + (size_t)y * w + x)] = __builtin_nanf("");
   }
   std::vector<float*> dG(NS), drec(NS), dflow(NS), dA(NS), dbl(NS);
   std::vector<void*> hand(NS);
