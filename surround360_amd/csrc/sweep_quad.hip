@@ -21,6 +21,7 @@
 // Measured (tools/sweep_microbench tp1, 32 pole-level flows x 2 streams): 20.5 Gpx/s against 13.8 for the previous
 // per-step control flow; a single flow still runs ~1.25x slower than with sweep_lock.hip. FlowEngine picks this
 // kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -66,27 +67,31 @@ constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
 constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
 constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every kQPub steps
 
+// Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
+// The sweeps of one launch then hold a bounded share of every CU — a wave's working set is ~8 KB (17 gradient rows +
+// its record / flow lines) and beyond ~15 waves per CU the 32 KB L1 thrashes — and the kernels of another context
+// find free wave slots, registers and LDS next to them.
 template <bool FAST>
-__global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ rec, const float2* __restrict__ G,
-                                                   float2* __restrict__ flow, unsigned long long* __restrict__ H,
+__global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
+                                                   float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
                                                    unsigned* __restrict__ errflag) {
   __shared__ float2 s_up[kUpRing];
   __shared__ float2 s_res[kQRows][kQResRing];
-  __shared__ unsigned s_ticket;
   const int lane = threadIdx.x;
-  if (lane == 0) s_ticket = atomicAdd(hdr, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
-  __syncthreads();
-  const unsigned tk = s_ticket;
+  for (;;) {
+  unsigned tk = 0;
+  if (lane == 0) tk = atomicAdd(hdr, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
+  tk = __builtin_amdgcn_readfirstlane(tk);
   const int band = (int)(tk / (unsigned)B), b = (int)(tk - (unsigned)band * (unsigned)B);
   if (band >= nb) return;
   const float2* __restrict__ G1 = G + bs * idx.i1[b];
   const char* __restrict__ G1b0 = reinterpret_cast<const char*>(G1);
   const char* __restrict__ G1b1 = reinterpret_cast<const char*>(G1 + w);
-  rec += bs * b;
-  flow += bs * b;
-  H += (size_t)b * nb * w;
+  const float4* __restrict__ rec = recAll + bs * b;
+  float2* __restrict__ flow = flowAll + bs * b;
+  unsigned long long* __restrict__ H = HAll + (size_t)b * nb * w;
   const unsigned long long* Hin = H + (size_t)band * w;
   unsigned long long* Hout = H + (size_t)(band + 1) * w;
   const int r = lane >> 2, q = lane & 3;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       }
     }
   }
+  }  // next ticket
 }
 
 // ==========================================================================================
@@ -299,19 +305,27 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  // Occupancy cap: a wave's working set (17 gradient rows + its record / flow lines) is ~8 KB, and with the 28 waves
-  // per CU the 66 VGPRs allow, the 32 KB L1 thrashes: capping a CU at ~15 waves through an otherwise unused dynamic
-  // LDS allocation measured +19 % on saturated side levels and neutral elsewhere (tools/mb_experiment.sh).
-  // S360_QUAD_DYNLDS (bytes) tunes it; the results do not depend on it.
-  static const size_t dyn = [] {
+  static const size_t dyn = [] {  // S360_QUAD_DYNLDS: extra LDS per wave (experiments with the residency of other kernels)
     const char* e = std::getenv("S360_QUAD_DYNLDS");
-    return e ? (size_t)std::atoi(e) : (size_t)5632;
+    return e ? (size_t)std::atoi(e) : (size_t)0;
   }();
+  // S360_QUAD_WAVES_PER_CU: persistent waves per CU of one launch (tuning only; the results do not depend on it)
+  static const int perCu = [] {
+    const char* e = std::getenv("S360_QUAD_WAVES_PER_CU");
+    const int v = e ? std::atoi(e) : 10;
+    return v > 0 ? v : 10;
+  }();
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int grid = std::min(nb * B, cus * perCu);
   if (fast)
-    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(nb * B), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
                        fc, nb, B, errflag);
   else
-    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(nb * B), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
+    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
                        fc, nb, B, errflag);
 }
 
