@@ -207,6 +207,10 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         nin = s_in[j][s1 & (kRingK - 1)][rr];
         nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
       }
+#ifdef S360_SWEEP_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TS(6);
+#endif
       if (!run) continue;
       if (!any) {
         const float2 keep = active ? fo : fl;
@@ -318,49 +322,63 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       const int xi = sidx - rr;
       if (rowOk[j] && xi >= 0 && xi < w && sidx < nsteps) flow[rowOff[j] + col(xi)] = s_out[j][sidx & (kRingK - 1)][rr];
     };
-    // event of wave j when it enters chunk cc: chunk cc-1 is complete and its ring slots are free
-    auto event = [&](int j, int cc) {
-      sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // previous prefetch round (long since landed)
-      int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    // The service work of compute wave j entering chunk cc (chunk cc-1 is complete and its ring slots are free) is
+    // spread over four consecutive steps, so that no step's share outlasts the compute waves' own step: this wave
+    // shares a SIMD with a compute wave at lower priority, and the whole workgroup waits for it at every barrier
+    // (one 150-instruction event per chunk cost ~0.9 us on the steps it fell on, ~15 % of the sweep).
+    //   phase 0: chunk cc+1 (in registers since the previous event) -> LDS ring, and where its pixels will sample
+    //            I1's gradients (predicted by the blurred flow and by the current flow)
+    //   phase 1: chunk cc+2 -> registers            phase 2: results of chunk cc-1 -> global memory
+    //   phase 3: touch the predicted gradient lines, so that the compute waves' gathers find them in L1
+    int po[NW][4];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) po[j][0] = po[j][1] = po[j][2] = po[j][3] = 0;
+    auto phase = [&](int j, int cc, int ph) {
       if (S360_DBG(fc, 8)) return;
       const bool wr = cc + 1 < nchunks;
-      if (wr) {
-        // Where the pixels of chunk cc+1 will sample I1's gradients, predicted by the blurred flow and by the
-        // current flow: touching those lines now makes the compute waves' gathers L1 hits.
-        const float xf = (float)col((cc + 1) * kChunk + st - rr);
-        const Foot fa = footprint(w, xf + rRec[j].z, rowY[j] + rRec[j].w, c);
-        const Foot fb = footprint(w, xf + rFlow[j].x, rowY[j] + rFlow[j].y, c);
-        o0 = 2 * fa.off; o1 = 2 * (fa.off + w); o2 = 2 * fb.off; o3 = 2 * (fb.off + w);
-        write_chunk(j, cc + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (cc + 2 < nchunks) load_chunk(j, cc + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (cc >= 1) flush_chunk(j, cc - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (wr && !S360_DBG(fc, 4)) {
-        pf0 = G1w[o0]; pf1 = G1w[o1]; pf2 = G1w[o2]; pf3 = G1w[o3];
+      if (ph == 0) {
+        if (wr) {
+          const float xf = (float)col((cc + 1) * kChunk + st - rr);
+          const Foot fa = footprint(w, xf + rRec[j].z, rowY[j] + rRec[j].w, c);
+          const Foot fb = footprint(w, xf + rFlow[j].x, rowY[j] + rFlow[j].y, c);
+          po[j][0] = 2 * fa.off; po[j][1] = 2 * (fa.off + w); po[j][2] = 2 * fb.off; po[j][3] = 2 * (fb.off + w);
+          write_chunk(j, cc + 1);
+        }
+      } else if (ph == 1) {
+        if (cc + 2 < nchunks) load_chunk(j, cc + 2);
+      } else if (ph == 2) {
+        if (cc >= 1) flush_chunk(j, cc - 1);
+      } else {
+        sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // previous round (long since landed)
+        if (wr && !S360_DBG(fc, 4)) {
+          pf0 = G1w[po[j][0]]; pf1 = G1w[po[j][1]]; pf2 = G1w[po[j][2]]; pf3 = G1w[po[j][3]];
+        }
       }
     };
     // prologue: chunk 0 into LDS, chunk 1 into registers
 #pragma unroll
     for (int j = 0; j < NW; ++j) load_chunk(j, 0);
 #pragma unroll
-    for (int j = 0; j < NW; ++j) event(j, -1);
+    for (int j = 0; j < NW; ++j) {
+      phase(j, -1, 0);
+      phase(j, -1, 1);
+      phase(j, -1, 3);
+    }
     for (int t = -1; t < T; ++t) {
       wg_barrier();
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int s = t - kLag * j;
-        if (s >= 1 && (s & (kChunk - 1)) == 1) event(j, s >> 4);
+        const int ph = (s - 1) & (kChunk - 1);
+        if (s >= 1 && ph < 4) phase(j, (s - 1) >> 4, ph);
       }
     }
     wg_barrier();
-    // epilogue: the chunks the loop did not reach
+    // epilogue: the chunks the loop did not reach (chunk cc-1 is flushed at local step 16 cc + 3)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int sl = T - 1 - kLag * j;
-      const int done = sl >= 1 ? ((sl - 1) >> 4) : 0;  // chunks [0, done) were flushed in the loop
+      const int done = sl >= 3 ? ((sl - 3) >> 4) : 0;  // chunks [0, done) were flushed in the loop
       for (int cidx = done; cidx < nchunks; ++cidx) flush_chunk(j, cidx);
     }
     sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;

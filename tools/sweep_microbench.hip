@@ -212,6 +212,18 @@ int main(int argc, char** argv) {
     printf("mode %d %dx%d B=%d streams=%d: %.2f Gpx/s\n", md, w, h, B, ns, throughput(w, h, B, md, ns, 4));
     return 0;
   }
+  if (argc > 4 && std::string(argv[1]) == "ts") {  // sweep_microbench_ts only: cycle phases of compute wave 0 of ticket 0 (lock kernel)
+    const int w = atoi(argv[2]), h = atoi(argv[3]), B = atoi(argv[4]);
+    const float us = run(w, h, B, true, 2, 1);
+    const char* names[7] = {"loop top", "candidates + addresses + gather issue", "barrier", "gather wait (after the LDS preload)", "errorFunction", "selection + gradient step + LDS store", "LDS preload of the next step"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 7; ++i) tot += g_ts[i];
+    printf("lock %dx%d B=%d: %.1f us per launch; s_memtime ticks of wave 0 / ticket 0 over %d steps (last launch)\n", w, h, B, us, w + 3);
+    for (int i = 0; i < 7; ++i) printf("  %-40s %10llu ticks  %5.1f %%  %.1f per step\n", names[i], g_ts[i], 100.0 * g_ts[i] / (double)tot, g_ts[i] / (double)(w + 3));
+    printf("  total %llu ticks = %.1f per step\n", tot, tot / (double)(w + 3));
+    printf("  bulk service wave: %llu ticks inside events = %.1f per event (4 events per 16 steps)\n", g_ts[7], g_ts[7] / ((w + 3) / 4.0));
+    return 0;
+  }
   if (argc > 1 && std::string(argv[1]) == "tp") {
     printf("saturated sweep throughput, Gpx/s (one px = one pixel update of one sweep)\n");
     struct C2 { int w, h, B; const char* name; };
