@@ -166,9 +166,10 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       // and the evaluation are skipped; workgroups made of such rows run at the speed of the empty iteration.
       const bool take = active && upd;
       const bool any = run && __ballot(take) != 0ull;
-      float2 up = make_float2(0.f, 0.f);
-      float ax = 0.f, ay = 0.f, xR = 0.f, yR = 0.f;
-      f4a8 ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+      // (deliberately not initialised: set and read only on the `any` path; zero-filling them cost 14 moves per step)
+      float2 up;
+      float ax, ay, xR, yR;
+      f4a8 ta, tb;
       if (any) {
         // up neighbour in every lane (needed by the selection below)
         up.x = from_row_above<0xF>(upl.x, fl.x);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   tk = __builtin_amdgcn_readfirstlane(tk);
   const int band = (int)(tk / (unsigned)B), b = (int)(tk - (unsigned)band * (unsigned)B);
   if (band >= nb) return;
-  const float2* __restrict__ G1 = G + bs * idx.i1[b];
+  const float2* __restrict__ G1 = G + bs * (size_t)__builtin_amdgcn_readfirstlane(idx.i1[b]);  // (wave-uniform: keeps the base in SGPRs)
   const char* __restrict__ G1b0 = reinterpret_cast<const char*>(G1);
   const char* __restrict__ G1b1 = reinterpret_cast<const char*>(G1 + w);
   const float4* __restrict__ rec = recAll + bs * b;
@@ -209,7 +209,10 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
         if (pending) process(limit);
         unsigned spins = 0;
         while (upFilled < need) {
-          if (spins) __builtin_amdgcn_s_sleep(2);
+          if (spins) {  // back off: a band waiting for its predecessor should leave the issue slots and the L2 to it
+            if (spins < 4) __builtin_amdgcn_s_sleep(8);
+            else __builtin_amdgcn_s_sleep(48);
+          }
           issue();
           process(limit);
           if (++spins > (1u << 20) ||
