@@ -142,8 +142,10 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
                                       : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, 4);
     return (b + 255) & ~(size_t)255;
   };
+  // + per level one word per (flow, row): all-ones = no pixel of the row is updated (written by the record kernel)
+  auto rowflag_bytes = [&](int l) { return ((size_t)B * lv_.h[l] * sizeof(unsigned) + 255) & ~(size_t)255; };
   std::vector<size_t> hoff(L + 1, 0);
-  for (int l = 0; l < L; ++l) hoff[l + 1] = hoff[l] + 2 * handoff_bytes(l);
+  for (int l = 0; l < L; ++l) hoff[l + 1] = hoff[l] + 2 * handoff_bytes(l) + rowflag_bytes(l);
   handoff_.ensure(hoff[L]);
   S360_HIP(hipMemsetAsync(handoff_.p, 0xFF, hoff[L], st));
   if (!err_.p) {
@@ -219,14 +221,15 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     {
       ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweep records
-      launch_blur_to_records(st, cur, rec_.as<float4>(), wl, hl, nl, B, tFlow, G_.as<float2>(), LA(l), idx);
+      launch_blur_to_records(st, cur, rec_.as<float4>(), wl, hl, nl, B, tFlow, G_.as<float2>(), LA(l), idx,
+                             reinterpret_cast<unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
     }
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
       if (sweep_mode_ == 3)
         launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
-                          fastOk);
+                          fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
       else
         launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk);

@@ -41,7 +41,8 @@ void launch_upscale_blur(hipStream_t st, const float2* src, int sw, int sh, size
                          size_t dbs, int B, float post_scale, const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t);
 void launch_blur_to_records(hipStream_t st, const float2* flow, float4* rec, int w, int h, size_t bs, int B,
-                            const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx);
+                            const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx,
+                            unsigned* rowflags = nullptr);
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale);
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
@@ -62,7 +63,7 @@ bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& divisors);
 size_t sweep_quad_handoff_bytes(int w, int h, int B);
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, bool fast);
+                       const PixFlowConsts& pc, bool fast, const unsigned* rowflags = nullptr);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

@@ -1,0 +1,146 @@
+// median.hip — medianBlur(flow, 5) of PixFlow (PixFlow.h:398,411) for gfx950.
+//
+// Its own translation unit because it is built with -ffinite-math-only: flows never hold NaNs, and without that
+// promise every fminf / fmaxf input loaded from memory is first canonicalised (v_max_f32 x, x, x) — 120 extra
+// instructions per 16 medians (9 % of the kernel). Nothing else in this file does floating-point arithmetic; the
+// result of a min / max of non-NaN values is the same instruction's result either way.
+#include "flow_kernels.hpp"
+
+#include "devmath.hpp"
+
+namespace s360 {
+
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+
+static inline dim3 grid2d(int w, int h, int B, dim3 blk) { return dim3((w + blk.x - 1) / blk.x, (h + blk.y - 1) / blk.y, B); }
+
+// ------------------------------------------------------------------------------------------
+// medianBlur(5) on CV_32FC2, replicate border (PixFlow.h:398,411): exact per-channel median of 25.
+__device__ __forceinline__ void mnmx(float& a, float& b) {
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+// Sort of three: v_min3 / v_med3 / v_max3 — three instructions where three compare-exchanges take six.
+__device__ __forceinline__ void sort3(float& a, float& b, float& c) {
+  const float lo = fminf(fminf(a, b), c), hi = fmaxf(fmaxf(a, b), c), md = __builtin_amdgcn_fmed3f(a, b, c);
+  a = lo;
+  b = md;
+  c = hi;
+}
+// Exact median of 25 with the 99-comparator selection network of Devillard's "Fast median search" (after Paeth,
+// Graphics Gems): verified for all 2^25 0/1 inputs (0-1 principle), tools/verify_median_network.py. 66 of its
+// comparators form 22 runs of three that sort three wires; those are S360_S3 (same function, half the instructions).
+// Comparators whose outputs are never read again are removed by the compiler.
+__device__ __forceinline__ float median25(const float* in) {
+  float p[25];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) p[i] = in[i];
+#define S360_CE(a, b) mnmx(p[a], p[b])
+#define S360_S3(a, b, c) sort3(p[a], p[b], p[c])
+  S360_CE(0, 1); S360_S3(2, 3, 4); S360_S3(5, 6, 7); S360_S3(8, 9, 10); S360_S3(11, 12, 13); S360_S3(14, 15, 16);
+  S360_S3(17, 18, 19); S360_S3(20, 21, 22); S360_CE(23, 24); S360_CE(2, 5); S360_S3(0, 3, 6); S360_S3(1, 4, 7);
+  S360_S3(8, 11, 14); S360_S3(9, 12, 15); S360_S3(10, 13, 16); S360_S3(17, 20, 23); S360_S3(18, 21, 24);
+  S360_CE(19, 22); S360_CE(8, 17); S360_S3(0, 9, 18); S360_S3(1, 10, 19); S360_S3(2, 11, 20); S360_S3(3, 12, 21);
+  S360_S3(4, 13, 22); S360_S3(5, 14, 23); S360_S3(6, 15, 24); S360_CE(7, 16); S360_CE(7, 19); S360_CE(13, 21);
+  S360_CE(15, 23); S360_CE(7, 13); S360_CE(7, 15); S360_CE(1, 9); S360_CE(3, 11); S360_CE(5, 17); S360_CE(11, 17);
+  S360_CE(9, 17); S360_CE(4, 10); S360_CE(6, 12); S360_CE(7, 14); S360_CE(4, 6); S360_CE(4, 7); S360_CE(12, 14);
+  S360_CE(10, 14); S360_CE(6, 7); S360_CE(10, 12); S360_CE(6, 10); S360_CE(6, 17); S360_CE(12, 17); S360_CE(7, 17);
+  S360_CE(7, 10); S360_CE(12, 18); S360_CE(7, 12); S360_CE(10, 18); S360_S3(10, 12, 20);
+#undef S360_CE
+#undef S360_S3
+  return p[12];
+}
+__global__ __launch_bounds__(256) void k_median5_c2(const float2* __restrict__ src, float2* __restrict__ dst, int w,
+                                                    int h, size_t bs) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  src += bs * blockIdx.z;
+  dst += bs * blockIdx.z;
+  float vx[25], vy[25];
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const float2* r = src + (size_t)clip_idx(y + dy, h) * w;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const float2 p = r[clip_idx(x + dx, w)];
+      vx[(dy + 2) * 5 + dx + 2] = p.x;
+      vy[(dy + 2) * 5 + dx + 2] = p.y;
+    }
+  }
+  float2 o;
+  o.x = median25(vx);
+  o.y = median25(vy);
+  dst[(size_t)y * w + x] = o;
+}
+
+// The same medians for 8 horizontally adjacent pixels per thread from 12 shared columns: every column of 5 is sorted
+// once and used by 5 windows, aligned column pairs are merged once and used by 4, and the 6 median candidates of two
+// adjacent pairs are selected once and used by 2 — 79 min/max operations per median instead of 112 and 60 eight-byte
+// loads per 8 pixels instead of 200. The networks are generated and verified by tools/gen_median_network.py.
+#include "median_tile.inc"
+constexpr int MED_T = 8;                      // outputs per thread
+constexpr int MED_BX = 32, MED_BY = 8;        // threads per block: a block produces (32 * 8) x 8 pixels
+constexpr int MED_LW = MED_BX * MED_T + 4, MED_LH = MED_BY + 4;
+// The tile (with its 2-pixel replicate border) goes through LDS once, split into its two channels: a thread then reads
+// the 60 values of ONE channel at a time (three 16-byte LDS reads per window row), which keeps the generated network
+// at ~100 registers instead of the ~190 it needs with both channels' inputs live.
+__global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restrict__ src, float2* __restrict__ dst, int w,
+                                                         int h, size_t bs) {
+  __shared__ __attribute__((aligned(16))) float s_p[2][MED_LH][MED_LW];
+  const int tid = threadIdx.x;
+  const int X0 = blockIdx.x * (MED_BX * MED_T), Y0 = blockIdx.y * MED_BY;
+  src += bs * blockIdx.z;
+  dst += bs * blockIdx.z;
+  for (int i = tid; i < MED_LH * MED_LW; i += 256) {
+    const int ly = i / MED_LW, lx = i - ly * MED_LW;
+    const float2 p = src[(size_t)clip_idx(Y0 - 2 + ly, h) * w + clip_idx(X0 - 2 + lx, w)];
+    s_p[0][ly][lx] = p.x;
+    s_p[1][ly][lx] = p.y;
+  }
+  __syncthreads();
+  const int tx = tid & (MED_BX - 1), ty = tid >> 5;
+  const int x0 = X0 + tx * MED_T, y = Y0 + ty;
+  if (x0 >= w || y >= h) return;
+  float o[2][MED_T];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    float in[(MED_T + 4) * 5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const float4* row = reinterpret_cast<const float4*>(&s_p[ch][ty + r][tx * MED_T]);  // 32-byte aligned
+#pragma unroll
+      for (int q = 0; q < (MED_T + 4) / 4; ++q) {
+        const float4 v = row[q];
+        in[(4 * q) * 5 + r] = v.x;
+        in[(4 * q + 1) * 5 + r] = v.y;
+        in[(4 * q + 2) * 5 + r] = v.z;
+        in[(4 * q + 3) * 5 + r] = v.w;
+      }
+    }
+    median5x5_row8(in, o[ch]);
+  }
+  float2* out = dst + (size_t)y * w + x0;
+  if (x0 + MED_T <= w) {
+#pragma unroll
+    for (int k = 0; k < MED_T; k += 2) {
+      f4a8 q = {o[0][k], o[1][k], o[0][k + 1], o[1][k + 1]};
+      *reinterpret_cast<f4a8*>(out + k) = q;
+    }
+  } else {
+    for (int k = 0; k < MED_T && x0 + k < w; ++k) out[k] = make_float2(o[0][k], o[1][k]);
+  }
+}
+
+void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B) {
+  dim3 blk(64, 4);
+  if (w >= 64) {  // 8 pixels per thread; narrow levels keep one pixel per thread (more threads than the chip otherwise idles)
+    dim3 grd((w + MED_BX * MED_T - 1) / (MED_BX * MED_T), (h + MED_BY - 1) / MED_BY, B);
+    hipLaunchKernelGGL(k_median5_c2_row8, grd, dim3(256), 0, st, src, dst, w, h, bs);
+    return;
+  }
+  hipLaunchKernelGGL(k_median5_c2, grid2d(w, h, B, blk), blk, 0, st, src, dst, w, h, bs);
+}
+
+}  // namespace s360

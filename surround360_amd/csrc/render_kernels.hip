@@ -578,20 +578,34 @@ __global__ __launch_bounds__(256) void k_erode_cross_fixed(const uchar4* __restr
   __shared__ unsigned char s_o[ERF_TH][ERF_TW];   // horizontal-arm result
   const int x0 = blockIdx.x * ERF_TW, y0 = blockIdx.y * ERF_TH;
   const int tid = threadIdx.x;
+  const unsigned ref = img[(size_t)y0 * w + x0].w;  // uniform tiles (alpha 0 or 255 almost everywhere) leave after the load
+  bool same = true;
   for (int t = tid; t < (ERF_TH / 2) * HW; t += 256) {
     const int j = t / HW, lx = t - j * HW;
     const int gx = x0 - E + lx, gy = y0 + 2 * j;
     const bool cx = gx >= 0 && gx < w;
     const unsigned a0 = (cx && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
     const unsigned a1 = (cx && gy + 1 < h) ? img[(size_t)(gy + 1) * w + gx].w : 255u;
+    same = same && a0 == ref && a1 == ref;
     s_h[j][lx] = a0 | (a1 << 16);
   }
   for (int t = tid; t < VH * ERF_TW; t += 256) {
     const int ly = t >> 7, lx = t & (ERF_TW - 1);
     const int gx = x0 + lx, gy = y0 - E + ly;
-    s_v[ly][lx] = (gx < w && gy >= 0 && gy < h) ? img[(size_t)gy * w + gx].w : 255;
+    const unsigned v = (gx < w && gy >= 0 && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
+    same = same && v == ref;
+    s_v[ly][lx] = (unsigned char)v;
   }
-  __syncthreads();
+  if (__syncthreads_and(same)) {  // the minimum over any window of a constant tile (out-of-image = 255 included) is the constant
+    const int ly = tid >> 2, gy = y0 + ly, gx0 = x0 + (tid & 3) * 32;
+    if (gy < h)
+      for (int i = 0; i < 32; i += 2) {
+        const int gx = gx0 + i;
+        if (gx + 1 < w) *reinterpret_cast<unsigned short*>(out + (size_t)gy * w + gx) = (unsigned short)(ref | (ref << 8));
+        else if (gx < w) out[(size_t)gy * w + gx] = (uint8_t)ref;
+      }
+    return;
+  }
   us2 a[NIN];
   if (tid < 128) {  // horizontal arm: row pair j, strip k of 32 columns
     const int j = tid >> 2, k = tid & 3;
@@ -726,11 +740,25 @@ __global__ __launch_bounds__(256) void k_gauss_u8_fixed(const uint8_t* __restric
 #pragma unroll
   for (int j = 0; j < NT; ++j) ksum += k[j];
   const bool exact = ksum <= 256;
+  // Constant tiles (alpha 0 or 255 almost everywhere) leave after the load: every window sums to ksum^2 * v, which both
+  // roundings of the column pass return as v when the taps sum to 256, and as 0 for v = 0 whatever the taps.
+  const int ref = a[(size_t)y0 * w + x0];
+  bool same = ref == 0 || ksum == 256;
   for (int ly = ty; ly < IH; ly += 4) {
     const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
-    for (int lx = tx; lx < IW; lx += GU_TW) s_a[ly][lx] = row[reflect101(x0 - R + lx, w)];
+    for (int lx = tx; lx < IW; lx += GU_TW) {
+      const int v = row[reflect101(x0 - R + lx, w)];
+      same = same && v == ref;
+      s_a[ly][lx] = v;
+    }
   }
-  __syncthreads();
+  if (__syncthreads_and(same)) {
+    const int ly = threadIdx.x >> 3, gy = y0 + ly, gx0 = x0 + (threadIdx.x & 7) * 8;
+    if (gy < h)
+      for (int i = 0; i < 8; ++i)
+        if (gx0 + i < w) out[(size_t)gy * w + gx0 + i] = (uint8_t)ref;
+    return;
+  }
   // row pass: task = (row, group of 4 consecutive x)
   for (int t = threadIdx.x; t < IH * (GU_TW / 4); t += 256) {
     const int g = t / IH, ly = t - g * IH, lx0 = g * 4;

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
-                                                   unsigned* __restrict__ errflag) {
+                                                   unsigned* __restrict__ errflag,
+                                                   const unsigned* __restrict__ rowflags) {
   __shared__ float2 s_up[kUpRing];
   __shared__ float2 s_res[kQRows][kQResRing];
   const int lane = threadIdx.x;
@@ -94,6 +95,28 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   unsigned long long* __restrict__ H = HAll + (size_t)b * nb * w;
   const unsigned long long* Hin = H + (size_t)band * w;
   unsigned long long* Hout = H + (size_t)(band + 1) * w;
+  if (rowflags) {
+    // A band none of whose rows has an updated pixel (the record kernel leaves the row's word all-ones) changes
+    // nothing: it hands its last row's flow to the band below as it is and takes the next ticket. Most bands of a
+    // pole flow are like that.
+    bool real = false;
+    if (lane < kQRows) {
+      const int yiL = band * kQRows + lane;
+      if (yiL < h) real = rowflags[(size_t)b * h + (dir > 0 ? yiL : h - 1 - yiL)] == 0u;
+    }
+    if (__ballot(real) == 0ull) {
+      if (band + 1 < nb) {  // (then all 16 rows exist)
+        const int yl = band * kQRows + kQRows - 1;
+        const float2* __restrict__ last = flow + (size_t)(dir > 0 ? yl : h - 1 - yl) * w;
+        for (int xi = lane; xi < w; xi += 64) {
+          const float2 v = last[dir > 0 ? xi : w - 1 - xi];
+          __hip_atomic_store(Hout + xi, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      continue;
+    }
+  }
   const int r = lane >> 2, q = lane & 3;
   const int yi = band * kQRows + r;
   const bool rowValid = yi < h;
@@ -296,7 +319,7 @@ size_t sweep_quad_handoff_bytes(int w, int h, int B) {
 }
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, bool fast) {
+                       const PixFlowConsts& pc, bool fast, const unsigned* rowflags) {
   const SweepConst c = make_sweep_const(pc, w, h);
   SweepFast fc;
   fc.rcCols = 1.0f / c.fcols;
@@ -326,10 +349,10 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   const int grid = std::min(nb * B, cus * perCu);
   if (fast)
     hipLaunchKernelGGL((k_sweep_quad<true>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
-                       fc, nb, B, errflag);
+                       fc, nb, B, errflag, rowflags);
   else
     hipLaunchKernelGGL((k_sweep_quad<false>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
-                       fc, nb, B, errflag);
+                       fc, nb, B, errflag, rowflags);
 }
 
 }  // namespace s360
