@@ -150,9 +150,16 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
   src += (SRC == 2 ? up.sbs * CN : bs * (SRC == 1 ? 1 : CN)) * blockIdx.z;
-  for (int i = tid; i < IH * IW; i += NT) {
-    const int ly = i / IW, lx = i - ly * IW;
-    const int gy = reflect101(ty0 - R + ly, h), gx = reflect101(tx0 - R + lx, w);
+  // tile load: when the thread count is a multiple of the (padded) tile width a thread keeps its column and walks
+  // down the rows — no division, one reflected column index per thread
+  constexpr int LW = (IW + 7) & ~7;
+  constexpr bool kColumnWalk = (NT % LW) == 0;
+  const int lxc = tid % LW, lyc = tid / LW;
+  const int gxc = reflect101(tx0 - R + (lxc < IW ? lxc : 0), w);
+  for (int i = kColumnWalk ? lyc : tid; i < (kColumnWalk ? IH : IH * IW); i += (kColumnWalk ? NT / LW : NT)) {
+    if (kColumnWalk && lxc >= IW) break;
+    const int ly = kColumnWalk ? i : i / IW, lx = kColumnWalk ? lxc : i - ly * IW;
+    const int gy = reflect101(ty0 - R + ly, h), gx = kColumnWalk ? gxc : reflect101(tx0 - R + lx, w);
     if (SRC == 2) {  // k_resize_linear_f32's arithmetic at (gx, gy), then the scalar multiply
       int sx, sy;
       float fx, fy;

@@ -580,21 +580,57 @@ __global__ __launch_bounds__(256) void k_erode_cross_fixed(const uchar4* __restr
   const int tid = threadIdx.x;
   const unsigned ref = img[(size_t)y0 * w + x0].w;  // uniform tiles (alpha 0 or 255 almost everywhere) leave after the load
   bool same = true;
-  for (int t = tid; t < (ERF_TH / 2) * HW; t += 256) {
-    const int j = t / HW, lx = t - j * HW;
-    const int gx = x0 - E + lx, gy = y0 + 2 * j;
-    const bool cx = gx >= 0 && gx < w;
-    const unsigned a0 = (cx && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
-    const unsigned a1 = (cx && gy + 1 < h) ? img[(size_t)(gy + 1) * w + gx].w : 255u;
-    same = same && a0 == ref && a1 == ref;
-    s_h[j][lx] = a0 | (a1 << 16);
-  }
-  for (int t = tid; t < VH * ERF_TW; t += 256) {
-    const int ly = t >> 7, lx = t & (ERF_TW - 1);
-    const int gx = x0 + lx, gy = y0 - E + ly;
-    const unsigned v = (gx < w && gy >= 0 && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
-    same = same && v == ref;
-    s_v[ly][lx] = (unsigned char)v;
+  if ((w & 3) == 0 && (E & 3) == 3) {
+    // Four pixels per load (16 bytes; x0 and w are multiples of 4, so a group is entirely inside or outside the image).
+    // The horizontal tile starts one column early (x0 - E - 1) to keep the groups aligned: s_h index = lx + 1 below.
+    const uint4* __restrict__ img4 = reinterpret_cast<const uint4*>(img);
+    constexpr int GH = (HW + 1 + 3) / 4;  // groups per row pair: columns [x0 - E - 1, x0 - E - 1 + 4 GH)
+    static_assert(4 * GH <= HWP + 4, "s_h row too short");
+    for (int t = tid; t < (ERF_TH / 2) * GH; t += 256) {
+      const int j = t / GH, g = t - j * GH;
+      const int gx = x0 - E - 1 + 4 * g, gy = y0 + 2 * j;
+      uint4 p0 = make_uint4(~0u, ~0u, ~0u, ~0u), p1 = p0;
+      if (gx >= 0 && gx < w) {
+        if (gy < h) p0 = img4[((size_t)gy * w + gx) >> 2];
+        if (gy + 1 < h) p1 = img4[((size_t)(gy + 1) * w + gx) >> 2];
+      }
+      const unsigned a0[4] = {p0.x >> 24, p0.y >> 24, p0.z >> 24, p0.w >> 24};
+      const unsigned a1[4] = {p1.x >> 24, p1.y >> 24, p1.z >> 24, p1.w >> 24};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lx = 4 * g + k - 1;  // index in the tile that starts at x0 - E
+        if (lx >= 0 && lx < HW) {
+          same = same && a0[k] == ref && a1[k] == ref;
+          s_h[j][lx] = a0[k] | (a1[k] << 16);
+        }
+      }
+    }
+    for (int t = tid; t < VH * (ERF_TW / 4); t += 256) {
+      const int ly = t / (ERF_TW / 4), g = t - ly * (ERF_TW / 4);
+      const int gx = x0 + 4 * g, gy = y0 - E + ly;
+      uint4 p = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (gx < w && gy >= 0 && gy < h) p = img4[((size_t)gy * w + gx) >> 2];
+      const unsigned v = (p.x >> 24) | ((p.y >> 24) << 8) | ((p.z >> 24) << 16) | (p.w & 0xff000000u);
+      same = same && v == ref * 0x01010101u;
+      *reinterpret_cast<unsigned*>(&s_v[ly][4 * g]) = v;
+    }
+  } else {
+    for (int t = tid; t < (ERF_TH / 2) * HW; t += 256) {
+      const int j = t / HW, lx = t - j * HW;
+      const int gx = x0 - E + lx, gy = y0 + 2 * j;
+      const bool cx = gx >= 0 && gx < w;
+      const unsigned a0 = (cx && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
+      const unsigned a1 = (cx && gy + 1 < h) ? img[(size_t)(gy + 1) * w + gx].w : 255u;
+      same = same && a0 == ref && a1 == ref;
+      s_h[j][lx] = a0 | (a1 << 16);
+    }
+    for (int t = tid; t < VH * ERF_TW; t += 256) {
+      const int ly = t >> 7, lx = t & (ERF_TW - 1);
+      const int gx = x0 + lx, gy = y0 - E + ly;
+      const unsigned v = (gx < w && gy >= 0 && gy < h) ? img[(size_t)gy * w + gx].w : 255u;
+      same = same && v == ref;
+      s_v[ly][lx] = (unsigned char)v;
+    }
   }
   if (__syncthreads_and(same)) {  // the minimum over any window of a constant tile (out-of-image = 255 included) is the constant
     const int ly = tid >> 2, gy = y0 + ly, gx0 = x0 + (tid & 3) * 32;
@@ -744,12 +780,38 @@ __global__ __launch_bounds__(256) void k_gauss_u8_fixed(const uint8_t* __restric
   // roundings of the column pass return as v when the taps sum to 256, and as 0 for v = 0 whatever the taps.
   const int ref = a[(size_t)y0 * w + x0];
   bool same = ref == 0 || ksum == 256;
-  for (int ly = ty; ly < IH; ly += 4) {
-    const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
-    for (int lx = tx; lx < IW; lx += GU_TW) {
-      const int v = row[reflect101(x0 - R + lx, w)];
-      same = same && v == ref;
-      s_a[ly][lx] = v;
+  if ((w & 3) == 0 && (R & 3) == 3) {
+    // four bytes per load: groups start at x0 - R - 1 (a multiple of 4) and lie entirely inside or outside the row
+    constexpr int GW = (IW + 1 + 3) / 4;
+    for (int t = threadIdx.x; t < IH * GW; t += 256) {
+      const int ly = t / GW, g = t - ly * GW;
+      const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
+      const int gx = x0 - R - 1 + 4 * g;
+      unsigned v4;
+      if (gx >= 0 && gx < w) {
+        v4 = *reinterpret_cast<const unsigned*>(row + gx);
+      } else {
+        v4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v4 |= (unsigned)row[reflect101(gx + k, w)] << (8 * k);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lx = 4 * g + k - 1, v = (int)((v4 >> (8 * k)) & 0xffu);
+        if (lx >= 0 && lx < IW) {
+          same = same && v == ref;
+          s_a[ly][lx] = v;
+        }
+      }
+    }
+  } else {
+    for (int ly = ty; ly < IH; ly += 4) {
+      const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
+      for (int lx = tx; lx < IW; lx += GU_TW) {
+        const int v = row[reflect101(x0 - R + lx, w)];
+        same = same && v == ref;
+        s_a[ly][lx] = v;
+      }
     }
   }
   if (__syncthreads_and(same)) {
