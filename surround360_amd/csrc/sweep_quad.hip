@@ -17,10 +17,16 @@
 //   * no service waves, no barriers: a workgroup is ONE wave; other resident waves cover its memory latency. Left
 //     neighbour = registers, up neighbour = DPP (row_shr:4 / row_bcast:15), a band's first row takes the last row of
 //     the band above from 8-byte {fx,fy} granules in global memory (all-ones = not written; bands are ticketed in
-//     band-major order, spins are bounded).
-// Measured (tools/sweep_microbench tp1, 32 pole-level flows x 2 streams): 20.5 Gpx/s against 13.8 for the previous
-// per-step control flow; a single flow still runs ~1.25x slower than with sweep_lock.hip. FlowEngine picks this
-// kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+//     band-major order, spins are bounded);
+//   * waves are persistent (capped grid, a finished band takes the next ticket): ~10-15 waves per CU is where the
+//     32 KB L1 still holds the gradient rows the waves gather from;
+//   * pixels below the alpha threshold are not updated (PixFlow.h:390): a step none of whose 16 pixels is updated
+//     skips both rounds, a band waits for the band above only where its first row is updated, and a band without any
+//     updated pixel (per-row flags written by the record kernel) hands its last row on and leaves — 63 % of a pole
+//     flow's pixels are like that.
+// Measured (tools/sweep_microbench tp1, see tools/mb_experiment.sh): ~24 Gpx/s on saturated side levels (336 flows of
+// 607x884), ~22 Gpx/s on the 48 pole flows of a 12-frame batch; a single flow runs ~1.4x slower than with
+// sweep_lock.hip. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
