@@ -86,6 +86,11 @@ constexpr int MED_LW = MED_BX * MED_T + 4, MED_LH = MED_BY + 4;
 // The tile (with its 2-pixel replicate border) goes through LDS once, split into its two channels: a thread then reads
 // the 60 values of ONE channel at a time (three 16-byte LDS reads per window row), which keeps the generated network
 // at ~100 registers instead of the ~190 it needs with both channels' inputs live.
+static_assert(MED_T == 8 && (MED_LW & 3) == 0, "med_pos assumes two 4-float groups per thread");
+__device__ __forceinline__ int med_pos(int lx) {  // column -> position in the LDS row (even groups, then odd groups)
+  const int g = lx >> 2;
+  return (((g >> 1) + (g & 1) * ((MED_LW / 4 + 1) / 2)) << 2) | (lx & 3);
+}
 __global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restrict__ src, float2* __restrict__ dst, int w,
                                                          int h, size_t bs) {
   __shared__ __attribute__((aligned(16))) float s_p[2][MED_LH][MED_LW];
@@ -93,11 +98,18 @@ __global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restric
   const int X0 = blockIdx.x * (MED_BX * MED_T), Y0 = blockIdx.y * MED_BY;
   src += bs * blockIdx.z;
   dst += bs * blockIdx.z;
-  for (int i = tid; i < MED_LH * MED_LW; i += 256) {
-    const int ly = i / MED_LW, lx = i - ly * MED_LW;
-    const float2 p = src[(size_t)clip_idx(Y0 - 2 + ly, h) * w + clip_idx(X0 - 2 + lx, w)];
-    s_p[0][ly][lx] = p.x;
-    s_p[1][ly][lx] = p.y;
+  // A thread keeps its column and walks down the 12 rows (no division, one clamped column index); columns 256..259
+  // are taken by the first four threads. Within a row the 4-float groups are stored even groups first, odd groups
+  // after them (med_pos): a thread's three 16-byte reads below then fall on consecutive addresses across the lanes
+  // instead of every other group (a two-way bank conflict on every read).
+  for (int lx = tid; lx < MED_LW; lx += 256) {
+    const int gx = clip_idx(X0 - 2 + lx, w), px = med_pos(lx);
+#pragma unroll
+    for (int ly = 0; ly < MED_LH; ++ly) {
+      const float2 p = src[(size_t)clip_idx(Y0 - 2 + ly, h) * w + gx];
+      s_p[0][ly][px] = p.x;
+      s_p[1][ly][px] = p.y;
+    }
   }
   __syncthreads();
   const int tx = tid & (MED_BX - 1), ty = tid >> 5;
@@ -109,10 +121,10 @@ __global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restric
     float in[(MED_T + 4) * 5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-      const float4* row = reinterpret_cast<const float4*>(&s_p[ch][ty + r][tx * MED_T]);  // 32-byte aligned
+      const float4* row = reinterpret_cast<const float4*>(&s_p[ch][ty + r][0]);
 #pragma unroll
       for (int q = 0; q < (MED_T + 4) / 4; ++q) {
-        const float4 v = row[q];
+        const float4 v = row[med_pos(tx * MED_T + 4 * q) >> 2];
         in[(4 * q) * 5 + r] = v.x;
         in[(4 * q + 1) * 5 + r] = v.y;
         in[(4 * q + 2) * 5 + r] = v.z;
