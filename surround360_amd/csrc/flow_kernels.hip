@@ -290,35 +290,41 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
 template <int CN>
 __global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restrict__ src, int sw, int sh, size_t sbs,
                                                            float* __restrict__ dst, int dw, int dh, size_t dbs,
-                                                           double scx, double scy, float post_scale, int do_scale) {
+                                                           double scx, double scy, float post_scale, int do_scale,
+                                                           int planes_per_thread) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x;
   const int dy = blockIdx.y * blockDim.y + threadIdx.y;
   if (dx >= dw || dy >= dh) return;
-  src += sbs * CN * blockIdx.z;
-  dst += dbs * CN * blockIdx.z;
   int sx, sy;
   float fx, fy;
   resize_coord(dx, scx, &sx, &fx);
   if (sx < 0) { fx = 0; sx = 0; }
   if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
   resize_coord(dy, scy, &sy, &fy);
-  const float* S0 = src + (size_t)clip_idx(sy, sh) * sw * CN;
-  const float* S1 = src + (size_t)clip_idx(sy + 1, sh) * sw * CN;
+  const size_t r0 = (size_t)clip_idx(sy, sh) * sw * CN, r1 = (size_t)clip_idx(sy + 1, sh) * sw * CN;
   const float b0 = 1.f - fy, b1 = fy;
+  const bool edge = sx >= sw - 1;
+  const float a0 = 1.f - fx, a1 = fx;
+  // the planes of a launch share their geometry: one thread produces this pixel of `planes_per_thread` of them
+  for (int pl = 0; pl < planes_per_thread; ++pl) {
+    const size_t z = (size_t)blockIdx.z * planes_per_thread + pl;
+    const float* S0 = src + sbs * CN * z + r0;
+    const float* S1 = src + sbs * CN * z + r1;
+    float* D = dst + dbs * CN * z;
 #pragma unroll
-  for (int k = 0; k < CN; ++k) {
-    float h0, h1;
-    if (sx >= sw - 1) {
-      h0 = S0[sx * CN + k] * 1.0f;
-      h1 = S1[sx * CN + k] * 1.0f;
-    } else {
-      const float a0 = 1.f - fx, a1 = fx;
-      h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
-      h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
+    for (int k = 0; k < CN; ++k) {
+      float h0, h1;
+      if (edge) {
+        h0 = S0[sx * CN + k] * 1.0f;
+        h1 = S1[sx * CN + k] * 1.0f;
+      } else {
+        h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
+        h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
+      }
+      float v = h0 * b0 + h1 * b1;
+      if (do_scale) v *= post_scale;
+      D[((size_t)dy * dw + dx) * CN + k] = v;
     }
-    float v = h0 * b0 + h1 * b1;
-    if (do_scale) v *= post_scale;
-    dst[((size_t)dy * dw + dx) * CN + k] = v;
   }
 }
 
@@ -385,24 +391,32 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32c2_tiled(const float2* 
   const int X0 = clip_idx(s_sx[0] - 1, sw), X1 = clip_idx(s_sx[UC_TW - 1] + 2, sw);
   const int Y0 = clip_idx(s_sy[0] - 1, sh), Y1 = clip_idx(s_sy[UC_TH - 1] + 2, sh);
   const int W = X1 - X0 + 1, H = Y1 - Y0 + 1;  // <= UC_SW x UC_SH for ratios <= 1 (checked by the launcher)
-  for (int i = tid; i < H * W; i += 256) {
-    const int ly = i / W, lx = i - ly * W;
-    s_src[ly][lx] = src[(size_t)(Y0 + ly) * sw + X0 + lx];
+  // A thread keeps its column c = tid & 63 through all three phases (256 is a multiple of the tile width): no
+  // division in the load, and its source offsets and horizontal coefficients are read once, not once per row.
+  const int c = tid & (UC_TW - 1), q = tid >> 6;
+  for (int ly = q; ly < H; ly += 4)
+    if (c < W) s_src[ly][c] = src[(size_t)(Y0 + ly) * sw + X0 + c];
+  if (W > UC_TW) {  // the up to 8 remaining columns of the window
+    const int lx = UC_TW + (tid & 7);
+    for (int ly = tid >> 3; ly < H; ly += 32)
+      if (lx < W) s_src[ly][lx] = src[(size_t)(Y0 + ly) * sw + X0 + lx];
   }
   __syncthreads();
-  for (int i = tid; i < H * UC_TW; i += 256) {  // horizontal pass of every source row of the window
-    const int ly = i >> 6, c = i & (UC_TW - 1);
+  {  // horizontal pass of every source row of the window
     const int sx = s_sx[c];
-    const float2 p0 = s_src[ly][clip_idx(sx - 1, sw) - X0], p1 = s_src[ly][clip_idx(sx, sw) - X0],
-                 p2 = s_src[ly][clip_idx(sx + 1, sw) - X0], p3 = s_src[ly][clip_idx(sx + 2, sw) - X0];
+    const int o0 = clip_idx(sx - 1, sw) - X0, o1 = clip_idx(sx, sw) - X0, o2 = clip_idx(sx + 1, sw) - X0,
+              o3 = clip_idx(sx + 2, sw) - X0;
     const float a0 = s_ax[c][0], a1 = s_ax[c][1], a2 = s_ax[c][2], a3 = s_ax[c][3];
-    float2 hv;
-    hv.x = p0.x * a0 + p1.x * a1 + p2.x * a2 + p3.x * a3;
-    hv.y = p0.y * a0 + p1.y * a1 + p2.y * a2 + p3.y * a3;
-    s_h[ly][c] = hv;
+    for (int ly = q; ly < H; ly += 4) {
+      const float2 p0 = s_src[ly][o0], p1 = s_src[ly][o1], p2 = s_src[ly][o2], p3 = s_src[ly][o3];
+      float2 hv;
+      hv.x = p0.x * a0 + p1.x * a1 + p2.x * a2 + p3.x * a3;
+      hv.y = p0.y * a0 + p1.y * a1 + p2.y * a2 + p3.y * a3;
+      s_h[ly][c] = hv;
+    }
   }
   __syncthreads();
-  const int c = tid & (UC_TW - 1), r0 = (tid >> 6) * 4;
+  const int r0 = q * 4;
   const int dx = dx0 + c;
   if (dx >= dw) return;
 #pragma unroll
@@ -593,12 +607,13 @@ void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, 
                               size_t dbs, int cn, int B, float post_scale, int do_scale) {
   const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
   dim3 blk(32, 8);
+  const int ppt = (B % 4 == 0) ? 4 : (B % 2 == 0) ? 2 : 1;  // planes per thread (the coordinates are computed once)
   if (cn == 1)
-    hipLaunchKernelGGL((k_resize_linear_f32<1>), grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs,
-                       scx, scy, post_scale, do_scale);
+    hipLaunchKernelGGL((k_resize_linear_f32<1>), grid2d(dw, dh, B / ppt, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh,
+                       dbs, scx, scy, post_scale, do_scale, ppt);
   else
-    hipLaunchKernelGGL((k_resize_linear_f32<2>), grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs,
-                       scx, scy, post_scale, do_scale);
+    hipLaunchKernelGGL((k_resize_linear_f32<2>), grid2d(dw, dh, B / ppt, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh,
+                       dbs, scx, scy, post_scale, do_scale, ppt);
 }
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
                                int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab) {
