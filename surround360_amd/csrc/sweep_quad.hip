@@ -77,15 +77,20 @@ constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every 
 // The sweeps of one launch then hold a bounded share of every CU — a wave's working set is ~8 KB (17 gradient rows +
 // its record / flow lines) and beyond ~15 waves per CU the 32 KB L1 thrashes — and the kernels of another context
 // find free wave slots, registers and LDS next to them.
-template <bool FAST>
+template <bool FAST, bool LDSIN>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
                                                    unsigned* __restrict__ errflag,
                                                    const unsigned* __restrict__ rowflags) {
+  // LDSIN: the records and flows of a 16-step chunk are fetched once (four pixels per lane, eight loads per chunk
+  // instead of two per step) and staged in LDS; a slot of s_res then holds a pixel's flow before its step and its
+  // result after it, indexed by step. Row strides of 17 elements keep the 16 rows of a read on distinct banks.
+  constexpr int kRW = LDSIN ? kQChunk + 1 : kQResRing;
   __shared__ float2 s_up[kUpRing];
-  __shared__ float2 s_res[kQRows][kQResRing];
+  __shared__ float2 s_res[kQRows][kRW];
+  __shared__ float4 s_rec[LDSIN ? kQRows : 1][LDSIN ? kQChunk + 1 : 1];
   const int lane = threadIdx.x;
   for (;;) {
   unsigned tk = 0;
@@ -217,13 +222,36 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   float2 fl = make_float2(0.f, 0.f);  // result of the previous pixel of this row (same in the 4 lanes of the quad)
   float4 nrc;
   float2 nfo;
-  {
+  float4 cr[4];  // LDSIN: the next chunk's records / flows of this lane's four steps (4 q .. 4 q + 3)
+  float2 cf[4];
+  auto chunk_load = [&](int sbase) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xc = col(sbase + 4 * q + j - r);
+      cr[j] = recRow[xc];
+      cf[j] = flowRow[xc];
+    }
+  };
+  auto chunk_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s_rec[r][4 * q + j] = cr[j];
+      s_res[r][4 * q + j] = cf[j];
+    }
+  };
+  if (LDSIN) {
+    chunk_load(0);
+    chunk_store();
+    nrc = s_rec[r][0];
+    nfo = s_res[r][0];
+  } else {
     const int x0c = col(0 - r);
     nrc = recRow[x0c];
     nfo = flowRow[x0c];
   }
   for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
     const int send = min(s0 + kQChunk, nsteps);
+    if (LDSIN && s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
     for (int s = s0; s < send; ++s) {
       // Row 0 needs column s of the band above only if its pixel is updated at this step (pixels below the alpha
       // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
@@ -254,7 +282,12 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       }
       const float4 rc = nrc;
       const float2 fo = nfo;
-      {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
+      if (LDSIN) {  // inputs of the next step of this chunk (the first step of the next chunk is read after the refill)
+        if (s + 1 < send) {
+          nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
+          nfo = s_res[r][(s + 1) & (kQChunk - 1)];
+        }
+      } else {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
         const int xn = S360_DBG(fc, 8) ? col(-r) : col(s + 1 - r);  // (dbg 8: timing experiment, inputs that always hit)
         if (S360_DBG(fc, 16)) {  // (dbg 16: inputs as streaming loads that do not allocate in L1; results unchanged)
           typedef float f4n __attribute__((ext_vector_type(4)));
@@ -295,11 +328,11 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
         res.y = take ? res.y : alt.y;
       }
       fl = res;
-      if (q == 0) s_res[r][xi & (kQResRing - 1)] = res;
+      if (q == 0) s_res[r][LDSIN ? (s & (kQChunk - 1)) : (xi & (kQResRing - 1))] = res;
       if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
         const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
         if (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1)) {
-          const float2 v = s_res[kQRows - 1][xi0 & (kQResRing - 1)];
+          const float2 v = s_res[kQRows - 1][LDSIN ? ((xi0 + kQRows - 1) & (kQChunk - 1)) : (xi0 & (kQResRing - 1))];
           __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -311,8 +344,14 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #pragma unroll
       for (int k = 0; k < kQChunk / 4; ++k) {
         const int xi = base + 4 * k;
-        if (rowValid && xi >= 0 && xi < w && xi < send - r && !S360_DBG(fc, 4)) flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][xi & (kQResRing - 1)];
+        if (rowValid && xi >= 0 && xi < w && xi < send - r && !S360_DBG(fc, 4))
+          flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][LDSIN ? ((xi + r) & (kQChunk - 1)) : (xi & (kQResRing - 1))];
       }
+    }
+    if (LDSIN && send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
+      chunk_store();
+      nrc = s_rec[r][0];
+      nfo = s_res[r][0];
     }
   }
   }  // next ticket
@@ -353,12 +392,22 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     return n > 0 ? n : 256;
   }();
   const int grid = std::min(nb * B, cus * perCu);
-  if (fast)
-    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
-                       fc, nb, B, errflag, rowflags);
-  else
-    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c,
-                       fc, nb, B, errflag, rowflags);
+  // S360_QUAD_LDSIN=0: inputs loaded per step instead of staged per chunk (tuning only; same results)
+  static const bool ldsin = [] {
+    const char* e = std::getenv("S360_QUAD_LDSIN");
+    return !(e && e[0] == '0');
+  }();
+#define S360_LAUNCH_QUAD(F, L)                                                                                      \
+  hipLaunchKernelGGL((k_sweep_quad<F, L>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
+                     fc, nb, B, errflag, rowflags)
+  if (fast) {
+    if (ldsin) S360_LAUNCH_QUAD(true, true);
+    else S360_LAUNCH_QUAD(true, false);
+  } else {
+    if (ldsin) S360_LAUNCH_QUAD(false, true);
+    else S360_LAUNCH_QUAD(false, false);
+  }
+#undef S360_LAUNCH_QUAD
 }
 
 }  // namespace s360
