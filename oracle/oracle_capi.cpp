@@ -9,6 +9,7 @@
 #include <map>
 #include <string>
 
+#include "isp.h"
 #include "render.h"
 
 using namespace orc;
@@ -390,6 +391,25 @@ void orc_frame_pole_to_side_flow(orc_frame* f, const uint8_t* side, int sw, int 
   ImgU8 r = poleToSideFlow(f->rig, f->P, wrapU8(side, sw, sh, 4), wrapU8(pole, pw, ph, 4), nullptr, &st);
   std::memcpy(warped, r.d.data(), r.bytes());
   if (flow_out) std::memcpy(flow_out, st.flow.d.data(), st.flow.bytes());
+}
+
+
+// ---- soft ISP (isp.h; CameraIsp.h through Raw2Rgb's non-accelerated path) ----------------------
+// cfg: orc::IspConfig (4-byte fields only; mirrored field by field by tests/oracle_lib.py IspConfigC)
+int orc_isp_config_size() { return (int)sizeof(IspConfig); }
+int orc_isp_run(const IspConfig* cfg, const uint16_t* raw, int w, int h, void* out, char* err, int err_cap) {
+  try {
+    ispRun(*cfg, raw, w, h, out);
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; }
+    return -1;
+  }
+}
+void orc_isp_tables(const IspConfig* cfg, float* ccm9, float* lut /*4096 x 3*/) {
+  const IspTables t = ispSetup(*cfg);
+  std::memcpy(ccm9, t.compositeCCM, sizeof(t.compositeCCM));
+  std::memcpy(lut, t.toneLut.data(), t.toneLut.size() * sizeof(float));
 }
 
 }  // extern "C"

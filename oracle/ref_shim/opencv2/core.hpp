@@ -1,0 +1,180 @@
+// TEST INFRASTRUCTURE. Container-only stand-in for the OpenCV types the reference's soft ISP (camera_isp/CameraIsp.h and
+// the util headers it includes) is written against, so that the reference's OWN SOURCE can be compiled from
+// /root/reference into oracle/_ref without OpenCV. It provides storage and indexing (Mat, Vec, Point3_, Size), the
+// element-wise Vec arithmetic those headers use, and the three matrix operations of CameraIsp::setup on 3x3 float
+// matrices. Every ISP arithmetic operation on pixels is the reference's code, not this file's.
+//
+// From memory of OpenCV 3.x (not verifiable offline), stated here because the composite CCM depends on it:
+//   * Mat * Mat on 3x3 CV_32F takes gemm's unrolled small-matrix path: float products summed left to right in float
+//   * Mat *= double scales every element in float (convertTo with a float working type)
+//   * Vec<float,n> * float and Vec + Vec are plain per-element float operations
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace cv {
+
+typedef unsigned char uchar;
+typedef unsigned short ushort;
+
+enum { CV_8U = 0, CV_8S = 1, CV_16U = 2, CV_16S = 3, CV_32S = 4, CV_32F = 5, CV_64F = 6 };
+#define CV_CN_SHIFT 3
+#define CV_MAT_DEPTH_MASK 7
+#define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << CV_CN_SHIFT))
+#define CV_8UC1 CV_MAKETYPE(cv::CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(cv::CV_8U, 3)
+#define CV_8UC4 CV_MAKETYPE(cv::CV_8U, 4)
+#define CV_16UC1 CV_MAKETYPE(cv::CV_16U, 1)
+#define CV_16UC3 CV_MAKETYPE(cv::CV_16U, 3)
+#define CV_32FC1 CV_MAKETYPE(cv::CV_32F, 1)
+#define CV_32FC2 CV_MAKETYPE(cv::CV_32F, 2)
+#define CV_32FC3 CV_MAKETYPE(cv::CV_32F, 3)
+enum { IMREAD_COLOR = 1 };
+#define CV_LOAD_IMAGE_GRAYSCALE 0
+#define CV_LOAD_IMAGE_ANYDEPTH 2
+
+template <typename T, int N>
+struct Vec {
+  T val[N];
+  Vec() { for (int i = 0; i < N; ++i) val[i] = T(0); }
+  Vec(T a, T b) { static_assert(N == 2, ""); val[0] = a; val[1] = b; }
+  Vec(T a, T b, T c) { static_assert(N == 3, ""); val[0] = a; val[1] = b; val[2] = c; }
+  Vec(T a, T b, T c, T d) { static_assert(N == 4, ""); val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+  template <typename U>
+  Vec(const Vec<U, N>& o) { for (int i = 0; i < N; ++i) val[i] = T(o.val[i]); }
+  T& operator[](int i) { return val[i]; }
+  const T& operator[](int i) const { return val[i]; }
+};
+template <typename T, int N>
+inline Vec<T, N> operator+(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (int i = 0; i < N; ++i) r.val[i] = T(a.val[i] + b.val[i]); return r; }
+template <typename T, int N>
+inline Vec<T, N> operator-(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (int i = 0; i < N; ++i) r.val[i] = T(a.val[i] - b.val[i]); return r; }
+template <typename T, int N>
+inline Vec<T, N> operator*(const Vec<T, N>& a, float s) { Vec<T, N> r; for (int i = 0; i < N; ++i) r.val[i] = T(a.val[i] * s); return r; }
+template <typename T, int N>
+inline Vec<T, N> operator*(float s, const Vec<T, N>& a) { return a * s; }
+template <typename T, int N>
+inline std::ostream& operator<<(std::ostream& o, const Vec<T, N>& v) { o << "["; for (int i = 0; i < N; ++i) o << (i ? ", " : "") << v.val[i]; return o << "]"; }
+typedef Vec<uchar, 3> Vec3b;
+typedef Vec<uchar, 4> Vec4b;
+typedef Vec<short, 3> Vec3s;
+typedef Vec<ushort, 3> Vec3w;
+typedef Vec<float, 2> Vec2f;
+typedef Vec<float, 3> Vec3f;
+typedef Vec<float, 4> Vec4f;
+typedef Vec<double, 3> Vec3d;
+
+template <typename T>
+struct Point_ {
+  T x, y;
+  Point_() : x(0), y(0) {}
+  Point_(T a, T b) : x(a), y(b) {}
+};
+typedef Point_<int> Point;
+typedef Point_<float> Point2f;
+template <typename T>
+struct Point3_ {
+  T x, y, z;
+  Point3_() : x(0), y(0), z(0) {}
+  Point3_(T a, T b, T c) : x(a), y(b), z(c) {}
+  Point3_(const Vec<T, 3>& v) : x(v.val[0]), y(v.val[1]), z(v.val[2]) {}
+  operator Vec<T, 3>() const { return Vec<T, 3>(x, y, z); }
+};
+typedef Point3_<float> Point3f;
+template <typename T>
+inline std::ostream& operator<<(std::ostream& o, const Point3_<T>& p) { return o << "[" << p.x << ", " << p.y << ", " << p.z << "]"; }
+template <typename T>
+inline std::ostream& operator<<(std::ostream& o, const std::vector<Point3_<T>>& v) { for (auto& p : v) o << p << ";"; return o; }
+
+struct Size {
+  int width, height;
+  Size() : width(0), height(0) {}
+  Size(int w, int h) : width(w), height(h) {}
+};
+struct Rect { int x, y, width, height; };
+struct Scalar { double val[4]; };
+
+inline size_t elemSize(int type) {
+  static const int d[7] = {1, 1, 2, 2, 4, 4, 8};
+  return (size_t)d[type & CV_MAT_DEPTH_MASK] * (size_t)((type >> CV_CN_SHIFT) + 1);
+}
+
+class Mat {
+ public:
+  int rows, cols;
+  uchar* data;
+  Mat() : rows(0), cols(0), data(nullptr), type_(0) {}
+  Mat(int r, int c, int type) { create(r, c, type); }
+  Mat(Size s, int type) { create(s.height, s.width, type); }
+  Mat(int r, int c, int type, void* ext) : rows(r), cols(c), data((uchar*)ext), type_(type) {}  // wraps, does not copy
+  void create(int r, int c, int type) {
+    rows = r; cols = c; type_ = type;
+    store_.reset(new std::vector<uchar>((size_t)r * c * elemSize(type) + 64));  // uninitialised in OpenCV; zero here
+    data = store_->data();
+  }
+  static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
+  static Mat eye(int r, int c, int type) {
+    Mat m(r, c, type);
+    assert(type == CV_32F);
+    for (int i = 0; i < std::min(r, c); ++i) m.at<float>(i, i) = 1.0f;
+    return m;
+  }
+  int type() const { return type_; }
+  int depth() const { return type_ & CV_MAT_DEPTH_MASK; }
+  int channels() const { return (type_ >> CV_CN_SHIFT) + 1; }
+  Size size() const { return Size(cols, rows); }
+  bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+  Mat clone() const {
+    Mat m(rows, cols, type_);
+    std::memcpy(m.data, data, (size_t)rows * cols * elemSize(type_));
+    return m;
+  }
+  template <typename T> T& at(int i, int j) { return reinterpret_cast<T*>(data)[(size_t)i * cols + j]; }
+  template <typename T> const T& at(int i, int j) const { return reinterpret_cast<const T*>(data)[(size_t)i * cols + j]; }
+  template <typename T> T& at(int i) { return reinterpret_cast<T*>(data)[i]; }
+  template <typename T> const T& at(int i) const { return reinterpret_cast<const T*>(data)[i]; }
+
+ private:
+  int type_;
+  std::shared_ptr<std::vector<uchar>> store_;
+};
+inline std::ostream& operator<<(std::ostream& o, const Mat& m) {
+  if (m.type() == CV_32F) for (int i = 0; i < m.rows; ++i) for (int j = 0; j < m.cols; ++j) o << m.at<float>(i, j) << (j + 1 == m.cols ? ";" : ",");
+  return o;
+}
+// gemm's small-matrix path for CV_32F (see the header note)
+inline Mat operator*(const Mat& a, const Mat& b) {
+  assert(a.type() == CV_32F && b.type() == CV_32F && a.cols == b.rows);
+  Mat d(a.rows, b.cols, CV_32F);
+  for (int i = 0; i < a.rows; ++i)
+    for (int j = 0; j < b.cols; ++j) {
+      float t = a.at<float>(i, 0) * b.at<float>(0, j);
+      for (int k = 1; k < a.cols; ++k) t = t + a.at<float>(i, k) * b.at<float>(k, j);
+      d.at<float>(i, j) = t;
+    }
+  return d;
+}
+inline Mat& operator*=(Mat& a, const Mat& b) { a = a * b; return a; }
+inline Mat& operator*=(Mat& a, double s) {
+  assert(a.type() == CV_32F);
+  for (int i = 0; i < a.rows * a.cols; ++i) a.at<float>(i) = a.at<float>(i) * (float)s;
+  return a;
+}
+inline void transpose(const Mat& src, Mat& dst) {
+  assert(src.type() == CV_32F);
+  Mat d(src.cols, src.rows, CV_32F);
+  for (int i = 0; i < src.rows; ++i) for (int j = 0; j < src.cols; ++j) d.at<float>(j, i) = src.at<float>(i, j);
+  dst = d;
+}
+inline void dct(const Mat&, Mat&) { throw std::runtime_error("shim: dct (FREQUENCY_DM_FILTER) is not available"); }
+inline void idct(const Mat&, Mat&) { throw std::runtime_error("shim: idct (FREQUENCY_DM_FILTER) is not available"); }
+
+}  // namespace cv

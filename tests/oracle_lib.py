@@ -383,3 +383,122 @@ class Frame:
         fl = np.empty((ph, int(np.float32(pw) * np.float32(1.2)), 2), np.float32) if want_flow else None
         lib().orc_frame_pole_to_side_flow(self.h, _p(side), sw, sh, _p(pole), pw, ph, _p(out), _p(fl))
         return (out, fl) if want_flow else out
+
+
+# ---- soft ISP (oracle/isp.h; reference CameraIsp.h through Raw2Rgb's non-accelerated path) --------------------------
+ISP_MAX_CURVE_POINTS = 16
+BAYER_PATTERNS = ("RGGB", "GRBG", "GBRG", "BGGR")
+
+
+class IspConfigC(C.Structure):
+    """orc::IspConfig (oracle/isp.h) field by field."""
+    _fields_ = [
+        ("blackLevel", C.c_float * 3), ("clampMin", C.c_float * 3), ("clampMax", C.c_float * 3),
+        ("whiteBalanceGain", C.c_float * 3), ("ccm", C.c_float * 9), ("saturation", C.c_float), ("contrast", C.c_float),
+        ("gamma", C.c_float * 3), ("lowKeyBoost", C.c_float * 3), ("highKeyBoost", C.c_float * 3),
+        ("sharpening", C.c_float * 3), ("sharpeningSupport", C.c_float), ("noiseCore", C.c_float),
+        ("nVignetteH", C.c_int), ("nVignetteV", C.c_int),
+        ("vignetteRollOffH", (C.c_float * 3) * ISP_MAX_CURVE_POINTS),
+        ("vignetteRollOffV", (C.c_float * 3) * ISP_MAX_CURVE_POINTS),
+        ("stuckPixelRadius", C.c_int), ("bayerPattern", C.c_int),
+        ("outputBpp", C.c_int), ("demosaicFilter", C.c_int), ("resize", C.c_int), ("disableToneCurve", C.c_int),
+        ("blackLevelOffset", C.c_int),
+    ]
+
+
+def isp_config_from_json(json_text, output_bpp=8, demosaic_filter=2, resize=1, disable_tone_curve=0,
+                         black_level_offset=0):
+    """The CameraIsp constructor's reading of the "CameraIsp" object (CameraIsp.h:425-607): defaults, then the keys
+    present; JSON doubles are narrowed to float exactly as `v.x = vec[0].ToDouble()` does."""
+    c = IspConfigC()
+    for k in range(3):
+        c.clampMax[k] = c.whiteBalanceGain[k] = c.gamma[k] = 1.0
+    for k in (0, 4, 8):
+        c.ccm[k] = 1.0
+    c.saturation = c.contrast = 1.0
+    c.sharpeningSupport = np.float32(10.0) / np.float32(2048.0)
+    c.noiseCore = 1000.0
+    c.nVignetteH = c.nVignetteV = 1
+    for k in range(3):
+        c.vignetteRollOffH[0][k] = c.vignetteRollOffV[0][k] = 1.0
+    c.bayerPattern = 2  # "GBRG"
+    j = json.loads(json_text).get("CameraIsp", {})
+
+    def vec(name, dst):
+        if name in j:
+            for k in range(3):
+                dst[k] = j[name][k]
+    vec("blackLevel", c.blackLevel); vec("clampMin", c.clampMin); vec("clampMax", c.clampMax)
+    vec("whiteBalanceGain", c.whiteBalanceGain); vec("gamma", c.gamma); vec("lowKeyBoost", c.lowKeyBoost)
+    vec("highKeyBoost", c.highKeyBoost); vec("sharpening", c.sharpening)
+    if "ccm" in j:
+        for a in range(3):
+            for b in range(3):
+                c.ccm[a * 3 + b] = j["ccm"][a][b]
+    for name in ("saturation", "contrast", "sharpeningSupport", "noiseCore"):
+        if name in j:
+            setattr(c, name, j[name])
+    for name, dst, cnt in (("vignetteRollOffH", c.vignetteRollOffH, "nVignetteH"),
+                           ("vignetteRollOffV", c.vignetteRollOffV, "nVignetteV")):
+        if name in j:
+            pts = j[name]
+            assert 1 <= len(pts) <= ISP_MAX_CURVE_POINTS
+            setattr(c, cnt, len(pts))
+            for i, p in enumerate(pts):
+                for k in range(3):
+                    dst[i][k] = p[k]
+    if "stuckPixelRadius" in j:
+        c.stuckPixelRadius = 2 * int(j["stuckPixelRadius"])
+    if "bayerPattern" in j:  # setup() uses find(): the first pattern name contained in the string, in this order
+        c.bayerPattern = next(i for i, n in enumerate(BAYER_PATTERNS) if n in j["bayerPattern"])
+    c.outputBpp, c.demosaicFilter, c.resize = output_bpp, demosaic_filter, resize
+    c.disableToneCurve, c.blackLevelOffset = disable_tone_curve, black_level_offset
+    return c
+
+
+def _isp_out(raw, cfg):
+    h, w = raw.shape
+    return np.zeros((h // cfg.resize, w // cfg.resize, 3), np.uint8 if cfg.outputBpp == 8 else np.uint16)
+
+
+def isp_run(cfg, raw):
+    """oracle restatement: raw (H x W uint16 Bayer) -> (H/resize) x (W/resize) x 3 BGR, uint8 / uint16."""
+    raw = np.ascontiguousarray(raw, np.uint16)
+    assert lib().orc_isp_config_size() == C.sizeof(IspConfigC)
+    out = _isp_out(raw, cfg)
+    err = C.create_string_buffer(256)
+    if lib().orc_isp_run(C.byref(cfg), _p(raw), raw.shape[1], raw.shape[0], _p(out), err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+    return out
+
+
+def isp_tables(cfg):
+    ccm, lut = np.zeros(9, np.float32), np.zeros((4096, 3), np.float32)
+    lib().orc_isp_tables(C.byref(cfg), _p(ccm), _p(lut))
+    return ccm.reshape(3, 3), lut
+
+
+_REF_ISP = None
+
+
+def ref_isp_lib():
+    """oracle/_ref/libref_isp.so — the reference's own CameraIsp.h compiled over the container stand-in. Built here when
+    /root/reference exists; on the GPU box the prebuilt file travels with the snapshot. None if neither."""
+    global _REF_ISP
+    so = os.path.join(ORACLE_DIR, "_ref", "libref_isp.so")
+    if os.path.isdir("/root/reference/surround360_render/source/camera_isp"):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "ref"])
+    if _REF_ISP is None and os.path.exists(so):
+        _REF_ISP = C.CDLL(so)
+    return _REF_ISP
+
+
+def ref_isp_run(json_text, raw, output_bpp=8, demosaic_filter=2, resize=1, disable_tone_curve=0, black_level_offset=0):
+    raw = np.ascontiguousarray(raw, np.uint16)
+    h, w = raw.shape
+    out = np.zeros((h // resize, w // resize, 3), np.uint8 if output_bpp == 8 else np.uint16)
+    err = C.create_string_buffer(256)
+    if ref_isp_lib().ref_isp_run(json_text.encode(), _p(raw), w, h, output_bpp, demosaic_filter, resize,
+                                 disable_tone_curve, black_level_offset, _p(out), err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+    return out
