@@ -291,6 +291,49 @@ int s360_profile_get(s360_ctx* ctx, char* names_out, size_t names_cap, float* ms
 int s360_save_flow_to_file(const char* path, const float* flow, int w, int h);
 int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, size_t cap_floats);
 
+/* ---- soft ISP: 16-bit Bayer raw -> BGR ---------------------------------
+ * Replaces the non-accelerated path of Raw2Rgb (SR/camera_isp/Raw2Rgb.cpp:441-456 -> CameraIsp.h): black level,
+ * anti-vignetting, white balance, clamp + stretch, demosaic (bilinear or edge-aware), composite CCM + tone-curve LUT,
+ * IIR unsharp mask, 8- or 16-bit output. Independent of s360_ctx (no rig is involved).
+ * Not available: FREQUENCY_DM_FILTER (demosaic_filter 1; cv::dct) and stuck-pixel removal with a non-zero radius
+ * (a serial in-place pass, CameraIsp.h:1024-1104; radius 0 in every shipped configuration) -> S360_ERR_INVALID_ARG. */
+#define S360_ISP_MAX_CURVE_POINTS 16
+typedef struct s360_isp_config {
+  /* the "CameraIsp" JSON object as the constructor stores it (CameraIsp.h:425-607): doubles narrowed to float */
+  float black_level[3], clamp_min[3], clamp_max[3], white_balance_gain[3];
+  float ccm[9]; /* row-major 3x3 */
+  float saturation, contrast;
+  float gamma[3], low_key_boost[3], high_key_boost[3], sharpening[3];
+  float sharpening_support, noise_core;
+  int32_t n_vignette_h, n_vignette_v;
+  float vignette_roll_off_h[S360_ISP_MAX_CURVE_POINTS][3], vignette_roll_off_v[S360_ISP_MAX_CURVE_POINTS][3];
+  int32_t stuck_pixel_radius; /* 2 x the JSON value (CameraIsp.h:512) */
+  int32_t bayer_pattern;      /* 0 RGGB, 1 GRBG, 2 GBRG (default), 3 BGGR */
+  /* Raw2Rgb flags (Raw2Rgb.cpp:25-39) */
+  int32_t output_bpp;         /* 8 or 16 */
+  int32_t demosaic_filter;    /* 0 bilinear, 2 edge-aware (default) */
+  int32_t resize;             /* 1, 2, 4, 8 */
+  int32_t disable_tone_curve, black_level_offset;
+} s360_isp_config;
+/* CameraIsp(json, output_bpp) defaults (CameraIsp.h:440-462) + Raw2Rgb's flag defaults. */
+void s360_isp_config_defaults(s360_isp_config* cfg);
+/* The constructor's reading of an ISP configuration (the text of e.g. res/config/isp/cmosis_fujinon.json): defaults,
+ * then every key present under "CameraIsp". The Raw2Rgb flag fields keep the values they have in *cfg. */
+int s360_isp_config_from_json(const char* json_text, s360_isp_config* cfg);
+typedef struct s360_isp s360_isp;
+/* Builds the composite CCM and the 4096-entry tone curve on the host (CameraIsp::setup, buildToneCurveLut) and uploads
+ * them. One object per configuration; frames of any size can follow. */
+int s360_isp_create(s360_isp** out, int device, const s360_isp_config* cfg);
+void s360_isp_destroy(s360_isp* isp);
+/* CameraIsp::loadImage + getImage(swizzle = true). raw16: h x w uint16 (host). out: (h / resize) x (w / resize) x 3,
+ * B,G,R, uint8 or uint16 by output_bpp (host). */
+int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* out_bgr);
+/* The host-side tables of a configuration (no device needed; what s360_isp_create uploads): ccm9 = composite CCM x 4095
+ * (CameraIsp::setup), lut = 4096 x 3 floats (buildToneCurveLut), curve_h = w x 3 and curve_v = h x 3 vignette gains of
+ * a w x h frame (curveHAtPixel / curveVAtPixel; either may be NULL). */
+int s360_isp_config_tables(const s360_isp_config* cfg, float* ccm9, float* lut, int w, int h, float* curve_h,
+                           float* curve_v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,25 @@ class Geometry(C.Structure):
     ]
 
 
+ISP_MAX_CURVE_POINTS = 16
+
+
+class IspConfig(C.Structure):
+    """s360_isp_config (include/s360.h)."""
+    _fields_ = [
+        ("black_level", C.c_float * 3), ("clamp_min", C.c_float * 3), ("clamp_max", C.c_float * 3),
+        ("white_balance_gain", C.c_float * 3), ("ccm", C.c_float * 9), ("saturation", C.c_float),
+        ("contrast", C.c_float), ("gamma", C.c_float * 3), ("low_key_boost", C.c_float * 3),
+        ("high_key_boost", C.c_float * 3), ("sharpening", C.c_float * 3), ("sharpening_support", C.c_float),
+        ("noise_core", C.c_float), ("n_vignette_h", C.c_int32), ("n_vignette_v", C.c_int32),
+        ("vignette_roll_off_h", (C.c_float * 3) * ISP_MAX_CURVE_POINTS),
+        ("vignette_roll_off_v", (C.c_float * 3) * ISP_MAX_CURVE_POINTS),
+        ("stuck_pixel_radius", C.c_int32), ("bayer_pattern", C.c_int32), ("output_bpp", C.c_int32),
+        ("demosaic_filter", C.c_int32), ("resize", C.c_int32), ("disable_tone_curve", C.c_int32),
+        ("black_level_offset", C.c_int32),
+    ]
+
+
 # every symbol include/s360.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "s360_version", "s360_device_count", "s360_last_error", "s360_rig_load_json", "s360_camera_init",
@@ -59,6 +78,8 @@ SYMBOLS = [
     "s360_comm_get_unique_id", "s360_comm_init_rank", "s360_comm_init_all", "s360_comm_destroy",
     "s360_frame_gather_strips", "s360_comm_loopback", "s360_frame_set_partition",
     "s360_frame_download_equirect_of", "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch",
+    "s360_isp_config_defaults", "s360_isp_config_from_json", "s360_isp_create", "s360_isp_destroy", "s360_isp_process",
+    "s360_isp_config_tables",
 ]
 
 _lib = None
@@ -79,6 +100,9 @@ def lib():
         L.s360_camera_usable_pixels_radius.restype = C.c_float
         L.s360_stream.restype = C.c_void_p
         L.s360_stream.argtypes = [C.c_void_p]
+        L.s360_isp_config_defaults.restype = None
+        L.s360_isp_destroy.restype = None
+        L.s360_isp_destroy.argtypes = [C.c_void_p]
         for name in ("s360_destroy", "s360_synchronize", "s360_get_geometry"):
             getattr(L, name).argtypes = None
         _lib = L

@@ -8,6 +8,7 @@
 
 #include "../../include/s360.h"
 #include "ctx.hpp"
+#include "isp.hpp"
 #include "render.hpp"
 
 using namespace s360;
@@ -834,6 +835,63 @@ int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, 
     } else ok = false;
     std::fclose(f);
     if (!ok) throw Error(S360_ERR_IO, std::string("bad flow file: ") + path);
+  });
+}
+
+
+// ---- soft ISP (isp.cpp / isp_kernels.hip; Raw2Rgb's non-accelerated path, CameraIsp.h) ------------------------------
+void s360_isp_config_defaults(s360_isp_config* cfg) {
+  if (cfg) isp_config_defaults(cfg);
+}
+int s360_isp_config_from_json(const char* json_text, s360_isp_config* cfg) {
+  return guard(nullptr, [&] {
+    need(json_text && cfg, "null argument");
+    isp_config_from_json(json_text, cfg);
+  });
+}
+int s360_isp_create(s360_isp** out, int device, const s360_isp_config* cfg) {
+  if (!out) return S360_ERR_INVALID_ARG;
+  *out = nullptr;
+  s360_isp* o = nullptr;
+  const int rc = guard(nullptr, [&] {
+    need(cfg != nullptr, "null argument");
+    o = new s360_isp;
+    isp_init(o, device, *cfg);
+  });
+  if (rc != S360_OK) {
+    if (o) isp_release(o);
+    delete o;
+    return rc;
+  }
+  *out = o;
+  return S360_OK;
+}
+void s360_isp_destroy(s360_isp* isp) {
+  if (!isp) return;
+  isp_release(isp);
+  delete isp;
+}
+int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* out_bgr) {
+  return guard(nullptr, [&] {
+    need(isp && raw16 && out_bgr && w > 0 && h > 0, "bad argument");
+    isp_process(isp, raw16, w, h, out_bgr);
+  });
+}
+int s360_isp_config_tables(const s360_isp_config* cfg, float* ccm9, float* lut, int w, int h, float* curve_h,
+                           float* curve_v) {
+  return guard(nullptr, [&] {
+    need(cfg != nullptr, "null argument");
+    IspDev d;
+    std::vector<float> l, ch, cv;
+    isp_derive(*cfg, d, l);
+    if (ccm9) std::memcpy(ccm9, d.ccm, 9 * sizeof(float));
+    if (lut) std::memcpy(lut, l.data(), l.size() * sizeof(float));
+    if (curve_h || curve_v) {
+      need(w > 0 && h > 0, "bad frame size");
+      isp_vignette_curves(*cfg, w, h, ch, cv);
+      if (curve_h) std::memcpy(curve_h, ch.data(), ch.size() * sizeof(float));
+      if (curve_v) std::memcpy(curve_v, cv.data(), cv.size() * sizeof(float));
+    }
   });
 }
 

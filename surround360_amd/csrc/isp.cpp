@@ -1,0 +1,297 @@
+// isp.cpp — host side of the soft ISP: the CameraIsp constructor's reading of a configuration, CameraIsp::setup /
+// buildToneCurveLut (composite CCM, tone curve) and the vignette curves on the CPU like the reference, per-object device
+// buffers, one frame = upload, 5-8 kernels, download. Reference: surround360_render/source/camera_isp/CameraIsp.h.
+#include "isp.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "json_mini.hpp"
+
+namespace s360 {
+
+namespace {
+inline float clampf(float x, float a, float b) { return x < a ? a : x > b ? b : x; }  // MathUtil.h:38-41
+inline float lerpf(float x0, float x1, float a) { return x0 * (1.0f - a) + x1 * a; }   // MathUtil.h:58-61
+// BezierCurve<float, Vec3f>::operator()(i, j, t) on one channel (MathUtil.h:205-213): De Casteljau by recursion
+float bezier(const float (*p)[3], int ch, int i, int j, float t) {
+  if (i == j) return p[i][ch];
+  return lerpf(bezier(p, ch, i, j - 1, t), bezier(p, ch, i + 1, j, t), t);
+}
+// tone curve pieces (CameraIsp.h:361-388)
+float bezier4(float a, float b, float c, float d, float t) {
+  return lerpf(lerpf(lerpf(a, b, t), lerpf(b, c, t), t), lerpf(lerpf(b, c, t), lerpf(c, d, t), t), t);
+}
+float high_key(float boost, float x) {
+  const float a = 0.5f, b = clampf(0.6666f, 0.0f, 1.0f), c = clampf(0.8333f + boost, 0.0f, 1.0f), d = 1.0f;
+  return x > 0.5f ? bezier4(a, b, c, d, (x - 0.5f) * 2.0f) : 0;
+}
+float low_key(float boost, float x) {
+  const float a = 0.0f, b = clampf(0.1666f + boost, 0.0f, 1.0f), c = clampf(0.3333f, 0.0f, 1.0f), d = 0.5f;
+  return x <= 0.5f ? bezier4(a, b, c, d, x * 2.0f) : 0;
+}
+// 3x3 CV_32F product: float products summed left to right (what cv::gemm's small-matrix path does)
+void mul33(const float* a, const float* b, float* d) {
+  float t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = a[i * 3] * b[j];
+      s = s + a[i * 3 + 1] * b[3 + j];
+      s = s + a[i * 3 + 2] * b[6 + j];
+      t[i * 3 + j] = s;
+    }
+  std::memcpy(d, t, sizeof t);
+}
+void vec3(const JV& o, const char* key, float* dst) {
+  const JV* a = o.get(key);
+  if (!a) return;
+  if (a->t != JV::ARR || a->arr.size() != 3) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' is not a 3-vector");
+  for (int k = 0; k < 3; ++k) dst[k] = (float)a->arr[k].num;
+}
+void num(const JV& o, const char* key, float* dst) {
+  if (const JV* a = o.get(key)) *dst = (float)a->num;
+}
+void coord_list(const JV& o, const char* key, float (*dst)[3], int32_t* count) {
+  const JV* a = o.get(key);
+  if (!a) return;
+  if (a->t != JV::ARR || a->arr.empty() || a->arr.size() > S360_ISP_MAX_CURVE_POINTS)
+    throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' needs 1.." + std::to_string(S360_ISP_MAX_CURVE_POINTS) + " points");
+  *count = (int32_t)a->arr.size();
+  for (size_t i = 0; i < a->arr.size(); ++i) {
+    const JV& p = a->arr[i];
+    if (p.t != JV::ARR || p.arr.size() != 3) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' holds a non-3-vector");
+    for (int k = 0; k < 3; ++k) dst[i][k] = (float)p.arr[k].num;
+  }
+}
+}  // namespace
+
+void isp_config_defaults(s360_isp_config* c) {  // CameraIsp.h:440-462
+  std::memset(c, 0, sizeof *c);
+  for (int k = 0; k < 3; ++k) c->clamp_max[k] = c->white_balance_gain[k] = c->gamma[k] = 1.0f;
+  c->ccm[0] = c->ccm[4] = c->ccm[8] = 1.0f;
+  c->saturation = c->contrast = 1.0f;
+  c->sharpening_support = 10.0f / 2048.0f;
+  c->noise_core = 1000.0f;
+  c->n_vignette_h = c->n_vignette_v = 1;
+  for (int k = 0; k < 3; ++k) c->vignette_roll_off_h[0][k] = c->vignette_roll_off_v[0][k] = 1.0f;
+  c->bayer_pattern = 2;  // "GBRG"
+  c->output_bpp = 8;     // Raw2Rgb.cpp flag defaults
+  c->demosaic_filter = 2;
+  c->resize = 1;
+}
+
+void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.h:464-607
+  const s360_isp_config flags = *c;
+  isp_config_defaults(c);
+  c->output_bpp = flags.output_bpp;
+  c->demosaic_filter = flags.demosaic_filter;
+  c->resize = flags.resize;
+  c->disable_tone_curve = flags.disable_tone_curve;
+  c->black_level_offset = flags.black_level_offset;
+  const std::string s(text);
+  JP p{s.data(), s.data() + s.size()};
+  const JV root = p.value();
+  const JV* isp = root.get("CameraIsp");
+  if (!isp || isp->t != JV::OBJ) return;  // "Missing CameraIsp: using defaults"
+  vec3(*isp, "blackLevel", c->black_level);
+  vec3(*isp, "clampMin", c->clamp_min);
+  vec3(*isp, "clampMax", c->clamp_max);
+  vec3(*isp, "whiteBalanceGain", c->white_balance_gain);
+  vec3(*isp, "gamma", c->gamma);
+  vec3(*isp, "lowKeyBoost", c->low_key_boost);
+  vec3(*isp, "highKeyBoost", c->high_key_boost);
+  vec3(*isp, "sharpening", c->sharpening);
+  num(*isp, "saturation", &c->saturation);
+  num(*isp, "contrast", &c->contrast);
+  num(*isp, "sharpeningSupport", &c->sharpening_support);
+  num(*isp, "noiseCore", &c->noise_core);
+  coord_list(*isp, "vignetteRollOffH", c->vignette_roll_off_h, &c->n_vignette_h);
+  coord_list(*isp, "vignetteRollOffV", c->vignette_roll_off_v, &c->n_vignette_v);
+  if (const JV* m = isp->get("ccm")) {
+    if (m->t != JV::ARR || m->arr.size() != 3) throw Error(S360_ERR_IO, "isp json: 'ccm' is not 3x3");
+    for (int i = 0; i < 3; ++i) {
+      if (m->arr[i].t != JV::ARR || m->arr[i].arr.size() != 3) throw Error(S360_ERR_IO, "isp json: 'ccm' is not 3x3");
+      for (int j = 0; j < 3; ++j) c->ccm[i * 3 + j] = (float)m->arr[i].arr[j].num;
+    }
+  }
+  if (const JV* r = isp->get("stuckPixelRadius")) c->stuck_pixel_radius = 2 * (int)r->num;
+  if (const JV* b = isp->get("bayerPattern")) {  // setup(): the first of these names the string contains
+    static const char* names[4] = {"RGGB", "GRBG", "GBRG", "BGGR"};
+    int found = -1;
+    for (int i = 0; i < 4 && found < 0; ++i)
+      if (b->str.find(names[i]) != std::string::npos) found = i;
+    if (found < 0) throw Error(S360_ERR_IO, "isp json: unknown bayerPattern '" + b->str + "'");
+    c->bayer_pattern = found;
+  }
+}
+
+// Everything the kernels need that depends on the configuration only — host arithmetic like the reference's
+// (CameraIsp::setup, buildToneCurveLut, addBlackLevelOffset). No device involved.
+void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut) {
+  if (cfg.output_bpp != 8 && cfg.output_bpp != 16) throw Error(S360_ERR_INVALID_ARG, "output_bpp must be 8 or 16");
+  if (cfg.demosaic_filter == 1) throw Error(S360_ERR_INVALID_ARG, "demosaic_filter 1 (DCT) is not supported");
+  if (cfg.demosaic_filter != 0 && cfg.demosaic_filter != 2) throw Error(S360_ERR_INVALID_ARG, "expecting Demosaic filter in [0,2]");
+  if (cfg.resize != 1 && cfg.resize != 2 && cfg.resize != 4 && cfg.resize != 8)
+    throw Error(S360_ERR_INVALID_ARG, "expecting a resize value of 1, 2, 4, or 8. got " + std::to_string(cfg.resize));
+  if (cfg.stuck_pixel_radius > 0) throw Error(S360_ERR_INVALID_ARG, "stuck-pixel removal (stuckPixelRadius > 0) is not supported");
+  if (cfg.bayer_pattern < 0 || cfg.bayer_pattern > 3) throw Error(S360_ERR_INVALID_ARG, "bayer_pattern must be 0..3");
+  if (cfg.n_vignette_h < 1 || cfg.n_vignette_h > S360_ISP_MAX_CURVE_POINTS || cfg.n_vignette_v < 1 ||
+      cfg.n_vignette_v > S360_ISP_MAX_CURVE_POINTS)
+    throw Error(S360_ERR_INVALID_ARG, "vignette curves need 1..16 control points");
+  std::memset(&d, 0, sizeof d);
+  d.resize = cfg.resize;
+  d.demosaic = cfg.demosaic_filter;
+  d.outputBpp = cfg.output_bpp;
+  static const unsigned R[4] = {1u << 0, 1u << 1, 1u << 2, 1u << 3};               // red site: bit i * 2 + j
+  static const unsigned G[4] = {(1u << 1) | (1u << 2), (1u << 0) | (1u << 3), (1u << 0) | (1u << 3), (1u << 1) | (1u << 2)};
+  d.redMask = R[cfg.bayer_pattern];
+  d.greenMask = G[cfg.bayer_pattern];
+  const int maxPixelValue = 65535;  // 16-bit input (loadImage)
+  d.areaRecip = 1.0f / (maxPixelValue * float(cfg.resize * cfg.resize));
+  for (int k = 0; k < 3; ++k) {
+    const float bl = cfg.black_level[k] + float(cfg.black_level_offset);  // addBlackLevelOffset
+    d.black[k] = bl / float(maxPixelValue);
+    d.blackScale[k] = 1.0f / (1.0f - d.black[k]);
+    d.wb[k] = cfg.white_balance_gain[k];
+    d.clampMin[k] = cfg.clamp_min[k];
+    d.clampMax[k] = cfg.clamp_max[k];
+    d.amount[k] = 1.0f + cfg.sharpening[k];
+  }
+  d.sharpen = cfg.sharpening[0] != 0.0 && cfg.sharpening[1] != 0.0 && cfg.sharpening[2] != 0.0;
+  d.noiseCore = cfg.noise_core;
+  d.maxVal = (1 << cfg.output_bpp) - 1.0f;
+  d.alpha = powf(cfg.sharpening_support, 1.0f / 4.0f);
+  // CameraIsp::setup (:662-686): satMat = yuv2rgb * diag(1, sat, sat) * rgb2yuv; compositeCCM = ccm^T * satMat * 4095
+  static const float rgb2yuv[9] = {0.299f, 0.587f, 0.114f, -0.14713f, -0.28886f, 0.436f, 0.615f, -0.51499f, -0.10001f};
+  static const float yuv2rgb[9] = {1.0f, 0.0f, 1.13983f, 1.0f, -0.39465f, -0.58060f, 1.0f, 2.03211f, 0.0f};
+  const float sat[9] = {1.0f, 0, 0, 0, cfg.saturation, 0, 0, 0, cfg.saturation};
+  float tmp[9], satMat[9], ccmT[9], comp[9];
+  mul33(yuv2rgb, sat, tmp);
+  mul33(tmp, rgb2yuv, satMat);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) ccmT[j * 3 + i] = cfg.ccm[i * 3 + j];
+  mul33(ccmT, satMat, comp);
+  for (int i = 0; i < 9; ++i) comp[i] = comp[i] * 4095.0f;
+  std::memcpy(d.ccm, comp, sizeof comp);
+  // buildToneCurveLut (:390-425)
+  lut.resize(4096 * 3);
+  const float range = float((1 << cfg.output_bpp) - 1);
+  const float dx = 1.0f / 4095.0f;
+  const float angle = M_PI * 0.25f * cfg.contrast;
+  const float slope = tanf(angle);
+  const float bias = 0.5f * (1.0f - slope);
+  for (int i = 0; i < 4096; ++i) {
+    const float x = dx * i;
+    float* e = &lut[(size_t)i * 3];
+    if (cfg.disable_tone_curve) {
+      e[0] = e[1] = e[2] = x * range;
+    } else {
+      for (int k = 0; k < 3; ++k) {
+        float v = powf(x, cfg.gamma[k]);
+        v = low_key(cfg.low_key_boost[k], v) + high_key(cfg.high_key_boost[k], v);
+        e[k] = clampf((slope * v + bias) * range, 0.0f, range);
+      }
+    }
+  }
+}
+
+void isp_vignette_curves(const s360_isp_config& cfg, int w, int h, std::vector<float>& ch, std::vector<float>& cv) {
+  const int maxDimension = std::max(w, h);  // curveHAtPixel / curveVAtPixel (CameraIsp.h:709-715)
+  ch.resize((size_t)w * 3);
+  cv.resize((size_t)h * 3);
+  for (int j = 0; j < w; ++j)
+    for (int k = 0; k < 3; ++k) ch[(size_t)j * 3 + k] = bezier(cfg.vignette_roll_off_h, k, 0, cfg.n_vignette_h - 1, float(j) / float(maxDimension));
+  for (int i = 0; i < h; ++i)
+    for (int k = 0; k < 3; ++k) cv[(size_t)i * 3 + k] = bezier(cfg.vignette_roll_off_v, k, 0, cfg.n_vignette_v - 1, float(i) / float(maxDimension));
+}
+
+void isp_init(s360_isp* o, int device, const s360_isp_config& cfg) {
+  isp_derive(cfg, o->dev, o->lut);
+  o->ccm.assign(o->dev.ccm, o->dev.ccm + 9);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Error(S360_ERR_NO_DEVICE, "no HIP device available (libs360 has no CPU path)");
+  if (device < 0 || device >= ndev) throw Error(S360_ERR_INVALID_ARG, "device index out of range");
+  o->device = device;
+  o->cfg = cfg;
+  S360_HIP(hipSetDevice(device));
+  S360_HIP(hipStreamCreateWithFlags(&o->st, hipStreamNonBlocking));
+  o->dLut.ensure(o->lut.size() * sizeof(float));
+  S360_HIP(hipMemcpyAsync(o->dLut.p, o->lut.data(), o->lut.size() * sizeof(float), hipMemcpyHostToDevice, o->st));
+  // 2^(i/32) bit patterns minus i << 47 (the table of glibc's expf, see isp_kernels.hip)
+  unsigned long long tab[32];
+  for (int i = 0; i < 32; ++i) {
+    const double v = exp2((double)i / 32);
+    unsigned long long u;
+    std::memcpy(&u, &v, 8);
+    tab[i] = u - ((unsigned long long)i << 47);
+  }
+  o->dExp.ensure(sizeof tab);
+  S360_HIP(hipMemcpyAsync(o->dExp.p, tab, sizeof tab, hipMemcpyHostToDevice, o->st));
+  S360_HIP(hipStreamSynchronize(o->st));
+}
+
+void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out) {
+  const s360_isp_config& cfg = o->cfg;
+  const int w = inW / cfg.resize, h = inH / cfg.resize;
+  // the 9x9 homogeneity window and the reflected +-2 taps index up to 4 pixels past an edge (the reference reads out
+  // of bounds below that size)
+  if (w < 8 || h < 8) throw Error(S360_ERR_INVALID_ARG, "image too small for the ISP (needs at least 8x8 after resize)");
+  S360_HIP(hipSetDevice(o->device));
+  const size_t n = (size_t)w * h;
+  if (o->curveW != w || o->curveH != h) {  // vignette curves at every column / row (curveHAtPixel / curveVAtPixel)
+    std::vector<float> ch, cv;
+    isp_vignette_curves(cfg, w, h, ch, cv);
+    o->dCurveH.ensure(ch.size() * sizeof(float));
+    o->dCurveV.ensure(cv.size() * sizeof(float));
+    S360_HIP(hipMemcpyAsync(o->dCurveH.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice, o->st));
+    S360_HIP(hipMemcpyAsync(o->dCurveV.p, cv.data(), cv.size() * sizeof(float), hipMemcpyHostToDevice, o->st));
+    S360_HIP(hipStreamSynchronize(o->st));  // the staging vectors go out of scope
+    o->curveW = w;
+    o->curveH = h;
+  }
+  const size_t outBytes = n * 3 * (cfg.output_bpp == 8 ? 1 : 2);
+  o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
+  o->dPlane.ensure(n * sizeof(float));
+  o->dImg.ensure(n * 3 * sizeof(float));
+  o->dOut.ensure(outBytes);
+  if (cfg.demosaic_filter == 2) {
+    o->dGV.ensure(n * sizeof(float));
+    o->dGH.ensure(n * sizeof(float));
+    o->dGreen.ensure(n * sizeof(float));
+    o->dFlag.ensure(n);
+  }
+  if (o->dev.sharpen) {
+    o->dLp.ensure(n * 3 * sizeof(float));
+    o->dScratch.ensure(n * 3 * sizeof(float));
+  }
+  S360_HIP(hipMemcpyAsync(o->dRaw.p, raw16, (size_t)inW * inH * sizeof(uint16_t), hipMemcpyHostToDevice, o->st));
+  IspFrameBufs B;
+  B.plane = o->dPlane.as<float>();
+  B.gV = o->dGV.as<float>();
+  B.gH = o->dGH.as<float>();
+  B.green = o->dGreen.as<float>();
+  B.img = o->dImg.as<float>();
+  B.lp = o->dLp.as<float>();
+  B.scratch = o->dScratch.as<float>();
+  B.flag = o->dFlag.as<unsigned char>();
+  B.curveH = o->dCurveH.as<float>();
+  B.curveV = o->dCurveV.as<float>();
+  B.lut = o->dLut.as<float>();
+  B.exptab = o->dExp.as<unsigned long long>();
+  isp_launch(o->st, o->dev, o->dRaw.as<unsigned short>(), inW, inH, B, o->dOut.p);
+  S360_HIP(hipGetLastError());
+  S360_HIP(hipMemcpyAsync(out, o->dOut.p, outBytes, hipMemcpyDeviceToHost, o->st));
+  S360_HIP(hipStreamSynchronize(o->st));
+}
+
+void isp_release(s360_isp* o) {
+  if (o->st) {
+    (void)hipSetDevice(o->device);
+    (void)hipStreamSynchronize(o->st);
+    (void)hipStreamDestroy(o->st);
+    o->st = nullptr;
+  }
+}
+
+}  // namespace s360

@@ -1,0 +1,51 @@
+// isp.hpp — internal interface of the soft ISP (isp.cpp: configuration, host-built tables, per-object buffers;
+// isp_kernels.hip: the kernels). Reference: surround360_render/source/camera_isp/CameraIsp.h.
+#pragma once
+#include <vector>
+
+#include "../../include/s360.h"
+#include "core.hpp"
+
+namespace s360 {
+
+// kernel parameters derived from the configuration on the host (passed by value)
+struct IspDev {
+  int resize, demosaic, outputBpp, sharpen;
+  unsigned redMask, greenMask;  // bit (i & 1) * 2 + (j & 1) of the Bayer tables (CameraIsp.h:613-660)
+  float areaRecip;              // 1 / (65535 * resize^2) (resizeInput)
+  float black[3], blackScale[3], wb[3], clampMin[3], clampMax[3];
+  float ccm[9];                 // composite CCM x 4095
+  float noiseCore, amount[3], maxVal, alpha;
+};
+struct IspFrameBufs {
+  float *plane, *gV, *gH, *green, *img, *lp, *scratch;
+  unsigned char* flag;
+  const float *curveH, *curveV, *lut;
+  const unsigned long long* exptab;
+};
+void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int inW, int inH, const IspFrameBufs& B,
+                void* out);
+
+}  // namespace s360
+
+// The object behind the C ABI (s360_isp_*).
+struct s360_isp {
+  int device = 0;
+  hipStream_t st = nullptr;
+  s360_isp_config cfg;
+  s360::IspDev dev;
+  std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
+  s360::DevBuf dLut, dExp, dCurveH, dCurveV, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dOut;
+  int curveW = -1, curveH = -1;
+  std::string err;
+};
+
+namespace s360 {
+void isp_config_defaults(s360_isp_config* c);
+void isp_config_from_json(const char* text, s360_isp_config* c);
+void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut);
+void isp_vignette_curves(const s360_isp_config& cfg, int w, int h, std::vector<float>& ch, std::vector<float>& cv);
+void isp_init(s360_isp* o, int device, const s360_isp_config& cfg);
+void isp_process(s360_isp* o, const uint16_t* raw16, int w, int h, void* out);
+void isp_release(s360_isp* o);
+}  // namespace s360

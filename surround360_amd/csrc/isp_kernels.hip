@@ -1,0 +1,318 @@
+// isp_kernels.hip — the soft ISP of Surround360 on gfx950: 16-bit Bayer raw -> BGR.
+//
+// Reference: surround360_render/source/camera_isp/CameraIsp.h (the non-accelerated path of Raw2Rgb,
+// Raw2Rgb.cpp:441-456): loadImage/resizeInput (:338-358, 831-854), blackLevelAdjust (:1106-1126), antiVignette
+// (:1145-1154), whiteBalance (:1005-1021), clampAndStretch (:1128-1143), demosaicBilinearFilter (:89-148),
+// demosaicEdgeAware (:181-335), colorCorrect (:1214-1242), sharpen (:1244-1259; util/Filter.h:38-126), getImage
+// (:1275-1299). float32 in the reference's operation order (the library is built with -ffp-contract=off).
+//
+// Kernels (all HBM-bound streaming / small-stencil passes over planes of 4 B per pixel):
+//   k_isp_front        raw16 -> normalised Bayer plane (box resize, black level, vignette curves, white balance, clamp)
+//   k_isp_green_cand   vertical / horizontal green candidates and the "horizontal is smoother" flag
+//   k_isp_green_pick   9x9 vote over the flags -> the green plane
+//   k_isp_color<DM>    red / blue by constant-hue interpolation (or the bilinear demosaic), composite CCM, tone LUT
+//   k_isp_iir_rows / k_isp_iir_cols   the two-tap IIR low pass (causal + anticausal, reflected ends), one chain per
+//                      (row, channel) / (column, channel) as in the reference — the recurrence cannot be re-associated
+//   k_isp_finish       unsharp mask with noise coring (exact expf, below) and the float -> 8/16-bit BGR store
+#include "isp.hpp"
+
+#include "devmath.hpp"
+
+namespace s360 {
+
+namespace {
+
+__device__ __forceinline__ int reflecti(int x, int r) { return x < 0 ? -x : x >= r ? 2 * r - x - 2 : x; }  // MathUtil.h:43-46
+__device__ __forceinline__ float clampf(float x, float a, float b) { return x < a ? a : x > b ? b : x; }     // MathUtil.h:38-41
+__device__ __forceinline__ float lerpf(float x0, float x1, float a) { return x0 * (1.0f - a) + x1 * a; }     // MathUtil.h:58-61
+__device__ __forceinline__ float bilerpf(float x00, float x01, float x10, float x11, float a, float b) {
+  return lerpf(lerpf(x00, x01, a), lerpf(x10, x11, a), b);
+}
+__device__ __forceinline__ bool is_red(const IspDev& d, int i, int j) { return (d.redMask >> ((i & 1) * 2 + (j & 1))) & 1; }
+__device__ __forceinline__ bool is_green(const IspDev& d, int i, int j) { return (d.greenMask >> ((i & 1) * 2 + (j & 1))) & 1; }
+
+// expf as glibc 2.35 computes it on x86-64 with FMA (sysdeps/ieee754/flt-32/e_expf.c through the multiarch FMA
+// build): double arithmetic, 32-entry 2^(i/32) table, cubic in double, with the contractions gcc -mfma makes.
+// tools/expf_check.c compares this sequence with the host's expf for every float <= 0 (2 139 095 041 values): no
+// difference. Only arguments <= 0 occur (noise coring). The table is built on the host with exp2().
+__device__ __forceinline__ float expf_glibc_neg(float x, const unsigned long long* __restrict__ tab) {
+  const unsigned ux = __float_as_uint(x);
+  const unsigned abstop = (ux >> 20) & 0x7ff;
+  if (abstop >= (0x42b00000u >> 20)) {  // |x| >= 88 or NaN
+    if (ux == 0xff800000u) return 0.0f;
+    if (abstop >= (0x7f800000u >> 20)) return x + x;
+    if (x < -0x1.9fe368p6f) return 0.0f;      // underflow
+    if (x < -0x1.9d1d9ep6f) return 0x1p-149f;  // __math_may_uflowf
+  }
+  const double kInvLn2N = 0x1.71547652b82fep+0 * 32, kShift = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+  const double xd = (double)x;
+  double kd = __builtin_fma(kInvLn2N, xd, kShift);
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= kShift;
+  const double r = __builtin_fma(kInvLn2N, xd, -kd);
+  const unsigned long long t = tab[ki & 31] + (ki << (52 - 5));
+  const double s = __longlong_as_double((long long)t);
+  const double z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  y = y * s;
+  return (float)y;
+}
+
+}  // namespace
+
+// ---- front end: one thread per output pixel of the (resized) Bayer plane -------------------------------------------
+__global__ __launch_bounds__(256) void k_isp_front(const unsigned short* __restrict__ raw, int inW, int inH,
+                                                   float* __restrict__ plane, int w, int h, IspDev d,
+                                                   const float* __restrict__ curveH, const float* __restrict__ curveV) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= w) return;
+  // resizeInput<uint16_t>: sum of resize x resize samples of the same Bayer colour
+  const int rs = d.resize, rr = rs > 1 ? 2 : 1;
+  float sum = 0.0f;
+  for (int k = 0; k < rs; ++k) {
+    const int ipp = reflecti(i * rs + k * 2 + (i % rr), inH);
+    for (int l = 0; l < rs; ++l) {
+      const int jpp = reflecti(j * rs + l * 2 + (j % rr), inW);
+      sum += (float)raw[(size_t)ipp * inW + jpp];
+    }
+  }
+  float v = sum * d.areaRecip;
+  const int ch = is_red(d, i, j) ? 0 : is_green(d, i, j) ? 1 : 2;
+  if (v < 1.0f) v = (v - d.black[ch]) * d.blackScale[ch];            // blackLevelAdjust
+  v *= curveH[j * 3 + ch] * curveV[i * 3 + ch];                       // antiVignette
+  v = clampf(v * d.wb[ch], 0.0f, 1.0f);                               // whiteBalance(clampOutput)
+  const float lo = d.clampMin[ch], hi = d.clampMax[ch];               // clampAndStretch
+  v = clampf(v, lo, hi);
+  plane[(size_t)i * w + j] = (v - lo) / (hi - lo);
+}
+
+// ---- edge-aware demosaic, green channel ----------------------------------------------------------------------------
+// gV / gH: the green value interpolated along the column / the row (Laplacian-corrected with the pixel's own colour);
+// flag = (dH <= dV): the horizontal direction is at least as smooth.
+__global__ __launch_bounds__(256) void k_isp_green_cand(const float* __restrict__ p, int w, int h, IspDev d,
+                                                        float* __restrict__ gV, float* __restrict__ gH,
+                                                        unsigned char* __restrict__ flag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= w) return;
+  const int i_1 = reflecti(i - 1, h), i1 = reflecti(i + 1, h), i_2 = reflecti(i - 2, h), i2 = reflecti(i + 2, h);
+  const int j_1 = reflecti(j - 1, w), j1 = reflecti(j + 1, w), j_2 = reflecti(j - 2, w), j2 = reflecti(j + 2, w);
+  auto P = [&](int y, int x) { return p[(size_t)y * w + x]; };
+  const float c = P(i, j);
+  float v, hz, dv, dh;
+  if (is_green(d, i, j)) {
+    v = c;
+    hz = c;
+    dv = (fabsf(P(i2, j) - c) + fabsf(c - P(i_2, j))) / 2.0f;
+    dh = (fabsf(P(i, j2) - c) + fabsf(c - P(i, j_2))) / 2.0f;
+  } else {  // green neighbours above / below and left / right; the pixel's own colour two steps away
+    v = (P(i_1, j) + P(i1, j)) / 2.0f;
+    hz = (P(i, j_1) + P(i, j1)) / 2.0f;
+    dv = (fabsf(P(i_1, j) - P(i1, j))) / 2.0f;
+    dh = (fabsf(P(i, j_1) - P(i, j1))) / 2.0f;
+    v += (2.0f * c - P(i_2, j) - P(i2, j)) / 4.0f;
+    hz += (2.0f * c - P(i, j_2) - P(i, j2)) / 4.0f;
+    dv += fabsf(-2.0f * c + P(i_2, j) + P(i2, j)) / 2.0f;
+    dh += fabsf(-2.0f * c + P(i, j_2) + P(i, j2)) / 2.0f;
+  }
+  const size_t o = (size_t)i * w + j;
+  gV[o] = v;
+  gH[o] = hz;
+  flag[o] = dh <= dv ? 1 : 0;
+}
+// homogeneity vote over the 9x9 neighbourhood (reflected): fewer than 40 of 81 "horizontal" votes -> vertical
+constexpr int GP_T = 32;
+__global__ __launch_bounds__(GP_T * GP_T / 4) void k_isp_green_pick(const unsigned char* __restrict__ flag,
+                                                                    const float* __restrict__ gV,
+                                                                    const float* __restrict__ gH, int w, int h,
+                                                                    float* __restrict__ green) {
+  __shared__ unsigned char s_f[GP_T + 8][GP_T + 8];
+  __shared__ unsigned char s_r[GP_T + 8][GP_T];  // horizontal 9-sums
+  const int x0 = blockIdx.x * GP_T, y0 = blockIdx.y * GP_T, tid = threadIdx.x;
+  for (int t = tid; t < (GP_T + 8) * (GP_T + 8); t += GP_T * GP_T / 4) {
+    const int ly = t / (GP_T + 8), lx = t - ly * (GP_T + 8);
+    s_f[ly][lx] = flag[(size_t)reflecti(min(y0 + ly - 4, h + 3), h) * w + reflecti(min(x0 + lx - 4, w + 3), w)];
+  }
+  __syncthreads();
+  for (int t = tid; t < (GP_T + 8) * GP_T; t += GP_T * GP_T / 4) {
+    const int ly = t / GP_T, lx = t - ly * GP_T;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s += s_f[ly][lx + k];
+    s_r[ly][lx] = (unsigned char)s;
+  }
+  __syncthreads();
+  for (int t = tid; t < GP_T * GP_T; t += GP_T * GP_T / 4) {
+    const int ly = t / GP_T, lx = t - ly * GP_T;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cnt += s_r[ly + k][lx];
+    const size_t o = (size_t)y * w + x;
+    green[o] = cnt < 40 ? gV[o] : gH[o];  // hCount < diameterSquared / 2
+  }
+}
+
+// ---- red / blue, colour correction ---------------------------------------------------------------------------------
+// DM 2: constant-hue interpolation of (colour - green) around the pixel; DM 0: the bilinear demosaic on the Bayer plane.
+template <int DM>
+__global__ __launch_bounds__(256) void k_isp_color(const float* __restrict__ p, const float* __restrict__ green, int w,
+                                                   int h, IspDev d, const float* __restrict__ lut,
+                                                   float* __restrict__ img /*[h][w][3] r,g,b*/) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= w) return;
+  const int i_1 = reflecti(i - 1, h), i1 = reflecti(i + 1, h), j_1 = reflecti(j - 1, w), j1 = reflecti(j + 1, w);
+  auto P = [&](int y, int x) { return p[(size_t)y * w + x]; };
+  const bool redGreenRow = (is_red(d, i, 0) && is_green(d, i, 1)) || (is_red(d, i, 1) && is_green(d, i, 0));
+  const bool red = is_red(d, i, j), grn = is_green(d, i, j);
+  float r, g, b;
+  if (DM == 0) {
+    const float c = P(i, j);
+    if (red) {
+      r = c;
+      g = bilerpf(P(i_1, j), P(i1, j), P(i, j_1), P(i, j1), 0.5f, 0.5f);
+      b = bilerpf(P(i_1, j_1), P(i1, j_1), P(i_1, j1), P(i1, j1), 0.5f, 0.5f);
+    } else if (grn) {
+      g = c;
+      if (redGreenRow) {
+        b = (P(i_1, j) + P(i1, j)) / 2.0f;
+        r = (P(i, j_1) + P(i, j1)) / 2.0f;
+      } else {
+        r = (P(i_1, j) + P(i1, j)) / 2.0f;
+        b = (P(i, j_1) + P(i, j1)) / 2.0f;
+      }
+    } else {
+      b = c;
+      g = bilerpf(P(i_1, j), P(i1, j), P(i, j_1), P(i, j1), 0.5f, 0.5f);
+      r = bilerpf(P(i_1, j_1), P(i1, j_1), P(i_1, j1), P(i1, j1), 0.5f, 0.5f);
+    }
+  } else {
+    const int i_2 = reflecti(i - 2, h), i2 = reflecti(i + 2, h), j_2 = reflecti(j - 2, w), j2 = reflecti(j + 2, w);
+    auto D = [&](int y, int x) { return P(y, x) - green[(size_t)y * w + x]; };  // colour minus green at a red / blue site
+    const float pg = green[(size_t)i * w + j];
+    g = pg;
+    if (red || !grn) {
+      const float diag = (D(i_1, j_1) + D(i1, j_1) + D(i_1, j1) + D(i1, j1)) / 4.0f + pg;
+      const float own = (D(i, j) + D(i_2, j) + D(i2, j) + D(i, j_2) + D(i, j2)) / 5.0f + pg;
+      r = red ? own : diag;
+      b = red ? diag : own;
+    } else {
+      // (the reference adds (i+1, j+2) twice and never (i+1, j): CameraIsp.h:298-304)
+      const float c1 = (D(i_1, j_2) + D(i_1, j) + D(i_1, j2) + D(i1, j_2) + D(i1, j2) + D(i1, j2)) / 6.0f + pg;
+      const float c2 = (D(i_2, j_1) + D(i, j_1) + D(i2, j_1) + D(i_2, j1) + D(i, j1) + D(i2, j1)) / 6.0f + pg;
+      b = redGreenRow ? c1 : c2;
+      r = redGreenRow ? c2 : c1;
+    }
+  }
+  // colorCorrect: composite CCM (already scaled by 4095), clamp, truncate to the LUT index
+  float* o = img + ((size_t)i * w + j) * 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float v = d.ccm[k * 3] * r + d.ccm[k * 3 + 1] * g + d.ccm[k * 3 + 2] * b;
+    const int idx = (int)clampf(v, 0.0f, 4095.0f);
+    o[k] = lut[idx * 3 + k];
+  }
+}
+
+// ---- IIR low pass (Filter.h:38-90): v = ip * (1 - alpha) + v * alpha along the row, then back; reflected ends -------
+// One thread per (row, channel): `scratch` holds the causal pass ([rows][w][3]); the anticausal pass writes lp.
+__global__ __launch_bounds__(64) void k_isp_iir_rows(const float* __restrict__ img, float* __restrict__ scratch,
+                                                     float* __restrict__ lp, int w, int h, float alpha, float maxVal) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= h * 3) return;
+  const int i = t / 3, k = t - i * 3;
+  const float* src = img + (size_t)i * w * 3 + k;
+  float* buf = scratch + (size_t)i * w * 3 + k;
+  float* dst = lp + (size_t)i * w * 3 + k;
+  const float ia = 1.0f - alpha;
+  float v = src[0];
+  for (int j = 1; j <= w; ++j) {
+    v = src[(size_t)reflecti(j, w) * 3] * ia + v * alpha;
+    buf[(size_t)reflecti(j - 1, w) * 3] = v;
+  }
+  for (int j = w - 2; j >= -1; --j) {
+    v = buf[(size_t)reflecti(j, w) * 3] * ia + v * alpha;
+    dst[(size_t)(j + 1) * 3] = clampf(v, 0.0f, maxVal);
+  }
+}
+// One thread per (column, channel), in place on lp (the causal pass reads every row before the anticausal pass
+// rewrites it); consecutive threads are consecutive floats of a row: coalesced.
+__global__ __launch_bounds__(256) void k_isp_iir_cols(float* __restrict__ lp, float* __restrict__ scratch, int w, int h,
+                                                      float alpha, float maxVal) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= w * 3) return;
+  const size_t pitch = (size_t)w * 3;
+  const float ia = 1.0f - alpha;
+  float v = lp[t];
+  for (int i = 1; i <= h; ++i) {
+    v = lp[(size_t)reflecti(i, h) * pitch + t] * ia + v * alpha;
+    scratch[(size_t)reflecti(i - 1, h) * pitch + t] = v;
+  }
+  for (int i = h - 2; i >= -1; --i) {
+    v = scratch[(size_t)reflecti(i, h) * pitch + t] * ia + v * alpha;
+    lp[(size_t)(i + 1) * pitch + t] = clampf(v, 0.0f, maxVal);
+  }
+}
+
+// ---- unsharp mask with noise coring (Filter.h:92-126) + output conversion (CameraIsp.h:1275-1299) ----------------------
+template <bool SHARPEN, typename OUT>
+__global__ __launch_bounds__(256) void k_isp_finish(const float* __restrict__ img, const float* __restrict__ lp,
+                                                    size_t n /*pixels*/, IspDev d,
+                                                    const unsigned long long* __restrict__ exptab,
+                                                    OUT* __restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = img[p * 3 + k];
+    if (SHARPEN) {
+      const float l = lp[p * 3 + k];
+      const float hp = v - l;
+      const float ng = 1.0f - expf_glibc_neg(-((hp * hp) * d.noiseCore), exptab);
+      v = clampf(l + hp * ng * d.amount[k], 0.0f, d.maxVal);
+    }
+    out[p * 3 + (2 - k)] = (OUT)(int)v;  // float -> uchar / short by truncation; swizzled to B,G,R
+  }
+}
+
+// ======================================================================================================================
+void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int inW, int inH, const IspFrameBufs& B,
+                void* out) {
+  const int w = inW / d.resize, h = inH / d.resize;
+  const size_t n = (size_t)w * h;
+  const dim3 row(256), grd((w + 255) / 256, h);
+  hipLaunchKernelGGL(k_isp_front, grd, row, 0, st, raw, inW, inH, B.plane, w, h, d, B.curveH, B.curveV);
+  if (d.demosaic == 0) {
+    hipLaunchKernelGGL((k_isp_color<0>), grd, row, 0, st, B.plane, nullptr, w, h, d, B.lut, B.img);
+  } else {
+    hipLaunchKernelGGL(k_isp_green_cand, grd, row, 0, st, B.plane, w, h, d, B.gV, B.gH, B.flag);
+    hipLaunchKernelGGL(k_isp_green_pick, dim3((w + GP_T - 1) / GP_T, (h + GP_T - 1) / GP_T), dim3(GP_T * GP_T / 4), 0, st,
+                       B.flag, B.gV, B.gH, w, h, B.green);
+    hipLaunchKernelGGL((k_isp_color<2>), grd, row, 0, st, B.plane, B.green, w, h, d, B.lut, B.img);
+  }
+  const unsigned gp = (unsigned)((n + 255) / 256);
+  if (d.sharpen) {
+    hipLaunchKernelGGL(k_isp_iir_rows, dim3((h * 3 + 63) / 64), dim3(64), 0, st, B.img, B.scratch, B.lp, w, h, d.alpha,
+                       d.maxVal);
+    hipLaunchKernelGGL(k_isp_iir_cols, dim3((w * 3 + 255) / 256), dim3(256), 0, st, B.lp, B.scratch, w, h, d.alpha,
+                       d.maxVal);
+    if (d.outputBpp == 8)
+      hipLaunchKernelGGL((k_isp_finish<true, unsigned char>), dim3(gp), dim3(256), 0, st, B.img, B.lp, n, d, B.exptab,
+                         (unsigned char*)out);
+    else
+      hipLaunchKernelGGL((k_isp_finish<true, unsigned short>), dim3(gp), dim3(256), 0, st, B.img, B.lp, n, d, B.exptab,
+                         (unsigned short*)out);
+  } else {
+    if (d.outputBpp == 8)
+      hipLaunchKernelGGL((k_isp_finish<false, unsigned char>), dim3(gp), dim3(256), 0, st, B.img, nullptr, n, d,
+                         B.exptab, (unsigned char*)out);
+    else
+      hipLaunchKernelGGL((k_isp_finish<false, unsigned short>), dim3(gp), dim3(256), 0, st, B.img, nullptr, n, d,
+                         B.exptab, (unsigned short*)out);
+  }
+}
+
+}  // namespace s360

@@ -1,6 +1,8 @@
 // rig.cpp — see rig.hpp. Host-only, double precision.
 #include "rig.hpp"
 
+#include "json_mini.hpp"
+
 #include <cctype>
 #include <algorithm>
 #include <cmath>
@@ -196,89 +198,7 @@ float Rig::ring_radius() const {
   return (float)std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
 }
 
-// ---- a small recursive-descent JSON reader (objects, arrays, strings, numbers, literals) ----
 namespace {
-struct JV {
-  enum T { NUL, NUM, STR, ARR, OBJ, BOOL } t = NUL;
-  double num = 0;
-  std::string str;
-  std::vector<JV> arr;
-  std::map<std::string, JV> obj;
-  const JV* get(const char* k) const {
-    auto it = obj.find(k);
-    return it == obj.end() ? nullptr : &it->second;
-  }
-};
-struct JP {
-  const char* s;
-  const char* e;
-  void ws() { while (s < e && std::isspace((unsigned char)*s)) ++s; }
-  [[noreturn]] void fail(const char* m) { throw Error(S360_ERR_IO, std::string("rig json: ") + m); }
-  JV value() {
-    ws();
-    if (s >= e) fail("unexpected end");
-    JV v;
-    if (*s == '{') {
-      ++s; v.t = JV::OBJ; ws();
-      if (s < e && *s == '}') { ++s; return v; }
-      for (;;) {
-        ws();
-        JV k = string();
-        ws();
-        if (s >= e || *s != ':') fail("expected ':'");
-        ++s;
-        v.obj[k.str] = value();
-        ws();
-        if (s < e && *s == ',') { ++s; continue; }
-        if (s < e && *s == '}') { ++s; break; }
-        fail("expected ',' or '}'");
-      }
-    } else if (*s == '[') {
-      ++s; v.t = JV::ARR; ws();
-      if (s < e && *s == ']') { ++s; return v; }
-      for (;;) {
-        v.arr.push_back(value());
-        ws();
-        if (s < e && *s == ',') { ++s; continue; }
-        if (s < e && *s == ']') { ++s; break; }
-        fail("expected ',' or ']'");
-      }
-    } else if (*s == '"') {
-      v = string();
-    } else if (!std::strncmp(s, "true", 4)) { v.t = JV::BOOL; v.num = 1; s += 4;
-    } else if (!std::strncmp(s, "false", 5)) { v.t = JV::BOOL; s += 5;
-    } else if (!std::strncmp(s, "null", 4)) { s += 4;
-    } else {
-      char* end = nullptr;
-      v.num = std::strtod(s, &end);
-      if (end == s) fail("bad number");
-      v.t = JV::NUM;
-      s = end;
-    }
-    return v;
-  }
-  JV string() {
-    if (s >= e || *s != '"') fail("expected string");
-    ++s;
-    JV v;
-    v.t = JV::STR;
-    while (s < e && *s != '"') {
-      if (*s == '\\' && s + 1 < e) {
-        ++s;
-        switch (*s) {
-          case 'n': v.str += '\n'; break;
-          case 't': v.str += '\t'; break;
-          case 'u': s += 4; v.str += '?'; break;
-          default: v.str += *s;
-        }
-        ++s;
-      } else v.str += *s++;
-    }
-    if (s >= e) fail("unterminated string");
-    ++s;
-    return v;
-  }
-};
 void vec(const JV& o, const char* key, int n, double* out) {
   const JV* a = o.get(key);
   if (!a || a->t != JV::ARR || (int)a->arr.size() != n) throw Error(S360_ERR_IO, std::string("rig json: bad vector ") + key);

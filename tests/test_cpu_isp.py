@@ -86,3 +86,108 @@ def test_unsupported_modes_raise(oracle):
     c.stuckPixelRadius = 2
     with pytest.raises(RuntimeError):
         oracle.isp_run(c, raw)
+
+
+# ---- host half of the product (libs360, no device needed): configuration reading and derived tables -----------------
+def _cfg_pairs(oracle, name, **kw):
+    from surround360_amd import isp as I
+    js = isputil.CONFIGS[name]
+    got = I.config_from_json(js, kw.get("bpp", 8), kw.get("dm", 2), kw.get("rs", 1), kw.get("tone", 0), kw.get("off", 0))
+    want = oracle.isp_config_from_json(js, kw.get("bpp", 8), kw.get("dm", 2), kw.get("rs", 1), kw.get("tone", 0),
+                                       kw.get("off", 0))
+    return got, want
+
+
+@pytest.mark.parametrize("name", sorted(isputil.CONFIGS))
+def test_library_reads_configuration_like_the_constructor(oracle, s360lib, name):
+    """s360_isp_config_from_json against the test plumbing's independent reading of the same JSON (which the compiled
+    reference agrees with through test_restatement_equals_compiled_reference)."""
+    got, want = _cfg_pairs(oracle, name, bpp=16, dm=0, rs=2, tone=1, off=7)
+    pairs = [("black_level", "blackLevel"), ("clamp_min", "clampMin"), ("clamp_max", "clampMax"),
+             ("white_balance_gain", "whiteBalanceGain"), ("ccm", "ccm"), ("gamma", "gamma"),
+             ("low_key_boost", "lowKeyBoost"), ("high_key_boost", "highKeyBoost"), ("sharpening", "sharpening")]
+    for a, b in pairs:
+        assert list(getattr(got, a)) == list(getattr(want, b)), a
+    for a, b in [("saturation", "saturation"), ("contrast", "contrast"), ("sharpening_support", "sharpeningSupport"),
+                 ("noise_core", "noiseCore"), ("n_vignette_h", "nVignetteH"), ("n_vignette_v", "nVignetteV"),
+                 ("stuck_pixel_radius", "stuckPixelRadius"), ("bayer_pattern", "bayerPattern"),
+                 ("output_bpp", "outputBpp"), ("demosaic_filter", "demosaicFilter"), ("resize", "resize"),
+                 ("disable_tone_curve", "disableToneCurve"), ("black_level_offset", "blackLevelOffset")]:
+        assert getattr(got, a) == getattr(want, b), a
+    for i in range(got.n_vignette_h):
+        assert list(got.vignette_roll_off_h[i]) == list(want.vignetteRollOffH[i])
+    for i in range(got.n_vignette_v):
+        assert list(got.vignette_roll_off_v[i]) == list(want.vignetteRollOffV[i])
+
+
+@pytest.mark.parametrize("name,bpp,tone", [("full", 8, 0), ("full", 16, 0), ("grbg", 16, 0), ("empty", 8, 1)])
+def test_library_tables_equal_oracle(oracle, s360lib, name, bpp, tone):
+    """Composite CCM and tone curve built on the host by libs360 (powf / tanf like the reference) == the oracle's, bit
+    for bit."""
+    from surround360_amd import isp as I
+    got, want = _cfg_pairs(oracle, name, bpp=bpp, tone=tone)
+    ccm, lut, _, _ = I.config_tables(got)
+    occm, olut = oracle.isp_tables(want)
+    assert np.array_equal(ccm.view(np.uint32), occm.view(np.uint32))
+    assert np.array_equal(lut.view(np.uint32), olut.view(np.uint32))
+
+
+def test_library_rejects_unsupported(s360lib):
+    from surround360_amd import _capi, isp as I
+    with pytest.raises(_capi.S360Error):
+        I.config_from_json('{"CameraIsp": {"ccm": [[1, 0], [0, 1]]}}')
+    with pytest.raises(_capi.S360Error):
+        I.config_from_json('{"CameraIsp": {"bayerPattern": "XYZW"}}')
+    c = I.config_from_json(isputil.CONFIG_MINIMAL, demosaic_filter=1)
+    with pytest.raises(_capi.S360Error):
+        I.config_tables(c)  # DCT demosaic
+    c = I.config_from_json(isputil.CONFIG_MINIMAL, resize=3)
+    with pytest.raises(_capi.S360Error):
+        I.config_tables(c)
+
+
+def test_library_vignette_curves(s360lib):
+    """curveHAtPixel / curveVAtPixel: De Casteljau in float32, written out again here with numpy scalars."""
+    from surround360_amd import isp as I
+    import json
+    cfg = I.config_from_json(isputil.CONFIG_FULL)
+    w, h = 37, 53
+    _, _, ch, cv = I.config_tables(cfg, w, h)
+    f = np.float32
+
+    def bez(pts, t):
+        pts = [f(p) for p in pts]
+        while len(pts) > 1:  # lerp(a, b, t) = a * (1 - t) + b * t, level by level == the reference's recursion
+            pts = [f(f(a * f(f(1) - t)) + f(b * t)) for a, b in zip(pts[:-1], pts[1:])]
+        return pts[0]
+    j = json.loads(isputil.CONFIG_FULL)["CameraIsp"]
+    md = f(max(w, h))
+    for x in (0, 1, 17, 36):
+        for k in range(3):
+            assert ch[x, k] == bez([p[k] for p in j["vignetteRollOffH"]], f(f(x) / md))
+    for y in (0, 26, 52):
+        for k in range(3):
+            assert cv[y, k] == bez([p[k] for p in j["vignetteRollOffV"]], f(f(y) / md))
+
+
+# ---- the HIP kernels themselves, emulated on the CPU (developer tool: tools/hip_cpu_shim, tools/isp_emulate.cpp) ----
+@pytest.mark.parametrize("case", [("full", 64, 48, 16, 2, 1, 0, 0), ("full", 70, 50, 8, 0, 1, 0, 0),
+                                  ("grbg", 96, 64, 16, 2, 2, 0, 25)], ids=_case_id)
+def test_kernels_emulated_on_cpu(oracle, s360lib, case):
+    """isp_kernels.hip + isp.cpp compiled with g++ over a stand-in for the HIP runtime, one std::thread per GPU thread:
+    the kernels' indexing and float arithmetic (IEEE on both sides, -ffp-contract=off) against the oracle, here where no
+    GPU is attached. The GPU itself is tested by tests/test_gpu_isp.py."""
+    import ctypes as C
+    import subprocess
+    from surround360_amd import isp as I
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tools"), "-s", "libisp_emu.so"])
+    emu = C.CDLL(os.path.join(root, "tools", "libisp_emu.so"))
+    name, w, h, bpp, dm, rs, tone, off = case
+    js, raw = isputil.CONFIGS[name], isputil.bayer_frame(w, h, seed=w + h)
+    cfg = I.config_from_json(js, bpp, dm, rs, tone, off)
+    got = np.zeros((h // rs, w // rs, 3), np.uint8 if bpp == 8 else np.uint16)
+    err = C.create_string_buffer(256)
+    assert emu.emu_isp_run(C.byref(cfg), raw.ctypes.data_as(C.c_void_p), w, h, got.ctypes.data_as(C.c_void_p), err, 256) == 0, err.value
+    want = oracle.isp_run(oracle.isp_config_from_json(js, bpp, dm, rs, tone, off), raw)
+    assert np.array_equal(got, want)
