@@ -328,6 +328,10 @@ void s360_isp_destroy(s360_isp* isp);
 /* CameraIsp::loadImage + getImage(swizzle = true). raw16: h x w uint16 (host). out: (h / resize) x (w / resize) x 3,
  * B,G,R, uint8 or uint16 by output_bpp (host). */
 int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* out_bgr);
+/* The same from the sensor's packed bytes as Unpacker reads them from a .bin container (Unpacker.cpp:136-143;
+ * RawConverter::convert8Frame / convert12Frame, RawConverter.cpp:15-59): bits 8 (w * h bytes) or 12 (3 * w / 2 bytes
+ * per row, even w); widened to 16 bits on the device, then as s360_isp_process. */
+int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr);
 /* The host-side tables of a configuration (no device needed; what s360_isp_create uploads): ccm9 = composite CCM x 4095
  * (CameraIsp::setup), lut = 4096 x 3 floats (buildToneCurveLut), curve_h = w x 3 and curve_v = h x 3 vignette gains of
  * a w x h frame (curveHAtPixel / curveVAtPixel; either may be NULL). */

@@ -141,6 +141,25 @@ inline IspTables ispSetup(const IspConfig& c) {
   return t;
 }
 
+// RawConverter::convert8Frame / convert12Frame (camera_isp/RawConverter.cpp:15-59): the sensor's packed bytes -> 16-bit
+// samples. 8-bit: v * 0x101. 12-bit: three bytes hold two pixels (b0 << 4 | b1 & 15, then b2 << 4 | b1 >> 4), packed
+// continuously over the whole frame; the 12-bit value is widened by replicating its top bits (v << 4 | v >> 8).
+inline void ispUnpackFrame(int bits, const uint8_t* frame, int w, int h, uint16_t* out) {
+  const size_t n = (size_t)w * h;
+  if (bits == 8) {
+    for (size_t i = 0; i < n; ++i) out[i] = (uint16_t)(frame[i] * 0x101);
+    return;
+  }
+  size_t p = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint16_t lo = frame[p], hi = frame[p + 1];
+    uint16_t v;
+    if ((i % (size_t)w) & 1) { p += 2; v = (uint16_t)(hi << 4 | lo >> 4); }
+    else { p += 1; v = (uint16_t)(lo << 4 | (hi & 0xF)); }
+    out[i] = (uint16_t)(v << 4 | v >> 8);
+  }
+}
+
 // One frame through CameraIsp::loadImage + getImage(swizzle = true). raw: inH x inW uint16. out: (inH/resize) x
 // (inW/resize) x 3 in B,G,R order, uint8 (outputBpp 8) or uint16 bit patterns (outputBpp 16).
 inline void ispRun(const IspConfig& c, const uint16_t* raw, int inW, int inH, void* out) {

@@ -406,6 +406,7 @@ int orc_isp_run(const IspConfig* cfg, const uint16_t* raw, int w, int h, void* o
     return -1;
   }
 }
+void orc_isp_unpack_frame(int bits, const uint8_t* frame, int w, int h, uint16_t* out) { ispUnpackFrame(bits, frame, w, h, out); }
 void orc_isp_tables(const IspConfig* cfg, float* ccm9, float* lut /*4096 x 3*/) {
   const IspTables t = ispSetup(*cfg);
   std::memcpy(ccm9, t.compositeCCM, sizeof(t.compositeCCM));

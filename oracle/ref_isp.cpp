@@ -10,10 +10,17 @@
 #include <string>
 
 #include "CameraIsp.h"
+#include "RawConverter.h"
 
 using namespace surround360;
 
 extern "C" {
+// RawConverter::convert8Frame / convert12Frame (Unpacker.cpp:141-143): packed sensor bytes -> h x w uint16
+int ref_convert_frame(int bits, const void* frame, int w, int h, uint16_t* out) {
+  auto v = bits == 8 ? RawConverter::convert8Frame(frame, w, h) : RawConverter::convert12Frame(frame, w, h);
+  std::memcpy(out, v->data(), (size_t)w * h * sizeof(uint16_t));
+  return 0;
+}
 // raw16: h x w uint16 (row-major). out: (h / resize) x (w / resize) x 3, uint8 or uint16 by output_bpp, BGR order
 // (swizzle = true like Raw2Rgb's runPipeline). Returns 0, or -1 with the message in err.
 int ref_isp_run(const char* json_text, const uint16_t* raw16, int w, int h, int output_bpp, int demosaic_filter,

@@ -877,6 +877,12 @@ int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* o
     isp_process(isp, raw16, w, h, out_bgr);
   });
 }
+int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr) {
+  return guard(nullptr, [&] {
+    need(isp && frame && out_bgr && w > 0 && h > 0, "bad argument");
+    isp_process_packed(isp, frame, bits, w, h, out_bgr);
+  });
+}
 int s360_isp_config_tables(const s360_isp_config* cfg, float* ccm9, float* lut, int w, int h, float* curve_h,
                            float* curve_v) {
   return guard(nullptr, [&] {

@@ -231,13 +231,33 @@ void isp_init(s360_isp* o, int device, const s360_isp_config& cfg) {
   S360_HIP(hipStreamSynchronize(o->st));
 }
 
+static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out);
+
 void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out) {
+  S360_HIP(hipSetDevice(o->device));
+  o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
+  S360_HIP(hipMemcpyAsync(o->dRaw.p, raw16, (size_t)inW * inH * sizeof(uint16_t), hipMemcpyHostToDevice, o->st));
+  isp_run_uploaded(o, inW, inH, out);
+}
+// Unpacker's per-frame work (Unpacker.cpp:136-143, 169-183): the sensor's packed bytes are widened on the device
+void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int inW, int inH, void* out) {
+  if (bits != 8 && bits != 12) throw Error(S360_ERR_INVALID_ARG, "packed frames are 8 or 12 bits per pixel");
+  if (bits == 12 && (inW & 1)) throw Error(S360_ERR_INVALID_ARG, "12-bit packed frames need an even width");
+  S360_HIP(hipSetDevice(o->device));
+  const size_t bytes = bits == 8 ? (size_t)inW * inH : (size_t)inH * (3 * (size_t)inW / 2);
+  o->dPacked.ensure(bytes);
+  o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
+  S360_HIP(hipMemcpyAsync(o->dPacked.p, frame, bytes, hipMemcpyHostToDevice, o->st));
+  isp_launch_unpack(o->st, o->dPacked.as<unsigned char>(), bits, inW, inH, o->dRaw.as<unsigned short>());
+  isp_run_uploaded(o, inW, inH, out);
+}
+
+static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out) {
   const s360_isp_config& cfg = o->cfg;
   const int w = inW / cfg.resize, h = inH / cfg.resize;
   // the 9x9 homogeneity window and the reflected +-2 taps index up to 4 pixels past an edge (the reference reads out
   // of bounds below that size)
   if (w < 8 || h < 8) throw Error(S360_ERR_INVALID_ARG, "image too small for the ISP (needs at least 8x8 after resize)");
-  S360_HIP(hipSetDevice(o->device));
   const size_t n = (size_t)w * h;
   if (o->curveW != w || o->curveH != h) {  // vignette curves at every column / row (curveHAtPixel / curveVAtPixel)
     std::vector<float> ch, cv;
@@ -251,7 +271,6 @@ void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out
     o->curveH = h;
   }
   const size_t outBytes = n * 3 * (cfg.output_bpp == 8 ? 1 : 2);
-  o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
   o->dPlane.ensure(n * sizeof(float));
   o->dImg.ensure(n * 3 * sizeof(float));
   o->dOut.ensure(outBytes);
@@ -265,7 +284,6 @@ void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out
     o->dLp.ensure(n * 3 * sizeof(float));
     o->dScratch.ensure(n * 3 * sizeof(float));
   }
-  S360_HIP(hipMemcpyAsync(o->dRaw.p, raw16, (size_t)inW * inH * sizeof(uint16_t), hipMemcpyHostToDevice, o->st));
   IspFrameBufs B;
   B.plane = o->dPlane.as<float>();
   B.gV = o->dGV.as<float>();

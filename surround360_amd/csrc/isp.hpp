@@ -23,6 +23,7 @@ struct IspFrameBufs {
   const float *curveH, *curveV, *lut;
   const unsigned long long* exptab;
 };
+void isp_launch_unpack(hipStream_t st, const unsigned char* frame, int bits, int w, int h, unsigned short* out);
 void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int inW, int inH, const IspFrameBufs& B,
                 void* out);
 
@@ -35,7 +36,7 @@ struct s360_isp {
   s360_isp_config cfg;
   s360::IspDev dev;
   std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
-  s360::DevBuf dLut, dExp, dCurveH, dCurveV, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dOut;
+  s360::DevBuf dLut, dExp, dCurveH, dCurveV, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dOut, dPacked;
   int curveW = -1, curveH = -1;
   std::string err;
 };
@@ -47,5 +48,6 @@ void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut);
 void isp_vignette_curves(const s360_isp_config& cfg, int w, int h, std::vector<float>& ch, std::vector<float>& cv);
 void isp_init(s360_isp* o, int device, const s360_isp_config& cfg);
 void isp_process(s360_isp* o, const uint16_t* raw16, int w, int h, void* out);
+void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int w, int h, void* out);
 void isp_release(s360_isp* o);
 }  // namespace s360

@@ -63,6 +63,29 @@ __device__ __forceinline__ float expf_glibc_neg(float x, const unsigned long lon
 
 }  // namespace
 
+// ---- RawConverter::convert8Frame / convert12Frame (RawConverter.cpp:15-59): packed sensor bytes -> 16-bit samples ------
+// 12-bit: three bytes hold two pixels (b0 << 4 | b1 & 15, then b2 << 4 | b1 >> 4); the value is widened by replicating
+// its top bits (v << 4 | v >> 8). Even widths only (a row is then 3 w / 2 bytes; the reference's running byte pointer
+// reads past the row for odd widths).
+__global__ __launch_bounds__(256) void k_isp_unpack(const unsigned char* __restrict__ frame, int bits, int w, int h,
+                                                    unsigned short* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  unsigned v;
+  if (bits == 8) {
+    v = (unsigned)frame[(size_t)y * w + x] * 0x101u;
+  } else {
+    const unsigned char* p = frame + (size_t)y * (3 * (size_t)w / 2) + (size_t)(x >> 1) * 3 + (x & 1);
+    const unsigned lo = p[0], hi = p[1];
+    const unsigned u = (x & 1) ? (hi << 4 | lo >> 4) : (lo << 4 | (hi & 0xFu));
+    v = (u << 4 | u >> 8) & 0xFFFFu;
+  }
+  out[(size_t)y * w + x] = (unsigned short)v;
+}
+void isp_launch_unpack(hipStream_t st, const unsigned char* frame, int bits, int w, int h, unsigned short* out) {
+  hipLaunchKernelGGL(k_isp_unpack, dim3((w + 255) / 256, h), dim3(256), 0, st, frame, bits, w, h, out);
+}
+
 // ---- front end: one thread per output pixel of the (resized) Bayer plane -------------------------------------------
 __global__ __launch_bounds__(256) void k_isp_front(const unsigned short* __restrict__ raw, int inW, int inH,
                                                    float* __restrict__ plane, int w, int h, IspDev d,

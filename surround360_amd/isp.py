@@ -55,6 +55,15 @@ class CameraIsp:
         check(lib().s360_isp_process(self.h, raw.ctypes.data_as(C.c_void_p), ww, hh, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def get_image_packed(self, frame, bits, w, h):
+        """frame: the sensor's packed bytes of one w x h image (8 or 12 bits per pixel, as in a .bin container)."""
+        fr = np.ascontiguousarray(frame, np.uint8)
+        r = self.config.resize
+        out = np.empty((h // r, w // r, 3), np.uint8 if self.config.output_bpp == 8 else np.uint16)
+        check(lib().s360_isp_process_packed(self.h, fr.ctypes.data_as(C.c_void_p), bits, w, h,
+                                            out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         if self.h:
             lib().s360_isp_destroy(self.h)

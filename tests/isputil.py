@@ -51,3 +51,17 @@ def bayer_frame(w, h, seed=0, pattern="GBRG", bits=16):
         for j in range(2):
             raw[i::2, j::2] = rgb[i::2, j::2, idx[pattern[i * 2 + j]]]
     return np.clip(raw * 65535.0 + 0.06 * 65535, 0, 65535).astype(np.uint16)
+
+
+def pack_frame(raw16, bits):
+    """The sensor-side packing RawConverter undoes: raw16 (H x W uint16) -> bytes of an 8- or 12-bit frame (even W)."""
+    h, w = raw16.shape
+    if bits == 8:
+        return (raw16 >> 8).astype(np.uint8).ravel()
+    v = (raw16 >> 4).astype(np.uint32)  # 12-bit samples
+    a, b = v[:, 0::2], v[:, 1::2]
+    out = np.zeros((h, w // 2, 3), np.uint8)
+    out[..., 0] = a >> 4
+    out[..., 1] = (a & 0xF) | ((b & 0xF) << 4)
+    out[..., 2] = b >> 4
+    return out.ravel()

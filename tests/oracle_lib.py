@@ -502,3 +502,22 @@ def ref_isp_run(json_text, raw, output_bpp=8, demosaic_filter=2, resize=1, disab
                                  disable_tone_curve, black_level_offset, _p(out), err, 256) != 0:
         raise RuntimeError(err.value.decode())
     return out
+
+
+def isp_packed_bytes(bits, w, h):
+    return w * h if bits == 8 else h * (3 * w // 2)
+
+
+def isp_unpack_frame(frame, bits, w, h):
+    """oracle: RawConverter::convert8Frame / convert12Frame."""
+    fr = np.ascontiguousarray(frame, np.uint8)
+    out = np.zeros((h, w), np.uint16)
+    lib().orc_isp_unpack_frame(bits, _p(fr), w, h, _p(out))
+    return out
+
+
+def ref_unpack_frame(frame, bits, w, h):
+    fr = np.ascontiguousarray(frame, np.uint8)
+    out = np.zeros((h, w), np.uint16)
+    ref_isp_lib().ref_convert_frame(bits, _p(fr), w, h, _p(out))
+    return out

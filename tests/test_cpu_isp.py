@@ -191,3 +191,41 @@ def test_kernels_emulated_on_cpu(oracle, s360lib, case):
     assert emu.emu_isp_run(C.byref(cfg), raw.ctypes.data_as(C.c_void_p), w, h, got.ctypes.data_as(C.c_void_p), err, 256) == 0, err.value
     want = oracle.isp_run(oracle.isp_config_from_json(js, bpp, dm, rs, tone, off), raw)
     assert np.array_equal(got, want)
+
+
+# ---- packed sensor frames (Unpacker.cpp:136-143; RawConverter.cpp:15-59) ---------------------------------------------
+@pytest.mark.parametrize("bits,w,h", [(8, 64, 48), (12, 64, 48), (12, 130, 7), (8, 63, 5)])
+def test_unpack_restatement_equals_compiled_reference(ref, bits, w, h):
+    rng = np.random.default_rng(bits + w)
+    frame = rng.integers(0, 256, ref.isp_packed_bytes(bits, w, h) + 2, dtype=np.uint8)
+    a, b = ref.isp_unpack_frame(frame, bits, w, h), ref.ref_unpack_frame(frame, bits, w, h)
+    assert np.array_equal(a, b)
+
+
+def test_unpack_inverts_packing(oracle):
+    raw = isputil.bayer_frame(64, 32, seed=3)
+    got = oracle.isp_unpack_frame(isputil.pack_frame(raw, 12), 12, 64, 32)
+    v = (raw >> 4).astype(np.uint32)
+    assert np.array_equal(got, ((v << 4) | (v >> 8)).astype(np.uint16))  # 12 -> 16 bits by replicating the top bits
+    got8 = oracle.isp_unpack_frame(isputil.pack_frame(raw, 8), 8, 64, 32)
+    assert np.array_equal(got8, (raw >> 8).astype(np.uint16) * 0x101)
+
+
+def test_packed_path_emulated_on_cpu(oracle, s360lib):
+    import ctypes as C
+    import subprocess
+    from surround360_amd import isp as I
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "tools"), "-s", "libisp_emu.so"])
+    emu = C.CDLL(os.path.join(root, "tools", "libisp_emu.so"))
+    w, h = 64, 48
+    for bits in (12, 8):
+        frame = isputil.pack_frame(isputil.bayer_frame(w, h, seed=9), bits)
+        cfg = I.config_from_json(isputil.CONFIG_GRBG_NOSHARP, 16)
+        got = np.zeros((h, w, 3), np.uint16)
+        err = C.create_string_buffer(256)
+        assert emu.emu_isp_run_packed(C.byref(cfg), frame.ctypes.data_as(C.c_void_p), bits, w, h,
+                                      got.ctypes.data_as(C.c_void_p), err, 256) == 0, err.value
+        raw16 = oracle.isp_unpack_frame(frame, bits, w, h)
+        want = oracle.isp_run(oracle.isp_config_from_json(isputil.CONFIG_GRBG_NOSHARP, 16), raw16)
+        assert np.array_equal(got, want), bits

@@ -47,3 +47,21 @@ def test_isp_two_sizes_one_object(oracle, s360lib):
             assert np.array_equal(isp.get_image(raw), oracle.isp_run(oracle.isp_config_from_json(js, 16), raw))
     finally:
         isp.close()
+
+
+@pytest.mark.parametrize("bits", [12, 8])
+def test_isp_from_packed_sensor_frames(oracle, s360lib, bits):
+    """Unpacker's per-frame work: packed 8- / 12-bit sensor bytes -> 16-bit samples on the device -> ISP."""
+    from surround360_amd import _capi, isp as I
+    w, h = 256, 160
+    frame = isputil.pack_frame(isputil.bayer_frame(w, h, seed=bits), bits)
+    js = isputil.CONFIG_FULL
+    want = oracle.isp_run(oracle.isp_config_from_json(js, 16), oracle.isp_unpack_frame(frame, bits, w, h))
+    isp = I.CameraIsp(I.config_from_json(js, 16))
+    try:
+        got = isp.get_image_packed(frame, bits, w, h)
+        assert np.array_equal(got, want)
+        with pytest.raises(_capi.S360Error):
+            isp.get_image_packed(frame, 10, w, h)
+    finally:
+        isp.close()

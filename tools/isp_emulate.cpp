@@ -10,6 +10,18 @@ EmuBarrier g_emu_barrier;
 #include "../surround360_amd/csrc/isp.hpp"
 #include <cstring>
 
+extern "C" int emu_isp_run_packed(const s360_isp_config* cfg, const uint8_t* frame, int bits, int w, int h, void* out, char* err, int cap) {
+  try {
+    s360_isp o;
+    s360::isp_init(&o, 0, *cfg);
+    s360::isp_process_packed(&o, frame, bits, w, h, out);
+    s360::isp_release(&o);
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && cap > 0) { std::strncpy(err, e.what(), cap - 1); err[cap - 1] = 0; }
+    return -1;
+  }
+}
 extern "C" int emu_isp_run(const s360_isp_config* cfg, const uint16_t* raw, int w, int h, void* out, char* err, int cap) {
   try {
     s360_isp o;
