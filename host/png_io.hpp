@@ -1,6 +1,6 @@
 // png_io.hpp — minimal PNG codec on zlib for the host binary (the reference uses cv::imread / cv::imwrite,
 // RigDescription.cpp:87-105, TRSP:961). Reads every PNG colour type and bit depth (1..16 bits, Adam7 interlace) into
-// 8-bit B,G,R(,A) like imread's 8-bit decode; writes 8-bit RGB / RGBA and fails loudly on a short write. Pixel order at this interface is OpenCV's: B,G,R(,A).
+// 8-bit B,G,R(,A) like imread's 8-bit decode; writes 8-bit RGB / RGBA (and the ISP's 16-bit RGB) and fails loudly on a short write; read_gray keeps the depth of 8-/16-bit greyscale raw images. Pixel order at this interface is OpenCV's: B,G,R(,A).
 #pragma once
 #include <zlib.h>
 
@@ -184,9 +184,11 @@ inline void chunk(OutFile& f, const char* type, const uint8_t* data, size_t len)
 // frame. The scanlines are therefore deflated in parallel (pigz-style): bands of rows become independent raw-deflate
 // streams that end with a sync flush (byte-aligned, no final block) — concatenated they are ONE valid deflate stream;
 // the zlib header and the Adler-32 of the whole image (adler32_combine of the bands) are added around them.
-inline void write(const std::string& path, const uint8_t* px, int w, int h, int c, int level = 1, int max_threads = 0) {
+// fill_row(y, dst) writes the (w * c * depth / 8) bytes of scanline y in PNG order (R,G,B(,A); 16-bit samples big-endian).
+template <typename FillRow>
+inline void write_rows(const std::string& path, FillRow fill_row, int w, int h, int c, int depth, int level, int max_threads) {
   if (c != 3 && c != 4) throw std::runtime_error("png write: 3 or 4 channels only");
-  const size_t stride = (size_t)w * c + 1;
+  const size_t stride = (size_t)w * c * (depth / 8) + 1;
   // bands of ~2 MB of scanlines
   const int rows_per_band = (int)std::max<size_t>(1, std::min<size_t>((size_t)h, ((size_t)2 << 20) / stride + 1));
   const int nbands = (h + rows_per_band - 1) / rows_per_band;
@@ -199,12 +201,8 @@ inline void write(const std::string& path, const uint8_t* px, int w, int h, int 
     uint8_t* o = raw.data();
     for (int y = y0; y < y1; ++y) {
       *o++ = 0;  // filter type None
-      const uint8_t* s = px + (size_t)y * w * c;
-      for (int x = 0; x < w; ++x) {
-        o[0] = s[2]; o[1] = s[1]; o[2] = s[0];
-        if (c == 4) o[3] = s[3];
-        o += c; s += c;
-      }
+      fill_row(y, o);
+      o += stride - 1;
     }
     B.raw = raw.size();
     B.adler = adler32(1L, raw.data(), (uInt)raw.size());
@@ -243,7 +241,7 @@ inline void write(const std::string& path, const uint8_t* px, int w, int h, int 
   f.put(sig, 8);
   uint8_t ihdr[13];
   put32(ihdr, (uint32_t)w); put32(ihdr + 4, (uint32_t)h);
-  ihdr[8] = 8; ihdr[9] = c == 3 ? 2 : 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  ihdr[8] = (uint8_t)depth; ihdr[9] = c == 3 ? 2 : 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
   chunk(f, "IHDR", ihdr, 13);
   // zlib stream = header, the bands' deflate data, Adler-32; one IDAT chunk per piece
   static const uint8_t zhdr[2] = {0x78, 0x01};
@@ -264,6 +262,94 @@ inline void write(const std::string& path, const uint8_t* px, int w, int h, int 
   chunk(f, "IDAT", tail, 4);
   chunk(f, "IEND", nullptr, 0);
   f.close();
+}
+// 8-bit B,G,R(,A) -> RGB / RGBA PNG
+inline void write(const std::string& path, const uint8_t* px, int w, int h, int c, int level = 1, int max_threads = 0) {
+  write_rows(path, [=](int y, uint8_t* o) {
+    const uint8_t* s = px + (size_t)y * w * c;
+    for (int x = 0; x < w; ++x) {
+      o[0] = s[2]; o[1] = s[1]; o[2] = s[0];
+      if (c == 4) o[3] = s[3];
+      o += c; s += c;
+    }
+  }, w, h, c, 8, level, max_threads);
+}
+// 16-bit B,G,R (CV_16UC3) -> 16-bit RGB PNG (big-endian samples), what imwrite does for the ISP's 16-bit output
+inline void write16(const std::string& path, const uint16_t* px, int w, int h, int level = 1, int max_threads = 0) {
+  write_rows(path, [=](int y, uint8_t* o) {
+    const uint16_t* s = px + (size_t)y * w * 3;
+    for (int x = 0; x < w; ++x, s += 3, o += 6) {
+      o[0] = s[2] >> 8; o[1] = (uint8_t)s[2]; o[2] = s[1] >> 8; o[3] = (uint8_t)s[1]; o[4] = s[0] >> 8; o[5] = (uint8_t)s[0];
+    }
+  }, w, h, 3, 16, level, max_threads);
+}
+
+// Greyscale PNG, 8 or 16 bits, unchanged depth (imread(path, GRAYSCALE | ANYDEPTH) on a raw Bayer image, Raw2Rgb.cpp:402-404):
+// `depth` receives 8 or 16; samples are returned as uint16 (8-bit ones unscaled). Other colour types are rejected: a
+// Bayer mosaic is not a colour image.
+inline std::vector<uint16_t> read_gray(const std::string& path, int* w_out, int* h_out, int* depth_out) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("failed to load image: " + path);
+  std::vector<uint8_t> file;
+  uint8_t buf[1 << 16];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+  std::fclose(f);
+  static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+  if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw std::runtime_error("not a PNG file: " + path);
+  size_t pos = 8;
+  int w = 0, h = 0, depth = 0, ctype = -1;
+  std::vector<uint8_t> idat;
+  while (pos + 12 <= file.size()) {
+    const uint32_t len = be32(&file[pos]);
+    const char* type = (const char*)&file[pos + 4];
+    const uint8_t* data = &file[pos + 8];
+    if (len > file.size() || pos + 12 + len > file.size()) break;
+    if (!std::memcmp(type, "IHDR", 4)) {
+      if (len < 13) throw std::runtime_error("corrupt PNG header: " + path);
+      const uint32_t uw = be32(data), uh = be32(data + 4);
+      if (uw == 0 || uh == 0 || uw > 65535u || uh > 65535u) throw std::runtime_error("unsupported PNG dimensions: " + path);
+      w = (int)uw; h = (int)uh; depth = data[8]; ctype = data[9];
+      if (data[10] != 0 || data[11] != 0 || data[12] != 0) throw std::runtime_error("unsupported PNG coding (interlaced raw image?): " + path);
+    } else if (!std::memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), data, data + len);
+    } else if (!std::memcmp(type, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (ctype != 0 || (depth != 8 && depth != 16)) throw std::runtime_error("raw input must be an 8- or 16-bit greyscale PNG: " + path);
+  const int bps = depth / 8;
+  const size_t stride = (size_t)w * bps;
+  std::vector<uint8_t> raw((stride + 1) * h);
+  uLongf rawlen = (uLongf)raw.size();
+  if (idat.empty() || uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size())
+    throw std::runtime_error("corrupt PNG data: " + path);
+  std::vector<uint16_t> out((size_t)w * h);
+  std::vector<uint8_t> prev(stride, 0), cur(stride);
+  const uint8_t* in = raw.data();
+  for (int y = 0; y < h; ++y) {
+    const int ft = *in++;
+    for (size_t i = 0; i < stride; ++i) {
+      const int a = i >= (size_t)bps ? cur[i - bps] : 0, b = prev[i], c = i >= (size_t)bps ? prev[i - bps] : 0;
+      int v = in[i];
+      switch (ft) {
+        case 0: break;
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) >> 1; break;
+        case 4: v += paeth(a, b, c); break;
+        default: throw std::runtime_error("corrupt PNG filter: " + path);
+      }
+      cur[i] = (uint8_t)v;
+    }
+    in += stride;
+    uint16_t* o = &out[(size_t)y * w];
+    for (int x = 0; x < w; ++x) o[x] = bps == 1 ? cur[x] : (uint16_t)(cur[2 * x] << 8 | cur[2 * x + 1]);
+    prev.swap(cur);
+  }
+  *w_out = w; *h_out = h; *depth_out = depth;
+  return out;
 }
 
 }  // namespace pngio

@@ -176,3 +176,84 @@ def test_optical_flow_harness_flags(tmp_path):
     assert r.returncode != 0 and "failed to load image" in r.stderr
     r = subprocess.run([exe, "--nope", "1"], capture_output=True, text=True)
     assert r.returncode == 1 and "unknown command line flag" in r.stderr
+
+
+SNIPPET16 = r'''
+#include "png_io.hpp"
+int main(int argc, char** argv) {  // argv: gray_in.png rgb16_out.png : grey samples g -> 16-bit pixel (B, G, R) = (g, g ^ 0x5a5a, ~g)
+  int w, h, depth;
+  std::vector<uint16_t> g = pngio::read_gray(argv[1], &w, &h, &depth);
+  std::vector<uint16_t> px((size_t)w * h * 3);
+  for (size_t i = 0; i < g.size(); ++i) { px[3 * i] = g[i]; px[3 * i + 1] = g[i] ^ 0x5a5a; px[3 * i + 2] = (uint16_t)~g[i]; }
+  pngio::write16(argv[2], px.data(), w, h);
+  std::printf("%d %d %d\n", w, h, depth);
+  return 0;
+}
+'''
+
+
+def test_png_16bit_gray_read_and_rgb16_write(tmp_path):
+    """The ISP host binary's I/O: greyscale raw images keep their depth (imread GRAYSCALE | ANYDEPTH), the 16-bit BGR
+    result is written as a 16-bit RGB PNG. Checked against files written / read by PIL and by a hand-built decoder."""
+    import struct
+    import zlib
+    src = tmp_path / "rt16.cpp"
+    src.write_text(SNIPPET16)
+    exe = str(tmp_path / "rt16")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz",
+                           "-lpthread"])
+    rng = np.random.default_rng(16)
+    for depth, dt in ((16, np.uint16), (8, np.uint8)):
+        g = rng.integers(0, 1 << depth, (41, 67), dtype=np.uint32).astype(dt)
+        p_in, p_out = str(tmp_path / ("g%d.png" % depth)), str(tmp_path / ("o%d.png" % depth))
+        Image.fromarray(g, "I;16" if depth == 16 else "L").save(p_in)
+        out = subprocess.check_output([exe, p_in, p_out], text=True).split()
+        assert [int(v) for v in out] == [67, 41, depth]
+        data = open(p_out, "rb").read()  # decode the 16-bit RGB PNG by hand (PIL reduces 16-bit RGB to 8 bits)
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(data):
+            n, t = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(t + body)
+            if t == b"IHDR":
+                ihdr = struct.unpack(">IIBBBBB", body)
+            elif t == b"IDAT":
+                idat += body
+            pos += 12 + n
+        assert ihdr == (67, 41, 16, 2, 0, 0, 0)
+        raw = zlib.decompress(idat)
+        rows = np.frombuffer(raw, np.uint8).reshape(41, 1 + 67 * 6)
+        assert (rows[:, 0] == 0).all()
+        rgb = rows[:, 1:].reshape(41, 67, 3, 2).astype(np.uint16)
+        rgb = (rgb[..., 0] << 8) | rgb[..., 1]
+        g16 = g.astype(np.uint16)
+        assert np.array_equal(rgb[..., 2], g16) and np.array_equal(rgb[..., 1], g16 ^ 0x5a5a)
+        assert np.array_equal(rgb[..., 0], ~g16)
+
+
+def test_raw2rgb_flags(tmp_path):
+    """host/Raw2Rgb: requireArg order and messages of Raw2Rgb.cpp:377-381, input checks; without a GPU the run ends at
+    s360_isp_create with the library's "no HIP device" error (there is no CPU path)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "surround360_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "Raw2Rgb")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "missing required command line argument: input_image_path" in r.stderr
+    r = subprocess.run([exe, "--input_image_path", "x.png", "--output_image_path", "y.png"], capture_output=True, text=True)
+    assert r.returncode != 0 and "isp_config_path" in r.stderr
+    cfg = tmp_path / "isp.json"
+    cfg.write_text('{"CameraIsp": {"bayerPattern": "GBRG", "width": 16, "height": 12}}')
+    r = subprocess.run([exe, "--input_image_path", str(tmp_path / "none.png"), "--output_image_path", str(tmp_path / "o.png"),
+                        "--isp_config_path", str(cfg)], capture_output=True, text=True)
+    assert r.returncode != 0 and "failed to load image" in r.stderr
+    Image.fromarray(np.zeros((12, 16, 3), np.uint8), "RGB").save(str(tmp_path / "rgb.png"))
+    r = subprocess.run([exe, "--input_image_path", str(tmp_path / "rgb.png"), "--output_image_path", str(tmp_path / "o.png"),
+                        "--isp_config_path", str(cfg)], capture_output=True, text=True)
+    assert r.returncode != 0 and "greyscale" in r.stderr
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"CameraIsp": {"bayerPattern": "QQQQ"}}')
+    Image.fromarray(np.zeros((12, 16), np.uint8), "L").save(str(tmp_path / "g.png"))
+    r = subprocess.run([exe, "--input_image_path", str(tmp_path / "g.png"), "--output_image_path", str(tmp_path / "o.png"),
+                        "--isp_config_path", str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "bayerPattern" in r.stderr

@@ -207,3 +207,49 @@ def test_optical_flow_harness(tmp_path, oracle, s360lib):
         got = R.read_flow_from_file(str(tmp_path / "disparity" / (name + "_pixflow_low.bin")))
         want = oracle.compute_optical_flow(a, b, "pixflow_low", hint)
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+
+
+def test_raw2rgb_binary(tmp_path, oracle, s360lib):
+    """host/Raw2Rgb (Raw2Rgb.cpp, soft-ISP path): 16-bit greyscale PNG and headerless .raw inputs, 8- and 16-bit PNG
+    outputs, bit-exact against the oracle; "Runtime = ... ms" logged."""
+    import struct
+    import zlib
+    import isputil
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "Raw2Rgb")
+    w, h = 160, 96
+    raw = isputil.bayer_frame(w, h, seed=4)
+    cfgj = json.loads(isputil.CONFIG_FULL)
+    cfgj["CameraIsp"]["width"], cfgj["CameraIsp"]["height"] = w, h
+    cfg_path = str(tmp_path / "isp.json")
+    open(cfg_path, "w").write(json.dumps(cfgj))
+    Image.fromarray(raw, "I;16").save(str(tmp_path / "in.png"))
+    raw.tofile(str(tmp_path / "in.raw"))
+
+    def png16(path):
+        data = open(path, "rb").read()
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(data):
+            n, t = struct.unpack(">I4s", data[pos:pos + 8])
+            if t == b"IHDR":
+                ihdr = struct.unpack(">IIBBBBB", data[pos + 8:pos + 8 + n])
+            elif t == b"IDAT":
+                idat += data[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        ww, hh = ihdr[:2]
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(hh, 1 + ww * 6)[:, 1:].reshape(hh, ww, 3, 2).astype(np.uint16)
+        return ((rows[..., 0] << 8) | rows[..., 1])[..., ::-1]  # RGB -> BGR
+
+    for inp, bpp, dm, extra in (("in.png", 16, 2, []), ("in.raw", 8, 0, ["--disable_tone_curve"]),
+                                ("in.png", 8, 2, ["--resize", "2", "--black_level_offset=20"])):
+        out = str(tmp_path / ("out_%s_%d.png" % (inp[-3:], bpp)))
+        r = subprocess.run([exe, "--input_image_path", str(tmp_path / inp), "--output_image_path", out,
+                            "--isp_config_path", cfg_path, "--output_bpp", str(bpp), "--demosaic_filter", str(dm)] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Runtime = " in r.stderr
+        rs = 2 if "--resize" in extra else 1
+        want = oracle.isp_run(oracle.isp_config_from_json(json.dumps(cfgj), bpp, dm, rs, int("--disable_tone_curve" in extra),
+                                                          20 if rs == 2 else 0), raw)
+        got = png16(out) if bpp == 16 else np.asarray(Image.open(out))[:, :, ::-1]
+        assert np.array_equal(got, want), (inp, bpp)
