@@ -332,6 +332,14 @@ int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* o
  * RawConverter::convert8Frame / convert12Frame, RawConverter.cpp:15-59): bits 8 (w * h bytes) or 12 (3 * w / 2 bytes
  * per row, even w); widened to 16 bits on the device, then as s360_isp_process. */
 int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr);
+/* A camera's raw Bayer frame through the ISP straight into a frame's source slot, on the context's upload stream and
+ * without leaving the device — the reference's chain through files (Unpacker writes the ISP's 16-bit result as a PNG,
+ * RigDescription::loadSideCameraImages / imread decodes it to 8 bits = its high byte). camera: side index, or
+ * S360_CAMERA_TOP / S360_CAMERA_BOTTOM. The ISP object must have output_bpp 16 and live on the context's device; it may
+ * be shared by all cameras of a rig that use one configuration. Replaces s360_frame_upload_side / _top / _bottom. */
+#define S360_CAMERA_TOP (-1)
+#define S360_CAMERA_BOTTOM (-2)
+int s360_frame_upload_raw(s360_ctx* ctx, s360_isp* isp, int camera, const uint16_t* raw16, int w, int h);
 /* The host-side tables of a configuration (no device needed; what s360_isp_create uploads): ccm9 = composite CCM x 4095
  * (CameraIsp::setup), lut = 4096 x 3 floats (buildToneCurveLut), curve_h = w x 3 and curve_v = h x 3 vignette gains of
  * a w x h frame (curveHAtPixel / curveVAtPixel; either may be NULL). */

@@ -232,6 +232,7 @@ void isp_init(s360_isp* o, int device, const s360_isp_config& cfg) {
 }
 
 static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out);
+static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH);
 
 void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out) {
   S360_HIP(hipSetDevice(o->device));
@@ -252,7 +253,8 @@ void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int inW, in
   isp_run_uploaded(o, inW, inH, out);
 }
 
-static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out) {
+// Enqueues the ISP of the frame already in dRaw on `st`; the result (B,G,R, 8 or 16 bit) is left in dOut.
+static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   const s360_isp_config& cfg = o->cfg;
   const int w = inW / cfg.resize, h = inH / cfg.resize;
   // the 9x9 homogeneity window and the reflected +-2 taps index up to 4 pixels past an edge (the reference reads out
@@ -264,9 +266,9 @@ static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out) {
     isp_vignette_curves(cfg, w, h, ch, cv);
     o->dCurveH.ensure(ch.size() * sizeof(float));
     o->dCurveV.ensure(cv.size() * sizeof(float));
-    S360_HIP(hipMemcpyAsync(o->dCurveH.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice, o->st));
-    S360_HIP(hipMemcpyAsync(o->dCurveV.p, cv.data(), cv.size() * sizeof(float), hipMemcpyHostToDevice, o->st));
-    S360_HIP(hipStreamSynchronize(o->st));  // the staging vectors go out of scope
+    S360_HIP(hipMemcpyAsync(o->dCurveH.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    S360_HIP(hipMemcpyAsync(o->dCurveV.p, cv.data(), cv.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    S360_HIP(hipStreamSynchronize(st));  // the staging vectors go out of scope
     o->curveW = w;
     o->curveH = h;
   }
@@ -297,10 +299,25 @@ static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out) {
   B.curveV = o->dCurveV.as<float>();
   B.lut = o->dLut.as<float>();
   B.exptab = o->dExp.as<unsigned long long>();
-  isp_launch(o->st, o->dev, o->dRaw.as<unsigned short>(), inW, inH, B, o->dOut.p);
+  isp_launch(st, o->dev, o->dRaw.as<unsigned short>(), inW, inH, B, o->dOut.p);
   S360_HIP(hipGetLastError());
+}
+
+static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out) {
+  isp_enqueue(o, o->st, inW, inH);
+  const size_t outBytes = (size_t)(inW / o->cfg.resize) * (inH / o->cfg.resize) * 3 * (o->cfg.output_bpp == 8 ? 1 : 2);
   S360_HIP(hipMemcpyAsync(out, o->dOut.p, outBytes, hipMemcpyDeviceToHost, o->st));
   S360_HIP(hipStreamSynchronize(o->st));
+}
+// For callers that keep the result on the device (render.hip: camera images straight into a frame): the raw frame must
+// already be in dRaw (isp_raw_buffer) and everything is enqueued on the caller's stream.
+void* isp_raw_buffer(s360_isp* o, int inW, int inH) {
+  o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
+  return o->dRaw.p;
+}
+const void* isp_enqueue_on(s360_isp* o, hipStream_t st, int inW, int inH) {
+  isp_enqueue(o, st, inW, inH);
+  return o->dOut.p;
 }
 
 void isp_release(s360_isp* o) {

@@ -50,4 +50,6 @@ void isp_init(s360_isp* o, int device, const s360_isp_config& cfg);
 void isp_process(s360_isp* o, const uint16_t* raw16, int w, int h, void* out);
 void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int w, int h, void* out);
 void isp_release(s360_isp* o);
+void* isp_raw_buffer(s360_isp* o, int inW, int inH);
+const void* isp_enqueue_on(s360_isp* o, hipStream_t st, int inW, int inH);
 }  // namespace s360

@@ -3,6 +3,8 @@
 // with no host round trips; buffers are persistent (sized once from rig + eqr size).
 #include "render.hpp"
 
+#include "isp.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -240,6 +242,46 @@ void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) 
   launch_bgr_to_bgra(c->stUp, F.staging.as<uint8_t>(), 3, dst.as<uchar4>(), n);
   uploads_done(c);
   (top ? F.have_top : F.have_bottom) = true;
+}
+
+// A camera's raw Bayer frame through the ISP straight into the frame's source slot ("feeding the GPU
+// directly"): what the reference does through files — Unpacker writes the ISP's 16-bit result as a PNG, the renderer's
+// imread decodes it to 8 bits, i.e. keeps the high byte — happens on the upload stream without leaving the device.
+// which: side index, -1 top, -2 bottom.
+void frame_upload_raw(s360_ctx* c, s360_isp* isp, int which, const uint16_t* raw16, int inW, int inH) {
+  if (isp->cfg.output_bpp != 16)
+    throw Error(S360_ERR_INVALID_ARG, "uploading through the ISP needs output_bpp 16 (the reference's chain stores 16-bit PNGs and imread keeps their high byte)");
+  if (isp->device != c->device) throw Error(S360_ERR_INVALID_ARG, "the ISP object lives on another device");
+  FrameState& F = frame_state(c);
+  if (which < -2 || which >= F.P) throw Error(S360_ERR_INVALID_ARG, "camera index out of range");
+  ensure_upload_stream(c);
+  const int w = inW / isp->cfg.resize, h = inH / isp->cfg.resize;
+  const size_t n = (size_t)w * h;
+  upload_bytes(c, isp_raw_buffer(isp, inW, inH), raw16, (size_t)inW * inH * sizeof(uint16_t));
+  const void* out16 = isp_enqueue_on(isp, c->stUp, inW, inH);
+  F.staging.ensure(n * 4);
+  launch_u16_high_byte(c->stUp, static_cast<const unsigned short*>(out16), F.staging.as<uint8_t>(), n * 3);
+  if (which >= 0) {  // as frame_upload_side from the staging buffer
+    if (F.have_side && (w != F.srcW || h != F.srcH)) throw Error(S360_ERR_INVALID_ARG, "side image size changed");
+    if (F.P > 64) throw Error(S360_ERR_INVALID_ARG, "more than 64 side cameras");
+    F.srcW = w;
+    F.srcH = h;
+    F.sideSrc.ensure(F.P * n * sizeof(uchar4));
+    if (c->haveSideSrcFree) S360_HIP(hipStreamWaitEvent(c->stUp, c->evSideSrcFree, 0));
+    launch_prepare_side_src(c->stUp, F.staging.as<uint8_t>(), 3, F.sideSrc.as<uchar4>() + n * which, w, h,
+                            c->P.side_alpha_feather_size);
+    F.have_side = true;
+    F.side_uploaded |= 1ull << which;
+  } else {  // as frame_upload_pole
+    const bool top = which == -1;
+    if (top) { F.topW = w; F.topH = h; } else { F.poleW = w; F.poleH = h; }
+    DevBuf& dst = top ? F.topSrc : F.botSrc;
+    dst.ensure(n * sizeof(uchar4));
+    if (c->havePoleSrcFree) S360_HIP(hipStreamWaitEvent(c->stUp, c->evPoleSrcFree, 0));
+    launch_bgr_to_bgra(c->stUp, F.staging.as<uint8_t>(), 3, dst.as<uchar4>(), n);
+    (top ? F.have_top : F.have_bottom) = true;
+  }
+  uploads_done(c);
 }
 
 void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w, int h) {

@@ -1180,8 +1180,19 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
   }
 }
 
+// 16-bit samples -> their high byte: what imread's 8-bit decode makes of the ISP's 16-bit PNGs (png_set_strip_16)
+__global__ __launch_bounds__(256) void k_u16_high_byte(const unsigned short* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (uint8_t)(src[i] >> 8);
+}
+
 // ==========================================================================================
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_u16_high_byte(hipStream_t st, const unsigned short* src, uint8_t* dst, size_t n) {
+  hipLaunchKernelGGL(k_u16_high_byte, dim3(cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+}
 
 void launch_bgr_to_bgra(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, size_t n) {
   hipLaunchKernelGGL(k_bgr_to_bgra, dim3(cdiv(n, 256)), dim3(256), 0, st, src, channels, dst, n);

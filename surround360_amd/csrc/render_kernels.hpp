@@ -32,6 +32,7 @@ struct PoleWarpParams {  // TRSP:483-536
 
 // generic
 void launch_bgr_to_bgra(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, size_t n);
+void launch_u16_high_byte(hipStream_t st, const unsigned short* src, uint8_t* dst, size_t n);
 // projectSideToSpherical's source preparation: BGR(A) -> BGRA with the top/bottom alpha ramp (TRSP:108-125)
 void launch_prepare_side_src(hipStream_t st, const uint8_t* src, int channels, uchar4* dst, int w, int h, int feather);
 // bicubicRemapToSpherical's warp map (ImageWarper.cpp:151-167); trig tables per column / row are host-built.

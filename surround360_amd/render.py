@@ -223,6 +223,12 @@ class Context:
             b = _u8(bottom)
             self._ck(lib().s360_frame_upload_bottom(self.h, _p(b), b.shape[1], b.shape[0]))
 
+    def upload_raw(self, isp, camera, raw16):
+        """A camera's raw Bayer frame (H x W uint16) through `isp` (surround360_amd.isp.CameraIsp, output_bpp 16) into
+        this frame's source slot on the device. camera: side index, -1 top, -2 bottom."""
+        r = np.ascontiguousarray(raw16, np.uint16)
+        self._ck(lib().s360_frame_upload_raw(self.h, isp.h, int(camera), _p(r), r.shape[1], r.shape[0]))
+
     def upload_pole_removal(self, bottom2, mask, mask2):
         """Secondary bottom camera image + the two red pole masks (BGR) for enable_pole_removal (PoleRemoval.cpp:48-66)."""
         b2, m1, m2 = _u8(bottom2), _u8(mask), _u8(mask2)

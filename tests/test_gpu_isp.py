@@ -65,3 +65,45 @@ def test_isp_from_packed_sensor_frames(oracle, s360lib, bits):
             isp.get_image_packed(frame, 10, w, h)
     finally:
         isp.close()
+
+
+def test_raw_frames_straight_into_the_renderer(tmp_path, rig_json, oracle, s360lib):
+    """s360_frame_upload_raw: 17 raw Bayer frames -> ISP -> frame source slots on the device, then the whole stereo frame.
+    Equals the reference's chain through files: ISP at 16 bits (oracle), stored as 16-bit PNGs, decoded to 8 bits by the
+    renderer's imread (= the high byte), uploaded as 8-bit images."""
+    import rigutil
+    from surround360_amd import isp as I, render as R
+    CAM = 256
+    path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_small.json"), CAM / 2048.0)
+    flags = dict(eqr_width=504, eqr_height=252, enable_top=1, enable_bottom=1)
+    rig = R.RigDescription(path)
+    js = isputil.CONFIG_GRBG_NOSHARP
+    raws = [isputil.bayer_frame(CAM, CAM, seed=100 + k) for k in range(16)]  # 14 side, top, bottom
+    ocfg = oracle.isp_config_from_json(js, 16)
+    imgs8 = [(oracle.isp_run(ocfg, r) >> 8).astype(np.uint8) for r in raws]
+    a = R.Context(rig, R.make_params(**flags))
+    b = R.Context(rig, R.make_params(**flags))
+    isp = I.CameraIsp(I.config_from_json(js, 16))
+    try:
+        a.upload_frame(imgs8[:14], imgs8[14], imgs8[15])
+        a.render()
+        want = a.download_equirect()
+        for k in range(14):
+            b.upload_raw(isp, k, raws[k])
+        b.upload_raw(isp, -1, raws[14])
+        b.upload_raw(isp, -2, raws[15])
+        b.render()
+        got = b.download_equirect()
+        assert want.std() > 5
+        assert np.array_equal(got, want), "%d bytes differ" % int((got != want).sum())
+        isp8 = I.CameraIsp(I.config_from_json(js, 8))
+        try:
+            from surround360_amd import _capi
+            with pytest.raises(_capi.S360Error):
+                b.upload_raw(isp8, 0, raws[0])  # an 8-bit ISP is not the reference's chain
+        finally:
+            isp8.close()
+    finally:
+        isp.close()
+        a.close()
+        b.close()
