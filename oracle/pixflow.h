@@ -1,5 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
-// PARITY UNPINNED (see cvlite.h header).
+// The logic restated here is PINNED to the reference's source: optical_flow/PixFlow.h compiled from /root/reference over
+// oracle/ref_shim (oracle/ref_pixflow.cpp) gives the same bits (tests/test_cpu_refpin.py). The OpenCV primitives it calls
+// (cvlite.h) stay unpinned (see that header).
 //
 // pixflow.h: CPU restatement of PixFlow<false, MaxPercentage>::computeOpticalFlow
 // following surround360_render/source/optical_flow/PixFlow.h:81-534 and the

@@ -8,6 +8,12 @@
 //   * Mat * Mat on 3x3 CV_32F takes gemm's unrolled small-matrix path: float products summed left to right in float
 //   * Mat *= double scales every element in float (convertTo with a float working type)
 //   * Vec<float,n> * float and Vec + Vec are plain per-element float operations
+//   * Mat *= s, Mat /= s, Mat * s on CV_32F data: every element times (float)s resp. (float)(1.0 / s) (convertTo)
+//   * norm(Point2f) = sqrt((double)x * x + (double)y * y)
+// opencv2/imgproc.hpp of this directory routes the imgproc ALGORITHMS the optical-flow sources call (resize,
+// GaussianBlur, Sobel, medianBlur, cvtColor, split) to the oracle's own restatements in cvlite.h: compiling the
+// reference's PixFlow.h over it checks the oracle's restatement of PixFlow's logic against the reference's source,
+// with the OpenCV primitives common to both sides (they stay unpinned, see cvlite.h).
 #pragma once
 #include <algorithm>
 #include <cassert>
@@ -21,6 +27,12 @@
 #include <vector>
 
 namespace cv {
+
+using std::string;  // name lookup only: the reference's headers find these through `using namespace cv`
+using std::vector;
+using std::min;
+using std::max;
+namespace detail {}
 
 typedef unsigned char uchar;
 typedef unsigned short ushort;
@@ -38,6 +50,13 @@ enum { CV_8U = 0, CV_8S = 1, CV_16U = 2, CV_16S = 3, CV_32S = 4, CV_32F = 5, CV_
 #define CV_32FC2 CV_MAKETYPE(cv::CV_32F, 2)
 #define CV_32FC3 CV_MAKETYPE(cv::CV_32F, 3)
 enum { IMREAD_COLOR = 1 };
+enum { MORPH_RECT = 0, MORPH_CROSS = 1, MORPH_ELLIPSE = 2 };
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2 };
+enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT_101 = 4 };
+enum { COLOR_BGRA2GRAY = 10, COLOR_BGR2BGRA = 0, COLOR_BGRA2BGR = 1 };
+#define CV_INTER_LINEAR 1
+#define CV_INTER_CUBIC 2
+#define CV_BGRA2GRAY 10
 #define CV_LOAD_IMAGE_GRAYSCALE 0
 #define CV_LOAD_IMAGE_ANYDEPTH 2
 
@@ -62,6 +81,14 @@ inline Vec<T, N> operator*(const Vec<T, N>& a, float s) { Vec<T, N> r; for (int 
 template <typename T, int N>
 inline Vec<T, N> operator*(float s, const Vec<T, N>& a) { return a * s; }
 template <typename T, int N>
+inline Vec<T, N>& operator+=(Vec<T, N>& a, const Vec<T, N>& b) { for (int i = 0; i < N; ++i) a.val[i] = T(a.val[i] + b.val[i]); return a; }
+template <typename T, int N>
+inline Vec<T, N> operator/(const Vec<T, N>& a, float s) { Vec<T, N> r; for (int i = 0; i < N; ++i) r.val[i] = T(a.val[i] * (1.f / s)); return r; }
+template <typename T, int N>
+inline bool operator==(const Vec<T, N>& a, const Vec<T, N>& b) { for (int i = 0; i < N; ++i) if (a.val[i] != b.val[i]) return false; return true; }
+template <typename T, int N>
+inline bool operator!=(const Vec<T, N>& a, const Vec<T, N>& b) { return !(a == b); }
+template <typename T, int N>
 inline std::ostream& operator<<(std::ostream& o, const Vec<T, N>& v) { o << "["; for (int i = 0; i < N; ++i) o << (i ? ", " : "") << v.val[i]; return o << "]"; }
 typedef Vec<uchar, 3> Vec3b;
 typedef Vec<uchar, 4> Vec4b;
@@ -77,9 +104,19 @@ struct Point_ {
   T x, y;
   Point_() : x(0), y(0) {}
   Point_(T a, T b) : x(a), y(b) {}
+  T dot(const Point_& o) const { return T(x * o.x + y * o.y); }
 };
 typedef Point_<int> Point;
 typedef Point_<float> Point2f;
+template <typename T> inline Point_<T> operator+(const Point_<T>& a, const Point_<T>& b) { return Point_<T>(T(a.x + b.x), T(a.y + b.y)); }
+template <typename T> inline Point_<T> operator-(const Point_<T>& a, const Point_<T>& b) { return Point_<T>(T(a.x - b.x), T(a.y - b.y)); }
+template <typename T> inline Point_<T> operator*(const Point_<T>& a, float s) { return Point_<T>(T(a.x * s), T(a.y * s)); }
+template <typename T> inline Point_<T> operator*(float s, const Point_<T>& a) { return Point_<T>(T(a.x * s), T(a.y * s)); }
+template <typename T> inline Point_<T>& operator-=(Point_<T>& a, const Point_<T>& b) { a.x = T(a.x - b.x); a.y = T(a.y - b.y); return a; }
+template <typename T> inline Point_<T>& operator+=(Point_<T>& a, const Point_<T>& b) { a.x = T(a.x + b.x); a.y = T(a.y + b.y); return a; }
+template <typename T> inline Point_<T>& operator/=(Point_<T>& a, float s) { a.x = T(a.x / s); a.y = T(a.y / s); return a; }
+template <typename T> inline Point_<T> operator/(const Point_<T>& a, float s) { Point_<T> t(a); t /= s; return t; }
+template <typename T> inline double norm(const Point_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y); }
 template <typename T>
 struct Point3_ {
   T x, y, z;
@@ -98,8 +135,14 @@ struct Size {
   int width, height;
   Size() : width(0), height(0) {}
   Size(int w, int h) : width(w), height(h) {}
+  bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+  bool operator!=(const Size& o) const { return !(*this == o); }
 };
-struct Rect { int x, y, width, height; };
+struct Rect {
+  int x, y, width, height;
+  Rect() : x(0), y(0), width(0), height(0) {}
+  Rect(int a, int b, int c, int d) : x(a), y(b), width(c), height(d) {}
+};
 struct Scalar { double val[4]; };
 
 inline size_t elemSize(int type) {
@@ -109,18 +152,30 @@ inline size_t elemSize(int type) {
 
 class Mat {
  public:
-  int rows, cols;
+  int rows, cols, dims;
   uchar* data;
-  Mat() : rows(0), cols(0), data(nullptr), type_(0) {}
+  Mat() : rows(0), cols(0), dims(0), data(nullptr), type_(0) {}
   Mat(int r, int c, int type) { create(r, c, type); }
   Mat(Size s, int type) { create(s.height, s.width, type); }
-  Mat(int r, int c, int type, void* ext) : rows(r), cols(c), data((uchar*)ext), type_(type) {}  // wraps, does not copy
+  Mat(int r, int c, int type, void* ext) : rows(r), cols(c), dims(2), data((uchar*)ext), type_(type) {}  // wraps, does not copy
   void create(int r, int c, int type) {
-    rows = r; cols = c; type_ = type;
+    rows = r; cols = c; type_ = type; dims = 2;
     store_.reset(new std::vector<uchar>((size_t)r * c * elemSize(type) + 64));  // uninitialised in OpenCV; zero here
     data = store_->data();
   }
   static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
+  static Mat zeros(Size s, int type) { return Mat(s.height, s.width, type); }
+  template <typename T> T* ptr(int y) { return reinterpret_cast<T*>(data + (size_t)y * cols * elemSize(type_)); }
+  template <typename T> const T* ptr(int y) const { return reinterpret_cast<const T*>(data + (size_t)y * cols * elemSize(type_)); }
+  size_t total() const { return (size_t)rows * cols; }
+  // convertTo(dst, CV_32F) from 8-bit data (PixFlow.h:128-133): exact
+  void convertTo(Mat& dst, int rtype) const {
+    assert(depth() == CV_8U && (rtype & CV_MAT_DEPTH_MASK) == CV_32F);
+    Mat d(rows, cols, CV_MAKETYPE(CV_32F, channels()));
+    const size_t n = total() * channels();
+    for (size_t i = 0; i < n; ++i) reinterpret_cast<float*>(d.data)[i] = (float)data[i];
+    dst = d;
+  }
   static Mat eye(int r, int c, int type) {
     Mat m(r, c, type);
     assert(type == CV_32F);
@@ -164,9 +219,16 @@ inline Mat operator*(const Mat& a, const Mat& b) {
 }
 inline Mat& operator*=(Mat& a, const Mat& b) { a = a * b; return a; }
 inline Mat& operator*=(Mat& a, double s) {
-  assert(a.type() == CV_32F);
-  for (int i = 0; i < a.rows * a.cols; ++i) a.at<float>(i) = a.at<float>(i) * (float)s;
+  assert(a.depth() == CV_32F);
+  const size_t n = a.total() * a.channels();
+  for (size_t i = 0; i < n; ++i) reinterpret_cast<float*>(a.data)[i] = reinterpret_cast<float*>(a.data)[i] * (float)s;
   return a;
+}
+inline Mat& operator/=(Mat& a, double s) { return a *= (double)(float)(1.0 / s); }
+inline Mat operator*(const Mat& a, double s) {
+  Mat d = a.clone();
+  d *= s;
+  return d;
 }
 inline void transpose(const Mat& src, Mat& dst) {
   assert(src.type() == CV_32F);

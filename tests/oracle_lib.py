@@ -478,19 +478,9 @@ def isp_tables(cfg):
     return ccm.reshape(3, 3), lut
 
 
-_REF_ISP = None
-
-
 def ref_isp_lib():
-    """oracle/_ref/libref_isp.so — the reference's own CameraIsp.h compiled over the container stand-in. Built here when
-    /root/reference exists; on the GPU box the prebuilt file travels with the snapshot. None if neither."""
-    global _REF_ISP
-    so = os.path.join(ORACLE_DIR, "_ref", "libref_isp.so")
-    if os.path.isdir("/root/reference/surround360_render/source/camera_isp"):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "ref"])
-    if _REF_ISP is None and os.path.exists(so):
-        _REF_ISP = C.CDLL(so)
-    return _REF_ISP
+    """oracle/_ref/libref_isp.so — the reference's own CameraIsp.h compiled over the container stand-in (see ref_lib)."""
+    return ref_lib("isp")
 
 
 def ref_isp_run(json_text, raw, output_bpp=8, demosaic_filter=2, resize=1, disable_tone_curve=0, black_level_offset=0):
@@ -520,4 +510,69 @@ def ref_unpack_frame(frame, bits, w, h):
     fr = np.ascontiguousarray(frame, np.uint8)
     out = np.zeros((h, w), np.uint16)
     ref_isp_lib().ref_convert_frame(bits, _p(fr), w, h, _p(out))
+    return out
+
+
+# ---- the reference's own sources, compiled over oracle/ref_shim (oracle/_ref; built where /root/reference exists) ------
+_REF_LIBS = {}
+
+
+def ref_lib(name):
+    """oracle/_ref/libref_<name>.so ("isp", "pixflow", "render") or None."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libref_%s.so" % name)
+    if name not in _REF_LIBS:
+        if os.path.isdir("/root/reference/surround360_render/source/optical_flow"):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "ref"])
+        _REF_LIBS[name] = C.CDLL(so) if os.path.exists(so) else None
+    return _REF_LIBS[name]
+
+
+def _ref_call(fn, *args):
+    err = C.create_string_buffer(256)
+    if fn(*args, err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+
+
+def ref_compute_optical_flow(i0, i1, alg="pixflow_low", hint="UNKNOWN", prev_flow=None, prev_i0=None, prev_i1=None):
+    """The reference's PixFlow.h (makeOpticalFlowByName(alg)->computeOpticalFlow) over the oracle's OpenCV primitives."""
+    i0, i1 = np.ascontiguousarray(i0), np.ascontiguousarray(i1)
+    h, w, _ = i0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    pf = np.ascontiguousarray(prev_flow, np.float32) if prev_flow is not None else None
+    p0 = np.ascontiguousarray(prev_i0) if prev_i0 is not None else None
+    p1 = np.ascontiguousarray(prev_i1) if prev_i1 is not None else None
+    _ref_call(ref_lib("pixflow").ref_pixflow, alg.encode(), _p(i0), _p(i1), w, h, _p(pf), _p(p0), _p(p1), HINT[hint], _p(flow))
+    return flow
+
+
+def ref_combine_lazy_novel_views(img_l, img_r, flow_l_to_r, flow_r_to_l, chunk_w, num_novel_views, cam_image_width,
+                                 verge_disp):
+    img_l, img_r = np.ascontiguousarray(img_l), np.ascontiguousarray(img_r)
+    fl, fr = np.ascontiguousarray(flow_l_to_r, np.float32), np.ascontiguousarray(flow_r_to_l, np.float32)
+    h, w, _ = img_l.shape
+    cl, cr = np.zeros((h, chunk_w, 4), np.uint8), np.zeros((h, chunk_w, 4), np.uint8)
+    _ref_call(ref_lib("render").ref_combine_lazy_novel_views, _p(img_l), _p(img_r), _p(fl), _p(fr), w, h, chunk_w,
+              num_novel_views, cam_image_width, C.c_float(verge_disp), _p(cl), _p(cr))
+    return cl, cr
+
+
+def ref_flatten_layers(base, top):
+    base, top = np.ascontiguousarray(base), np.ascontiguousarray(top)
+    out = np.zeros_like(base)
+    _ref_call(ref_lib("render").ref_flatten_layers, _p(base), _p(top), base.shape[1], base.shape[0], _p(out))
+    return out
+
+
+def ref_feather_alpha_channel(src, erode_size):
+    src = np.ascontiguousarray(src)
+    out = np.zeros_like(src)
+    _ref_call(ref_lib("render").ref_feather_alpha_channel, _p(src), src.shape[1], src.shape[0], erode_size, _p(out))
+    return out
+
+
+def ref_offset_horizontal_wrap(src, offset):
+    src = np.ascontiguousarray(src)
+    out = np.zeros_like(src)
+    _ref_call(ref_lib("render").ref_offset_horizontal_wrap, _p(src), src.shape[1], src.shape[0], src.shape[2],
+              C.c_float(offset), _p(out))
     return out
