@@ -574,6 +574,19 @@ def main():
                 want, cb = cpu_baseline_8k(*frames[0])
                 cb["checked_against_gpu"] = bool(np.array_equal(want, single0))
                 out["cpu_baseline"] = cb
+
+            # ---- ISP front end: raw 2048x2048 Bayer frames -> BGR, alone and straight into a frame ----
+            # In a process of its own (tools/isp_time.py): informative, and nothing it does can cost the lines above.
+            try:
+                import subprocess
+                cmd = [sys.executable, os.path.join(ROOT, "tools", "isp_time.py"), "--json", "--device", str(local_rank)]
+                if args.no_cpu_baseline:
+                    cmd.append("--no-cpu")
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                out["isp"] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+            except Exception as e:  # noqa: BLE001
+                out["isp"] = {"error": repr(e)}
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         import traceback
         bail("post-timed-region phase failed: %r %s" % (e, traceback.format_exc()[-600:]))

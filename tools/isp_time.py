@@ -1,22 +1,85 @@
-import sys, time, numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import torch  # HIP runtime first
-import isputil, oracle_lib as O
-from surround360_amd import isp as I
-js = isputil.CONFIG_FULL
-raw = isputil.bayer_frame(2048, 2048, seed=1)
-for bpp, dm in ((8, 2), (16, 2), (8, 0)):
-    cfg = I.config_from_json(js, bpp, dm)
-    isp = I.CameraIsp(cfg)
-    out = isp.get_image(raw)
-    t = time.perf_counter()
-    for _ in range(5):
-        out = isp.get_image(raw)
-    ms = (time.perf_counter() - t) / 5 * 1e3
-    isp.close()
-    print("2048x2048 bpp%d dm%d: %.2f ms per image incl. PCIe both ways" % (bpp, dm, ms), flush=True)
-t = time.perf_counter()
-want = O.isp_run(O.isp_config_from_json(js, 16, 2), raw)
-cpu = time.perf_counter() - t
-cfg = I.config_from_json(js, 16, 2); isp = I.CameraIsp(cfg); got = isp.get_image(raw); isp.close()
-print("oracle 2048x2048 bpp16 dm2: %.2f s; equal to GPU: %s" % (cpu, bool(np.array_equal(got, want))))
+#!/usr/bin/env python
+"""ISP timing on the GPU box (run from the repo root): ms per 2048x2048 raw image through s360_isp_process (host buffers
+on both sides), equality with the oracle at that size, and a whole 8K frame fed from 17 raw images through
+s360_frame_upload_raw (ISP on the upload stream, nothing leaves the device) followed by one render.
+  python tools/isp_time.py            human-readable lines
+  python tools/isp_time.py --json     one JSON line (bench.py's "isp" leg runs this in a process of its own)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    import torch  # noqa: F401  (the HIP runtime before libs360, like tests/conftest.py)
+    import isputil
+    from surround360_amd import isp as I, render as R
+    js = isputil.CONFIG_FULL
+    raws = [isputil.bayer_frame(2048, 2048, seed=k) for k in range(3)]
+    res = {"input": "16-bit Bayer frames 2048x2048, every configuration key set, IIR sharpening on "
+                    "(CameraIsp.h through Raw2Rgb.cpp:441-456)"}
+    for key, bpp, dm in (("ms_per_image_bpp16_edge_aware", 16, 2), ("ms_per_image_bpp8_edge_aware", 8, 2),
+                         ("ms_per_image_bpp8_bilinear", 8, 0)):
+        isp = I.CameraIsp(I.config_from_json(js, bpp, dm), device=args.device)
+        isp.get_image(raws[0])
+        t = time.perf_counter()
+        for k in range(6):
+            out = isp.get_image(raws[k % 3])
+        res[key] = round(1e3 * (time.perf_counter() - t) / 6, 3)
+        isp.close()
+        if not args.json:
+            print("2048x2048 bpp%d dm%d: %.2f ms per image incl. PCIe both ways" % (bpp, dm, res[key]), flush=True)
+    if not args.no_cpu:
+        import oracle_lib as O
+        t = time.perf_counter()
+        want = O.isp_run(O.isp_config_from_json(js, 16, 2), raws[0])
+        res["cpu_seconds_per_image"] = round(time.perf_counter() - t, 3)
+        isp = I.CameraIsp(I.config_from_json(js, 16, 2), device=args.device)
+        res["checked"] = bool(np.array_equal(isp.get_image(raws[0]), want))
+        isp.close()
+        if not args.json:
+            print("oracle 2048x2048 bpp16 dm2: %.2f s; equal to GPU: %s" % (res["cpu_seconds_per_image"], res["checked"]))
+    # a whole frame from raw images: 17 x upload_raw + render (latency sweep kernel), frames back to back
+    rig = R.RigDescription(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"))
+    flags = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192, final_eqr_height=8192)
+    ctx = R.Context(rig, R.make_params(**flags), device=args.device)
+    isp = I.CameraIsp(I.config_from_json(js, 16, 2), device=args.device)
+    try:
+        def frame():
+            for k in range(14):
+                ctx.upload_raw(isp, k, raws[k % 3])
+            ctx.upload_raw(isp, -1, raws[0])
+            ctx.upload_raw(isp, -2, raws[1])
+            ctx.render(False)
+        frame()
+        ctx.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            frame()
+        ctx.synchronize()
+        res["frame_from_raw_ms"] = round(1e3 * (time.perf_counter() - t) / 3, 2)
+        res["frame_from_raw_note"] = ("17 x s360_frame_upload_raw (ISP on the upload stream, the result stays on the device) + "
+                                      "one 8K frame render, latency sweep kernel, frames back to back")
+        if not args.json:
+            print("8K frame from 17 raw images (ISP + render): %.1f ms" % res["frame_from_raw_ms"])
+    finally:
+        isp.close()
+        ctx.close()
+    if args.json:
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
