@@ -65,3 +65,25 @@ def pack_frame(raw16, bits):
     out[..., 1] = (a & 0xF) | ((b & 0xF) << 4)
     out[..., 2] = b >> 4
     return out.ravel()
+
+
+def footage_file(path, frames, bits, serials, timestamp=1234, file_index=0, file_count=1):
+    """A capture container as BinaryFootageFile.cpp reads it: a 4096-byte metadata page, then the packed frames
+    interleaved by camera (frames[f][cam] = H x W uint16). The camera stamps its serial number over bytes 4..7 of every
+    frame; returns the frame bytes as written (frames_bytes[f][cam]) so a test can unpack exactly those."""
+    h, w = frames[0][0].shape
+    ncam = len(frames[0])
+    page = np.zeros(4096, np.uint8)
+    page[:32] = np.array([0xfaceb00c, timestamp, file_index, file_count, w, h, bits, ncam], np.uint32).view(np.uint8)
+    written = []
+    with open(path, "wb") as f:
+        f.write(page.tobytes())
+        for per_cam in frames:
+            row = []
+            for cam, img in enumerate(per_cam):
+                fr = pack_frame(img, bits).copy()
+                fr[4:8] = np.array([serials[cam]], np.uint32).view(np.uint8)
+                f.write(fr.tobytes())
+                row.append(fr)
+            written.append(row)
+    return written

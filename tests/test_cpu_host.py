@@ -3,7 +3,10 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 from PIL import Image
+
+import oracle_lib as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -257,3 +260,48 @@ def test_raw2rgb_flags(tmp_path):
     r = subprocess.run([exe, "--input_image_path", str(tmp_path / "g.png"), "--output_image_path", str(tmp_path / "o.png"),
                         "--isp_config_path", str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "bayerPattern" in r.stderr
+
+
+@pytest.mark.parametrize("bits", [8, 12])
+def test_unpacker_raw_path(tmp_path, bits):
+    """host/Unpacker without ISP configs (Unpacker.cpp:156-161 "we can still unpack raws"): container parsing
+    (BinaryFootageFile.cpp), the frame range flags, per-serial directories, the widened 16-bit TIFFs against the
+    oracle's RawConverter, and the serial -> camN renaming of the output directory. Needs no GPU: no ISP object is made."""
+    import isputil
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "surround360_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "Unpacker")
+    w, h, nf = 32, 12, 4
+    serials = [17430921, 16241093, 17431022]  # not in sorted order: cam0 is the smallest serial
+    rng = np.random.default_rng(bits)
+    frames = [[rng.integers(0, 65536, (h, w), dtype=np.uint16) for _ in serials] for _ in range(nf)]
+    binp = tmp_path / "0.bin"
+    written = isputil.footage_file(str(binp), frames, bits, serials)
+    out, raw, isp = tmp_path / "rgb", tmp_path / "raw", tmp_path / "isp"
+    for d in (out, raw, isp):
+        d.mkdir()
+    r = subprocess.run([exe, "--isp_dir", str(isp), "--output_dir", str(out), "--output_raw_dir", str(raw),
+                        "--bin_list", str(binp), "--start_frame", "1", "--frame_count", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "numberOfCameras = 3" in r.stdout and "bpp = %d" % bits in r.stdout
+    assert "Cannot convert to RGB, file not found" in r.stderr
+    assert sorted(os.listdir(out)) == ["cam0", "cam1", "cam2"]  # renamed (and empty: no ISP config for any serial)
+    assert sorted(os.listdir(raw)) == sorted(str(s) for s in serials)  # the raw directory keeps the serial names
+    for cam, s in enumerate(serials):
+        assert sorted(os.listdir(raw / str(s))) == ["000001.tiff", "000002.tiff"]
+        for f in (1, 2):
+            got = np.array(Image.open(str(raw / str(s) / ("%06d.tiff" % f))))
+            assert got.dtype == np.uint16 and got.shape == (h, w)
+            assert np.array_equal(got, O.isp_unpack_frame(written[f][cam], bits, w, h))
+    # frame range errors and clamps (Unpacker.cpp:113-129)
+    r = subprocess.run([exe, "--isp_dir", str(isp), "--output_dir", str(out), "--bin_list", str(binp), "--start_frame", "9"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Start frame (9) larger than total number of frames (3)" in r.stderr
+    r = subprocess.run([exe, "--isp_dir", str(isp), "--output_dir", str(out), "--bin_list", str(binp), "--start_frame", "3",
+                        "--frame_count", "5"], capture_output=True, text=True)
+    assert r.returncode == 0 and "End frame (7) larger than total number of frames (3)" in r.stderr
+    r = subprocess.run([exe, "--output_dir", str(out), "--bin_list", str(binp)], capture_output=True, text=True)
+    assert r.returncode != 0 and "missing required command line argument: isp_dir" in r.stderr
+    r = subprocess.run([exe, "--isp_dir", str(isp), "--output_dir", str(out), "--bin_list", str(tmp_path / "none.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Error opening file" in r.stderr
