@@ -72,7 +72,11 @@ typedef float f2n __attribute__((ext_vector_type(2)));
 
 // One barrier per step. Hand-written so that no vmcnt wait is attached (the service waves keep loads in flight
 // across steps; __syncthreads()/the s_barrier builtin would drain them on gfx9-class targets).
+#ifdef S360_WAVE_EMULATION
+__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 template <int K>
 __device__ __forceinline__ float row_bcast(float v) {  // value of lane K of this lane's 16-lane row

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   if (LDSIN) {
     chunk_load(0);
     chunk_store();
+    S360_WAVE_SYNC();
     nrc = s_rec[r][0];
     nfo = s_res[r][0];
   } else {
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       }
       fl = res;
       if (q == 0) s_res[r][LDSIN ? (s & (kQChunk - 1)) : (xi & (kQResRing - 1))] = res;
+      S360_WAVE_SYNC();  // (read below by the publishing lanes and by the chunk's write-back)
       if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
         const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
         if (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1)) {
@@ -349,7 +351,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       }
     }
     if (LDSIN && send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
+      S360_WAVE_SYNC();
       chunk_store();
+      S360_WAVE_SYNC();
       nrc = s_rec[r][0];
       nfo = s_res[r][0];
     }
