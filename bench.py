@@ -587,6 +587,25 @@ def main():
                 out["isp"] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
             except Exception as e:  # noqa: BLE001
                 out["isp"] = {"error": repr(e)}
+
+            # ---- kernel variants behind run-time switches that have not been timed on hardware yet: the same 8K frame
+            # alone, latency sweep kernel, one process per variant (tools/variant_time.py); informative only ----
+            variants = {"default": {}, "S360_LOCK_PEEL=1": {"S360_LOCK_PEEL": "1"}}
+            ab = {}
+            for name, env in variants.items():
+                try:
+                    import subprocess
+                    e = dict(os.environ)
+                    e.update(env)
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variant_time.py"), "--json", "--device",
+                                        str(local_rank)], capture_output=True, text=True, timeout=180, env=e)
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    ab[name] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+                except Exception as ex:  # noqa: BLE001
+                    ab[name] = {"error": repr(ex)}
+            if all("sha1" in v for v in ab.values()):
+                ab["identical_output"] = len({v["sha1"] for v in ab.values() if isinstance(v, dict)}) == 1
+            out["variants"] = ab
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         import traceback
         bail("post-timed-region phase failed: %r %s" % (e, traceback.format_exc()[-600:]))

@@ -56,3 +56,16 @@ def test_quad_tuning_switches_keep_the_result(emulator):
     _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
     _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=3, EMU_CUS=1, EMU_LANE_ORDER="shuffle")
     _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 0])
+
+
+@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
+def test_lock_kernel_with_peeled_steady_state(emulator, mask):
+    """S360_LOCK_PEEL=1: the build whose steps with all four rows inside the image are specialised."""
+    _run(emulator, ["lock", 37, 40, 2, 21, mask, 1], S360_LOCK_PEEL=1)
+    _run(emulator, ["lock", 37, 40, 2, 21, mask, 0], S360_LOCK_PEEL=1, EMU_LANE_ORDER="shuffle")
+
+
+@pytest.mark.parametrize("w,h", [(3, 2), (4, 5), (5, 16), (6, 17), (17, 33), (130, 21)])
+def test_lock_peeled_sizes(emulator, w, h):
+    """Widths below, at and above the first width with a steady range (5)."""
+    _run(emulator, ["lock", w, h, 2, 22, "random", 1], S360_LOCK_PEEL=1)

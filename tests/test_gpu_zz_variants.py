@@ -1,0 +1,42 @@
+"""Kernel variants behind run-time switches, on hardware: a variant must give byte-identical flows. The switches are read
+once per process, so each side of the comparison runs in a process of its own. Sorted last: these variants were brought
+to bit-exactness on the CPU emulation (tests/test_cpu_sweep_emulation.py) after the round's GPU minutes were spent."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SNIPPET = r'''
+import hashlib, os, sys
+sys.path.insert(0, %(root)r)
+import torch  # noqa: F401
+from surround360_amd import render as R, synth
+rig = R.RigDescription(os.path.join(%(root)r, "tests", "golden", "rig_17cam.json"))
+ctx = R.Context(rig, R.make_params())
+h = hashlib.sha1()
+for (w, hh, seed) in ((333, 444, 1), (1214, 700, 2)):
+    i0, i1 = synth.flow_pair(w, hh, seed=seed)
+    i0[: hh // 3, :, 3] = 0  # a band of pixels below the alpha threshold, like the pole flows
+    for alg in ("pixflow_low", "pixflow_search_20"):
+        h.update(ctx.compute_optical_flow(i0, i1, alg, "LEFT").tobytes())
+        h.update(ctx.compute_optical_flow(i1, i0, alg, "RIGHT").tobytes())
+ctx.close()
+print("SHA1", h.hexdigest())
+'''
+
+
+def _flows_digest(**env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", SNIPPET % {"root": ROOT}], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [ln for ln in r.stdout.splitlines() if ln.startswith("SHA1")][-1]
+
+
+def test_lock_kernel_with_peeled_steady_state(s360lib):
+    assert _flows_digest(S360_LOCK_PEEL="1") == _flows_digest()
