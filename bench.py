@@ -590,15 +590,21 @@ def main():
 
             # ---- kernel variants behind run-time switches that have not been timed on hardware yet: the same 8K frame
             # alone, latency sweep kernel, one process per variant (tools/variant_time.py); informative only ----
-            variants = {"default": {}, "S360_LOCK_PEEL=1": {"S360_LOCK_PEEL": "1"}}
+            variants = {"default": {}, "S360_LOCK_PEEL=1": {"S360_LOCK_PEEL": "1"},
+                        "S360_LOCK_NW=2": {"S360_LOCK_NW": "2"}, "S360_LOCK_NW=8": {"S360_LOCK_NW": "8"},
+                        "S360_LOCK_NW=2 S360_LOCK_PEEL=1": {"S360_LOCK_NW": "2", "S360_LOCK_PEEL": "1"}}
             ab = {}
+            t_leg = time.perf_counter()
             for name, env in variants.items():
+                if time.perf_counter() - t_leg > 300.0:
+                    ab[name] = {"skipped": "the leg's time budget was spent"}
+                    continue
                 try:
                     import subprocess
                     e = dict(os.environ)
                     e.update(env)
                     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variant_time.py"), "--json", "--device",
-                                        str(local_rank)], capture_output=True, text=True, timeout=180, env=e)
+                                        str(local_rank)], capture_output=True, text=True, timeout=120, env=e)
                     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     ab[name] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
                 except Exception as ex:  # noqa: BLE001

@@ -139,7 +139,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   // all-ones ("not written") by ONE memset instead of one per launch.
   auto handoff_bytes = [&](int l) {
     const size_t b = sweep_mode_ == 3 ? sweep_quad_handoff_bytes(lv_.w[l], lv_.h[l], B)
-                                      : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, 4);
+                                      : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, sweep_lock_waves());
     return (b + 255) & ~(size_t)255;
   };
   // + per level one word per (flow, row): all-ones = no pixel of the row is updated (written by the record kernel)

@@ -52,6 +52,7 @@ void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev,
                                size_t bs, int B, const FlowIdx& idx);
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
 // lockstep banded sweep (sweep_lock.hip): nw compute waves (4 rows each) + 2 service waves per workgroup
+int sweep_lock_waves();  // compute waves per workgroup of this process (4 unless S360_LOCK_NW says 2 or 8)
 int sweep_lock_num_wgs(int h, int nw);
 size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw);
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,

@@ -700,10 +700,22 @@ static void launch_lock_t(hipStream_t st, const float4* rec, const float2* G, fl
                      h, bs, idx, dir, c, fc, nwg, B, errflag);
 }
 
+// Compute waves per workgroup (4 rows each). 4 is what every measurement of this kernel was taken with; S360_LOCK_NW=2
+// (one wave per SIMD, twice the workgroups per flow) and =8 (half the band-to-band hand-offs through global memory,
+// compute waves sharing SIMDs) are builds of the same code that have no hardware timing yet.
+int sweep_lock_waves() {
+  static const int nw = [] {
+    const char* e = std::getenv("S360_LOCK_NW");
+    const int v = e ? std::atoi(e) : 4;
+    return (v == 2 || v == 8) ? v : 4;
+  }();
+  return nw;
+}
+
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast) {
-  constexpr int nw = 4;
+  const int nw = sweep_lock_waves();
   const SweepConst c = make_sweep_const(pc, w, h);
   SweepFast fc;
   fc.rcCols = 1.0f / c.fcols;
@@ -720,14 +732,21 @@ void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float
     const char* e = std::getenv("S360_LOCK_PEEL");
     return e && e[0] == '1';
   }();
-#define S360_LAUNCH_LOCK(F, P) launch_lock_t<nw, F, P>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg)
-  if (fast) {
-    if (peel) S360_LAUNCH_LOCK(true, true);
-    else S360_LAUNCH_LOCK(true, false);
-  } else {
-    if (peel) S360_LAUNCH_LOCK(false, true);
-    else S360_LAUNCH_LOCK(false, false);
-  }
+#define S360_LAUNCH_LOCK(N, F, P) launch_lock_t<N, F, P>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg)
+#define S360_LAUNCH_LOCK_N(N)                   \
+  do {                                          \
+    if (fast) {                                 \
+      if (peel) S360_LAUNCH_LOCK(N, true, true); \
+      else S360_LAUNCH_LOCK(N, true, false);    \
+    } else {                                    \
+      if (peel) S360_LAUNCH_LOCK(N, false, true); \
+      else S360_LAUNCH_LOCK(N, false, false);   \
+    }                                           \
+  } while (0)
+  if (nw == 2) S360_LAUNCH_LOCK_N(2);
+  else if (nw == 8) S360_LAUNCH_LOCK_N(8);
+  else S360_LAUNCH_LOCK_N(4);
+#undef S360_LAUNCH_LOCK_N
 #undef S360_LAUNCH_LOCK
 }
 

@@ -69,3 +69,13 @@ def test_lock_kernel_with_peeled_steady_state(emulator, mask):
 def test_lock_peeled_sizes(emulator, w, h):
     """Widths below, at and above the first width with a steady range (5)."""
     _run(emulator, ["lock", w, h, 2, 22, "random", 1], S360_LOCK_PEEL=1)
+
+
+@pytest.mark.parametrize("nw", [2, 8])
+def test_lock_workgroup_heights(emulator, nw):
+    """S360_LOCK_NW: 2 / 8 compute waves per workgroup (bands of 8 / 32 rows), alone and with the peeled steps."""
+    for mask in ("random", "bands", "rows0"):
+        _run(emulator, ["lock", 41, 70, 2, 23, mask, 1], S360_LOCK_NW=nw)
+        _run(emulator, ["lock", 41, 70, 2, 23, mask, 0], S360_LOCK_NW=nw, S360_LOCK_PEEL=1, EMU_LANE_ORDER="shuffle")
+    _run(emulator, ["lock", 3, 2, 2, 24, "random", 1], S360_LOCK_NW=nw, S360_LOCK_PEEL=1)
+    _run(emulator, ["lock", 64, 65, 3, 24, "random", 1], S360_LOCK_NW=nw, S360_LOCK_PEEL=1)

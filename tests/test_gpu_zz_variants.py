@@ -38,5 +38,16 @@ def _flows_digest(**env):
     return [ln for ln in r.stdout.splitlines() if ln.startswith("SHA1")][-1]
 
 
-def test_lock_kernel_with_peeled_steady_state(s360lib):
-    assert _flows_digest(S360_LOCK_PEEL="1") == _flows_digest()
+@pytest.fixture(scope="module")
+def default_digest(s360lib):
+    return _flows_digest()
+
+
+def test_lock_kernel_with_peeled_steady_state(default_digest):
+    assert _flows_digest(S360_LOCK_PEEL="1") == default_digest
+
+
+@pytest.mark.parametrize("nw", ["2", "8"])
+def test_lock_kernel_with_other_workgroup_heights(default_digest, nw):
+    """S360_LOCK_NW: 2 or 8 compute waves (8 or 32 rows) per workgroup instead of 4, with the peeled steps as well."""
+    assert _flows_digest(S360_LOCK_NW=nw, S360_LOCK_PEEL="1") == default_digest

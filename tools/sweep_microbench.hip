@@ -53,7 +53,7 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, in
   CK(hipMalloc(&dG, hG.size() * 4));
   CK(hipMalloc(&drec, hrec.size() * 4));
   CK(hipMalloc(&dflow, hflow.size() * 4));
-  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, 4), sweep_quad_handoff_bytes(w, h, B));
+  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   CK(hipMalloc(&hand, hb));
   CK(hipMalloc(&err, 8));
   CK(hipMemset(err, 0, 8));
@@ -117,7 +117,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<void*> hand(NS);
   std::vector<unsigned*> err(NS);
   std::vector<hipStream_t> st(NS);
-  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, 4), sweep_quad_handoff_bytes(w, h, B));
+  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
     CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
