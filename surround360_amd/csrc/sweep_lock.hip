@@ -422,7 +422,12 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       };
       const int tA = min(max(kLag * j + 4, -1), T), tB = min(max(kLag * j + w, tA), T);  // steady: local steps [4, w)
       for (int t = -1; t < tA; ++t) step(std::false_type{}, t);
-      for (int t = tA; t < tB; ++t) step(std::true_type{}, t);
+      int t2 = tA;
+      for (; t2 + 1 < tB; t2 += 2) {
+        step(std::true_type{}, t2);
+        step(std::true_type{}, t2 + 1);
+      }
+      if (t2 < tB) step(std::true_type{}, t2);
       for (int t = tB; t < T; ++t) step(std::false_type{}, t);
     }
     TS_DUMP();
