@@ -590,27 +590,34 @@ def main():
 
             # ---- kernel variants behind run-time switches that have not been timed on hardware yet: the same 8K frame
             # alone, latency sweep kernel, one process per variant (tools/variant_time.py); informative only ----
-            variants = {"default": {}, "S360_LOCK_PEEL=1": {"S360_LOCK_PEEL": "1"},
-                        "S360_LOCK_NW=2": {"S360_LOCK_NW": "2"}, "S360_LOCK_NW=8": {"S360_LOCK_NW": "8"},
-                        "S360_LOCK_NW=2 S360_LOCK_PEEL=1": {"S360_LOCK_NW": "2", "S360_LOCK_PEEL": "1"}}
-            ab = {}
+            # (this process's contexts are released first: a 12-slot batch needs ~100 GB of its own)
+            for c in ctxs:
+                c.close()
+            torch.cuda.empty_cache()
+            variants = [("latency", "default", {}, 1), ("latency", "S360_LOCK_PEEL=1", {"S360_LOCK_PEEL": "1"}, 1),
+                        ("throughput", "default", {}, S), ("throughput", "S360_QUAD_PEEL=1", {"S360_QUAD_PEEL": "1"}, S),
+                        ("latency", "S360_LOCK_NW=2", {"S360_LOCK_NW": "2"}, 1),
+                        ("latency", "S360_LOCK_NW=8", {"S360_LOCK_NW": "8"}, 1),
+                        ("latency", "S360_LOCK_NW=2 S360_LOCK_PEEL=1", {"S360_LOCK_NW": "2", "S360_LOCK_PEEL": "1"}, 1)]
+            ab = {"latency": {}, "throughput": {}}
             t_leg = time.perf_counter()
-            for name, env in variants.items():
-                if time.perf_counter() - t_leg > 300.0:
-                    ab[name] = {"skipped": "the leg's time budget was spent"}
+            for group, name, env, slots in variants:
+                if time.perf_counter() - t_leg > 180.0:
+                    ab[group][name] = {"skipped": "the leg's time budget was spent"}
                     continue
                 try:
                     import subprocess
                     e = dict(os.environ)
                     e.update(env)
                     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variant_time.py"), "--json", "--device",
-                                        str(local_rank)], capture_output=True, text=True, timeout=120, env=e)
+                                        str(local_rank), "--slots", str(slots)], capture_output=True, text=True, timeout=100, env=e)
                     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                    ab[name] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+                    ab[group][name] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
                 except Exception as ex:  # noqa: BLE001
-                    ab[name] = {"error": repr(ex)}
-            if all("sha1" in v for v in ab.values()):
-                ab["identical_output"] = len({v["sha1"] for v in ab.values() if isinstance(v, dict)}) == 1
+                    ab[group][name] = {"error": repr(ex)}
+            for group in ("latency", "throughput"):
+                shas = {v.get("sha1") for v in ab[group].values() if "sha1" in v}
+                ab[group]["identical_output"] = len(shas) == 1 if shas else None
             out["variants"] = ab
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         import traceback

@@ -214,10 +214,10 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
           nin = s_in[j][s1 & (kRingK - 1)][rr];
           nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
         }
-  #ifdef S360_SWEEP_TIMING
+#ifdef S360_SWEEP_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TS(6);
-  #endif
+#endif
         if (!run) continue;
         if (!any) {
           const float2 keep = active ? fo : fl;
@@ -352,10 +352,10 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
           nin = s_in[j][s1 & (kRingK - 1)][rr];
           nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
         }
-  #ifdef S360_SWEEP_TIMING
+#ifdef S360_SWEEP_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TS(6);
-  #endif
+#endif
         if (!run) return;
         if (!any) {
           const float2 keep = active ? fo : fl;

@@ -26,7 +26,7 @@
 //     flow's pixels are like that.
 // Measured (tools/sweep_microbench tp1, see tools/mb_experiment.sh): ~24 Gpx/s on saturated side levels (336 flows of
 // 607x884), ~22 Gpx/s on the 48 pole flows of a 12-frame batch; a single flow runs ~1.4x slower than with
-// sweep_lock.hip. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode / S360_SWEEP=quad).
+// sweep_lock.hip. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -77,7 +77,7 @@ constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every 
 // The sweeps of one launch then hold a bounded share of every CU — a wave's working set is ~8 KB (17 gradient rows +
 // its record / flow lines) and beyond ~15 waves per CU the 32 KB L1 thrashes — and the kernels of another context
 // find free wave slots, registers and LDS next to them.
-template <bool FAST, bool LDSIN>
+template <bool FAST, bool LDSIN, bool PEEL>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
@@ -169,12 +169,12 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   };
   // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
   // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
-  auto update = [&](auto ieee, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool& tiny) -> float2 {
+  auto update = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool& tiny) -> float2 {
     const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
     const float e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
     const float e0 = quad_bcast<0>(e);
     float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
-    if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column
+    if (!decltype(steady)::value && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
     if (!hasUp) e2 = kInf;     // no up proposal in the first row
     float2 f = fo;
     float cur = e0;
@@ -250,15 +250,123 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     nrc = recRow[x0c];
     nfo = flowRow[x0c];
   }
-  for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
-    const int send = min(s0 + kQChunk, nsteps);
-    if (LDSIN && s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
-    for (int s = s0; s < send; ++s) {
-      // Row 0 needs column s of the band above only if its pixel is updated at this step (pixels below the alpha
-      // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
-      // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
-      // of steps that did not need the band above (the columns passed meanwhile are dropped).
-      if (hasUpBand && s < w && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
+  if constexpr (!PEEL) {
+    for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
+      const int send = min(s0 + kQChunk, nsteps);
+      if (LDSIN && s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
+      for (int s = s0; s < send; ++s) {
+        // Row 0 needs column s of the band above only if its pixel is updated at this step (pixels below the alpha
+        // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
+        // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
+        // of steps that did not need the band above (the columns passed meanwhile are dropped).
+        if (hasUpBand && s < w && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
+          const int need = min(s + kQNeed, w), limit = s + kUpRing;
+          if (upFilled < s) {
+            upFilled = s;
+            pending = false;
+          }
+          if (pending) process(limit);
+          unsigned spins = 0;
+          while (upFilled < need) {
+            if (spins) {  // back off: a band waiting for its predecessor should leave the issue slots and the L2 to it
+              if (spins < 4) __builtin_amdgcn_s_sleep(8);
+              else __builtin_amdgcn_s_sleep(48);
+            }
+            issue();
+            process(limit);
+            if (++spins > (1u << 20) ||
+                ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
+              if (lane == 0) atomicExch(errflag, 1u);
+            }
+          }
+          if (upFilled < w && upFilled - s < 2 * kQNeed + 8) issue();  // running low: taken at the next check
+        }
+        const float4 rc = nrc;
+        const float2 fo = nfo;
+        if (LDSIN) {  // inputs of the next step of this chunk (the first step of the next chunk is read after the refill)
+          if (s + 1 < send) {
+            nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
+            nfo = s_res[r][(s + 1) & (kQChunk - 1)];
+          }
+        } else {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
+          const int xn = S360_DBG(fc, 8) ? col(-r) : col(s + 1 - r);  // (dbg 8: timing experiment, inputs that always hit)
+          if (S360_DBG(fc, 16)) {  // (dbg 16: inputs as streaming loads that do not allocate in L1; results unchanged)
+            typedef float f4n __attribute__((ext_vector_type(4)));
+            typedef float f2n __attribute__((ext_vector_type(2)));
+            const f4n a = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(recRow) + xn);
+            const f2n bq = __builtin_nontemporal_load(reinterpret_cast<const f2n*>(flowRow) + xn);
+            nrc = make_float4(a.x, a.y, a.z, a.w);
+            nfo = make_float2(bq.x, bq.y);
+          } else {
+            nrc = recRow[xn];
+            nfo = flowRow[xn];
+          }
+        }
+        const float2 upl = s_up[s & (kUpRing - 1)];
+        const int xi = s - r;
+        const bool active = rowValid && xi >= 0 && xi < w;
+        const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
+        const bool upd = rc.x == rc.x;
+        float2 up;
+        up.x = from_row_above_q(upl.x, fl.x);
+        up.y = from_row_above_q(upl.y, fl.y);
+        // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
+        // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
+        // two gather rounds and the evaluations are skipped.
+        const bool take = active && upd;
+        const float2 alt = active ? fo : fl;
+        float2 res = alt;
+        if (__ballot(take) != 0ull) {
+          if (FAST) {
+            bool tiny = false;
+            res = update(std::false_type{}, std::false_type{}, x, xi, rc, fo, fl, up, tiny);
+            if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, std::false_type{}, x, xi, rc, fo, fl, up, tiny);
+          } else {
+            bool tiny = false;
+            res = update(std::true_type{}, std::false_type{}, x, xi, rc, fo, fl, up, tiny);
+          }
+          res.x = take ? res.x : alt.x;
+          res.y = take ? res.y : alt.y;
+        }
+        fl = res;
+        if (q == 0) s_res[r][LDSIN ? (s & (kQChunk - 1)) : (xi & (kQResRing - 1))] = res;
+        S360_WAVE_SYNC();  // (read below by the publishing lanes and by the chunk's write-back)
+        if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
+          const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
+          if (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1)) {
+            const float2 v = s_res[kQRows - 1][LDSIN ? ((xi0 + kQRows - 1) & (kQChunk - 1)) : (xi0 & (kQResRing - 1))];
+            __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
+      {
+        const int base = s0 - r + q;
+  #pragma unroll
+        for (int k = 0; k < kQChunk / 4; ++k) {
+          const int xi = base + 4 * k;
+          if (rowValid && xi >= 0 && xi < w && xi < send - r && !S360_DBG(fc, 4))
+            flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][LDSIN ? ((xi + r) & (kQChunk - 1)) : (xi & (kQResRing - 1))];
+        }
+      }
+      if (LDSIN && send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
+        S360_WAVE_SYNC();
+        chunk_store();
+        S360_WAVE_SYNC();
+        nrc = s_rec[r][0];
+        nfo = s_res[r][0];
+      }
+    }
+  } else {
+    // PEEL builds (LDS-staged inputs only): a chunk all of whose 16 steps have every row of the wave inside the image with a
+    // left neighbour (local steps 16 .. w-1, chunk-aligned) runs the same step with the range tests, the first-column case,
+    // the sweep direction select and the publish / write-back bounds folded away.
+    const int xLane = dir > 0 ? -r : w - 1 + r, xSign = dir > 0 ? 1 : -1;
+    auto step = [&](auto steady, int s, int send) {
+      constexpr bool ST = decltype(steady)::value;
+      if (hasUpBand && (ST || s < w) && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
         const int need = min(s + kQNeed, w), limit = s + kUpRing;
         if (upFilled < s) {
           upFilled = s;
@@ -283,79 +391,71 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       }
       const float4 rc = nrc;
       const float2 fo = nfo;
-      if (LDSIN) {  // inputs of the next step of this chunk (the first step of the next chunk is read after the refill)
-        if (s + 1 < send) {
-          nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
-          nfo = s_res[r][(s + 1) & (kQChunk - 1)];
-        }
-      } else {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
-        const int xn = S360_DBG(fc, 8) ? col(-r) : col(s + 1 - r);  // (dbg 8: timing experiment, inputs that always hit)
-        if (S360_DBG(fc, 16)) {  // (dbg 16: inputs as streaming loads that do not allocate in L1; results unchanged)
-          typedef float f4n __attribute__((ext_vector_type(4)));
-          typedef float f2n __attribute__((ext_vector_type(2)));
-          const f4n a = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(recRow) + xn);
-          const f2n bq = __builtin_nontemporal_load(reinterpret_cast<const f2n*>(flowRow) + xn);
-          nrc = make_float4(a.x, a.y, a.z, a.w);
-          nfo = make_float2(bq.x, bq.y);
-        } else {
-          nrc = recRow[xn];
-          nfo = flowRow[xn];
-        }
+      if (s + 1 < send) {
+        nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
+        nfo = s_res[r][(s + 1) & (kQChunk - 1)];
       }
       const float2 upl = s_up[s & (kUpRing - 1)];
       const int xi = s - r;
-      const bool active = rowValid && xi >= 0 && xi < w;
-      const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
+      const bool active = ST ? rowValid : (rowValid && xi >= 0 && xi < w);
+      const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);
       const bool upd = rc.x == rc.x;
       float2 up;
       up.x = from_row_above_q(upl.x, fl.x);
       up.y = from_row_above_q(upl.y, fl.y);
-      // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
-      // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
-      // two gather rounds and the evaluations are skipped.
       const bool take = active && upd;
       const float2 alt = active ? fo : fl;
       float2 res = alt;
       if (__ballot(take) != 0ull) {
         if (FAST) {
           bool tiny = false;
-          res = update(std::false_type{}, x, xi, rc, fo, fl, up, tiny);
-          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
+          res = update(std::false_type{}, steady, x, xi, rc, fo, fl, up, tiny);
+          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, tiny);
         } else {
           bool tiny = false;
-          res = update(std::true_type{}, x, xi, rc, fo, fl, up, tiny);
+          res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, tiny);
         }
         res.x = take ? res.x : alt.x;
         res.y = take ? res.y : alt.y;
       }
       fl = res;
-      if (q == 0) s_res[r][LDSIN ? (s & (kQChunk - 1)) : (xi & (kQResRing - 1))] = res;
-      S360_WAVE_SYNC();  // (read below by the publishing lanes and by the chunk's write-back)
-      if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
+      if (q == 0) s_res[r][s & (kQChunk - 1)] = res;
+      S360_WAVE_SYNC();
+      if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || (!ST && s == nsteps - 1))) {
         const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
-        if (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1)) {
-          const float2 v = s_res[kQRows - 1][LDSIN ? ((xi0 + kQRows - 1) & (kQChunk - 1)) : (xi0 & (kQResRing - 1))];
+        if (ST ? lane < kQPub : (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1))) {
+          const float2 v = s_res[kQRows - 1][(xi0 + kQRows - 1) & (kQChunk - 1)];
           __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-    }
-    // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
-    {
-      const int base = s0 - r + q;
-#pragma unroll
-      for (int k = 0; k < kQChunk / 4; ++k) {
-        const int xi = base + 4 * k;
-        if (rowValid && xi >= 0 && xi < w && xi < send - r && !S360_DBG(fc, 4))
-          flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][LDSIN ? ((xi + r) & (kQChunk - 1)) : (xi & (kQResRing - 1))];
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
+      const int send = min(s0 + kQChunk, nsteps);
+      if (s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
+      const bool steadyChunk = s0 >= kQRows && s0 + kQChunk <= w;
+      if (steadyChunk) {
+        for (int s = s0; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
+      } else {
+        for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
       }
-    }
-    if (LDSIN && send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
-      S360_WAVE_SYNC();
-      chunk_store();
-      S360_WAVE_SYNC();
-      nrc = s_rec[r][0];
-      nfo = s_res[r][0];
+      // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
+      {
+        const int base = s0 - r + q;
+  #pragma unroll
+        for (int k = 0; k < kQChunk / 4; ++k) {
+          const int xi = base + 4 * k;
+          if (rowValid && (steadyChunk || (xi >= 0 && xi < w && xi < send - r)))
+            flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][(xi + r) & (kQChunk - 1)];
+        }
+      }
+      if (send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
+        S360_WAVE_SYNC();
+        chunk_store();
+        S360_WAVE_SYNC();
+        nrc = s_rec[r][0];
+        nfo = s_res[r][0];
+      }
     }
   }
   }  // next ticket
@@ -401,15 +501,22 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     const char* e = std::getenv("S360_QUAD_LDSIN");
     return !(e && e[0] == '0');
   }();
-#define S360_LAUNCH_QUAD(F, L)                                                                                      \
-  hipLaunchKernelGGL((k_sweep_quad<F, L>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
-                     fc, nb, B, errflag, rowflags)
+  // S360_QUAD_PEEL=1: the build whose all-interior chunks are specialised (same results; not yet timed on hardware)
+  static const bool peel = [] {
+    const char* e = std::getenv("S360_QUAD_PEEL");
+    return e && e[0] == '1';
+  }();
+#define S360_LAUNCH_QUAD(F, L, P)                                                                                      \
+  hipLaunchKernelGGL((k_sweep_quad<F, L, P>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, \
+                     c, fc, nb, B, errflag, rowflags)
   if (fast) {
-    if (ldsin) S360_LAUNCH_QUAD(true, true);
-    else S360_LAUNCH_QUAD(true, false);
+    if (ldsin && peel) S360_LAUNCH_QUAD(true, true, true);
+    else if (ldsin) S360_LAUNCH_QUAD(true, true, false);
+    else S360_LAUNCH_QUAD(true, false, false);
   } else {
-    if (ldsin) S360_LAUNCH_QUAD(false, true);
-    else S360_LAUNCH_QUAD(false, false);
+    if (ldsin && peel) S360_LAUNCH_QUAD(false, true, true);
+    else if (ldsin) S360_LAUNCH_QUAD(false, true, false);
+    else S360_LAUNCH_QUAD(false, false, false);
   }
 #undef S360_LAUNCH_QUAD
 }

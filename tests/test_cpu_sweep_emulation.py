@@ -79,3 +79,17 @@ def test_lock_workgroup_heights(emulator, nw):
         _run(emulator, ["lock", 41, 70, 2, 23, mask, 0], S360_LOCK_NW=nw, S360_LOCK_PEEL=1, EMU_LANE_ORDER="shuffle")
     _run(emulator, ["lock", 3, 2, 2, 24, "random", 1], S360_LOCK_NW=nw, S360_LOCK_PEEL=1)
     _run(emulator, ["lock", 64, 65, 3, 24, "random", 1], S360_LOCK_NW=nw, S360_LOCK_PEEL=1)
+
+
+@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
+def test_quad_kernel_with_peeled_interior_chunks(emulator, mask):
+    """S360_QUAD_PEEL=1: chunks whose 16 steps have every row inside the image run the specialised step."""
+    _run(emulator, ["quad", 70, 50, 2, 31, mask, 1, 1], S360_QUAD_PEEL=1)
+    _run(emulator, ["quad", 53, 40, 2, 32, mask, 0, 0], S360_QUAD_PEEL=1, EMU_LANE_ORDER="shuffle")
+
+
+@pytest.mark.parametrize("w,h", [(3, 2), (16, 16), (31, 16), (32, 17), (33, 33), (48, 20), (200, 70)])
+def test_quad_peeled_sizes(emulator, w, h):
+    """Widths without, with exactly one and with several interior chunks (the first one is steps 16..31: w >= 32)."""
+    _run(emulator, ["quad", w, h, 2, 33, "random", 1, 1], S360_QUAD_PEEL=1)
+    _run(emulator, ["quad", w, h, 2, 33, "bands", 1, 1], S360_QUAD_PEEL=1, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)

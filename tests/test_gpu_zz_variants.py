@@ -18,6 +18,7 @@ import torch  # noqa: F401
 from surround360_amd import render as R, synth
 rig = R.RigDescription(os.path.join(%(root)r, "tests", "golden", "rig_17cam.json"))
 ctx = R.Context(rig, R.make_params())
+ctx.set_sweep_mode(os.environ.get("TEST_SWEEP_MODE", "latency"))
 h = hashlib.sha1()
 for (w, hh, seed) in ((333, 444, 1), (1214, 700, 2)):
     i0, i1 = synth.flow_pair(w, hh, seed=seed)
@@ -45,6 +46,11 @@ def default_digest(s360lib):
 
 def test_lock_kernel_with_peeled_steady_state(default_digest):
     assert _flows_digest(S360_LOCK_PEEL="1") == default_digest
+
+
+def test_quad_kernel_with_peeled_interior_chunks(s360lib):
+    """S360_QUAD_PEEL=1 against the default build of the throughput kernel."""
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1") == _flows_digest(TEST_SWEEP_MODE="throughput")
 
 
 @pytest.mark.parametrize("nw", ["2", "8"])
