@@ -3,8 +3,9 @@
 // camera.h: restatement of the rig geometry model, Eigen/folly-free:
 //   surround360_render/source/render/Camera.h:133-284, Camera.cpp:16-83,144-167
 //   surround360_render/source/render/RigDescription.cpp:18-78, RigDescription.h:58-60
-// Known answers: Camera::unitTest (Camera.cpp:291-410) is replayed by
-// tests/test_camera.py through oracle_capi.cpp.
+// Known answers: Camera::unitTest (Camera.cpp:291-410) is replayed by tests/test_cpu_oracle.py through
+// oracle_capi.cpp; the reference's own Camera.cpp / RigDescription.cpp run inside oracle/_ref/TestRenderStereoPanorama,
+// whose outputs equal this oracle's (tests/test_cpu_refprogram.py). Eigen itself is restated, here and in ref_shim.
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -49,7 +49,10 @@ enum { CV_8U = 0, CV_8S = 1, CV_16U = 2, CV_16S = 3, CV_32S = 4, CV_32F = 5, CV_
 #define CV_32FC1 CV_MAKETYPE(cv::CV_32F, 1)
 #define CV_32FC2 CV_MAKETYPE(cv::CV_32F, 2)
 #define CV_32FC3 CV_MAKETYPE(cv::CV_32F, 3)
-enum { IMREAD_COLOR = 1 };
+#define CV_32FC4 CV_MAKETYPE(cv::CV_32F, 4)
+#define CV_8UC2 CV_MAKETYPE(cv::CV_8U, 2)
+#define CV_64FC1 CV_MAKETYPE(cv::CV_64F, 1)
+enum { IMREAD_UNCHANGED = -1, IMREAD_GRAYSCALE = 0, IMREAD_COLOR = 1 };
 enum { MORPH_RECT = 0, MORPH_CROSS = 1, MORPH_ELLIPSE = 2 };
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2 };
 enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT_101 = 4 };
@@ -57,6 +60,10 @@ enum { COLOR_BGRA2GRAY = 10, COLOR_BGR2BGRA = 0, COLOR_BGRA2BGR = 1 };
 #define CV_INTER_LINEAR 1
 #define CV_INTER_CUBIC 2
 #define CV_BGRA2GRAY 10
+#define CV_BGR2BGRA 0
+#define CV_BGRA2BGR 1
+#define CV_LOAD_IMAGE_COLOR 1
+#define CV_LOAD_IMAGE_UNCHANGED -1
 #define CV_LOAD_IMAGE_GRAYSCALE 0
 #define CV_LOAD_IMAGE_ANYDEPTH 2
 
@@ -98,6 +105,9 @@ typedef Vec<float, 2> Vec2f;
 typedef Vec<float, 3> Vec3f;
 typedef Vec<float, 4> Vec4f;
 typedef Vec<double, 3> Vec3d;
+// norm(Matx): L2 norm accumulated in double
+template <typename T, int N>
+inline double norm(const Vec<T, N>& v) { double s = 0; for (int i = 0; i < N; ++i) s += (double)v.val[i] * (double)v.val[i]; return std::sqrt(s); }
 
 template <typename T>
 struct Point_ {
@@ -143,7 +153,11 @@ struct Rect {
   Rect() : x(0), y(0), width(0), height(0) {}
   Rect(int a, int b, int c, int d) : x(a), y(b), width(c), height(d) {}
 };
-struct Scalar { double val[4]; };
+struct Scalar {
+  double val[4];
+  Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+  double operator[](int i) const { return val[i]; }
+};
 
 inline size_t elemSize(int type) {
   static const int d[7] = {1, 1, 2, 2, 4, 4, 8};
@@ -154,26 +168,30 @@ class Mat {
  public:
   int rows, cols, dims;
   uchar* data;
-  Mat() : rows(0), cols(0), dims(0), data(nullptr), type_(0) {}
+  size_t step;  // bytes from one row to the next (a region of interest keeps its parent's)
+  Mat() : rows(0), cols(0), dims(0), data(nullptr), step(0), type_(0) {}
   Mat(int r, int c, int type) { create(r, c, type); }
   Mat(Size s, int type) { create(s.height, s.width, type); }
-  Mat(int r, int c, int type, void* ext) : rows(r), cols(c), dims(2), data((uchar*)ext), type_(type) {}  // wraps, does not copy
+  Mat(int r, int c, int type, void* ext) : rows(r), cols(c), dims(2), data((uchar*)ext), step((size_t)c * elemSize(type)), type_(type) {}  // wraps, does not copy
   void create(int r, int c, int type) {
     rows = r; cols = c; type_ = type; dims = 2;
+    step = (size_t)c * elemSize(type);
     store_.reset(new std::vector<uchar>((size_t)r * c * elemSize(type) + 64));  // uninitialised in OpenCV; zero here
     data = store_->data();
   }
+  bool isContinuous() const { return step == (size_t)cols * elemSize(type_); }
   static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
   static Mat zeros(Size s, int type) { return Mat(s.height, s.width, type); }
-  template <typename T> T* ptr(int y) { return reinterpret_cast<T*>(data + (size_t)y * cols * elemSize(type_)); }
-  template <typename T> const T* ptr(int y) const { return reinterpret_cast<const T*>(data + (size_t)y * cols * elemSize(type_)); }
+  template <typename T> T* ptr(int y) { return reinterpret_cast<T*>(data + (size_t)y * step); }
+  template <typename T> const T* ptr(int y) const { return reinterpret_cast<const T*>(data + (size_t)y * step); }
   size_t total() const { return (size_t)rows * cols; }
   // convertTo(dst, CV_32F) from 8-bit data (PixFlow.h:128-133): exact
   void convertTo(Mat& dst, int rtype) const {
     assert(depth() == CV_8U && (rtype & CV_MAT_DEPTH_MASK) == CV_32F);
+    const Mat s = isContinuous() ? *this : clone();
     Mat d(rows, cols, CV_MAKETYPE(CV_32F, channels()));
     const size_t n = total() * channels();
-    for (size_t i = 0; i < n; ++i) reinterpret_cast<float*>(d.data)[i] = (float)data[i];
+    for (size_t i = 0; i < n; ++i) reinterpret_cast<float*>(d.data)[i] = (float)s.data[i];
     dst = d;
   }
   static Mat eye(int r, int c, int type) {
@@ -187,13 +205,24 @@ class Mat {
   int channels() const { return (type_ >> CV_CN_SHIFT) + 1; }
   Size size() const { return Size(cols, rows); }
   bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-  Mat clone() const {
+  Mat clone() const {  // always continuous
     Mat m(rows, cols, type_);
-    std::memcpy(m.data, data, (size_t)rows * cols * elemSize(type_));
+    for (int y = 0; y < rows; ++y) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, m.step);
     return m;
   }
-  template <typename T> T& at(int i, int j) { return reinterpret_cast<T*>(data)[(size_t)i * cols + j]; }
-  template <typename T> const T& at(int i, int j) const { return reinterpret_cast<const T*>(data)[(size_t)i * cols + j]; }
+  // A region of interest: a view that shares the parent's pixels and row step, as in OpenCV. (at(y, x) with x beyond the
+  // view's width then lands in the parent's row, not in the view's next row — TestRenderStereoPanorama.cpp:530-535
+  // walks a view with the parent's width.)
+  Mat operator()(const Rect& r) const {
+    assert(r.x >= 0 && r.y >= 0 && r.x + r.width <= cols && r.y + r.height <= rows);
+    Mat m;
+    m.rows = r.height; m.cols = r.width; m.dims = 2; m.type_ = type_; m.step = step; m.store_ = store_;
+    m.data = data + (size_t)r.y * step + (size_t)r.x * elemSize(type_);
+    return m;
+  }
+  void copyTo(Mat& dst) const { dst = clone(); }
+  template <typename T> T& at(int i, int j) { return *reinterpret_cast<T*>(data + (size_t)i * step + (size_t)j * sizeof(T)); }
+  template <typename T> const T& at(int i, int j) const { return *reinterpret_cast<const T*>(data + (size_t)i * step + (size_t)j * sizeof(T)); }
   template <typename T> T& at(int i) { return reinterpret_cast<T*>(data)[i]; }
   template <typename T> const T& at(int i) const { return reinterpret_cast<const T*>(data)[i]; }
 
@@ -219,7 +248,7 @@ inline Mat operator*(const Mat& a, const Mat& b) {
 }
 inline Mat& operator*=(Mat& a, const Mat& b) { a = a * b; return a; }
 inline Mat& operator*=(Mat& a, double s) {
-  assert(a.depth() == CV_32F);
+  assert(a.depth() == CV_32F && a.isContinuous());
   const size_t n = a.total() * a.channels();
   for (size_t i = 0; i < n; ++i) reinterpret_cast<float*>(a.data)[i] = reinterpret_cast<float*>(a.data)[i] * (float)s;
   return a;

@@ -11,14 +11,17 @@
 namespace cv {
 
 namespace shim {
-inline orc::ImgF to_imgf(const Mat& m) {
-  assert(m.depth() == CV_32F);
+inline Mat cont(const Mat& m) { return m.isContinuous() ? m : m.clone(); }  // the functions below index packed rows
+inline orc::ImgF to_imgf(const Mat& m0) {
+  assert(m0.depth() == CV_32F);
+  const Mat m = cont(m0);
   orc::ImgF r(m.cols, m.rows, m.channels());
   std::memcpy(r.d.data(), m.data, r.bytes());
   return r;
 }
-inline orc::ImgU8 to_imgu8(const Mat& m) {
-  assert(m.depth() == CV_8U);
+inline orc::ImgU8 to_imgu8(const Mat& m0) {
+  assert(m0.depth() == CV_8U);
+  const Mat m = cont(m0);
   orc::ImgU8 r(m.cols, m.rows, m.channels());
   std::memcpy(r.d.data(), m.data, r.bytes());
   return r;
@@ -39,18 +42,23 @@ inline Mat from_img(const orc::ImgU8& i) {
 }
 }  // namespace shim
 
-inline Mat imread(const std::string&, int = IMREAD_COLOR) { shim::unsupported("imread"); }
-inline bool imwrite(const std::string&, const Mat&, const std::vector<int>& = std::vector<int>()) { shim::unsupported("imwrite"); }
+// imread / imwrite for 8-bit PNG files through the repository's own PNG codec (host/png_io.hpp; checked against PIL in
+// tests/test_cpu_host.py): IMREAD_COLOR -> B,G,R; IMREAD_UNCHANGED keeps an alpha channel; imwrite stores B,G,R(,A) or grey.
+Mat imread(const std::string& path, int flags = IMREAD_COLOR);
+bool imwrite(const std::string& path, const Mat& img, const std::vector<int>& params = std::vector<int>());
 
 // remap as the stereo path calls it: float (x, y) map in map1, no map2.
 //   INTER_CUBIC, BORDER_CONSTANT(0): CV_8UC4 / CV_8UC3 images and CV_32FC2 flows -> cvlite's restatements
 //   INTER_NEAREST, BORDER_WRAP (offsetHorizontalWrap): source = (cvRound(x), cvRound(y)) wrapped
-inline void remap(const Mat& src, Mat& dst, const Mat& map1, const Mat& map2, int interpolation,
+inline void remap(const Mat& src0, Mat& dst, const Mat& map10, const Mat& map2, int interpolation,
                   int borderMode = BORDER_CONSTANT) {
+  const Mat src = shim::cont(src0), map1 = shim::cont(map10);
   if (!map2.empty() || map1.type() != CV_32FC2) shim::unsupported("this remap map format");
   const orc::ImgF mp = shim::to_imgf(map1);
   if (interpolation == INTER_CUBIC && borderMode == BORDER_CONSTANT && src.depth() == CV_8U) {
     dst = shim::from_img(orc::remapCubicU8(shim::to_imgu8(src), mp));
+  } else if (interpolation == INTER_CUBIC && borderMode == BORDER_WRAP && src.depth() == CV_8U) {  // cubemap faces
+    dst = shim::from_img(orc::remapCubicU8Wrap(shim::to_imgu8(src), mp));
   } else if (interpolation == INTER_CUBIC && borderMode == BORDER_CONSTANT && src.depth() == CV_32F) {
     dst = shim::from_img(orc::remapCubicF32(shim::to_imgf(src), mp));
   } else if (interpolation == INTER_NEAREST && borderMode == BORDER_WRAP && src.depth() == CV_8U) {
@@ -69,7 +77,8 @@ inline void remap(const Mat& src, Mat& dst, const Mat& map1, const Mat& map2, in
     shim::unsupported("this remap variant");
   }
 }
-inline void hconcat(const Mat& a, const Mat& b, Mat& dst) {
+inline void hconcat(const Mat& a0, const Mat& b0, Mat& dst) {
+  const Mat a = shim::cont(a0), b = shim::cont(b0);
   assert(a.rows == b.rows && a.type() == b.type());
   Mat d(a.rows, a.cols + b.cols, a.type());
   const size_t es = elemSize(a.type());
@@ -79,7 +88,8 @@ inline void hconcat(const Mat& a, const Mat& b, Mat& dst) {
   }
   dst = d;
 }
-inline void vconcat(const Mat& a, const Mat& b, Mat& dst) {
+inline void vconcat(const Mat& a0, const Mat& b0, Mat& dst) {
+  const Mat a = shim::cont(a0), b = shim::cont(b0);
   assert(a.cols == b.cols && a.type() == b.type());
   Mat d(a.rows + b.rows, a.cols, a.type());
   const size_t es = elemSize(a.type());
@@ -87,16 +97,35 @@ inline void vconcat(const Mat& a, const Mat& b, Mat& dst) {
   std::memcpy(d.data + a.total() * es, b.data, b.total() * es);
   dst = d;
 }
-inline void flip(const Mat& src, const Mat& dst, int code) {  // in place on shared data, as OpenCV does for dst == src
-  if (code != 1 || src.data != dst.data) shim::unsupported("this flip variant");
+// flip: code 1 = around the vertical axis, -1 = both axes; in place (dst shares src's pixels) or into dst
+inline void flip(const Mat& src0, Mat& dst, int code) {
+  if (code != 1 && code != -1) shim::unsupported("this flip variant");
+  const Mat src = shim::cont(src0);
   const size_t es = elemSize(src.type());
-  std::vector<uchar> tmp(es);
+  Mat d(src.rows, src.cols, src.type());
   for (int y = 0; y < src.rows; ++y)
-    for (int x = 0; x < src.cols / 2; ++x) {
-      uchar* a = src.data + ((size_t)y * src.cols + x) * es;
-      uchar* b = src.data + ((size_t)y * src.cols + src.cols - 1 - x) * es;
-      std::memcpy(tmp.data(), a, es); std::memcpy(a, b, es); std::memcpy(b, tmp.data(), es);
-    }
+    for (int x = 0; x < src.cols; ++x)
+      std::memcpy(d.data + ((size_t)y * d.cols + x) * es,
+                  src.data + ((size_t)(code == -1 ? src.rows - 1 - y : y) * src.cols + src.cols - 1 - x) * es, es);
+  if (dst.data == src0.data) for (int y = 0; y < d.rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, d.data + (size_t)y * d.step, d.step);
+  else dst = d;
+}
+inline void flip(const Mat& src, const Mat& dst, int code) {  // (OutputArray accepts a const Mat: in place on shared pixels only)
+  if (dst.data != src.data) shim::unsupported("flip into a const destination");
+  Mat d;
+  flip(src, d, code);
+  for (int y = 0; y < d.rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, d.data + (size_t)y * d.step, d.step);
+}
+inline void copyMakeBorder(const Mat& src0, Mat& dst, int top, int bottom, int left, int right, int borderType, const Scalar& value = Scalar()) {
+  const Mat src = shim::cont(src0);
+  if (borderType != BORDER_CONSTANT || src.depth() != CV_8U) shim::unsupported("this copyMakeBorder variant");
+  const int cn = src.channels();
+  Mat d(src.rows + top + bottom, src.cols + left + right, src.type());
+  for (size_t i = 0; i < d.total(); ++i)
+    for (int k = 0; k < cn; ++k) d.data[i * cn + k] = (uchar)(value.val[k] < 0 ? 0 : value.val[k] > 255 ? 255 : (int)(value.val[k] + 0.5));
+  for (int y = 0; y < src.rows; ++y)
+    std::memcpy(d.data + ((size_t)(y + top) * d.cols + left) * cn, src.data + (size_t)y * src.cols * cn, (size_t)src.cols * cn);
+  dst = d;
 }
 inline Mat getStructuringElement(int shape, Size ksize, Point anchor = Point(-1, -1)) {
   if (shape != MORPH_CROSS || ksize.width != ksize.height || !(ksize.width & 1) || anchor.x != ksize.width / 2 || anchor.y != anchor.x)
@@ -107,7 +136,9 @@ inline void erode(const Mat& src, Mat& dst, const Mat& kernel) {  // centred cro
   if (src.type() != CV_8UC1) shim::unsupported("this erode variant");
   dst = shim::from_img(orc::erodeCrossU8C1(shim::to_imgu8(src), kernel.cols / 2));
 }
-inline void merge(const std::vector<Mat>& mv, Mat& dst) {
+inline void merge(const std::vector<Mat>& mv0, Mat& dst) {
+  std::vector<Mat> mv;
+  for (const Mat& m : mv0) mv.push_back(shim::cont(m));
   const int cn = (int)mv.size();
   Mat d(mv[0].rows, mv[0].cols, CV_MAKETYPE(mv[0].depth(), cn));
   const size_t es = elemSize(mv[0].type());
@@ -138,7 +169,8 @@ inline void medianBlur(const Mat& src, Mat& dst, int ksize) {
   if (ksize != 5 || src.depth() != CV_32F) shim::unsupported("this medianBlur variant");
   dst = shim::from_img(orc::medianBlur5(shim::to_imgf(src)));
 }
-inline void split(const Mat& src, std::vector<Mat>& mv) {
+inline void split(const Mat& src0, std::vector<Mat>& mv) {
+  const Mat src = shim::cont(src0);
   const int cn = src.channels();
   mv.assign(cn, Mat());
   const size_t es = elemSize(src.type()) / cn;
@@ -148,11 +180,27 @@ inline void split(const Mat& src, std::vector<Mat>& mv) {
     mv[k] = m;
   }
 }
-inline void cvtColor(const Mat& src, Mat& dst, int code) {
-  if (code != CV_BGRA2GRAY || src.type() != CV_8UC4) shim::unsupported("this cvtColor variant");
-  Mat m(src.rows, src.cols, CV_8UC1);
-  for (size_t i = 0; i < src.total(); ++i) m.data[i] = (uchar)orc::bgr2gray(src.data[4 * i], src.data[4 * i + 1], src.data[4 * i + 2]);
-  dst = m;
+inline void cvtColor(const Mat& src0, Mat& dst, int code) {
+  const Mat src = shim::cont(src0);
+  if (code == CV_BGRA2GRAY && src.type() == CV_8UC4) {
+    Mat m(src.rows, src.cols, CV_8UC1);
+    for (size_t i = 0; i < src.total(); ++i) m.data[i] = (uchar)orc::bgr2gray(src.data[4 * i], src.data[4 * i + 1], src.data[4 * i + 2]);
+    dst = m;
+  } else if (code == CV_BGR2BGRA && src.type() == CV_8UC3) {  // alpha = 255
+    Mat m(src.rows, src.cols, CV_8UC4);
+    for (size_t i = 0; i < src.total(); ++i) {
+      m.data[4 * i] = src.data[3 * i]; m.data[4 * i + 1] = src.data[3 * i + 1]; m.data[4 * i + 2] = src.data[3 * i + 2]; m.data[4 * i + 3] = 255;
+    }
+    dst = m;
+  } else if (code == CV_BGRA2BGR && src.type() == CV_8UC4) {
+    Mat m(src.rows, src.cols, CV_8UC3);
+    for (size_t i = 0; i < src.total(); ++i) {
+      m.data[3 * i] = src.data[4 * i]; m.data[3 * i + 1] = src.data[4 * i + 1]; m.data[3 * i + 2] = src.data[4 * i + 2];
+    }
+    dst = m;
+  } else {
+    shim::unsupported("this cvtColor variant");
+  }
 }
 
 }  // namespace cv

@@ -1,5 +1,8 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
-// PARITY UNPINNED (see cvlite.h header).
+// The logic restated here is PINNED to the reference's source: the reference's whole TestRenderStereoPanorama program,
+// compiled from /root/reference over oracle/ref_shim (make -C oracle ref), writes the same bytes as this file's pipeline
+// for two chained frames, sharpening + cubemap + pixflow_search_20, and pole removal — equirects, cubemap, every flow and
+// state image (tests/test_cpu_refprogram.py). The OpenCV / Eigen primitives under it stay unpinned (cvlite.h header).
 //
 // render.h: CPU restatement of the per-frame stereo panorama pipeline:
 //   surround360_render/source/test/TestRenderStereoPanorama.cpp (TRSP) :75-972

@@ -97,7 +97,10 @@ def make_params(**kw):
     p.eqr_height = 128
     p.final_eqr_width = 3480
     p.final_eqr_height = 960
+    names = {f[0] for f in ParamsC._fields_}
     for k, v in kw.items():
+        if k not in names:  # (setattr on a ctypes Structure would silently make a Python attribute)
+            raise AttributeError("no oracle parameter '%s'" % k)
         setattr(p, k, v)
     return p
 

@@ -1,0 +1,149 @@
+"""Shared by tests/golden/make_refprogram_golden.py, tests/test_cpu_refprogram.py and tests/test_gpu_refprogram.py: inputs
+and digests for runs of a TestRenderStereoPanorama program — the reference's own (oracle/_ref/TestRenderStereoPanorama,
+compiled from /root/reference over ref_shim where the reference exists) or the product's (host/TestRenderStereoPanorama).
+
+The inputs are made with integer numpy operations only (PCG64 integers, repeats, integer box filters), so that every
+machine generates the same bytes — the golden digests are of the reference program's outputs for exactly these inputs.
+They are not a consistent 3-D scene: side camera k sees a window of one long wrapped texture shifted by a third of the
+image per camera (adjacent cameras overlap like the rig's), the pole cameras see textures of their own, frame f moves
+everything by 2 f pixels."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAM, EQR_W, EQR_H, FINAL = 256, 504, 252, 480
+GOLDEN = os.path.join(ROOT, "tests", "golden", "refprogram_golden.json")
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama")
+HOST_EXE = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+
+
+def _box(a, r):
+    """Integer box filter of radius r along both axes (wrapping), exact in int64."""
+    for ax in (0, 1):
+        acc = np.zeros_like(a)
+        for d in range(-r, r + 1):
+            acc += np.roll(a, d, axis=ax)
+        a = acc // (2 * r + 1)
+    return a
+
+
+def _texture(h, w, seed):
+    rng = np.random.default_rng(seed)
+    coarse = rng.integers(0, 256, ((h + 15) // 16, (w + 15) // 16, 3), dtype=np.int64)
+    fine = rng.integers(0, 256, ((h + 3) // 4, (w + 3) // 4, 3), dtype=np.int64)
+    c = np.repeat(np.repeat(coarse, 16, axis=0), 16, axis=1)[:h, :w]
+    f = np.repeat(np.repeat(fine, 4, axis=0), 4, axis=1)[:h, :w]
+    t = (_box(c, 6) * 5 + _box(f, 1) * 3) // 8
+    return np.clip((t - 128) * 2 + 128, 0, 255).astype(np.uint8)  # B,G,R
+
+
+def rig_ids(rig_path):
+    cams = json.load(open(rig_path))["cameras"]
+    side = [c["id"] for c in cams if "side" in c.get("group", "")]
+    other = [c for c in cams if "side" not in c.get("group", "")]
+    top = max(other, key=lambda c: c["forward"][2])["id"]
+    bottoms = [c["id"] for c in other if c["id"] != top]
+    return side, top, bottoms
+
+
+def frame_images(rig_path, frame_index, size=CAM):
+    """{camera id: size x size x 3 uint8 B,G,R} for every camera of the rig."""
+    side, top, bottoms = rig_ids(rig_path)
+    step = size // 3
+    pano = _texture(size, step * len(side), 360)
+    pano = np.roll(pano, -2 * frame_index, axis=1)
+    wide = np.concatenate([pano, pano[:, :size]], axis=1)
+    out = {cid: np.ascontiguousarray(wide[:, k * step:k * step + size]) for k, cid in enumerate(side)}
+    for j, cid in enumerate([top] + bottoms):
+        out[cid] = np.ascontiguousarray(np.roll(_texture(size, size, 1000 + j), 2 * frame_index, axis=0))
+    return out
+
+
+def pole_mask(size, cx_num, cx_den):
+    """Red (B,G,R = 0,0,255) wedge on white, like res/pole_masks/*.png; integer geometry."""
+    yy, xx = np.mgrid[0:size, 0:size]
+    m = np.full((size, size, 3), 255, np.uint8)
+    red = (np.abs(xx * cx_den - size * cx_num) * 25 < cx_den * (size + yy)) & (yy * 20 > size * 7)
+    m[red] = (0, 0, 255)
+    return m
+
+
+def write_inputs(work, rig_path, frames, masks=False):
+    """imgs_dir/<camera id>/<frame>.png and the directories the caller of the program makes (batch_process_video.py:133-135)."""
+    imgs, out = os.path.join(work, "rgb"), os.path.join(work, "out")
+    for k, f in enumerate(frames):
+        for cid, img in frame_images(rig_path, k).items():
+            d = os.path.join(imgs, cid)
+            os.makedirs(d, exist_ok=True)
+            Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(os.path.join(d, f + ".png"))
+        os.makedirs(os.path.join(out, "debug", f, "flow_images"), exist_ok=True)
+        os.makedirs(os.path.join(out, "flow", f), exist_ok=True)
+    os.makedirs(os.path.join(out, "logs"), exist_ok=True)
+    mdir = None
+    if masks:
+        mdir = os.path.join(work, "masks")
+        os.makedirs(mdir, exist_ok=True)
+        _, _, bottoms = rig_ids(rig_path)
+        for j, cid in enumerate(bottoms):
+            Image.fromarray(np.ascontiguousarray(pole_mask(CAM, 10 - j, 20)[:, :, ::-1])).save(os.path.join(mdir, cid + ".png"))
+    return imgs, out, mdir
+
+
+# name -> (frames, extra flags of the program)
+CASES = {
+    "two_frames": (["000000", "000001"], ["--enable_top", "--enable_bottom", "--sharpening", "0.0"]),
+    "sharpen_cubemap_search": (["000000"], ["--enable_top", "--enable_bottom", "--sharpening", "0.25", "--side_flow_alg",
+                                            "pixflow_search_20", "--cubemap_width", "96", "--cubemap_height", "96",
+                                            "--cubemap_format", "video"]),
+    "pole_removal": (["000000", "000001"], ["--enable_bottom", "--enable_pole_removal", "--sharpening", "0.0"]),
+}
+
+
+def run_case(exe, work, rig_path, name, timeout=900):
+    """Runs the frames of a case through the program (chained with --prev_frame_data_dir); returns the output directory."""
+    frames, extra = CASES[name]
+    imgs, out, mdir = write_inputs(work, rig_path, frames, masks="--enable_pole_removal" in extra)
+    prev = "NONE"
+    for f in frames:
+        cmd = [exe, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", f, "--output_data_dir", out,
+               "--prev_frame_data_dir", prev, "--output_equirect_path", os.path.join(out, "eqr_%s.png" % f),
+               "--eqr_width", str(EQR_W), "--eqr_height", str(EQR_H), "--final_eqr_width", str(FINAL),
+               "--final_eqr_height", str(FINAL)] + extra
+        if "--cubemap_width" in extra:
+            cmd += ["--output_cubemap_path", os.path.join(out, "cube_%s.png" % f)]
+        if mdir:
+            cmd += ["--bottom_pole_masks_dir", mdir]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        assert r.returncode == 0, "%s frame %s: rc %d\n%s" % (name, f, r.returncode, r.stderr[-2000:])
+        prev = f
+    return out
+
+
+def _digest_png(path):
+    a = np.asarray(Image.open(path))
+    return hashlib.sha256(repr(a.shape).encode() + a.tobytes()).hexdigest()
+
+
+def digests(out, name):
+    """SHA-256 of every result and state file of a case: PNGs by decoded pixels (+ shape), flow .bin files by bytes."""
+    frames, extra = CASES[name]
+    d = {}
+    for f in frames:
+        d["eqr_%s" % f] = _digest_png(os.path.join(out, "eqr_%s.png" % f))
+        cube = os.path.join(out, "cube_%s.png" % f)
+        if os.path.exists(cube):
+            d["cube_%s" % f] = _digest_png(cube)
+        for sub, kind in (("flow", ".bin"), (os.path.join("debug", f, "flow_images"), ".png")):
+            folder = os.path.join(out, "flow", f) if sub == "flow" else os.path.join(out, sub)
+            for fn in sorted(os.listdir(folder)):
+                p = os.path.join(folder, fn)
+                if fn.endswith(".bin"):
+                    d["%s/%s" % (f, fn)] = hashlib.sha256(open(p, "rb").read()).hexdigest()
+                elif fn.endswith(".png"):
+                    d["%s/%s" % (f, fn)] = _digest_png(p)
+    return d

@@ -1,0 +1,31 @@
+"""The HIP program against the REFERENCE'S OWN PROGRAM. tests/golden/refprogram_golden.json holds SHA-256 digests of every
+file the reference's TestRenderStereoPanorama — compiled from /root/reference over oracle/ref_shim, see
+tests/test_cpu_refprogram.py, which also proves those outputs equal the oracle's — writes for the cases of
+tests/refprog.py (two chained frames; sharpening + cubemap + pixflow_search_20; pole removal over two frames).
+host/TestRenderStereoPanorama, running the HIP library, gets the same integer-generated inputs and the same flags here
+and must produce the same stereo equirects, cubemap, 28 + 4 flow files per frame and state images, digest for digest.
+(No reference and no oracle involved at run time. Sorted last: added after round 2's GPU minutes were spent.)"""
+import json
+import os
+import subprocess
+
+import pytest
+
+import refprog
+import rigutil
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(refprog.CASES))
+def test_hip_program_writes_what_the_reference_program_writes(tmp_path, name, s360lib):
+    subprocess.check_call(["make", "-C", os.path.join(refprog.ROOT, "host"), "-s"])
+    rig = rigutil.scaled_rig_json(os.path.join(refprog.ROOT, "tests", "golden", "rig_17cam.json"),
+                                  str(tmp_path / "rig_small.json"), refprog.CAM / 2048.0)
+    out = refprog.run_case(refprog.HOST_EXE, str(tmp_path), rig, name)
+    got = refprog.digests(out, name)
+    golden = json.load(open(refprog.GOLDEN))[name]
+    missing = sorted(k for k in golden if k not in got)
+    assert not missing, "files the reference program writes and this one does not: %s" % missing
+    differing = sorted(k for k in golden if got[k] != golden[k])
+    assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
