@@ -100,7 +100,8 @@ CASES = {
     "sharpen_cubemap_search": (["000000"], ["--enable_top", "--enable_bottom", "--sharpening", "0.25", "--side_flow_alg",
                                             "pixflow_search_20", "--cubemap_width", "96", "--cubemap_height", "96",
                                             "--cubemap_format", "video"]),
-    "pole_removal": (["000000", "000001"], ["--enable_bottom", "--enable_pole_removal", "--sharpening", "0.0"]),
+    "pole_removal": (["000000", "000001"], ["--enable_bottom", "--enable_pole_removal", "--sharpening", "0.0", "--cubemap_width",
+                                            "64", "--cubemap_height", "64", "--cubemap_format", "photo"]),
 }
 
 

@@ -70,7 +70,8 @@ def test_reference_program_equals_oracle_and_golden(tmp_path, rig_small, name):
                             use_prev=k > 0)
         assert np.array_equal(_png_bgr(os.path.join(out, "eqr_%s.png" % f)), want), "%s frame %s: equirect" % (name, f)
         if flag("--cubemap_width"):
-            assert np.array_equal(_png_bgr(os.path.join(out, "cube_%s.png" % f)), of.cubemap(96, 96, "video"))
+            cw = int(flag("--cubemap_width"))
+            assert np.array_equal(_png_bgr(os.path.join(out, "cube_%s.png" % f)), of.cubemap(cw, cw, flag("--cubemap_format")))
         fdir, idir = os.path.join(out, "flow", f), os.path.join(out, "debug", f, "flow_images")
         for i in range(len(side_ids)):  # the temporal state of the 14 pairs (TestRenderStereoPanorama.cpp:201-255)
             assert _same_bits(_flow_bin(os.path.join(fdir, "flowLtoR_%d.bin" % i)), of.get_f32("flow_l_to_r", i)), (f, i)
