@@ -93,6 +93,71 @@ def cpu_baseline_8k(side, top, bottom):
                            "cores = peak threads in use"}
 
 
+REF_PROGRAM = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama")
+
+
+def cpu_baseline_reference(side, top, bottom, rig_path=RIG, flags=None, timeout=900):
+    """kind "reference": the reference's OWN program — test/TestRenderStereoPanorama.cpp and its libraries compiled from the
+    reference's sources over stand-ins for OpenCV / Eigen / folly / gflags / glog (oracle/_ref, built by build() where the
+    reference exists; tests/test_cpu_refprogram.py) — rendering the bench's frame once as a process, the way
+    batch_process_video.py runs it: PNG inputs from disk, its own threads, equirect + state files to disk. Returns
+    (equirect BGR, record) or None when the program is not there or fails (the caller then times the oracle port)."""
+    if not os.path.exists(REF_PROGRAM):
+        return None
+    import shutil
+    import subprocess
+    import tempfile
+    from PIL import Image
+    flags = dict(FLAGS_8K if flags is None else flags)
+    cams = json.load(open(rig_path))["cameras"]
+    side_ids = [c["id"] for c in cams if "side" in c.get("group", "")]
+    other = [c for c in cams if "side" not in c.get("group", "")]
+    top_id = max(other, key=lambda c: c["forward"][2])["id"]
+    bot_id = min(other, key=lambda c: c["forward"][2])["id"]
+    work = tempfile.mkdtemp(prefix="s360_refprog_")
+    try:
+        imgs, out = os.path.join(work, "rgb"), os.path.join(work, "out")
+        for cid, img in list(zip(side_ids, side)) + [(top_id, top), (bot_id, bottom)]:
+            os.makedirs(os.path.join(imgs, cid))
+            Image.fromarray(np.ascontiguousarray(np.asarray(img)[:, :, ::-1])).save(os.path.join(imgs, cid, "000000.png"), compress_level=1)
+        os.makedirs(os.path.join(out, "debug", "000000", "flow_images"))
+        os.makedirs(os.path.join(out, "flow", "000000"))
+        eqr = os.path.join(out, "eqr.png")
+        cmd = [REF_PROGRAM, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", "000000", "--output_data_dir", out,
+               "--prev_frame_data_dir", "NONE", "--output_equirect_path", eqr, "--sharpening", "0.0"]
+        for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
+            cmd += ["--" + k, str(flags[k])]
+        cmd += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
+        t0 = time.time()
+        p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        peak = 1
+        while p.poll() is None:  # peak number of threads the program runs (its own std::thread fan-out)
+            try:
+                for ln in open("/proc/%d/status" % p.pid):
+                    if ln.startswith("Threads:"):
+                        peak = max(peak, int(ln.split()[1]))
+            except OSError:
+                pass
+            if time.time() - t0 > timeout:
+                p.kill()
+                return None
+            time.sleep(0.1)
+        sec = time.time() - t0
+        if p.returncode != 0:
+            return None
+        Image.MAX_IMAGE_PIXELS = None
+        got = np.ascontiguousarray(np.asarray(Image.open(eqr))[:, :, ::-1])
+        return got, {"value": 1.0 / sec, "unit": "frames/s", "cores": max(1, peak - 1), "kind": "reference",
+                     "host_cores_available": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
+                     "sample": "the reference's own TestRenderStereoPanorama program (its sources compiled over stand-ins for "
+                               "OpenCV / Eigen / folly / gflags / glog: oracle/_ref, -O2, no FMA) rendering ONE full 8K frame of "
+                               "the bench workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low) as one process: 17 PNG "
+                               "inputs decoded from disk, the program's own thread fan-out, equirect and per-frame state files "
+                               "encoded to disk — what batch_process_video.py pays per frame; cores = peak threads it ran"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 # SURVEY.md §8(d): compulsory bytes per 8K frame of the warp/blend kernel families (MB)
 WARP_BLEND_MB = {"project_side": 176 + 180, "project_pole": 2 * 12.6 + 141, "novel_view": 840, "assemble_pano": 400,
                  "pole_warp": 1600, "flatten": 1650}
@@ -571,8 +636,16 @@ def main():
             out["video_stream"] = video
 
             if not args.no_cpu_baseline:
-                want, cb = cpu_baseline_8k(*frames[0])
-                cb["checked_against_gpu"] = bool(np.array_equal(want, single0))
+                ref = None
+                try:
+                    ref = cpu_baseline_reference(*frames[0])
+                except Exception as e:  # noqa: BLE001
+                    out.setdefault("errors", []).append("reference program baseline failed: %r" % (e,))
+                if ref is not None:
+                    want, cb = ref
+                else:  # no oracle/_ref on this machine: the oracle port of the same path
+                    want, cb = cpu_baseline_8k(*frames[0])
+                cb["checked_against_gpu"] = bool(want.shape == single0.shape and np.array_equal(want, single0))
                 out["cpu_baseline"] = cb
 
             # ---- ISP front end: raw 2048x2048 Bayer frames -> BGR, alone and straight into a frame ----
