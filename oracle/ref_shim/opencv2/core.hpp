@@ -221,6 +221,20 @@ class Mat {
     return m;
   }
   void copyTo(Mat& dst) const { dst = clone(); }
+  Mat& operator=(const Scalar& s) {  // every element set to the scalar (integer depths: saturate_cast of a finite value)
+    const int cn = channels(), d = depth();
+    for (int y = 0; y < rows; ++y)
+      for (int x = 0; x < cols; ++x)
+        for (int k = 0; k < cn; ++k) {
+          uchar* e = data + (size_t)y * step + ((size_t)x * cn + k) * (elemSize(type_) / cn);
+          const double v = s.val[k < 4 ? k : 3];
+          if (d == CV_8U) *e = (uchar)(v < 0 ? 0 : v > 255 ? 255 : std::lrint(v));
+          else if (d == CV_16U) *reinterpret_cast<ushort*>(e) = (ushort)(v < 0 ? 0 : v > 65535 ? 65535 : std::lrint(v));
+          else if (d == CV_32F) *reinterpret_cast<float*>(e) = (float)v;
+          else assert(!"Mat = Scalar: depth not provided");
+        }
+    return *this;
+  }
   template <typename T> T& at(int i, int j) { return *reinterpret_cast<T*>(data + (size_t)i * step + (size_t)j * sizeof(T)); }
   template <typename T> const T& at(int i, int j) const { return *reinterpret_cast<const T*>(data + (size_t)i * step + (size_t)j * sizeof(T)); }
   template <typename T> T& at(int i) { return reinterpret_cast<T*>(data)[i]; }
@@ -265,6 +279,7 @@ inline void transpose(const Mat& src, Mat& dst) {
   for (int i = 0; i < src.rows; ++i) for (int j = 0; j < src.cols; ++j) d.at<float>(j, i) = src.at<float>(i, j);
   dst = d;
 }
+inline double invert(const Mat&, Mat&) { throw std::runtime_error("shim: invert (the DNG writer's colour matrices) is not available"); }
 inline void dct(const Mat&, Mat&) { throw std::runtime_error("shim: dct (FREQUENCY_DM_FILTER) is not available"); }
 inline void idct(const Mat&, Mat&) { throw std::runtime_error("shim: idct (FREQUENCY_DM_FILTER) is not available"); }
 

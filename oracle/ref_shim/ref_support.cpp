@@ -4,6 +4,18 @@
 
 namespace cv {
 Mat imread(const std::string& path, int flags) {
+  if (flags == (CV_LOAD_IMAGE_GRAYSCALE | CV_LOAD_IMAGE_ANYDEPTH)) {  // raw Bayer frames: 8- or 16-bit greyscale, depth kept
+    try {
+      int w = 0, h = 0, depth = 0;
+      const std::vector<uint16_t> px = pngio::read_gray(path, &w, &h, &depth);
+      Mat m(h, w, depth == 16 ? CV_16UC1 : CV_8UC1);
+      if (depth == 16) std::memcpy(m.data, px.data(), (size_t)w * h * 2);
+      else for (size_t i = 0; i < (size_t)w * h; ++i) m.data[i] = (uchar)px[i];
+      return m;
+    } catch (const std::exception&) {
+      return Mat();
+    }
+  }
   pngio::Image im;
   try {
     im = pngio::read(path, flags == IMREAD_UNCHANGED);
@@ -16,7 +28,15 @@ Mat imread(const std::string& path, int flags) {
 }
 bool imwrite(const std::string& path, const Mat& img0, const std::vector<int>&) {
   const Mat img = shim::cont(img0);
-  if (img.depth() != CV_8U) shim::unsupported("imwrite of non-8-bit images");
+  if (img.type() == CV_16UC3) {
+    try {
+      pngio::write16(path, reinterpret_cast<const uint16_t*>(img.data), img.cols, img.rows);
+    } catch (const std::exception&) {
+      return false;
+    }
+    return true;
+  }
+  if (img.depth() != CV_8U) shim::unsupported("imwrite of this depth");
   try {
     if (img.channels() == 1) {
       Mat bgr(img.rows, img.cols, CV_8UC3);

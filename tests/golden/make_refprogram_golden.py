@@ -23,4 +23,13 @@ if __name__ == "__main__":
             out = refprog.run_case(refprog.REF_EXE, os.path.join(tmp, name), rig, name)
             res[name] = refprog.digests(out, name)
             print(name, len(res[name]), "files")
+        if os.path.exists(refprog.REF_RAW2RGB):  # the ISP program (camera_isp/Raw2Rgb.cpp)
+            import hashlib
+            import isputil
+            res["raw2rgb"] = {}
+            for name in refprog.RAW_CASES:
+                _, outp = refprog.run_raw_case(refprog.REF_RAW2RGB, os.path.join(tmp, "r_" + name), isputil.CONFIG_FULL, name)
+                a = refprog.png_pixels_bgr(outp)
+                res["raw2rgb"][name] = hashlib.sha256(repr((a.shape, str(a.dtype))).encode() + a.tobytes()).hexdigest()
+            print("raw2rgb", len(res["raw2rgb"]), "files")
     json.dump(res, open(refprog.GOLDEN, "w"), indent=0, sort_keys=True)

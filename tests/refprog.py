@@ -148,3 +148,70 @@ def digests(out, name):
                 elif fn.endswith(".png"):
                     d["%s/%s" % (f, fn)] = _digest_png(p)
     return d
+
+
+# ---- the ISP program (camera_isp/Raw2Rgb.cpp, soft path) ------------------------------------------------------------------
+REF_RAW2RGB = os.path.join(ROOT, "oracle", "_ref", "Raw2Rgb")
+HOST_RAW2RGB = os.path.join(ROOT, "host", "Raw2Rgb")
+RAW_W, RAW_H = 160, 96
+# name -> (input depth, flags of the program)
+RAW_CASES = {
+    "png16_bpp16_edge_aware": (16, ["--output_bpp", "16", "--demosaic_filter", "2"]),
+    "png16_bpp8_bilinear_resize2_black20": (16, ["--output_bpp", "8", "--demosaic_filter", "0", "--resize", "2", "--black_level_offset", "20"]),
+    "png8_bpp8_edge_aware_no_tone_curve": (8, ["--output_bpp", "8", "--demosaic_filter", "2", "--disable_tone_curve"]),
+}
+
+
+def bayer_frame_int(w, h, seed, pattern="GBRG"):
+    """H x W uint16 Bayer mosaic of an integer-generated texture (full 16-bit range: v * 257)."""
+    tex = _texture(h, w, seed).astype(np.uint16) * 257
+    idx = {"R": 2, "G": 1, "B": 0}
+    raw = np.zeros((h, w), np.uint16)
+    for i in range(2):
+        for j in range(2):
+            raw[i::2, j::2] = tex[i::2, j::2, idx[pattern[i * 2 + j]]]
+    return raw
+
+
+def run_raw_case(exe, work, config_json, name):
+    """Writes the input PNG (16-bit, or the high bytes as an 8-bit PNG) and runs the program; returns (raw16 the ISP sees, output path)."""
+    depth, flags = RAW_CASES[name]
+    os.makedirs(work, exist_ok=True)
+    raw = bayer_frame_int(RAW_W, RAW_H, 77)
+    cfg = os.path.join(work, "isp.json")
+    open(cfg, "w").write(config_json)
+    inp, outp = os.path.join(work, "in.png"), os.path.join(work, "out.png")
+    if depth == 16:
+        Image.fromarray(raw, "I;16").save(inp)
+        seen = raw
+    else:
+        raw8 = (raw >> 8).astype(np.uint8)
+        Image.fromarray(raw8, "L").save(inp)
+        seen = raw8.astype(np.uint16) * 257  # convert8bitTo16bit
+    r = subprocess.run([exe, "--input_image_path", inp, "--output_image_path", outp, "--isp_config_path", cfg] + flags,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "%s: rc %d\n%s" % (name, r.returncode, r.stderr[-2000:])
+    return seen, outp
+
+
+def png_pixels_bgr(path):
+    """8- or 16-bit RGB PNG -> H x W x 3 B,G,R array of the file's depth (PIL does not decode 16-bit RGB)."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, t = struct.unpack(">I4s", data[pos:pos + 8])
+        if t == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", data[pos + 8:pos + 8 + n])
+        elif t == b"IDAT":
+            idat += data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    w, h, depth, ctype = ihdr[:4]
+    if depth == 8:
+        return np.asarray(Image.open(path))[:, :, ::-1]
+    assert depth == 16 and ctype == 2
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 6)
+    assert not rows[:, 0].any()  # filter type 0 on every row (both writers emit that)
+    px = rows[:, 1:].reshape(h, w, 3, 2).astype(np.uint16)
+    return ((px[..., 0] << 8) | px[..., 1])[..., ::-1]

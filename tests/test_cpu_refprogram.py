@@ -125,3 +125,22 @@ def test_reference_program_equals_oracle_at_8k(tmp_path):
     Image.MAX_IMAGE_PIXELS = None
     got = np.asarray(Image.open(eqr))[:, :, ::-1]
     assert got.shape == want.shape == (8192, 8192, 3) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", list(refprog.RAW_CASES))
+def test_reference_raw2rgb_program_equals_oracle_and_golden(tmp_path, name):
+    """camera_isp/Raw2Rgb.cpp (its main(), flags, 8 -> 16 bit widening, the soft CameraIsp) compiled from /root/reference
+    over the stand-ins: 16-bit and 8-bit greyscale PNG in, 8- / 16-bit RGB PNG out, equal to the oracle's ISP."""
+    import hashlib
+    import isputil
+    if not os.path.exists(refprog.REF_RAW2RGB):
+        pytest.skip("oracle/_ref/Raw2Rgb not built")
+    depth, flags = refprog.RAW_CASES[name]
+    seen, outp = refprog.run_raw_case(refprog.REF_RAW2RGB, str(tmp_path), isputil.CONFIG_FULL, name)
+    opt = lambda k, d: int(flags[flags.index(k) + 1]) if k in flags else d  # noqa: E731
+    cfg = O.isp_config_from_json(isputil.CONFIG_FULL, opt("--output_bpp", 8), opt("--demosaic_filter", 2), opt("--resize", 1),
+                                 int("--disable_tone_curve" in flags), opt("--black_level_offset", 0))
+    got = refprog.png_pixels_bgr(outp)
+    assert np.array_equal(got, O.isp_run(cfg, seen)), name
+    digest = hashlib.sha256(repr((got.shape, str(got.dtype))).encode() + got.tobytes()).hexdigest()
+    assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]

@@ -29,3 +29,15 @@ def test_hip_program_writes_what_the_reference_program_writes(tmp_path, name, s3
     assert not missing, "files the reference program writes and this one does not: %s" % missing
     differing = sorted(k for k in golden if got[k] != golden[k])
     assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
+
+
+@pytest.mark.parametrize("name", list(refprog.RAW_CASES))
+def test_hip_raw2rgb_writes_what_the_reference_program_writes(tmp_path, name, s360lib):
+    """host/Raw2Rgb (the HIP ISP) against the digests of the reference's own Raw2Rgb program for the same inputs and flags."""
+    import hashlib
+    import isputil
+    subprocess.check_call(["make", "-C", os.path.join(refprog.ROOT, "host"), "-s"])
+    _, outp = refprog.run_raw_case(refprog.HOST_RAW2RGB, str(tmp_path), isputil.CONFIG_FULL, name)
+    a = refprog.png_pixels_bgr(outp)
+    digest = hashlib.sha256(repr((a.shape, str(a.dtype))).encode() + a.tobytes()).hexdigest()
+    assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
