@@ -668,6 +668,20 @@ bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& cs) {
     std::memcpy(&bits, &v, 4);
     if (!known.count(bits) && std::find(todo.begin(), todo.end(), v) == todo.end()) todo.push_back(v);
   }
+#ifdef S360_WAVE_EMULATION  // (tools/hip_wave_shim: the same check as k_verify_div as a host loop, not as 8 M emulated lanes)
+  for (float cc : todo) {
+    const float rc = 1.0f / cc;
+    bool ok = true;
+    for (unsigned m = 0; m < (1u << 23) && ok; ++m) {
+      const float x = __uint_as_float(0x3f800000u | m);
+      ok = x / cc == fdiv_m(x, cc, rc) && (-x) / cc == fdiv_m(-x, cc, rc);
+    }
+    unsigned bits;
+    std::memcpy(&bits, &cc, 4);
+    known[bits] = ok;
+  }
+  todo.clear();
+#endif
   if (!todo.empty()) {
     float* dc = nullptr;
     unsigned* dbad = nullptr;

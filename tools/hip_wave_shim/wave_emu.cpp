@@ -5,6 +5,7 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <random>
 
@@ -84,9 +85,16 @@ void run_group(Group& g) {
   const char* ord = std::getenv("EMU_LANE_ORDER");
   const int order = !ord ? 0 : !std::strcmp(ord, "rev") ? 1 : !std::strcmp(ord, "shuffle") ? 2 : 0;
   std::mt19937 rng(12345u + g.bid.x);
-  for (Lane& L : g.lanes) {
-    L.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (L.stack == MAP_FAILED) die(g, "mmap of a lane stack failed");
+  // lane stacks are kept per OS thread and reused by the workgroups (and launches) that thread runs
+  thread_local std::vector<void*> t_stacks;
+  while (t_stacks.size() < g.lanes.size()) {
+    void* st = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (st == MAP_FAILED) die(g, "mmap of a lane stack failed");
+    t_stacks.push_back(st);
+  }
+  for (size_t li = 0; li < g.lanes.size(); ++li) {
+    Lane& L = g.lanes[li];
+    L.stack = t_stacks[li];
     uintptr_t top = ((uintptr_t)L.stack + kStack) & ~(uintptr_t)15;
     void** sp = (void**)(top - 8);  // after the `ret` into lane_main: rsp == 8 (mod 16), as after a call
     *--sp = (void*)&lane_main;
@@ -149,7 +157,6 @@ void run_group(Group& g) {
       if (++idle_rounds > 200000000) die(g, "a workgroup has been spinning for too long");
     } else idle_rounds = 0;
   }
-  for (Lane& L : g.lanes) munmap(L.stack, kStack);
   t_g = nullptr;
 }
 }  // namespace
@@ -188,22 +195,73 @@ void nap() {
   me().state = NAPPING;
   yield_to_scheduler();
 }
-void launch(std::function<void()> body, dim3 grid, dim3 block) {
-  const unsigned nt = block.x * block.y * block.z;
+// Workgroups are taken in launch order by a pool of OS threads (EMU_THREADS, default 2 x the hardware threads): as on
+// the GPU, a workgroup that has started runs to completion, and one that waits for another (the sweeps' band hand-off)
+// waits for one that was started before it.
+namespace {
+struct Pool {
   std::vector<std::thread> th;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx)
-        th.emplace_back([&body, bx, by, bz, grid, block, nt] {
-          Group g;
-          g.bid = uint3_{bx, by, bz};
-          g.bdim = block;
-          g.gdim = grid;
-          g.body = &body;
-          g.lanes.resize(nt);
-          for (unsigned t = 0; t < nt; ++t) g.lanes[t].tid = uint3_{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-          run_group(g);
-        });
-  for (auto& t : th) t.join();
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  const std::function<void()>* body = nullptr;
+  dim3 grid, block;
+  unsigned long long next = 0, total = 0, finished = 0, epoch = 0;
+  bool stop = false;
+  void worker() {
+    unsigned long long seen = 0;
+    for (;;) {
+      unsigned long long i;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || (epoch != seen && next < total) || (epoch != seen && next >= total); });
+        if (stop) return;
+        if (next >= total) { seen = epoch; continue; }
+        i = next++;
+      }
+      Group g;
+      g.bid = uint3_{(unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((unsigned long long)grid.x * grid.y))};
+      g.bdim = block;
+      g.gdim = grid;
+      g.body = body;
+      const unsigned nt = block.x * block.y * block.z;
+      g.lanes.resize(nt);
+      for (unsigned t = 0; t < nt; ++t) g.lanes[t].tid = uint3_{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+      run_group(g);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (++finished == total) done_cv.notify_all();
+      }
+    }
+  }
+  Pool() {
+    const char* e = std::getenv("EMU_THREADS");
+    unsigned n = e ? (unsigned)std::atoi(e) : 2 * std::max(1u, std::thread::hardware_concurrency());
+    if (n < 1) n = 1;
+    for (unsigned k = 0; k < n; ++k) th.emplace_back([this] { worker(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+  void run(const std::function<void()>& b, dim3 g, dim3 blk) {
+    std::unique_lock<std::mutex> lk(mu);
+    body = &b; grid = g; block = blk;
+    next = 0; finished = 0; total = (unsigned long long)g.x * g.y * g.z;
+    ++epoch;
+    cv.notify_all();
+    done_cv.wait(lk, [&] { return finished == total; });
+  }
+};
+}  // namespace
+void launch(std::function<void()> body, dim3 grid, dim3 block) {
+  static std::mutex one;  // launches of different host threads run one after the other
+  std::lock_guard<std::mutex> lk(one);
+  static Pool pool;
+  if ((unsigned long long)grid.x * grid.y * grid.z == 0) return;
+  pool.run(body, grid, block);
 }
 }  // namespace emu
