@@ -12,6 +12,16 @@
 
 #define S360_HD __host__ __device__ __forceinline__
 
+// Wave-synchronous LDS hand-overs — one lane writes, another lane of the same wave reads, no barrier in between — are
+// ordered by the hardware (a wave's LDS accesses execute in program order for all its lanes). The CPU emulation the
+// tests run the kernels under (tools/hip_wave_shim) runs the lanes of a wave one after the other between two cross-lane
+// operations and needs those points marked; in the product build the mark is nothing at all.
+#ifdef S360_WAVE_EMULATION
+#define S360_WAVE_SYNC() emu::wave_sync()
+#else
+#define S360_WAVE_SYNC()
+#endif
+
 namespace s360 {
 
 S360_HD int cv_round(float v) {

@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
   for (int t = 0; t < ntiles; ++t) {
 #pragma unroll
     for (int kk = 0; kk < IIR_CH; ++kk) s_in[kk * IIR_LD + lane] = pre[kk];
+    S360_WAVE_SYNC();  // (one wave per workgroup: the tile is written position-major and read chain-major)
     if (t + 1 < ntiles) load_tile(t + 1);
     const int cnt = min(IIR_T, g.n - t * IIR_T);
     const unsigned char* sb = reinterpret_cast<const unsigned char*>(s_in) + (size_t)k * IIR_LD * 4 + c;
@@ -1093,6 +1094,7 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
       v = (float)sb[j * 4] * am + v * alpha;
       so[j * 4] = v;
     }
+    S360_WAVE_SYNC();
     // store the tile's float results: ROWS: 1 KB per chain row; columns: 256 B per position
     const int e = t * IIR_T + lane;
     if (e < g.n) {
@@ -1133,6 +1135,7 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
   for (int t = ntiles - 1; t >= 0; --t) {
 #pragma unroll
     for (int kk = 0; kk < IIR_CH; ++kk) *reinterpret_cast<float4*>(s_in + ((size_t)kk * IIR_LD + lane) * 4) = pre[kk];
+    S360_WAVE_SYNC();
     if (t > 0) load_tile(t - 1);
     const int cnt = min(IIR_T, g.n - t * IIR_T);
     const float* si = s_in + (size_t)k * IIR_LD * 4 + c;
@@ -1152,6 +1155,7 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
       v = si[j * 4] * am + v * alpha;
       so[j * 4] = c == 3 ? (unsigned char)255 : (unsigned char)clamp255(v);
     }
+    S360_WAVE_SYNC();
     const int e = t * IIR_T + lane;
     if (e < g.n) {
 #pragma unroll

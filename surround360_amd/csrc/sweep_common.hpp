@@ -76,16 +76,6 @@ struct SweepFast {  // reciprocals of the three divisors of the sweep, verified 
   float rcCols, rcRows, rcEps;
   int dbg;  // always 0 in the product library (see S360_DBG)
 };
-// Wave-synchronous LDS hand-overs — one lane writes, another lane of the same wave reads, no barrier in between — are
-// ordered by the hardware (a wave's LDS accesses execute in program order for all its lanes). The CPU emulation the
-// tests run the sweeps under (tools/hip_wave_shim) runs the lanes of a wave one after the other between two cross-lane
-// operations and needs those points marked; in the product build the mark is nothing at all.
-#ifdef S360_WAVE_EMULATION
-#define S360_WAVE_SYNC() emu::wave_sync()
-#else
-#define S360_WAVE_SYNC()
-#endif
-
 // Timing experiments that invalidate the results (skip polls / publishes / gathers ...) exist only in the developer
 // tools: tools/Makefile builds the sweep sources with -DS360_TIMING_EXPERIMENTS, the product library never does, and
 // there S360_DBG() is the constant 0 — no environment variable can switch a result-changing path on.

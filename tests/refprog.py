@@ -182,11 +182,11 @@ def run_raw_case(exe, work, config_json, name):
     open(cfg, "w").write(config_json)
     inp, outp = os.path.join(work, "in.png"), os.path.join(work, "out.png")
     if depth == 16:
-        Image.fromarray(raw, "I;16").save(inp)
+        Image.fromarray(raw).save(inp)  # (uint16 -> 16-bit greyscale PNG)
         seen = raw
     else:
         raw8 = (raw >> 8).astype(np.uint8)
-        Image.fromarray(raw8, "L").save(inp)
+        Image.fromarray(raw8).save(inp)
         seen = raw8.astype(np.uint16) * 257  # convert8bitTo16bit
     r = subprocess.run([exe, "--input_image_path", inp, "--output_image_path", outp, "--isp_config_path", cfg] + flags,
                        capture_output=True, text=True, timeout=600)

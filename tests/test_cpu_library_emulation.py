@@ -1,0 +1,81 @@
+"""The whole product library without a GPU. tools/libs360_emu.so is every source of surround360_amd/csrc — the C ABI,
+the frame pipeline, the flow engine, the ISP, all HIP kernels — compiled for the CPU over tools/hip_wave_shim (workgroups
+as OS threads, lanes as coroutines, DPP / ballot / shuffles / barriers as rendezvous; kernels run to completion at
+launch, copies are memcpy), and tools/emu/* are the host programs of host/ linked against it. They get the same
+command lines as the real programs get on the GPU box (tests/test_gpu_zz_refprogram.py, test_gpu_zz_unpacker.py,
+test_gpu_host.py) and must write the same files: here that is checked against the REFERENCE'S OWN PROGRAMS' digests
+(tests/golden/refprogram_golden.json) and against the oracle.
+
+What this covers: the logic of the HIP sources — indexing, tiling, batching, hand-offs, state handling, file formats.
+What it cannot: arithmetic that the device does differently from the host (its libm for double exp / atan2, v_sqrt,
+denormal handling) and anything about timing; those are what the -m gpu tests are for. It is NOT a fallback: the product
+never loads this library (surround360_amd/_capi.py loads libs360.so or fails)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib as O
+import refprog
+import rigutil
+
+ROOT = refprog.ROOT
+EMU = os.path.join(ROOT, "tools", "emu")
+
+
+@pytest.fixture(scope="module")
+def emu_programs():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s", "libs360_emu.so", "emu_programs"])
+    return EMU
+
+
+@pytest.mark.parametrize("name", list(refprog.CASES))
+def test_emulated_program_writes_what_the_reference_program_writes(tmp_path, emu_programs, name):
+    """Two chained frames; sharpening + cubemap + pixflow_search_20; pole removal over two frames: stereo equirects,
+    cubemap, 28 + 4 flows per frame, overlap / pole / pole-removal state images — 342 files, digest for digest."""
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
+                                  refprog.CAM / 2048.0)
+    out = refprog.run_case(os.path.join(emu_programs, "TestRenderStereoPanorama"), str(tmp_path), rig, name)
+    got = refprog.digests(out, name)
+    golden = json.load(open(refprog.GOLDEN))[name]
+    assert sorted(got) == sorted(golden)
+    differing = sorted(k for k in golden if got[k] != golden[k])
+    assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
+
+
+@pytest.mark.parametrize("name", list(refprog.RAW_CASES))
+def test_emulated_raw2rgb_writes_what_the_reference_program_writes(tmp_path, emu_programs, name):
+    import isputil
+    _, outp = refprog.run_raw_case(os.path.join(emu_programs, "Raw2Rgb"), str(tmp_path), isputil.CONFIG_FULL, name)
+    a = refprog.png_pixels_bgr(outp)
+    digest = hashlib.sha256(repr((a.shape, str(a.dtype))).encode() + a.tobytes()).hexdigest()
+    assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
+
+
+@pytest.mark.parametrize("bits", [12, 8])
+def test_emulated_unpacker(tmp_path, emu_programs, bits):
+    from test_gpu_zz_unpacker import check_unpacker
+    check_unpacker(os.path.join(emu_programs, "Unpacker"), tmp_path, O, bits)
+
+
+def test_emulated_optical_flow_harness(tmp_path, emu_programs):
+    """host/TestOpticalFlow --mode test (BASELINE configs[1]'s harness) on a small pair: both directions against the oracle."""
+    from surround360_amd import synth
+    i0, i1 = synth.flow_pair(150, 120, seed=11)
+    Image.fromarray(np.ascontiguousarray(i0[:, :, [2, 1, 0, 3]])).save(str(tmp_path / "left.png"))
+    Image.fromarray(np.ascontiguousarray(i1[:, :, [2, 1, 0, 3]])).save(str(tmp_path / "right.png"))
+    r = subprocess.run([os.path.join(emu_programs, "TestOpticalFlow"), "--mode", "test", "--test_dir", str(tmp_path), "--left_img",
+                        "left.png", "--right_img", "right.png", "--flow_alg", "pixflow_low", "--repetitions", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("RUNTIME (sec) = ") == 1
+    for name, a, b, hint in (("flowLtoR", i0, i1, "LEFT"), ("flowRtoL", i1, i0, "RIGHT")):
+        p = str(tmp_path / "disparity" / (name + "_pixflow_low.bin"))
+        hdr = np.fromfile(p, dtype=np.int32, count=2)
+        got = np.fromfile(p, dtype=np.float32, offset=8).reshape(int(hdr[0]), int(hdr[1]), 2)
+        want = O.compute_optical_flow(a, b, "pixflow_low", hint)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), name

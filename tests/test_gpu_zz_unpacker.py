@@ -40,7 +40,11 @@ def _png16_bgr(path):
 @pytest.mark.parametrize("bits", [12, 8])
 def test_unpacker_binary(tmp_path, oracle, s360lib, bits):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "Unpacker")
+    check_unpacker(os.path.join(ROOT, "host", "Unpacker"), tmp_path, oracle, bits)
+
+
+def check_unpacker(exe, tmp_path, oracle, bits):
+    """(also run by tests/test_cpu_library_emulation.py on the program linked against the emulated library)"""
     w, h, nf = 128, 96, 3
     serials = [17430921, 16241093]
     configs = [isputil.CONFIG_FULL, isputil.CONFIG_GRBG_NOSHARP]

@@ -38,14 +38,22 @@ struct dim3 {
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 struct uint3_ { unsigned x, y, z; };
-struct alignas(8) float2 { float x, y; };
-struct alignas(16) float4 { float x, y, z, w; };
-struct alignas(8) int2 { int x, y; };
-struct alignas(8) uint2 { unsigned x, y; };
-struct alignas(4) uchar4 { unsigned char x, y, z, w; };
-inline float2 make_float2(float x, float y) { return float2{x, y}; }
-inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
-inline int2 make_int2(int x, int y) { return int2{x, y}; }
+#define EMU_VEC(T, name, al2, al4)                                                          \
+  struct alignas(al2) name##2 { T x, y; };                                                   \
+  struct name##3 { T x, y, z; };                                                             \
+  struct alignas(al4) name##4 { T x, y, z, w; };                                             \
+  inline name##2 make_##name##2(T x, T y) { return name##2{x, y}; }                          \
+  inline name##3 make_##name##3(T x, T y, T z) { return name##3{x, y, z}; }                  \
+  inline name##4 make_##name##4(T x, T y, T z, T w) { return name##4{x, y, z, w}; }
+EMU_VEC(float, float, 8, 16)
+EMU_VEC(double, double, 16, 32)
+EMU_VEC(int, int, 8, 16)
+EMU_VEC(unsigned, uint, 8, 16)
+EMU_VEC(short, short, 4, 8)
+EMU_VEC(unsigned short, ushort, 4, 8)
+EMU_VEC(signed char, char, 2, 4)
+EMU_VEC(unsigned char, uchar, 2, 4)
+#undef EMU_VEC
 
 namespace emu {
 enum Op { OP_BALLOT = 1, OP_FIRST, OP_DPP, OP_SYNC };
@@ -63,6 +71,7 @@ Rendezvous arrive(Op op, unsigned long long v);
 bool peer(const Rendezvous& r, int lane, unsigned long long* v);  // false: that lane did not take part (has exited)
 void barrier();
 void nap();  // s_sleep: lets the other waves / workgroups run
+int barrier_and(int pred);  // __syncthreads_and
 inline void wave_sync() { (void)arrive(OP_SYNC, 0); }
 void launch(std::function<void()> body, dim3 grid, dim3 block);
 }  // namespace emu
@@ -78,11 +87,28 @@ typedef void* hipStream_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+// everything is synchronous here: a kernel has run when its launch returns, copies are memcpy, streams and events are names
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::calloc(1, n ? n : 1); return hipSuccess; }
+template <typename T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = *t = (size_t)64 << 30; return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 struct hipEvent_st;
 typedef hipEvent_st* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* t, hipEvent_t, hipEvent_t) { *t = 0; return hipSuccess; }
@@ -118,10 +144,51 @@ using std::min;
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline int atomicMin(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline int atomicMax(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline long long __double_as_longlong(double d) { long long u; std::memcpy(&u, &d, 8); return u; }
+inline double __longlong_as_double(long long u) { double d; std::memcpy(&d, &u, 8); return d; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_ACQUIRE)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_RELEASE)
 inline void __syncthreads() { emu::barrier(); }
+inline int __syncthreads_and(int pred) { return emu::barrier_and(pred); }
+// cross-lane exchange by XOR of the lane index (width 64)
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  static_assert(sizeof(T) == 4, "32-bit values only");
+  (void)width;
+  unsigned u;
+  std::memcpy(&u, &v, 4);
+  const emu::Rendezvous r = emu::arrive(emu::OP_DPP, u);
+  unsigned long long o;
+  if (emu::peer(r, emu::lane_id() ^ mask, &o)) u = (unsigned)o;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+// v_perm_b32: bytes of {src0 (4..7), src1 (0..3)} picked by the selector's bytes; 8..11 sign replication, 12 zero, 13+ 0xFF
+inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
+  const unsigned long long in = ((unsigned long long)s0 << 32) | s1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned k = (sel >> (8 * i)) & 0xFF;
+    unsigned b;
+    if (k <= 7) b = (unsigned)(in >> (8 * k)) & 0xFF;
+    else if (k <= 11) b = ((in >> (16 * (k - 8) + 15)) & 1) ? 0xFF : 0x00;
+    else if (k == 12) b = 0x00;
+    else b = 0xFF;
+    r |= b << (8 * i);
+  }
+  return r;
+}
+#define __builtin_amdgcn_perm(a, b, s) emu_perm((unsigned)(a), (unsigned)(b), (unsigned)(s))
+// v_dot2_i32_i16
+template <typename V>
+inline int emu_sdot2(V a, V b, int c, bool) { return (int)a.x * (int)b.x + (int)a.y * (int)b.y + c; }
+#define __builtin_amdgcn_sdot2(a, b, c, clamp) emu_sdot2(a, b, c, clamp)
 
 inline unsigned long long __ballot(int pred) {
   const emu::Rendezvous r = emu::arrive(emu::OP_BALLOT, pred ? 1u : 0u);

@@ -58,6 +58,7 @@ struct Group {
   uint3_ bid{0, 0, 0};
   dim3 bdim, gdim;
   const std::function<void()>* body = nullptr;
+  bool vote_fail = false;
 };
 thread_local Group* t_g = nullptr;
 Lane& me() { return t_g->lanes[t_g->cur]; }
@@ -194,6 +195,16 @@ void barrier() {
 void nap() {
   me().state = NAPPING;
   yield_to_scheduler();
+}
+int barrier_and(int pred) {  // everybody votes | everybody reads | everybody resets, before anybody can vote again
+  Group& g = *t_g;
+  if (!pred) g.vote_fail = true;
+  barrier();
+  const int r = g.vote_fail ? 0 : 1;
+  barrier();
+  g.vote_fail = false;  // (every lane; new votes come only after the third barrier)
+  barrier();
+  return r;
 }
 // Workgroups are taken in launch order by a pool of OS threads (EMU_THREADS, default 2 x the hardware threads): as on
 // the GPU, a workgroup that has started runs to completion, and one that waits for another (the sweeps' band hand-off)
