@@ -14,6 +14,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 RIG_JSON = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
 
+# Developer switch, tests only: S360_TEST_EMULATED_LIB=1 points the Python binding of THIS TEST PROCESS at
+# tools/libs360_emu.so (the library's sources compiled for the CPU over tools/hip_wave_shim, see
+# tests/test_cpu_library_emulation.py), so that `pytest -m gpu -k "not fullsize"` can be tried where no GPU is attached.
+# The product never looks at this variable.
+if os.environ.get("S360_TEST_EMULATED_LIB") == "1":
+    from surround360_amd import _capi as _capi_for_emulation
+    _capi_for_emulation.LIB_PATH = os.path.join(ROOT, "tools", "libs360_emu.so")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
