@@ -79,3 +79,16 @@ def test_emulated_optical_flow_harness(tmp_path, emu_programs):
         got = np.fromfile(p, dtype=np.float32, offset=8).reshape(int(hdr[0]), int(hdr[1]), 2)
         want = O.compute_optical_flow(a, b, "pixflow_low", hint)
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("variant", [dict(S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="2", S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="8"),
+                                     dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1")])
+def test_emulated_kernel_variants_give_the_same_flows(emu_programs, variant):
+    """The switch-selected sweep builds (tests/test_gpu_zz_variants.py) through the whole flow path of the emulated
+    library: both algorithms, both directions, a band of masked rows — same digest as the default build."""
+    from test_gpu_zz_variants import _flows_digest
+    common = dict(S360_TEST_EMULATED_LIB="1", TEST_FLOW_SIZES="150x120,97x131")
+    base = dict(common)
+    if "TEST_SWEEP_MODE" in variant:
+        base["TEST_SWEEP_MODE"] = variant["TEST_SWEEP_MODE"]
+    assert _flows_digest(**dict(common, **variant)) == _flows_digest(**base)

@@ -15,12 +15,16 @@ SNIPPET = r'''
 import hashlib, os, sys
 sys.path.insert(0, %(root)r)
 import torch  # noqa: F401
+if os.environ.get("S360_TEST_EMULATED_LIB") == "1":  # (tests/test_cpu_library_emulation.py: the same comparison on the CPU)
+    from surround360_amd import _capi
+    _capi.LIB_PATH = os.path.join(%(root)r, "tools", "libs360_emu.so")
 from surround360_amd import render as R, synth
 rig = R.RigDescription(os.path.join(%(root)r, "tests", "golden", "rig_17cam.json"))
 ctx = R.Context(rig, R.make_params())
 ctx.set_sweep_mode(os.environ.get("TEST_SWEEP_MODE", "latency"))
 h = hashlib.sha1()
-for (w, hh, seed) in ((333, 444, 1), (1214, 700, 2)):
+sizes = [tuple(int(v) for v in s.split("x")) for s in os.environ.get("TEST_FLOW_SIZES", "333x444,1214x700").split(",")]
+for seed, (w, hh) in enumerate(sizes, 1):
     i0, i1 = synth.flow_pair(w, hh, seed=seed)
     i0[: hh // 3, :, 3] = 0  # a band of pixels below the alpha threshold, like the pole flows
     for alg in ("pixflow_low", "pixflow_search_20"):
@@ -32,6 +36,7 @@ print("SHA1", h.hexdigest())
 
 
 def _flows_digest(**env):
+    """(env: the variant's switch; TEST_SWEEP_MODE; on the CPU also S360_TEST_EMULATED_LIB=1 and smaller TEST_FLOW_SIZES)"""
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", SNIPPET % {"root": ROOT}], capture_output=True, text=True, env=e, timeout=600)
