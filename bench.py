@@ -669,13 +669,14 @@ def main():
             torch.cuda.empty_cache()
             variants = [("latency", "default", {}, 1), ("latency", "S360_LOCK_PEEL=1", {"S360_LOCK_PEEL": "1"}, 1),
                         ("throughput", "default", {}, S), ("throughput", "S360_QUAD_PEEL=1", {"S360_QUAD_PEEL": "1"}, S),
+                        ("throughput", "S360_SWEEP_TRI=1", {"S360_SWEEP_TRI": "1"}, S),
                         ("latency", "S360_LOCK_NW=2", {"S360_LOCK_NW": "2"}, 1),
                         ("latency", "S360_LOCK_NW=8", {"S360_LOCK_NW": "8"}, 1),
                         ("latency", "S360_LOCK_NW=2 S360_LOCK_PEEL=1", {"S360_LOCK_NW": "2", "S360_LOCK_PEEL": "1"}, 1)]
             ab = {"latency": {}, "throughput": {}}
             t_leg = time.perf_counter()
             for group, name, env, slots in variants:
-                if time.perf_counter() - t_leg > 180.0:
+                if time.perf_counter() - t_leg > 240.0:
                     ab[group][name] = {"skipped": "the leg's time budget was spent"}
                     continue
                 try:

@@ -1122,19 +1122,23 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
   const int lane = threadIdx.x, k = lane >> 2, c = lane & 3;
   const int chain0 = blockIdx.x * IIR_CH;
   const int ntiles = (g.n + IIR_T - 1) / IIR_T;
-  float4 pre[IIR_CH];
+  // (native vector type: an array of HIP's float4 structs captured by the lambda is not promoted to registers — it was
+  // 272 bytes of scratch memory per lane, with every prefetched tile waited for at once in order to be stored there)
+  typedef float f4r __attribute__((ext_vector_type(4)));
+  f4r pre[IIR_CH];
   auto load_tile = [&](int t) {  // B at positions bnd(e - 1)
     const int e = min(t * IIR_T + lane, g.n - 1);
     const int pos = iir_bnd<ROWS>(e - 1, g.n);
 #pragma unroll
-    for (int kk = 0; kk < IIR_CH; ++kk) pre[kk] = Bf[iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos)];
+    for (int kk = 0; kk < IIR_CH; ++kk)
+      pre[kk] = *reinterpret_cast<const f4r*>(Bf + iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos));
   };
   const float am = 1.0f - alpha;
   float v = reinterpret_cast<const float*>(carry)[(size_t)min(chain0 + k, g.nchains - 1) * 4 + c];
   load_tile(ntiles - 1);
   for (int t = ntiles - 1; t >= 0; --t) {
 #pragma unroll
-    for (int kk = 0; kk < IIR_CH; ++kk) *reinterpret_cast<float4*>(s_in + ((size_t)kk * IIR_LD + lane) * 4) = pre[kk];
+    for (int kk = 0; kk < IIR_CH; ++kk) *reinterpret_cast<f4r*>(s_in + ((size_t)kk * IIR_LD + lane) * 4) = pre[kk];
     S360_WAVE_SYNC();
     if (t > 0) load_tile(t - 1);
     const int cnt = min(IIR_T, g.n - t * IIR_T);

@@ -222,21 +222,38 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   float2 fl = make_float2(0.f, 0.f);  // result of the previous pixel of this row (same in the 4 lanes of the quad)
   float4 nrc;
   float2 nfo;
-  float4 cr[4];  // LDSIN: the next chunk's records / flows of this lane's four steps (4 q .. 4 q + 3)
-  float2 cf[4];
+  // LDSIN: the next chunk's records / flows of this lane's four steps (4 q .. 4 q + 3). In the build every measurement of
+  // this kernel was taken with, `cr` is an array of HIP's float4 structs; the compiler does not promote it to registers
+  // through the lambdas' captures: it lives in scratch memory (ScratchSize 80), and each chunk's loads are waited for
+  // right after they are issued in order to be stored there — the prefetch "lands during the chunk" only as far as L2.
+  // The PEEL build (not yet timed) declares the arrays with native vector types, which stay in VGPRs (ScratchSize 0).
+  typedef float f4r __attribute__((ext_vector_type(4)));
+  typedef float f2r __attribute__((ext_vector_type(2)));
+  typename std::conditional<PEEL, f4r, float4>::type cr[4];
+  typename std::conditional<PEEL, f2r, float2>::type cf[4];
   auto chunk_load = [&](int sbase) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xc = col(sbase + 4 * q + j - r);
-      cr[j] = recRow[xc];
-      cf[j] = flowRow[xc];
+      if constexpr (PEEL) {
+        cr[j] = *reinterpret_cast<const f4r*>(recRow + xc);
+        cf[j] = *reinterpret_cast<const f2r*>(flowRow + xc);
+      } else {
+        cr[j] = recRow[xc];
+        cf[j] = flowRow[xc];
+      }
     }
   };
   auto chunk_store = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s_rec[r][4 * q + j] = cr[j];
-      s_res[r][4 * q + j] = cf[j];
+      if constexpr (PEEL) {
+        *reinterpret_cast<f4r*>(&s_rec[r][4 * q + j]) = cr[j];
+        *reinterpret_cast<f2r*>(&s_res[r][4 * q + j]) = cf[j];
+      } else {
+        s_rec[r][4 * q + j] = cr[j];
+        s_res[r][4 * q + j] = cf[j];
+      }
     }
   };
   if (LDSIN) {

@@ -93,3 +93,17 @@ def test_quad_peeled_sizes(emulator, w, h):
     """Widths without, with exactly one and with several interior chunks (the first one is steps 16..31: w >= 32)."""
     _run(emulator, ["quad", w, h, 2, 33, "random", 1, 1], S360_QUAD_PEEL=1)
     _run(emulator, ["quad", w, h, 2, 33, "bands", 1, 1], S360_QUAD_PEEL=1, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
+
+
+@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
+def test_tri_kernel(emulator, mask):
+    """sweep_tri.hip (S360_SWEEP_TRI=1): three lanes per pixel, 20 rows per wave."""
+    _run(emulator, ["tri", 70, 50, 2, 41, mask, 1, 1])
+    _run(emulator, ["tri", 53, 45, 3, 42, mask, 0, 0], EMU_LANE_ORDER="shuffle")
+
+
+@pytest.mark.parametrize("w,h", [(3, 2), (16, 20), (17, 21), (33, 40), (34, 41), (130, 61)])
+def test_tri_sizes(emulator, w, h):
+    """One band exactly, one row more, two bands, chunk boundaries; persistent waves taking several tickets."""
+    _run(emulator, ["tri", w, h, 2, 43, "random", 1, 1])
+    _run(emulator, ["tri", w, h, 2, 43, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1, EMU_LANE_ORDER="rev")

@@ -58,6 +58,11 @@ def test_quad_kernel_with_peeled_interior_chunks(s360lib):
     assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1") == _flows_digest(TEST_SWEEP_MODE="throughput")
 
 
+def test_throughput_kernel_with_three_lanes_per_pixel(s360lib):
+    """S360_SWEEP_TRI=1 (sweep_tri.hip) against the default build of the throughput kernel."""
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1") == _flows_digest(TEST_SWEEP_MODE="throughput")
+
+
 @pytest.mark.parametrize("nw", ["2", "8"])
 def test_lock_kernel_with_other_workgroup_heights(default_digest, nw):
     """S360_LOCK_NW: 2 or 8 compute waves (8 or 32 rows) per workgroup instead of 4, with the peeled steps as well."""

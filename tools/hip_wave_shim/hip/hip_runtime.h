@@ -211,13 +211,14 @@ inline T emu_readfirstlane(T x) {
   return x;
 }
 #define __builtin_amdgcn_readfirstlane(x) emu_readfirstlane(x)
-// v_mov_b32_dpp semantics (the controls the kernels use): quad_perm, row_shr:n, row_bcast:15, row_newbcast:n
+// v_mov_b32_dpp semantics (the controls the kernels use): quad_perm, row_shl:n, row_shr:n, row_bcast:15, row_newbcast:n
 inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const emu::Rendezvous r = emu::arrive(emu::OP_DPP, (unsigned)src);
   const int lane = emu::lane_id(), row = lane >> 4, inrow = lane & 15;
   if (!((row_mask >> row) & 1) || !((bank_mask >> (inrow >> 2)) & 1)) return old;
   int from = -1;
   if (ctrl >= 0 && ctrl <= 0xFF) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) from = inrow + (ctrl & 15) <= 15 ? lane + (ctrl & 15) : -1;
   else if (ctrl >= 0x111 && ctrl <= 0x11F) from = inrow >= (ctrl & 15) ? lane - (ctrl & 15) : -1;
   else if (ctrl == 0x142) from = row > 0 ? row * 16 - 1 : -1;
   else if (ctrl >= 0x150 && ctrl <= 0x15F) from = (lane & ~15) | (ctrl & 15);

@@ -131,6 +131,10 @@ int main(int argc, char** argv) {
     if (kernel == "lock") {
       std::vector<unsigned char> handoff(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), 0xFF);
       launch_sweep_lock(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast);
+    } else if (kernel == "tri") {
+      std::vector<unsigned char> handoff(sweep_tri_handoff_bytes(w, h, B), 0xFF);
+      launch_sweep_tri(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,
+                       useRowflags ? rowflags.data() : nullptr);
     } else {
       std::vector<unsigned char> handoff(sweep_quad_handoff_bytes(w, h, B), 0xFF);
       launch_sweep_quad(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,
