@@ -26,17 +26,27 @@ def main():
     ap.add_argument("--slots", type=int, default=1)
     args = ap.parse_args()
     import torch
-    from surround360_amd import render as R, synth
     rig_path = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
-    torch.cuda.set_device(args.device)
-    dev = torch.device("cuda", args.device)
-    world = synth.World(4096, seed=360, device=dev)
-    rr = synth.RigRenderer(rig_path, world, 2048)
+    flags = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192, final_eqr_height=8192)
+    emulated = os.environ.get("S360_TEST_EMULATED_LIB") == "1"  # (developer check of this tool's control flow without a GPU)
+    if emulated:
+        from surround360_amd import _capi
+        _capi.LIB_PATH = os.path.join(ROOT, "tools", "libs360_emu.so")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import rigutil
+        rig_path = rigutil.scaled_rig_json(rig_path, "/tmp/variant_time_rig_small.json", 256 / 2048.0)
+        flags.update(eqr_width=504, eqr_height=252, final_eqr_width=480, final_eqr_height=480)
+    from surround360_amd import render as R, synth
+    if not emulated:
+        torch.cuda.set_device(args.device)
+    dev = torch.device("cpu") if emulated else torch.device("cuda", args.device)
+    world = synth.World(512 if emulated else 4096, seed=360, device=dev)
+    rr = synth.RigRenderer(rig_path, world, 256 if emulated else 2048)
     S = max(1, args.slots)
     frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(min(S, 3))]
     del rr, world
-    torch.cuda.empty_cache()
-    flags = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192, final_eqr_height=8192)
+    if not emulated:
+        torch.cuda.empty_cache()
     ctx = R.Context(R.RigDescription(rig_path), R.make_params(**flags), device=args.device)
     try:
         if S > 1:
