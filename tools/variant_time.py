@@ -79,6 +79,7 @@ def main():
                 ctx.select_frame_slot(j)
             h.update(ctx.download_equirect().tobytes())
         res = {"slots": S, "ms_per_frame": round(ms, 3), "sweep_ms_per_frame": round(sweep_ms, 3), "sha1": h.hexdigest(),
+               "kernel_ms_per_frame": {k: round(v[0] / args.reps / S, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
                "env": {k: v for k, v in os.environ.items() if k.startswith("S360_")}}
     finally:
         ctx.close()
