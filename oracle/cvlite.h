@@ -4,7 +4,8 @@
 // imgproc primitives that Surround360's stereo-panorama hot path calls
 // (resize, remap, GaussianBlur, Sobel, medianBlur, cvtColor, erode, ...).
 //
-// PARITY UNPINNED (these primitives; the reference's own logic above them is pinned, see pixflow.h / isp.h): OpenCV
+// PARITY UNPINNED (these primitives only; everything the reference's authors wrote above them is pinned — the reference's
+// whole programs run over them, see render.h / pixflow.h / isp.h and tests/test_cpu_refprogram.py): OpenCV
 // (pinned by the reference at git f109c01, WITH_IPP=OFF,
 // surround360_render/README.md:144-153) is not available in this environment and
 // the reference ships no golden vectors for this path. Each
