@@ -100,6 +100,7 @@ CASES = {
     "sharpen_cubemap_search": (["000000"], ["--enable_top", "--enable_bottom", "--sharpening", "0.25", "--side_flow_alg",
                                             "pixflow_search_20", "--cubemap_width", "96", "--cubemap_height", "96",
                                             "--cubemap_format", "video"]),
+    "three_frames_sharpened": (["000007", "000008", "000009"], ["--enable_top", "--enable_bottom", "--sharpening", "0.25"]),
     "pole_removal": (["000000", "000001"], ["--enable_bottom", "--enable_pole_removal", "--sharpening", "0.0", "--cubemap_width",
                                             "64", "--cubemap_height", "64", "--cubemap_format", "photo"]),
 }
@@ -122,6 +123,20 @@ def run_case(exe, work, rig_path, name, timeout=900):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         assert r.returncode == 0, "%s frame %s: rc %d\n%s" % (name, f, r.returncode, r.stderr[-2000:])
         prev = f
+    return out
+
+
+def run_stream(exe, work, rig_path, name, timeout=900):
+    """The frames of a case as ONE stream in one process (host/TestRenderStereoPanorama --num_frames N: temporal state kept
+    on the device, frame pipelining, overlapped I/O); returns the output directory. Equirects eqr_<frame>.png as run_case."""
+    frames, extra = CASES[name]
+    imgs, out, mdir = write_inputs(work, rig_path, frames)
+    cmd = [exe, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", frames[0], "--num_frames", str(len(frames)),
+           "--output_data_dir", out, "--output_equirect_path", os.path.join(out, "eqr_%s.png"),
+           "--eqr_width", str(EQR_W), "--eqr_height", str(EQR_H), "--final_eqr_width", str(FINAL),
+           "--final_eqr_height", str(FINAL)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, "%s as a stream: rc %d\n%s" % (name, r.returncode, r.stderr[-2000:])
     return out
 
 

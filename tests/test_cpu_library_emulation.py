@@ -47,6 +47,18 @@ def test_emulated_program_writes_what_the_reference_program_writes(tmp_path, emu
     assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
 
 
+def test_emulated_stream_mode_equals_the_reference_programs_chain(tmp_path, emu_programs):
+    """--num_frames 3 (one process, device-resident temporal state, frame pipelining) against the equirects the
+    reference's program writes when it is run three times, chained with --prev_frame_data_dir."""
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
+                                  refprog.CAM / 2048.0)
+    name = "three_frames_sharpened"
+    out = refprog.run_stream(os.path.join(emu_programs, "TestRenderStereoPanorama"), str(tmp_path), rig, name)
+    golden = json.load(open(refprog.GOLDEN))[name]
+    for f in refprog.CASES[name][0]:
+        assert refprog._digest_png(os.path.join(out, "eqr_%s.png" % f)) == golden["eqr_%s" % f], f
+
+
 @pytest.mark.parametrize("name", list(refprog.RAW_CASES))
 def test_emulated_raw2rgb_writes_what_the_reference_program_writes(tmp_path, emu_programs, name):
     import isputil

@@ -31,6 +31,19 @@ def test_hip_program_writes_what_the_reference_program_writes(tmp_path, name, s3
     assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
 
 
+def test_hip_stream_mode_equals_the_reference_programs_chain(tmp_path, s360lib):
+    """--num_frames 3 (one process: device-resident temporal state, frame pipelining, overlapped I/O) against the
+    equirects the reference's program writes when it is run three times, chained with --prev_frame_data_dir."""
+    subprocess.check_call(["make", "-C", os.path.join(refprog.ROOT, "host"), "-s"])
+    rig = rigutil.scaled_rig_json(os.path.join(refprog.ROOT, "tests", "golden", "rig_17cam.json"),
+                                  str(tmp_path / "rig_small.json"), refprog.CAM / 2048.0)
+    name = "three_frames_sharpened"
+    out = refprog.run_stream(refprog.HOST_EXE, str(tmp_path), rig, name)
+    golden = json.load(open(refprog.GOLDEN))[name]
+    for f in refprog.CASES[name][0]:
+        assert refprog._digest_png(os.path.join(out, "eqr_%s.png" % f)) == golden["eqr_%s" % f], f
+
+
 @pytest.mark.parametrize("name", list(refprog.RAW_CASES))
 def test_hip_raw2rgb_writes_what_the_reference_program_writes(tmp_path, name, s360lib):
     """host/Raw2Rgb (the HIP ISP) against the digests of the reference's own Raw2Rgb program for the same inputs and flags."""
