@@ -669,7 +669,8 @@ def main():
                 c.close()
             torch.cuda.empty_cache()
             variants = [("latency", "default", {}, 1), ("latency", "S360_LOCK_PEEL=1", {"S360_LOCK_PEEL": "1"}, 1),
-                        ("throughput", "default", {}, S), ("throughput", "S360_QUAD_PEEL=1", {"S360_QUAD_PEEL": "1"}, S),
+                        ("throughput", "default", {}, S), ("throughput", "S360_QUAD_PEEL=2", {"S360_QUAD_PEEL": "2"}, S),
+                        ("throughput", "S360_QUAD_PEEL=1", {"S360_QUAD_PEEL": "1"}, S),
                         ("throughput", "S360_SWEEP_TRI=1", {"S360_SWEEP_TRI": "1"}, S),
                         ("latency", "S360_LOCK_NW=2", {"S360_LOCK_NW": "2"}, 1),
                         ("latency", "S360_LOCK_NW=8", {"S360_LOCK_NW": "8"}, 1),

@@ -56,6 +56,11 @@ __device__ __forceinline__ float from_row_above_q(float old, float v) {
   return __builtin_bit_cast(float, r);
 }
 
+// v of the lane whose byte address (lane * 4) is `src`
+__device__ __forceinline__ float lane_value(int src, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v)));
+}
+
 }  // namespace
 
 // Everything that is not the pixel update itself is amortised over several steps, with wave-uniform control: the
@@ -77,7 +82,7 @@ constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every 
 // The sweeps of one launch then hold a bounded share of every CU — a wave's working set is ~8 KB (17 gradient rows +
 // its record / flow lines) and beyond ~15 waves per CU the 32 KB L1 thrashes — and the kernels of another context
 // find free wave slots, registers and LDS next to them.
-template <bool FAST, bool LDSIN, bool PEEL>
+template <bool FAST, bool LDSIN, bool PEEL, bool R2X>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
@@ -169,18 +174,86 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   };
   // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
   // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
+  // R2X builds ("round-2 exchange", not yet timed): the two finite-difference probes sit kGradEpsilon = 0.001 px away from
+  // the winner of round 1, i.e. almost always in the same bilinear cell, whose four texels the winner's lane has just
+  // gathered. The probe lanes then take those eight floats from that lane (ds_bpermute) instead of gathering them again
+  // from memory: one dependent gather round per step instead of two, 3 gathers per pixel instead of 5. A wave in which any
+  // probe leaves the winner's cell takes the original path for that step, so the results are the same bits.
+  struct Cell { float mx, my; int x0, y0; };
+  bool r2xTake = true;  // (R2X) this lane's pixel is updated at this step: only such pixels can send the wave to the fallback
+  auto cell_of = [&](int x, float ax, float ay) -> Cell {
+    Cell k;
+    k.mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
+    k.my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
+    k.x0 = (int)k.mx;
+    k.y0 = (int)k.my;
+    return k;
+  };
+  auto error_of = [&](auto ieee, const Texels& tt, const Cell& k, float4 rc, float ax, float ay, bool& tiny) -> float {
+    const float xR = __builtin_amdgcn_fractf(k.mx), yR = __builtin_amdgcn_fractf(k.my);
+    if (decltype(ieee)::value) {
+      Foot ft;
+      ft.off = 0; ft.xR = xR; ft.yR = yR;
+      return error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+    }
+    bool t1;
+    const float e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, t1);
+    tiny = tiny || t1;
+    return e;
+  };
   auto update = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool& tiny) -> float2 {
     const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
-    const float e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
+    float e;
+    float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;  // (R2X) the texels this lane gathered in round 1
+    if constexpr (R2X) {
+      const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
+      const Cell k = cell_of(x, ax, ay);
+      const unsigned boff = (unsigned)(__umul24(k.y0, w) + k.x0) << 3;
+      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
+      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
+      g0 = ta.x; g1 = ta.y; g2 = ta.z; g3 = ta.w; g4 = tb.x; g5 = tb.y; g6 = tb.z; g7 = tb.w;
+      Texels t1;
+      t1.r0 = make_float4(g0, g1, g2, g3);
+      t1.r1 = make_float4(g4, g5, g6, g7);
+      e = error_of(ieee, t1, k, rc, ax, ay, tiny);
+    } else {
+      e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
+    }
     const float e0 = quad_bcast<0>(e);
     float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
     if (!decltype(steady)::value && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
     if (!hasUp) e2 = kInf;     // no up proposal in the first row
     float2 f = fo;
     float cur = e0;
-    if (e1 < cur) { f = fl; cur = e1; }
-    if (e2 < cur) { f = up; cur = e2; }
-    const float pe = evaluate(ieee, x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f), tiny);
+    int win = 0;  // (R2X) the quad lane that evaluated the winner
+    if constexpr (R2X) {  // the same two proposals, written as selects (with an index beside them the compiler would
+      const bool b1 = e1 < e0;  // otherwise pick the winner's flow from a table in scratch memory)
+      const float c1 = b1 ? e1 : e0;
+      const bool b2 = e2 < c1;
+      f.x = b2 ? up.x : (b1 ? fl.x : fo.x);
+      f.y = b2 ? up.y : (b1 ? fl.y : fo.y);
+      cur = b2 ? e2 : c1;
+      win = b2 ? 2 : (b1 ? 1 : 0);
+    } else {
+      if (e1 < cur) { f = fl; cur = e1; }
+      if (e2 < cur) { f = up; cur = e2; }
+    }
+    float pe;
+    if constexpr (R2X) {
+      const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
+      const Cell pk = cell_of(x, pax, pay), wk = cell_of(x, f.x + 0.0f, f.y + 0.0f);
+      if (__ballot(q < 2 && r2xTake && (pk.x0 != wk.x0 || pk.y0 != wk.y0)) == 0ull) {
+        const int src = ((lane & ~3) | win) << 2;
+        Texels t2;
+        t2.r0 = make_float4(lane_value(src, g0), lane_value(src, g1), lane_value(src, g2), lane_value(src, g3));
+        t2.r1 = make_float4(lane_value(src, g4), lane_value(src, g5), lane_value(src, g6), lane_value(src, g7));
+        pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
+      } else {
+        pe = evaluate(ieee, x, rc, pax, pay, tiny);
+      }
+    } else {
+      pe = evaluate(ieee, x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f), tiny);
+    }
     const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
     const float nx = ex - cur, ny = ey - cur;
     float ggx, ggy;
@@ -423,6 +496,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       const bool take = active && upd;
       const float2 alt = active ? fo : fl;
       float2 res = alt;
+      r2xTake = take;
       if (__ballot(take) != 0ull) {
         if (FAST) {
           bool tiny = false;
@@ -518,22 +592,25 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     const char* e = std::getenv("S360_QUAD_LDSIN");
     return !(e && e[0] == '0');
   }();
-  // S360_QUAD_PEEL=1: the build whose all-interior chunks are specialised (same results; not yet timed on hardware)
-  static const bool peel = [] {
+  // S360_QUAD_PEEL=1: the build whose all-interior chunks are specialised and whose prefetch arrays stay in registers;
+  // =2: the same plus the round-2 texel exchange (R2X). Same results; not yet timed on hardware.
+  static const int peel = [] {
     const char* e = std::getenv("S360_QUAD_PEEL");
-    return e && e[0] == '1';
+    return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
   }();
-#define S360_LAUNCH_QUAD(F, L, P)                                                                                      \
-  hipLaunchKernelGGL((k_sweep_quad<F, L, P>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, \
+#define S360_LAUNCH_QUAD(F, L, P, X)                                                                                      \
+  hipLaunchKernelGGL((k_sweep_quad<F, L, P, X>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, \
                      c, fc, nb, B, errflag, rowflags)
   if (fast) {
-    if (ldsin && peel) S360_LAUNCH_QUAD(true, true, true);
-    else if (ldsin) S360_LAUNCH_QUAD(true, true, false);
-    else S360_LAUNCH_QUAD(true, false, false);
+    if (ldsin && peel == 2) S360_LAUNCH_QUAD(true, true, true, true);
+    else if (ldsin && peel == 1) S360_LAUNCH_QUAD(true, true, true, false);
+    else if (ldsin) S360_LAUNCH_QUAD(true, true, false, false);
+    else S360_LAUNCH_QUAD(true, false, false, false);
   } else {
-    if (ldsin && peel) S360_LAUNCH_QUAD(false, true, true);
-    else if (ldsin) S360_LAUNCH_QUAD(false, true, false);
-    else S360_LAUNCH_QUAD(false, false, false);
+    if (ldsin && peel == 2) S360_LAUNCH_QUAD(false, true, true, true);
+    else if (ldsin && peel == 1) S360_LAUNCH_QUAD(false, true, true, false);
+    else if (ldsin) S360_LAUNCH_QUAD(false, true, false, false);
+    else S360_LAUNCH_QUAD(false, false, false, false);
   }
 #undef S360_LAUNCH_QUAD
 }

@@ -95,6 +95,7 @@ def test_emulated_optical_flow_harness(tmp_path, emu_programs):
 
 @pytest.mark.parametrize("variant", [dict(S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="2", S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="8"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1"),
+                                     dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="2"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1")])
 def test_emulated_kernel_variants_give_the_same_flows(emu_programs, variant):
     """The switch-selected sweep builds (tests/test_gpu_zz_variants.py) through the whole flow path of the emulated

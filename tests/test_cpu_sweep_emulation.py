@@ -107,3 +107,12 @@ def test_tri_sizes(emulator, w, h):
     """One band exactly, one row more, two bands, chunk boundaries; persistent waves taking several tickets."""
     _run(emulator, ["tri", w, h, 2, 43, "random", 1, 1])
     _run(emulator, ["tri", w, h, 2, 43, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1, EMU_LANE_ORDER="rev")
+
+
+@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
+def test_quad_kernel_with_round_two_exchange(emulator, mask):
+    """S360_QUAD_PEEL=2: the probes of round 2 take the winner's texels from its lane (ds_bpermute) when they stay in its
+    bilinear cell, and the whole wave gathers again when one of them does not."""
+    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1], S360_QUAD_PEEL=2)
+    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], S360_QUAD_PEEL=2, EMU_LANE_ORDER="shuffle")
+    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_PEEL=2, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)

@@ -53,14 +53,21 @@ def test_lock_kernel_with_peeled_steady_state(default_digest):
     assert _flows_digest(S360_LOCK_PEEL="1") == default_digest
 
 
-def test_quad_kernel_with_peeled_interior_chunks(s360lib):
-    """S360_QUAD_PEEL=1 against the default build of the throughput kernel."""
-    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1") == _flows_digest(TEST_SWEEP_MODE="throughput")
+@pytest.fixture(scope="module")
+def default_throughput_digest(s360lib):
+    return _flows_digest(TEST_SWEEP_MODE="throughput")
 
 
-def test_throughput_kernel_with_three_lanes_per_pixel(s360lib):
+@pytest.mark.parametrize("level", ["1", "2"])
+def test_quad_kernel_with_peeled_interior_chunks(default_throughput_digest, level):
+    """S360_QUAD_PEEL=1 (specialised interior chunks, prefetch arrays in registers) and =2 (plus the round-2 texel exchange)
+    against the default build of the throughput kernel."""
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL=level) == default_throughput_digest
+
+
+def test_throughput_kernel_with_three_lanes_per_pixel(default_throughput_digest):
     """S360_SWEEP_TRI=1 (sweep_tri.hip) against the default build of the throughput kernel."""
-    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1") == _flows_digest(TEST_SWEEP_MODE="throughput")
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1") == default_throughput_digest
 
 
 @pytest.mark.parametrize("nw", ["2", "8"])

@@ -169,6 +169,13 @@ inline T __shfl_xor(T v, int mask, int width = 64) {
   std::memcpy(&v, &u, 4);
   return v;
 }
+// ds_bpermute_b32: every lane reads the value of the lane whose byte address (lane * 4) it names (0 from a lane that is gone)
+inline int emu_ds_bpermute(int addr, int v) {
+  const emu::Rendezvous r = emu::arrive(emu::OP_DPP, (unsigned)v);
+  unsigned long long o = 0;
+  return emu::peer(r, (addr >> 2) & 63, &o) ? (int)(unsigned)o : 0;
+}
+#define __builtin_amdgcn_ds_bpermute(addr, v) emu_ds_bpermute(addr, v)
 // v_perm_b32: bytes of {src0 (4..7), src1 (0..3)} picked by the selector's bytes; 8..11 sign replication, 12 zero, 13+ 0xFF
 inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
   const unsigned long long in = ((unsigned long long)s0 << 32) | s1;
