@@ -93,19 +93,24 @@ def test_emulated_optical_flow_harness(tmp_path, emu_programs):
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
 
 
+_EMU_COMMON = dict(S360_TEST_EMULATED_LIB="1", TEST_FLOW_SIZES="150x120,97x131")
+
+
+@pytest.fixture(scope="module")
+def emulated_default_digests(emu_programs):
+    from test_gpu_zz_variants import _flows_digest
+    return {"latency": _flows_digest(**_EMU_COMMON), "throughput": _flows_digest(TEST_SWEEP_MODE="throughput", **_EMU_COMMON)}
+
+
 @pytest.mark.parametrize("variant", [dict(S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="2", S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="8"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="2"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1")])
-def test_emulated_kernel_variants_give_the_same_flows(emu_programs, variant):
+def test_emulated_kernel_variants_give_the_same_flows(emulated_default_digests, variant):
     """The switch-selected sweep builds (tests/test_gpu_zz_variants.py) through the whole flow path of the emulated
     library: both algorithms, both directions, a band of masked rows — same digest as the default build."""
     from test_gpu_zz_variants import _flows_digest
-    common = dict(S360_TEST_EMULATED_LIB="1", TEST_FLOW_SIZES="150x120,97x131")
-    base = dict(common)
-    if "TEST_SWEEP_MODE" in variant:
-        base["TEST_SWEEP_MODE"] = variant["TEST_SWEEP_MODE"]
-    assert _flows_digest(**dict(common, **variant)) == _flows_digest(**base)
+    assert _flows_digest(**dict(_EMU_COMMON, **variant)) == emulated_default_digests[variant.get("TEST_SWEEP_MODE", "latency")]
 
 
 def test_operator_level_gpu_tests_pass_on_the_emulated_library(emu_programs):
