@@ -671,6 +671,7 @@ def main():
             variants = [("latency", "default", {}, 1), ("latency", "S360_LOCK_PEEL=1", {"S360_LOCK_PEEL": "1"}, 1),
                         ("throughput", "default", {}, S), ("throughput", "S360_QUAD_PEEL=2", {"S360_QUAD_PEEL": "2"}, S),
                         ("throughput", "S360_QUAD_PEEL=1", {"S360_QUAD_PEEL": "1"}, S),
+                        ("throughput", "S360_SWEEP_TRI=2", {"S360_SWEEP_TRI": "2"}, S),
                         ("throughput", "S360_SWEEP_TRI=1", {"S360_SWEEP_TRI": "1"}, S),
                         ("latency", "S360_LOCK_NW=2", {"S360_LOCK_NW": "2"}, 1),
                         ("latency", "S360_LOCK_NW=8", {"S360_LOCK_NW": "8"}, 1),

@@ -10,6 +10,7 @@
 //   * the three evaluations of a round are exchanged with row_shr / row_shl by 1 and 2 and a per-role select (a quad
 //     broadcast does not exist for groups of three): ~16 more instructions per step for 25 % more pixels per step;
 //   * bands are 20 rows high: w + 19 steps per band, 20 % fewer bands and hand-offs per flow.
+// S360_SWEEP_TRI=2 adds the round-2 texel exchange of sweep_quad.hip (the probes take the winner's texels from its lane).
 // Bit-identical to the other sweeps on the CPU emulation (tests/test_cpu_sweep_emulation.py); not yet timed on hardware.
 #include <algorithm>
 #include <cstdlib>
@@ -34,6 +35,10 @@ __device__ __forceinline__ float dpp_row(float v) {  // row_shr:n (0x110 + n) / 
 // previous result of the row above = the pixel three lanes to the left. The first pixel of DPP rows 1..3 takes lane 15 of
 // the previous DPP row (the passive copy of its last pixel: row_bcast:15 into lanes 0..3, then row_shr:3 overwrites lane 3
 // with lane 0); the first pixel of the wave (row 0 of the band) keeps `old` = the granule-fed value.
+// v of the lane whose byte address (lane * 4) is `src`
+__device__ __forceinline__ float lane_value_t(int src, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v)));
+}
 __device__ __forceinline__ float from_row_above_t(float old, float v) {
   int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x142, 0xE, 0x1, false);
   r = __builtin_amdgcn_update_dpp(r, __builtin_bit_cast(int, v), 0x113, 0xF, 0xF, false);
@@ -61,7 +66,7 @@ constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every 
 // The sweeps of one launch then hold a bounded share of every CU — a wave's working set is ~8 KB (17 gradient rows +
 // its record / flow lines) and beyond ~15 waves per CU the 32 KB L1 thrashes — and the kernels of another context
 // find free wave slots, registers and LDS next to them.
-template <bool FAST>
+template <bool FAST, bool R2X>
 __global__ __launch_bounds__(64) void k_sweep_tri(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
@@ -155,9 +160,47 @@ __global__ __launch_bounds__(64) void k_sweep_tri(const float4* __restrict__ rec
   };
   // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
   // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
+  // R2X (S360_SWEEP_TRI=2): the round-2 texel exchange of sweep_quad.hip — the probes take the winner's texels from its lane.
+  struct Cell { float mx, my; int x0, y0; };
+  bool r2xTake = true;
+  auto cell_of = [&](int x, float ax, float ay) -> Cell {
+    Cell k;
+    k.mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
+    k.my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
+    k.x0 = (int)k.mx;
+    k.y0 = (int)k.my;
+    return k;
+  };
+  auto error_of = [&](auto ieee, const Texels& tt, const Cell& k, float4 rc, float ax, float ay, bool& tiny) -> float {
+    const float xR = __builtin_amdgcn_fractf(k.mx), yR = __builtin_amdgcn_fractf(k.my);
+    if (decltype(ieee)::value) {
+      Foot ft;
+      ft.off = 0; ft.xR = xR; ft.yR = yR;
+      return error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+    }
+    bool t1;
+    const float e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, t1);
+    tiny = tiny || t1;
+    return e;
+  };
   auto update = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool& tiny) -> float2 {
     const float2 cand = q == 0 ? fo : (q == 1 ? fl : up);
-    const float e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
+    float e;
+    float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;  // (R2X) the texels this lane gathered in round 1
+    if constexpr (R2X) {
+      const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
+      const Cell k = cell_of(x, ax, ay);
+      const unsigned boff = (unsigned)(__umul24(k.y0, w) + k.x0) << 3;
+      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
+      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
+      g0 = ta.x; g1 = ta.y; g2 = ta.z; g3 = ta.w; g4 = tb.x; g5 = tb.y; g6 = tb.z; g7 = tb.w;
+      Texels t1;
+      t1.r0 = make_float4(g0, g1, g2, g3);
+      t1.r1 = make_float4(g4, g5, g6, g7);
+      e = error_of(ieee, t1, k, rc, ax, ay, tiny);
+    } else {
+      e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
+    }
     // the three errors of the pixel in each of its lanes: neighbours one and two lanes to either side, picked by role
     const float er1 = dpp_row<0x111>(e), er2 = dpp_row<0x112>(e), el1 = dpp_row<0x101>(e), el2 = dpp_row<0x102>(e);
     const float e0 = q == 0 ? e : (q == 1 ? er1 : er2);
@@ -166,9 +209,31 @@ __global__ __launch_bounds__(64) void k_sweep_tri(const float4* __restrict__ rec
     if (!hasUp) e2 = kInf;     // no up proposal in the first row
     float2 f = fo;
     float cur = e0;
-    if (e1 < cur) { f = fl; cur = e1; }
-    if (e2 < cur) { f = up; cur = e2; }
-    const float pe = evaluate(ieee, x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f), tiny);
+    float pe;
+    if constexpr (R2X) {
+      const bool b1 = e1 < e0;
+      const float c1 = b1 ? e1 : e0;
+      const bool b2 = e2 < c1;
+      f.x = b2 ? up.x : (b1 ? fl.x : fo.x);
+      f.y = b2 ? up.y : (b1 ? fl.y : fo.y);
+      cur = b2 ? e2 : c1;
+      const int win = b2 ? 2 : (b1 ? 1 : 0);  // = the role of the lane that evaluated the winner
+      const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
+      const Cell pk = cell_of(x, pax, pay), wk = cell_of(x, f.x + 0.0f, f.y + 0.0f);
+      if (__ballot(q < 2 && r2xTake && (pk.x0 != wk.x0 || pk.y0 != wk.y0)) == 0ull) {
+        const int src = (lane - min(q, 2) + win) << 2;
+        Texels t2;
+        t2.r0 = make_float4(lane_value_t(src, g0), lane_value_t(src, g1), lane_value_t(src, g2), lane_value_t(src, g3));
+        t2.r1 = make_float4(lane_value_t(src, g4), lane_value_t(src, g5), lane_value_t(src, g6), lane_value_t(src, g7));
+        pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
+      } else {
+        pe = evaluate(ieee, x, rc, pax, pay, tiny);
+      }
+    } else {
+      if (e1 < cur) { f = fl; cur = e1; }
+      if (e2 < cur) { f = up; cur = e2; }
+      pe = evaluate(ieee, x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f), tiny);
+    }
     const float pr1 = dpp_row<0x111>(pe), pr2 = dpp_row<0x112>(pe), pl1 = dpp_row<0x101>(pe);
     const float ex = q == 0 ? pe : (q == 1 ? pr1 : pr2), ey = q == 0 ? pl1 : (q == 1 ? pe : pr1);
     const float nx = ex - cur, ny = ey - cur;
@@ -316,6 +381,7 @@ __global__ __launch_bounds__(64) void k_sweep_tri(const float4* __restrict__ rec
       const bool take = active && upd;
       const float2 alt = active ? fo : fl;
       float2 res = alt;
+      r2xTake = take;
       if (__ballot(take) != 0ull) {
         if (FAST) {
           bool tiny = false;
@@ -395,12 +461,21 @@ void launch_sweep_tri(hipStream_t st, const float4* rec, const float2* G, float2
     return n > 0 ? n : 256;
   }();
   const int grid = std::min(nb * B, cus * perCu);
-  if (fast)
-    hipLaunchKernelGGL((k_sweep_tri<true>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B,
-                       errflag, rowflags);
-  else
-    hipLaunchKernelGGL((k_sweep_tri<false>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B,
-                       errflag, rowflags);
+  static const bool r2x = [] {  // S360_SWEEP_TRI=2: with the round-2 texel exchange
+    const char* e = std::getenv("S360_SWEEP_TRI");
+    return e && e[0] == '2';
+  }();
+#define S360_LAUNCH_TRI(F, X)                                                                                                   \
+  hipLaunchKernelGGL((k_sweep_tri<F, X>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B, \
+                     errflag, rowflags)
+  if (fast) {
+    if (r2x) S360_LAUNCH_TRI(true, true);
+    else S360_LAUNCH_TRI(true, false);
+  } else {
+    if (r2x) S360_LAUNCH_TRI(false, true);
+    else S360_LAUNCH_TRI(false, false);
+  }
+#undef S360_LAUNCH_TRI
 }
 
 }  // namespace s360

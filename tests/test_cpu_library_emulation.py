@@ -105,7 +105,8 @@ def emulated_default_digests(emu_programs):
 @pytest.mark.parametrize("variant", [dict(S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="2", S360_LOCK_PEEL="1"), dict(S360_LOCK_NW="8"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="1"),
                                      dict(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL="2"),
-                                     dict(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1")])
+                                     dict(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1"),
+                                     dict(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="2")])
 def test_emulated_kernel_variants_give_the_same_flows(emulated_default_digests, variant):
     """The switch-selected sweep builds (tests/test_gpu_zz_variants.py) through the whole flow path of the emulated
     library: both algorithms, both directions, a band of masked rows — same digest as the default build."""

@@ -116,3 +116,10 @@ def test_quad_kernel_with_round_two_exchange(emulator, mask):
     _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1], S360_QUAD_PEEL=2)
     _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], S360_QUAD_PEEL=2, EMU_LANE_ORDER="shuffle")
     _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_PEEL=2, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
+
+
+@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
+def test_tri_kernel_with_round_two_exchange(emulator, mask):
+    """S360_SWEEP_TRI=2: three lanes per pixel and the round-2 texel exchange."""
+    _run(emulator, ["tri", 70, 50, 2, 61, mask, 1, 1], S360_SWEEP_TRI=2)
+    _run(emulator, ["tri", 53, 45, 3, 62, mask, 0, 0], S360_SWEEP_TRI=2, EMU_LANE_ORDER="shuffle")

@@ -65,9 +65,10 @@ def test_quad_kernel_with_peeled_interior_chunks(default_throughput_digest, leve
     assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_PEEL=level) == default_throughput_digest
 
 
-def test_throughput_kernel_with_three_lanes_per_pixel(default_throughput_digest):
-    """S360_SWEEP_TRI=1 (sweep_tri.hip) against the default build of the throughput kernel."""
-    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI="1") == default_throughput_digest
+@pytest.mark.parametrize("level", ["1", "2"])
+def test_throughput_kernel_with_three_lanes_per_pixel(default_throughput_digest, level):
+    """S360_SWEEP_TRI=1 (sweep_tri.hip) and =2 (with the round-2 texel exchange) against the default throughput kernel."""
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_SWEEP_TRI=level) == default_throughput_digest
 
 
 @pytest.mark.parametrize("nw", ["2", "8"])
