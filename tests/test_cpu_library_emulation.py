@@ -124,3 +124,35 @@ def test_operator_level_gpu_tests_pass_on_the_emulated_library(emu_programs):
                        capture_output=True, text=True, env=e, timeout=1800, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.skipif(os.environ.get("S360_RUN_8K_REFPROGRAM") != "1", reason="half an hour of CPU: set S360_RUN_8K_REFPROGRAM=1")
+def test_emulated_program_equals_the_reference_program_at_8k(tmp_path, emu_programs):
+    """BASELINE configs[2] (17 cameras of 2048x2048, eqr 8400x4096 -> 8192x8192, top + bottom) through the emulated HIP
+    program and through the reference's own program: the stereo equirect, the 32 flow files and the 36 state images.
+    Measured in this container (8 cores): reference program 91 s, emulated library 1119 s; 0 of 201 326 592 equirect
+    bytes, 0 of 32 flow files and 0 of 36 state images differ."""
+    rig = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
+    imgs8 = refprog.frame_images(rig, 0, size=2048)
+    imgs = str(tmp_path / "rgb")
+    for cid, img in imgs8.items():
+        os.makedirs(os.path.join(imgs, cid))
+        Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(os.path.join(imgs, cid, "000000.png"), compress_level=1)
+    outs = {}
+    for tag, exe in (("ref", refprog.REF_EXE), ("emu", os.path.join(emu_programs, "TestRenderStereoPanorama"))):
+        out = str(tmp_path / tag)
+        os.makedirs(os.path.join(out, "debug", "000000", "flow_images"))
+        os.makedirs(os.path.join(out, "flow", "000000"))
+        subprocess.check_call([exe, "--rig_json_file", rig, "--imgs_dir", imgs, "--frame_number", "000000", "--output_data_dir", out,
+                               "--prev_frame_data_dir", "NONE", "--output_equirect_path", os.path.join(out, "eqr.png"),
+                               "--eqr_width", "8400", "--eqr_height", "4096", "--final_eqr_width", "8192", "--final_eqr_height", "8192",
+                               "--enable_top", "--enable_bottom", "--sharpening", "0.0"], timeout=9000)
+        outs[tag] = out
+    Image.MAX_IMAGE_PIXELS = None
+    assert np.array_equal(np.asarray(Image.open(os.path.join(outs["ref"], "eqr.png"))), np.asarray(Image.open(os.path.join(outs["emu"], "eqr.png"))))
+    fdir = os.path.join("flow", "000000")
+    for f in sorted(os.listdir(os.path.join(outs["ref"], fdir))):
+        assert open(os.path.join(outs["ref"], fdir, f), "rb").read() == open(os.path.join(outs["emu"], fdir, f), "rb").read(), f
+    idir = os.path.join("debug", "000000", "flow_images")
+    for f in sorted(os.listdir(os.path.join(outs["ref"], idir))):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(outs["ref"], idir, f))), np.asarray(Image.open(os.path.join(outs["emu"], idir, f)))), f
