@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../include/s360.h"
+#include "jpeg_io.hpp"
 #include "png_io.hpp"
 
 namespace {
@@ -136,9 +137,10 @@ void mkdirs(const std::string& path) {
     if (i < path.size()) cur += path[i];
   }
 }
+// imread: the decoder is chosen by the file's signature — PNG (every colour type / depth) or baseline JPEG (jpeg_io.hpp)
 pngio::Image load_png(const std::string& path, bool keep_alpha) {
   try {
-    return pngio::read(path, keep_alpha);
+    return jpegio::read_any(path, keep_alpha);
   } catch (const std::exception& e) {
     die(e.what());
   }

@@ -305,3 +305,64 @@ def test_unpacker_raw_path(tmp_path, bits):
     r = subprocess.run([exe, "--isp_dir", str(isp), "--output_dir", str(out), "--bin_list", str(tmp_path / "none.bin")],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "Error opening file" in r.stderr
+
+
+JPEG_SNIPPET = r'''
+#include "jpeg_io.hpp"
+int main(int argc, char** argv) {  // argv: in.jpg out.raw
+  try {
+    pngio::Image im = jpegio::read_any(argv[1], false);
+    FILE* f = std::fopen(argv[2], "wb");
+    std::fwrite(im.px.data(), 1, im.px.size(), f);
+    std::fclose(f);
+    std::printf("%d %d %d\n", im.w, im.h, im.c);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+'''
+
+
+def test_jpeg_reader_equals_libjpeg(tmp_path):
+    """host/jpeg_io.hpp against PIL (libjpeg-turbo at libjpeg's defaults, as cv::imread uses it): 4:4:4 / 4:2:2 / 4:2:0,
+    qualities, sizes that are not multiples of the MCU, restart markers, greyscale — bit for bit; progressive files and an
+    EXIF orientation other than 1 are rejected with a message."""
+    src = tmp_path / "jpg.cpp"
+    src.write_text(JPEG_SNIPPET)
+    exe = str(tmp_path / "jpg")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz"])
+    rng = np.random.default_rng(1)
+
+    def scene(h, w):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy // 7) % 256], -1).astype(np.uint8)
+        a[h // 4:h // 2, w // 3:w // 2] = [250, 10, 30]
+        return np.clip(a.astype(int) + rng.integers(0, 40, (h, w, 3)) - 20, 0, 255).astype(np.uint8)
+
+    def decode(p, shape):
+        r = subprocess.run([exe, p, str(tmp_path / "o.raw")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return np.fromfile(str(tmp_path / "o.raw"), np.uint8).reshape(shape)
+
+    p = str(tmp_path / "t.jpg")
+    for (h, w) in ((64, 64), (37, 53), (128, 200), (17, 16), (8, 8), (1, 1), (33, 17)):
+        for sub in (0, 1, 2):
+            for q, extra in ((30, {}), (75, {"restart_marker_blocks": 3}), (95, {})):
+                Image.fromarray(scene(h, w)).save(p, quality=q, subsampling=sub, **extra)
+                want = np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1]
+                assert np.array_equal(decode(p, (h, w, 3)), want), (h, w, sub, q)
+    Image.fromarray(scene(40, 61)[:, :, 0]).save(p, quality=80)  # greyscale -> B = G = R
+    assert np.array_equal(decode(p, (40, 61, 3)), np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1])
+    Image.fromarray(scene(32, 32)).save(p, progressive=True)
+    r = subprocess.run([exe, p, str(tmp_path / "o.raw")], capture_output=True, text=True)
+    assert r.returncode != 0 and "progressive" in r.stderr
+    ex = Image.Exif()
+    ex[0x0112] = 6
+    Image.fromarray(scene(32, 32)).save(p, exif=ex)
+    r = subprocess.run([exe, p, str(tmp_path / "o.raw")], capture_output=True, text=True)
+    assert r.returncode != 0 and "orientation" in r.stderr
+    ex[0x0112] = 1
+    Image.fromarray(scene(32, 32)).save(p, exif=ex)
+    assert np.array_equal(decode(p, (32, 32, 3)), np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1])

@@ -156,3 +156,38 @@ def test_emulated_program_equals_the_reference_program_at_8k(tmp_path, emu_progr
     idir = os.path.join("debug", "000000", "flow_images")
     for f in sorted(os.listdir(os.path.join(outs["ref"], idir))):
         assert np.array_equal(np.asarray(Image.open(os.path.join(outs["ref"], idir, f))), np.asarray(Image.open(os.path.join(outs["emu"], idir, f)))), f
+
+
+def test_emulated_program_reads_jpeg_camera_images(tmp_path, emu_programs):
+    """The side cameras' images as .jpg (the extension is sniffed from the camera directory like getImageFileExtension,
+    SystemUtil.h:96-105; top / bottom stay .png, TestRenderStereoPanorama.cpp:602,652): the frame equals the oracle's
+    frame of the decoded images."""
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
+                                  refprog.CAM / 2048.0)
+    imgs = refprog.frame_images(rig, 0)
+    side_ids, top_id, bottoms = refprog.rig_ids(rig)
+    idir, out = str(tmp_path / "rgb"), str(tmp_path / "out")
+    decoded = {}
+    for cid, img in imgs.items():
+        os.makedirs(os.path.join(idir, cid))
+        if cid in side_ids:
+            p = os.path.join(idir, cid, "000000.jpg")
+            Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(p, quality=90, subsampling=2)
+            decoded[cid] = np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1])
+        else:
+            Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(os.path.join(idir, cid, "000000.png"))
+            decoded[cid] = img
+    os.makedirs(os.path.join(out, "debug", "000000", "flow_images"))
+    os.makedirs(os.path.join(out, "flow", "000000"))
+    eqr = os.path.join(out, "eqr.png")
+    r = subprocess.run([os.path.join(emu_programs, "TestRenderStereoPanorama"), "--rig_json_file", rig, "--imgs_dir", idir,
+                        "--frame_number", "000000", "--output_data_dir", out, "--output_equirect_path", eqr, "--enable_top",
+                        "--enable_bottom", "--eqr_width", str(refprog.EQR_W), "--eqr_height", str(refprog.EQR_H),
+                        "--final_eqr_width", str(refprog.FINAL), "--final_eqr_height", str(refprog.FINAL)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cams, _ = O.load_rig(rig)
+    of = O.Frame(cams, O.make_params(eqr_width=refprog.EQR_W, eqr_height=refprog.EQR_H, final_eqr_width=refprog.FINAL,
+                                     final_eqr_height=refprog.FINAL, enable_top=1, enable_bottom=1))
+    want, _ = of.render([decoded[c] for c in side_ids], decoded[top_id], decoded[bottoms[0]])
+    assert np.array_equal(np.asarray(Image.open(eqr))[:, :, ::-1], want)
