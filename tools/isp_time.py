@@ -25,9 +25,14 @@ def main():
     args = ap.parse_args()
     import torch  # noqa: F401  (the HIP runtime before libs360, like tests/conftest.py)
     import isputil
+    emulated = os.environ.get("S360_TEST_EMULATED_LIB") == "1"  # (developer check of this tool's control flow without a GPU)
+    if emulated:
+        from surround360_amd import _capi
+        _capi.LIB_PATH = os.path.join(ROOT, "tools", "libs360_emu.so")
     from surround360_amd import isp as I, render as R
     js = isputil.CONFIG_FULL
-    raws = [isputil.bayer_frame(2048, 2048, seed=k) for k in range(3)]
+    SZ = 256 if emulated else 2048
+    raws = [isputil.bayer_frame(SZ, SZ, seed=k) for k in range(3)]
     res = {"input": "16-bit Bayer frames 2048x2048, every configuration key set, IIR sharpening on "
                     "(CameraIsp.h through Raw2Rgb.cpp:441-456)"}
     for key, bpp, dm in (("ms_per_image_bpp16_edge_aware", 16, 2), ("ms_per_image_bpp8_edge_aware", 8, 2),
@@ -52,8 +57,13 @@ def main():
         if not args.json:
             print("oracle 2048x2048 bpp16 dm2: %.2f s; equal to GPU: %s" % (res["cpu_seconds_per_image"], res["checked"]))
     # a whole frame from raw images: 17 x upload_raw + render (latency sweep kernel), frames back to back
-    rig = R.RigDescription(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"))
+    rig_path = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
     flags = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192, final_eqr_height=8192)
+    if emulated:
+        import rigutil
+        rig_path = rigutil.scaled_rig_json(rig_path, "/tmp/isp_time_rig_small.json", SZ / 2048.0)
+        flags.update(eqr_width=504, eqr_height=252, final_eqr_width=480, final_eqr_height=480)
+    rig = R.RigDescription(rig_path)
     ctx = R.Context(rig, R.make_params(**flags), device=args.device)
     isp = I.CameraIsp(I.config_from_json(js, 16, 2), device=args.device)
     try:
