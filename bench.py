@@ -73,12 +73,12 @@ def sweep_algorithmic_bytes(geom, n_side_flows, n_pole_flows, eqr_w):
     return 2 * SWEEP_BYTES_PER_PX * (n_side_flows * side + n_pole_flows * pole)  # forward + backward sweep per level
 
 
-def cpu_baseline_8k(side, top, bottom):
+def cpu_baseline_8k(side, top, bottom, rig_path=RIG, flags=None):
     """The oracle (kind "port") on the bench's own 8K frame, once, with the reference's thread shape."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # test infrastructure: used here only as the timed CPU baseline
-    cams, _ = O.load_rig(RIG)
-    f = O.Frame(cams, O.make_params(**FLAGS_8K))
+    cams, _ = O.load_rig(rig_path)
+    f = O.Frame(cams, O.make_params(**(FLAGS_8K if flags is None else flags)))
     t0 = time.time()
     out, _ = f.render(side, top, bottom, threaded=True)
     sec = time.time() - t0
@@ -203,12 +203,30 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    # Developer dry run, NOT a bench configuration: S360_TEST_EMULATED_LIB=1 walks this whole script on a machine without
+    # a GPU — the library's sources compiled for the CPU (tools/libs360_emu.so), a rig scaled to 256x256 cameras, eqr
+    # 504x252, a handful of steps — to check the script's control flow. Its JSON line says "dry_run".
+    dry = os.environ.get("S360_TEST_EMULATED_LIB") == "1"
+    rig_path, cam_size, world_h, pair_size = RIG, 2048, 4096, 2048
+    flags = dict(FLAGS_8K)
+    if dry:
+        from surround360_amd import _capi
+        _capi.LIB_PATH = os.path.join(ROOT, "tools", "libs360_emu.so")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import rigutil
+        cam_size, world_h, pair_size = 256, 512, 150
+        rig_path = rigutil.scaled_rig_json(RIG, "/tmp/bench_dry_run_rig.json", cam_size / 2048.0)
+        flags.update(eqr_width=504, eqr_height=252, final_eqr_width=480, final_eqr_height=480)
+
+        class _NoCuda:  # the handful of torch.cuda calls of this script
+            set_device = synchronize = empty_cache = staticmethod(lambda *a, **k: None)
+            mem_get_info = staticmethod(lambda *a, **k: (0, 0))
+        torch.cuda = _NoCuda
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks timing tensors live
 
-    flags = dict(FLAGS_8K)
-    rig = R.RigDescription(RIG)
+    rig = R.RigDescription(rig_path)
     P = rig.get_side_camera_count()
     F = max(1, args.inflight)
     S = max(1, args.slots)
@@ -216,8 +234,8 @@ def main():
     # through the 17 rig cameras on the GPU; frame k = world rotated by 0.2 deg * k, one disc moving 0.5 deg per frame.
     # (The world is 8192x4096: the 16384x8192 of §8d needs 3 GB for the texture + depth alone; stated in `data`.)
     n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 2)
-    wtex = synth.World(4096, seed=360, device=dev)  # the same stream on every rank (the sharded frame needs identical inputs)
-    rr = synth.RigRenderer(RIG, wtex, 2048)
+    wtex = synth.World(world_h, seed=360, device=dev)  # the same stream on every rank (the sharded frame needs identical inputs)
+    rr = synth.RigRenderer(rig_path, wtex, cam_size)
     frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_video))]
     del rr, wtex
     torch.cuda.empty_cache()
@@ -470,6 +488,8 @@ def main():
     }
     out.update(checked)
     out["hbm_used_GB_in_timed_region"] = hbm_used_gb
+    if dry:
+        out["dry_run"] = "NOT A MEASUREMENT: the library emulated on the CPU at toy sizes (S360_TEST_EMULATED_LIB=1)"
 
     def emit():
         if rank == 0:
@@ -584,7 +604,7 @@ def main():
                                                            "finish_ms_without": out["single_frame"]["kernel_ms_per_frame"].get("finish")}
 
             # ---- BASELINE configs[1]: one 2048x2048 pair, both directions (TestOpticalFlow.cpp:50-143) ----
-            i0, i1 = synth.flow_pair(2048, 2048, seed=360)
+            i0, i1 = synth.flow_pair(pair_size, pair_size, seed=360)
             cf = R.Context(rig, R.make_params(), device=local_rank)
             cf.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
             t1 = time.perf_counter()
@@ -639,13 +659,13 @@ def main():
             if not args.no_cpu_baseline:
                 ref = None
                 try:
-                    ref = cpu_baseline_reference(*frames[0])
+                    ref = cpu_baseline_reference(*frames[0], rig_path=rig_path, flags=flags)
                 except Exception as e:  # noqa: BLE001
                     out.setdefault("errors", []).append("reference program baseline failed: %r" % (e,))
                 if ref is not None:
                     want, cb = ref
                 else:  # no oracle/_ref on this machine: the oracle port of the same path
-                    want, cb = cpu_baseline_8k(*frames[0])
+                    want, cb = cpu_baseline_8k(*frames[0], rig_path=rig_path, flags=flags)
                 cb["checked_against_gpu"] = bool(want.shape == single0.shape and np.array_equal(want, single0))
                 out["cpu_baseline"] = cb
 

@@ -191,3 +191,21 @@ def test_emulated_program_reads_jpeg_camera_images(tmp_path, emu_programs):
                                      final_eqr_height=refprog.FINAL, enable_top=1, enable_bottom=1))
     want, _ = of.render([decoded[c] for c in side_ids], decoded[top_id], decoded[bottoms[0]])
     assert np.array_equal(np.asarray(Image.open(eqr))[:, :, ::-1], want)
+
+
+@pytest.mark.skipif(os.environ.get("S360_RUN_BENCH_DRY") != "1", reason="four minutes of CPU: set S360_RUN_BENCH_DRY=1")
+def test_bench_script_dry_run(emu_programs):
+    """bench.py from its first line to its JSON line on the emulated library at toy sizes (S360_TEST_EMULATED_LIB=1: NOT a
+    measurement): timed region with 2 contexts x 2 frame slots, the check of every timed frame, the isolated / single-frame
+    / sharpening / flow-pair / video-stream legs, the reference program as the CPU baseline, the ISP leg and the variants
+    leg with all ten switch-selected builds."""
+    import sys
+    e = dict(os.environ, S360_TEST_EMULATED_LIB="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--slots", "2", "--inflight", "2",
+                        "--video-frames", "3"], capture_output=True, text=True, env=e, timeout=3000, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "dry_run" in d and "errors" not in d
+    assert d["checked"] is True and d["cpu_baseline"]["checked_against_gpu"] is True and d["config2_flow_pair"]["checked"] is True
+    assert d["isp"]["checked"] is True
+    assert d["variants"]["latency"]["identical_output"] is True and d["variants"]["throughput"]["identical_output"] is True
