@@ -5,6 +5,7 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <random>
@@ -103,9 +104,9 @@ void run_group(Group& g) {
     L.sp = sp;
   }
   std::vector<int> idx(64);
-  int idle_rounds = 0;
+  int idle_rounds = 0, nap_rounds = 0;
   for (;;) {
-    bool progressed = false, alive = false;
+    bool progressed = false, alive = false, useful = false;  // useful: a lane did something other than come back from a nap
     for (int wv = 0; wv < nwaves; ++wv) {
       const int lo = wv * 64, hi = std::min(n, lo + 64), m = hi - lo;
       for (int k = 0; k < m; ++k) idx[k] = order == 1 ? hi - 1 - k : lo + k;
@@ -116,6 +117,7 @@ void run_group(Group& g) {
         g.cur = idx[k];
         emu_switch(&g.sched_sp, L.sp);
         progressed = true;
+        if (L.state != NAPPING) useful = true;
       }
       // every live lane of the wave is now blocked; a cross-lane operation completes when all of them are at it
       int at_op = 0, at_bar = 0, nap = 0, live = 0;
@@ -151,6 +153,12 @@ void run_group(Group& g) {
       for (Lane& L : g.lanes) if (L.state == AT_BARRIER) L.state = READY;
       progressed = true;
     }
+    if (progressed && !useful) {
+      // every lane that ran is polling something another workgroup has to write: give that workgroup the core. (The
+      // kernels bound their spins by counting them; on a loaded machine a pure yield loop can use up such a bound
+      // before the other OS thread has been scheduled at all.)
+      std::this_thread::sleep_for(std::chrono::microseconds(++nap_rounds > 64 ? 50 : 0));
+    } else nap_rounds = 0;
     if (!progressed) {
       if (!ready) die(g, "deadlock: every lane waits and nothing can release them");
       // only napping lanes: another workgroup has to move first
