@@ -52,6 +52,13 @@ bool imwrite(const std::string& path, const Mat& img0, const std::vector<int>&) 
 }
 }  // namespace cv
 
+// glog's command-line flags that scripts/batch_process_video.py passes to the program (accepted, without effect here)
+#include "gflags/gflags.h"
+DEFINE_int32(logbuflevel, 0, "");
+DEFINE_string(log_dir, "", "");
+DEFINE_int32(stderrthreshold, 2, "");
+DEFINE_int32(v, 0, "");
+
 // gflags' own help flags, which util/SystemUtil.cpp:21-24 declares and touches
 namespace fLB {
 bool FLAGS_help = false;

@@ -96,7 +96,12 @@ def write_inputs(work, rig_path, frames, masks=False):
 
 # name -> (frames, extra flags of the program)
 CASES = {
-    "two_frames": (["000000", "000001"], ["--enable_top", "--enable_bottom", "--sharpening", "0.0"]),
+    # (with every flag scripts/batch_process_video.py:29-56 passes, glog's included)
+    "two_frames": (["000000", "000001"], ["--enable_top", "--enable_bottom", "--sharpening", "0.0", "--logbuflevel", "-1",
+                                          "--stderrthreshold", "0", "--v", "1", "--cubemap_format", "video", "--side_flow_alg",
+                                          "pixflow_low", "--polar_flow_alg", "pixflow_low", "--poleremoval_flow_alg", "pixflow_low",
+                                          "--cubemap_width", "96", "--cubemap_height", "96", "--interpupilary_dist", "6.4",
+                                          "--zero_parallax_dist", "10000"]),
     "sharpen_cubemap_search": (["000000"], ["--enable_top", "--enable_bottom", "--sharpening", "0.25", "--side_flow_alg",
                                             "pixflow_search_20", "--cubemap_width", "96", "--cubemap_height", "96",
                                             "--cubemap_format", "video"]),
@@ -118,6 +123,8 @@ def run_case(exe, work, rig_path, name, timeout=900):
                "--final_eqr_height", str(FINAL)] + extra
         if "--cubemap_width" in extra:
             cmd += ["--output_cubemap_path", os.path.join(out, "cube_%s.png" % f)]
+        if "--logbuflevel" in extra:
+            cmd += ["--log_dir", os.path.join(out, "logs")]
         if mdir:
             cmd += ["--bottom_pole_masks_dir", mdir]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)

@@ -36,7 +36,7 @@ def emu_programs():
 @pytest.mark.parametrize("name", list(refprog.CASES))
 def test_emulated_program_writes_what_the_reference_program_writes(tmp_path, emu_programs, name):
     """Two chained frames; sharpening + cubemap + pixflow_search_20; three chained frames sharpened; pole removal: stereo equirects,
-    cubemap, 28 + 4 flows per frame, overlap / pole / pole-removal state images — 549 files over the four cases, digest for digest."""
+    cubemap, 28 + 4 flows per frame, overlap / pole / pole-removal state images — 551 files over the four cases, digest for digest."""
     rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
                                   refprog.CAM / 2048.0)
     out = refprog.run_case(os.path.join(emu_programs, "TestRenderStereoPanorama"), str(tmp_path), rig, name)
