@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 
 #include "../../include/s360.h"
@@ -17,6 +18,9 @@ static thread_local std::string g_err;
 
 template <typename F>
 static int guard(s360_ctx* c, F&& f) {
+  // thread-safe per context: concurrent callers of one context are serialised here
+  std::unique_lock<std::recursive_mutex> lk;
+  if (c) lk = std::unique_lock<std::recursive_mutex>(c->mu);
   try {
     if (c) c->make_current();
     f();
@@ -64,7 +68,14 @@ int s360_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-const char* s360_last_error(const s360_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char* s360_last_error(const s360_ctx* ctx) {
+  if (!ctx) return g_err.c_str();
+  // a copy per calling thread: another thread's failing call may replace ctx->err at any time
+  static thread_local std::string copy;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  copy = ctx->err;
+  return copy.c_str();
+}
 
 // ---- rig -------------------------------------------------------------------------------------
 int s360_rig_load_json(const char* path, s360_camera* cams, int max_cams) {
@@ -255,7 +266,7 @@ int s360_compute_optical_flow_batch(s360_ctx* c, const char* alg, int batch, con
                                     const uint8_t* prev_i1, int hint, float* flow_out) {
   return guard(c, [&] {
     need(c && alg && i0 && i1 && flow_out, "null argument");
-    need(w >= 50 && h >= 50, "image too small for the flow pyramid");
+    need(w >= 4 && h >= 4, "image too small: the reference's bilinear taps need a 2x2 image after the x0.5 entry downscale (PixFlow.h:457-475)");
     need(batch >= 1 && batch <= kMaxFlows, "batch out of range");
     need(hint >= 0 && hint <= 4, "bad direction hint");
     need(!prev_flow || (prev_i0 && prev_i1), "prev_flow given without previous images");
@@ -659,7 +670,10 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     S360_HIP(hipStreamWaitEvent(c->stDown, F.outDone[b], 0));
     S360_HIP(hipMemcpyAsync(out_bgr, F.outBGR[b].p, (size_t)c->g.out_width * c->g.out_height * 3, hipMemcpyDeviceToHost, c->stDown));
     S360_HIP(hipStreamSynchronize(c->stDown));
-    if (c->flow) { /* sweep time-outs of that frame are reported by the next synchronising call */ }
+    // the frame's sweep error words were snapshotted in front of outDone[b] (render.hpp): a timed-out banded sweep
+    // fails THIS frame's download, before the host hands the pixels to an encoder
+    if (F.outErr[b] && (F.outErr[b][0] | F.outErr[b][1] | F.outErr[b][2]))
+      throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
   });
 }
 

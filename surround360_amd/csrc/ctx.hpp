@@ -1,6 +1,7 @@
 // ctx.hpp — the s360_ctx object behind the C ABI: one per device.
 #pragma once
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,10 @@ struct FrameState;  // render.hip
 }
 
 struct s360_ctx {
+  // Every C-ABI entry point that takes a context holds this lock for its whole duration (api.hip `guard`): a context is
+  // safe to call from any number of host threads — the 14 std::threads of TRSP:320-335 may share one — and the calls
+  // execute one after the other in lock order. Recursive: batch entry points call the single-pair ones.
+  mutable std::recursive_mutex mu;
   int device = 0;
   hipStream_t st = nullptr;
   // Frame pipelining (s360_set_frame_pipelining): the pole stage / composite (frame_finish) runs on st2 so that it

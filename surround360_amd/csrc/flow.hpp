@@ -73,6 +73,8 @@ class FlowEngine {
   void set_sweep_mode(int m) { sweep_mode_ = (m == 3) ? 3 : 2; }
   // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag
   unsigned take_error(hipStream_t st);
+  // the device word behind take_error (nullptr before the first compute): frame_finish snapshots it per output buffer
+  const unsigned* error_word() const { return err_.as<unsigned>(); }
 
  private:
 };

@@ -431,7 +431,15 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
     Fs.push_back(&F);
   }
   ensure_maps(c);
-  if (n == 0) return;
+  if (n == 0) {
+    // a rank that owns no pair still takes part in the frame's stream protocol: the strips it is about to RECEIVE
+    // (frame_gather_strips on st) must wait for the previous frame's assemble_pano, and the events later stages and
+    // the next upload wait for must be recorded
+    if (c->evSideSrcFree) { S360_HIP(hipEventRecord(c->evSideSrcFree, st)); c->haveSideSrcFree = true; }
+    if (c->pipeline && c->haveStripsFree) S360_HIP(hipStreamWaitEvent(st, c->evStripsFree, 0));
+    if (c->pipeline) S360_HIP(hipEventRecord(c->evSideDone, st));
+    return;
+  }
   if (2 * n * (int)Fs.size() > kMaxFlows) throw Error(S360_ERR_INVALID_ARG, "too many flows for one batch");
   wait_for_uploads(c, st);
   // temporal state is used only if every slot of the batch has it (one FlowEngine batch = one setting)
@@ -782,6 +790,17 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
           eye = F.eyeFinal[e].as<uchar4>();
         }
         launch_pack_bgr(st, eye, outW, eyeH, F.outBGR[ob].as<uint8_t>() + (size_t)e * outW * eyeH * 3);
+      }
+      if (!F.outErr[ob]) {
+        S360_HIP(hipHostMalloc((void**)&F.outErr[ob], 4 * sizeof(unsigned), hipHostMallocDefault));
+        std::memset(F.outErr[ob], 0, 4 * sizeof(unsigned));
+      }
+      {
+        FlowEngine* eng[3] = {c->flow.get(), c->flow_pole.get(), c->flow_pr.get()};
+        for (int i = 0; i < 3; ++i) {
+          if (eng[i] && eng[i]->error_word())
+            S360_HIP(hipMemcpyAsync(&F.outErr[ob][i], eng[i]->error_word(), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        }
       }
       S360_HIP(hipEventRecord(F.outDone[ob], st));
       F.out_cur = ob;

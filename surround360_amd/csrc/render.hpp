@@ -44,9 +44,17 @@ struct FrameState {
   // kernels that fill outBGR[i].
   DevBuf outBGR[2];
   hipEvent_t outDone[2] = {nullptr, nullptr};
+  // pinned snapshot of the three flow engines' sweep error words, copied on the render stream just in front of
+  // outDone[i]: s360_frame_download_equirect_of refuses a frame whose sweeps timed out without waiting for the frame
+  // that renders behind it (the words are cumulative, so a non-zero value may also come from that next frame's side
+  // flows — either way the stream's results are invalid from here on)
+  unsigned* outErr[2] = {nullptr, nullptr};
   int out_cur = 0;           // buffer of the most recently ENQUEUED frame
   long long frames_done = 0;  // frames enqueued so far
-  ~FrameState() { for (auto& e : outDone) if (e) (void)hipEventDestroy(e); }
+  ~FrameState() {
+    for (auto& e : outDone) if (e) (void)hipEventDestroy(e);
+    for (auto& p : outErr) if (p) (void)hipHostFree(p);
+  }
   int cur_side = 0, cur_pole = 0, last_side = 0, last_pole = 0;
   bool have_prev_side = false, have_prev_pole = false;
   bool keep_intermediates = false;  // copy panoramas before the pole composite (parity tests)

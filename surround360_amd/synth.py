@@ -282,6 +282,10 @@ class RigRenderer:
         imgs = [self._camera(i, yaw_deg, disc_deg) for i in range(len(self.cams))]
         return [imgs[i] for i in self.side], imgs[self.top], imgs[self.bottom]
 
+    def frame_all_numpy(self, yaw_deg=0.0, disc_deg=None):
+        """Every camera of the rig in JSON order (pole removal needs the secondary bottom camera as well)."""
+        return [self._camera(i, yaw_deg, disc_deg).cpu().numpy() for i in range(len(self.cams))]
+
     def frame_numpy(self, yaw_deg=0.0, disc_deg=None):
         side, top, bottom = self.frame(yaw_deg, disc_deg)
         return [s.cpu().numpy() for s in side], top.cpu().numpy(), bottom.cpu().numpy()

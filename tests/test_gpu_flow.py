@@ -108,3 +108,46 @@ def test_ieee_division_path_bit_exact(gpu_rig, oracle, monkeypatch):
         assert np.array_equal(bits(got), bits(want))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("w,h", [(4, 4), (5, 7), (20, 49), (49, 60), (51, 33)])
+def test_flow_below_the_pyramid_threshold(ctx, oracle, w, h):
+    """Inputs whose x0.5 downscale is at or below kPyrMinImageSize = 24: buildPyramid (PixFlow.h:477-491) returns one
+    level and the reference still runs — so does the library (round 2 rejected anything below 50 px)."""
+    i0, i1 = synth.flow_pair(w, h, seed=100 * w + h)
+    for alg in ("pixflow_low", "pixflow_search_20"):
+        got = ctx.compute_optical_flow(i0, i1, alg, "LEFT")
+        want = oracle.compute_optical_flow(i0, i1, alg, "LEFT")
+        assert np.array_equal(bits(got), bits(want)), (alg, w, h)
+
+
+def test_fourteen_threads_share_one_context(ctx, oracle):
+    """TRSP:320-335 runs renderStereoPanoramaChunksThread on 14 std::threads, each with its own flow operator
+    (NovelView.cpp:281-298). INTEGRATION.md lets all of them call ONE s360_ctx: entry points lock the context
+    (SURVEY 8b "thread-safe per ctx"), so 14 concurrent callers with 14 different pairs — and different sizes, so that
+    the shared scratch buffers are re-sized under their feet if the lock were missing — all get the oracle's flow."""
+    import threading
+    sizes = [(160 + 8 * (k % 5), 176 + 6 * (k % 3)) for k in range(14)]
+    pairs = [synth.flow_pair(w, h, seed=700 + k) for k, (w, h) in enumerate(sizes)]
+    hints = ["LEFT", "RIGHT"]
+    got = [None] * 14
+    errors = []
+    start = threading.Barrier(14)
+
+    def work(k):
+        try:
+            start.wait()
+            for rep in range(2):  # two rounds: the second interleaves with other threads' first
+                got[k] = ctx.compute_optical_flow(pairs[k][0], pairs[k][1], "pixflow_low", hints[k % 2])
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(14)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(14):
+        want = oracle.compute_optical_flow(pairs[k][0], pairs[k][1], "pixflow_low", hints[k % 2])
+        assert np.array_equal(bits(got[k]), bits(want)), "thread %d" % k
