@@ -43,7 +43,7 @@ import numpy as np  # noqa: E402
 
 RIG = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
 FLAGS_8K = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192,
-                final_eqr_height=8192)  # the reference's "8k" preset, batch_process_video.py:194-199
+                final_eqr_height=8192, sharpening=0.25)  # the reference's "8k" preset, batch_process_video.py:194-199 (SHARPENNING = 0.25)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SWEEP_BYTES_PER_PX = 48  # a sweep reads 40 B + writes 8 B per pixel-level
 
@@ -124,7 +124,7 @@ def cpu_baseline_reference(side, top, bottom, rig_path=RIG, flags=None, timeout=
         os.makedirs(os.path.join(out, "flow", "000000"))
         eqr = os.path.join(out, "eqr.png")
         cmd = [REF_PROGRAM, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", "000000", "--output_data_dir", out,
-               "--prev_frame_data_dir", "NONE", "--output_equirect_path", eqr, "--sharpening", "0.0"]
+               "--prev_frame_data_dir", "NONE", "--output_equirect_path", eqr, "--sharpening", repr(float(flags.get("sharpening", 0.0)))]
         for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
             cmd += ["--" + k, str(flags[k])]
         cmd += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
@@ -151,7 +151,7 @@ def cpu_baseline_reference(side, top, bottom, rig_path=RIG, flags=None, timeout=
                      "host_cores_available": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
                      "sample": "the reference's own TestRenderStereoPanorama program (its sources compiled over stand-ins for "
                                "OpenCV / Eigen / folly / gflags / glog: oracle/_ref, -O2, no FMA) rendering ONE full 8K frame of "
-                               "the bench workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low) as one process: 17 PNG "
+                               "the bench workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low, sharpening as benched) as one process: 17 PNG "
                                "inputs decoded from disk, the program's own thread fan-out, equirect and per-frame state files "
                                "encoded to disk — what batch_process_video.py pays per frame; cores = peak threads it ran"}
     finally:
@@ -179,7 +179,8 @@ def main():
     ap.add_argument("--slots", type=int, default=12,
                     help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
                          "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
-    ap.add_argument("--video-frames", type=int, default=32)
+    ap.add_argument("--video-frames", type=int, default=190,
+                    help="frames of the configs[4] stream leg (SURVEY 8d: 190, steady state over frames 10-189)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # hardware queues for the in-flight frames (read at HIP init)
@@ -233,10 +234,27 @@ def main():
     # ---- synthetic stream: one seeded equirect world (noise + near objects at 2 m / 5 m), rendered
     # through the 17 rig cameras on the GPU; frame k = world rotated by 0.2 deg * k, one disc moving 0.5 deg per frame.
     # (The world is 8192x4096: the 16384x8192 of §8d needs 3 GB for the texture + depth alone; stated in `data`.)
-    n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 2)
+    n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 12)
+    # distinct frames kept in host memory for the stream leg: all of them if the host has room (17 x 12.6 MB each),
+    # otherwise a ring walked forwards and backwards (consecutive frames still differ by one step of motion)
+    frame_bytes = 17 * cam_size * cam_size * 3
+    n_distinct = n_video
+    try:
+        avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+        if 2.5 * n_video * frame_bytes + (60 << 30) > avail:
+            n_distinct = min(n_video, 48)
+    except Exception:  # noqa: BLE001
+        n_distinct = min(n_video, 48)
     wtex = synth.World(world_h, seed=360, device=dev)  # the same stream on every rank (the sharded frame needs identical inputs)
     rr = synth.RigRenderer(rig_path, wtex, cam_size)
-    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_video))]
+    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_distinct))]
+
+    def stream_frame(k):  # frame k of the stream: 0,1,..,n-1,n-2,..,1,0,1,.. over the distinct frames held
+        if n_distinct >= n_video:
+            return frames[k]
+        period = 2 * (n_distinct - 1)
+        m = k % period
+        return frames[m if m < n_distinct else period - m]
     del rr, wtex
     torch.cuda.empty_cache()
 
@@ -328,6 +346,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     enqueue_ms_per_frame = 1e3 * sum(enqueue_s) / max(args.steps * S, 1)
+    # ---- the same region once more without the sharpening pass (SURVEY 8d asks for both; FLAGS_sharpening is a run-time
+    # flag): fewer steps, same contexts, same frames. Secondary figure, never `value`.
+    steps0 = max(2 * F, min(args.steps, 8))
+    for c in ctxs:
+        c.set_sharpening(0.0)
+    for _ in range(F):
+        step()
+    drain()
+    t0s = time.perf_counter()
+    for _ in range(steps0):
+        step()
+    drain()
+    dt0 = time.perf_counter() - t0s
+    if dist is not None:
+        t = torch.tensor([dt0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt0 = float(t.item())
+    for c in ctxs:
+        c.set_sharpening(flags["sharpening"])
+    for _ in range(F):  # the frames checked below are the sharpened ones again
+        step()
+    drain()
     # Per-kernel-family breakdown: one more step per context with the same contexts in flight, untimed, with the
     # library's per-family HIP events switched on (two event records per family scope perturb the launch stream,
     # which is why the timed steps above run without them).
@@ -476,12 +516,16 @@ def main():
         "data": "synthetic (seeded 8192x4096 equirect world through the 17-camera rig, 2048x2048 inputs; every in-flight "
                 "context holds a different frame of the stream)",
         "config": {"workload": "BASELINE configs[2]: full 17-cam synthetic frame (2048x2048 inputs), eqr 8400x4096 -> stereo "
-                               "8192x8192, top+bottom poles, pixflow_low, sharpening 0",
+                               "8192x8192, top+bottom poles, pixflow_low, sharpening 0.25 (the reference's 8k preset, "
+                               "batch_process_video.py:194-199)",
                    "parallelism": "independent frames: each of %d GPU(s) renders whole frames, %d in flight per GPU "
                                   "(one context + HIP stream each), no data-path collective" % (world, F),
                    "frames_in_flight": F * S, "contexts": F, "slots_per_context": S, "frames_per_step": S,
                    "rccl_ranks": world},
         "roofline": roofline,
+        "without_sharpening": {"value": world * steps0 * S / dt0, "unit": "frames/s", "steps": steps0,
+                               "ms_per_step": 1e3 * dt0 / steps0,
+                               "note": "the same contexts and frames with --sharpening 0 (SURVEY 8d: both figures)"},
         "kernel_ms_per_frame_in_flight": {k: round(v[0] / (prof_steps * S), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         "host": {"submit_threads": F, "enqueue_ms_per_frame": enqueue_ms_per_frame,
                  "settle_batches_before_warmup": settle["batches"], "settle_seconds": round(settle["seconds"], 2)},
@@ -584,24 +628,24 @@ def main():
                 "equals_single_gpu_frame": ok}
 
         if world == 1 and not args.no_extras:
-            # ---- the reference presets' sharpening 0.25 (batch_process_video.py:176-199) ----
-            cs = R.Context(rig, R.make_params(sharpening=0.25, **flags), device=local_rank)
-            cs.upload_frame(*frames[0])
-            cs.render(False)
-            cs.synchronize()
+            # ---- the same single frame without the sharpening pass (secondary; the presets all sharpen) ----
+            ctx.set_sharpening(0.0)
+            ctx.render(False)
+            sync(barrier=False)
             t1 = time.perf_counter()
             for _ in range(3):
-                cs.render(False)
-            cs.synchronize()
+                ctx.render(False)
+            sync(barrier=False)
             ms = 1e3 * (time.perf_counter() - t1) / 3
-            cs.profile_enable(True)
+            ctx.profile_enable(True)
             for _ in range(3):
-                cs.render(False)
-            cs.synchronize()
-            pr = cs.profile_get()
-            cs.close()
-            out["single_frame"]["with_sharpening_0.25"] = {"ms": ms, "finish_ms": pr.get("finish", (0, 0))[0] / 3,
-                                                           "finish_ms_without": out["single_frame"]["kernel_ms_per_frame"].get("finish")}
+                ctx.render(False)
+            sync(barrier=False)
+            pr = ctx.profile_get()
+            ctx.profile_enable(False)
+            ctx.set_sharpening(flags["sharpening"])
+            out["single_frame"]["without_sharpening"] = {"ms": ms, "finish_ms": pr.get("finish", (0, 0))[0] / 3,
+                                                         "finish_ms_with": out["single_frame"]["kernel_ms_per_frame"].get("finish")}
 
             # ---- BASELINE configs[1]: one 2048x2048 pair, both directions (TestOpticalFlow.cpp:50-143) ----
             i0, i1 = synth.flow_pair(pair_size, pair_size, seed=360)
@@ -628,32 +672,72 @@ def main():
                                      np.array_equal(gr.view(np.uint32), wr.view(np.uint32)))
             out["config2_flow_pair"] = c2
 
-            # ---- BASELINE configs[4] on one GPU: one video stream, distinct frames, temporal regularisation ----
-            def stream(pipelined):
+            # ---- BASELINE configs[4] on one GPU: one video stream of 190 frames (Building-20 shape),
+            # temporal regularisation, steady state over frames 10..N-1, the finished frame fetched while the next renders ----
+            def stream(pipelined, n_frames, fetch):
                 ctx.set_frame_pipelining(pipelined)
-                ctx.upload_frame(*frames[0])
-                ctx.render(False)
-                ctx.upload_frame(*frames[1])
-                ctx.render(True)
-                sync(barrier=False)
+                eq = np.empty((g.out_height, g.out_width, 3), np.uint8) if fetch else None
+                lead = min(10, n_frames - 2)
                 up = 0.0
-                t2 = time.perf_counter()
-                for k in range(2, n_video):
+                t2 = None
+                for k in range(n_frames):
+                    if k == lead:  # frames 0..lead-1 are the run-in (the first has no temporal state, buffers are sized)
+                        sync(barrier=False)
+                        up = 0.0
+                        t2 = time.perf_counter()
                     tu = time.perf_counter()
-                    ctx.upload_frame(*frames[k])  # host memory -> pinned ring -> upload stream; overlaps frame k-1
+                    ctx.upload_frame(*stream_frame(k))  # host memory -> pinned ring -> upload stream; overlaps frame k-1
                     up += time.perf_counter() - tu
-                    ctx.render(True)
+                    ctx.render(k > 0)
+                    if fetch and k > 0:  # what host/TestRenderStereoPanorama --num_frames does: frame k-1 comes back while k renders
+                        eq = ctx.download_equirect_of(1)
+                if fetch:
+                    eq = ctx.download_equirect()
                 sync(barrier=False)
-                ms = 1e3 * (time.perf_counter() - t2) / (n_video - 2)
+                n = n_frames - lead
+                ms = 1e3 * (time.perf_counter() - t2) / n
                 ctx.set_frame_pipelining(False)
-                return {"frames": n_video - 2, "ms_per_frame": ms, "frames_per_s": 1e3 / ms,
-                        "host_upload_ms_per_frame": 1e3 * up / (n_video - 2)}
+                return {"frames": n_frames, "steady_state_frames": n, "ms_per_frame": ms, "frames_per_s": 1e3 / ms,
+                        "host_upload_ms_per_frame": 1e3 * up / n, "equirect_fetched_per_frame": bool(fetch)}, eq
             ctx.set_sweep_mode("latency")
-            video = {"mode": "one stream of %d distinct frames (world rotating 0.2 deg/frame, one moving disc); frame k regularised "
-                             "toward frame k-1's device-resident flows and images; inputs uploaded from host memory while the "
-                             "previous frame renders" % n_video}
-            video.update(stream(False))
-            video["pipelined"] = stream(True)
+            video = {"mode": "one stream of %d frames (%d distinct in host memory%s; world rotating 0.2 deg/frame, one moving disc); "
+                             "frame k regularised toward frame k-1's device-resident flows and images; inputs uploaded from host "
+                             "memory while the previous frame renders; sharpening 0.25; steady state = frames 10..%d" % (
+                                 n_video, n_distinct, "" if n_distinct >= n_video else ", walked forwards and backwards",
+                                 n_video - 1)}
+            unp, _ = stream(False, min(n_video, 40), False)
+            video["unpipelined"] = unp
+            pip, last_eq = stream(True, n_video, True)
+            video.update(pip)
+            # the per-frame state spill (.bin flows + flow_images of TRSP:201-255, 413-452): a stream keeps that state on the
+            # device; writing it for every frame like the reference costs one download + write of 32 flows and 36 images
+            try:
+                import shutil
+                import tempfile
+                tmpd = tempfile.mkdtemp(prefix="s360_spill_")
+                t1 = time.perf_counter()
+                fl = [ctx.get_f32(nm, i) for nm in ("flow_l_to_r", "flow_r_to_l") for i in range(P)]
+                fl += [ctx.get_f32("flow_pole", u) for u in range(4)]
+                im = [ctx.get_u8(nm, i) for nm in ("overlap_l", "overlap_r") for i in range(P)]
+                im += [ctx.get_u8(nm, u) for nm in ("extended_side", "extended_fisheye") for u in range(4)]
+                t_dl = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                for i, f in enumerate(fl):
+                    R.save_flow_to_file(f, os.path.join(tmpd, "flow_%d.bin" % i))
+                t_wr = time.perf_counter() - t1
+                nbytes = sum(f.nbytes for f in fl)
+                shutil.rmtree(tmpd, ignore_errors=True)
+                video["spill_ms_per_frame"] = round(1e3 * (t_dl + t_wr), 1)
+                video["spill"] = {"download_ms": round(1e3 * t_dl, 1), "bin_write_ms": round(1e3 * t_wr, 1),
+                                  "flow_bytes": nbytes, "image_bytes": sum(i.nbytes for i in im),
+                                  "note": "one frame's temporal state fetched to host memory (28 side + 4 pole flows, 28 overlap + 8 "
+                                          "extended pole images) and the 32 flows written as the reference's .bin files to a temporary "
+                                          "directory; PNG encoding of the state images not included. The stream above does not pay "
+                                          "this: its state stays on the device (host/TestRenderStereoPanorama --num_frames writes it "
+                                          "after the last frame only)"}
+                del fl, im
+            except Exception as e:  # noqa: BLE001
+                video["spill"] = {"error": repr(e)}
             out["video_stream"] = video
 
             if not args.no_cpu_baseline:
@@ -682,40 +766,6 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["isp"] = {"error": repr(e)}
 
-            # ---- kernel variants behind run-time switches that have not been timed on hardware yet: the same 8K frame
-            # alone, latency sweep kernel, one process per variant (tools/variant_time.py); informative only ----
-            # (this process's contexts are released first: a 12-slot batch needs ~100 GB of its own)
-            for c in ctxs:
-                c.close()
-            torch.cuda.empty_cache()
-            variants = [("latency", "default", {}, 1), ("latency", "S360_LOCK_PEEL=1", {"S360_LOCK_PEEL": "1"}, 1),
-                        ("throughput", "default", {}, S), ("throughput", "S360_QUAD_PEEL=2", {"S360_QUAD_PEEL": "2"}, S),
-                        ("throughput", "S360_QUAD_PEEL=1", {"S360_QUAD_PEEL": "1"}, S),
-                        ("throughput", "S360_SWEEP_TRI=2", {"S360_SWEEP_TRI": "2"}, S),
-                        ("throughput", "S360_SWEEP_TRI=1", {"S360_SWEEP_TRI": "1"}, S),
-                        ("latency", "S360_LOCK_NW=2", {"S360_LOCK_NW": "2"}, 1),
-                        ("latency", "S360_LOCK_NW=8", {"S360_LOCK_NW": "8"}, 1),
-                        ("latency", "S360_LOCK_NW=2 S360_LOCK_PEEL=1", {"S360_LOCK_NW": "2", "S360_LOCK_PEEL": "1"}, 1)]
-            ab = {"latency": {}, "throughput": {}}
-            # informative, so bounded: no new run once the whole bench has been going for 6 minutes
-            for group, name, env, slots in variants:
-                if time.perf_counter() - t_process > 360.0:
-                    ab[group][name] = {"skipped": "the bench's time budget was spent"}
-                    continue
-                try:
-                    import subprocess
-                    e = dict(os.environ)
-                    e.update(env)
-                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variant_time.py"), "--json", "--device",
-                                        str(local_rank), "--slots", str(slots)], capture_output=True, text=True, timeout=100, env=e)
-                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                    ab[group][name] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
-                except Exception as ex:  # noqa: BLE001
-                    ab[group][name] = {"error": repr(ex)}
-            for group in ("latency", "throughput"):
-                shas = {v.get("sha1") for v in ab[group].values() if "sha1" in v}
-                ab[group]["identical_output"] = len(shas) == 1 if shas else None
-            out["variants"] = ab
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         import traceback
         bail("post-timed-region phase failed: %r %s" % (e, traceback.format_exc()[-600:]))

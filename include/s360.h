@@ -122,6 +122,9 @@ int s360_get_geometry(const s360_ctx* ctx, s360_geometry* out);
 /* The HIP stream all of this context's work is enqueued on (hipStream_t as void*). */
 void* s360_stream(s360_ctx* ctx);
 int s360_synchronize(s360_ctx* ctx);
+/* FLAGS_sharpening (TRSP:56, read at TRSP:901) is an ordinary run-time flag of the reference: the frames rendered after
+ * this call are sharpened by `sharpening` (0 = off) instead of s360_params.sharpening. */
+int s360_set_sharpening(s360_ctx* ctx, double sharpening);
 
 /* ---- operator level (host pointers in/out; each call uploads, runs on the GPU, downloads) --- */
 /* OpticalFlowInterface::computeOpticalFlow via makeOpticalFlowByName(alg)

@@ -67,7 +67,7 @@ SYMBOLS = [
     "s360_version", "s360_device_count", "s360_last_error", "s360_rig_load_json", "s360_camera_init",
     "s360_camera_pixel", "s360_camera_get_fov", "s360_rig_find_top", "s360_rig_find_bottom", "s360_rig_find_bottom2", "s360_camera_usable_pixels_radius", "s360_derive_geometry",
     "s360_pole_ramp", "s360_create",
-    "s360_destroy", "s360_get_geometry", "s360_stream", "s360_synchronize", "s360_compute_optical_flow",
+    "s360_destroy", "s360_get_geometry", "s360_stream", "s360_synchronize", "s360_set_sharpening", "s360_compute_optical_flow",
     "s360_compute_optical_flow_batch", "s360_bicubic_remap_to_spherical", "s360_spherical_warp_map",
     "s360_combine_lazy_novel_views", "s360_flatten_layers_deghost_prefer_base", "s360_offset_horizontal_wrap",
     "s360_feather_alpha_channel", "s360_pole_to_side_flow", "s360_sharpen", "s360_frame_upload_side",

@@ -256,6 +256,12 @@ int s360_set_frame_pipelining(s360_ctx* c, int on) {
     c->haveStripsFree = false;
   });
 }
+int s360_set_sharpening(s360_ctx* c, double sharpening) {
+  return guard(c, [&] {
+    need(c && sharpening >= 0.0, "bad argument");
+    c->P.sharpening = sharpening;  // read by the next frame_finish (TRSP:901-915)
+  });
+}
 int s360_set_keep_intermediates(s360_ctx* c, int on) {
   return guard(c, [&] { need(c, "null ctx"); frame_state(c).keep_intermediates = on != 0; });
 }

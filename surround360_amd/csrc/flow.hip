@@ -227,14 +227,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
-      static const bool tri = [] {  // S360_SWEEP_TRI=1: the three-lanes-per-pixel build of the throughput sweep (sweep_tri.hip)
-        const char* e = std::getenv("S360_SWEEP_TRI");
-        return e && (e[0] == '1' || e[0] == '2');
-      }();
-      if (sweep_mode_ == 3 && tri)  // (its hand-off arena is never larger than the quad kernel's: fewer, taller bands)
-        launch_sweep_tri(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
-                         fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
-      else if (sweep_mode_ == 3)
+      if (sweep_mode_ == 3)
         launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
       else

@@ -65,11 +65,6 @@ size_t sweep_quad_handoff_bytes(int w, int h, int B);
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast, const unsigned* rowflags = nullptr);
-// the same with three lanes per pixel and 20 rows per wave (sweep_tri.hip; experiment behind S360_SWEEP_TRI=1)
-size_t sweep_tri_handoff_bytes(int w, int h, int B);
-void launch_sweep_tri(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff, unsigned* errflag,
-                      int w, int h, size_t bs, int B, const FlowIdx& idx, int dir, const PixFlowConsts& pc, bool fast,
-                      const unsigned* rowflags = nullptr);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_verify_div(const float* __restrict__ cs
   if (x / cc != fdiv_m(x, cc, rc) || (-x) / cc != fdiv_m(-x, cc, rc)) atomicOr(bad + blockIdx.y, 1u);
 }
 
-template <int NW, bool FAST, bool PEEL>
+template <int NW, bool FAST>
 __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __restrict__ rec,
                                                               const float2* __restrict__ G, float2* __restrict__ flow,
                                                               unsigned long long* __restrict__ H,
@@ -154,282 +154,152 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     // One iteration = one step. The barrier sits in the shadow of the bilinear gathers: everything a step needs
     // from other waves was read from LDS one iteration earlier (after that iteration's barrier), so the wave
     // starts its dependent chain without waiting for anybody.
-    if constexpr (!PEEL) {
-      for (int t = -1; t < T; ++t) {
-        TS(0);
-        const int s = t - kLag * j;
-        const bool run = s >= 0 && s < nsteps && !S360_DBG(fc, 16);
-        const LkIn in = nin;
-        const float2 upl = nup;
-        const int xi = s - rr;
-        const bool active = rowValid && xi >= 0 && xi < w;
-        const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
-        const float4 rc = in.rec;
-        const float2 fo = in.flow;
-        const bool upd = rc.x == rc.x;
-        // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403). When none of the wave's 4 pixels is
-        // updated at this step (the upper ~60 % of the pole flows, which the side cameras do not cover) the gathers
-        // and the evaluation are skipped; workgroups made of such rows run at the speed of the empty iteration.
-        const bool take = active && upd;
-        const bool any = run && __ballot(take) != 0ull;
-        // (deliberately not initialised: set and read only on the `any` path; zero-filling them cost 14 moves per step)
-        float2 up;
-        float ax, ay, xR, yR;
-        f4a8 ta, tb;
-        if (any) {
-          // up neighbour in every lane (needed by the selection below)
-          up.x = from_row_above<0xF>(upl.x, fl.x);
-          up.y = from_row_above<0xF>(upl.y, fl.y);
-          // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
-          float2 cand;
-          cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
-          cand.y = fromLds ? (bank == 0 ? fo.y : upl.y) : fl.y;
-          cand.x = from_row_above<0x4>(cand.x, fl.x);
-          cand.y = from_row_above<0x4>(cand.y, fl.y);
-          ax = cand.x + ox;
-          ay = cand.y + oy;
-          // Every lane evaluates (idle lanes and masked pixels produce values nobody reads; addresses are clamped).
-          // getPixBilinear32FExtend's clamp (PixFlow.h:457-464): max(0, .) then min(., size-2) == med3 here; the
-          // operands are non-negative, so (int) truncation == floor and x - float(int(x)) == fract(x) exactly.
-          const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
-          const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
-          const int x0 = (int)mx, y0 = (int)my;
-          xR = __builtin_amdgcn_fractf(mx);
-          yR = __builtin_amdgcn_fractf(my);
-          const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
-          if (!S360_DBG(fc, 64)) {  // (timing experiment: 64 = no gathers)
-            ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
-            tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
-          } else {
-            ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
-          }
-        }
-        TS(1);
-        wg_barrier();
-        TS(2);
-        // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
-        // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.
-        const int s1 = s + 1;
-        if (s1 >= 0 && s1 < nsteps) {
-          nin = s_in[j][s1 & (kRingK - 1)][rr];
-          nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
-        }
-#ifdef S360_SWEEP_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        TS(6);
-#endif
-        if (!run) continue;
-        if (!any) {
-          const float2 keep = active ? fo : fl;
-          fl = keep;
-          if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = keep;
-          continue;
-        }
-        TS_WAITV();
-        TS(3);
-        Texels tt;
-        tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
-        tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-        float e;
-        if (FAST) {
-          bool tiny;
-          e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
-          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
-            Foot ft;
-            ft.off = 0; ft.xR = xR; ft.yR = yR;
-            e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
-          }
+    // STEADY: the steps at which all four rows of the wave are inside the image with a left neighbour
+    // (local steps 4 .. w-1). There the range tests, the first-column case and the per-wave choice of the LDS source
+    // of the up value are compile-time facts; the same code, ~40 instructions per step shorter.
+    const float2* upBase = j == 0 ? &s_up0[0] : &s_out[j > 0 ? j - 1 : 0][0][3];
+    const int upStride = j == 0 ? 1 : 4, upShift = j == 0 ? 0 : 3;
+    const int xLane = dir > 0 ? -rr : w - 1 + rr, xSign = dir > 0 ? 1 : -1;
+    auto step = [&](auto steady, int t) {
+      constexpr bool ST = decltype(steady)::value;
+      TS(0);
+      const int s = t - kLag * j;
+      const bool run = ST || (s >= 0 && s < nsteps && !S360_DBG(fc, 16));
+      const LkIn in = nin;
+      const float2 upl = nup;
+      const int xi = s - rr;
+      const bool active = ST ? rowValid : (rowValid && xi >= 0 && xi < w);
+      const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);  // unclamped: out-of-range columns are inactive, their gathers are clamped
+      const float4 rc = in.rec;
+      const float2 fo = in.flow;
+      const bool upd = rc.x == rc.x;
+      // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403). When none of the wave's 4 pixels is
+      // updated at this step (the upper ~60 % of the pole flows, which the side cameras do not cover) the gathers
+      // and the evaluation are skipped; workgroups made of such rows run at the speed of the empty iteration.
+      const bool take = active && upd;
+      const bool any = run && __ballot(take) != 0ull;
+      // (deliberately not initialised: set and read only on the `any` path; zero-filling them cost 14 moves per step)
+      float2 up;
+      float ax, ay, xR, yR;
+      f4a8 ta, tb;
+      if (any) {
+        // up neighbour in every lane (needed by the selection below)
+        up.x = from_row_above<0xF>(upl.x, fl.x);
+        up.y = from_row_above<0xF>(upl.y, fl.y);
+        // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
+        float2 cand;
+        cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
+        cand.y = fromLds ? (bank == 0 ? fo.y : upl.y) : fl.y;
+        cand.x = from_row_above<0x4>(cand.x, fl.x);
+        cand.y = from_row_above<0x4>(cand.y, fl.y);
+        ax = cand.x + ox;
+        ay = cand.y + oy;
+        // Every lane evaluates (idle lanes and masked pixels produce values nobody reads; addresses are clamped).
+        // getPixBilinear32FExtend's clamp (PixFlow.h:457-464): max(0, .) then min(., size-2) == med3 here; the
+        // operands are non-negative, so (int) truncation == floor and x - float(int(x)) == fract(x) exactly.
+        const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
+        const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
+        const int x0 = (int)mx, y0 = (int)my;
+        xR = __builtin_amdgcn_fractf(mx);
+        yR = __builtin_amdgcn_fractf(my);
+        const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+        if (!S360_DBG(fc, 64)) {  // (timing experiment: 64 = no gathers)
+          ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
+          tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
         } else {
+          ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
+        }
+      }
+      TS(1);
+      wg_barrier();
+      TS(2);
+      // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
+      // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.
+      const int s1 = s + 1;
+      if (ST) {
+        nin = s_in[j][s1 & (kRingK - 1)][rr];
+        nup = upBase[((s1 + upShift) & (kRingK - 1)) * upStride];
+      } else if (s1 >= 0 && s1 < nsteps) {
+        nin = s_in[j][s1 & (kRingK - 1)][rr];
+        nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
+      }
+#ifdef S360_SWEEP_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TS(6);
+#endif
+      if (!run) return;
+      if (!any) {
+        const float2 keep = active ? fo : fl;
+        fl = keep;
+        if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = keep;
+        return;
+      }
+      TS_WAITV();
+      TS(3);
+      Texels tt;
+      tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+      tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+      float e;
+      if (FAST) {
+        bool tiny;
+        e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
           Foot ft;
           ft.off = 0; ft.xR = xR; ft.yR = yR;
           e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
         }
-        TS(4);
-        const float e0 = row_bcast<0>(e), e0x = row_bcast<1>(e), e0y = row_bcast<2>(e);
-        float e1 = row_bcast<4>(e);
-        const float e1x = row_bcast<5>(e), e1y = row_bcast<6>(e);
-        float e2 = row_bcast<8>(e);
-        const float e2x = row_bcast<9>(e), e2y = row_bcast<10>(e);
-        if (!(xi > 0)) e1 = kInf;  // no left proposal in the first column (PixFlow.h:392 / :405)
-        if (!hasUp) e2 = kInf;     // no up proposal in the first row (:393 / :406)
-        // proposeFlowUpdate x2 in the reference's order, then the gradient step on the winner
-        float2 f = fo;
-        float cur = e0, ex = e0x, ey = e0y;
-        if (e1 < cur) { f = fl; cur = e1; ex = e1x; ey = e1y; }
-        if (e2 < cur) { f = up; cur = e2; ex = e2x; ey = e2y; }
-        const float nx = ex - cur, ny = ey - cur;
-        float ggx, ggy;
-        if (FAST) {
-          ggx = fdiv_m(nx, kEps, fc.rcEps);
-          ggy = fdiv_m(ny, kEps, fc.rcEps);
-          const bool tiny = min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
-          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
-            ggx = nx / kEps;
-            ggy = ny / kEps;
-          }
-        } else {
+      } else {
+        Foot ft;
+        ft.off = 0; ft.xR = xR; ft.yR = yR;
+        e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
+      }
+      TS(4);
+      const float e0 = row_bcast<0>(e), e0x = row_bcast<1>(e), e0y = row_bcast<2>(e);
+      float e1 = row_bcast<4>(e);
+      const float e1x = row_bcast<5>(e), e1y = row_bcast<6>(e);
+      float e2 = row_bcast<8>(e);
+      const float e2x = row_bcast<9>(e), e2y = row_bcast<10>(e);
+      if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column (PixFlow.h:392 / :405)
+      if (!hasUp) e2 = kInf;            // no up proposal in the first row (:393 / :406)
+      // proposeFlowUpdate x2 in the reference's order, then the gradient step on the winner
+      float2 f = fo;
+      float cur = e0, ex = e0x, ey = e0y;
+      if (e1 < cur) { f = fl; cur = e1; ex = e1x; ey = e1y; }
+      if (e2 < cur) { f = up; cur = e2; ex = e2x; ey = e2y; }
+      const float nx = ex - cur, ny = ey - cur;
+      float ggx, ggy;
+      if (FAST) {
+        ggx = fdiv_m(nx, kEps, fc.rcEps);
+        ggy = fdiv_m(ny, kEps, fc.rcEps);
+        const bool tiny = min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
           ggx = nx / kEps;
           ggy = ny / kEps;
         }
-        float2 res;
-        res.x = f.x - c.gradStep * ggx;
-        res.y = f.y - c.gradStep * ggy;
-        // not-updated pixels keep their flow; inactive lanes keep the previous result
-        const float2 alt = active ? fo : fl;
-        res.x = take ? res.x : alt.x;
-        res.y = take ? res.y : alt.y;
-        fl = res;
-        if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
-        TS(5);
+      } else {
+        ggx = nx / kEps;
+        ggy = ny / kEps;
       }
-    } else {
-      // STEADY (PEEL builds): the steps at which all four rows of the wave are inside the image with a left neighbour
-      // (local steps 4 .. w-1). There the range tests, the first-column case and the per-wave choice of the LDS source
-      // of the up value are compile-time facts; the same code, ~40 instructions per step shorter.
-      const float2* upBase = j == 0 ? &s_up0[0] : &s_out[j > 0 ? j - 1 : 0][0][3];
-      const int upStride = j == 0 ? 1 : 4, upShift = j == 0 ? 0 : 3;
-      const int xLane = dir > 0 ? -rr : w - 1 + rr, xSign = dir > 0 ? 1 : -1;
-      auto step = [&](auto steady, int t) {
-        constexpr bool ST = decltype(steady)::value;
-        TS(0);
-        const int s = t - kLag * j;
-        const bool run = ST || (s >= 0 && s < nsteps && !S360_DBG(fc, 16));
-        const LkIn in = nin;
-        const float2 upl = nup;
-        const int xi = s - rr;
-        const bool active = ST ? rowValid : (rowValid && xi >= 0 && xi < w);
-        const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);  // unclamped: out-of-range columns are inactive, their gathers are clamped
-        const float4 rc = in.rec;
-        const float2 fo = in.flow;
-        const bool upd = rc.x == rc.x;
-        // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403). When none of the wave's 4 pixels is
-        // updated at this step (the upper ~60 % of the pole flows, which the side cameras do not cover) the gathers
-        // and the evaluation are skipped; workgroups made of such rows run at the speed of the empty iteration.
-        const bool take = active && upd;
-        const bool any = run && __ballot(take) != 0ull;
-        // (deliberately not initialised: set and read only on the `any` path; zero-filling them cost 14 moves per step)
-        float2 up;
-        float ax, ay, xR, yR;
-        f4a8 ta, tb;
-        if (any) {
-          // up neighbour in every lane (needed by the selection below)
-          up.x = from_row_above<0xF>(upl.x, fl.x);
-          up.y = from_row_above<0xF>(upl.y, fl.y);
-          // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
-          float2 cand;
-          cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
-          cand.y = fromLds ? (bank == 0 ? fo.y : upl.y) : fl.y;
-          cand.x = from_row_above<0x4>(cand.x, fl.x);
-          cand.y = from_row_above<0x4>(cand.y, fl.y);
-          ax = cand.x + ox;
-          ay = cand.y + oy;
-          // Every lane evaluates (idle lanes and masked pixels produce values nobody reads; addresses are clamped).
-          // getPixBilinear32FExtend's clamp (PixFlow.h:457-464): max(0, .) then min(., size-2) == med3 here; the
-          // operands are non-negative, so (int) truncation == floor and x - float(int(x)) == fract(x) exactly.
-          const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
-          const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
-          const int x0 = (int)mx, y0 = (int)my;
-          xR = __builtin_amdgcn_fractf(mx);
-          yR = __builtin_amdgcn_fractf(my);
-          const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
-          if (!S360_DBG(fc, 64)) {  // (timing experiment: 64 = no gathers)
-            ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
-            tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
-          } else {
-            ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
-          }
-        }
-        TS(1);
-        wg_barrier();
-        TS(2);
-        // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
-        // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.
-        const int s1 = s + 1;
-        if (ST) {
-          nin = s_in[j][s1 & (kRingK - 1)][rr];
-          nup = upBase[((s1 + upShift) & (kRingK - 1)) * upStride];
-        } else if (s1 >= 0 && s1 < nsteps) {
-          nin = s_in[j][s1 & (kRingK - 1)][rr];
-          nup = (j == 0) ? s_up0[s1 & (kRingK - 1)] : s_out[j > 0 ? j - 1 : 0][(s1 + 3) & (kRingK - 1)][3];
-        }
-#ifdef S360_SWEEP_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        TS(6);
-#endif
-        if (!run) return;
-        if (!any) {
-          const float2 keep = active ? fo : fl;
-          fl = keep;
-          if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = keep;
-          return;
-        }
-        TS_WAITV();
-        TS(3);
-        Texels tt;
-        tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
-        tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-        float e;
-        if (FAST) {
-          bool tiny;
-          e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
-          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
-            Foot ft;
-            ft.off = 0; ft.xR = xR; ft.yR = yR;
-            e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
-          }
-        } else {
-          Foot ft;
-          ft.off = 0; ft.xR = xR; ft.yR = yR;
-          e = error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
-        }
-        TS(4);
-        const float e0 = row_bcast<0>(e), e0x = row_bcast<1>(e), e0y = row_bcast<2>(e);
-        float e1 = row_bcast<4>(e);
-        const float e1x = row_bcast<5>(e), e1y = row_bcast<6>(e);
-        float e2 = row_bcast<8>(e);
-        const float e2x = row_bcast<9>(e), e2y = row_bcast<10>(e);
-        if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column (PixFlow.h:392 / :405)
-        if (!hasUp) e2 = kInf;            // no up proposal in the first row (:393 / :406)
-        // proposeFlowUpdate x2 in the reference's order, then the gradient step on the winner
-        float2 f = fo;
-        float cur = e0, ex = e0x, ey = e0y;
-        if (e1 < cur) { f = fl; cur = e1; ex = e1x; ey = e1y; }
-        if (e2 < cur) { f = up; cur = e2; ex = e2x; ey = e2y; }
-        const float nx = ex - cur, ny = ey - cur;
-        float ggx, ggy;
-        if (FAST) {
-          ggx = fdiv_m(nx, kEps, fc.rcEps);
-          ggy = fdiv_m(ny, kEps, fc.rcEps);
-          const bool tiny = min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
-          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
-            ggx = nx / kEps;
-            ggy = ny / kEps;
-          }
-        } else {
-          ggx = nx / kEps;
-          ggy = ny / kEps;
-        }
-        float2 res;
-        res.x = f.x - c.gradStep * ggx;
-        res.y = f.y - c.gradStep * ggy;
-        // not-updated pixels keep their flow; inactive lanes keep the previous result
-        const float2 alt = active ? fo : fl;
-        res.x = take ? res.x : alt.x;
-        res.y = take ? res.y : alt.y;
-        fl = res;
-        if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
-        TS(5);
-      };
-      const int tA = min(max(kLag * j + 4, -1), T), tB = min(max(kLag * j + w, tA), T);  // steady: local steps [4, w)
-      for (int t = -1; t < tA; ++t) step(std::false_type{}, t);
-      int t2 = tA;
-      for (; t2 + 1 < tB; t2 += 2) {
-        step(std::true_type{}, t2);
-        step(std::true_type{}, t2 + 1);
-      }
-      if (t2 < tB) step(std::true_type{}, t2);
-      for (int t = tB; t < T; ++t) step(std::false_type{}, t);
+      float2 res;
+      res.x = f.x - c.gradStep * ggx;
+      res.y = f.y - c.gradStep * ggy;
+      // not-updated pixels keep their flow; inactive lanes keep the previous result
+      const float2 alt = active ? fo : fl;
+      res.x = take ? res.x : alt.x;
+      res.y = take ? res.y : alt.y;
+      fl = res;
+      if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
+      TS(5);
+    };
+    const int tA = min(max(kLag * j + 4, -1), T), tB = min(max(kLag * j + w, tA), T);  // steady: local steps [4, w)
+    for (int t = -1; t < tA; ++t) step(std::false_type{}, t);
+    int t2 = tA;
+    for (; t2 + 1 < tB; t2 += 2) {
+      step(std::true_type{}, t2);
+      step(std::true_type{}, t2 + 1);
     }
+    if (t2 < tB) step(std::true_type{}, t2);
+    for (int t = tB; t < T; ++t) step(std::false_type{}, t);
     TS_DUMP();
     wg_barrier();
     return;
@@ -711,30 +581,23 @@ bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& cs) {
   return true;
 }
 
-template <int NW, bool FAST, bool PEEL>
+template <int NW, bool FAST>
 static void launch_lock_t(hipStream_t st, const float4* rec, const float2* G, float2* flow, unsigned long long* H,
                           unsigned* hdr, unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                           const SweepConst& c, const SweepFast& fc, int nwg) {
-  hipLaunchKernelGGL((k_sweep_lock<NW, FAST, PEEL>), dim3(nwg * B), dim3((NW + 2) * 64), 0, st, rec, G, flow, H, hdr, w,
+  hipLaunchKernelGGL((k_sweep_lock<NW, FAST>), dim3(nwg * B), dim3((NW + 2) * 64), 0, st, rec, G, flow, H, hdr, w,
                      h, bs, idx, dir, c, fc, nwg, B, errflag);
 }
 
-// Compute waves per workgroup (4 rows each). 4 is what every measurement of this kernel was taken with; S360_LOCK_NW=2
-// (one wave per SIMD, twice the workgroups per flow) and =8 (half the band-to-band hand-offs through global memory,
-// compute waves sharing SIMDs) are builds of the same code that have no hardware timing yet.
-int sweep_lock_waves() {
-  static const int nw = [] {
-    const char* e = std::getenv("S360_LOCK_NW");
-    const int v = e ? std::atoi(e) : 4;
-    return (v == 2 || v == 8) ? v : 4;
-  }();
-  return nw;
-}
+// Compute waves per workgroup (4 rows each): 2 — one compute wave per SIMD next to the two service waves, bands of 8
+// rows. (Measured on an 8K frame, round 2's bench record: 4 waves 119.2 ms of sweeps per frame, 2 waves with the
+// specialised steady-state steps 117.0 ms, 8 waves 186 ms; the other builds are gone.)
+int sweep_lock_waves() { return 2; }
 
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast) {
-  const int nw = sweep_lock_waves();
+  constexpr int nw = 2;
   const SweepConst c = make_sweep_const(pc, w, h);
   SweepFast fc;
   fc.rcCols = 1.0f / c.fcols;
@@ -746,27 +609,8 @@ void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float
   // (FlowEngine resets the hand-off arena of all its sweep launches with one memset)
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  // S360_LOCK_PEEL=1: the build whose steady-state steps are specialised (same results; not yet timed on hardware)
-  static const bool peel = [] {
-    const char* e = std::getenv("S360_LOCK_PEEL");
-    return e && e[0] == '1';
-  }();
-#define S360_LAUNCH_LOCK(N, F, P) launch_lock_t<N, F, P>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg)
-#define S360_LAUNCH_LOCK_N(N)                   \
-  do {                                          \
-    if (fast) {                                 \
-      if (peel) S360_LAUNCH_LOCK(N, true, true); \
-      else S360_LAUNCH_LOCK(N, true, false);    \
-    } else {                                    \
-      if (peel) S360_LAUNCH_LOCK(N, false, true); \
-      else S360_LAUNCH_LOCK(N, false, false);   \
-    }                                           \
-  } while (0)
-  if (nw == 2) S360_LAUNCH_LOCK_N(2);
-  else if (nw == 8) S360_LAUNCH_LOCK_N(8);
-  else S360_LAUNCH_LOCK_N(4);
-#undef S360_LAUNCH_LOCK_N
-#undef S360_LAUNCH_LOCK
+  if (fast) launch_lock_t<2, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
+  else launch_lock_t<2, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
 }
 
 }  // namespace s360

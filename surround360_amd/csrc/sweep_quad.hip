@@ -18,8 +18,16 @@
 //     neighbour = registers, up neighbour = DPP (row_shr:4 / row_bcast:15), a band's first row takes the last row of
 //     the band above from 8-byte {fx,fy} granules in global memory (all-ones = not written; bands are ticketed in
 //     band-major order, spins are bounded);
-//   * waves are persistent (capped grid, a finished band takes the next ticket): ~10-15 waves per CU is where the
-//     32 KB L1 still holds the gradient rows the waves gather from;
+//   * waves are persistent (capped grid, a finished band takes the next ticket);
+//   * the records and incoming flows of a 16-step chunk are fetched once (four pixels per lane) while the previous chunk
+//     computes and staged in LDS; all-interior chunks run a step with the range tests folded away;
+//   * WIN builds: the I1-gradient texels the chunk's bilinear taps can touch are staged in LDS as well — a window of
+//     kWinRows x kWinCols texels placed around the cells the chunk's own incoming flows point at, filled with coalesced
+//     row segments once per chunk — so that the two dependent gather rounds of a step are LDS reads (~100 cycles)
+//     instead of L1/L2 gathers (500+). A wave any of whose relevant taps leaves the window gathers from global memory
+//     for that round exactly as before: same texels, same bits;
+//   * non-WIN builds keep the round-2 texel exchange: the two finite-difference probes sit 0.001 px from round 1's
+//     winner, i.e. almost always in the cell that lane has just gathered, and take its texels with ds_bpermute;
 //   * pixels below the alpha threshold are not updated (PixFlow.h:390): a step none of whose 16 pixels is updated
 //     skips both rounds, a band waits for the band above only where its first row is updated, and a band without any
 //     updated pixel (per-row flags written by the record kernel) hands its last row on and leaves — 63 % of a pole
@@ -65,10 +73,9 @@ __device__ __forceinline__ float lane_value(int src, float v) {
 
 // Everything that is not the pixel update itself is amortised over several steps, with wave-uniform control: the
 // results of kQChunk steps are written back together (through an LDS ring, so that no global store sits in front of
-// the next step's gathers — loads and stores retire in order through one counter on gfx950), the band above is
+// the next step's loads — loads and stores retire in order through one counter on gfx950), the band above is
 // checked every kQNeed steps and the last row's granules are published every kQPub steps.
 constexpr int kQChunk = 16;
-constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
 #ifndef S360_QNEED
 #define S360_QNEED 4
 #endif
@@ -78,24 +85,45 @@ constexpr int kQResRing = 2 * kQChunk;  // result columns per row kept in LDS
 constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
 constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every kQPub steps
 
+// The LDS window of I1-gradient texels (WIN builds). In image coordinates the pixels of a chunk form a parallelogram:
+// row y of the band lags one column per row, so x + y is the same for the 16 pixels of a step and spans 16 values over a
+// chunk. The window is stored in those coordinates: LDS row jy holds image row wy0 + jy, column ju holds image column
+// (wu0 + ju) - (wy0 + jy). A bilinear cell (x0, y0) is inside iff 0 <= y0 - wy0 <= kWinRows - 2 and
+// 0 <= x0 + y0 - wu0 <= kWinCols - 3; its texels are [jy][ju], [jy][ju + 1], [jy + 1][ju + 1], [jy + 1][ju + 2].
+// 16 + 2 rows / columns are the chunk itself; the rest is room for the flows' spread inside the chunk and for the
+// left / up candidates and the probes around them. Rows are padded to 34 texels = 68 dwords: the 16 rows of a step
+// read 16-byte pieces at (almost) the same ju, which then fall on 16 disjoint groups of 4 banks.
+constexpr int kWinRows = 24;
+constexpr int kWinCols = 32;
+constexpr int kWinStride = 34;
+constexpr int kNoWin = 0x3fffffff;
+
+#ifdef S360_WAVE_EMULATION
+// developer statistics (CPU emulation only): wave-steps that ran an update round / that left the window for global memory
+unsigned long long g_quad_rounds = 0, g_quad_fallbacks = 0, g_quad_chunks = 0, g_quad_fills = 0;
+#define S360_QSTAT(v) __atomic_fetch_add(&(v), 1ull, __ATOMIC_RELAXED)
+#else
+#define S360_QSTAT(v)
+#endif
+
 // Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
-// The sweeps of one launch then hold a bounded share of every CU — a wave's working set is ~8 KB (17 gradient rows +
-// its record / flow lines) and beyond ~15 waves per CU the 32 KB L1 thrashes — and the kernels of another context
-// find free wave slots, registers and LDS next to them.
-template <bool FAST, bool LDSIN, bool PEEL, bool R2X>
+template <bool FAST, bool WIN>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
                                                    unsigned* __restrict__ errflag,
                                                    const unsigned* __restrict__ rowflags) {
-  // LDSIN: the records and flows of a 16-step chunk are fetched once (four pixels per lane, eight loads per chunk
-  // instead of two per step) and staged in LDS; a slot of s_res then holds a pixel's flow before its step and its
-  // result after it, indexed by step. Row strides of 17 elements keep the 16 rows of a read on distinct banks.
-  constexpr int kRW = LDSIN ? kQChunk + 1 : kQResRing;
+  // The records and flows of a 16-step chunk are fetched once (four pixels per lane, eight loads per chunk instead of
+  // two per step) and staged in LDS; a slot of s_res holds a pixel's flow before its step and its result after it,
+  // indexed by step. Row strides of 17 elements keep the 16 rows of a read on distinct banks.
+  constexpr int kRW = kQChunk + 1;
+  typedef float f4r __attribute__((ext_vector_type(4)));
+  typedef float f2r __attribute__((ext_vector_type(2)));
   __shared__ float2 s_up[kUpRing];
   __shared__ float2 s_res[kQRows][kRW];
-  __shared__ float4 s_rec[LDSIN ? kQRows : 1][LDSIN ? kQChunk + 1 : 1];
+  __shared__ float4 s_rec[kQRows][kRW];
+  __shared__ f2r s_win[WIN ? kWinRows * kWinStride : 1];
   const int lane = threadIdx.x;
   for (;;) {
   unsigned tk = 0;
@@ -147,40 +175,10 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const float kEps = 0.001f, kInf = __int_as_float(0x7f800000);
   const int nsteps = w + kQRows - 1;
   auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
+  int wy0 = kNoWin, wu0 = 0;  // (WIN) placement of the LDS window, wave-uniform
 
-  // errorFunction at (x + ax, y + ay) for this lane's pixel (PixFlow.h:493-534). `tiny` collects the lanes whose
-  // operands leave the proven range of the fast division / square root.
-  auto evaluate = [&](auto ieee, int x, float4 rc, float ax, float ay, bool& tiny) -> float {
-    const float mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
-    const float my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
-    const int x0 = (int)mx, y0 = (int)my;
-    const float xR = __builtin_amdgcn_fractf(mx), yR = __builtin_amdgcn_fractf(my);
-    unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
-    if (S360_DBG(fc, 1)) boff = (unsigned)lane << 4;  // timing experiment (results invalid): gathers that always hit
-    const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
-    const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
-    Texels tt;
-    tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
-    tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-    if (decltype(ieee)::value) {
-      Foot ft;
-      ft.off = 0; ft.xR = xR; ft.yR = yR;
-      return error_from(tt, ft, rc.x, rc.y, rc.z, rc.w, ax, ay, c);
-    }
-    bool t1;
-    const float e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, t1);
-    tiny = tiny || t1;
-    return e;
-  };
-  // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
-  // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
-  // R2X builds ("round-2 exchange", not yet timed): the two finite-difference probes sit kGradEpsilon = 0.001 px away from
-  // the winner of round 1, i.e. almost always in the same bilinear cell, whose four texels the winner's lane has just
-  // gathered. The probe lanes then take those eight floats from that lane (ds_bpermute) instead of gathering them again
-  // from memory: one dependent gather round per step instead of two, 3 gathers per pixel instead of 5. A wave in which any
-  // probe leaves the winner's cell takes the original path for that step, so the results are the same bits.
+  // getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464) of the tap (x + ax, y + ay) of this lane's pixel
   struct Cell { float mx, my; int x0, y0; };
-  bool r2xTake = true;  // (R2X) this lane's pixel is updated at this step: only such pixels can send the wave to the fallback
   auto cell_of = [&](int x, float ax, float ay) -> Cell {
     Cell k;
     k.mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
@@ -189,6 +187,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     k.y0 = (int)k.my;
     return k;
   };
+  // errorFunction (PixFlow.h:493-534) on the texels of cell k. `tiny` collects the lanes whose operands leave the
+  // proven range of the fast division / square root.
   auto error_of = [&](auto ieee, const Texels& tt, const Cell& k, float4 rc, float ax, float ay, bool& tiny) -> float {
     const float xR = __builtin_amdgcn_fractf(k.mx), yR = __builtin_amdgcn_fractf(k.my);
     if (decltype(ieee)::value) {
@@ -201,58 +201,80 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     tiny = tiny || t1;
     return e;
   };
-  auto update = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool& tiny) -> float2 {
-    const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
-    float e;
-    float g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;  // (R2X) the texels this lane gathered in round 1
-    if constexpr (R2X) {
-      const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
-      const Cell k = cell_of(x, ax, ay);
-      const unsigned boff = (unsigned)(__umul24(k.y0, w) + k.x0) << 3;
-      const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
-      const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
-      g0 = ta.x; g1 = ta.y; g2 = ta.z; g3 = ta.w; g4 = tb.x; g5 = tb.y; g6 = tb.z; g7 = tb.w;
-      Texels t1;
-      t1.r0 = make_float4(g0, g1, g2, g3);
-      t1.r1 = make_float4(g4, g5, g6, g7);
-      e = error_of(ieee, t1, k, rc, ax, ay, tiny);
-    } else {
-      e = evaluate(ieee, x, rc, cand.x + 0.0f, cand.y + 0.0f, tiny);
+  auto gather = [&](const Cell& k) -> Texels {  // the cell's four texels from global memory
+    unsigned boff = (unsigned)(__umul24(k.y0, w) + k.x0) << 3;
+    if (S360_DBG(fc, 1)) boff = (unsigned)lane << 4;  // timing experiment (results invalid): gathers that always hit
+    const f4a8 ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
+    const f4a8 tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
+    Texels tt;
+    tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+    tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+    return tt;
+  };
+  // (WIN) the same four texels from the LDS window, or from global memory for the whole wave if a lane that matters
+  // (`rel`) has its cell outside the window
+  auto fetch = [&](const Cell& k, bool rel) -> Texels {
+    const int jy = k.y0 - wy0, ju = k.x0 + k.y0 - wu0;
+    const bool in = (unsigned)jy <= (unsigned)(kWinRows - 2) && (unsigned)ju <= (unsigned)(kWinCols - 3);
+    S360_QSTAT(g_quad_rounds);
+    if (__builtin_expect(__ballot(rel && !in) != 0ull, 0)) {
+      S360_QSTAT(g_quad_fallbacks);
+      return gather(k);
     }
+    const int off = in ? jy * kWinStride + ju : 0;  // (lanes that do not matter read slot 0)
+    const f4a8 ta = *reinterpret_cast<const f4a8*>(&s_win[off]);
+    const f4a8 tb = *reinterpret_cast<const f4a8*>(&s_win[off + kWinStride + 1]);
+    Texels tt;
+    tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+    tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+    return tt;
+  };
+  // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
+  // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
+  auto update = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool take,
+                    bool& tiny) -> float2 {
+    constexpr bool ST = decltype(steady)::value;
+    const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
+    const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
+    const Cell k = cell_of(x, ax, ay);
+    Texels t1;
+    if constexpr (WIN) t1 = fetch(k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)));
+    else t1 = gather(k);
+    const float e = error_of(ieee, t1, k, rc, ax, ay, tiny);
     const float e0 = quad_bcast<0>(e);
     float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
-    if (!decltype(steady)::value && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
-    if (!hasUp) e2 = kInf;     // no up proposal in the first row
-    float2 f = fo;
-    float cur = e0;
-    int win = 0;  // (R2X) the quad lane that evaluated the winner
-    if constexpr (R2X) {  // the same two proposals, written as selects (with an index beside them the compiler would
-      const bool b1 = e1 < e0;  // otherwise pick the winner's flow from a table in scratch memory)
-      const float c1 = b1 ? e1 : e0;
-      const bool b2 = e2 < c1;
-      f.x = b2 ? up.x : (b1 ? fl.x : fo.x);
-      f.y = b2 ? up.y : (b1 ? fl.y : fo.y);
-      cur = b2 ? e2 : c1;
-      win = b2 ? 2 : (b1 ? 1 : 0);
-    } else {
-      if (e1 < cur) { f = fl; cur = e1; }
-      if (e2 < cur) { f = up; cur = e2; }
-    }
+    if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
+    if (!hasUp) e2 = kInf;            // no up proposal in the first row
+    // proposeFlowUpdate x2 in the reference's order, written as selects (with an index beside them the compiler would
+    // pick the winner's flow from a table in scratch memory)
+    const bool b1 = e1 < e0;
+    const float c1 = b1 ? e1 : e0;
+    const bool b2 = e2 < c1;
+    float2 f;
+    f.x = b2 ? up.x : (b1 ? fl.x : fo.x);
+    f.y = b2 ? up.y : (b1 ? fl.y : fo.y);
+    const float cur = b2 ? e2 : c1;
+    const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
+    const Cell pk = cell_of(x, pax, pay);
     float pe;
-    if constexpr (R2X) {
-      const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
-      const Cell pk = cell_of(x, pax, pay), wk = cell_of(x, f.x + 0.0f, f.y + 0.0f);
-      if (__ballot(q < 2 && r2xTake && (pk.x0 != wk.x0 || pk.y0 != wk.y0)) == 0ull) {
+    if constexpr (WIN) {
+      const Texels t2 = fetch(pk, take && q < 2);
+      pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
+    } else {
+      // round-2 exchange: the probes take the winner's texels from the lane that gathered them unless a probe of an
+      // updated pixel leaves the winner's cell (then the wave gathers again: same bits either way)
+      const Cell wk = cell_of(x, f.x + 0.0f, f.y + 0.0f);
+      if (__ballot(q < 2 && take && (pk.x0 != wk.x0 || pk.y0 != wk.y0)) == 0ull) {
+        const int win = b2 ? 2 : (b1 ? 1 : 0);  // the quad lane that evaluated the winner
         const int src = ((lane & ~3) | win) << 2;
         Texels t2;
-        t2.r0 = make_float4(lane_value(src, g0), lane_value(src, g1), lane_value(src, g2), lane_value(src, g3));
-        t2.r1 = make_float4(lane_value(src, g4), lane_value(src, g5), lane_value(src, g6), lane_value(src, g7));
+        t2.r0 = make_float4(lane_value(src, t1.r0.x), lane_value(src, t1.r0.y), lane_value(src, t1.r0.z), lane_value(src, t1.r0.w));
+        t2.r1 = make_float4(lane_value(src, t1.r1.x), lane_value(src, t1.r1.y), lane_value(src, t1.r1.z), lane_value(src, t1.r1.w));
         pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
       } else {
-        pe = evaluate(ieee, x, rc, pax, pay, tiny);
+        const Texels t2 = gather(pk);
+        pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
       }
-    } else {
-      pe = evaluate(ieee, x, rc, f.x + (q == 0 ? kEps : 0.0f), f.y + (q == 1 ? kEps : 0.0f), tiny);
     }
     const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
     const float nx = ex - cur, ny = ey - cur;
@@ -295,258 +317,179 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   float2 fl = make_float2(0.f, 0.f);  // result of the previous pixel of this row (same in the 4 lanes of the quad)
   float4 nrc;
   float2 nfo;
-  // LDSIN: the next chunk's records / flows of this lane's four steps (4 q .. 4 q + 3). In the build every measurement of
-  // this kernel was taken with, `cr` is an array of HIP's float4 structs; the compiler does not promote it to registers
-  // through the lambdas' captures: it lives in scratch memory (ScratchSize 80), and each chunk's loads are waited for
-  // right after they are issued in order to be stored there — the prefetch "lands during the chunk" only as far as L2.
-  // The PEEL build (not yet timed) declares the arrays with native vector types, which stay in VGPRs (ScratchSize 0).
-  typedef float f4r __attribute__((ext_vector_type(4)));
-  typedef float f2r __attribute__((ext_vector_type(2)));
-  typename std::conditional<PEEL, f4r, float4>::type cr[4];
-  typename std::conditional<PEEL, f2r, float2>::type cf[4];
+  // the next chunk's records / flows of this lane's four steps (4 q .. 4 q + 3): native vector types, which stay in
+  // VGPRs through the lambdas' captures (HIP's float4 struct went to scratch memory)
+  f4r cr[4];
+  f2r cf[4];
   auto chunk_load = [&](int sbase) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xc = col(sbase + 4 * q + j - r);
-      if constexpr (PEEL) {
-        cr[j] = *reinterpret_cast<const f4r*>(recRow + xc);
-        cf[j] = *reinterpret_cast<const f2r*>(flowRow + xc);
-      } else {
-        cr[j] = recRow[xc];
-        cf[j] = flowRow[xc];
-      }
+      cr[j] = *reinterpret_cast<const f4r*>(recRow + xc);
+      cf[j] = *reinterpret_cast<const f2r*>(flowRow + xc);
     }
   };
   auto chunk_store = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if constexpr (PEEL) {
-        *reinterpret_cast<f4r*>(&s_rec[r][4 * q + j]) = cr[j];
-        *reinterpret_cast<f2r*>(&s_res[r][4 * q + j]) = cf[j];
+      *reinterpret_cast<f4r*>(&s_rec[r][4 * q + j]) = cr[j];
+      *reinterpret_cast<f2r*>(&s_res[r][4 * q + j]) = cf[j];
+    }
+  };
+  // (WIN) Places the window around the cells the incoming flows of the chunk starting at step `sbase` point at (cr / cf
+  // hold that chunk: four pixels per lane) and fills it: 12 coalesced loads of 8 bytes per lane, two window rows per
+  // wave-wide load. Pixels that are not updated do not count; a chunk without updated pixels leaves the window alone.
+  auto win_fill = [&](int sbase) {
+    typedef short s2r __attribute__((ext_vector_type(2)));
+    s2r lo = {32767, 32767}, hi = {-32768, -32768};  // (y0, x0 + y0) minima / maxima; coordinates are < 2^15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xi = sbase + 4 * q + j - r;
+      if (rowValid && xi >= 0 && xi < w && cr[j].x == cr[j].x) {
+        const Cell k = cell_of(dir > 0 ? xi : w - 1 - xi, cf[j].x + 0.0f, cf[j].y + 0.0f);
+        const s2r v = {(short)k.y0, (short)(k.x0 + k.y0)};
+        lo = __builtin_elementwise_min(lo, v);
+        hi = __builtin_elementwise_max(hi, v);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const int lo2 = __shfl_xor(__builtin_bit_cast(int, lo), m), hi2 = __shfl_xor(__builtin_bit_cast(int, hi), m);
+      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s2r, lo2));
+      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s2r, hi2));
+    }
+    S360_QSTAT(g_quad_chunks);
+    const int ymin = __builtin_amdgcn_readfirstlane((int)lo.x), umin = __builtin_amdgcn_readfirstlane((int)lo.y);
+    const int ymax = __builtin_amdgcn_readfirstlane((int)hi.x), umax = __builtin_amdgcn_readfirstlane((int)hi.y);
+    if (ymax < ymin) return;  // nothing to update in this chunk: no taps
+    // rows ymin .. ymax + 1 and columns umin .. umax + 2 are what the incoming flows need; the slack goes evenly to
+    // both sides (the left / up candidates and the probes land next to them)
+    const int ny0 = ymin - max(0, (kWinRows - (ymax - ymin + 2)) >> 1);
+    const int nu0 = umin - max(0, (kWinCols - (umax - umin + 3)) >> 1);
+    S360_QSTAT(g_quad_fills);
+    f2r wv[kWinRows / 2];
+    const int jc = lane & 31, jr = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < kWinRows / 2; ++i) {
+      const int Y = ny0 + 2 * i + jr, X = nu0 + jc - Y;
+      wv[i] = *reinterpret_cast<const f2r*>(G1 + (size_t)min(max(Y, 0), h - 1) * w + min(max(X, 0), w - 1));
+    }
+    S360_WAVE_SYNC();  // (the previous chunk's taps have been read)
+#pragma unroll
+    for (int i = 0; i < kWinRows / 2; ++i) s_win[(2 * i + jr) * kWinStride + jc] = wv[i];
+    S360_WAVE_SYNC();
+    wy0 = ny0;
+    wu0 = nu0;
+  };
+  chunk_load(0);
+  if constexpr (WIN) win_fill(0);
+  chunk_store();
+  S360_WAVE_SYNC();
+  nrc = s_rec[r][0];
+  nfo = s_res[r][0];
+  // A chunk all of whose 16 steps have every row of the wave inside the image with a left neighbour (local steps
+  // 16 .. w-1, chunk-aligned) runs the step with the range tests, the first-column case, the sweep direction select and
+  // the publish / write-back bounds folded away (`steady`).
+  const int xLane = dir > 0 ? -r : w - 1 + r, xSign = dir > 0 ? 1 : -1;
+  auto step = [&](auto steady, int s, int send) {
+    constexpr bool ST = decltype(steady)::value;
+    // Row 0 needs column s of the band above only if its pixel is updated at this step (pixels below the alpha
+    // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
+    // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
+    // of steps that did not need the band above (the columns passed meanwhile are dropped).
+    if (hasUpBand && (ST || s < w) && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
+      const int need = min(s + kQNeed, w), limit = s + kUpRing;
+      if (upFilled < s) {
+        upFilled = s;
+        pending = false;
+      }
+      if (pending) process(limit);
+      unsigned spins = 0;
+      while (upFilled < need) {
+        if (spins) {  // back off: a band waiting for its predecessor should leave the issue slots and the L2 to it
+          if (spins < 4) __builtin_amdgcn_s_sleep(8);
+          else __builtin_amdgcn_s_sleep(48);
+        }
+        issue();
+        process(limit);
+        if (++spins > (1u << 20) ||
+            ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
+          if (lane == 0) atomicExch(errflag, 1u);
+        }
+      }
+      if (upFilled < w && upFilled - s < 2 * kQNeed + 8) issue();  // running low: taken at the next check
+    }
+    const float4 rc = nrc;
+    const float2 fo = nfo;
+    if (s + 1 < send) {  // inputs of the next step of this chunk (the first step of the next chunk is read after the refill)
+      nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
+      nfo = s_res[r][(s + 1) & (kQChunk - 1)];
+    }
+    const float2 upl = s_up[s & (kUpRing - 1)];
+    const int xi = s - r;
+    const bool active = ST ? rowValid : (rowValid && xi >= 0 && xi < w);
+    const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);  // unclamped: out-of-range columns are inactive
+    const bool upd = rc.x == rc.x;
+    float2 up;
+    up.x = from_row_above_q(upl.x, fl.x);
+    up.y = from_row_above_q(upl.y, fl.y);
+    // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
+    // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
+    // two rounds are skipped.
+    const bool take = active && upd;
+    const float2 alt = active ? fo : fl;
+    float2 res = alt;
+    if (__ballot(take) != 0ull) {
+      if (FAST) {
+        bool tiny = false;
+        res = update(std::false_type{}, steady, x, xi, rc, fo, fl, up, take, tiny);
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, take, tiny);
       } else {
-        s_rec[r][4 * q + j] = cr[j];
-        s_res[r][4 * q + j] = cf[j];
+        bool tiny = false;
+        res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, take, tiny);
+      }
+      res.x = take ? res.x : alt.x;
+      res.y = take ? res.y : alt.y;
+    }
+    fl = res;
+    if (q == 0) s_res[r][s & (kQChunk - 1)] = res;
+    S360_WAVE_SYNC();  // (read below by the publishing lanes and by the chunk's write-back)
+    if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || (!ST && s == nsteps - 1))) {  // the last row's granules for the band below
+      const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
+      if (ST ? lane < kQPub : (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1))) {
+        const float2 v = s_res[kQRows - 1][(xi0 + kQRows - 1) & (kQChunk - 1)];
+        __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   };
-  if (LDSIN) {
-    chunk_load(0);
-    chunk_store();
-    S360_WAVE_SYNC();
-    nrc = s_rec[r][0];
-    nfo = s_res[r][0];
-  } else {
-    const int x0c = col(0 - r);
-    nrc = recRow[x0c];
-    nfo = flowRow[x0c];
-  }
-  if constexpr (!PEEL) {
-    for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
-      const int send = min(s0 + kQChunk, nsteps);
-      if (LDSIN && s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
-      for (int s = s0; s < send; ++s) {
-        // Row 0 needs column s of the band above only if its pixel is updated at this step (pixels below the alpha
-        // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
-        // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
-        // of steps that did not need the band above (the columns passed meanwhile are dropped).
-        if (hasUpBand && s < w && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
-          const int need = min(s + kQNeed, w), limit = s + kUpRing;
-          if (upFilled < s) {
-            upFilled = s;
-            pending = false;
-          }
-          if (pending) process(limit);
-          unsigned spins = 0;
-          while (upFilled < need) {
-            if (spins) {  // back off: a band waiting for its predecessor should leave the issue slots and the L2 to it
-              if (spins < 4) __builtin_amdgcn_s_sleep(8);
-              else __builtin_amdgcn_s_sleep(48);
-            }
-            issue();
-            process(limit);
-            if (++spins > (1u << 20) ||
-                ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-              dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
-              if (lane == 0) atomicExch(errflag, 1u);
-            }
-          }
-          if (upFilled < w && upFilled - s < 2 * kQNeed + 8) issue();  // running low: taken at the next check
-        }
-        const float4 rc = nrc;
-        const float2 fo = nfo;
-        if (LDSIN) {  // inputs of the next step of this chunk (the first step of the next chunk is read after the refill)
-          if (s + 1 < send) {
-            nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
-            nfo = s_res[r][(s + 1) & (kQChunk - 1)];
-          }
-        } else {  // inputs of the next step (one step ahead: their latency hides behind this step's two gather rounds)
-          const int xn = S360_DBG(fc, 8) ? col(-r) : col(s + 1 - r);  // (dbg 8: timing experiment, inputs that always hit)
-          if (S360_DBG(fc, 16)) {  // (dbg 16: inputs as streaming loads that do not allocate in L1; results unchanged)
-            typedef float f4n __attribute__((ext_vector_type(4)));
-            typedef float f2n __attribute__((ext_vector_type(2)));
-            const f4n a = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(recRow) + xn);
-            const f2n bq = __builtin_nontemporal_load(reinterpret_cast<const f2n*>(flowRow) + xn);
-            nrc = make_float4(a.x, a.y, a.z, a.w);
-            nfo = make_float2(bq.x, bq.y);
-          } else {
-            nrc = recRow[xn];
-            nfo = flowRow[xn];
-          }
-        }
-        const float2 upl = s_up[s & (kUpRing - 1)];
-        const int xi = s - r;
-        const bool active = rowValid && xi >= 0 && xi < w;
-        const int x = dir > 0 ? xi : w - 1 - xi;  // unclamped: out-of-range columns are inactive, their gathers are clamped
-        const bool upd = rc.x == rc.x;
-        float2 up;
-        up.x = from_row_above_q(upl.x, fl.x);
-        up.y = from_row_above_q(upl.y, fl.y);
-        // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
-        // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
-        // two gather rounds and the evaluations are skipped.
-        const bool take = active && upd;
-        const float2 alt = active ? fo : fl;
-        float2 res = alt;
-        if (__ballot(take) != 0ull) {
-          if (FAST) {
-            bool tiny = false;
-            res = update(std::false_type{}, std::false_type{}, x, xi, rc, fo, fl, up, tiny);
-            if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, std::false_type{}, x, xi, rc, fo, fl, up, tiny);
-          } else {
-            bool tiny = false;
-            res = update(std::true_type{}, std::false_type{}, x, xi, rc, fo, fl, up, tiny);
-          }
-          res.x = take ? res.x : alt.x;
-          res.y = take ? res.y : alt.y;
-        }
-        fl = res;
-        if (q == 0) s_res[r][LDSIN ? (s & (kQChunk - 1)) : (xi & (kQResRing - 1))] = res;
-        S360_WAVE_SYNC();  // (read below by the publishing lanes and by the chunk's write-back)
-        if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || s == nsteps - 1)) {  // the last row's granules for the band below
-          const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
-          if (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1)) {
-            const float2 v = s_res[kQRows - 1][LDSIN ? ((xi0 + kQRows - 1) & (kQChunk - 1)) : (xi0 & (kQResRing - 1))];
-            __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
-      // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
-      {
-        const int base = s0 - r + q;
-  #pragma unroll
-        for (int k = 0; k < kQChunk / 4; ++k) {
-          const int xi = base + 4 * k;
-          if (rowValid && xi >= 0 && xi < w && xi < send - r && !S360_DBG(fc, 4))
-            flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][LDSIN ? ((xi + r) & (kQChunk - 1)) : (xi & (kQResRing - 1))];
-        }
-      }
-      if (LDSIN && send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
-        S360_WAVE_SYNC();
-        chunk_store();
-        S360_WAVE_SYNC();
-        nrc = s_rec[r][0];
-        nfo = s_res[r][0];
+  for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
+    const int send = min(s0 + kQChunk, nsteps);
+    if (s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
+    const bool steadyChunk = s0 >= kQRows && s0 + kQChunk <= w;
+    if (steadyChunk) {
+      for (int s = s0; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
+    } else {
+      for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
+    }
+    // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
+    {
+      const int base = s0 - r + q;
+#pragma unroll
+      for (int k = 0; k < kQChunk / 4; ++k) {
+        const int xi = base + 4 * k;
+        if (rowValid && (steadyChunk || (xi >= 0 && xi < w && xi < send - r)) && !S360_DBG(fc, 4))
+          flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][(xi + r) & (kQChunk - 1)];
       }
     }
-  } else {
-    // PEEL builds (LDS-staged inputs only): a chunk all of whose 16 steps have every row of the wave inside the image with a
-    // left neighbour (local steps 16 .. w-1, chunk-aligned) runs the same step with the range tests, the first-column case,
-    // the sweep direction select and the publish / write-back bounds folded away.
-    const int xLane = dir > 0 ? -r : w - 1 + r, xSign = dir > 0 ? 1 : -1;
-    auto step = [&](auto steady, int s, int send) {
-      constexpr bool ST = decltype(steady)::value;
-      if (hasUpBand && (ST || s < w) && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
-        const int need = min(s + kQNeed, w), limit = s + kUpRing;
-        if (upFilled < s) {
-          upFilled = s;
-          pending = false;
-        }
-        if (pending) process(limit);
-        unsigned spins = 0;
-        while (upFilled < need) {
-          if (spins) {  // back off: a band waiting for its predecessor should leave the issue slots and the L2 to it
-            if (spins < 4) __builtin_amdgcn_s_sleep(8);
-            else __builtin_amdgcn_s_sleep(48);
-          }
-          issue();
-          process(limit);
-          if (++spins > (1u << 20) ||
-              ((spins & 255u) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            dead = true;  // the band above is gone: stop waiting, flag the result invalid, keep draining
-            if (lane == 0) atomicExch(errflag, 1u);
-          }
-        }
-        if (upFilled < w && upFilled - s < 2 * kQNeed + 8) issue();  // running low: taken at the next check
-      }
-      const float4 rc = nrc;
-      const float2 fo = nfo;
-      if (s + 1 < send) {
-        nrc = s_rec[r][(s + 1) & (kQChunk - 1)];
-        nfo = s_res[r][(s + 1) & (kQChunk - 1)];
-      }
-      const float2 upl = s_up[s & (kUpRing - 1)];
-      const int xi = s - r;
-      const bool active = ST ? rowValid : (rowValid && xi >= 0 && xi < w);
-      const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);
-      const bool upd = rc.x == rc.x;
-      float2 up;
-      up.x = from_row_above_q(upl.x, fl.x);
-      up.y = from_row_above_q(upl.y, fl.y);
-      const bool take = active && upd;
-      const float2 alt = active ? fo : fl;
-      float2 res = alt;
-      r2xTake = take;
-      if (__ballot(take) != 0ull) {
-        if (FAST) {
-          bool tiny = false;
-          res = update(std::false_type{}, steady, x, xi, rc, fo, fl, up, tiny);
-          if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, tiny);
-        } else {
-          bool tiny = false;
-          res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, tiny);
-        }
-        res.x = take ? res.x : alt.x;
-        res.y = take ? res.y : alt.y;
-      }
-      fl = res;
-      if (q == 0) s_res[r][s & (kQChunk - 1)] = res;
+    if (send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
+      if constexpr (WIN) win_fill(send);
       S360_WAVE_SYNC();
-      if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || (!ST && s == nsteps - 1))) {
-        const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
-        if (ST ? lane < kQPub : (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1))) {
-          const float2 v = s_res[kQRows - 1][(xi0 + kQRows - 1) & (kQChunk - 1)];
-          __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    };
-    for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
-      const int send = min(s0 + kQChunk, nsteps);
-      if (s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
-      const bool steadyChunk = s0 >= kQRows && s0 + kQChunk <= w;
-      if (steadyChunk) {
-        for (int s = s0; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
-      } else {
-        for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
-      }
-      // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
-      {
-        const int base = s0 - r + q;
-  #pragma unroll
-        for (int k = 0; k < kQChunk / 4; ++k) {
-          const int xi = base + 4 * k;
-          if (rowValid && (steadyChunk || (xi >= 0 && xi < w && xi < send - r)))
-            flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][(xi + r) & (kQChunk - 1)];
-        }
-      }
-      if (send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
-        S360_WAVE_SYNC();
-        chunk_store();
-        S360_WAVE_SYNC();
-        nrc = s_rec[r][0];
-        nfo = s_res[r][0];
-      }
+      chunk_store();
+      S360_WAVE_SYNC();
+      nrc = s_rec[r][0];
+      nfo = s_res[r][0];
     }
   }
   }  // next ticket
@@ -571,15 +514,17 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  static const size_t dyn = [] {  // S360_QUAD_DYNLDS: extra LDS per wave (experiments with the residency of other kernels)
-    const char* e = std::getenv("S360_QUAD_DYNLDS");
-    return e ? (size_t)std::atoi(e) : (size_t)0;
+  // S360_QUAD_WIN=0: the build without the LDS gradient window (tuning only; the results do not depend on it)
+  static const bool winEnv = [] {
+    const char* e = std::getenv("S360_QUAD_WIN");
+    return !(e && e[0] == '0');
   }();
+  const bool win = winEnv && w + h < 32768;  // (the window's bounds are reduced as packed 16-bit coordinates)
   // S360_QUAD_WAVES_PER_CU: persistent waves per CU of one launch (tuning only; the results do not depend on it)
   static const int perCu = [] {
     const char* e = std::getenv("S360_QUAD_WAVES_PER_CU");
-    const int v = e ? std::atoi(e) : 10;
-    return v > 0 ? v : 10;
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : (winEnv ? 11 : 10);
   }();
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -587,30 +532,15 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     return n > 0 ? n : 256;
   }();
   const int grid = std::min(nb * B, cus * perCu);
-  // S360_QUAD_LDSIN=0: inputs loaded per step instead of staged per chunk (tuning only; same results)
-  static const bool ldsin = [] {
-    const char* e = std::getenv("S360_QUAD_LDSIN");
-    return !(e && e[0] == '0');
-  }();
-  // S360_QUAD_PEEL=1: the build whose all-interior chunks are specialised and whose prefetch arrays stay in registers;
-  // =2: the same plus the round-2 texel exchange (R2X). Same results; not yet timed on hardware.
-  static const int peel = [] {
-    const char* e = std::getenv("S360_QUAD_PEEL");
-    return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
-  }();
-#define S360_LAUNCH_QUAD(F, L, P, X)                                                                                      \
-  hipLaunchKernelGGL((k_sweep_quad<F, L, P, X>), dim3(grid), dim3(64), dyn, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, \
+#define S360_LAUNCH_QUAD(F, W)                                                                                    \
+  hipLaunchKernelGGL((k_sweep_quad<F, W>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, \
                      c, fc, nb, B, errflag, rowflags)
   if (fast) {
-    if (ldsin && peel == 2) S360_LAUNCH_QUAD(true, true, true, true);
-    else if (ldsin && peel == 1) S360_LAUNCH_QUAD(true, true, true, false);
-    else if (ldsin) S360_LAUNCH_QUAD(true, true, false, false);
-    else S360_LAUNCH_QUAD(true, false, false, false);
+    if (win) S360_LAUNCH_QUAD(true, true);
+    else S360_LAUNCH_QUAD(true, false);
   } else {
-    if (ldsin && peel == 2) S360_LAUNCH_QUAD(false, true, true, true);
-    else if (ldsin && peel == 1) S360_LAUNCH_QUAD(false, true, true, false);
-    else if (ldsin) S360_LAUNCH_QUAD(false, true, false, false);
-    else S360_LAUNCH_QUAD(false, false, false, false);
+    if (win) S360_LAUNCH_QUAD(false, true);
+    else S360_LAUNCH_QUAD(false, false);
   }
 #undef S360_LAUNCH_QUAD
 }

@@ -318,6 +318,10 @@ class Context:
         self._ck(lib().s360_frame_cubemap(self.h, int(face_width), int(face_height), fmt.encode(), whc, _p(out)))
         return out
 
+    def set_sharpening(self, sharpening):
+        """FLAGS_sharpening for the frames rendered from now on (TRSP:56, :901)."""
+        self._ck(lib().s360_set_sharpening(self.h, C.c_double(sharpening)))
+
     def keep_intermediates(self, on=True):
         self._ck(lib().s360_set_keep_intermediates(self.h, int(on)))
 

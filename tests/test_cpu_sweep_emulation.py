@@ -51,75 +51,43 @@ def test_sizes(emulator, w, h):
 
 
 def test_quad_tuning_switches_keep_the_result(emulator):
-    """Inputs per step instead of per chunk; two persistent waves taking all tickets; no row flags."""
-    _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 1], S360_QUAD_LDSIN=0)
+    """Two persistent waves taking all tickets; no row flags."""
     _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
     _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=3, EMU_CUS=1, EMU_LANE_ORDER="shuffle")
     _run(emulator, ["quad", 70, 50, 2, 15, "bands", 1, 0])
 
 
-@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-def test_lock_kernel_with_peeled_steady_state(emulator, mask):
-    """S360_LOCK_PEEL=1: the build whose steps with all four rows inside the image are specialised."""
-    _run(emulator, ["lock", 37, 40, 2, 21, mask, 1], S360_LOCK_PEEL=1)
-    _run(emulator, ["lock", 37, 40, 2, 21, mask, 0], S360_LOCK_PEEL=1, EMU_LANE_ORDER="shuffle")
-
-
-@pytest.mark.parametrize("w,h", [(3, 2), (4, 5), (5, 16), (6, 17), (17, 33), (130, 21)])
-def test_lock_peeled_sizes(emulator, w, h):
-    """Widths below, at and above the first width with a steady range (5)."""
-    _run(emulator, ["lock", w, h, 2, 22, "random", 1], S360_LOCK_PEEL=1)
-
-
-@pytest.mark.parametrize("nw", [2, 8])
-def test_lock_workgroup_heights(emulator, nw):
-    """S360_LOCK_NW: 2 / 8 compute waves per workgroup (bands of 8 / 32 rows), alone and with the peeled steps."""
-    for mask in ("random", "bands", "rows0"):
-        _run(emulator, ["lock", 41, 70, 2, 23, mask, 1], S360_LOCK_NW=nw)
-        _run(emulator, ["lock", 41, 70, 2, 23, mask, 0], S360_LOCK_NW=nw, S360_LOCK_PEEL=1, EMU_LANE_ORDER="shuffle")
-    _run(emulator, ["lock", 3, 2, 2, 24, "random", 1], S360_LOCK_NW=nw, S360_LOCK_PEEL=1)
-    _run(emulator, ["lock", 64, 65, 3, 24, "random", 1], S360_LOCK_NW=nw, S360_LOCK_PEEL=1)
-
-
-@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-def test_quad_kernel_with_peeled_interior_chunks(emulator, mask):
-    """S360_QUAD_PEEL=1: chunks whose 16 steps have every row inside the image run the specialised step."""
-    _run(emulator, ["quad", 70, 50, 2, 31, mask, 1, 1], S360_QUAD_PEEL=1)
-    _run(emulator, ["quad", 53, 40, 2, 32, mask, 0, 0], S360_QUAD_PEEL=1, EMU_LANE_ORDER="shuffle")
+@pytest.mark.parametrize("w,h", [(3, 2), (4, 5), (5, 16), (6, 17), (17, 33), (130, 21), (41, 70), (64, 65)])
+def test_lock_sizes(emulator, w, h):
+    """Widths below, at and above the first width with a steady range (5); bands of 8 rows (2 compute waves)."""
+    _run(emulator, ["lock", w, h, 2, 22, "random", 1])
+    _run(emulator, ["lock", w, h, 2, 23, "rows0", 0], EMU_LANE_ORDER="shuffle")
 
 
 @pytest.mark.parametrize("w,h", [(3, 2), (16, 16), (31, 16), (32, 17), (33, 33), (48, 20), (200, 70)])
-def test_quad_peeled_sizes(emulator, w, h):
+def test_quad_sizes(emulator, w, h):
     """Widths without, with exactly one and with several interior chunks (the first one is steps 16..31: w >= 32)."""
-    _run(emulator, ["quad", w, h, 2, 33, "random", 1, 1], S360_QUAD_PEEL=1)
-    _run(emulator, ["quad", w, h, 2, 33, "bands", 1, 1], S360_QUAD_PEEL=1, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
+    _run(emulator, ["quad", w, h, 2, 33, "random", 1, 1])
+    _run(emulator, ["quad", w, h, 2, 33, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
 
 
 @pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-def test_tri_kernel(emulator, mask):
-    """sweep_tri.hip (S360_SWEEP_TRI=1): three lanes per pixel, 20 rows per wave."""
-    _run(emulator, ["tri", 70, 50, 2, 41, mask, 1, 1])
-    _run(emulator, ["tri", 53, 45, 3, 42, mask, 0, 0], EMU_LANE_ORDER="shuffle")
+@pytest.mark.parametrize("win", [1, 0])
+def test_quad_lds_window_and_round_two_exchange(emulator, mask, win):
+    """S360_QUAD_WIN=1 (default): the bilinear taps of both rounds come from the LDS window of I1-gradient texels placed
+    per chunk, and a wave one of whose taps leaves it gathers from global memory for that round (the generator's +-40 px
+    outliers and +-2 px noise make both happen all the time). S360_QUAD_WIN=0: global gathers in round 1 and the probes of
+    round 2 take the winner's texels from its lane (ds_bpermute) when they stay in its cell."""
+    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1], S360_QUAD_WIN=win)
+    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], S360_QUAD_WIN=win, EMU_LANE_ORDER="shuffle")
+    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_WIN=win, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
 
 
-@pytest.mark.parametrize("w,h", [(3, 2), (16, 20), (17, 21), (33, 40), (34, 41), (130, 61)])
-def test_tri_sizes(emulator, w, h):
-    """One band exactly, one row more, two bands, chunk boundaries; persistent waves taking several tickets."""
-    _run(emulator, ["tri", w, h, 2, 43, "random", 1, 1])
-    _run(emulator, ["tri", w, h, 2, 43, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1, EMU_LANE_ORDER="rev")
-
-
-@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-def test_quad_kernel_with_round_two_exchange(emulator, mask):
-    """S360_QUAD_PEEL=2: the probes of round 2 take the winner's texels from its lane (ds_bpermute) when they stay in its
-    bilinear cell, and the whole wave gathers again when one of them does not."""
-    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1], S360_QUAD_PEEL=2)
-    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], S360_QUAD_PEEL=2, EMU_LANE_ORDER="shuffle")
-    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_PEEL=2, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
-
-
-@pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-def test_tri_kernel_with_round_two_exchange(emulator, mask):
-    """S360_SWEEP_TRI=2: three lanes per pixel and the round-2 texel exchange."""
-    _run(emulator, ["tri", 70, 50, 2, 61, mask, 1, 1], S360_SWEEP_TRI=2)
-    _run(emulator, ["tri", 53, 45, 3, 62, mask, 0, 0], S360_SWEEP_TRI=2, EMU_LANE_ORDER="shuffle")
+def test_quad_lds_window_on_smooth_flows(emulator):
+    """Flows as the pipeline produces them (smooth, a few pixels of disparity): nearly every round is served by the
+    window — the emulator's counters say how many — and the bits are those of the raster-order loop."""
+    out = _run(emulator, ["quad", 160, 120, 2, 71, "smooth", 1, 1], EMU_LANE_ORDER="rev")
+    stats = [ln for ln in out.splitlines() if ln.startswith("quad window:")]
+    assert stats, out
+    frac = float(stats[-1].split("fallback fraction")[1].split()[0])
+    assert frac < 0.05, stats[-1]

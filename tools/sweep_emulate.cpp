@@ -5,9 +5,10 @@
 // hand-offs, the masked-pixel short cuts and the ticket / persistent-wave logic where no GPU is attached.
 //   sweep_emulate <lock|quad> <w> <h> <flows> <seed> <mask: none|random|bands|rows0|most> <fast: 0|1> [rowflags: 0|1]
 // Exit status 0 = bit-identical flows. Environment: EMU_LANE_ORDER=fwd|rev|shuffle, EMU_CUS, S360_QUAD_WAVES_PER_CU,
-// S360_QUAD_LDSIN (the kernels' own tuning switches).
+// S360_QUAD_WIN (the kernels' own tuning switches).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -17,6 +18,7 @@
 #include "../surround360_amd/csrc/sweep_common.hpp"
 
 using namespace s360;
+namespace s360 { extern unsigned long long g_quad_rounds, g_quad_fallbacks, g_quad_chunks, g_quad_fills; }
 
 namespace {
 PixFlowConsts consts() {  // OpticalFlowFactory.h:26-41
@@ -107,9 +109,14 @@ int main(int argc, char** argv) {
         float4 r = make_float4(0.2f * U(rng), 0.2f * U(rng), 3.f * U(rng), 3.f * U(rng));
         float2 f = make_float2(r.z + 2.f * U(rng), r.w + 2.f * U(rng));
         const unsigned k = rng();
+        if (mask == "smooth") {  // what the pipeline feeds the sweeps: a smooth disparity field with sub-pixel roughness
+          const float sx = 9.f * std::sin(0.021f * x + 0.013f * y + b) + 3.f, sy = 1.5f * std::cos(0.017f * x - 0.011f * y);
+          r.z = sx; r.w = sy;
+          f = make_float2(sx + 0.3f * U(rng), sy + 0.3f * U(rng));
+        } else
         if (k % 97 == 0) { f = make_float2(0.f, 0.f); r.z = 1e-16f; r.w = 0.f; }  // operands below the fast path's range
-        if (k % 89 == 0) f = make_float2(r.z, r.w);                              // smoothness term exactly zero
-        if (k % 83 == 0) f = make_float2(40.f * U(rng), 40.f * U(rng));          // samples clamped at the borders
+        if (mask != "smooth" && k % 89 == 0) f = make_float2(r.z, r.w);                              // smoothness term exactly zero
+        if (mask != "smooth" && k % 83 == 0) f = make_float2(40.f * U(rng), 40.f * U(rng));          // samples clamped at the borders
         bool masked = false;
         if (mask == "random") masked = (k >> 8) % 10 < 3;
         else if (mask == "bands") masked = y < (h * 5) / 8 ? true : (k >> 8) % 10 < 2;  // like a pole flow: the upper rows have no data
@@ -131,10 +138,6 @@ int main(int argc, char** argv) {
     if (kernel == "lock") {
       std::vector<unsigned char> handoff(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), 0xFF);
       launch_sweep_lock(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast);
-    } else if (kernel == "tri") {
-      std::vector<unsigned char> handoff(sweep_tri_handoff_bytes(w, h, B), 0xFF);
-      launch_sweep_tri(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,
-                       useRowflags ? rowflags.data() : nullptr);
     } else {
       std::vector<unsigned char> handoff(sweep_quad_handoff_bytes(w, h, B), 0xFF);
       launch_sweep_quad(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,
@@ -152,6 +155,9 @@ int main(int argc, char** argv) {
     std::printf("%s %dx%d flows %d dir %+d mask %s fast %d: %zu pixels updated, %zu differ, error flag %u\n", kernel.c_str(), w, h, B, dir,
                 mask.c_str(), (int)fast, changed, bad, errflag);
     if (bad || errflag) return 1;
+    if (kernel == "quad" && g_quad_rounds)
+      std::printf("quad window: %llu rounds, fallback fraction %.4f , %llu chunks, %llu fills\n", g_quad_rounds / 64,
+                  (double)g_quad_fallbacks / (double)g_quad_rounds, g_quad_chunks / 64, g_quad_fills / 64);
     flow = want;  // the backward sweep continues from the forward sweep's result, as in the pipeline
   }
   return 0;
