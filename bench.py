@@ -601,11 +601,17 @@ def main():
             ctx.comm_init_rank(ids[0], rank, world)
             ctx.set_sweep_mode("latency")
 
+            owner = parallel.pole_owners(world)  # pole unit u on rank u (2-3 ranks: the two poles on ranks 0 / 1)
+            masks, needs = parallel.unit_masks(owner, world), parallel.strip_needs(owner, world)
+
             def sharded():
                 ctx.render_pairs(p0, p1, False)
-                ctx.gather_strips(bounds, 0)  # grouped ncclSend/ncclRecv on the context stream (comm.cpp)
+                ctx.exchange_strips(bounds, needs)  # grouped ncclSend/ncclRecv on the context stream (comm.cpp)
+                if masks[rank] or rank == 0:
+                    ctx.pole_units(masks[rank], False)
+                ctx.gather_pole_layers(owner, 0)    # second grouped exchange: the warped pole layers to the root
                 if rank == 0:
-                    ctx.finish(15, False)
+                    ctx.composite(15)
             sharded()
             sync()
             n_single = 3
@@ -621,9 +627,10 @@ def main():
             if rank == 0:
                 ok = bool(np.array_equal(ctx.download_equirect(), single0))
             out["single_frame"] = {
-                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), ONE native RCCL exchange (grouped "
-                        "ncclSend/ncclRecv, s360_frame_gather_strips) gathering the strips on rank 0, which runs the 4 pole "
-                        "units and the composite" % (world, bounds),
+                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), one native RCCL exchange (grouped "
+                        "ncclSend/ncclRecv, s360_frame_exchange_strips) handing the strips to the ranks that assemble an eye, the "
+                        "pole units on ranks %s, a second grouped exchange returning their warped layers to rank 0, which "
+                        "composites" % (world, bounds, owner),
                 "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9), "rccl_ranks": world,
                 "equals_single_gpu_frame": ok}
 

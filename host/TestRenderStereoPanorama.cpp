@@ -167,10 +167,34 @@ struct Job {
   int P = 0, ncams = 0, ti = -1, bi = -1, b2 = -1;
   s360_params prm;
   s360_geometry g;
-  std::vector<s360_ctx*> ctx;  // one per GPU; ctx[0] is the root (poles, composite, output)
+  std::vector<s360_ctx*> ctx;  // one per GPU; ctx[0] is the root (composite, output)
   std::vector<int> bounds;     // pairs [bounds[r], bounds[r+1]) are rendered by ctx[r]
+  int owner[4] = {-1, -1, -1, -1};  // GPU of pole unit u (top_left, top_right, bottom_left, bottom_right); -1 = not enabled
+  std::vector<int> unitMask, need;  // per GPU: its pole units; the eyes whose complete strips it assembles
   int extW = 0;
+  s360_ctx* owner_ctx(int u) const { return ctx[owner[u] < 0 ? 0 : owner[u]]; }
+  int bottom_gpu() const { return owner[2] >= 0 ? owner[2] : 0; }
 };
+
+// Pole unit -> GPU (the reference runs the four units as four threads, TRSP:811-860). 4 or more GPUs: unit u
+// on GPU u — with pole removal both bottom units on GPU 2, where the merged bottom image is then computed once. 2 or 3
+// GPUs: the top units on GPU 0, the bottom units on GPU 1 (each needs one pole image, one FlowEngine batch of two flows).
+void assign_pole_units(Job& J) {
+  const int G = (int)J.ctx.size();
+  J.unitMask.assign(G, 0);
+  J.need.assign(G, 0);
+  for (int u = 0; u < 4; ++u) {
+    const bool on = u < 2 ? J.prm.enable_top : J.prm.enable_bottom;
+    if (!on) { J.owner[u] = -1; continue; }
+    int r = 0;
+    if (G >= 4) r = (J.prm.enable_pole_removal && u == 3) ? 2 : u;
+    else if (G >= 2) r = u < 2 ? 0 : 1;
+    J.owner[u] = r;
+    J.unitMask[r] |= 1 << u;
+    J.need[r] |= 1 << (u & 1);  // poleToSideFlowThread reads the whole side panorama of its eye
+  }
+  J.need[0] = 3;  // the root composites both eyes
+}
 
 FrameInputs load_frame(const Job& J, const std::string& frame) {
   FrameInputs in;
@@ -202,7 +226,7 @@ FrameInputs load_frame(const Job& J, const std::string& frame) {
   return in;
 }
 
-// every GPU gets the side images its pairs touch; the root also gets the pole images (asynchronous: upload stream)
+// every GPU gets the side images its pairs touch and the pole images of its pole units (asynchronous: upload stream)
 void upload_frame(const Job& J, const FrameInputs& in) {
   const int G = (int)J.ctx.size();
   for (int r = 0; r < G; ++r) {
@@ -211,12 +235,14 @@ void upload_frame(const Job& J, const FrameInputs& in) {
     for (int k = 0; k < J.P; ++k)
       if (need[k]) ck(s360_frame_upload_side(J.ctx[r], k, in.side[k].px.data(), in.side[k].w, in.side[k].h, in.side[k].c), J.ctx[r]);
   }
-  s360_ctx* root = J.ctx[0];
-  if (J.prm.enable_top) ck(s360_frame_upload_top(root, in.top.px.data(), in.top.w, in.top.h), root);
-  if (J.prm.enable_bottom) {
-    ck(s360_frame_upload_bottom(root, in.bottom.px.data(), in.bottom.w, in.bottom.h), root);
-    if (J.prm.enable_pole_removal)
-      ck(s360_frame_upload_pole_removal(root, in.bottom2.px.data(), in.mask1.px.data(), in.mask2.px.data(), in.bottom.w, in.bottom.h), root);
+  for (int r = 0; r < G; ++r) {  // the pole images go to the GPUs that run units of that pole
+    s360_ctx* c = J.ctx[r];
+    if (J.unitMask[r] & 3) ck(s360_frame_upload_top(c, in.top.px.data(), in.top.w, in.top.h), c);
+    if (J.unitMask[r] & 12) {
+      ck(s360_frame_upload_bottom(c, in.bottom.px.data(), in.bottom.w, in.bottom.h), c);
+      if (J.prm.enable_pole_removal)
+        ck(s360_frame_upload_pole_removal(c, in.bottom2.px.data(), in.mask1.px.data(), in.mask2.px.data(), in.bottom.w, in.bottom.h), c);
+    }
   }
 }
 
@@ -246,8 +272,8 @@ void load_prev_state(const Job& J, const std::string& prev) {
       ck(s360_frame_set_prev_side(J.ctx[r], i, fl.data(), fr.data(), L.px.data(), R.px.data()), J.ctx[r]);
     }
   }
-  s360_ctx* root = J.ctx[0];
   if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:95-110
+    s360_ctx* root = J.ctx[J.bottom_gpu()];  // the GPU that merges the bottom cameras
     int w = 0, h = 0;
     if (s360_read_flow_from_file((flowPrevDir + "/flow_bottom_secondary.bin").c_str(), nullptr, &w, &h, 0) < 0)
       die(std::string("bad previous flow file: flow_bottom_secondary.bin: ") + s360_last_error(nullptr));
@@ -270,13 +296,14 @@ void load_prev_state(const Job& J, const std::string& prev) {
     const pngio::Image Fi = load_png(imgPrevDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png", true);
     if (S.c != 4 || Fi.c != 4 || S.w != J.extW || S.h != rows || Fi.w != J.extW || Fi.h != rows)
       die("previous extended pole images have the wrong size/channels");
-    ck(s360_frame_set_prev_pole(root, u, pf.data(), S.px.data(), Fi.px.data()), root);
+    ck(s360_frame_set_prev_pole(J.owner_ctx(u), u, pf.data(), S.px.data(), Fi.px.data()), J.owner_ctx(u));  // a unit's state lives where it runs
   }
 }
 
 // Enqueue one frame. One GPU: the whole frame on its stream. G GPUs (TRSP:320-385): every GPU renders its
-// block of pairs, ONE grouped RCCL exchange gathers the strips on the root, the root runs the pole units and the
-// composite. One host thread per GPU for the collective call (single-process RCCL).
+// block of pairs, ONE grouped RCCL exchange hands the strips to the GPUs that assemble an eye (the root: both; the owner
+// of a pole unit: its eye), the pole units run where assign_pole_units put them, a second grouped exchange returns their
+// warped layers to the root, the root composites. One host thread per GPU for the collective calls (single-process RCCL).
 void render_frame(const Job& J, bool usePrev) {
   const int G = (int)J.ctx.size();
   if (G == 1) {
@@ -286,9 +313,12 @@ void render_frame(const Job& J, bool usePrev) {
   std::vector<std::thread> th;
   for (int r = 0; r < G; ++r)
     th.emplace_back([&, r] {
-      ck(s360_frame_render_pairs(J.ctx[r], J.bounds[r], J.bounds[r + 1], usePrev ? 1 : 0), J.ctx[r]);
-      ck(s360_frame_gather_strips(J.ctx[r], J.bounds.data(), 0), J.ctx[r]);
-      if (r == 0) ck(s360_frame_finish(J.ctx[0], 15, usePrev ? 1 : 0), J.ctx[0]);
+      s360_ctx* c = J.ctx[r];
+      ck(s360_frame_render_pairs(c, J.bounds[r], J.bounds[r + 1], usePrev ? 1 : 0), c);
+      ck(s360_frame_exchange_strips(c, J.bounds.data(), J.need.data()), c);  // exchange 1: strips to whoever assembles that eye
+      if (J.unitMask[r] || r == 0) ck(s360_frame_pole_units(c, J.unitMask[r], usePrev ? 1 : 0), c);
+      ck(s360_frame_gather_pole_layers(c, J.owner, 0), c);                    // exchange 2: warped pole layers to the root
+      if (r == 0) ck(s360_frame_composite(c, 15), c);
     });
   for (auto& t : th) t.join();
 }
@@ -317,8 +347,8 @@ void write_state(const Job& J, const std::string& frame) {
       ck(s360_save_flow_to_file((flowDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
     }
   }
-  s360_ctx* root = J.ctx[0];
   if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
+    s360_ctx* root = J.ctx[J.bottom_gpu()];
     ck(s360_frame_get_u8(root, "bottom_image", 0, whc, nullptr), root);
     std::vector<uint8_t> bimg((size_t)whc[0] * whc[1] * 4);
     std::vector<float> bfl((size_t)whc[0] * whc[1] * 2);
@@ -334,6 +364,7 @@ void write_state(const Job& J, const std::string& frame) {
     const int rows = u < 2 ? g.top_rows : g.bottom_rows;
     std::vector<uint8_t> e((size_t)J.extW * rows * 4);
     std::vector<float> pf((size_t)J.extW * rows * 2);
+    s360_ctx* root = J.owner_ctx(u);
     ck(s360_frame_get_u8(root, "extended_side", u, whc, e.data()), root);
     save_png(flowImagesDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
     ck(s360_frame_get_u8(root, "extended_fisheye", u, whc, e.data()), root);
@@ -415,6 +446,7 @@ int main(int argc, char** argv) {
   J.extW = int(float(prm.eqr_width) * 1.2f);
   J.bounds.assign(1, 0);
   for (int r = 0; r < G; ++r) J.bounds.push_back(J.bounds.back() + J.P / G + (r < J.P % G ? 1 : 0));  // 14 over 8 -> 2,2,2,2,2,2,1,1
+  assign_pole_units(J);
   if (G > 1) {
     if (s360_comm_init_all(J.ctx.data(), G) < 0) die(s360_last_error(nullptr));
     for (int r = 0; r < G; ++r) ck(s360_frame_set_partition(J.ctx[r], J.bounds[r], J.bounds[r + 1]), J.ctx[r]);

@@ -114,7 +114,13 @@ int s360_derive_geometry(const s360_camera* cams, int n_cams, const s360_params*
  * (degrees). Host only. */
 int s360_pole_ramp(const s360_camera* cams, int n_cams, float out4[4]);
 
-/* ---- context: one per device; owns streams, persistent HBM buffers, cached warp maps -------- */
+/* ---- context: one per device; owns streams, persistent HBM buffers, cached warp maps --------
+ * Thread safety: every entry point that takes a context locks it for the duration of the call, so any number of host
+ * threads may call into ONE context concurrently — the 14 std::threads of TRSP:320-335, each with "its own" flow
+ * operator (NovelView.cpp:281-298), may share it; their calls execute one after the other. Calls on different contexts
+ * run in parallel. For throughput hand the pairs over together (s360_compute_optical_flow_batch, s360_frame_render):
+ * 14 serialised single-pair calls cost 14 flow latencies. With concurrent callers read a failed call's message with
+ * s360_last_error(NULL) (the calling thread's own last error); s360_last_error(ctx) is the context's most recent one. */
 /* cams: the whole rig (side cameras in rig order + pole cameras), as RigDescription holds it. */
 int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams, const s360_params* params);
 void s360_destroy(s360_ctx* ctx);
@@ -257,6 +263,24 @@ int s360_comm_init_all(s360_ctx* const* ctxs, int n);
 int s360_comm_destroy(s360_ctx* ctx);
 /* bounds: nranks + 1 non-decreasing pair indices from 0 to n_side. */
 int s360_frame_gather_strips(s360_ctx* ctx, const int* bounds, int root);
+/* The pole units on several GPUs as well (SURVEY §8e second stage; the reference runs its four poleToSideFlowThread
+ * threads concurrently, TRSP:811-860). Per frame, on every rank, all enqueued on s360_stream():
+ *   s360_frame_render_pairs(block of the rank)
+ *   s360_frame_exchange_strips(bounds, need_mask)   need_mask[r]: eyes (bit 0 left, bit 1 right) whose complete strips
+ *                                                   rank r needs: 3 for the root and for a rank that owns units of
+ *                                                   both eyes, 1 << eye for the owner of one unit, 0 otherwise
+ *   s360_frame_pole_units(pole_mask of the rank, use_prev)   panoramas + flow + warp of the rank's units (bit u:
+ *                                                   0 top_left, 1 top_right, 2 bottom_left, 3 bottom_right); the
+ *                                                   rank needs the pole image(s) of its units (s360_frame_upload_top /
+ *                                                   _bottom) and keeps those units' temporal state
+ *   s360_frame_gather_pole_layers(owner, root)      owner[u] = rank of unit u (-1: not enabled): the warped layers
+ *                                                   (eqr_width x pole rows) travel to the root, one grouped exchange
+ *   s360_frame_composite(mask of all enabled units) root only: flattenLayersDeghostPreferBase x4, sharpen, resize, stack
+ * s360_frame_finish(mask) == s360_frame_pole_units(mask) + s360_frame_composite(mask) on one context. */
+int s360_frame_exchange_strips(s360_ctx* ctx, const int* bounds, const int* need_mask /* [nranks] */);
+int s360_frame_pole_units(s360_ctx* ctx, int pole_mask, int use_prev);
+int s360_frame_gather_pole_layers(s360_ctx* ctx, const int owner[4], int root);
+int s360_frame_composite(s360_ctx* ctx, int pole_mask);
 /* Self-test for single-GPU boxes: one grouped ncclSend + ncclRecv of this rank to itself, eye-0 strip of pair
  * src_pair into the slot of dst_pair, on s360_stream(). */
 int s360_comm_loopback(s360_ctx* ctx, int src_pair, int dst_pair);

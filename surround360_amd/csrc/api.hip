@@ -621,6 +621,18 @@ int s360_comm_destroy(s360_ctx* c) {
 int s360_frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
   return guard(c, [&] { need(c && bounds, "null argument"); frame_gather_strips(c, bounds, root); });
 }
+int s360_frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask) {
+  return guard(c, [&] { need(c && bounds && need_mask, "null argument"); frame_exchange_strips(c, bounds, need_mask); });
+}
+int s360_frame_gather_pole_layers(s360_ctx* c, const int owner[4], int root) {
+  return guard(c, [&] { need(c && owner, "null argument"); frame_gather_pole_layers(c, owner, root); });
+}
+int s360_frame_pole_units(s360_ctx* c, int pole_mask, int use_prev) {
+  return guard(c, [&] { need(c, "null ctx"); frame_pole_units(c, pole_mask, use_prev); });
+}
+int s360_frame_composite(s360_ctx* c, int pole_mask) {
+  return guard(c, [&] { need(c, "null ctx"); frame_composite(c, pole_mask); });
+}
 int s360_comm_loopback(s360_ctx* c, int src_pair, int dst_pair) {
   return guard(c, [&] { need(c, "null ctx"); comm_loopback(c, src_pair, dst_pair); });
 }

@@ -105,34 +105,38 @@ void comm_destroy(s360_ctx* c) {
   c->comm_rank = 0;
 }
 
-// bounds[r] .. bounds[r+1]: the pairs rank r rendered (contiguous, possibly empty). Enqueued on the context stream:
-// ordered after this rank's s360_frame_render_pairs and before its s360_frame_finish.
-void frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
+// bounds[r] .. bounds[r+1]: the pairs rank r rendered (contiguous, possibly empty). need_mask[r]: the eyes (bit 0 left,
+// bit 1 right) whose COMPLETE set of strips rank r needs next — the root of the composite needs both, the owner of a pole
+// unit the eye(s) of its unit(s) (poleToSideFlowThread reads the whole side panorama of its eye, TRSP:388-398), the other
+// ranks nothing. One ncclGroup: every rank sends its block of eye e to every other rank that needs eye e and receives
+// the blocks it needs straight into [eye][pair][camH][stripW] at the pair's offset. Enqueued on the context stream:
+// ordered after this rank's s360_frame_render_pairs and before its pole units / composite.
+void frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask) {
   if (!c->comm) throw Error(S360_ERR_STATE, "no communicator: call s360_comm_init_rank / s360_comm_init_all first");
   Rccl& R = rccl();
   FrameState& F = frame_state(c);
   const int P = F.P, nr = c->comm_size, me = c->comm_rank;
-  if (root < 0 || root >= nr) throw Error(S360_ERR_INVALID_ARG, "bad root");
   if (bounds[0] != 0 || bounds[nr] != P) throw Error(S360_ERR_INVALID_ARG, "bounds must cover the pairs [0, n_side)");
-  for (int r = 0; r < nr; ++r)
+  for (int r = 0; r < nr; ++r) {
     if (bounds[r + 1] < bounds[r]) throw Error(S360_ERR_INVALID_ARG, "bounds must be non-decreasing");
+    if (need_mask[r] & ~3) throw Error(S360_ERR_INVALID_ARG, "need_mask: bit 0 = left eye, bit 1 = right eye");
+  }
   const size_t per = (size_t)c->g.cam_image_height * (c->P.eqr_width / P) * sizeof(uchar4);
   F.strips.ensure(2 * P * per);
   uint8_t* base = F.strips.as<uint8_t>();
   if (nr > 1) {
     nccl_ck(R.GroupStart(), "ncclGroupStart");
     ncclResult_t rc = ncclSuccess;
+    const int mine = bounds[me + 1] - bounds[me];
     for (int eye = 0; eye < 2 && rc == ncclSuccess; ++eye) {
       uint8_t* e = base + (size_t)eye * P * per;
-      if (me == root) {
-        for (int r = 0; r < nr && rc == ncclSuccess; ++r) {
-          const int n = bounds[r + 1] - bounds[r];
-          if (r == root || n == 0) continue;
+      for (int r = 0; r < nr && rc == ncclSuccess; ++r) {
+        if (r == me) continue;
+        const int n = bounds[r + 1] - bounds[r];
+        if (mine > 0 && ((need_mask[r] >> eye) & 1))  // r assembles this eye: it gets my block
+          rc = R.Send(e + bounds[me] * per, mine * per, ncclUint8, r, (ncclComm_t)c->comm, c->st);
+        if (rc == ncclSuccess && n > 0 && ((need_mask[me] >> eye) & 1))  // I assemble this eye: r's block comes in
           rc = R.Recv(e + bounds[r] * per, n * per, ncclUint8, r, (ncclComm_t)c->comm, c->st);
-        }
-      } else {
-        const int n = bounds[me + 1] - bounds[me];
-        if (n > 0) rc = R.Send(e + bounds[me] * per, n * per, ncclUint8, root, (ncclComm_t)c->comm, c->st);
       }
     }
     const ncclResult_t rc2 = R.GroupEnd();
@@ -141,6 +145,53 @@ void frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
   }
   // frame pipelining: the finish stream must also wait for the gathered strips
   if (c->pipeline && c->evSideDone) S360_HIP(hipEventRecord(c->evSideDone, c->st));
+}
+// the gather of SURVEY 8e's first variant: only the root assembles (it runs all pole units and the composite)
+void frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
+  if (!c->comm) throw Error(S360_ERR_STATE, "no communicator: call s360_comm_init_rank / s360_comm_init_all first");
+  if (root < 0 || root >= c->comm_size) throw Error(S360_ERR_INVALID_ARG, "bad root");
+  std::vector<int> need(c->comm_size, 0);
+  need[root] = 3;
+  frame_exchange_strips(c, bounds, need.data());
+}
+
+// The second exchange of a frame whose pole units run on several GPUs (the reference's four
+// poleToSideFlowThread threads, TRSP:811-860): owner[u] is the rank that ran unit u (0 top_left, 1 top_right,
+// 2 bottom_left, 3 bottom_right; -1 = unit not enabled). Each owner other than the root sends the unit's warped layer —
+// the pole rows; below them the layer is transparent padding (TRSP:538-546) — and the root receives it where its own
+// units' layers live, ready for s360_frame_composite. One ncclGroup on the context stream.
+void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root) {
+  if (!c->comm) throw Error(S360_ERR_STATE, "no communicator: call s360_comm_init_rank / s360_comm_init_all first");
+  Rccl& R = rccl();
+  FrameState& F = frame_state(c);
+  const int nr = c->comm_size, me = c->comm_rank;
+  if (root < 0 || root >= nr) throw Error(S360_ERR_INVALID_ARG, "bad root");
+  const int W = c->P.eqr_width, H = c->P.eqr_height;
+  const size_t en = (size_t)W * H * sizeof(uchar4);
+  int todo = 0;
+  for (int u = 0; u < 4; ++u) {
+    if (owner[u] >= nr) throw Error(S360_ERR_INVALID_ARG, "owner: not a rank");
+    if (owner[u] < 0 || owner[u] == root) continue;
+    const size_t bytes = (size_t)W * (u < 2 ? c->g.top_rows : c->g.bottom_rows) * sizeof(uchar4);
+    if (me == owner[u] && !F.poleWarped[u].p) throw Error(S360_ERR_STATE, "pole unit " + std::to_string(u) + " has not been run on its owner");
+    if (me == root) {
+      F.poleWarped[u].ensure(en);
+      S360_HIP(hipMemsetAsync(F.poleWarped[u].as<uint8_t>() + bytes, 0, en - bytes, c->st));
+    }
+    if (me == owner[u] || me == root) ++todo;
+  }
+  if (!todo) return;
+  nccl_ck(R.GroupStart(), "ncclGroupStart");
+  ncclResult_t rc = ncclSuccess;
+  for (int u = 0; u < 4 && rc == ncclSuccess; ++u) {
+    if (owner[u] < 0 || owner[u] == root) continue;
+    const size_t bytes = (size_t)W * (u < 2 ? c->g.top_rows : c->g.bottom_rows) * sizeof(uchar4);
+    if (me == owner[u]) rc = R.Send(F.poleWarped[u].p, bytes, ncclUint8, root, (ncclComm_t)c->comm, c->st);
+    else if (me == root) rc = R.Recv(F.poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
+  }
+  const ncclResult_t rc2 = R.GroupEnd();
+  nccl_ck(rc, "ncclSend/ncclRecv");
+  nccl_ck(rc2, "ncclGroupEnd");
 }
 
 // One grouped send+recv of a rank to itself through the same code path (pair `src` of eye 0 into the slot of pair

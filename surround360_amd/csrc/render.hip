@@ -587,15 +587,22 @@ struct FinishStream {
 // Pole stage + composite of a set of frame slots: per slot panorama assembly, pole projections and the flow inputs of
 // the enabled pole units; then the pole flows of ALL slots in one FlowEngine batch (two when the top and bottom pole
 // projections differ in height); then per slot warp, composite, sharpen / final resize / stacking.
-static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_mask, int use_prev) {
+// `phases`: 1 = panorama assembly + the pole units of `pole_mask` (their warped layers stay in F.poleWarped), 2 = composite
+// of the layers of `composite_mask` (computed here or received: frame_gather_pole_layers) + sharpen / resize / stack.
+// s360_frame_finish is both phases with the same mask; a frame whose pole units are spread over GPUs
+// runs phase 1 on every owner and phase 2 on the root.
+static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_mask, int use_prev, int phases = 3,
+                         int composite_mask = -1) {
+  if (composite_mask < 0) composite_mask = pole_mask;
+  if (!(phases & 1)) pole_mask = 0;
   const s360_geometry& g = c->g;
   Profiler& prof = c->prof;
   FinishStream finishStream(c);
   hipStream_t st = c->st;
   const int P = (int)c->rig.side.size(), W = c->P.eqr_width, H = c->P.eqr_height, camH = g.cam_image_height, stripW = W / P;
   const size_t en = (size_t)W * H;
-  if (!c->P.enable_top) pole_mask &= ~3;
-  if (!c->P.enable_bottom) pole_mask &= ~12;
+  if (!c->P.enable_top) { pole_mask &= ~3; composite_mask &= ~3; }
+  if (!c->P.enable_bottom) { pole_mask &= ~12; composite_mask &= ~12; }
   const int rowsT = g.top_rows, rowsB = g.bottom_rows;
   const int extW = int(float(W) * 1.2f);  // TRSP:400-401
   const size_t xs = (size_t)extW * std::max(rowsT, rowsB);  // slot stride of the extended images / pole flows
@@ -615,6 +622,10 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
   for (int k : slotIds) {
     SlotScope ss(c, k);
     FrameState& F = frame_state(c);
+    if (!(phases & 1)) {
+      if (!F.pano[0].p || !F.pano[1].p) throw Error(S360_ERR_STATE, "composite without assembled panoramas (s360_frame_pole_units first)");
+      continue;
+    }
     if (!F.strips.p) throw Error(S360_ERR_STATE, "no strips rendered for this frame");
     for (int e = 0; e < 2; ++e) F.pano[e].ensure(en * sizeof(uchar4));
     F.panoTmp.ensure(en * sizeof(uchar4));
@@ -677,7 +688,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         }
     }
   }
-  if (c->pipeline) {  // the next frame's novel views may overwrite the strips from here on
+  if (c->pipeline && (phases & 1)) {  // the next frame's novel views may overwrite the strips from here on
     S360_HIP(hipEventRecord(c->evStripsFree, st));
     c->haveStripsFree = true;
   }
@@ -745,16 +756,21 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       F.have_prev_pole = true;
       F.last_pole = cur;
     }
+    if (!(phases & 2)) continue;
     {
       ProfScope ps(prof, "flatten");  // TRSP:864-885
+      F.panoTmp.ensure(en * sizeof(uchar4));
+      for (int u = 0; u < 4; ++u)
+        if ((composite_mask & (1 << u)) && !F.poleWarped[u].p)
+          throw Error(S360_ERR_STATE, "composite: the warped layer of pole unit " + std::to_string(u) + " is neither computed nor received");
       for (int e = 0; e < 2; ++e) {
-        if (pole_mask & (1 << e)) {
+        if (composite_mask & (1 << e)) {
           launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 0,
                          F.tab.dev);
           std::swap(F.pano[e].p, F.panoTmp.p);
           std::swap(F.pano[e].cap, F.panoTmp.cap);
         }
-        if (pole_mask & (4 << e)) {
+        if (composite_mask & (4 << e)) {
           launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[2 + e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 1,
                          F.tab.dev);
           std::swap(F.pano[e].p, F.panoTmp.p);
@@ -809,6 +825,8 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
   }
 }
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev) { finish_stage(c, {c->slot}, pole_mask, use_prev); }
+void frame_pole_units(s360_ctx* c, int pole_mask, int use_prev) { finish_stage(c, {c->slot}, pole_mask, use_prev, 1, 0); }
+void frame_composite(s360_ctx* c, int pole_mask) { finish_stage(c, {c->slot}, 0, 0, 2, pole_mask); }
 
 // Every slot at once (independent frames of a multi-stream job): one launch sequence, the 28 side flows of every slot
 // in ONE batch of the flow kernels, the 4 pole flows of every slot in another. Results per slot are those of

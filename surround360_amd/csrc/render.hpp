@@ -76,6 +76,9 @@ void frame_upload_raw(s360_ctx* c, struct s360_isp* isp, int which, const uint16
 void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w, int h);
 void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev);
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev);
+// the two halves of frame_finish for a frame whose pole units are spread over GPUs
+void frame_pole_units(s360_ctx* c, int pole_mask, int use_prev);
+void frame_composite(s360_ctx* c, int pole_mask);
 // all slots at once: per-frame kernels slot by slot, the side flows of all slots in one FlowEngine batch, the pole
 // flows of all slots in another
 void frame_render_batch(s360_ctx* c, int use_prev);
@@ -89,6 +92,8 @@ void comm_init_rank(s360_ctx* c, const void* id128, int rank, int nranks);
 void comm_init_all(s360_ctx* const* ctxs, int n);
 void comm_destroy(s360_ctx* c);
 void frame_gather_strips(s360_ctx* c, const int* bounds, int root);
+void frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask);
+void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root);
 void comm_loopback(s360_ctx* c, int src_pair, int dst_pair);
 
 // operator-level helpers on device buffers

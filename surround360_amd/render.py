@@ -271,6 +271,21 @@ class Context:
         arr = (C.c_int * len(bounds))(*bounds)
         self._ck(lib().s360_frame_gather_strips(self.h, arr, int(root)))
 
+    def exchange_strips(self, bounds, need_mask):
+        b = (C.c_int * len(bounds))(*bounds)
+        n = (C.c_int * len(need_mask))(*need_mask)
+        self._ck(lib().s360_frame_exchange_strips(self.h, b, n))
+
+    def pole_units(self, pole_mask, use_prev=False):
+        self._ck(lib().s360_frame_pole_units(self.h, int(pole_mask), int(bool(use_prev))))
+
+    def gather_pole_layers(self, owner, root=0):
+        o = (C.c_int * 4)(*owner)
+        self._ck(lib().s360_frame_gather_pole_layers(self.h, o, int(root)))
+
+    def composite(self, pole_mask=15):
+        self._ck(lib().s360_frame_composite(self.h, int(pole_mask)))
+
     def comm_loopback(self, src_pair, dst_pair):
         self._ck(lib().s360_comm_loopback(self.h, int(src_pair), int(dst_pair)))
 

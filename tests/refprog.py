@@ -111,8 +111,9 @@ CASES = {
 }
 
 
-def run_case(exe, work, rig_path, name, timeout=900):
-    """Runs the frames of a case through the program (chained with --prev_frame_data_dir); returns the output directory."""
+def run_case(exe, work, rig_path, name, timeout=900, more_args=(), env=None):
+    """Runs the frames of a case through the program (chained with --prev_frame_data_dir); returns the output directory.
+    more_args / env: opt-in flags of OUR program only (--num_gpus ...) and variables for its process."""
     frames, extra = CASES[name]
     imgs, out, mdir = write_inputs(work, rig_path, frames, masks="--enable_pole_removal" in extra)
     prev = "NONE"
@@ -127,7 +128,8 @@ def run_case(exe, work, rig_path, name, timeout=900):
             cmd += ["--log_dir", os.path.join(out, "logs")]
         if mdir:
             cmd += ["--bottom_pole_masks_dir", mdir]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        cmd += list(more_args)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
         assert r.returncode == 0, "%s frame %s: rc %d\n%s" % (name, f, r.returncode, r.stderr[-2000:])
         prev = f
     return out

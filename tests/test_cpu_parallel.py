@@ -1,13 +1,24 @@
-"""N>1 path on CPU: world_size-2 gloo run of the pair partition + strip gather (surround360_amd/parallel.py)."""
+"""The N>1 path without GPUs, through the NATIVE exchange code (surround360_amd/csrc/comm.cpp), not a Python twin:
+
+* the policy layer (surround360_amd/parallel.py: pair blocks, pole-unit owners, which rank assembles which eye);
+* host/TestRenderStereoPanorama --num_gpus 2 / 3 / 8 linked against the emulated library (tools/emu/, ranks = host
+  threads, the RCCL stand-in of tools/hip_wave_shim/rccl_emu.cpp): s360_frame_exchange_strips with unequal and empty
+  blocks, pole units spread over the ranks, s360_frame_gather_pole_layers, temporal state per owner over two chained
+  frames — every file equal to the REFERENCE program's (tests/golden/refprogram_golden.json);
+* world_size 2 and 3 as separate PROCESSES under torch.distributed (`gloo`, 127.0.0.1), the way bench.py runs on a
+  node: tests/mp_sharded_frame.py, the emulated RCCL talking through files."""
+import json
 import os
+import subprocess
+import sys
 
-import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
+import refprog
+import rigutil
 from surround360_amd import parallel
+
+ROOT = refprog.ROOT
 
 
 def test_partition_pairs():
@@ -18,36 +29,45 @@ def test_partition_pairs():
     assert b[-1] == 14 and all(0 <= b[i + 1] - b[i] <= 1 for i in range(16))
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    P, camH, stripW = 14, 6, 5
-    bounds = parallel.partition_pairs(P, world)
-    strips = torch.zeros((2, P, camH, stripW, 4), dtype=torch.uint8)
-    for p in range(bounds[rank], bounds[rank + 1]):
-        for eye in range(2):
-            strips[eye, p] = 10 * p + eye + 1  # what this rank "rendered"
-    parallel.gather_strips(strips, bounds, rank, world, 0)
-    if rank == 0:
-        exp = torch.zeros_like(strips)
-        for p in range(P):
-            for eye in range(2):
-                exp[eye, p] = 10 * p + eye + 1
-        q.put(bool(torch.equal(strips, exp)))
-    dist.barrier()
-    dist.destroy_process_group()
+def test_pole_unit_assignment_matches_survey_8e():
+    assert parallel.pole_owners(8) == [0, 1, 2, 3]  # "pole unit u -> devices 0-3"
+    assert parallel.pole_owners(4, pole_removal=True) == [0, 1, 2, 2]  # the merged bottom image is computed once
+    assert parallel.pole_owners(2) == [0, 0, 1, 1] and parallel.pole_owners(3) == [0, 0, 1, 1]
+    assert parallel.pole_owners(1) == [0, 0, 0, 0]
+    assert parallel.pole_owners(8, enable_top=False) == [-1, -1, 2, 3]
+    own = parallel.pole_owners(8)
+    assert parallel.unit_masks(own, 8) == [1, 2, 4, 8, 0, 0, 0, 0]
+    assert parallel.strip_needs(own, 8) == [3, 2, 1, 2, 0, 0, 0, 0]  # the root composites both eyes; unit u reads eye u & 1
+    assert parallel.strip_needs(parallel.pole_owners(2), 2) == [3, 3]
+
+
+@pytest.fixture(scope="module")
+def emu_programs():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools"), "-s", "libs360_emu.so", "emu_programs"])
+    return os.path.join(ROOT, "tools", "emu")
+
+
+@pytest.mark.parametrize("name,gpus", [("two_frames", 2), ("two_frames", 3), ("two_frames", 8), ("pole_removal", 4)])
+def test_sharded_program_writes_what_the_reference_program_writes(tmp_path, emu_programs, name, gpus):
+    """--num_gpus G: pairs in blocks (8 ranks: 2,2,2,2,2,2,1,1), the strips exchanged once, the pole units on their owners
+    (with their temporal state across the chained frames), the warped layers gathered, the composite on rank 0 — the 140
+    (134) files of the case, digest for digest the reference program's."""
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
+                                  refprog.CAM / 2048.0)
+    out = refprog.run_case(os.path.join(emu_programs, "TestRenderStereoPanorama"), str(tmp_path), rig, name,
+                           more_args=["--num_gpus", str(gpus)], env={"EMU_DEVICES": str(gpus)})
+    got = refprog.digests(out, name)
+    golden = json.load(open(refprog.GOLDEN))[name]
+    assert sorted(got) == sorted(golden)
+    differing = sorted(k for k in golden if got[k] != golden[k])
+    assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_gather_strips_gloo(world):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
+def test_sharded_frame_across_processes_gloo(tmp_path, emu_programs, world):
     port = 29500 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    ok = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert ok
+    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "mp_sharded_frame.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "SHARDED_FRAME_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -90,7 +90,7 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
 // everything is synchronous here: a kernel has run when its launch returns, copies are memcpy, streams and events are names
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { const char* e = std::getenv("EMU_DEVICES"); *n = e && std::atoi(e) > 0 ? std::atoi(e) : 1; return hipSuccess; }  // EMU_DEVICES: emulated GPUs (multi-GPU host program runs)
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
