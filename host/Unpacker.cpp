@@ -43,7 +43,7 @@ struct Footage {
   size_t size = 0;
   Header md{};
   size_t frame_size() const { return (size_t)md.width * md.height * md.bitsPerPixel / 8; }
-  size_t frames() const { return md.numberOfCameras ? (size - 4096) / frame_size() / md.numberOfCameras : 0; }
+  size_t frames() const { return (md.numberOfCameras && frame_size() && size >= 4096) ? (size - 4096) / frame_size() / md.numberOfCameras : 0; }
   const uint8_t* frame(size_t f, size_t cam) const {
     const uint8_t* p = base + 4096 + (md.numberOfCameras * f + cam) * frame_size();
     if (p + frame_size() > base + size) throw std::runtime_error("frame out of range for " + path);

@@ -9,7 +9,11 @@
 //   * YCbCr -> RGB with libjpeg's 16-bit fixed-point tables (jdcolor.c); greyscale is replicated into B, G, R.
 // tests/test_cpu_host.py compares it bit for bit with PIL (libjpeg-turbo, whose SIMD paths are bit-exact with libjpeg's C
 // code) over subsamplings, qualities, odd sizes and restart markers. Progressive, arithmetic-coded, 12-bit and CMYK files and
-// files with an EXIF orientation other than "top-left" (OpenCV >= 3.1 rotates those) are rejected with a message.
+// files with an EXIF orientation other than "top-left" (OpenCV >= 3.1 rotates those) are rejected with a message, and so are
+// the 4:4:0 (h1v2) and 4:1:1 samplings (cv::imread decodes them; cameras do not write them).
+// Assumption, stated: the OpenCV being replaced links libjpeg-turbo or libjpeg 6b-8 (merged h2v1 / h2v2 fancy upsampling as
+// above). An OpenCV built with its bundled IJG libjpeg 9 upsamples chroma by DCT scaling and yields different pixels for
+// subsampled files; nothing here reproduces that.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -64,7 +68,11 @@ class Reader {
       const size_t len = be16(pos_);
       if (len < 2 || pos_ + len > d_.size()) fail("truncated segment");
       const size_t seg = pos_ + 2, end = pos_ + len;
-      if (m == 0xC0 || m == 0xC1) { read_sof(seg, end); sof = true; }
+      if (m == 0xC0 || m == 0xC1) {
+        if (sof) fail("second frame header in one JPEG");  // (hierarchical files only; the geometry below is per frame)
+        read_sof(seg, end);
+        sof = true;
+      }
       else if (m == 0xC2) fail("progressive JPEG is not supported");
       else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) fail("this JPEG process (lossless / arithmetic / hierarchical) is not supported");
       else if (m == 0xCC) fail("arithmetic-coded JPEG is not supported");
@@ -112,6 +120,7 @@ class Reader {
   }
   void read_sof(size_t p, size_t end) {
     if (end - p < 6) fail("bad frame header");
+    hmax_ = vmax_ = 1;
     if (d_[p] != 8) fail("only 8-bit JPEG is supported");
     h_ = (int)be16(p + 1);
     w_ = (int)be16(p + 3);
@@ -184,6 +193,7 @@ class Reader {
     }
   }
   void read_sos(size_t p, size_t end) {
+    if (end <= p) fail("empty scan header");
     const int n = d_[p];
     if (n != ncomp_ || end - p < 1 + (size_t)n * 2 + 3) fail("only single-scan (non-interleaved-free) baseline JPEG is supported");
     for (int i = 0; i < n; ++i) {

@@ -357,13 +357,22 @@ void s360_isp_destroy(s360_isp* isp);
 int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* out_bgr);
 /* The same from the sensor's packed bytes as Unpacker reads them from a .bin container (Unpacker.cpp:136-143;
  * RawConverter::convert8Frame / convert12Frame, RawConverter.cpp:15-59): bits 8 (w * h bytes) or 12 (3 * w / 2 bytes
- * per row, even w); widened to 16 bits on the device, then as s360_isp_process. */
+ * per row, even w); widened to 16 bits on the device, then as s360_isp_process.
+ * NOT the reference Unpacker's pixels: camera_isp/Unpacker.cpp:24,178 instantiates CameraIspPipe, the Halide-generated
+ * pipeline, whose arithmetic differs from the soft CameraIsp (CameraIsp.h) and cannot be built or restated here (no
+ * Halide). This entry point — and host/Unpacker on top of it — runs the SOFT-ISP arithmetic, the one Raw2Rgb runs
+ * without --accelerate (Raw2Rgb.cpp:441-456), pinned bit for bit to CameraIsp.h compiled from the reference.
+ * Also not available (S360_ERR_INVALID_ARG): demosaic_filter 1 = FREQUENCY_DM_FILTER (CameraIsp.h:1175-1192, needs
+ * cv::dct) and stuckPixelRadius > 0 (CameraIsp.h:1024-1104); no shipped ISP configuration uses either. */
 int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr);
 /* A camera's raw Bayer frame through the ISP straight into a frame's source slot, on the context's upload stream and
  * without leaving the device — the reference's chain through files (Unpacker writes the ISP's 16-bit result as a PNG,
  * RigDescription::loadSideCameraImages / imread decodes it to 8 bits = its high byte). camera: side index, or
  * S360_CAMERA_TOP / S360_CAMERA_BOTTOM. The ISP object must have output_bpp 16 and live on the context's device; it may
- * be shared by all cameras of a rig that use one configuration. Replaces s360_frame_upload_side / _top / _bottom. */
+ * be shared by all cameras of a rig that use one configuration (cameras of different resolutions included), but it
+ * feeds ONE context: its kernels run on that context's upload stream over the object's own buffers, so a second context
+ * using it is refused with S360_ERR_STATE — create one ISP object per context. Replaces s360_frame_upload_side / _top /
+ * _bottom. */
 #define S360_CAMERA_TOP (-1)
 #define S360_CAMERA_BOTTOM (-2)
 int s360_frame_upload_raw(s360_ctx* ctx, s360_isp* isp, int camera, const uint16_t* raw16, int w, int h);

@@ -43,14 +43,19 @@ void mul33(const float* a, const float* b, float* d) {
     }
   std::memcpy(d, t, sizeof t);
 }
+// a JSON number, or an error like the reference's ToDouble() / ToInt() on anything else (CameraIsp.h:464-607)
+double number_of(const JV& v, const char* key) {
+  if (v.t != JV::NUM) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' holds a value that is not a number");
+  return v.num;
+}
 void vec3(const JV& o, const char* key, float* dst) {
   const JV* a = o.get(key);
   if (!a) return;
   if (a->t != JV::ARR || a->arr.size() != 3) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' is not a 3-vector");
-  for (int k = 0; k < 3; ++k) dst[k] = (float)a->arr[k].num;
+  for (int k = 0; k < 3; ++k) dst[k] = (float)number_of(a->arr[k], key);
 }
 void num(const JV& o, const char* key, float* dst) {
-  if (const JV* a = o.get(key)) *dst = (float)a->num;
+  if (const JV* a = o.get(key)) *dst = (float)number_of(*a, key);
 }
 void coord_list(const JV& o, const char* key, float (*dst)[3], int32_t* count) {
   const JV* a = o.get(key);
@@ -61,7 +66,7 @@ void coord_list(const JV& o, const char* key, float (*dst)[3], int32_t* count) {
   for (size_t i = 0; i < a->arr.size(); ++i) {
     const JV& p = a->arr[i];
     if (p.t != JV::ARR || p.arr.size() != 3) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' holds a non-3-vector");
-    for (int k = 0; k < 3; ++k) dst[i][k] = (float)p.arr[k].num;
+    for (int k = 0; k < 3; ++k) dst[i][k] = (float)number_of(p.arr[k], key);
   }
 }
 }  // namespace
@@ -91,7 +96,7 @@ void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.
   c->black_level_offset = flags.black_level_offset;
   const std::string s(text);
   JP p{s.data(), s.data() + s.size()};
-  const JV root = p.value();
+  const JV root = p.document();
   const JV* isp = root.get("CameraIsp");
   if (!isp || isp->t != JV::OBJ) return;  // "Missing CameraIsp: using defaults"
   vec3(*isp, "blackLevel", c->black_level);
@@ -112,11 +117,12 @@ void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.
     if (m->t != JV::ARR || m->arr.size() != 3) throw Error(S360_ERR_IO, "isp json: 'ccm' is not 3x3");
     for (int i = 0; i < 3; ++i) {
       if (m->arr[i].t != JV::ARR || m->arr[i].arr.size() != 3) throw Error(S360_ERR_IO, "isp json: 'ccm' is not 3x3");
-      for (int j = 0; j < 3; ++j) c->ccm[i * 3 + j] = (float)m->arr[i].arr[j].num;
+      for (int j = 0; j < 3; ++j) c->ccm[i * 3 + j] = (float)number_of(m->arr[i].arr[j], "ccm");
     }
   }
-  if (const JV* r = isp->get("stuckPixelRadius")) c->stuck_pixel_radius = 2 * (int)r->num;
+  if (const JV* r = isp->get("stuckPixelRadius")) c->stuck_pixel_radius = 2 * (int)number_of(*r, "stuckPixelRadius");
   if (const JV* b = isp->get("bayerPattern")) {  // setup(): the first of these names the string contains
+    if (b->t != JV::STR) throw Error(S360_ERR_IO, "isp json: 'bayerPattern' is not a string");
     static const char* names[4] = {"RGGB", "GRBG", "GBRG", "BGGR"};
     int found = -1;
     for (int i = 0; i < 4 && found < 0; ++i)
@@ -261,16 +267,21 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   // of bounds below that size)
   if (w < 8 || h < 8) throw Error(S360_ERR_INVALID_ARG, "image too small for the ISP (needs at least 8x8 after resize)");
   const size_t n = (size_t)w * h;
-  if (o->curveW != w || o->curveH != h) {  // vignette curves at every column / row (curveHAtPixel / curveVAtPixel)
+  s360_isp::Curves* cur = nullptr;
+  for (auto& cv : o->curves)
+    if (cv.w == w && cv.h == h) cur = &cv;
+  if (!cur) {  // vignette curves at every column / row (curveHAtPixel / curveVAtPixel), built once per size
+    cur = &o->curves[o->curveNext];
+    o->curveNext = (o->curveNext + 1) % 4;
     std::vector<float> ch, cv;
     isp_vignette_curves(cfg, w, h, ch, cv);
-    o->dCurveH.ensure(ch.size() * sizeof(float));
-    o->dCurveV.ensure(cv.size() * sizeof(float));
-    S360_HIP(hipMemcpyAsync(o->dCurveH.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    S360_HIP(hipMemcpyAsync(o->dCurveV.p, cv.data(), cv.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    cur->h_.ensure(ch.size() * sizeof(float));
+    cur->v_.ensure(cv.size() * sizeof(float));
+    S360_HIP(hipMemcpyAsync(cur->h_.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    S360_HIP(hipMemcpyAsync(cur->v_.p, cv.data(), cv.size() * sizeof(float), hipMemcpyHostToDevice, st));
     S360_HIP(hipStreamSynchronize(st));  // the staging vectors go out of scope
-    o->curveW = w;
-    o->curveH = h;
+    cur->w = w;
+    cur->h = h;
   }
   const size_t outBytes = n * 3 * (cfg.output_bpp == 8 ? 1 : 2);
   o->dPlane.ensure(n * sizeof(float));
@@ -295,8 +306,8 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   B.lp = o->dLp.as<float>();
   B.scratch = o->dScratch.as<float>();
   B.flag = o->dFlag.as<unsigned char>();
-  B.curveH = o->dCurveH.as<float>();
-  B.curveV = o->dCurveV.as<float>();
+  B.curveH = cur->h_.as<float>();
+  B.curveV = cur->v_.as<float>();
   B.lut = o->dLut.as<float>();
   B.exptab = o->dExp.as<unsigned long long>();
   isp_launch(st, o->dev, o->dRaw.as<unsigned short>(), inW, inH, B, o->dOut.p);
@@ -316,6 +327,9 @@ void* isp_raw_buffer(s360_isp* o, int inW, int inH) {
   return o->dRaw.p;
 }
 const void* isp_enqueue_on(s360_isp* o, hipStream_t st, int inW, int inH) {
+  if (o->boundStream && o->boundStream != st)
+    throw Error(S360_ERR_STATE, "an ISP object feeds ONE context (s360_frame_upload_raw): create one per context");
+  o->boundStream = st;
   isp_enqueue(o, st, inW, inH);
   return o->dOut.p;
 }

@@ -36,8 +36,15 @@ struct s360_isp {
   s360_isp_config cfg;
   s360::IspDev dev;
   std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
-  s360::DevBuf dLut, dExp, dCurveH, dCurveV, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dOut, dPacked;
-  int curveW = -1, curveH = -1;
+  s360::DevBuf dLut, dExp, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dOut, dPacked;
+  // vignette curves per output size (curveHAtPixel / curveVAtPixel): a rig's side and pole cameras may differ in
+  // resolution, so a few sizes are kept instead of rebuilding (and synchronising the upload stream) at every switch
+  struct Curves { int w = -1, h = -1; s360::DevBuf h_, v_; };
+  Curves curves[4];
+  int curveNext = 0;
+  // s360_frame_upload_raw runs this object's kernels on a context's upload stream over the buffers above: the object
+  // belongs to the first context it is used with (another context's stream would race on dRaw / dPlane / ...)
+  hipStream_t boundStream = nullptr;
   std::string err;
 };
 

@@ -29,6 +29,12 @@ struct JP {
   const char* e;
   void ws() { while (s < e && std::isspace((unsigned char)*s)) ++s; }
   [[noreturn]] void fail(const char* m) { throw Error(S360_ERR_IO, std::string("json: ") + m); }
+  JV document() {  // one value, then nothing but white space
+    JV v = value();
+    ws();
+    if (s != e) fail("trailing characters after the document");
+    return v;
+  }
   JV value() {
     ws();
     if (s >= e) fail("unexpected end");
@@ -83,7 +89,9 @@ struct JP {
         switch (*s) {
           case 'n': v.str += '\n'; break;
           case 't': v.str += '\t'; break;
-          case 'u': s += 4; v.str += '?'; break;
+          case 'u':  // (ids and names of this format are ASCII: a \\uXXXX escape becomes one placeholder character)
+            if (e - s < 5) fail("truncated \\u escape");
+            s += 4; v.str += '?'; break;
           default: v.str += *s;
         }
         ++s;
