@@ -64,6 +64,10 @@ struct s360_ctx {
   int slot = 0;
   // warp maps of bicubicRemapToSpherical per rig camera: depend only on rig + sizes, shared by all slots
   s360::DevBuf sideMaps, topMap, botMap;
+  // the same maps as the packed remap reads them (render_kernels.hip): per destination pixel one dword, per 64x16 tile
+  // the box of source pixels; they also depend on the SOURCE size, so they are (re)built when that is first seen
+  struct PackedMap { s360::DevBuf packed, tiles; int sw = -1, sh = -1; };
+  PackedMap sidePk, topPk, botPk;
   bool maps_ready = false;
   void make_current() const { S360_HIP(hipSetDevice(device)); }
 };

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "devmath.hpp"
@@ -400,6 +401,18 @@ static void ensure_maps(s360_ctx* c) {
   c->maps_ready = true;
 }
 
+// coordinates + tile boxes of a cached map for sources of sw x sh (once per rig and source size)
+static void ensure_packed(s360_ctx* c, s360_ctx::PackedMap& pk, const float2* map, int sw, int sh, int dw, int dh, int batch,
+                          hipStream_t st) {
+  if (pk.sw == sw && pk.sh == sh) return;
+  pk.packed.ensure((size_t)batch * dw * dh * sizeof(unsigned));
+  pk.tiles.ensure((size_t)batch * remap_packed_tiles(dw, dh) * 16);
+  launch_remap_pack_map(st, map, sw, sh, dw, dh, pk.packed.as<unsigned>(), pk.tiles.p, batch);
+  S360_HIP(hipStreamSynchronize(st));  // (once; later frames may use these from another of the context's streams)
+  pk.sw = sw;
+  pk.sh = sh;
+}
+
 // Side stage for pairs [p0,p1) of a set of frame slots: per slot the projections of the cameras those pairs touch and
 // the overlap crops; then the two flows per pair of ALL slots in one FlowEngine batch; then per slot the fused
 // novel-view/blend into the strip buffers. One slot = the classic single frame.
@@ -459,8 +472,11 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
         if (!need[i]) { ++i; continue; }
         int j = i;
         while (j < P && need[j]) ++j;
-        launch_remap_cubic_u8c4(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, c->sideMaps.as<float2>() + pn * i,
-                                F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
+        ensure_packed(c, c->sidePk, c->sideMaps.as<float2>(), F.srcW, F.srcH, camW, camH, P, st);
+        launch_remap_cubic_u8c4_packed(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, c->sideMaps.as<float2>() + pn * i,
+                                       c->sidePk.packed.as<unsigned>() + pn * i,
+                                       (const char*)c->sidePk.tiles.p + 16 * remap_packed_tiles(camW, camH) * i,
+                                       F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
         i = j;
       }
     }
@@ -561,7 +577,15 @@ void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flo
   pw.phiMid = c->ramp.phiMid;
   pw.phiRampEnd = c->ramp.phiRampEnd;
   F.warpedExt.ensure((size_t)extW * rows * sizeof(uchar4));
-  launch_pole_warp(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev);
+  // S360_POLE_WARP_PACKED=0 (measurement switch of this round; same bytes): the one-kernel warp
+  static const bool packedWarp = [] { const char* e = std::getenv("S360_POLE_WARP_PACKED"); return !(e && e[0] == '0'); }();
+  if (packedWarp) {
+    F.warpPacked.ensure((size_t)extW * rows * sizeof(unsigned));
+    F.warpTiles.ensure(remap_packed_tiles(extW, rows) * 16);
+    launch_pole_warp_packed(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev, F.warpPacked.as<unsigned>(),
+                            F.warpTiles.p);
+  } else
+    launch_pole_warp(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev);
   launch_pole_finish(c->st, F.warpedExt.as<uchar4>(), warped_out, eqrH, pw);
 }
 
@@ -654,8 +678,10 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         if (!F.have_top) throw Error(S360_ERR_STATE, "top image not uploaded");
         F.topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
         const int yfs = rowsT - 1 - c->P.std_alpha_feather_size;
-        launch_remap_cubic_u8c4(st, F.topSrc.as<uchar4>(), F.topW, F.topH, c->topMap.as<float2>(),
-                                F.topSph.as<uchar4>(), W, rowsT, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
+        ensure_packed(c, c->topPk, c->topMap.as<float2>(), F.topW, F.topH, W, rowsT, 1, st);
+        launch_remap_cubic_u8c4_packed(st, F.topSrc.as<uchar4>(), F.topW, F.topH, c->topMap.as<float2>(),
+                                       c->topPk.packed.as<unsigned>(), c->topPk.tiles.p, F.topSph.as<uchar4>(), W, rowsT,
+                                       F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xs, extW);
       }
       if (pole_mask & 12) {
@@ -664,11 +690,15 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         const int yfs = rowsB - 1 - c->P.std_alpha_feather_size;
         if (c->P.enable_pole_removal) {  // TRSP:569-597: the bottom source is the merge of the two bottom cameras
           dev_pole_removal(c, F, use_prev != 0);
-          launch_remap_cubic_u8c4(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
-                                  F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 2, yfs, c->P.std_alpha_feather_size);
+          ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
+          launch_remap_cubic_u8c4_packed(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
+                                         c->botPk.packed.as<unsigned>(), c->botPk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
+                                         F.tab.dev, 2, yfs, c->P.std_alpha_feather_size);
         } else {
-          launch_remap_cubic_u8c4(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
-                                  F.botSph.as<uchar4>(), W, rowsB, F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
+          ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
+          launch_remap_cubic_u8c4_packed(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
+                                         c->botPk.packed.as<unsigned>(), c->botPk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
+                                         F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         }
         launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xs, extW);
       }
@@ -778,6 +808,35 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         }
       }
     }
+  }
+  if (!(phases & 2)) return;
+  // sharpenThread for both eyes of EVERY slot in one set of launches (TRSP:901-915 runs the two eyes on two threads): the
+  // IIR passes are one serial chain per (row, channel) — the 2 x 4096 rows of one frame are 512 waves, half a wave per
+  // SIMD — so a batch of slots is sharpened together (12 slots: 6 waves per SIMD cover each other's dependent chains)
+  if (c->P.sharpening > 0.0) {
+    ProfScope ps(prof, "finish");
+    std::vector<uchar4*> imgs, lps;
+    std::vector<float*> scr;
+    for (int k : slotIds) {
+      SlotScope ss(c, k);
+      FrameState& F = frame_state(c);
+      for (int e = 0; e < 2; ++e) {
+        F.sharpLp[e].ensure(en * sizeof(uchar4));
+        F.sharpBuf[e].ensure(sharpen_scratch_bytes(W, H));
+        imgs.push_back(F.pano[e].as<uchar4>());
+        lps.push_back(F.sharpLp[e].as<uchar4>());
+        scr.push_back(F.sharpBuf[e].as<float>());
+      }
+    }
+    const int per = sharpen_max_images();
+    for (size_t i = 0; i < imgs.size(); i += per) {
+      const int n = (int)std::min<size_t>(per, imgs.size() - i);
+      launch_sharpen_many(st, imgs.data() + i, lps.data() + i, scr.data() + i, n, W, H, 1.0f + (float)c->P.sharpening);
+    }
+  }
+  for (int k : slotIds) {
+    SlotScope ss(c, k);
+    FrameState& F = frame_state(c);
     {
       ProfScope ps(prof, "finish");  // TRSP:890-961
       const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
@@ -787,17 +846,6 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       F.outBGR[ob].ensure((size_t)outW * outH * 3);
       if (!F.outDone[ob]) S360_HIP(hipEventCreateWithFlags(&F.outDone[ob], hipEventDisableTiming));
       const bool resize = (outW != W) || (eyeH != H);
-      if (c->P.sharpening > 0.0) {  // both eyes in one set of launches (TRSP:901-915 runs them on two threads)
-        uchar4* imgs[2];
-        uchar4* lps[2];
-        float* scr[2];
-        for (int e = 0; e < 2; ++e) {
-          F.sharpLp[e].ensure(en * sizeof(uchar4));
-          F.sharpBuf[e].ensure(sharpen_scratch_bytes(W, H));
-          imgs[e] = F.pano[e].as<uchar4>(); lps[e] = F.sharpLp[e].as<uchar4>(); scr[e] = F.sharpBuf[e].as<float>();
-        }
-        launch_sharpen_many(st, imgs, lps, scr, 2, W, H, 1.0f + (float)c->P.sharpening);
-      }
       for (int e = 0; e < 2; ++e) {
         uchar4* eye = F.pano[e].as<uchar4>();
         if (resize) {

@@ -38,6 +38,7 @@ struct FrameState {
   DevBuf a8a, a8b, gtmp;
   DevBuf extImgs[2], poleFlows[2];    // [cur/prev]; slots: ext 0-3 side units, 4 top fisheye, 5 bottom fisheye
   DevBuf warpedExt, poleWarped[4];
+  DevBuf warpPacked, warpTiles;  // this frame's pole warp as packed coordinates + tile boxes (launch_pole_warp_packed)
   DevBuf eyeFinal[2], sharpLp[2], sharpBuf[2];
   // Stacked equirect of the last two frames (alternating): a streaming host downloads frame k from one buffer while
   // frame k+1 is composited into the other (s360_frame_download_equirect_of). outDone[i] is recorded behind the

@@ -314,6 +314,159 @@ __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uch
   dst[(size_t)y * dw + x] = o;
 }
 
+// ------------------------------------------------------------------------------------------
+// Packed bicubic remap: the same arithmetic as k_remap_cubic_u8c4_tiled with everything that depends only on the MAP
+// prepared by a kernel of its own (k_remap_pack) — once per rig for the cached spherical maps of the side and pole
+// cameras, once per frame for the pole warp: per destination tile of 64 x 16 pixels the box of source pixels its taps
+// touch, and per pixel ONE dword {live | tap origin relative to the box (11 + 10 bits) | 1/32-pixel fraction index
+// (10 bits)} instead of the 8-byte float map. The remap kernel then has one memory phase: the tile's packed coordinates
+// and its source box are requested together (no coordinate arithmetic, wave reductions, LDS atomics or barrier in front
+// of the box load), one barrier, 16 LDS taps per pixel folded with v_perm_b32 + v_dot2_i32_i16. 256 threads render 4
+// pixels each. Tiles whose box does not fit (map singularities) take the per-tap global gather from the float map.
+constexpr int PT_W = 64, PT_H = 16, PT_TY = 4, PT_CAP = 4096;
+
+template <class MapFn>
+__global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw, int sh, int dw, int dh,
+                                                            unsigned* __restrict__ packed, int4* __restrict__ tiles,
+                                                            size_t dbs, int tilesPerImage) {
+  mapfn.advance(dbs * blockIdx.z);
+  packed += dbs * blockIdx.z;
+  tiles += (size_t)tilesPerImage * blockIdx.z;
+  __shared__ int s_box[4];
+  const int tid = threadIdx.y * PT_W + threadIdx.x;
+  const int x = blockIdx.x * PT_W + threadIdx.x;
+  int sx[4], sy[4], fxy[4];
+  bool live[4];
+  int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
+    live[k] = false;
+    sx[k] = sy[k] = fxy[k] = 0;
+    if (x < dw && y < dh) {
+      const float2 m = mapfn(x, y);
+      remap_coord(m.x, m.y, &sx[k], &sy[k], &fxy[k]);
+      live[k] = !(sx[k] >= sw || sx[k] + 4 <= 0 || sy[k] >= sh || sy[k] + 4 <= 0);
+      if (live[k]) {
+        mnx = min(mnx, sx[k]); mxx = max(mxx, sx[k]);
+        mny = min(mny, sy[k]); mxy = max(mxy, sy[k]);
+      }
+    }
+  }
+  if (tid == 0) { s_box[0] = INT_MAX; s_box[1] = INT_MIN; s_box[2] = INT_MAX; s_box[3] = INT_MIN; }
+  mnx = wave_min_i(mnx); mxx = wave_max_i(mxx);
+  mny = wave_min_i(mny); mxy = wave_max_i(mxy);
+  __syncthreads();
+  if ((tid & 63) == 0 && mnx <= mxx) {
+    atomicMin(&s_box[0], mnx); atomicMax(&s_box[1], mxx);
+    atomicMin(&s_box[2], mny); atomicMax(&s_box[3], mxy);
+  }
+  __syncthreads();
+  const int bx0 = s_box[0], by0 = s_box[2];
+  const bool any = bx0 <= s_box[1];
+  int bw = any ? s_box[1] + 4 - bx0 : 0, bh = any ? s_box[3] + 4 - by0 : 0;
+  if (any && ((long long)bw * bh > PT_CAP || bw > 2047 || bh > 1023)) bh = -1;  // too large for the LDS tile / the packed fields
+  if (tid == 0) tiles[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = make_int4(bx0, by0, bw, bh);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
+    if (x < dw && y < dh)
+      packed[(size_t)y * dw + x] = (live[k] && bh > 0) ? (0x80000000u | ((unsigned)(sy[k] - by0) << 21) | ((unsigned)(sx[k] - bx0) << 10) | (unsigned)fxy[k]) : 0u;
+  }
+}
+
+template <class MapFn>
+__global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const uchar4* __restrict__ src, int sw, int sh,
+                                                                         const unsigned* __restrict__ packed,
+                                                                         const int4* __restrict__ tiles, MapFn mapfn,
+                                                                         uchar4* __restrict__ dst, int dw, int dh,
+                                                                         const short* __restrict__ tab, int alpha_mode,
+                                                                         int yFeatherStart, int featherSize, size_t sbs,
+                                                                         size_t dbs, int tilesPerImage) {
+  src += sbs * blockIdx.z;
+  dst += dbs * blockIdx.z;
+  packed += dbs * blockIdx.z;
+  mapfn.advance(dbs * blockIdx.z);
+  __shared__ uchar4 s_tile[PT_CAP];
+  const int4 box = tiles[(size_t)tilesPerImage * blockIdx.z + (size_t)blockIdx.y * gridDim.x + blockIdx.x];  // (uniform)
+  const int bx0 = box.x, by0 = box.y, bw = box.z, bh = box.w;
+  const int x = blockIdx.x * PT_W + threadIdx.x;
+  unsigned pk[4] = {0u, 0u, 0u, 0u};
+  if (bh > 0 && x < dw) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
+      if (y < dh) pk[k] = packed[(size_t)y * dw + x];
+    }
+  }
+  if (bh > 0) {  // the tile's source box, zero outside the image (BORDER_CONSTANT): requested together with the coordinates
+    for (int ly = threadIdx.y; ly < bh; ly += PT_TY) {
+      const int gy = by0 + ly;
+      const bool rowIn = gy >= 0 && gy < sh;
+      const uchar4* S = src + (size_t)(rowIn ? gy : 0) * sw;
+      for (int lx = threadIdx.x; lx < bw; lx += PT_W) {
+        const int gx = bx0 + lx;
+        s_tile[ly * bw + lx] = (rowIn && gx >= 0 && gx < sw) ? S[gx] : make_uchar4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
+    if (x >= dw || y >= dh) continue;
+    uchar4 o = make_uchar4(0, 0, 0, 0);
+    if (bh > 0) {
+      if (pk[k] & 0x80000000u) {
+        const int fxy = pk[k] & 1023, rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
+        const uint4* w4 = reinterpret_cast<const uint4*>(tab + fxy * 16);
+        const uint4 wa = w4[0], wb = w4[1];
+        const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + ry * bw + rx;
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned p0 = T[r * bw], p1 = T[r * bw + 1], p2 = T[r * bw + 2], p3 = T[r * bw + 3];
+          const s16x2 w01 = __builtin_bit_cast(s16x2, wq[2 * r]), w23 = __builtin_bit_cast(s16x2, wq[2 * r + 1]);
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) {
+            const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
+            const s16x2 lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p1, p0, sel));
+            const s16x2 hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p3, p2, sel));
+            acc[ch] = __builtin_amdgcn_sdot2(lo, w01, acc[ch], false);
+            acc[ch] = __builtin_amdgcn_sdot2(hi, w23, acc[ch], false);
+          }
+        }
+        o = make_uchar4((unsigned char)sat_u8((acc[0] + (1 << 14)) >> 15), (unsigned char)sat_u8((acc[1] + (1 << 14)) >> 15),
+                        (unsigned char)sat_u8((acc[2] + (1 << 14)) >> 15), (unsigned char)sat_u8((acc[3] + (1 << 14)) >> 15));
+      }
+    } else if (bh < 0) {  // box too large for LDS: per-tap gather through the map itself
+      const float2 m = mapfn(x, y);
+      int sx, sy, fxy;
+      remap_coord(m.x, m.y, &sx, &sy, &fxy);
+      if (!(sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0)) o = remap_cubic_u8c4_at(src, sw, sh, m.x, m.y, tab);
+    }
+    if (alpha_mode == 1) {
+      // remap ran on 3 channels, cvtColor BGR2BGRA sets 255, the feather loop overwrites the last rows
+      int a = 255;
+      if (y >= yFeatherStart) {
+        const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
+        a = (int)(unsigned char)(255.0f * alpha);
+      }
+      o.w = (unsigned char)a;
+    } else if (alpha_mode == 2) {
+      // 4-channel source (pole removal result): the interpolated alpha is kept, the feather rows take the minimum
+      // (TRSP:625-634)
+      if (y >= yFeatherStart) {
+        const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
+        const unsigned char a = (unsigned char)(255.0f * alpha);
+        o.w = o.w < a ? o.w : a;
+      }
+    }
+    dst[(size_t)y * dw + x] = o;
+  }
+}
+
 // ---- pole removal (PoleRemoval.cpp:32-188) -------------------------------------------------------------------
 // "is pure red" plane of a BGR mask image (cutRedMaskOutOfAlphaChannel's test, CvUtil.cpp:213-222)
 __global__ __launch_bounds__(256) void k_red_mask(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ red, size_t n) {
@@ -1026,7 +1179,7 @@ struct IirGeom {
   int nchains;  // ROWS: h, columns: w
   int w;        // image row pitch in pixels
 };
-constexpr int IIR_MAX_IMGS = 16;  // images per launch (blockIdx.y): the two eyes of every frame slot of a batch
+constexpr int IIR_MAX_IMGS = 32;  // images per launch (blockIdx.y): the two eyes of every frame slot of a batch
 struct IirImgs {
   const uchar4* x[IIR_MAX_IMGS];  // input of the pass
   uchar4* out[IIR_MAX_IMGS];      // 8-bit output of the anticausal half
@@ -1221,6 +1374,21 @@ void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, 
                      dim3(RT_W, RT_H), 0, st, src, sw, sh, mf, dst, dw, dh, T.bicubic_i, alpha_mode, yFeatherStart,
                      featherSize, (size_t)sw * sh, (size_t)dw * dh);
 }
+size_t remap_packed_tiles(int dw, int dh) { return (size_t)cdiv(dw, PT_W) * cdiv(dh, PT_H); }
+void launch_remap_pack_map(hipStream_t st, const float2* map, int sw, int sh, int dw, int dh, unsigned* packed, void* tiles,
+                           int batch) {
+  MapFromBuffer mf{map, dw};
+  hipLaunchKernelGGL((k_remap_pack<MapFromBuffer>), dim3(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), dim3(PT_W, PT_TY), 0, st, mf, sw,
+                     sh, dw, dh, packed, reinterpret_cast<int4*>(tiles), (size_t)dw * dh, (int)remap_packed_tiles(dw, dh));
+}
+void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, const unsigned* packed,
+                                    const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
+                                    int yFeatherStart, int featherSize, int batch) {
+  MapFromBuffer mf{map, dw};
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer>), dim3(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), dim3(PT_W, PT_TY),
+                     0, st, src, sw, sh, packed, reinterpret_cast<const int4*>(tiles), mf, dst, dw, dh, T.bicubic_i, alpha_mode,
+                     yFeatherStart, featherSize, (size_t)sw * sh, (size_t)dw * dh, (int)remap_packed_tiles(dw, dh));
+}
 void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
                           const DevTables& T) {
   MapFromFlowAdd mf{flow, w};
@@ -1277,6 +1445,16 @@ void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha,
                         int extW) {
   hipLaunchKernelGGL(k_extend_wrap, dim3(cdiv(extW, 256), rows), dim3(256), 0, st, img, alpha, cols, rows, ext, extW);
 }
+void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
+                             const PoleWarpParams& pw, const DevTables& T, unsigned* packed, void* tiles) {
+  MapFromPoleFlow mf{flow, pw};
+  const int nt = (int)remap_packed_tiles(pw.extW, pw.rows);
+  hipLaunchKernelGGL((k_remap_pack<MapFromPoleFlow>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1), dim3(PT_W, PT_TY), 0, st,
+                     mf, pw.extW, pw.rows, pw.extW, pw.rows, packed, reinterpret_cast<int4*>(tiles), (size_t)0, nt);
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
+                     dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
+                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 0, 1, (size_t)0, (size_t)0, nt);
+}
 void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
                       const PoleWarpParams& pw, const DevTables& T) {
   MapFromPoleFlow mf{flow, pw};
@@ -1307,12 +1485,13 @@ void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* d
 }
 // iirLowPass (wrap horizontally, reflect vertically) + sharpenWithIirLowPass on one eye, in place (TRSP:688-696).
 // scratch: w*h float4 + max(w,h) float4 (the chains' carried state).
+int sharpen_max_images() { return IIR_MAX_IMGS; }
 size_t sharpen_scratch_bytes(int w, int h) { return ((size_t)w * h + (size_t)std::max(w, h)) * sizeof(float4); }
 // n images of the same size in one set of launches (the chains of one image cannot fill the chip: 16 384 of them for
 // the row pass of a 4096-row eye, each 2 x 8400 dependent steps).
 void launch_sharpen_many(hipStream_t st, uchar4* const* imgs, uchar4* const* lps, float* const* scratch, int n, int w,
                          int h, float amount) {
-  if (n < 1 || n > IIR_MAX_IMGS) throw std::runtime_error("launch_sharpen_many: 1..16 images per launch");
+  if (n < 1 || n > IIR_MAX_IMGS) throw std::runtime_error("launch_sharpen_many: 1..32 images per launch");
   const float alpha = powf(0.25f, 1.0f / 4.0f);  // host libm, Filter.h:49
   const size_t npix = (size_t)w * h;
   const IirGeom gr{w, h, w}, gc{h, w, w};

@@ -43,6 +43,16 @@ void launch_spherical_map(hipStream_t st, float2* map, int dw, int dh, const Dev
 void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, uchar4* dst, int dw,
                              int dh, const DevTables& T, int alpha_mode, int yFeatherStart, int featherSize,
                              int batch = 1 /* images of identical geometry: sources sw*sh, maps and outputs dw*dh apart */);
+// The same through coordinates prepared once per map (render_kernels.hip "packed bicubic remap"): launch_remap_pack_map
+// fills `packed` (one dword per destination pixel) and `tiles` (remap_packed_tiles(dw, dh) x 16 bytes per image) from a
+// float map; the remap then reads those instead of the map (the map is only touched by tiles whose source box does not
+// fit in LDS).
+size_t remap_packed_tiles(int dw, int dh);
+void launch_remap_pack_map(hipStream_t st, const float2* map, int sw, int sh, int dw, int dh, unsigned* packed, void* tiles,
+                           int batch = 1);
+void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, const unsigned* packed,
+                                    const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
+                                    int yFeatherStart, int featherSize, int batch = 1);
 // overlap crops (TRSP:196-198) for pairs [p0,p1): out[j] = right part of proj p0+j, out[n+j] = left part of
 // proj (p0+j+1)%P, n = p1-p0
 void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH, int P, int overlapW, uchar4* out,
@@ -64,6 +74,10 @@ void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha 
 // pole warp map + remap (TRSP:487-503)
 void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
                       const PoleWarpParams& pw, const DevTables& T);
+// the same as two kernels: coordinates + tile boxes of this frame's warp, then the packed remap
+void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
+                             const PoleWarpParams& pw, const DevTables& T, unsigned* packed /* extW*rows */,
+                             void* tiles /* remap_packed_tiles(extW, rows) * 16 bytes */);
 // seam blend + alpha ramp + bottom padding (TRSP:505-546): out is eqrW x eqrH
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw);
 // flattenLayersDeghostPreferBase (CvUtil.cpp:224-260); flip_top: top layer is indexed (W-1-x, H-1-y)
@@ -82,6 +96,7 @@ void launch_circle_alpha(hipStream_t st, const uchar4* src, const uint8_t* red /
 void launch_pole_removal_combine(hipStream_t st, uchar4* bottom, const uchar4* warped2, size_t n);
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst);
 // sharpen (Filter.h:40-127) on BGRA in place, lp scratch same size
+int sharpen_max_images();  // images one launch_sharpen_many call takes
 size_t sharpen_scratch_bytes(int w, int h);
 void launch_sharpen_many(hipStream_t st, uchar4* const* imgs, uchar4* const* lps, float* const* scratch, int n, int w,
                          int h, float amount);

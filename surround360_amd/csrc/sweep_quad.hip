@@ -21,13 +21,13 @@
 //   * waves are persistent (capped grid, a finished band takes the next ticket);
 //   * the records and incoming flows of a 16-step chunk are fetched once (four pixels per lane) while the previous chunk
 //     computes and staged in LDS; all-interior chunks run a step with the range tests folded away;
-//   * WIN builds: the I1-gradient texels the chunk's bilinear taps can touch are staged in LDS as well — a window of
+//   * the I1-gradient texels the chunk's bilinear taps can touch are staged in LDS as well — a window of
 //     kWinRows x kWinCols texels placed around the cells the chunk's own incoming flows point at, filled with coalesced
 //     row segments once per chunk — so that the two dependent gather rounds of a step are LDS reads (~100 cycles)
 //     instead of L1/L2 gathers (500+). A wave any of whose relevant taps leaves the window gathers from global memory
-//     for that round exactly as before: same texels, same bits;
-//   * non-WIN builds keep the round-2 texel exchange: the two finite-difference probes sit 0.001 px from round 1's
-//     winner, i.e. almost always in the cell that lane has just gathered, and take its texels with ds_bpermute;
+//     for that round: same texels, same bits. (Measured against the previous build — global gathers in round 1, the
+//     probes of round 2 taking the winner's texels by ds_bpermute — on 12-slot 8K batches: 16.3 vs 17.4 ms of sweeps per
+//     frame; profiles/r03_v1_*);
 //   * pixels below the alpha threshold are not updated (PixFlow.h:390): a step none of whose 16 pixels is updated
 //     skips both rounds, a band waits for the band above only where its first row is updated, and a band without any
 //     updated pixel (per-row flags written by the record kernel) hands its last row on and leaves — 63 % of a pole
@@ -64,11 +64,6 @@ __device__ __forceinline__ float from_row_above_q(float old, float v) {
   return __builtin_bit_cast(float, r);
 }
 
-// v of the lane whose byte address (lane * 4) is `src`
-__device__ __forceinline__ float lane_value(int src, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v)));
-}
-
 }  // namespace
 
 // Everything that is not the pixel update itself is amortised over several steps, with wave-uniform control: the
@@ -85,7 +80,7 @@ constexpr int kQChunk = 16;
 constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
 constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every kQPub steps
 
-// The LDS window of I1-gradient texels (WIN builds). In image coordinates the pixels of a chunk form a parallelogram:
+// The LDS window of I1-gradient texels. In image coordinates the pixels of a chunk form a parallelogram:
 // row y of the band lags one column per row, so x + y is the same for the 16 pixels of a step and spans 16 values over a
 // chunk. The window is stored in those coordinates: LDS row jy holds image row wy0 + jy, column ju holds image column
 // (wu0 + ju) - (wy0 + jy). A bilinear cell (x0, y0) is inside iff 0 <= y0 - wy0 <= kWinRows - 2 and
@@ -97,6 +92,7 @@ constexpr int kWinRows = 24;
 constexpr int kWinCols = 32;
 constexpr int kWinStride = 34;
 constexpr int kNoWin = 0x3fffffff;
+constexpr int kWinAhead = 4;  // the next chunk's window is requested this many steps before the chunk ends
 
 #ifdef S360_WAVE_EMULATION
 // developer statistics (CPU emulation only): wave-steps that ran an update round / that left the window for global memory
@@ -107,7 +103,7 @@ unsigned long long g_quad_rounds = 0, g_quad_fallbacks = 0, g_quad_chunks = 0, g
 #endif
 
 // Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
-template <bool FAST, bool WIN>
+template <bool FAST, bool AHEAD>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
@@ -123,7 +119,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   __shared__ float2 s_up[kUpRing];
   __shared__ float2 s_res[kQRows][kRW];
   __shared__ float4 s_rec[kQRows][kRW];
-  __shared__ f2r s_win[WIN ? kWinRows * kWinStride : 1];
+  __shared__ f2r s_win[kWinRows * kWinStride];
   const int lane = threadIdx.x;
   for (;;) {
   unsigned tk = 0;
@@ -175,7 +171,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const float kEps = 0.001f, kInf = __int_as_float(0x7f800000);
   const int nsteps = w + kQRows - 1;
   auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
-  int wy0 = kNoWin, wu0 = 0;  // (WIN) placement of the LDS window, wave-uniform
+  int wy0 = kNoWin, wu0 = 0;  // placement of the LDS window, wave-uniform
 
   // getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464) of the tap (x + ax, y + ay) of this lane's pixel
   struct Cell { float mx, my; int x0, y0; };
@@ -211,8 +207,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
     return tt;
   };
-  // (WIN) the same four texels from the LDS window, or from global memory for the whole wave if a lane that matters
-  // (`rel`) has its cell outside the window
+  // the same four texels from the LDS window, or from global memory for the whole wave if a lane that matters (`rel`)
+  // has its cell outside the window
   auto fetch = [&](const Cell& k, bool rel) -> Texels {
     const int jy = k.y0 - wy0, ju = k.x0 + k.y0 - wu0;
     const bool in = (unsigned)jy <= (unsigned)(kWinRows - 2) && (unsigned)ju <= (unsigned)(kWinCols - 3);
@@ -237,9 +233,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
     const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
     const Cell k = cell_of(x, ax, ay);
-    Texels t1;
-    if constexpr (WIN) t1 = fetch(k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)));
-    else t1 = gather(k);
+    const Texels t1 = fetch(k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)));
     const float e = error_of(ieee, t1, k, rc, ax, ay, tiny);
     const float e0 = quad_bcast<0>(e);
     float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
@@ -256,26 +250,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float cur = b2 ? e2 : c1;
     const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
     const Cell pk = cell_of(x, pax, pay);
-    float pe;
-    if constexpr (WIN) {
-      const Texels t2 = fetch(pk, take && q < 2);
-      pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
-    } else {
-      // round-2 exchange: the probes take the winner's texels from the lane that gathered them unless a probe of an
-      // updated pixel leaves the winner's cell (then the wave gathers again: same bits either way)
-      const Cell wk = cell_of(x, f.x + 0.0f, f.y + 0.0f);
-      if (__ballot(q < 2 && take && (pk.x0 != wk.x0 || pk.y0 != wk.y0)) == 0ull) {
-        const int win = b2 ? 2 : (b1 ? 1 : 0);  // the quad lane that evaluated the winner
-        const int src = ((lane & ~3) | win) << 2;
-        Texels t2;
-        t2.r0 = make_float4(lane_value(src, t1.r0.x), lane_value(src, t1.r0.y), lane_value(src, t1.r0.z), lane_value(src, t1.r0.w));
-        t2.r1 = make_float4(lane_value(src, t1.r1.x), lane_value(src, t1.r1.y), lane_value(src, t1.r1.z), lane_value(src, t1.r1.w));
-        pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
-      } else {
-        const Texels t2 = gather(pk);
-        pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
-      }
-    }
+    const Texels t2 = fetch(pk, take && q < 2);
+    const float pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
     const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
     const float nx = ex - cur, ny = ey - cur;
     float ggx, ggy;
@@ -336,44 +312,49 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       *reinterpret_cast<f2r*>(&s_res[r][4 * q + j]) = cf[j];
     }
   };
-  // (WIN) Places the window around the cells the incoming flows of the chunk starting at step `sbase` point at (cr / cf
-  // hold that chunk: four pixels per lane) and fills it: 12 coalesced loads of 8 bytes per lane, two window rows per
-  // wave-wide load. Pixels that are not updated do not count; a chunk without updated pixels leaves the window alone.
-  auto win_fill = [&](int sbase) {
-    typedef short s2r __attribute__((ext_vector_type(2)));
-    s2r lo = {32767, 32767}, hi = {-32768, -32768};  // (y0, x0 + y0) minima / maxima; coordinates are < 2^15
+  // Places the window around the cells the incoming flows of the chunk starting at step `sbase` point at (cr / cf hold
+  // that chunk: four pixels per lane) and loads it into registers: 12 coalesced loads of 8 bytes per lane, two window
+  // rows per wave-wide load. Pixels that are not updated do not count; a chunk without updated pixels leaves the window
+  // alone. Issued four steps before the chunk ends so that the loads land behind the remaining steps; win_commit then
+  // moves them into LDS between the chunks.
+  f2r wv[kWinRows / 2];
+  int ny0 = kNoWin, nu0 = 0;  // placement of the window being loaded (kNoWin: none)
+  auto win_issue = [&](int sbase) {
+    int ymin = 0x7fffffff, umin = 0x7fffffff, ymax = -1, umax = -1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xi = sbase + 4 * q + j - r;
       if (rowValid && xi >= 0 && xi < w && cr[j].x == cr[j].x) {
         const Cell k = cell_of(dir > 0 ? xi : w - 1 - xi, cf[j].x + 0.0f, cf[j].y + 0.0f);
-        const s2r v = {(short)k.y0, (short)(k.x0 + k.y0)};
-        lo = __builtin_elementwise_min(lo, v);
-        hi = __builtin_elementwise_max(hi, v);
+        ymin = min(ymin, k.y0); ymax = max(ymax, k.y0);
+        umin = min(umin, k.x0 + k.y0); umax = max(umax, k.x0 + k.y0);
       }
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
-      const int lo2 = __shfl_xor(__builtin_bit_cast(int, lo), m), hi2 = __shfl_xor(__builtin_bit_cast(int, hi), m);
-      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(s2r, lo2));
-      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(s2r, hi2));
+      ymin = min(ymin, __shfl_xor(ymin, m)); umin = min(umin, __shfl_xor(umin, m));
+      ymax = max(ymax, __shfl_xor(ymax, m)); umax = max(umax, __shfl_xor(umax, m));
     }
     S360_QSTAT(g_quad_chunks);
-    const int ymin = __builtin_amdgcn_readfirstlane((int)lo.x), umin = __builtin_amdgcn_readfirstlane((int)lo.y);
-    const int ymax = __builtin_amdgcn_readfirstlane((int)hi.x), umax = __builtin_amdgcn_readfirstlane((int)hi.y);
+    ymin = __builtin_amdgcn_readfirstlane(ymin); umin = __builtin_amdgcn_readfirstlane(umin);
+    ymax = __builtin_amdgcn_readfirstlane(ymax); umax = __builtin_amdgcn_readfirstlane(umax);
+    ny0 = kNoWin;
     if (ymax < ymin) return;  // nothing to update in this chunk: no taps
     // rows ymin .. ymax + 1 and columns umin .. umax + 2 are what the incoming flows need; the slack goes evenly to
     // both sides (the left / up candidates and the probes land next to them)
-    const int ny0 = ymin - max(0, (kWinRows - (ymax - ymin + 2)) >> 1);
-    const int nu0 = umin - max(0, (kWinCols - (umax - umin + 3)) >> 1);
+    ny0 = ymin - max(0, (kWinRows - (ymax - ymin + 2)) >> 1);
+    nu0 = umin - max(0, (kWinCols - (umax - umin + 3)) >> 1);
     S360_QSTAT(g_quad_fills);
-    f2r wv[kWinRows / 2];
     const int jc = lane & 31, jr = lane >> 5;
 #pragma unroll
     for (int i = 0; i < kWinRows / 2; ++i) {
       const int Y = ny0 + 2 * i + jr, X = nu0 + jc - Y;
       wv[i] = *reinterpret_cast<const f2r*>(G1 + (size_t)min(max(Y, 0), h - 1) * w + min(max(X, 0), w - 1));
     }
+  };
+  auto win_commit = [&]() {
+    if (ny0 == kNoWin) return;
+    const int jc = lane & 31, jr = lane >> 5;
     S360_WAVE_SYNC();  // (the previous chunk's taps have been read)
 #pragma unroll
     for (int i = 0; i < kWinRows / 2; ++i) s_win[(2 * i + jr) * kWinStride + jc] = wv[i];
@@ -382,7 +363,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     wu0 = nu0;
   };
   chunk_load(0);
-  if constexpr (WIN) win_fill(0);
+  win_issue(0);
+  win_commit();
   chunk_store();
   S360_WAVE_SYNC();
   nrc = s_rec[r][0];
@@ -468,10 +450,19 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const int send = min(s0 + kQChunk, nsteps);
     if (s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
     const bool steadyChunk = s0 >= kQRows && s0 + kQChunk <= w;
+    const bool more = send < nsteps;
     if (steadyChunk) {
-      for (int s = s0; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
+      if constexpr (AHEAD) {
+        for (int s = s0; s < s0 + kQChunk - kWinAhead; ++s) step(std::true_type{}, s, s0 + kQChunk);
+        if (more) win_issue(send);  // (the next chunk's records and flows, loaded at the start of this one, are here by now)
+        for (int s = s0 + kQChunk - kWinAhead; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
+      } else {
+        for (int s = s0; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
+        if (more) win_issue(send);
+      }
     } else {
       for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
+      if (more) win_issue(send);
     }
     // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
     {
@@ -483,8 +474,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
           flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][(xi + r) & (kQChunk - 1)];
       }
     }
-    if (send < nsteps) {  // the next chunk's inputs take the slots the write-back has just read
-      if constexpr (WIN) win_fill(send);
+    if (more) {  // the next chunk's inputs take the slots the write-back has just read
+      win_commit();
       S360_WAVE_SYNC();
       chunk_store();
       S360_WAVE_SYNC();
@@ -514,17 +505,11 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
-  // S360_QUAD_WIN=0: the build without the LDS gradient window (tuning only; the results do not depend on it)
-  static const bool winEnv = [] {
-    const char* e = std::getenv("S360_QUAD_WIN");
-    return !(e && e[0] == '0');
-  }();
-  const bool win = winEnv && w + h < 32768;  // (the window's bounds are reduced as packed 16-bit coordinates)
   // S360_QUAD_WAVES_PER_CU: persistent waves per CU of one launch (tuning only; the results do not depend on it)
   static const int perCu = [] {
     const char* e = std::getenv("S360_QUAD_WAVES_PER_CU");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : (winEnv ? 11 : 10);
+    return v > 0 ? v : 11;
   }();
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -532,16 +517,17 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     return n > 0 ? n : 256;
   }();
   const int grid = std::min(nb * B, cus * perCu);
-#define S360_LAUNCH_QUAD(F, W)                                                                                    \
-  hipLaunchKernelGGL((k_sweep_quad<F, W>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, \
-                     c, fc, nb, B, errflag, rowflags)
-  if (fast) {
-    if (win) S360_LAUNCH_QUAD(true, true);
-    else S360_LAUNCH_QUAD(true, false);
-  } else {
-    if (win) S360_LAUNCH_QUAD(false, true);
-    else S360_LAUNCH_QUAD(false, false);
-  }
+  // S360_QUAD_AHEAD=0/1 (measurement switch of this round; results do not depend on it): request the next chunk's window
+  // four steps before the chunk ends (more registers: 2 waves per SIMD) or between the chunks (3 waves per SIMD)
+  static const bool ahead = [] {
+    const char* e = std::getenv("S360_QUAD_AHEAD");
+    return !(e && e[0] == '0');
+  }();
+#define S360_LAUNCH_QUAD(F, A)                                                                                       \
+  hipLaunchKernelGGL((k_sweep_quad<F, A>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
+                     fc, nb, B, errflag, rowflags)
+  if (fast) { if (ahead) S360_LAUNCH_QUAD(true, true); else S360_LAUNCH_QUAD(true, false); }
+  else { if (ahead) S360_LAUNCH_QUAD(false, true); else S360_LAUNCH_QUAD(false, false); }
 #undef S360_LAUNCH_QUAD
 }
 

@@ -102,7 +102,7 @@ def emulated_default_digests(emu_programs):
     return {"latency": _flows_digest(**_EMU_COMMON), "throughput": _flows_digest(TEST_SWEEP_MODE="throughput", **_EMU_COMMON)}
 
 
-@pytest.mark.parametrize("variant", [dict(TEST_SWEEP_MODE="throughput", S360_QUAD_WIN="0")])
+@pytest.mark.parametrize("variant", [dict(TEST_SWEEP_MODE="throughput", S360_QUAD_AHEAD="0")])
 def test_emulated_kernel_variants_give_the_same_flows(emulated_default_digests, variant):
     """The switch-selected sweep build (tests/test_gpu_zz_variants.py) through the whole flow path of the emulated
     library: both algorithms, both directions, a band of masked rows — same digest as the default build."""

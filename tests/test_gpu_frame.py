@@ -194,6 +194,34 @@ def test_frame_slots_batch_equals_single(setup):
         cb.close()
 
 
+def test_frame_slots_batch_sharpened(setup):
+    """--sharpening 0.25 in a batch: the IIR passes of all slots' eyes run in ONE set of launches (a frame's 2 x 4096 row
+    chains alone are half a wave per SIMD); slot by slot the bytes of the frame rendered alone."""
+    rig = R.RigDescription(setup["path"])
+    flags = dict(setup["flags"], sharpening=0.25)
+    frames = [rigutil.frame_inputs(setup["path"], CAM, yaw_deg=y) for y in (0.0, 1.1, 2.3)]
+    cb = R.Context(rig, R.make_params(**flags))
+    c1 = R.Context(rig, R.make_params(**flags))
+    try:
+        cb.set_frame_slots(3)
+        cb.set_sweep_mode("throughput")
+        for k in range(3):
+            cb.select_frame_slot(k)
+            cb.upload_frame(*frames[k])
+        cb.render_batch()
+        for k in range(3):
+            c1.upload_frame(*frames[k])
+            c1.render()
+            cb.select_frame_slot(k)
+            _cmp("sharpened batched slot %d" % k, cb.download_equirect(), c1.download_equirect())
+        c1.set_sharpening(0.0)
+        c1.render()
+        assert not np.array_equal(c1.download_equirect(), cb.download_equirect())  # (the sharpening pass does something)
+    finally:
+        cb.close()
+        c1.close()
+
+
 def test_native_rccl_gather_single_rank(setup):
     """The native strip gather (comm.cpp: grouped ncclSend/ncclRecv on the context stream) on the one GPU there is:
     a one-rank communicator, the gather as a no-op between render_pairs and finish, and one real RCCL send+recv of

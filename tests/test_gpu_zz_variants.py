@@ -1,5 +1,5 @@
-"""The one kernel build left behind a run-time switch, on hardware: S360_QUAD_WIN=0 (throughput sweep without the LDS
-window of I1-gradient texels: global gathers + round-2 texel exchange) must give byte-identical flows to the default. The
+"""The one kernel build left behind a run-time switch, on hardware: S360_QUAD_AHEAD=0 (throughput sweep requesting
+the next chunk's LDS window between the chunks instead of four steps early) must give byte-identical flows to the default. The
 switch is read once per process, so each side of the comparison runs in a process of its own. (Round 2's other variants
 were timed by that round's bench, adopted or deleted: DESIGN.md section 5.)"""
 import os
@@ -50,8 +50,8 @@ def default_throughput_digest(s360lib):
     return _flows_digest(TEST_SWEEP_MODE="throughput")
 
 
-def test_throughput_kernel_without_the_lds_window(default_throughput_digest):
-    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_WIN="0") == default_throughput_digest
+def test_throughput_kernel_window_request_between_chunks(default_throughput_digest):
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_AHEAD="0") == default_throughput_digest
 
 
 def test_throughput_equals_latency_kernel(default_throughput_digest):
