@@ -65,7 +65,7 @@ def test_config2_flow_pair_2048(gpu_rig, oracle, mode):
 def frame8k(rig_json, oracle, s360lib, gpu_rig):
     world = synth.World(4096, seed=360, device="cuda")
     rr = synth.RigRenderer(rig_json, world, 2048)
-    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(2)]
+    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(4)]
     del rr, world
     import torch
     torch.cuda.empty_cache()
@@ -191,6 +191,34 @@ def test_config5_second_frame_temporal(frame8k):
     for u in (0, 3):
         _cmp("flow_pole t1 %d" % u, ctx.get_f32("flow_pole", u), of.get_f32("flow_pole", u))
     _cmp("frame 2 (temporal)", ctx.download_equirect(), want)
+
+
+def test_config5_late_frame_of_a_chain(frame8k, gpu_rig):
+    """Frames 2 and 3 of the same stream (every frame regularised toward the one before: both halves of the temporal
+    double buffers have been read and written by now), on the sequential context against the oracle's chain, and the
+    whole 4-frame stream once more on a context with frame pipelining on (what host/TestRenderStereoPanorama
+    --num_frames and bench.py's video_stream leg run) against the same oracle frame."""
+    ctx, of = frame8k["ctx"], frame8k["of"]
+    want = None
+    for k in (2, 3):
+        side, top, bottom = frame8k["frames"][k]
+        want, _ = of.render(side, top, bottom, use_prev=True, threaded=True)
+        ctx.upload_frame(side, top, bottom)
+        ctx.render(use_prev=True)
+    for i in (3, 12):
+        _cmp("flow_r_to_l t3 %d" % i, ctx.get_f32("flow_r_to_l", i), of.get_f32("flow_r_to_l", i))
+    for u in (1, 2):
+        _cmp("flow_pole t3 %d" % u, ctx.get_f32("flow_pole", u), of.get_f32("flow_pole", u))
+    _cmp("frame 4 of the chain", ctx.download_equirect(), want)
+    pip = R.Context(gpu_rig, R.make_params(**FLAGS_8K))
+    try:
+        pip.set_frame_pipelining(True)
+        for k in range(4):
+            pip.upload_frame(*frame8k["frames"][k])
+            pip.render(use_prev=k > 0)  # no synchronisation between the frames
+        _cmp("frame 4 of the pipelined stream", pip.download_equirect(), want)
+    finally:
+        pip.close()
 
 
 # ---- the flag-gated rows at the 8k preset (VERDICT r02 "parity gap 1": green used to mean green at 1/16 size) ----
