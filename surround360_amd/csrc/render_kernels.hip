@@ -1204,17 +1204,24 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
   const int chain0 = blockIdx.x * IIR_CH;
   const int ntiles = (g.n + IIR_T - 1) / IIR_T;
   unsigned pre[IIR_CH];
-  auto load_tile = [&](int t) {  // X at positions bnd(e + 1), e = 64 t + lane (ROWS) / e = 64 t + lane for all 16 chains (columns)
-    const int e = min(t * IIR_T + lane, g.n - 1);
-    const int pos = iir_bnd<ROWS>(e + 1, g.n);
+  // X at positions bnd(e + 1). ROWS: load kk is chain kk at e = 64 t + lane (256 contiguous bytes). Columns: a chain is a
+  // column, so a load covers 4 image rows x the 16 chains (four 64-byte runs) — lane = (row lane >> 4 of the group, chain
+  // lane & 15), load i is rows 4 i .. 4 i + 3 of the tile — instead of one pixel from each of 64 rows.
+  const int cl = lane & 15, rl = lane >> 4;
+  auto load_tile = [&](int t) {
     if (ROWS) {
+      const int e = min(t * IIR_T + lane, g.n - 1);
+      const int pos = iir_bnd<ROWS>(e + 1, g.n);
 #pragma unroll
       for (int kk = 0; kk < IIR_CH; ++kk)
         pre[kk] = reinterpret_cast<const unsigned*>(X)[iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos)];
     } else {
-      const unsigned* row = reinterpret_cast<const unsigned*>(X) + (size_t)pos * g.w;
+      const int ch = min(chain0 + cl, g.nchains - 1);
 #pragma unroll
-      for (int kk = 0; kk < IIR_CH; ++kk) pre[kk] = row[min(chain0 + kk, g.nchains - 1)];
+      for (int i = 0; i < IIR_CH; ++i) {
+        const int e = min(t * IIR_T + 4 * i + rl, g.n - 1);
+        pre[i] = reinterpret_cast<const unsigned*>(X)[(size_t)iir_bnd<ROWS>(e + 1, g.n) * g.w + ch];
+      }
     }
   };
   const float am = 1.0f - alpha;
@@ -1226,7 +1233,10 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
   load_tile(0);
   for (int t = 0; t < ntiles; ++t) {
 #pragma unroll
-    for (int kk = 0; kk < IIR_CH; ++kk) s_in[kk * IIR_LD + lane] = pre[kk];
+    for (int kk = 0; kk < IIR_CH; ++kk) {
+      if (ROWS) s_in[kk * IIR_LD + lane] = pre[kk];
+      else s_in[cl * IIR_LD + 4 * kk + rl] = pre[kk];
+    }
     S360_WAVE_SYNC();  // (one wave per workgroup: the tile is written position-major and read chain-major)
     if (t + 1 < ntiles) load_tile(t + 1);
     const int cnt = min(IIR_T, g.n - t * IIR_T);
@@ -1248,15 +1258,23 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
       so[j * 4] = v;
     }
     S360_WAVE_SYNC();
-    // store the tile's float results: ROWS: 1 KB per chain row; columns: 256 B per position
-    const int e = t * IIR_T + lane;
-    if (e < g.n) {
+    // store the tile's float results: ROWS: 1 KB per chain row; columns: four 256-byte runs (4 rows x 16 chains) per store
+    if (ROWS) {
+      const int e = t * IIR_T + lane;
+      if (e < g.n) {
 #pragma unroll
-      for (int kk = 0; kk < IIR_CH; ++kk) {
-        if (chain0 + kk < g.nchains) {
-          const float4 o = *reinterpret_cast<const float4*>(s_out + ((size_t)kk * IIR_LD + lane) * 4);
-          Bf[iir_px<ROWS>(g, chain0 + kk, e)] = o;
+        for (int kk = 0; kk < IIR_CH; ++kk) {
+          if (chain0 + kk < g.nchains) {
+            const float4 o = *reinterpret_cast<const float4*>(s_out + ((size_t)kk * IIR_LD + lane) * 4);
+            Bf[iir_px<ROWS>(g, chain0 + kk, e)] = o;
+          }
         }
+      }
+    } else if (chain0 + cl < g.nchains) {
+#pragma unroll
+      for (int i = 0; i < IIR_CH; ++i) {
+        const int p = 4 * i + rl, e = t * IIR_T + p;
+        if (e < g.n) Bf[(size_t)e * g.w + chain0 + cl] = *reinterpret_cast<const float4*>(s_out + ((size_t)cl * IIR_LD + p) * 4);
       }
     }
   }
@@ -1279,19 +1297,32 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
   // 272 bytes of scratch memory per lane, with every prefetched tile waited for at once in order to be stored there)
   typedef float f4r __attribute__((ext_vector_type(4)));
   f4r pre[IIR_CH];
+  const int cl = lane & 15, rl = lane >> 4;  // columns: lane = (row of a group of 4, chain), as in k_iir_causal
   auto load_tile = [&](int t) {  // B at positions bnd(e - 1)
-    const int e = min(t * IIR_T + lane, g.n - 1);
-    const int pos = iir_bnd<ROWS>(e - 1, g.n);
+    if (ROWS) {
+      const int e = min(t * IIR_T + lane, g.n - 1);
+      const int pos = iir_bnd<ROWS>(e - 1, g.n);
 #pragma unroll
-    for (int kk = 0; kk < IIR_CH; ++kk)
-      pre[kk] = *reinterpret_cast<const f4r*>(Bf + iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos));
+      for (int kk = 0; kk < IIR_CH; ++kk)
+        pre[kk] = *reinterpret_cast<const f4r*>(Bf + iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos));
+    } else {
+      const int ch = min(chain0 + cl, g.nchains - 1);
+#pragma unroll
+      for (int i = 0; i < IIR_CH; ++i) {
+        const int e = min(t * IIR_T + 4 * i + rl, g.n - 1);
+        pre[i] = *reinterpret_cast<const f4r*>(Bf + (size_t)iir_bnd<ROWS>(e - 1, g.n) * g.w + ch);
+      }
+    }
   };
   const float am = 1.0f - alpha;
   float v = reinterpret_cast<const float*>(carry)[(size_t)min(chain0 + k, g.nchains - 1) * 4 + c];
   load_tile(ntiles - 1);
   for (int t = ntiles - 1; t >= 0; --t) {
 #pragma unroll
-    for (int kk = 0; kk < IIR_CH; ++kk) *reinterpret_cast<f4r*>(s_in + ((size_t)kk * IIR_LD + lane) * 4) = pre[kk];
+    for (int kk = 0; kk < IIR_CH; ++kk) {
+      if (ROWS) *reinterpret_cast<f4r*>(s_in + ((size_t)kk * IIR_LD + lane) * 4) = pre[kk];
+      else *reinterpret_cast<f4r*>(s_in + ((size_t)cl * IIR_LD + 4 * kk + rl) * 4) = pre[kk];
+    }
     S360_WAVE_SYNC();
     if (t > 0) load_tile(t - 1);
     const int cnt = min(IIR_T, g.n - t * IIR_T);
@@ -1313,15 +1344,16 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
       so[j * 4] = c == 3 ? (unsigned char)255 : (unsigned char)clamp255(v);
     }
     S360_WAVE_SYNC();
-    const int e = t * IIR_T + lane;
-    if (e < g.n) {
 #pragma unroll
-      for (int kk = 0; kk < IIR_CH; ++kk) {
-        if (chain0 + kk < g.nchains) {
-          const unsigned lw = s_out[kk * IIR_LD + lane];
-          const size_t o = iir_px<ROWS>(g, chain0 + kk, e);
+    for (int kk = 0; kk < IIR_CH; ++kk) {
+      // ROWS: store kk is chain kk at position 64 t + lane; columns: rows 4 kk .. 4 kk + 3 of the tile x the 16 chains
+      const int p = ROWS ? lane : 4 * kk + rl, chn = chain0 + (ROWS ? kk : cl), e = t * IIR_T + p;
+      if (e < g.n) {
+        if (chn < g.nchains) {
+          const unsigned lw = s_out[(ROWS ? kk : cl) * IIR_LD + p];
+          const size_t o = iir_px<ROWS>(g, chn, e);
           if (FUSE) {
-            uchar4 p = out[o];
+            uchar4 px = out[o];
             auto f = [&](unsigned char pc, unsigned lc) -> unsigned char {
               const float lf = (float)lc;
               const float hp = (float)pc - lf;
@@ -1330,8 +1362,8 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
               const float ng = hp == 0.0f ? 0.0f : 1.0f;
               return (unsigned char)clamp255(lf + hp * ng * amount);
             };
-            p.x = f(p.x, lw & 255u); p.y = f(p.y, (lw >> 8) & 255u); p.z = f(p.z, (lw >> 16) & 255u);
-            out[o] = p;
+            px.x = f(px.x, lw & 255u); px.y = f(px.y, (lw >> 8) & 255u); px.z = f(px.z, (lw >> 16) & 255u);
+            out[o] = px;
           } else {
             reinterpret_cast<unsigned*>(out)[o] = lw;
           }

@@ -103,7 +103,7 @@ unsigned long long g_quad_rounds = 0, g_quad_fallbacks = 0, g_quad_chunks = 0, g
 #endif
 
 // Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
-template <bool FAST, bool AHEAD>
+template <bool FAST>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
@@ -207,15 +207,21 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
     return tt;
   };
-  // the same four texels from the LDS window, or from global memory for the whole wave if a lane that matters (`rel`)
-  // has its cell outside the window
-  auto fetch = [&](const Cell& k, bool rel) -> Texels {
+  // errorFunction of cell k with its four texels from the LDS window — or, for the whole wave, from global memory if a
+  // lane that matters (`rel`) has its cell outside the window. The two paths are complete evaluations that only meet
+  // in the resulting error: if they met in the texel registers, every step would wait there for ALL outstanding global
+  // loads (one in-order counter), i.e. for the next chunk's prefetches as well.
+  auto evaluate = [&](auto ieee, const Cell& k, bool rel, float4 rc, float ax, float ay, bool& tiny) -> float {
     const int jy = k.y0 - wy0, ju = k.x0 + k.y0 - wu0;
     const bool in = (unsigned)jy <= (unsigned)(kWinRows - 2) && (unsigned)ju <= (unsigned)(kWinCols - 3);
     S360_QSTAT(g_quad_rounds);
     if (__builtin_expect(__ballot(rel && !in) != 0ull, 0)) {
       S360_QSTAT(g_quad_fallbacks);
-      return gather(k);
+      float e = error_of(ieee, gather(k), k, rc, ax, ay, tiny);
+#ifndef S360_WAVE_EMULATION
+      asm volatile("; window miss: evaluated from global memory" : "+v"(e));  // (keeps the two paths from being merged again)
+#endif
+      return e;
     }
     const int off = in ? jy * kWinStride + ju : 0;  // (lanes that do not matter read slot 0)
     const f4a8 ta = *reinterpret_cast<const f4a8*>(&s_win[off]);
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     Texels tt;
     tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
     tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
-    return tt;
+    return error_of(ieee, tt, k, rc, ax, ay, tiny);
   };
   // One pixel update (PixFlow.h:390-397 / 403-410) for the quad's pixel: round 1 evaluates the current / left / up
   // proposals in lanes 0..2, round 2 the two finite-difference probes of the winner in lanes 0..1.
@@ -233,8 +239,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
     const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
     const Cell k = cell_of(x, ax, ay);
-    const Texels t1 = fetch(k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)));
-    const float e = error_of(ieee, t1, k, rc, ax, ay, tiny);
+    const float e = evaluate(ieee, k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)), rc, ax, ay, tiny);
     const float e0 = quad_bcast<0>(e);
     float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
     if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
@@ -250,8 +255,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float cur = b2 ? e2 : c1;
     const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
     const Cell pk = cell_of(x, pax, pay);
-    const Texels t2 = fetch(pk, take && q < 2);
-    const float pe = error_of(ieee, t2, pk, rc, pax, pay, tiny);
+    const float pe = evaluate(ieee, pk, take && q < 2, rc, pax, pay, tiny);
     const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
     const float nx = ex - cur, ny = ey - cur;
     float ggx, ggy;
@@ -330,14 +334,23 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
         umin = min(umin, k.x0 + k.y0); umax = max(umax, k.x0 + k.y0);
       }
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      ymin = min(ymin, __shfl_xor(ymin, m)); umin = min(umin, __shfl_xor(umin, m));
-      ymax = max(ymax, __shfl_xor(ymax, m)); umax = max(umax, __shfl_xor(umax, m));
-    }
+    // wave-wide minima / maxima: inside the 16-lane DPP rows by row_shr 1, 2, 4, 8 (lane 15 of a row then holds the row's
+    // value), across the four rows by v_readlane of lanes 15 / 31 / 47 / 63 and scalar min / max — no LDS round trips
+    auto row_red = [&](int v, bool mx) -> int {
+#define S360_ROW_SHR_STEP(SH)                                                                                      \
+  {                                                                                                                \
+    const int o = __builtin_amdgcn_update_dpp(v, v, 0x110 + SH, 0xF, 0xF, false); /* lanes without a source keep v */ \
+    v = mx ? max(v, o) : min(v, o);                                                                                \
+  }
+      S360_ROW_SHR_STEP(1) S360_ROW_SHR_STEP(2) S360_ROW_SHR_STEP(4) S360_ROW_SHR_STEP(8)
+#undef S360_ROW_SHR_STEP
+      const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31);
+      const int c2 = __builtin_amdgcn_readlane(v, 47), d = __builtin_amdgcn_readlane(v, 63);
+      return mx ? max(max(a, b), max(c2, d)) : min(min(a, b), min(c2, d));
+    };
     S360_QSTAT(g_quad_chunks);
-    ymin = __builtin_amdgcn_readfirstlane(ymin); umin = __builtin_amdgcn_readfirstlane(umin);
-    ymax = __builtin_amdgcn_readfirstlane(ymax); umax = __builtin_amdgcn_readfirstlane(umax);
+    ymin = row_red(ymin, false); umin = row_red(umin, false);
+    ymax = row_red(ymax, true); umax = row_red(umax, true);
     ny0 = kNoWin;
     if (ymax < ymin) return;  // nothing to update in this chunk: no taps
     // rows ymin .. ymax + 1 and columns umin .. umax + 2 are what the incoming flows need; the slack goes evenly to
@@ -349,7 +362,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #pragma unroll
     for (int i = 0; i < kWinRows / 2; ++i) {
       const int Y = ny0 + 2 * i + jr, X = nu0 + jc - Y;
-      wv[i] = *reinterpret_cast<const f2r*>(G1 + (size_t)min(max(Y, 0), h - 1) * w + min(max(X, 0), w - 1));
+      // (32-bit byte offset from the wave-uniform plane base: one address VGPR, the base stays in SGPRs)
+      wv[i] = *reinterpret_cast<const f2r*>(G1b0 + ((unsigned)(__umul24(min(max(Y, 0), h - 1), w) + min(max(X, 0), w - 1)) << 3));
     }
   };
   auto win_commit = [&]() {
@@ -452,14 +466,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const bool steadyChunk = s0 >= kQRows && s0 + kQChunk <= w;
     const bool more = send < nsteps;
     if (steadyChunk) {
-      if constexpr (AHEAD) {
-        for (int s = s0; s < s0 + kQChunk - kWinAhead; ++s) step(std::true_type{}, s, s0 + kQChunk);
-        if (more) win_issue(send);  // (the next chunk's records and flows, loaded at the start of this one, are here by now)
-        for (int s = s0 + kQChunk - kWinAhead; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
-      } else {
-        for (int s = s0; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
-        if (more) win_issue(send);
-      }
+      for (int s = s0; s < s0 + kQChunk - kWinAhead; ++s) step(std::true_type{}, s, s0 + kQChunk);
+      if (more) win_issue(send);  // (the next chunk's records and flows, loaded at the start of this one, are here by now)
+      for (int s = s0 + kQChunk - kWinAhead; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
     } else {
       for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
       if (more) win_issue(send);
@@ -509,7 +518,7 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   static const int perCu = [] {
     const char* e = std::getenv("S360_QUAD_WAVES_PER_CU");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 11;
+    return v > 0 ? v : 8;  // (181 VGPRs: two waves per SIMD)
   }();
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -517,18 +526,12 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     return n > 0 ? n : 256;
   }();
   const int grid = std::min(nb * B, cus * perCu);
-  // S360_QUAD_AHEAD=0/1 (measurement switch of this round; results do not depend on it): request the next chunk's window
-  // four steps before the chunk ends (more registers: 2 waves per SIMD) or between the chunks (3 waves per SIMD)
-  static const bool ahead = [] {
-    const char* e = std::getenv("S360_QUAD_AHEAD");
-    return !(e && e[0] == '0');
-  }();
-#define S360_LAUNCH_QUAD(F, A)                                                                                       \
-  hipLaunchKernelGGL((k_sweep_quad<F, A>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
-                     fc, nb, B, errflag, rowflags)
-  if (fast) { if (ahead) S360_LAUNCH_QUAD(true, true); else S360_LAUNCH_QUAD(true, false); }
-  else { if (ahead) S360_LAUNCH_QUAD(false, true); else S360_LAUNCH_QUAD(false, false); }
-#undef S360_LAUNCH_QUAD
+  if (fast)
+    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B,
+                       errflag, rowflags);
+  else
+    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B,
+                       errflag, rowflags);
 }
 
 }  // namespace s360

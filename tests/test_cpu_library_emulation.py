@@ -96,18 +96,11 @@ def test_emulated_optical_flow_harness(tmp_path, emu_programs):
 _EMU_COMMON = dict(S360_TEST_EMULATED_LIB="1", TEST_FLOW_SIZES="150x120,97x131")
 
 
-@pytest.fixture(scope="module")
-def emulated_default_digests(emu_programs):
+def test_emulated_sweep_kernels_give_the_same_flows(emu_programs):
+    """tests/test_gpu_zz_variants.py's comparison through the whole flow path of the emulated library: both algorithms, both
+    directions, a band of masked rows — the throughput kernel's digest equals the latency kernel's."""
     from test_gpu_zz_variants import _flows_digest
-    return {"latency": _flows_digest(**_EMU_COMMON), "throughput": _flows_digest(TEST_SWEEP_MODE="throughput", **_EMU_COMMON)}
-
-
-@pytest.mark.parametrize("variant", [dict(TEST_SWEEP_MODE="throughput", S360_QUAD_AHEAD="0")])
-def test_emulated_kernel_variants_give_the_same_flows(emulated_default_digests, variant):
-    """The switch-selected sweep build (tests/test_gpu_zz_variants.py) through the whole flow path of the emulated
-    library: both algorithms, both directions, a band of masked rows — same digest as the default build."""
-    from test_gpu_zz_variants import _flows_digest
-    assert _flows_digest(**dict(_EMU_COMMON, **variant)) == emulated_default_digests[variant.get("TEST_SWEEP_MODE", "latency")]
+    assert _flows_digest(TEST_SWEEP_MODE="throughput", **_EMU_COMMON) == _flows_digest(**_EMU_COMMON)
 
 
 def test_operator_level_gpu_tests_pass_on_the_emulated_library(emu_programs):

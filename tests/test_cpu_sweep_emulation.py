@@ -72,14 +72,13 @@ def test_quad_sizes(emulator, w, h):
 
 
 @pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-@pytest.mark.parametrize("ahead", [1, 0])
-def test_quad_lds_window(emulator, mask, ahead):
+def test_quad_lds_window(emulator, mask):
     """The bilinear taps of both rounds come from the LDS window of I1-gradient texels placed per chunk, and a wave one of
     whose taps leaves it gathers from global memory for that round (the generator's +-40 px outliers and +-2 px noise make
-    both happen all the time). ahead: the window requested four steps before the chunk ends / between the chunks."""
-    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1], S360_QUAD_AHEAD=ahead)
-    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], S360_QUAD_AHEAD=ahead, EMU_LANE_ORDER="shuffle")
-    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_AHEAD=ahead, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
+    both happen all the time)."""
+    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1])
+    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], EMU_LANE_ORDER="shuffle")
+    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
 
 
 def test_quad_lds_window_on_smooth_flows(emulator):

@@ -1,7 +1,7 @@
-"""The one kernel build left behind a run-time switch, on hardware: S360_QUAD_AHEAD=0 (throughput sweep requesting
-the next chunk's LDS window between the chunks instead of four steps early) must give byte-identical flows to the default. The
-switch is read once per process, so each side of the comparison runs in a process of its own. (Round 2's other variants
-were timed by that round's bench, adopted or deleted: DESIGN.md section 5.)"""
+"""The two sweep kernels against each other on hardware, through the whole flow path and at sizes above the other tests': the
+throughput kernel (banded, LDS window, persistent waves) must give byte-identical flows to the latency kernel. Each side
+runs in a process of its own. (The kernel variants that round 2 left behind run-time switches were timed by that round's
+bench and adopted or deleted, and so was this round's: DESIGN.md section 5.)"""
 import os
 import subprocess
 import sys
@@ -48,10 +48,6 @@ def _flows_digest(**env):
 @pytest.fixture(scope="module")
 def default_throughput_digest(s360lib):
     return _flows_digest(TEST_SWEEP_MODE="throughput")
-
-
-def test_throughput_kernel_window_request_between_chunks(default_throughput_digest):
-    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_AHEAD="0") == default_throughput_digest
 
 
 def test_throughput_equals_latency_kernel(default_throughput_digest):

@@ -218,6 +218,14 @@ inline T emu_readfirstlane(T x) {
   return x;
 }
 #define __builtin_amdgcn_readfirstlane(x) emu_readfirstlane(x)
+// v_readlane_b32: the value of lane `lane` (which must be active), in every lane
+inline int emu_readlane(int x, int lane) {
+  const emu::Rendezvous r = emu::arrive(emu::OP_DPP, (unsigned)x);
+  unsigned long long v = 0;
+  if (!emu::peer(r, lane, &v)) { std::fprintf(stderr, "emu: v_readlane of an inactive lane\n"); std::abort(); }
+  return (int)(unsigned)v;
+}
+#define __builtin_amdgcn_readlane(x, lane) emu_readlane(x, lane)
 // v_mov_b32_dpp semantics (the controls the kernels use): quad_perm, row_shl:n, row_shr:n, row_bcast:15, row_newbcast:n
 inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const emu::Rendezvous r = emu::arrive(emu::OP_DPP, (unsigned)src);
