@@ -577,15 +577,12 @@ void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flo
   pw.phiMid = c->ramp.phiMid;
   pw.phiRampEnd = c->ramp.phiRampEnd;
   F.warpedExt.ensure((size_t)extW * rows * sizeof(uchar4));
-  // S360_POLE_WARP_PACKED=0 (measurement switch of this round; same bytes): the one-kernel warp
-  static const bool packedWarp = [] { const char* e = std::getenv("S360_POLE_WARP_PACKED"); return !(e && e[0] == '0'); }();
-  if (packedWarp) {
-    F.warpPacked.ensure((size_t)extW * rows * sizeof(unsigned));
-    F.warpTiles.ensure(remap_packed_tiles(extW, rows) * 16);
-    launch_pole_warp_packed(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev, F.warpPacked.as<unsigned>(),
-                            F.warpTiles.p);
-  } else
-    launch_pole_warp(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev);
+  // two kernels: this frame's warp as packed coordinates + tile boxes, then the packed remap (1.00 against 1.24 ms per
+  // 8K frame for the one-kernel form, profiles/r03_v2_*)
+  F.warpPacked.ensure((size_t)extW * rows * sizeof(unsigned));
+  F.warpTiles.ensure(remap_packed_tiles(extW, rows) * 16);
+  launch_pole_warp_packed(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev, F.warpPacked.as<unsigned>(),
+                          F.warpTiles.p);
   launch_pole_finish(c->st, F.warpedExt.as<uchar4>(), warped_out, eqrH, pw);
 }
 

@@ -1487,13 +1487,6 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
                      dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
                      warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 0, 1, (size_t)0, (size_t)0, nt);
 }
-void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
-                      const PoleWarpParams& pw, const DevTables& T) {
-  MapFromPoleFlow mf{flow, pw};
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_tiled<MapFromPoleFlow>), dim3(cdiv(pw.extW, RT_W), cdiv(pw.rows, RT_H), 1),
-                     dim3(RT_W, RT_H), 0, st, extFisheye, pw.extW, pw.rows, mf, warpedExt, pw.extW, pw.rows, T.bicubic_i, 0,
-                     0, 1, (size_t)0, (size_t)0);
-}
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   hipLaunchKernelGGL(k_pole_finish, dim3(cdiv(pw.cols, 256), eqrH), dim3(256), 0, st, warpedExt, out, eqrH, pw);
 }

@@ -72,9 +72,7 @@ void launch_gauss_u8(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int 
 void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha /*nullable*/, int cols, int rows,
                         uchar4* ext, int extW);
 // pole warp map + remap (TRSP:487-503)
-void launch_pole_warp(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
-                      const PoleWarpParams& pw, const DevTables& T);
-// the same as two kernels: coordinates + tile boxes of this frame's warp, then the packed remap
+// as two kernels: coordinates + tile boxes of this frame's warp (k_remap_pack), then the packed remap
 void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
                              const PoleWarpParams& pw, const DevTables& T, unsigned* packed /* extW*rows */,
                              void* tiles /* remap_packed_tiles(extW, rows) * 16 bytes */);
