@@ -47,13 +47,40 @@ namespace s360 {
 namespace {
 
 constexpr unsigned long long kEmptyGranuleQ = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kQRows = 16;   // rows per wave
+// Lanes per pixel (LPP). 4: a pixel is a DPP quad, 16 rows per wave; round 1 uses 3 of the 4 lanes, round 2 two: 5
+// evaluations in 8 lane slots. 3: 5 evaluations in 6 slots, 20 rows per wave — a 16-lane DPP row holds 5 pixels, lanes
+// {0,1,2} {3,4,5} {6,7,8} {9,10,11} {12,13,14}; lane 15 is a passive copy of the last pixel's result, so that row_bcast:15
+// can hand it to the first pixel of the next DPP row; the values of a round are exchanged with row_shr / row_shl by 1 and
+// 2 and a select per role (a quad broadcast does not exist for groups of three): ~16 more instructions per step for 25 %
+// more pixels per step, and bands of 20 rows (20 % fewer bands and hand-offs per flow).
+constexpr int quad_rows(int lpp) { return lpp == 3 ? 20 : 16; }
 constexpr int kUpRing = 64;  // columns of the band above kept in LDS
 
 template <int K>
 __device__ __forceinline__ float quad_bcast(float v) {  // value of lane K of this lane's quad
   const int i = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {  // row_shr:n (0x110 + n) / row_shl:n (0x100 + n); lanes without a source keep v
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+}
+// (LPP 3) the values of the pixel's lanes 0, 1, 2 in every lane of the pixel: role q has its own value, takes the others
+// from 1 or 2 lanes to the left / right (the passive lane 15 computes garbage that nobody reads)
+__device__ __forceinline__ void tri_exchange(float v, int q, float& v0, float& v1, float& v2) {
+  const float l1 = dpp_row<0x111>(v), l2 = dpp_row<0x112>(v), r1 = dpp_row<0x101>(v), r2 = dpp_row<0x102>(v);
+  v0 = q == 0 ? v : (q == 1 ? l1 : l2);
+  v1 = q == 0 ? r1 : (q == 1 ? v : l1);
+  v2 = q == 0 ? r2 : (q == 1 ? r1 : v);
+}
+// (LPP 3) previous result of the row above = the pixel three lanes to the left. The first pixel of DPP rows 1..3 takes
+// lane 15 of the previous DPP row (the passive copy of its last pixel: row_bcast:15 into lanes 0..3, then row_shr:3
+// overwrites lane 3 with lane 0); the first pixel of the wave (row 0 of the band) keeps `old` = the granule-fed value.
+__device__ __forceinline__ float from_row_above_t(float old, float v) {
+  int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x142, 0xE, 0x1, false);
+  r = __builtin_amdgcn_update_dpp(r, __builtin_bit_cast(int, v), 0x113, 0xF, 0xF, false);
+  return __builtin_bit_cast(float, r);
 }
 // previous result of the row above: lane - 4. Inside a 16-lane DPP row that is row_shr:4 (banks 1..3); the first
 // quad of DPP rows 1..3 takes lane 15 of the previous DPP row (row_bcast:15, bank 0); the first quad of the wave
@@ -85,10 +112,10 @@ constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every 
 // chunk. The window is stored in those coordinates: LDS row jy holds image row wy0 + jy, column ju holds image column
 // (wu0 + ju) - (wy0 + jy). A bilinear cell (x0, y0) is inside iff 0 <= y0 - wy0 <= kWinRows - 2 and
 // 0 <= x0 + y0 - wu0 <= kWinCols - 3; its texels are [jy][ju], [jy][ju + 1], [jy + 1][ju + 1], [jy + 1][ju + 2].
-// 16 + 2 rows / columns are the chunk itself; the rest is room for the flows' spread inside the chunk and for the
-// left / up candidates and the probes around them. Rows are padded to 34 texels = 68 dwords: the 16 rows of a step
+// rows + 2 rows and 16 + 2 columns are the chunk itself; the rest is room for the flows' spread inside the chunk and for
+// the left / up candidates and the probes around them. Rows are padded to 34 texels = 68 dwords: the 16 rows of a step
 // read 16-byte pieces at (almost) the same ju, which then fall on 16 disjoint groups of 4 banks.
-constexpr int kWinRows = 24;
+constexpr int win_rows(int lpp) { return quad_rows(lpp) + 8; }  // 24 / 28: the band + the cell's second row + slack
 constexpr int kWinCols = 32;
 constexpr int kWinStride = 34;
 constexpr int kNoWin = 0x3fffffff;
@@ -103,7 +130,7 @@ unsigned long long g_quad_rounds = 0, g_quad_fallbacks = 0, g_quad_chunks = 0, g
 #endif
 
 // Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
-template <bool FAST>
+template <bool FAST, int LPP>
 __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
@@ -113,6 +140,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   // The records and flows of a 16-step chunk are fetched once (four pixels per lane, eight loads per chunk instead of
   // two per step) and staged in LDS; a slot of s_res holds a pixel's flow before its step and its result after it,
   // indexed by step. Row strides of 17 elements keep the 16 rows of a read on distinct banks.
+  constexpr int kQRows = quad_rows(LPP), kWinRows = win_rows(LPP);
+  constexpr int kItems = kQRows * kQChunk / 64;  // pixel-steps of a chunk per lane (4 / 5)
   constexpr int kRW = kQChunk + 1;
   typedef float f4r __attribute__((ext_vector_type(4)));
   typedef float f2r __attribute__((ext_vector_type(2)));
@@ -157,7 +186,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       continue;
     }
   }
-  const int r = lane >> 2, q = lane & 3;
+  // r: row of the band; q: role in the pixel (0 current / x probe, 1 left / y probe, 2 up; 3: spare lane)
+  const int l16 = lane & 15, g5 = min(l16 / 3, 4);
+  const int r = LPP == 3 ? (lane >> 4) * 5 + g5 : lane >> 2, q = LPP == 3 ? l16 - 3 * g5 : lane & 3;
   const int yi = band * kQRows + r;
   const bool rowValid = yi < h;
   const int yic = rowValid ? yi : h - 1;
@@ -165,8 +196,6 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const bool hasUp = yi > 0;
   const bool hasUpBand = band > 0;
   const bool publishes = band + 1 < nb;
-  const float4* __restrict__ recRow = rec + (size_t)y * w;
-  float2* __restrict__ flowRow = flow + (size_t)y * w;
   const float fy = (float)y;
   const float kEps = 0.001f, kInf = __int_as_float(0x7f800000);
   const int nsteps = w + kQRows - 1;
@@ -175,14 +204,15 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 
   // getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464) of the tap (x + ax, y + ay) of this lane's pixel
   struct Cell { float mx, my; int x0, y0; };
-  auto cell_of = [&](int x, float ax, float ay) -> Cell {
+  auto cell_of_row = [&](int x, float fyRow, float ax, float ay) -> Cell {
     Cell k;
     k.mx = __builtin_amdgcn_fmed3f((float)x + ax, 0.0f, c.wm2);
-    k.my = __builtin_amdgcn_fmed3f(fy + ay, 0.0f, c.hm2);
+    k.my = __builtin_amdgcn_fmed3f(fyRow + ay, 0.0f, c.hm2);
     k.x0 = (int)k.mx;
     k.y0 = (int)k.my;
     return k;
   };
+  auto cell_of = [&](int x, float ax, float ay) -> Cell { return cell_of_row(x, fy, ax, ay); };
   // errorFunction (PixFlow.h:493-534) on the texels of cell k. `tiny` collects the lanes whose operands leave the
   // proven range of the fast division / square root.
   auto error_of = [&](auto ieee, const Texels& tt, const Cell& k, float4 rc, float ax, float ay, bool& tiny) -> float {
@@ -240,8 +270,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
     const Cell k = cell_of(x, ax, ay);
     const float e = evaluate(ieee, k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)), rc, ax, ay, tiny);
-    const float e0 = quad_bcast<0>(e);
-    float e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
+    float e0, e1, e2;
+    if constexpr (LPP == 3) tri_exchange(e, q, e0, e1, e2);
+    else { e0 = quad_bcast<0>(e); e1 = quad_bcast<1>(e); e2 = quad_bcast<2>(e); }
     if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
     if (!hasUp) e2 = kInf;            // no up proposal in the first row
     // proposeFlowUpdate x2 in the reference's order, written as selects (with an index beside them the compiler would
@@ -256,7 +287,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
     const Cell pk = cell_of(x, pax, pay);
     const float pe = evaluate(ieee, pk, take && q < 2, rc, pax, pay, tiny);
-    const float ex = quad_bcast<0>(pe), ey = quad_bcast<1>(pe);
+    float ex, ey;
+    if constexpr (LPP == 3) { float unused; tri_exchange(pe, q, ex, ey, unused); }
+    else { ex = quad_bcast<0>(pe); ey = quad_bcast<1>(pe); }
     const float nx = ex - cur, ny = ey - cur;
     float ggx, ggy;
     if (decltype(ieee)::value) {
@@ -297,23 +330,34 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   float2 fl = make_float2(0.f, 0.f);  // result of the previous pixel of this row (same in the 4 lanes of the quad)
   float4 nrc;
   float2 nfo;
-  // the next chunk's records / flows of this lane's four steps (4 q .. 4 q + 3): native vector types, which stay in
-  // VGPRs through the lambdas' captures (HIP's float4 struct went to scratch memory)
-  f4r cr[4];
-  f2r cf[4];
+  // The next chunk's records / flows: its kQRows x 16 pixel-steps are dealt to the lanes as items — item i of a lane is
+  // row 4 i + (lane >> 4), step lane & 15, i.e. a wave-wide load covers 16 consecutive pixels of four rows — and go
+  // through native vector types, which stay in VGPRs through the lambdas' captures (HIP's float4 struct went to scratch).
+  f4r cr[kItems];
+  f2r cf[kItems];
+  const int ioStep = lane & 15;
+  int ioOff[kItems];   // y * w of the item's row (clamped rows: never used, see ioOk)
+  bool ioOk[kItems];   // the item's row exists
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int yiI = band * kQRows + 4 * i + (lane >> 4);
+    ioOk[i] = yiI < h;
+    const int yc = ioOk[i] ? yiI : h - 1;
+    ioOff[i] = (dir > 0 ? yc : h - 1 - yc) * w;
+  }
   auto chunk_load = [&](int sbase) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int xc = col(sbase + 4 * q + j - r);
-      cr[j] = *reinterpret_cast<const f4r*>(recRow + xc);
-      cf[j] = *reinterpret_cast<const f2r*>(flowRow + xc);
+    for (int i = 0; i < kItems; ++i) {
+      const int xc = col(sbase + ioStep - (4 * i + (lane >> 4)));
+      cr[i] = *reinterpret_cast<const f4r*>(rec + ioOff[i] + xc);
+      cf[i] = *reinterpret_cast<const f2r*>(flow + ioOff[i] + xc);
     }
   };
   auto chunk_store = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<f4r*>(&s_rec[r][4 * q + j]) = cr[j];
-      *reinterpret_cast<f2r*>(&s_res[r][4 * q + j]) = cf[j];
+    for (int i = 0; i < kItems; ++i) {
+      *reinterpret_cast<f4r*>(&s_rec[4 * i + (lane >> 4)][ioStep]) = cr[i];
+      *reinterpret_cast<f2r*>(&s_res[4 * i + (lane >> 4)][ioStep]) = cf[i];
     }
   };
   // Places the window around the cells the incoming flows of the chunk starting at step `sbase` point at (cr / cf hold
@@ -326,10 +370,11 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   auto win_issue = [&](int sbase) {
     int ymin = 0x7fffffff, umin = 0x7fffffff, ymax = -1, umax = -1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int xi = sbase + 4 * q + j - r;
-      if (rowValid && xi >= 0 && xi < w && cr[j].x == cr[j].x) {
-        const Cell k = cell_of(dir > 0 ? xi : w - 1 - xi, cf[j].x + 0.0f, cf[j].y + 0.0f);
+    for (int j = 0; j < kItems; ++j) {
+      const int xi = sbase + ioStep - (4 * j + (lane >> 4));
+      if (ioOk[j] && xi >= 0 && xi < w && cr[j].x == cr[j].x) {
+        const int yiJ = band * kQRows + 4 * j + (lane >> 4);
+        const Cell k = cell_of_row(dir > 0 ? xi : w - 1 - xi, (float)(dir > 0 ? yiJ : h - 1 - yiJ), cf[j].x + 0.0f, cf[j].y + 0.0f);
         ymin = min(ymin, k.y0); ymax = max(ymax, k.y0);
         umin = min(umin, k.x0 + k.y0); umax = max(umax, k.x0 + k.y0);
       }
@@ -428,8 +473,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);  // unclamped: out-of-range columns are inactive
     const bool upd = rc.x == rc.x;
     float2 up;
-    up.x = from_row_above_q(upl.x, fl.x);
-    up.y = from_row_above_q(upl.y, fl.y);
+    up.x = LPP == 3 ? from_row_above_t(upl.x, fl.x) : from_row_above_q(upl.x, fl.x);
+    up.y = LPP == 3 ? from_row_above_t(upl.y, fl.y) : from_row_above_q(upl.y, fl.y);
     // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
     // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
     // two rounds are skipped.
@@ -447,6 +492,11 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       }
       res.x = take ? res.x : alt.x;
       res.y = take ? res.y : alt.y;
+    }
+    if constexpr (LPP == 3) {  // lane 15 of every DPP row: passive copy of its last pixel's result (for row_bcast:15)
+      const float px = dpp_row<0x111>(res.x), py = dpp_row<0x111>(res.y);
+      res.x = q == 3 ? px : res.x;
+      res.y = q == 3 ? py : res.y;
     }
     fl = res;
     if (q == 0) s_res[r][s & (kQChunk - 1)] = res;
@@ -473,14 +523,13 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
       for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
       if (more) win_issue(send);
     }
-    // ---- write-back of the chunk: row r produced columns [s0 - r, send - r) ----
+    // ---- write-back of the chunk: row rr produced columns [s0 - rr, send - rr); item = (row, step) as in chunk_load ----
     {
-      const int base = s0 - r + q;
 #pragma unroll
-      for (int k = 0; k < kQChunk / 4; ++k) {
-        const int xi = base + 4 * k;
-        if (rowValid && (steadyChunk || (xi >= 0 && xi < w && xi < send - r)) && !S360_DBG(fc, 4))
-          flowRow[dir > 0 ? xi : w - 1 - xi] = s_res[r][(xi + r) & (kQChunk - 1)];
+      for (int i = 0; i < kItems; ++i) {
+        const int rr = 4 * i + (lane >> 4), xi = s0 + ioStep - rr;
+        if (ioOk[i] && (steadyChunk || (xi >= 0 && xi < w && s0 + ioStep < send)) && !S360_DBG(fc, 4))
+          *reinterpret_cast<f2r*>(flow + ioOff[i] + (dir > 0 ? xi : w - 1 - xi)) = *reinterpret_cast<const f2r*>(&s_res[rr][ioStep]);
       }
     }
     if (more) {  // the next chunk's inputs take the slots the write-back has just read
@@ -496,7 +545,15 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 }
 
 // ==========================================================================================
-int sweep_quad_num_bands(int h) { return (h + kQRows - 1) / kQRows; }
+// S360_QUAD_LPP=3 / 4 (measurement switch of this round; the results do not depend on it): lanes per pixel
+static int quad_lpp() {
+  static const int v = [] {
+    const char* e = std::getenv("S360_QUAD_LPP");
+    return e && e[0] == '4' ? 4 : 3;
+  }();
+  return v;
+}
+int sweep_quad_num_bands(int h) { const int rows = quad_rows(quad_lpp()); return (h + rows - 1) / rows; }
 size_t sweep_quad_handoff_bytes(int w, int h, int B) {
   return 256 + (size_t)B * sweep_quad_num_bands(h) * w * sizeof(unsigned long long);
 }
@@ -526,12 +583,12 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
     return n > 0 ? n : 256;
   }();
   const int grid = std::min(nb * B, cus * perCu);
-  if (fast)
-    hipLaunchKernelGGL((k_sweep_quad<true>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B,
-                       errflag, rowflags);
-  else
-    hipLaunchKernelGGL((k_sweep_quad<false>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, fc, nb, B,
-                       errflag, rowflags);
+#define S360_LAUNCH_QUAD(F, L)                                                                                       \
+  hipLaunchKernelGGL((k_sweep_quad<F, L>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
+                     fc, nb, B, errflag, rowflags)
+  if (quad_lpp() == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
+  else { if (fast) S360_LAUNCH_QUAD(true, 4); else S360_LAUNCH_QUAD(false, 4); }
+#undef S360_LAUNCH_QUAD
 }
 
 }  // namespace s360

@@ -64,21 +64,25 @@ def test_lock_sizes(emulator, w, h):
     _run(emulator, ["lock", w, h, 2, 23, "rows0", 0], EMU_LANE_ORDER="shuffle")
 
 
-@pytest.mark.parametrize("w,h", [(3, 2), (16, 16), (31, 16), (32, 17), (33, 33), (48, 20), (200, 70)])
-def test_quad_sizes(emulator, w, h):
-    """Widths without, with exactly one and with several interior chunks (the first one is steps 16..31: w >= 32)."""
-    _run(emulator, ["quad", w, h, 2, 33, "random", 1, 1])
-    _run(emulator, ["quad", w, h, 2, 33, "bands", 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
+@pytest.mark.parametrize("w,h", [(3, 2), (16, 16), (31, 16), (32, 17), (33, 33), (48, 20), (47, 21), (64, 41), (200, 70)])
+@pytest.mark.parametrize("lpp", [3, 4])
+def test_quad_sizes(emulator, w, h, lpp):
+    """Widths without, with exactly one and with several interior chunks (the first one is steps 16..31 / 32..47: w >= 32 /
+    48); heights of exactly one band (16 / 20 rows), one row more, two bands and one row more."""
+    _run(emulator, ["quad", w, h, 2, 33, "random", 1, 1], S360_QUAD_LPP=lpp)
+    _run(emulator, ["quad", w, h, 2, 33, "bands", 1, 1], S360_QUAD_LPP=lpp, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1, EMU_LANE_ORDER="rev")
 
 
 @pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-def test_quad_lds_window(emulator, mask):
+@pytest.mark.parametrize("lpp", [3, 4])
+def test_quad_lds_window(emulator, mask, lpp):
     """The bilinear taps of both rounds come from the LDS window of I1-gradient texels placed per chunk, and a wave one of
     whose taps leaves it gathers from global memory for that round (the generator's +-40 px outliers and +-2 px noise make
-    both happen all the time)."""
-    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1])
-    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], EMU_LANE_ORDER="shuffle")
-    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
+    both happen all the time). lpp: lanes per pixel — 4 (a DPP quad, 16 rows per wave) or 3 (20 rows per wave, values
+    exchanged with row shifts, lane 15 of a DPP row a passive copy)."""
+    _run(emulator, ["quad", 70, 50, 2, 51, mask, 1, 1], S360_QUAD_LPP=lpp)
+    _run(emulator, ["quad", 53, 40, 2, 52, mask, 0, 0], S360_QUAD_LPP=lpp, EMU_LANE_ORDER="shuffle")
+    _run(emulator, ["quad", 200, 70, 2, 53, mask, 1, 1], S360_QUAD_LPP=lpp, S360_QUAD_WAVES_PER_CU=2, EMU_CUS=1)
 
 
 def test_quad_lds_window_on_smooth_flows(emulator):
