@@ -322,8 +322,14 @@ int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, 
  * Replaces the non-accelerated path of Raw2Rgb (SR/camera_isp/Raw2Rgb.cpp:441-456 -> CameraIsp.h): black level,
  * anti-vignetting, white balance, clamp + stretch, demosaic (bilinear or edge-aware), composite CCM + tone-curve LUT,
  * IIR unsharp mask, 8- or 16-bit output. Independent of s360_ctx (no rig is involved).
- * Not available: FREQUENCY_DM_FILTER (demosaic_filter 1; cv::dct) and stuck-pixel removal with a non-zero radius
- * (a serial in-place pass, CameraIsp.h:1024-1104; radius 0 in every shipped configuration) -> S360_ERR_INVALID_ARG. */
+ * Not available: FREQUENCY_DM_FILTER (demosaic_filter 1; cv::dct) -> S360_ERR_INVALID_ARG.
+ * Stuck-pixel removal (CameraIsp.h:1024-1104) with a non-zero radius: the reference's loop over the sorted region,
+ *     for (int k = region.size() - 1; k <= region.size() - stuckPixelThreshold; k--)        (:1090-1092)
+ * compares size_t values, so for 2 <= stuckPixelThreshold <= (stuckPixelRadius + 1)^2 (the population of a red / blue
+ * region; the shipped configurations say 5) its condition is false at once and the pass changes nothing: such
+ * configurations are accepted and are exactly that no-op (pinned against CameraIsp.h compiled: tests/test_cpu_isp.py).
+ * Thresholds outside that range make the pass a serial in-place median filter of the dark regions in boustrophedon
+ * order; those are rejected with S360_ERR_INVALID_ARG. */
 #define S360_ISP_MAX_CURVE_POINTS 16
 typedef struct s360_isp_config {
   /* the "CameraIsp" JSON object as the constructor stores it (CameraIsp.h:425-607): doubles narrowed to float */
@@ -341,6 +347,9 @@ typedef struct s360_isp_config {
   int32_t demosaic_filter;    /* 0 bilinear, 2 edge-aware (default) */
   int32_t resize;             /* 1, 2, 4, 8 */
   int32_t disable_tone_curve, black_level_offset;
+  /* removeStuckPixels (CameraIsp.h:1024-1104), read when stuck_pixel_radius > 0 */
+  int32_t stuck_pixel_threshold;
+  float stuck_pixel_darkness_threshold;
 } s360_isp_config;
 /* CameraIsp(json, output_bpp) defaults (CameraIsp.h:440-462) + Raw2Rgb's flag defaults. */
 void s360_isp_config_defaults(s360_isp_config* cfg);
@@ -363,7 +372,7 @@ int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* o
  * Halide). This entry point — and host/Unpacker on top of it — runs the SOFT-ISP arithmetic, the one Raw2Rgb runs
  * without --accelerate (Raw2Rgb.cpp:441-456), pinned bit for bit to CameraIsp.h compiled from the reference.
  * Also not available (S360_ERR_INVALID_ARG): demosaic_filter 1 = FREQUENCY_DM_FILTER (CameraIsp.h:1175-1192, needs
- * cv::dct) and stuckPixelRadius > 0 (CameraIsp.h:1024-1104); no shipped ISP configuration uses either. */
+ * cv::dct) and stuck-pixel removal with a threshold for which the reference's pass is not a no-op (see s360_isp_config). */
 int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr);
 /* A camera's raw Bayer frame through the ISP straight into a frame's source slot, on the context's upload stream and
  * without leaving the device — the reference's chain through files (Unpacker writes the ISP's 16-bit result as a PNG,

@@ -10,10 +10,12 @@
 // supereasyjson over a container-only OpenCV stand-in, oracle/ref_isp.cpp) by tests/test_cpu_isp.py, and against the
 // committed outputs of that library (tests/golden/isp_golden.npz) where /root/reference is absent.
 //
-// Not restated: the DCT demosaic (FREQUENCY_DM_FILTER needs cv::dct) and stuck-pixel removal with a non-zero radius
+// Not restated: the DCT demosaic (FREQUENCY_DM_FILTER needs cv::dct). Stuck-pixel removal with a non-zero radius IS
+// (round 3; formerly:
 // (a serial in-place pass over an unstable sort, CameraIsp.h:1024-1104; radius 0 in every shipped configuration).
 // Build with -ffp-contract=off like the rest of the oracle.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
@@ -41,6 +43,9 @@ struct IspConfig {
   int bayerPattern = 2;      // 0 RGGB, 1 GRBG, 2 GBRG (default), 3 BGGR
   // Raw2Rgb flags
   int outputBpp = 8, demosaicFilter = 2 /*EDGE_AWARE*/, resize = 1, disableToneCurve = 0, blackLevelOffset = 0;
+  // removeStuckPixels (CameraIsp.h:1024-1104), used when stuckPixelRadius > 0
+  int stuckPixelThreshold = 0;
+  float stuckPixelDarknessThreshold = 0.0f;
 };
 
 namespace isp_detail {
@@ -165,7 +170,6 @@ inline void ispUnpackFrame(int bits, const uint8_t* frame, int w, int h, uint16_
 inline void ispRun(const IspConfig& c, const uint16_t* raw, int inW, int inH, void* out) {
   using namespace isp_detail;
   if (c.demosaicFilter != 0 && c.demosaicFilter != 2) throw std::runtime_error("isp oracle: demosaic filter 1 (DCT) is not restated");
-  if (c.stuckPixelRadius > 0) throw std::runtime_error("isp oracle: stuck-pixel removal is not restated");
   if (c.resize != 1 && c.resize != 2 && c.resize != 4 && c.resize != 8) throw std::runtime_error("expecting a resize value of 1, 2, 4, or 8");
   const IspTables T = ispSetup(c);
   const int width = inW / c.resize, height = inH / c.resize;
@@ -229,6 +233,49 @@ inline void ispRun(const IspConfig& c, const uint16_t* raw, int inW, int inH, vo
       v = clampf(v, lo, hi);
       RAW(i, j) = (v - lo) / (hi - lo);
     }
+  if (c.stuckPixelRadius > 0) {  // removeStuckPixels (CameraIsp.h:1024-1104), in place and in its boustrophedon order
+    struct Pval { float val; int i, j; };
+    std::vector<Pval> region;
+    const int R = c.stuckPixelRadius;
+    for (int i = 0; i < height; ++i) {
+      const bool even = (i % 2) == 0;
+      const int jStart = even ? 0 : width - 1, jEnd = even ? width - 1 : 0, jStep = even ? 1 : -1;
+      for (int j = jStart; j != jEnd; j += jStep) {  // (the last pixel of a scan line is never visited: `!=`, :1054)
+        const bool tr = redPixel(i, j), tg = greenPixel(i, j), tb = !tr && !tg;
+        region.clear();
+        float mean = 0.0f;
+        for (int y = -R; y <= R; y++) {
+          const int ip = reflecti(i + y, height);
+          for (int x = -R; x <= R; x++) {
+            const int jp = reflecti(j + x, width);
+            const bool pr = redPixel(ip, jp), pg = greenPixel(ip, jp), pb = !pr && !pg;
+            if ((pr && tr) || (pg && tg) || (pb && tb)) {
+              mean += RAW(ip, jp);
+              region.push_back(Pval{RAW(ip, jp), ip, jp});
+            }
+          }
+        }
+        mean /= float(region.size());
+        if (mean < c.stuckPixelDarknessThreshold) {
+          // The reference sorts the region here and then walks it from the top while
+          //     int k = region.size() - 1;  k <= region.size() - stuckPixelThreshold;  k--          (:1090-1092)
+          // holds — a comparison of size_t values: with 2 <= threshold <= region.size() it is false at once and the pixel
+          // is left alone; otherwise (threshold 0, 1, negative or above the region's size) it is true for every k down to
+          // 0, the centre pixel is always found and takes the region's median value region[size / 2].val.
+          const size_t n = region.size(), lim = n - (size_t)c.stuckPixelThreshold;
+          bool found = false;
+          for (int k = (int)n - 1; (size_t)k <= lim; k--)
+            if (region[(size_t)k].i == i && region[(size_t)k].j == j) { found = true; break; }
+          if (found) {
+            std::vector<float> v(n);
+            for (size_t k = 0; k < n; ++k) v[k] = region[k].val;
+            std::sort(v.begin(), v.end());  // (only the median VALUE is read: the unstable order of equal values is immaterial)
+            RAW(i, j) = v[n / 2];
+          }
+        }
+      }
+    }
+  }
   // demosaic (CameraIsp.h:1156-1212): planes r, g, b hold the raw value at their own Bayer sites
   std::vector<float> r(n, 0.0f), g(n, 0.0f), b(n, 0.0f);
   auto AT = [&](std::vector<float>& m, int i, int j) -> float& { return m[(size_t)i * width + j]; };

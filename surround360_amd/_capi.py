@@ -59,6 +59,7 @@ class IspConfig(C.Structure):
         ("stuck_pixel_radius", C.c_int32), ("bayer_pattern", C.c_int32), ("output_bpp", C.c_int32),
         ("demosaic_filter", C.c_int32), ("resize", C.c_int32), ("disable_tone_curve", C.c_int32),
         ("black_level_offset", C.c_int32),
+        ("stuck_pixel_threshold", C.c_int32), ("stuck_pixel_darkness_threshold", C.c_float),
     ]
 
 

@@ -121,6 +121,9 @@ void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.
     }
   }
   if (const JV* r = isp->get("stuckPixelRadius")) c->stuck_pixel_radius = 2 * (int)number_of(*r, "stuckPixelRadius");
+  if (const JV* r = isp->get("stuckPixelThreshold")) c->stuck_pixel_threshold = (int)number_of(*r, "stuckPixelThreshold");
+  if (const JV* r = isp->get("stuckPixelDarknessThreshold"))
+    c->stuck_pixel_darkness_threshold = (float)number_of(*r, "stuckPixelDarknessThreshold");
   if (const JV* b = isp->get("bayerPattern")) {  // setup(): the first of these names the string contains
     if (b->t != JV::STR) throw Error(S360_ERR_IO, "isp json: 'bayerPattern' is not a string");
     static const char* names[4] = {"RGGB", "GRBG", "GBRG", "BGGR"};
@@ -140,7 +143,16 @@ void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut) 
   if (cfg.demosaic_filter != 0 && cfg.demosaic_filter != 2) throw Error(S360_ERR_INVALID_ARG, "expecting Demosaic filter in [0,2]");
   if (cfg.resize != 1 && cfg.resize != 2 && cfg.resize != 4 && cfg.resize != 8)
     throw Error(S360_ERR_INVALID_ARG, "expecting a resize value of 1, 2, 4, or 8. got " + std::to_string(cfg.resize));
-  if (cfg.stuck_pixel_radius > 0) throw Error(S360_ERR_INVALID_ARG, "stuck-pixel removal (stuckPixelRadius > 0) is not supported");
+  if (cfg.stuck_pixel_radius > 0) {
+    // removeStuckPixels' loop condition `k <= region.size() - stuckPixelThreshold` (size_t arithmetic, CameraIsp.h:1090-1092)
+    // is false from the start for 2 <= threshold <= region.size(): the pass is a no-op. The smallest region is a red /
+    // blue pixel's: the same-colour sites of a (2 R + 1)^2 window, R = stuck_pixel_radius = 2 x the JSON value.
+    const long long nmin = (long long)(cfg.stuck_pixel_radius + 1) * (cfg.stuck_pixel_radius + 1);
+    if (cfg.stuck_pixel_threshold < 2 || cfg.stuck_pixel_threshold > nmin)
+      throw Error(S360_ERR_INVALID_ARG, "stuck-pixel removal with stuckPixelThreshold " + std::to_string(cfg.stuck_pixel_threshold) +
+                                            ": outside 2.." + std::to_string(nmin) + " the reference's pass is a serial in-place median "
+                                            "filter of the dark regions (CameraIsp.h:1024-1104), which is not available");
+  }
   if (cfg.bayer_pattern < 0 || cfg.bayer_pattern > 3) throw Error(S360_ERR_INVALID_ARG, "bayer_pattern must be 0..3");
   if (cfg.n_vignette_h < 1 || cfg.n_vignette_h > S360_ISP_MAX_CURVE_POINTS || cfg.n_vignette_v < 1 ||
       cfg.n_vignette_v > S360_ISP_MAX_CURVE_POINTS)

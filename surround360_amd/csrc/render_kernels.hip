@@ -1192,12 +1192,25 @@ __device__ __forceinline__ size_t iir_px(const IirGeom& g, int chain, int pos) {
   return ROWS ? (size_t)chain * g.w + pos : (size_t)pos * g.w + chain;
 }
 
+// The float results of a causal half live in global memory until the anticausal half has read them: three floats per pixel
+// (B, G, R) — the alpha chain's value is never read, the output alpha is 255 (Filter.h:40-127 runs on 3-channel images) —
+// i.e. 12 + 12 instead of 16 + 16 bytes per pixel and pass pair.
+struct IirPx { float b, g, r; };
+__device__ __forceinline__ void iir_put(float* __restrict__ B, size_t px, float4 v) {
+  IirPx o{v.x, v.y, v.z};
+  *reinterpret_cast<IirPx*>(B + px * 3) = o;
+}
+typedef float iir_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ iir_f4 iir_get(const float* __restrict__ B, size_t px) {
+  const IirPx o = *reinterpret_cast<const IirPx*>(B + px * 3);
+  return iir_f4{o.b, o.g, o.r, 0.0f};
+}
 // Causal half: B[e] = v after consuming X[bnd(e+1)], e = 0..n-1, v0 = X[0]; carry[chain] = final v.
 template <bool ROWS>
 __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t npix, float alpha) {
   const uchar4* __restrict__ X = im.x[blockIdx.y];
-  float4* __restrict__ Bf = im.buf[blockIdx.y];
-  float4* __restrict__ carry = Bf + npix;
+  float* __restrict__ Bf = reinterpret_cast<float*>(im.buf[blockIdx.y]);
+  float* __restrict__ carry = Bf + npix * 3;
   __shared__ unsigned s_in[IIR_CH * IIR_LD];
   __shared__ float s_out[IIR_CH * IIR_LD * 4];
   const int lane = threadIdx.x, k = lane >> 2, c = lane & 3;
@@ -1266,7 +1279,7 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
         for (int kk = 0; kk < IIR_CH; ++kk) {
           if (chain0 + kk < g.nchains) {
             const float4 o = *reinterpret_cast<const float4*>(s_out + ((size_t)kk * IIR_LD + lane) * 4);
-            Bf[iir_px<ROWS>(g, chain0 + kk, e)] = o;
+            iir_put(Bf, iir_px<ROWS>(g, chain0 + kk, e), o);
           }
         }
       }
@@ -1274,19 +1287,19 @@ __global__ __launch_bounds__(64) void k_iir_causal(IirImgs im, IirGeom g, size_t
 #pragma unroll
       for (int i = 0; i < IIR_CH; ++i) {
         const int p = 4 * i + rl, e = t * IIR_T + p;
-        if (e < g.n) Bf[(size_t)e * g.w + chain0 + cl] = *reinterpret_cast<const float4*>(s_out + ((size_t)cl * IIR_LD + p) * 4);
+        if (e < g.n) iir_put(Bf, (size_t)e * g.w + chain0 + cl, *reinterpret_cast<const float4*>(s_out + ((size_t)cl * IIR_LD + p) * 4));
       }
     }
   }
-  if (chain0 + k < g.nchains) reinterpret_cast<float*>(carry)[(size_t)(chain0 + k) * 4 + c] = v;
+  if (chain0 + k < g.nchains) carry[(size_t)(chain0 + k) * 4 + c] = v;
 }
 
 // Anticausal half: for e = n-1 .. 0: v = lerp(B[bnd(e-1)], v); OUT[e] = clamp(v). FUSE: OUT is the unsharp mask of
 // `img` against that low-pass value, written in place.
 template <bool ROWS, bool FUSE>
 __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, size_t npix, float alpha, float amount) {
-  const float4* __restrict__ Bf = im.buf[blockIdx.y];
-  const float4* __restrict__ carry = Bf + npix;
+  const float* __restrict__ Bf = reinterpret_cast<const float*>(im.buf[blockIdx.y]);
+  const float* __restrict__ carry = Bf + npix * 3;
   uchar4* __restrict__ out = im.out[blockIdx.y];
   __shared__ float s_in[IIR_CH * IIR_LD * 4];
   __shared__ unsigned s_out[IIR_CH * IIR_LD];
@@ -1304,18 +1317,18 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
       const int pos = iir_bnd<ROWS>(e - 1, g.n);
 #pragma unroll
       for (int kk = 0; kk < IIR_CH; ++kk)
-        pre[kk] = *reinterpret_cast<const f4r*>(Bf + iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos));
+        pre[kk] = iir_get(Bf, iir_px<ROWS>(g, min(chain0 + kk, g.nchains - 1), pos));
     } else {
       const int ch = min(chain0 + cl, g.nchains - 1);
 #pragma unroll
       for (int i = 0; i < IIR_CH; ++i) {
         const int e = min(t * IIR_T + 4 * i + rl, g.n - 1);
-        pre[i] = *reinterpret_cast<const f4r*>(Bf + (size_t)iir_bnd<ROWS>(e - 1, g.n) * g.w + ch);
+        pre[i] = iir_get(Bf, (size_t)iir_bnd<ROWS>(e - 1, g.n) * g.w + ch);
       }
     }
   };
   const float am = 1.0f - alpha;
-  float v = reinterpret_cast<const float*>(carry)[(size_t)min(chain0 + k, g.nchains - 1) * 4 + c];
+  float v = carry[(size_t)min(chain0 + k, g.nchains - 1) * 4 + c];
   load_tile(ntiles - 1);
   for (int t = ntiles - 1; t >= 0; --t) {
 #pragma unroll

@@ -545,17 +545,23 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 }
 
 // ==========================================================================================
-// S360_QUAD_LPP=3 / 4 (measurement switch of this round; the results do not depend on it): lanes per pixel
-static int quad_lpp() {
-  static const int v = [] {
+// Lanes per pixel of a launch. Three lanes per pixel carry 25 % more pixels per instruction and pay ~16 instructions per
+// step for it: a launch that saturates the chip (the side flows of a batch of frame slots: thousands of bands) is
+// instruction-issue-bound and gains (30.3 against 27.2 Gpx/s on a saturated side level), a launch that is a dependency
+// chain (the pole flows: every band waits for its predecessor, about one band per SIMD) pays the longer step (33.1
+// against 34.3 Gpx/s); profiles/r03_v4_*. The choice only depends on the launch's shape, so that the hand-off arena can
+// be sized before the launch. S360_QUAD_LPP=3 / 4 overrides it (tests, tuning; the results do not depend on it).
+static int quad_lpp(int h, int B) {
+  static const int forced = [] {
     const char* e = std::getenv("S360_QUAD_LPP");
-    return e && e[0] == '4' ? 4 : 3;
+    return e && (e[0] == '3' || e[0] == '4') ? e[0] - '0' : 0;
   }();
-  return v;
+  if (forced) return forced;
+  return (long long)B * ((h + 15) / 16) >= 4096 ? 3 : 4;  // bands of 16 rows in the launch against 1024 SIMDs x 4
 }
-int sweep_quad_num_bands(int h) { const int rows = quad_rows(quad_lpp()); return (h + rows - 1) / rows; }
+int sweep_quad_num_bands(int h, int B) { const int rows = quad_rows(quad_lpp(h, B)); return (h + rows - 1) / rows; }
 size_t sweep_quad_handoff_bytes(int w, int h, int B) {
-  return 256 + (size_t)B * sweep_quad_num_bands(h) * w * sizeof(unsigned long long);
+  return 256 + (size_t)B * sweep_quad_num_bands(h, B) * w * sizeof(unsigned long long);
 }
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
@@ -566,7 +572,7 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
   fc.rcRows = 1.0f / c.frows;
   fc.rcEps = 1.0f / 0.001f;
   fc.dbg = S360_DBG_FROM_ENV();  // developer tools only: 1 gathers always hit, 2 no waiting on the band above, 4 no write-back
-  const int nb = sweep_quad_num_bands(h);
+  const int nb = sweep_quad_num_bands(h, B);
   // `handoff` must be all-ones (ticket counter in the first 256 bytes, then the granules): FlowEngine resets the
   // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
@@ -586,7 +592,7 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
 #define S360_LAUNCH_QUAD(F, L)                                                                                       \
   hipLaunchKernelGGL((k_sweep_quad<F, L>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
                      fc, nb, B, errflag, rowflags)
-  if (quad_lpp() == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
+  if (quad_lpp(h, B) == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
   else { if (fast) S360_LAUNCH_QUAD(true, 4); else S360_LAUNCH_QUAD(false, 4); }
 #undef S360_LAUNCH_QUAD
 }

@@ -32,6 +32,13 @@ CONFIG_GRBG_NOSHARP = json.dumps({"CameraIsp": {
 CONFIGS = {"full": CONFIG_FULL, "minimal": CONFIG_MINIMAL, "empty": CONFIG_EMPTY, "grbg": CONFIG_GRBG_NOSHARP}
 
 
+def stuck_pixel_config(radius, threshold, darkness, base=CONFIG_FULL):
+    """CONFIG_FULL with removeStuckPixels switched on (CameraIsp.h:1024-1104): stuckPixelRadius > 0."""
+    j = json.loads(base)
+    j["CameraIsp"].update(stuckPixelRadius=radius, stuckPixelThreshold=threshold, stuckPixelDarknessThreshold=darkness)
+    return json.dumps(j)
+
+
 def bayer_frame(w, h, seed=0, pattern="GBRG", bits=16):
     """A smooth colour scene with edges and noise, mosaiced: H x W uint16 (full 16-bit range used, like the 12-bit
     sensor data Unpacker scales up)."""

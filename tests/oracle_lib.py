@@ -406,6 +406,7 @@ class IspConfigC(C.Structure):
         ("stuckPixelRadius", C.c_int), ("bayerPattern", C.c_int),
         ("outputBpp", C.c_int), ("demosaicFilter", C.c_int), ("resize", C.c_int), ("disableToneCurve", C.c_int),
         ("blackLevelOffset", C.c_int),
+        ("stuckPixelThreshold", C.c_int), ("stuckPixelDarknessThreshold", C.c_float),
     ]
 
 
@@ -452,6 +453,8 @@ def isp_config_from_json(json_text, output_bpp=8, demosaic_filter=2, resize=1, d
                     dst[i][k] = p[k]
     if "stuckPixelRadius" in j:
         c.stuckPixelRadius = 2 * int(j["stuckPixelRadius"])
+    c.stuckPixelThreshold = int(j.get("stuckPixelThreshold", 0))
+    c.stuckPixelDarknessThreshold = float(j.get("stuckPixelDarknessThreshold", 0.0))
     if "bayerPattern" in j:  # setup() uses find(): the first pattern name contained in the string, in this order
         c.bayerPattern = next(i for i, n in enumerate(BAYER_PATTERNS) if n in j["bayerPattern"])
     c.outputBpp, c.demosaicFilter, c.resize = output_bpp, demosaic_filter, resize

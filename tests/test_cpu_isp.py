@@ -68,6 +68,42 @@ def test_shipped_configurations(ref, cfg):
         assert np.array_equal(got, ref.ref_isp_run(js, raw, bpp)), (cfg, bpp)
 
 
+# (radius, threshold, darkness threshold, does the reference's pass change pixels?)
+STUCK = [(1, 5, 0.5, False), (1, 2, 0.9, False), (2, 9, 0.9, False), (1, 9, 0.9, False),  # 2 <= threshold <= region: no-op
+         (1, 1, 0.5, True), (1, 0, 0.9, True), (1, 10, 0.9, True), (2, 26, 0.5, True), (1, -3, 0.9, True)]
+
+
+@pytest.mark.parametrize("radius,thr,dark,active", STUCK)
+def test_stuck_pixel_removal_equals_compiled_reference(ref, radius, thr, dark, active):
+    """removeStuckPixels with a non-zero radius through the reference's own CameraIsp.h, compiled: the restatement equals
+    it, and the loop condition of CameraIsp.h:1090-1092 (a comparison of size_t values) does what include/s360.h says it
+    does — for 2 <= stuckPixelThreshold <= the region's population the pass changes nothing (the same pixels as with
+    radius 0), outside that range it is a median filter of the dark regions."""
+    raw = isputil.bayer_frame(96, 72, seed=9)
+    raw[10:14, 20:24] = 65535  # a few hot sites in dark surroundings
+    raw[40:60, 10:30] //= 8
+    js = isputil.stuck_pixel_config(radius, thr, dark)
+    got = ref.isp_run(ref.isp_config_from_json(js, 16), raw)
+    want = ref.ref_isp_run(js, raw, 16)
+    assert np.array_equal(got, want), "%d samples differ" % (got != want).sum()
+    off = ref.ref_isp_run(isputil.stuck_pixel_config(0, thr, dark), raw, 16)
+    assert np.array_equal(want, off) == (not active)
+
+
+def test_library_accepts_the_stuck_pixel_no_op_and_rejects_the_filter(oracle, s360lib):
+    """libs360's host side: a configuration whose stuck-pixel pass is the reference's no-op derives the same tables as with
+    radius 0; one whose pass would filter is refused with a message."""
+    from surround360_amd import isp as I
+    ok = I.config_from_json(isputil.stuck_pixel_config(1, 5, 0.11), 16)
+    assert (ok.stuck_pixel_radius, ok.stuck_pixel_threshold) == (2, 5) and abs(ok.stuck_pixel_darkness_threshold - 0.11) < 1e-6
+    base = I.config_from_json(isputil.CONFIG_FULL, 16)
+    for a, b in zip(I.config_tables(ok)[:2], I.config_tables(base)[:2]):
+        assert np.array_equal(a, b)
+    for thr in (1, 0, 10, -3):
+        with pytest.raises(Exception, match="stuck"):
+            I.config_tables(I.config_from_json(isputil.stuck_pixel_config(1, thr, 0.5), 16))
+
+
 def test_tables(oracle):
     c = oracle.isp_config_from_json(isputil.CONFIG_FULL, 16)
     ccm, lut = oracle.isp_tables(c)
@@ -82,10 +118,6 @@ def test_unsupported_modes_raise(oracle):
     raw = isputil.bayer_frame(32, 32)
     with pytest.raises(RuntimeError):
         oracle.isp_run(oracle.isp_config_from_json(isputil.CONFIG_MINIMAL, 8, 1), raw)  # DCT demosaic
-    c = oracle.isp_config_from_json(isputil.CONFIG_MINIMAL, 8)
-    c.stuckPixelRadius = 2
-    with pytest.raises(RuntimeError):
-        oracle.isp_run(c, raw)
 
 
 # ---- host half of the product (libs360, no device needed): configuration reading and derived tables -----------------
@@ -110,7 +142,8 @@ def test_library_reads_configuration_like_the_constructor(oracle, s360lib, name)
         assert list(getattr(got, a)) == list(getattr(want, b)), a
     for a, b in [("saturation", "saturation"), ("contrast", "contrast"), ("sharpening_support", "sharpeningSupport"),
                  ("noise_core", "noiseCore"), ("n_vignette_h", "nVignetteH"), ("n_vignette_v", "nVignetteV"),
-                 ("stuck_pixel_radius", "stuckPixelRadius"), ("bayer_pattern", "bayerPattern"),
+                 ("stuck_pixel_radius", "stuckPixelRadius"), ("stuck_pixel_threshold", "stuckPixelThreshold"),
+                 ("bayer_pattern", "bayerPattern"),
                  ("output_bpp", "outputBpp"), ("demosaic_filter", "demosaicFilter"), ("resize", "resize"),
                  ("disable_tone_curve", "disableToneCurve"), ("black_level_offset", "blackLevelOffset")]:
         assert getattr(got, a) == getattr(want, b), a

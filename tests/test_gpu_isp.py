@@ -36,6 +36,24 @@ def test_isp_equals_oracle(oracle, s360lib, case):
     assert np.array_equal(again, got)
 
 
+def test_isp_with_stuck_pixel_radius(oracle, s360lib):
+    """stuckPixelRadius > 0 with the shipped configurations' stuckPixelThreshold 5: the reference's removeStuckPixels is
+    then a no-op (its loop condition, CameraIsp.h:1090-1092; pinned against CameraIsp.h compiled in tests/test_cpu_isp.py)
+    and the library accepts the configuration; a threshold for which the pass would filter is refused."""
+    from surround360_amd import isp as I
+    js = isputil.stuck_pixel_config(1, 5, 0.11)
+    raw = isputil.bayer_frame(160, 120, seed=4)
+    raw[40:60, 10:30] //= 8
+    want = oracle.isp_run(oracle.isp_config_from_json(js, 16), raw)
+    isp = I.CameraIsp(I.config_from_json(js, 16))
+    try:
+        assert np.array_equal(isp.get_image(raw), want)
+    finally:
+        isp.close()
+    with pytest.raises(Exception, match="stuck"):
+        I.CameraIsp(I.config_from_json(isputil.stuck_pixel_config(1, 1, 0.5), 16))
+
+
 def test_isp_two_sizes_one_object(oracle, s360lib):
     """The vignette curves follow the frame size."""
     from surround360_amd import isp as I
