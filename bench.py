@@ -150,7 +150,7 @@ def cpu_baseline_reference(side, top, bottom, rig_path=RIG, flags=None, timeout=
         return got, {"value": 1.0 / sec, "unit": "frames/s", "cores": max(1, peak - 1), "kind": "reference",
                      "host_cores_available": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
                      "sample": "the reference's own TestRenderStereoPanorama program (its sources compiled over stand-ins for "
-                               "OpenCV / Eigen / folly / gflags / glog: oracle/_ref, -O2, no FMA) rendering ONE full 8K frame of "
+                               "OpenCV / Eigen / folly / gflags / glog: oracle/_ref, built with the optimisation flags of the reference's own CMakeLists.txt:34 (-O3 -mavx -funroll-loops), no FMA) rendering ONE full 8K frame of "
                                "the bench workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low, sharpening as benched) as one process: 17 PNG "
                                "inputs decoded from disk, the program's own thread fan-out, equirect and per-frame state files "
                                "encoded to disk — what batch_process_video.py pays per frame; cores = peak threads it ran"}
