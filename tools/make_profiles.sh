@@ -13,7 +13,7 @@ set -e
 TAG=${1:?tag}
 SLOTS=${2:-12}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-OUT=gpurun_out/prof_$TAG
+OUT=${S360_PROF_DIR:-/tmp/s360_prof}/prof_$TAG  # (rocprofv3 databases: hundreds of MB — outside gpurun_out/, which is merged back and capped)
 mkdir -p $OUT profiles
 ISO="python bench.py --inflight 1 --slots $SLOTS --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/ks.log 2>&1
