@@ -42,11 +42,15 @@ tag, slots = sys.argv[1], int(sys.argv[2])
 txt = open("profiles/%s_pmc_fetch_write.txt" % tag).read()
 fetch, write = txt.split("\n\n", 1)
 def per_launch(block, kernel):
+    """launches and KB per launch over ALL instantiations of a kernel template (k_sweep_quad<true, 3> and <true, 4> are
+    the same kernel with three / four lanes per pixel: FlowEngine picks one per launch shape)"""
+    n, tot = 0, 0.0
     for line in block.splitlines():
         if kernel in line:
             f = line.split()
-            return int(f[-3]), float(f[-1])
-    return 0, 0.0
+            n += int(f[-3])
+            tot += float(f[-2])
+    return n, (tot / n if n else 0.0)
 d = {"source": "profiles/%s_pmc_fetch_write.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --inflight 1 --slots %d --steps 2 --warmup 1 --no-extras)" % (tag, slots),
      "correction": "gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM) -> read side doubled; WRITE_SIZE as reported",
      "frames_per_launch": slots, "kernels": {}}
