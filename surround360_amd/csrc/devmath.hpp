@@ -24,6 +24,28 @@
 
 namespace s360 {
 
+// XCD-aware tile order (cdna_hip_programming.md T1): the dispatcher places workgroup b on XCD b % 8, each XCD has its own
+// L2, so with the plain order the neighbours of a tile — whose halo / source box overlaps its own — run on seven other
+// L2s and every overlap is fetched again through the fabric. Here the grid's linear workgroup index is re-dealt so that
+// each XCD works through ONE contiguous run of tiles (x fastest, then y, then z): neighbours meet in the same L2.
+// Bijective for any grid size; a pure re-ordering of which workgroup renders which tile (results cannot depend on it).
+struct TileId { unsigned x, y, z; };
+__device__ __forceinline__ TileId xcd_tile() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy * gridDim.z;
+  const unsigned L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+  unsigned P = L;
+  if (T >= 64) {
+    const unsigned k = L & 7u, n = T >> 3, rem = T & 7u;  // XCD k serves n (+1 for k < rem) consecutive tiles
+    P = k * n + (k < rem ? k : rem) + (L >> 3);
+  }
+  TileId t;
+  t.x = P % gx;
+  const unsigned q = P / gx;
+  t.y = q % gy;
+  t.z = q / gy;
+  return t;
+}
+
 S360_HD int cv_round(float v) {
   if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT_MIN;
   return (int)__builtin_rintf(v);

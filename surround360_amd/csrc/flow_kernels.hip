@@ -147,9 +147,10 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   __shared__ __attribute__((aligned(8))) float s_in[IH][IWP][CN];
   __shared__ __attribute__((aligned(8))) float s_mid[IH][SB_TW + 1][CN];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-  const int tx0 = blockIdx.x * SB_TW, ty0 = blockIdx.y * SB_TH;
+  const TileId tile = xcd_tile();  // neighbouring tiles (shared halo) on the same XCD's L2
+  const int tx0 = tile.x * SB_TW, ty0 = tile.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
-  src += (SRC == 2 ? up.sbs * CN : bs * (SRC == 1 ? 1 : CN)) * blockIdx.z;
+  src += (SRC == 2 ? up.sbs * CN : bs * (SRC == 1 ? 1 : CN)) * tile.z;
   // tile load: when the thread count is a multiple of the (padded) tile width a thread keeps its column and walks
   // down the rows — no division, one reflected column index per thread
   constexpr int LW = (IW + 7) & ~7;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   }
   __syncthreads();
   // column pass: task = (column lx, group of 4 consecutive y)
-  dst = dst_tab ? dst_tab[blockIdx.z] : dst + bs * CN * blockIdx.z;
+  dst = dst_tab ? dst_tab[tile.z] : dst + bs * CN * tile.z;
   for (int t = tid; t < SB_TW * (SB_TH / 4); t += NT) {
     const int lx = t % SB_TW, ly0 = (t / SB_TW) * 4;
     const int gx = tx0 + lx;
@@ -266,16 +267,16 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
       if (gy >= h) continue;
       const size_t off = (size_t)gy * w + gx;
       if (EPI == 1) {
-        const float cc = 1.0f - A[bs * idx.i0[blockIdx.z] + off] * A[bs * idx.i1[blockIdx.z] + off];
+        const float cc = 1.0f - A[bs * idx.i0[tile.z] + off] * A[bs * idx.i1[tile.z] + off];
 #pragma unroll
         for (int k = 0; k < CN; ++k) outv[o][k] = cc * outv[o][k] + (1.0f - cc) * s_in[ly0 + o + R][lx + R][k];
       }
       if (EPI == 2) {
-        const float2 g = Gp[bs * idx.i0[blockIdx.z] + off];
-        const bool upd = A[bs * idx.i0[blockIdx.z] + off] > 0.9f && A[bs * idx.i1[blockIdx.z] + off] > 0.9f;
-        rec[bs * blockIdx.z + off] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, outv[o][0], outv[o][CN - 1]);
+        const float2 g = Gp[bs * idx.i0[tile.z] + off];
+        const bool upd = A[bs * idx.i0[tile.z] + off] > 0.9f && A[bs * idx.i1[tile.z] + off] > 0.9f;
+        rec[bs * tile.z + off] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, outv[o][0], outv[o][CN - 1]);
         // rows with at least one updated pixel (all-ones = none: the sweeps let bands without any leave at once)
-        if (rowflags && upd) rowflags[(size_t)blockIdx.z * h + gy] = 0u;
+        if (rowflags && upd) rowflags[(size_t)tile.z * h + gy] = 0u;
       } else {
 #pragma unroll
         for (int k = 0; k < CN; ++k) dst[off * CN + k] = outv[o][k];
@@ -375,9 +376,10 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32c2_tiled(const float2* 
   __shared__ float s_ax[UC_TW][4], s_ay[UC_TH][4];
   __shared__ int s_sx[UC_TW], s_sy[UC_TH];
   const int tid = threadIdx.x;
-  const int dx0 = blockIdx.x * UC_TW, dy0 = blockIdx.y * UC_TH;
-  src += sbs * blockIdx.z;
-  dst += dbs * blockIdx.z;
+  const TileId tile = xcd_tile();
+  const int dx0 = tile.x * UC_TW, dy0 = tile.y * UC_TH;
+  src += sbs * tile.z;
+  dst += dbs * tile.z;
   if (tid < UC_TW) {
     float f;
     resize_coord(min(dx0 + tid, dw - 1), scx, &s_sx[tid], &f);

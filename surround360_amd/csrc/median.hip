@@ -95,9 +95,10 @@ __global__ __launch_bounds__(256) void k_median5_c2_row8(const float2* __restric
                                                          int h, size_t bs) {
   __shared__ __attribute__((aligned(16))) float s_p[2][MED_LH][MED_LW];
   const int tid = threadIdx.x;
-  const int X0 = blockIdx.x * (MED_BX * MED_T), Y0 = blockIdx.y * MED_BY;
-  src += bs * blockIdx.z;
-  dst += bs * blockIdx.z;
+  const TileId tile = xcd_tile();  // neighbouring tiles (shared 2-pixel halo) on the same XCD's L2
+  const int X0 = tile.x * (MED_BX * MED_T), Y0 = tile.y * MED_BY;
+  src += bs * tile.z;
+  dst += bs * tile.z;
   // A thread keeps its column and walks down the 12 rows (no division, one clamped column index); columns 256..259
   // are taken by the first four threads. Within a row the 4-float groups are stored even groups first, odd groups
   // after them (med_pos): a thread's three 16-byte reads below then fall on consecutive addresses across the lanes

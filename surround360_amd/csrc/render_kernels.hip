@@ -383,19 +383,20 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
                                                                          const short* __restrict__ tab, int alpha_mode,
                                                                          int yFeatherStart, int featherSize, size_t sbs,
                                                                          size_t dbs, int tilesPerImage) {
-  src += sbs * blockIdx.z;
-  dst += dbs * blockIdx.z;
-  packed += dbs * blockIdx.z;
-  mapfn.advance(dbs * blockIdx.z);
+  const TileId tile = xcd_tile();  // neighbouring tiles (overlapping source boxes) on the same XCD's L2
+  src += sbs * tile.z;
+  dst += dbs * tile.z;
+  packed += dbs * tile.z;
+  mapfn.advance(dbs * tile.z);
   __shared__ uchar4 s_tile[PT_CAP];
-  const int4 box = tiles[(size_t)tilesPerImage * blockIdx.z + (size_t)blockIdx.y * gridDim.x + blockIdx.x];  // (uniform)
+  const int4 box = tiles[(size_t)tilesPerImage * tile.z + (size_t)tile.y * gridDim.x + tile.x];  // (uniform)
   const int bx0 = box.x, by0 = box.y, bw = box.z, bh = box.w;
-  const int x = blockIdx.x * PT_W + threadIdx.x;
+  const int x = tile.x * PT_W + threadIdx.x;
   unsigned pk[4] = {0u, 0u, 0u, 0u};
   if (bh > 0 && x < dw) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
+      const int y = tile.y * PT_H + threadIdx.y + PT_TY * k;
       if (y < dh) pk[k] = packed[(size_t)y * dw + x];
     }
   }
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
+    const int y = tile.y * PT_H + threadIdx.y + PT_TY * k;
     if (x >= dw || y >= dh) continue;
     uchar4 o = make_uchar4(0, 0, 0, 0);
     if (bh > 0) {
