@@ -150,6 +150,28 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   const TileId tile = xcd_tile();  // neighbouring tiles (shared halo) on the same XCD's L2
   const int tx0 = tile.x * SB_TW, ty0 = tile.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
+  // EPI 1 / 2: the epilogue's operands (the two alphas, EPI 2 also I0's gradient) of this thread's column task are
+  // requested NOW, in front of the tile load, instead of after the column pass: the kernel spent 80 % of its wave time
+  // waiting (profiles/r03_v5_pmc_sq.txt) and this was the second of its two exposed memory round trips per tile.
+  constexpr int kColTasks = SB_TW * (SB_TH / 4);
+  static_assert(EPI == 0 || kColTasks <= NT, "one column task per thread when the epilogue is prefetched");
+  float pa0[4] = {0.f, 0.f, 0.f, 0.f}, pa1[4] = {0.f, 0.f, 0.f, 0.f};
+  float2 pg[4];
+  if (EPI != 0 && tid < kColTasks) {
+    const int lx = tid % SB_TW, ly0 = (tid / SB_TW) * 4, gx = tx0 + lx;
+    const size_t b0 = bs * idx.i0[tile.z], b1 = bs * idx.i1[tile.z];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int gy = ty0 + ly0 + o;
+      pg[o] = make_float2(0.f, 0.f);
+      if (gx < w && gy < h) {
+        const size_t off = (size_t)gy * w + gx;
+        pa0[o] = A[b0 + off];
+        pa1[o] = A[b1 + off];
+        if (EPI == 2) pg[o] = Gp[b0 + off];
+      }
+    }
+  }
   src += (SRC == 2 ? up.sbs * CN : bs * (SRC == 1 ? 1 : CN)) * tile.z;
   // tile load: when the thread count is a multiple of the (padded) tile width a thread keeps its column and walks
   // down the rows — no division, one reflected column index per thread
@@ -157,8 +179,18 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   constexpr bool kColumnWalk = (NT % LW) == 0;
   const int lxc = tid % LW, lyc = tid / LW;
   const int gxc = reflect101(tx0 - R + (lxc < IW ? lxc : 0), w);
-  for (int i = kColumnWalk ? lyc : tid; i < (kColumnWalk ? IH : IH * IW); i += (kColumnWalk ? NT / LW : NT)) {
-    if (kColumnWalk && lxc >= IW) break;
+  // Two phases: every element this thread brings in is REQUESTED first (into registers), then all of them go to LDS. As
+  // one loop (load, store, next) the compiler waited for each element before it asked for the next one: 5-6 serialised
+  // memory round trips per tile.
+  constexpr int kLdStep = kColumnWalk ? NT / LW : NT, kLdEnd = kColumnWalk ? IH : IH * IW;
+  constexpr int kLdIters = (kLdEnd + kLdStep - 1) / kLdStep;
+  float ld[kLdIters][CN];
+#pragma unroll
+  for (int it = 0; it < kLdIters; ++it) {
+    const int i = (kColumnWalk ? lyc : tid) + it * kLdStep;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) ld[it][k] = 0.0f;
+    if (i >= kLdEnd || (kColumnWalk && lxc >= IW)) continue;
     const int ly = kColumnWalk ? i : i / IW, lx = kColumnWalk ? lxc : i - ly * IW;
     const int gy = reflect101(ty0 - R + ly, h), gx = kColumnWalk ? gxc : reflect101(tx0 - R + lx, w);
     if (SRC == 2) {  // k_resize_linear_f32's arithmetic at (gx, gy), then the scalar multiply
@@ -184,17 +216,27 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
         }
         float v = h0 * b0 + h1 * b1;
         v *= up.post_scale;
-        s_in[ly][lx][k] = v;
+        ld[it][k] = v;
       }
     } else if (SRC == 1) {  // Sobel ksize=1: [-1 0 +1], BORDER_REPLICATE, no scale
       const float* r0 = src + (size_t)gy * w;
-      s_in[ly][lx][0] = r0[min(gx + 1, w - 1)] - r0[max(gx - 1, 0)];
-      s_in[ly][lx][CN - 1] = src[(size_t)min(gy + 1, h - 1) * w + gx] - src[(size_t)max(gy - 1, 0) * w + gx];
+      ld[it][0] = r0[min(gx + 1, w - 1)] - r0[max(gx - 1, 0)];
+      ld[it][CN - 1] = src[(size_t)min(gy + 1, h - 1) * w + gx] - src[(size_t)max(gy - 1, 0) * w + gx];
     } else if (CN == 2) {
-      *reinterpret_cast<float2*>(&s_in[ly][lx][0]) = *reinterpret_cast<const float2*>(src + ((size_t)gy * w + gx) * CN);
+      const float2 v = *reinterpret_cast<const float2*>(src + ((size_t)gy * w + gx) * CN);
+      ld[it][0] = v.x;
+      ld[it][CN - 1] = v.y;
     } else {
-      s_in[ly][lx][0] = src[(size_t)gy * w + gx];
+      ld[it][0] = src[(size_t)gy * w + gx];
     }
+  }
+#pragma unroll
+  for (int it = 0; it < kLdIters; ++it) {
+    const int i = (kColumnWalk ? lyc : tid) + it * kLdStep;
+    if (i >= kLdEnd || (kColumnWalk && lxc >= IW)) continue;
+    const int ly = kColumnWalk ? i : i / IW, lx = kColumnWalk ? lxc : i - ly * IW;
+    if (CN == 2) *reinterpret_cast<float2*>(&s_in[ly][lx][0]) = make_float2(ld[it][0], ld[it][CN - 1]);
+    else s_in[ly][lx][0] = ld[it][0];
   }
   __syncthreads();
   // row pass: task = (row ly, group of 4 consecutive x). Two-channel images move through LDS as 8-byte pairs (one
@@ -267,13 +309,13 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
       if (gy >= h) continue;
       const size_t off = (size_t)gy * w + gx;
       if (EPI == 1) {
-        const float cc = 1.0f - A[bs * idx.i0[tile.z] + off] * A[bs * idx.i1[tile.z] + off];
+        const float cc = 1.0f - pa0[o] * pa1[o];
 #pragma unroll
         for (int k = 0; k < CN; ++k) outv[o][k] = cc * outv[o][k] + (1.0f - cc) * s_in[ly0 + o + R][lx + R][k];
       }
       if (EPI == 2) {
-        const float2 g = Gp[bs * idx.i0[tile.z] + off];
-        const bool upd = A[bs * idx.i0[tile.z] + off] > 0.9f && A[bs * idx.i1[tile.z] + off] > 0.9f;
+        const float2 g = pg[o];
+        const bool upd = pa0[o] > 0.9f && pa1[o] > 0.9f;
         rec[bs * tile.z + off] = make_float4(upd ? g.x : __int_as_float(0x7fc00000), g.y, outv[o][0], outv[o][CN - 1]);
         // rows with at least one updated pixel (all-ones = none: the sweeps let bands without any leave at once)
         if (rowflags && upd) rowflags[(size_t)tile.z * h + gy] = 0u;
@@ -288,11 +330,10 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
 // ------------------------------------------------------------------------------------------
 // resize INTER_LINEAR float (pyramid x0.9, PixFlow.h:487; final upscale :176).
 // Horizontal: s<0 => (0, f=0); s>=sw-1 => S[sw-1]*1; vertical rows clipped, f kept.
-template <int CN>
+template <int CN, int PPT>
 __global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restrict__ src, int sw, int sh, size_t sbs,
                                                            float* __restrict__ dst, int dw, int dh, size_t dbs,
-                                                           double scx, double scy, float post_scale, int do_scale,
-                                                           int planes_per_thread) {
+                                                           double scx, double scy, float post_scale, int do_scale) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x;
   const int dy = blockIdx.y * blockDim.y + threadIdx.y;
   if (dx >= dw || dy >= dh) return;
@@ -305,22 +346,38 @@ __global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restri
   const size_t r0 = (size_t)clip_idx(sy, sh) * sw * CN, r1 = (size_t)clip_idx(sy + 1, sh) * sw * CN;
   const float b0 = 1.f - fy, b1 = fy;
   const bool edge = sx >= sw - 1;
+  const int sx1 = edge ? sx : sx + 1;  // (the edge case multiplies the one tap by 1.0f: the second address is a dummy)
   const float a0 = 1.f - fx, a1 = fx;
-  // the planes of a launch share their geometry: one thread produces this pixel of `planes_per_thread` of them
-  for (int pl = 0; pl < planes_per_thread; ++pl) {
-    const size_t z = (size_t)blockIdx.z * planes_per_thread + pl;
+  // the planes of a launch share their geometry: one thread produces this pixel of PPT of them. All 4 x PPT taps are
+  // requested before the first is used — the kernel is pure memory latency (92 % of its wave time waiting when the
+  // planes were walked one after the other, profiles/r03_v5_pmc_sq.txt).
+  float t[PPT][CN][4];
+#pragma unroll
+  for (int pl = 0; pl < PPT; ++pl) {
+    const size_t z = (size_t)blockIdx.z * PPT + pl;
     const float* S0 = src + sbs * CN * z + r0;
     const float* S1 = src + sbs * CN * z + r1;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+      t[pl][k][0] = S0[sx * CN + k];
+      t[pl][k][1] = S0[sx1 * CN + k];
+      t[pl][k][2] = S1[sx * CN + k];
+      t[pl][k][3] = S1[sx1 * CN + k];
+    }
+  }
+#pragma unroll
+  for (int pl = 0; pl < PPT; ++pl) {
+    const size_t z = (size_t)blockIdx.z * PPT + pl;
     float* D = dst + dbs * CN * z;
 #pragma unroll
     for (int k = 0; k < CN; ++k) {
       float h0, h1;
       if (edge) {
-        h0 = S0[sx * CN + k] * 1.0f;
-        h1 = S1[sx * CN + k] * 1.0f;
+        h0 = t[pl][k][0] * 1.0f;
+        h1 = t[pl][k][2] * 1.0f;
       } else {
-        h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
-        h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
+        h0 = t[pl][k][0] * a0 + t[pl][k][1] * a1;
+        h1 = t[pl][k][2] * a0 + t[pl][k][3] * a1;
       }
       float v = h0 * b0 + h1 * b1;
       if (do_scale) v *= post_scale;
@@ -396,8 +453,20 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32c2_tiled(const float2* 
   // A thread keeps its column c = tid & 63 through all three phases (256 is a multiple of the tile width): no
   // division in the load, and its source offsets and horizontal coefficients are read once, not once per row.
   const int c = tid & (UC_TW - 1), q = tid >> 6;
-  for (int ly = q; ly < H; ly += 4)
-    if (c < W) s_src[ly][c] = src[(size_t)(Y0 + ly) * sw + X0 + c];
+  {  // (all rows of the thread's column requested before the first is stored: not one round trip per row)
+    constexpr int kIt = (UC_SH + 3) / 4;
+    float2 v[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int ly = q + 4 * it;
+      v[it] = (ly < H && c < W) ? src[(size_t)(Y0 + ly) * sw + X0 + c] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int ly = q + 4 * it;
+      if (ly < H && c < W) s_src[ly][c] = v[it];
+    }
+  }
   if (W > UC_TW) {  // the up to 8 remaining columns of the window
     const int lx = UC_TW + (tid & 7);
     for (int ly = tid >> 3; ly < H; ly += 32)
@@ -610,12 +679,12 @@ void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, 
   const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
   dim3 blk(32, 8);
   const int ppt = (B % 4 == 0) ? 4 : (B % 2 == 0) ? 2 : 1;  // planes per thread (the coordinates are computed once)
-  if (cn == 1)
-    hipLaunchKernelGGL((k_resize_linear_f32<1>), grid2d(dw, dh, B / ppt, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh,
-                       dbs, scx, scy, post_scale, do_scale, ppt);
-  else
-    hipLaunchKernelGGL((k_resize_linear_f32<2>), grid2d(dw, dh, B / ppt, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh,
-                       dbs, scx, scy, post_scale, do_scale, ppt);
+#define S360_RL(C, P)                                                                                                   \
+  hipLaunchKernelGGL((k_resize_linear_f32<C, P>), grid2d(dw, dh, B / P, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, \
+                     dbs, scx, scy, post_scale, do_scale)
+  if (cn == 1) { if (ppt == 4) S360_RL(1, 4); else if (ppt == 2) S360_RL(1, 2); else S360_RL(1, 1); }
+  else { if (ppt == 4) S360_RL(2, 4); else if (ppt == 2) S360_RL(2, 2); else S360_RL(2, 1); }
+#undef S360_RL
 }
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
                                int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab) {

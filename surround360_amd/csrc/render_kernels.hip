@@ -401,15 +401,33 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
     }
   }
   if (bh > 0) {  // the tile's source box, zero outside the image (BORDER_CONSTANT): requested together with the coordinates
-    for (int ly = threadIdx.y; ly < bh; ly += PT_TY) {
-      const int gy = by0 + ly;
-      const bool rowIn = gy >= 0 && gy < sh;
-      const uchar4* S = src + (size_t)(rowIn ? gy : 0) * sw;
-      for (int lx = threadIdx.x; lx < bw; lx += PT_W) {
-        const int gx = bx0 + lx;
-        s_tile[ly * bw + lx] = (rowIn && gx >= 0 && gx < sw) ? S[gx] : make_uchar4(0, 0, 0, 0);
+    // eight pixels (4 rows x 2 column groups) are requested before the first goes to LDS: as load-store pairs in a
+    // runtime loop the ~7 pixels of a thread were as many serialised memory round trips
+    const unsigned* S32 = reinterpret_cast<const unsigned*>(src);
+    unsigned* T32 = reinterpret_cast<unsigned*>(s_tile);
+    for (int ly0 = threadIdx.y; ly0 < bh; ly0 += 4 * PT_TY)
+      for (int lx0 = threadIdx.x; lx0 < bw; lx0 += 2 * PT_W) {
+        unsigned v[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ly = ly0 + j * PT_TY, gy = by0 + ly;
+          const bool rowIn = ly < bh && gy >= 0 && gy < sh;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int lx = lx0 + i * PT_W, gx = bx0 + lx;
+            v[j][i] = (rowIn && lx < bw && gx >= 0 && gx < sw) ? S32[(size_t)gy * sw + gx] : 0u;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ly = ly0 + j * PT_TY;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int lx = lx0 + i * PT_W;
+            if (ly < bh && lx < bw) T32[ly * bw + lx] = v[j][i];
+          }
+        }
       }
-    }
     __syncthreads();
   }
 #pragma unroll
