@@ -8,6 +8,8 @@
 // SR/util/CvUtil.cpp:93-115, 140-157, 224-260, SR/util/Filter.h:40-127.
 #include "render_kernels.hpp"
 
+#include <cstdint>
+
 #include <algorithm>
 
 #include <stdexcept>
@@ -527,6 +529,15 @@ __global__ __launch_bounds__(256) void k_pole_removal_combine(uchar4* __restrict
   }
 }
 
+// two pixels per thread (camW and overlapW even: both sides of the copy are 8-byte aligned)
+__global__ __launch_bounds__(256) void k_crop_overlaps_v2(const uint2* __restrict__ proj, int camW2, int camH, int P,
+                                                          int overlapW2, uint2* __restrict__ out, int p0, int n) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, j = blockIdx.z;
+  if (x >= overlapW2) return;
+  const int cam = j < n ? p0 + j : (p0 + (j - n) + 1) % P;
+  const int x0 = j < n ? camW2 - overlapW2 : 0;
+  out[((size_t)j * camH + y) * overlapW2 + x] = proj[((size_t)cam * camH + y) * camW2 + x0 + x];
+}
 __global__ __launch_bounds__(256) void k_crop_overlaps(const uchar4* __restrict__ proj, int camW, int camH, int P,
                                                        int overlapW, uchar4* __restrict__ out, int p0, int n) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, j = blockIdx.z;
@@ -1045,6 +1056,38 @@ __global__ __launch_bounds__(256) void k_extend_wrap(const uchar4* __restrict__ 
 }
 
 // ---- pole warp / finish ------------------------------------------------------------------------
+// the same, four pixels per thread (cols and extW multiples of 4: a group never straddles the wrap point)
+__global__ __launch_bounds__(256) void k_extend_wrap_v4(const uint4* __restrict__ img, const unsigned* __restrict__ alpha,
+                                                        int cols4, int rows, uint4* __restrict__ ext, int extW4) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= extW4) return;
+  const int sx = x % cols4;
+  uint4 p = img[(size_t)y * cols4 + sx];
+  if (alpha) {
+    const unsigned a = alpha[(size_t)y * cols4 + sx];
+    p.x = (p.x & 0xffffffu) | (a << 24);
+    p.y = (p.y & 0xffffffu) | ((a >> 8) << 24);
+    p.z = (p.z & 0xffffffu) | ((a >> 16) << 24);
+    p.w = (p.w & 0xffffffu) | (a & 0xff000000u);
+  }
+  ext[(size_t)y * extW4 + x] = p;
+}
+// one pixel of poleToSideFlowThread's seam blend + alpha ramp (TRSP:505-536): o = warped pixel, wr = the pixel `cols`
+// further right in the extended image (read only where x < maxBlendX)
+__device__ __forceinline__ uchar4 pole_finish_px(uchar4 o, uchar4 wr, int x, int y, const PoleWarpParams& pw) {
+  if (x < pw.maxBlendX) {
+    const float alpha = 1.0f - rampf((float)x, (float)pw.maxBlendX * 0.333f, (float)pw.maxBlendX * 0.667f);
+    const float srcB = o.x, srcG = o.y, srcR = o.z, srcA = o.w;
+    o.x = (unsigned char)trunc_u8((float)wr.x * alpha + srcB * (1.0f - alpha));
+    o.y = (unsigned char)trunc_u8((float)wr.y * alpha + srcG * (1.0f - alpha));
+    o.z = (unsigned char)trunc_u8((float)wr.z * alpha + srcR * (1.0f - alpha));
+    o.w = (unsigned char)trunc_u8(srcA);
+  }
+  const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
+  const float a2 = 1.0f - rampf(phi, pw.phiMid, pw.phiRampEnd);
+  o.w = (unsigned char)trunc_u8((float)o.w * a2);
+  return o;
+}
 __global__ __launch_bounds__(256) void k_pole_finish(const uchar4* __restrict__ warpedExt, uchar4* __restrict__ out,
                                                      int eqrH, PoleWarpParams pw) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -1052,21 +1095,29 @@ __global__ __launch_bounds__(256) void k_pole_finish(const uchar4* __restrict__ 
   uchar4 o = make_uchar4(0, 0, 0, 0);
   if (y < pw.rows) {
     o = warpedExt[(size_t)y * pw.extW + x];
-    if (x < pw.maxBlendX) {
-      const int xw = min(x + pw.cols, pw.extW - 1);
-      const uchar4 wr = warpedExt[(size_t)y * pw.extW + xw];
-      const float alpha = 1.0f - rampf((float)x, (float)pw.maxBlendX * 0.333f, (float)pw.maxBlendX * 0.667f);
-      const float srcB = o.x, srcG = o.y, srcR = o.z, srcA = o.w;
-      o.x = (unsigned char)trunc_u8((float)wr.x * alpha + srcB * (1.0f - alpha));
-      o.y = (unsigned char)trunc_u8((float)wr.y * alpha + srcG * (1.0f - alpha));
-      o.z = (unsigned char)trunc_u8((float)wr.z * alpha + srcR * (1.0f - alpha));
-      o.w = (unsigned char)trunc_u8(srcA);
-    }
-    const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
-    const float a2 = 1.0f - rampf(phi, pw.phiMid, pw.phiRampEnd);
-    o.w = (unsigned char)trunc_u8((float)o.w * a2);
+    uchar4 wr = o;
+    if (x < pw.maxBlendX) wr = warpedExt[(size_t)y * pw.extW + min(x + pw.cols, pw.extW - 1)];
+    o = pole_finish_px(o, wr, x, y, pw);
   }
   out[(size_t)y * pw.cols + x] = o;
+}
+// four pixels per thread (cols and extW multiples of 4, extW >= cols + maxBlendX: the seam partner of a group is a group)
+__global__ __launch_bounds__(256) void k_pole_finish_v4(const uint4* __restrict__ warpedExt, uint4* __restrict__ out, int eqrH,
+                                                        PoleWarpParams pw) {
+  const int x4 = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, x = 4 * x4;
+  if (x >= pw.cols) return;
+  uint4 o = make_uint4(0u, 0u, 0u, 0u);
+  if (y < pw.rows) {
+    const size_t row = (size_t)y * (pw.extW / 4);
+    o = warpedExt[row + x4];
+    uint4 wr = o;
+    if (x < pw.maxBlendX) wr = warpedExt[row + x4 + pw.cols / 4];
+    o.x = __builtin_bit_cast(unsigned, pole_finish_px(__builtin_bit_cast(uchar4, o.x), __builtin_bit_cast(uchar4, wr.x), x, y, pw));
+    o.y = __builtin_bit_cast(unsigned, pole_finish_px(__builtin_bit_cast(uchar4, o.y), __builtin_bit_cast(uchar4, wr.y), x + 1, y, pw));
+    o.z = __builtin_bit_cast(unsigned, pole_finish_px(__builtin_bit_cast(uchar4, o.z), __builtin_bit_cast(uchar4, wr.z), x + 2, y, pw));
+    o.w = __builtin_bit_cast(unsigned, pole_finish_px(__builtin_bit_cast(uchar4, o.w), __builtin_bit_cast(uchar4, wr.w), x + 3, y, pw));
+  }
+  out[(size_t)y * (pw.cols / 4) + x4] = o;
 }
 
 // flattenLayersDeghostPreferBase (CvUtil.cpp:224-260)
@@ -1168,6 +1219,15 @@ __global__ __launch_bounds__(256) void k_cubemap(const uchar4* __restrict__ eyeL
   o[2] = (uint8_t)sat_u8((s2 + (1 << 14)) >> 15);
 }
 
+// four BGRA pixels (16 bytes) in, twelve B,G,R bytes (three dwords) out per thread
+__global__ __launch_bounds__(256) void k_pack_bgr_v4(const uint4* __restrict__ src, size_t n4, unsigned* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const uint4 p = src[i];
+  dst[i * 3] = (p.x & 0xffffffu) | (p.y << 24);
+  dst[i * 3 + 1] = ((p.y >> 8) & 0xffffu) | (p.z << 16);
+  dst[i * 3 + 2] = ((p.z >> 16) & 0xffu) | (p.w << 8);
+}
 __global__ __launch_bounds__(256) void k_pack_bgr(const uchar4* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1472,8 +1532,12 @@ void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH
                           int p0, int p1) {
   const int n = p1 - p0;
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_crop_overlaps, dim3(cdiv(overlapW, 256), camH, 2 * n), dim3(256), 0, st, proj, camW, camH, P,
-                     overlapW, out, p0, n);
+  if ((camW & 1) == 0 && (overlapW & 1) == 0 && (reinterpret_cast<uintptr_t>(proj) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0)
+    hipLaunchKernelGGL(k_crop_overlaps_v2, dim3(cdiv(overlapW / 2, 256), camH, 2 * n), dim3(256), 0, st,
+                       reinterpret_cast<const uint2*>(proj), camW / 2, camH, P, overlapW / 2, reinterpret_cast<uint2*>(out), p0, n);
+  else
+    hipLaunchKernelGGL(k_crop_overlaps, dim3(cdiv(overlapW, 256), camH, 2 * n), dim3(256), 0, st, proj, camW, camH, P,
+                       overlapW, out, p0, n);
 }
 void launch_novel_view(hipStream_t st, const uchar4* overlaps, const float2* flows, uchar4* strips,
                        const NovelViewParams& nv, int p0, int p1, const DevTables& T) {
@@ -1507,7 +1571,12 @@ void launch_gauss_u8(hipStream_t st, const uint8_t* a, uint8_t* out, int w, int 
 }
 void launch_extend_wrap(hipStream_t st, const uchar4* img, const uint8_t* alpha, int cols, int rows, uchar4* ext,
                         int extW) {
-  hipLaunchKernelGGL(k_extend_wrap, dim3(cdiv(extW, 256), rows), dim3(256), 0, st, img, alpha, cols, rows, ext, extW);
+  if ((cols & 3) == 0 && (extW & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(ext) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(alpha) & 3) == 0)
+    hipLaunchKernelGGL(k_extend_wrap_v4, dim3(cdiv(extW / 4, 256), rows), dim3(256), 0, st, reinterpret_cast<const uint4*>(img),
+                       reinterpret_cast<const unsigned*>(alpha), cols / 4, rows, reinterpret_cast<uint4*>(ext), extW / 4);
+  else
+    hipLaunchKernelGGL(k_extend_wrap, dim3(cdiv(extW, 256), rows), dim3(256), 0, st, img, alpha, cols, rows, ext, extW);
 }
 void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const float2* flow, uchar4* warpedExt,
                              const PoleWarpParams& pw, const DevTables& T, unsigned* packed, void* tiles) {
@@ -1520,7 +1589,12 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
                      warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 0, 1, (size_t)0, (size_t)0, nt);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
-  hipLaunchKernelGGL(k_pole_finish, dim3(cdiv(pw.cols, 256), eqrH), dim3(256), 0, st, warpedExt, out, eqrH, pw);
+  if ((pw.cols & 3) == 0 && (pw.extW & 3) == 0 && pw.cols + ((pw.maxBlendX + 3) & ~3) <= pw.extW &&
+      (reinterpret_cast<uintptr_t>(warpedExt) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(k_pole_finish_v4, dim3(cdiv(pw.cols / 4, 256), eqrH), dim3(256), 0, st,
+                       reinterpret_cast<const uint4*>(warpedExt), reinterpret_cast<uint4*>(out), eqrH, pw);
+  else
+    hipLaunchKernelGGL(k_pole_finish, dim3(cdiv(pw.cols, 256), eqrH), dim3(256), 0, st, warpedExt, out, eqrH, pw);
 }
 void launch_flatten(hipStream_t st, const uchar4* base, const uchar4* top, uchar4* out, int w, int h, int flip_top,
                     const DevTables& T) {
@@ -1538,7 +1612,11 @@ void launch_cubemap(hipStream_t st, const uchar4* eyeL, const uchar4* eyeR, int 
 }
 void launch_pack_bgr(hipStream_t st, const uchar4* src, int w, int h, uint8_t* dst) {
   const size_t n = (size_t)w * h;
-  hipLaunchKernelGGL(k_pack_bgr, dim3(cdiv(n, 256)), dim3(256), 0, st, src, n, dst);
+  if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+    hipLaunchKernelGGL(k_pack_bgr_v4, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), n / 4,
+                       reinterpret_cast<unsigned*>(dst));
+  else
+    hipLaunchKernelGGL(k_pack_bgr, dim3(cdiv(n, 256)), dim3(256), 0, st, src, n, dst);
 }
 // iirLowPass (wrap horizontally, reflect vertically) + sharpenWithIirLowPass on one eye, in place (TRSP:688-696).
 // scratch: w*h float4 + max(w,h) float4 (the chains' carried state).
