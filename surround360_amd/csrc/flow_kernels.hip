@@ -187,11 +187,11 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   float ld[kLdIters][CN];
 #pragma unroll
   for (int it = 0; it < kLdIters; ++it) {
-    const int i = (kColumnWalk ? lyc : tid) + it * kLdStep;
-#pragma unroll
-    for (int k = 0; k < CN; ++k) ld[it][k] = 0.0f;
-    if (i >= kLdEnd || (kColumnWalk && lxc >= IW)) continue;
-    const int ly = kColumnWalk ? i : i / IW, lx = kColumnWalk ? lxc : i - ly * IW;
+    // (no branch here: the index is clamped instead, so that nothing separates this element's loads from the next one's —
+    // with an early-out per element the compiler waited for every element's loads before it issued the next ones; the
+    // elements that do not exist are loaded from a valid address and never stored)
+    const int i = min((kColumnWalk ? lyc : tid) + it * kLdStep, kLdEnd - 1);
+    const int ly = kColumnWalk ? i : i / IW, lx = kColumnWalk ? min(lxc, IW - 1) : i - ly * IW;
     const int gy = reflect101(ty0 - R + ly, h), gx = kColumnWalk ? gxc : reflect101(tx0 - R + lx, w);
     if (SRC == 2) {  // k_resize_linear_f32's arithmetic at (gx, gy), then the scalar multiply
       int sx, sy;
@@ -203,17 +203,14 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
       const float* S0 = src + (size_t)clip_idx(sy, up.sh) * up.sw * CN;
       const float* S1 = src + (size_t)clip_idx(sy + 1, up.sh) * up.sw * CN;
       const float b0 = 1.f - fy, b1 = fy;
+      const bool edge = sx >= up.sw - 1;
+      const int sx1 = edge ? sx : sx + 1;  // (edge: the one tap times 1.0f; the second address is a dummy — no branch around loads)
 #pragma unroll
       for (int k = 0; k < CN; ++k) {
-        float h0, h1;
-        if (sx >= up.sw - 1) {
-          h0 = S0[sx * CN + k] * 1.0f;
-          h1 = S1[sx * CN + k] * 1.0f;
-        } else {
-          const float a0 = 1.f - fx, a1 = fx;
-          h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
-          h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
-        }
+        const float t00 = S0[sx * CN + k], t01 = S0[sx1 * CN + k], t10 = S1[sx * CN + k], t11 = S1[sx1 * CN + k];
+        const float a0 = 1.f - fx, a1 = fx;
+        const float h0 = edge ? t00 * 1.0f : t00 * a0 + t01 * a1;
+        const float h1 = edge ? t10 * 1.0f : t10 * a0 + t11 * a1;
         float v = h0 * b0 + h1 * b1;
         v *= up.post_scale;
         ld[it][k] = v;

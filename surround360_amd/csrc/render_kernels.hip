@@ -95,9 +95,12 @@ __device__ __forceinline__ uchar4 remap_cubic_u8c4_at(const uchar4* __restrict__
     const uint4 wa = w4[0], wb = w4[1];
     const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
     int acc[4] = {0, 0, 0, 0};
+    u4a4 prow[4];  // (the four row loads go out together, behind the two weight loads above)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = *reinterpret_cast<const u4a4*>(src + (size_t)(sy + r) * sw + sx);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const u4a4 p = *reinterpret_cast<const u4a4*>(src + (size_t)(sy + r) * sw + sx);
+      const u4a4 p = prow[r];
       const s16x2_ w01 = __builtin_bit_cast(s16x2_, wq[2 * r]), w23 = __builtin_bit_cast(s16x2_, wq[2 * r + 1]);
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
@@ -141,18 +144,24 @@ __device__ __forceinline__ float2 remap_cubic_f32c2_at(const float2* __restrict_
   float2 o;
   if ((unsigned)sx < width1 && (unsigned)sy < height1) {
     typedef float f4a8_ __attribute__((ext_vector_type(4), aligned(8)));
+    // all twelve loads (4 rows x two 16-byte pixel pairs, 4 x four weights) are requested before the first is used: as
+    // load-use pairs row by row they were twelve serialised memory round trips per sample
     const float2* S = src + (size_t)sy * sw + sx;
-    const f4a8_* V = reinterpret_cast<const f4a8_*>(S);  // two pixels per 16-byte load
-    f4a8_ ab = V[0], cd = V[1];
-    o.x = ab.x * w[0] + ab.z * w[1] + cd.x * w[2] + cd.z * w[3];
-    o.y = ab.y * w[0] + ab.w * w[1] + cd.y * w[2] + cd.w * w[3];
+    f4a8_ ab[4], cd[4];
+    float4 wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f4a8_* V = reinterpret_cast<const f4a8_*>(S + (size_t)r * sw);  // two pixels per 16-byte load
+      ab[r] = V[0];
+      cd[r] = V[1];
+      wr[r] = *reinterpret_cast<const float4*>(w + 4 * r);
+    }
+    o.x = ab[0].x * wr[0].x + ab[0].z * wr[0].y + cd[0].x * wr[0].z + cd[0].z * wr[0].w;
+    o.y = ab[0].y * wr[0].x + ab[0].w * wr[0].y + cd[0].y * wr[0].z + cd[0].w * wr[0].w;
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
-      S += sw;
-      V = reinterpret_cast<const f4a8_*>(S);
-      ab = V[0]; cd = V[1];
-      o.x += ab.x * w[r * 4] + ab.z * w[r * 4 + 1] + cd.x * w[r * 4 + 2] + cd.z * w[r * 4 + 3];
-      o.y += ab.y * w[r * 4] + ab.w * w[r * 4 + 1] + cd.y * w[r * 4 + 2] + cd.w * w[r * 4 + 3];
+      o.x += ab[r].x * wr[r].x + ab[r].z * wr[r].y + cd[r].x * wr[r].z + cd[r].z * wr[r].w;
+      o.y += ab[r].y * wr[r].x + ab[r].w * wr[r].y + cd[r].y * wr[r].z + cd[r].w * wr[r].w;
     }
   } else if (sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0) {
     o = make_float2(0.f, 0.f);
@@ -197,6 +206,9 @@ struct MapFromBuffer {  // bicubicRemapToSpherical: cached warp map (ImageWarper
   const float2* map;
   int dw;
   __device__ __forceinline__ float2 operator()(int x, int y) const { return map[(size_t)y * dw + x]; }
+  // the same in two steps, so that a thread can request the values of several pixels before it uses the first
+  __device__ __forceinline__ float2 load(int x, int y) const { return map[(size_t)y * dw + x]; }
+  __device__ __forceinline__ float2 apply(int, int, float2 v) const { return v; }
   __device__ __forceinline__ void advance(size_t n) { map += n; }
 };
 struct MapFromPoleFlow {  // poleToSideFlowThread's ramped warp (TRSP:483-503)
@@ -206,6 +218,12 @@ struct MapFromPoleFlow {  // poleToSideFlowThread's ramped warp (TRSP:483-503)
     const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
     const float alpha = 1.0f - rampf(phi, pw.phiRampStart, pw.phiMid);
     const float2 f = flow[(size_t)y * pw.extW + x];
+    return make_float2((float)x + (1.0f - alpha) * f.x, (float)y + (1.0f - alpha) * f.y);
+  }
+  __device__ __forceinline__ float2 load(int x, int y) const { return flow[(size_t)y * pw.extW + x]; }
+  __device__ __forceinline__ float2 apply(int x, int y, float2 f) const {
+    const float phi = pw.poleCameraRadius * (float)(y + 0.5f) / (float)pw.rows;
+    const float alpha = 1.0f - rampf(phi, pw.phiRampStart, pw.phiMid);
     return make_float2((float)x + (1.0f - alpha) * f.x, (float)y + (1.0f - alpha) * f.y);
   }
   __device__ __forceinline__ void advance(size_t n) { flow += n; }
@@ -340,13 +358,16 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
   int sx[4], sy[4], fxy[4];
   bool live[4];
   int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
+  float2 raw[4];  // (the four map / flow values are requested together)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) raw[k] = mapfn.load(min(x, dw - 1), min((int)(blockIdx.y * PT_H + threadIdx.y + PT_TY * k), dh - 1));
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
     live[k] = false;
     sx[k] = sy[k] = fxy[k] = 0;
     if (x < dw && y < dh) {
-      const float2 m = mapfn(x, y);
+      const float2 m = mapfn.apply(x, y, raw[k]);
       remap_coord(m.x, m.y, &sx[k], &sy[k], &fxy[k]);
       live[k] = !(sx[k] >= sw || sx[k] + 4 <= 0 || sy[k] >= sh || sy[k] + 4 <= 0);
       if (live[k]) {
@@ -402,6 +423,15 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
       if (y < dh) pk[k] = packed[(size_t)y * dw + x];
     }
   }
+  // the four pixels' weight rows (32 bytes each from the 32 KB table; any 10-bit index is valid) also go out before the
+  // barrier instead of one pixel at a time behind it
+  uint4 wqa[4], wqb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint4* w4 = reinterpret_cast<const uint4*>(tab + (pk[k] & 1023u) * 16);
+    wqa[k] = w4[0];
+    wqb[k] = w4[1];
+  }
   if (bh > 0) {  // the tile's source box, zero outside the image (BORDER_CONSTANT): requested together with the coordinates
     // eight pixels (4 rows x 2 column groups) are requested before the first goes to LDS: as load-store pairs in a
     // runtime loop the ~7 pixels of a thread were as many serialised memory round trips
@@ -439,9 +469,8 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
     uchar4 o = make_uchar4(0, 0, 0, 0);
     if (bh > 0) {
       if (pk[k] & 0x80000000u) {
-        const int fxy = pk[k] & 1023, rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
-        const uint4* w4 = reinterpret_cast<const uint4*>(tab + fxy * 16);
-        const uint4 wa = w4[0], wb = w4[1];
+        const int rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
+        const uint4 wa = wqa[k], wb = wqb[k];
         const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
         const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + ry * bw + rx;
         int acc[4] = {0, 0, 0, 0};
