@@ -203,14 +203,17 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
       const float* S0 = src + (size_t)clip_idx(sy, up.sh) * up.sw * CN;
       const float* S1 = src + (size_t)clip_idx(sy + 1, up.sh) * up.sw * CN;
       const float b0 = 1.f - fy, b1 = fy;
-      const bool edge = sx >= up.sw - 1;
-      const int sx1 = edge ? sx : sx + 1;  // (edge: the one tap times 1.0f; the second address is a dummy — no branch around loads)
 #pragma unroll
       for (int k = 0; k < CN; ++k) {
-        const float t00 = S0[sx * CN + k], t01 = S0[sx1 * CN + k], t10 = S1[sx * CN + k], t11 = S1[sx1 * CN + k];
-        const float a0 = 1.f - fx, a1 = fx;
-        const float h0 = edge ? t00 * 1.0f : t00 * a0 + t01 * a1;
-        const float h1 = edge ? t10 * 1.0f : t10 * a0 + t11 * a1;
+        float h0, h1;
+        if (sx >= up.sw - 1) {
+          h0 = S0[sx * CN + k] * 1.0f;
+          h1 = S1[sx * CN + k] * 1.0f;
+        } else {
+          const float a0 = 1.f - fx, a1 = fx;
+          h0 = S0[sx * CN + k] * a0 + S0[(sx + 1) * CN + k] * a1;
+          h1 = S1[sx * CN + k] * a0 + S1[(sx + 1) * CN + k] * a1;
+        }
         float v = h0 * b0 + h1 * b1;
         v *= up.post_scale;
         ld[it][k] = v;

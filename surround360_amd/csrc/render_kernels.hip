@@ -423,15 +423,6 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
       if (y < dh) pk[k] = packed[(size_t)y * dw + x];
     }
   }
-  // the four pixels' weight rows (32 bytes each from the 32 KB table; any 10-bit index is valid) also go out before the
-  // barrier instead of one pixel at a time behind it
-  uint4 wqa[4], wqb[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint4* w4 = reinterpret_cast<const uint4*>(tab + (pk[k] & 1023u) * 16);
-    wqa[k] = w4[0];
-    wqb[k] = w4[1];
-  }
   if (bh > 0) {  // the tile's source box, zero outside the image (BORDER_CONSTANT): requested together with the coordinates
     // eight pixels (4 rows x 2 column groups) are requested before the first goes to LDS: as load-store pairs in a
     // runtime loop the ~7 pixels of a thread were as many serialised memory round trips
@@ -470,7 +461,10 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
     if (bh > 0) {
       if (pk[k] & 0x80000000u) {
         const int rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
-        const uint4 wa = wqa[k], wb = wqb[k];
+        // (the weight rows are fetched here, per pixel: requesting all four in front of the barrier cost 30 VGPRs and
+        // measured 10 % slower, profiles/r03_v7 vs r3i)
+        const uint4* w4 = reinterpret_cast<const uint4*>(tab + (pk[k] & 1023u) * 16);
+        const uint4 wa = w4[0], wb = w4[1];
         const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
         const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + ry * bw + rx;
         int acc[4] = {0, 0, 0, 0};
