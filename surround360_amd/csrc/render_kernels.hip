@@ -1440,6 +1440,16 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
     }
     S360_WAVE_SYNC();
     if (t > 0) load_tile(t - 1);
+    // FUSE: the image pixels the unsharp mask needs at the end of this tile are requested now (as load-use pairs in the
+    // output loop they were 16 serialised round trips per tile)
+    unsigned img[IIR_CH];
+    if (FUSE) {
+#pragma unroll
+      for (int kk = 0; kk < IIR_CH; ++kk) {
+        const int p = ROWS ? lane : 4 * kk + rl, chn = min(chain0 + (ROWS ? kk : cl), g.nchains - 1), e = min(t * IIR_T + p, g.n - 1);
+        img[kk] = reinterpret_cast<const unsigned*>(out)[iir_px<ROWS>(g, chn, e)];
+      }
+    }
     const int cnt = min(IIR_T, g.n - t * IIR_T);
     const float* si = s_in + (size_t)k * IIR_LD * 4 + c;
     unsigned char* so = reinterpret_cast<unsigned char*>(s_out) + (size_t)k * IIR_LD * 4 + c;
@@ -1468,7 +1478,7 @@ __global__ __launch_bounds__(64) void k_iir_anticausal(IirImgs im, IirGeom g, si
           const unsigned lw = s_out[(ROWS ? kk : cl) * IIR_LD + p];
           const size_t o = iir_px<ROWS>(g, chn, e);
           if (FUSE) {
-            uchar4 px = out[o];
+            uchar4 px = __builtin_bit_cast(uchar4, img[kk]);
             auto f = [&](unsigned char pc, unsigned lc) -> unsigned char {
               const float lf = (float)lc;
               const float hp = (float)pc - lf;
