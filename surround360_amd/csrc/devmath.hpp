@@ -18,8 +18,15 @@
 // operations and needs those points marked; in the product build the mark is nothing at all.
 #ifdef S360_WAVE_EMULATION
 #define S360_WAVE_SYNC() emu::wave_sync()
+#define S360_VM_DRAIN()
 #else
 #define S360_WAVE_SYNC()
+// s_waitcnt vmcnt(0) as a real machine instruction (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15): waits for every
+// outstanding global load / store of the wave AND tells the compiler's wait-count pass that nothing is pending behind
+// this point. Placed on COLD paths in front of a hot loop: the pass merges the pending-load state of all static
+// predecessors of a block, and a load that can only be pending on a cold path otherwise costs a wait in every iteration
+// of the hot one (wherever the hot loop reuses that load's register).
+#define S360_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
 
 namespace s360 {

@@ -104,7 +104,8 @@ constexpr int kQChunk = 16;
 #ifndef S360_QPUB
 #define S360_QPUB 4
 #endif
-constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference)
+constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference) ...
+constexpr int kQPhase = kQNeed - 1;  // ... at the steps with s % kQNeed == kQPhase, for the columns of the kQNeed steps after it
 constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every kQPub steps
 
 // The LDS window of I1-gradient texels. In image coordinates the pixels of a chunk form a parallelogram:
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const int nsteps = w + kQRows - 1;
   auto col = [&](int xi) { const int xc = min(max(xi, 0), w - 1); return dir > 0 ? xc : w - 1 - xc; };
   int wy0 = kNoWin, wu0 = 0;  // placement of the LDS window, wave-uniform
+  // the lanes whose evaluation counts in round 1 (current, left, up where a row above exists) and in round 2 (the probes)
+  const unsigned long long lanesRound1 = __ballot(q == 0 || q == 1 || (q == 2 && hasUp)), lanesRound2 = __ballot(q < 2);
 
   // getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464) of the tap (x + ax, y + ay) of this lane's pixel
   struct Cell { float mx, my; int x0, y0; };
@@ -241,11 +244,14 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   // lane that matters (`rel`) has its cell outside the window. The two paths are complete evaluations that only meet
   // in the resulting error: if they met in the texel registers, every step would wait there for ALL outstanding global
   // loads (one in-order counter), i.e. for the next chunk's prefetches as well.
-  auto evaluate = [&](auto ieee, const Cell& k, bool rel, float4 rc, float ax, float ay, bool& tiny) -> float {
+  // (`rel` && lane in `relLanes`: the lanes that matter. The part of the test that only depends on the lane's role is a
+  // constant lane mask in SGPRs — as a per-lane boolean it cost an exec-mask detour of ~15 instructions per round)
+  auto evaluate = [&](auto ieee, const Cell& k, bool rel, unsigned long long relLanes, float4 rc, float ax, float ay,
+                      bool& tiny) -> float {
     const int jy = k.y0 - wy0, ju = k.x0 + k.y0 - wu0;
     const bool in = (unsigned)jy <= (unsigned)(kWinRows - 2) && (unsigned)ju <= (unsigned)(kWinCols - 3);
     S360_QSTAT(g_quad_rounds);
-    if (__builtin_expect(__ballot(rel && !in) != 0ull, 0)) {
+    if (__builtin_expect((__ballot(rel && !in) & relLanes) != 0ull, 0)) {
       S360_QSTAT(g_quad_fallbacks);
       float e = error_of(ieee, gather(k), k, rc, ax, ay, tiny);
 #ifndef S360_WAVE_EMULATION
@@ -269,7 +275,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
     const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
     const Cell k = cell_of(x, ax, ay);
-    const float e = evaluate(ieee, k, take && (q == 0 || (q == 1 && (ST || xi > 0)) || (q == 2 && hasUp)), rc, ax, ay, tiny);
+    const float e = ST ? evaluate(ieee, k, take, lanesRound1, rc, ax, ay, tiny)
+                       : evaluate(ieee, k, take && (q == 0 || (q == 1 && xi > 0) || (q == 2 && hasUp)), ~0ull, rc, ax, ay, tiny);
     float e0, e1, e2;
     if constexpr (LPP == 3) tri_exchange(e, q, e0, e1, e2);
     else { e0 = quad_bcast<0>(e); e1 = quad_bcast<1>(e); e2 = quad_bcast<2>(e); }
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float cur = b2 ? e2 : c1;
     const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
     const Cell pk = cell_of(x, pax, pay);
-    const float pe = evaluate(ieee, pk, take && q < 2, rc, pax, pay, tiny);
+    const float pe = evaluate(ieee, pk, take, lanesRound2, rc, pax, pay, tiny);
     float ex, ey;
     if constexpr (LPP == 3) { float unused; tri_exchange(pe, q, ex, ey, unused); }
     else { ex = quad_bcast<0>(pe); ey = quad_bcast<1>(pe); }
@@ -356,7 +363,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   auto chunk_store = [&]() {
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-      *reinterpret_cast<f4r*>(&s_rec[4 * i + (lane >> 4)][ioStep]) = cr[i];
+      f4r rv = cr[i];
+      if (!ioOk[i]) rv.x = __int_as_float(0x7fc00000);  // rows below the image: "not updated", like a pixel below the alpha threshold
+      *reinterpret_cast<f4r*>(&s_rec[4 * i + (lane >> 4)][ioStep]) = rv;
       *reinterpret_cast<f2r*>(&s_res[4 * i + (lane >> 4)][ioStep]) = cf[i];
     }
   };
@@ -438,8 +447,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
     // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
     // of steps that did not need the band above (the columns passed meanwhile are dropped).
-    if (hasUpBand && (ST || s < w) && ((s & (kQNeed - 1)) == 0 || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
-      const int need = min(s + kQNeed, w), limit = s + kUpRing;
+    if (hasUpBand && (ST || s < w) && ((s & (kQNeed - 1)) == kQPhase || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
+      // through the column of the next scheduled check (which needs its own column like any other step)
+      const int need = min(((s + 1) | (kQNeed - 1)) + 1, w), limit = s + kUpRing;
       if (upFilled < s) {
         upFilled = s;
         pending = false;
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
     // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
     // two rounds are skipped.
-    const bool take = active && upd;
+    const bool take = ST ? upd : active && upd;  // (steady: active = the row exists, and the rows that do not have NaN records)
     const float2 alt = active ? fo : fl;
     float2 res = alt;
     if (__ballot(take) != 0ull) {
@@ -512,17 +522,24 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   };
   for (int s0 = 0; s0 < nsteps; s0 += kQChunk) {
     const int send = min(s0 + kQChunk, nsteps);
-    if (s0 + kQChunk < nsteps) chunk_load(s0 + kQChunk);  // lands during the chunk, stored at its end
     const bool steadyChunk = s0 >= kQRows && s0 + kQChunk <= w;
     const bool more = send < nsteps;
+    if (more) chunk_load(send);  // lands during the chunk, stored at its end
+    // The chunk's requests and the checks of the band above share the one in-order memory counter: a check waits for
+    // its poll and thereby for every load requested before it. The checks therefore sit at steps 3, 7, 11, 15 of a chunk
+    // (kQPhase), three steps behind the requests of the records / flows (chunk start) and of the window (step 12).
     if (steadyChunk) {
       for (int s = s0; s < s0 + kQChunk - kWinAhead; ++s) step(std::true_type{}, s, s0 + kQChunk);
-      if (more) win_issue(send);  // (the next chunk's records and flows, loaded at the start of this one, are here by now)
-      for (int s = s0 + kQChunk - kWinAhead; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
     } else {
       for (int s = s0; s < send; ++s) step(std::false_type{}, s, send);
-      if (more) win_issue(send);
+      // (edge chunks: two or three per band. What they leave pending must not look pending to the steady loops: the
+      // compiler's wait-count pass would wait in every steady step wherever one of those registers is reused — devmath.hpp)
+      S360_VM_DRAIN();
     }
+    // (ONE call site: with a second one behind the edge chunks' loop, block placement left a static path from those window
+    // loads to the steady loop, and every steady step drained the memory counter for loads that are never pending there)
+    if (more) win_issue(send);
+    if (steadyChunk) for (int s = s0 + kQChunk - kWinAhead; s < s0 + kQChunk; ++s) step(std::true_type{}, s, s0 + kQChunk);
     // ---- write-back of the chunk: row rr produced columns [s0 - rr, send - rr); item = (row, step) as in chunk_load ----
     {
 #pragma unroll
