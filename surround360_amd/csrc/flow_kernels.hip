@@ -386,6 +386,102 @@ __global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restri
   }
 }
 
+// The same resize for the image pyramids (one channel, x0.9 per level), tiled: with one thread per output pixel the kernel
+// is bound by its memory INSTRUCTIONS — four scattered 4-byte taps per output and plane; 68 % of the wave time ready
+// but not issued behind the address unit (profiles/r03_v8_pmc_sq.txt). Here a 64x16 tile's source box (<= 72x20 for
+// scales up to 1.13) is read once as 16-byte pieces into LDS for PPT planes, the FP64 coordinates are computed once per
+// tile column / row (80 per tile instead of 2 per pixel), and the taps are LDS reads. Arithmetic as in
+// k_resize_linear_f32, term by term.
+constexpr int RL_TW = 64, RL_TH = 16, RL_BW = 72, RL_BH = 20;
+template <int PPT>
+__global__ __launch_bounds__(256) void k_resize_linear_f32c1_tiled(const float* __restrict__ src, int sw, int sh, size_t sbs,
+                                                                   float* __restrict__ dst, int dw, int dh, size_t dbs,
+                                                                   double scx, double scy, float post_scale, int do_scale) {
+  __shared__ __attribute__((aligned(16))) float s_box[PPT][RL_BH][RL_BW];
+  __shared__ int s_sx[RL_TW], s_r0[RL_TH], s_r1[RL_TH];
+  __shared__ float s_fx[RL_TW], s_fy[RL_TH];
+  const TileId tile = xcd_tile();
+  const int tid = threadIdx.x, tx0 = tile.x * RL_TW, ty0 = tile.y * RL_TH;
+  if (tid < RL_TW) {  // column coordinates (absolute; columns beyond the image repeat the last one)
+    int sx;
+    float fx;
+    resize_coord(min(tx0 + tid, dw - 1), scx, &sx, &fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    s_sx[tid] = sx;
+    s_fx[tid] = fx;
+  } else if (tid < RL_TW + RL_TH) {
+    int sy;
+    float fy;
+    resize_coord(min(ty0 + tid - RL_TW, dh - 1), scy, &sy, &fy);
+    s_r0[tid - RL_TW] = clip_idx(sy, sh);
+    s_r1[tid - RL_TW] = clip_idx(sy + 1, sh);
+    s_fy[tid - RL_TW] = fy;
+  }
+  __syncthreads();
+  // the box: columns bx0 .. (last column's sx) + 1, rows by0 .. (last row's r1); the launcher guarantees that it fits
+  const int bx0 = s_sx[0], by0 = s_r0[0];
+  const int bw4 = (min(s_sx[RL_TW - 1] + 1, sw - 1) - bx0 + 4) >> 2, bh = s_r1[RL_TH - 1] - by0 + 1;
+  const int npieces = bh * bw4;
+  constexpr int kIters = (RL_BH * (RL_BW / 4) + 255) / 256;
+  float4 ld[kIters][PPT];
+  // all pieces requested before the first is stored (index clamped, no early-out: see k_sepblur)
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int i = min(tid + it * 256, npieces - 1);
+    const int row = i / bw4, gx = bx0 + 4 * (i - row * bw4);
+    const size_t off = (size_t)(by0 + row) * sw;
+#pragma unroll
+    for (int pl = 0; pl < PPT; ++pl) {
+      const float* S = src + sbs * ((size_t)blockIdx.z * PPT + pl) + off;
+      if (gx + 3 < sw) {
+        typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));  // (rows start at any 4-byte address)
+        const f4a4 q = *reinterpret_cast<const f4a4*>(S + gx);
+        ld[it][pl] = make_float4(q.x, q.y, q.z, q.w);
+      } else {  // the piece crosses the end of the row: the columns behind it are never tapped
+        ld[it][pl] = make_float4(S[min(gx, sw - 1)], S[min(gx + 1, sw - 1)], S[min(gx + 2, sw - 1)], S[sw - 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int i = tid + it * 256;
+    if (i >= npieces) continue;
+    const int row = i / bw4, c4 = i - row * bw4;
+#pragma unroll
+    for (int pl = 0; pl < PPT; ++pl) *reinterpret_cast<float4*>(&s_box[pl][row][4 * c4]) = ld[it][pl];
+  }
+  __syncthreads();
+  const int cx = tid & (RL_TW - 1), dx = tx0 + cx;
+  if (dx >= dw) return;
+  const int sxa = s_sx[cx], sxr = sxa - bx0;
+  const bool edge = sxa >= sw - 1;  // (then the second tap is a dummy: the one tap is multiplied by 1.0f)
+  const int sx1 = edge ? sxr : sxr + 1;
+  const float fx = s_fx[cx], a0 = 1.f - fx, a1 = fx;
+#pragma unroll
+  for (int j = 0; j < RL_TH / 4; ++j) {
+    const int ry = (tid >> 6) + 4 * j, dy = ty0 + ry;
+    if (dy >= dh) continue;
+    const int r0 = s_r0[ry] - by0, r1 = s_r1[ry] - by0;
+    const float fy = s_fy[ry], b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+    for (int pl = 0; pl < PPT; ++pl) {
+      const float t0 = s_box[pl][r0][sxr], t1 = s_box[pl][r0][sx1], t2 = s_box[pl][r1][sxr], t3 = s_box[pl][r1][sx1];
+      float h0, h1;
+      if (edge) {
+        h0 = t0 * 1.0f;
+        h1 = t2 * 1.0f;
+      } else {
+        h0 = t0 * a0 + t1 * a1;
+        h1 = t2 * a0 + t3 * a1;
+      }
+      float v = h0 * b0 + h1 * b1;
+      if (do_scale) v *= post_scale;
+      dst[dbs * ((size_t)blockIdx.z * PPT + pl) + (size_t)dy * dw + dx] = v;
+    }
+  }
+}
+
 // resize INTER_CUBIC float2 (flow upscale between levels, PixFlow.h:170-171; prevFlow :103-104),
 // followed by the scalar multiply.
 __global__ __launch_bounds__(256) void k_resize_cubic_f32c2(const float2* __restrict__ src, int sw, int sh,
@@ -677,8 +773,22 @@ void launch_blur_to_records(hipStream_t st, const float2* flow, float4* rec, int
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale) {
   const double scx = 1.0 / ((double)dw / (double)sw), scy = 1.0 / ((double)dh / (double)sh);
-  dim3 blk(32, 8);
   const int ppt = (B % 4 == 0) ? 4 : (B % 2 == 0) ? 2 : 1;  // planes per thread (the coordinates are computed once)
+  // one-channel planes (the image pyramids): tiled, if a tile's source box fits — x0.9 levels do, the smallest levels'
+  // rounded sizes may not
+  const int tw = std::min(dw, RL_TW), th = std::min(dh, RL_TH);
+  const bool fits = std::min(sw, (int)std::floor((tw - 1) * scx) + 3) + 3 <= RL_BW &&
+                    std::min(sh, (int)std::floor((th - 1) * scy) + 3) <= RL_BH;
+  if (cn == 1 && fits) {
+    const dim3 grid((dw + RL_TW - 1) / RL_TW, (dh + RL_TH - 1) / RL_TH, B / ppt);
+#define S360_RLT(P)                                                                                                   \
+  hipLaunchKernelGGL((k_resize_linear_f32c1_tiled<P>), grid, dim3(256), 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx, \
+                     scy, post_scale, do_scale)
+    if (ppt == 4) S360_RLT(4); else if (ppt == 2) S360_RLT(2); else S360_RLT(1);
+#undef S360_RLT
+    return;
+  }
+  dim3 blk(32, 8);
 #define S360_RL(C, P)                                                                                                   \
   hipLaunchKernelGGL((k_resize_linear_f32<C, P>), grid2d(dw, dh, B / P, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, \
                      dbs, scx, scy, post_scale, do_scale)
