@@ -9,14 +9,6 @@
 
 namespace s360 {
 
-int FlowEngine::latency_sweep_mode() {
-  static const int m = [] {
-    const char* e = std::getenv("S360_LATENCY_SWEEP");
-    return e && std::string(e) == "wave" ? 4 : 2;
-  }();
-  return m;
-}
-
 PixFlowConsts pixflow_consts_by_name(const std::string& name) {
   PixFlowConsts c;
   c.pyrScaleFactor = 0.9f;
@@ -146,8 +138,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   // Band hand-off granules + ticket counters of every sweep launch of this call (2 per level): one arena, reset to
   // all-ones ("not written") by ONE memset instead of one per launch.
   auto handoff_bytes = [&](int l) {
-    const size_t b = sweep_mode_ == 2 ? sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, sweep_lock_waves())
-                                      : sweep_quad_handoff_bytes(lv_.w[l], lv_.h[l], B, sweep_mode_ == 4);
+    const size_t b = sweep_mode_ == 3 ? sweep_quad_handoff_bytes(lv_.w[l], lv_.h[l], B)
+                                      : sweep_lock_handoff_bytes(lv_.w[l], lv_.h[l], B, sweep_lock_waves());
     return (b + 255) & ~(size_t)255;
   };
   // + per level one word per (flow, row): all-ones = no pixel of the row is updated (written by the record kernel)
@@ -235,10 +227,9 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
-      if (sweep_mode_ != 2)
+      if (sweep_mode_ == 3)
         launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
-                          fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)),
-                          sweep_mode_ == 4);
+                          fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
       else
         launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk);

@@ -65,14 +65,12 @@ class FlowEngine {
   const unsigned long long* batch_tables(hipStream_t st, const FlowBatch& b);
   DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, prevFlowDown_, prevPyr_, motionPyr_, I1eq_, rec_,
       handoff_, err_;
-  int sweep_mode_ = latency_sweep_mode();  // 2: lockstep kernel (latency, default), 3: wave kernel, throughput mapping, 4: wave kernel, latency mapping
+  int sweep_mode_ = 2;      // 2: lockstep kernel (latency, default), 3: quad kernel (throughput)
   int sweep_fast_ = -1;     // verified fast division / sqrt in the sweeps; S360_SWEEP_DIV=ieee selects the IEEE expansions (same bits)
 
  public:
   // 2 = lockstep (lowest latency of one flow), 3 = quad (highest chip-wide rate with many flows in flight)
-  void set_sweep_mode(int m) { sweep_mode_ = (m == 3 || m == 4) ? m : latency_sweep_mode(); }
-  // which kernel serves the latency mode: S360_LATENCY_SWEEP=lock | wave (tuning; the results do not depend on it)
-  static int latency_sweep_mode();
+  void set_sweep_mode(int m) { sweep_mode_ = (m == 3) ? 3 : 2; }
   // non-zero if a banded sweep timed out waiting for its neighbour band (results invalid); resets the flag
   unsigned take_error(hipStream_t st);
   // the device word behind take_error (nullptr before the first compute): frame_finish snapshots it per output buffer

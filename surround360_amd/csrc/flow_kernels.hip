@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void k_resize_linear_f32(const float* __restri
 
 // The same resize for the image pyramids (one channel, x0.9 per level), tiled: with one thread per output pixel the kernel
 // is bound by its memory INSTRUCTIONS — four scattered 4-byte taps per output and plane; 68 % of the wave time ready
-// but not issued behind the address unit (profiles/r03_v8_pmc_sq.txt). Here a 64x16 tile's source box (<= 72x20 for
+// but not issued behind the address unit (profiles/r03_v8_pmc_sq.txt). Here a 64x16 tile's source box (<= 76x20 for
 // scales up to 1.13) is read once as 16-byte pieces into LDS for PPT planes, the FP64 coordinates are computed once per
 // tile column / row (80 per tile instead of 2 per pixel), and the taps are LDS reads. Arithmetic as in
 // k_resize_linear_f32, term by term.
-constexpr int RL_TW = 64, RL_TH = 16, RL_BW = 72, RL_BH = 20;
+constexpr int RL_TW = 64, RL_TH = 16, RL_BW = 76, RL_BH = 20;
 template <int PPT>
 __global__ __launch_bounds__(256) void k_resize_linear_f32c1_tiled(const float* __restrict__ src, int sw, int sh, size_t sbs,
                                                                    float* __restrict__ dst, int dw, int dh, size_t dbs,
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_f32c1_tiled(const float* 
     const size_t off = (size_t)(by0 + row) * sw;
 #pragma unroll
     for (int pl = 0; pl < PPT; ++pl) {
-      const float* S = src + sbs * ((size_t)blockIdx.z * PPT + pl) + off;
+      const float* S = src + sbs * ((size_t)tile.z * PPT + pl) + off;
       if (gx + 3 < sw) {
         typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));  // (rows start at any 4-byte address)
         const f4a4 q = *reinterpret_cast<const f4a4*>(S + gx);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_f32c1_tiled(const float* 
       }
       float v = h0 * b0 + h1 * b1;
       if (do_scale) v *= post_scale;
-      dst[dbs * ((size_t)blockIdx.z * PPT + pl) + (size_t)dy * dw + dx] = v;
+      dst[dbs * ((size_t)tile.z * PPT + pl) + (size_t)dy * dw + dx] = v;
     }
   }
 }

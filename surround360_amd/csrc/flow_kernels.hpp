@@ -60,12 +60,11 @@ void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float
                        const PixFlowConsts& pc, bool fast);
 // true when the kernel's fast exact division may be used for all of these divisors (checked on the device, cached)
 bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& divisors);
-// single-wave sweep (sweep_quad.hip): 16 rows x 4 or 20 rows x 3 lanes per pixel and two rounds (throughput: many flows
-// in flight), or 4 rows x 16 lanes and one speculative round (`latency`: one frame's flows)
-size_t sweep_quad_handoff_bytes(int w, int h, int B, bool latency = false);
+// throughput-oriented sweep (sweep_quad.hip): one wave per workgroup, 16 rows x 4 or 20 rows x 3 lanes per pixel, two rounds
+size_t sweep_quad_handoff_bytes(int w, int h, int B);
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, bool fast, const unsigned* rowflags = nullptr, bool latency = false);
+                       const PixFlowConsts& pc, bool fast, const unsigned* rowflags = nullptr);
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq);
 

@@ -53,11 +53,7 @@ constexpr unsigned long long kEmptyGranuleQ = 0xFFFFFFFFFFFFFFFFull;
 // can hand it to the first pixel of the next DPP row; the values of a round are exchanged with row_shr / row_shl by 1 and
 // 2 and a select per role (a quad broadcast does not exist for groups of three): ~16 more instructions per step for 25 %
 // more pixels per step, and bands of 20 rows (20 % fewer bands and hand-offs per flow).
-// 16 (the LATENCY mapping, one flow batch of one frame): a pixel is a whole 16-lane DPP row, 4 rows per wave, and the
-// two dependent rounds collapse into one — the pixel's lanes evaluate all 9 evaluations either round could ask for at
-// once (bank = current / left / up proposal, role = the proposal itself / its x probe / its y probe), exchange them with
-// row_share and replay the reference's selection: one LDS round trip and one evaluation deep per step, bands of 4 rows.
-constexpr int quad_rows(int lpp) { return lpp == 3 ? 20 : lpp == 16 ? 4 : 16; }
+constexpr int quad_rows(int lpp) { return lpp == 3 ? 20 : 16; }
 constexpr int kUpRing = 64;  // columns of the band above kept in LDS
 
 template <int K>
@@ -86,18 +82,6 @@ __device__ __forceinline__ float from_row_above_t(float old, float v) {
   r = __builtin_amdgcn_update_dpp(r, __builtin_bit_cast(int, v), 0x113, 0xF, 0xF, false);
   return __builtin_bit_cast(float, r);
 }
-// (LPP 16) value of lane K of this lane's 16-lane row (row_share:K)
-template <int K>
-__device__ __forceinline__ float row_share(float v) {
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x150 + K, 0xF, 0xF, true));
-}
-// (LPP 16) previous result of the row above = any lane of the previous DPP row: row_bcast:15 into rows 1..3; row 0 of the
-// band keeps `old` = the granule-fed value.
-__device__ __forceinline__ float from_row_above_s(float old, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
-                                                              0x142, 0xE, 0xF, false));
-}
 // previous result of the row above: lane - 4. Inside a 16-lane DPP row that is row_shr:4 (banks 1..3); the first
 // quad of DPP rows 1..3 takes lane 15 of the previous DPP row (row_bcast:15, bank 0); the first quad of the wave
 // (row 0 of the band) keeps `old` = the granule-fed value.
@@ -123,14 +107,6 @@ constexpr int kQChunk = 16;
 constexpr int kQNeed = S360_QNEED;  // row 0 checks the band above every kQNeed steps (2..8 measured: no difference) ...
 constexpr int kQPhase = kQNeed - 1;  // ... at the steps with s % kQNeed == kQPhase, for the columns of the kQNeed steps after it
 constexpr int kQPub = S360_QPUB;   // the last row publishes its granules every kQPub steps
-// The latency mapping (LPP 16) keeps the bands close: a band follows its predecessor at (rows - 1) + kQPub - 1 + 2 kQNeed
-// steps plus the visibility of a store, and a flow of h rows is h / 4 bands.
-#ifndef S360_QNEED16
-#define S360_QNEED16 2
-#endif
-#ifndef S360_QPUB16
-#define S360_QPUB16 1
-#endif
 
 // The LDS window of I1-gradient texels. In image coordinates the pixels of a chunk form a parallelogram:
 // row y of the band lags one column per row, so x + y is the same for the 16 pixels of a step and spans 16 values over a
@@ -166,7 +142,6 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   // two per step) and staged in LDS; a slot of s_res holds a pixel's flow before its step and its result after it,
   // indexed by step. Row strides of 17 elements keep the 16 rows of a read on distinct banks.
   constexpr int kQRows = quad_rows(LPP), kWinRows = win_rows(LPP);
-  constexpr int kNeed = LPP == 16 ? S360_QNEED16 : kQNeed, kPhase = kNeed - 1, kPub = LPP == 16 ? S360_QPUB16 : kQPub;
   constexpr int kItems = kQRows * kQChunk / 64;  // pixel-steps of a chunk per lane (4 / 5)
   constexpr int kRW = kQChunk + 1;
   typedef float f4r __attribute__((ext_vector_type(4)));
@@ -214,9 +189,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   }
   // r: row of the band; q: role in the pixel (0 current / x probe, 1 left / y probe, 2 up; 3: spare lane)
   const int l16 = lane & 15, g5 = min(l16 / 3, 4);
-  // (LPP 16: r = the DPP row, q = lane in the row: bank q >> 2 = proposal, role q & 3 = the proposal / x probe / y probe)
-  const int r = LPP == 3 ? (lane >> 4) * 5 + g5 : LPP == 16 ? lane >> 4 : lane >> 2;
-  const int q = LPP == 3 ? l16 - 3 * g5 : LPP == 16 ? l16 : lane & 3;
+  const int r = LPP == 3 ? (lane >> 4) * 5 + g5 : lane >> 2, q = LPP == 3 ? l16 - 3 * g5 : lane & 3;
   const int yi = band * kQRows + r;
   const bool rowValid = yi < h;
   const int yic = rowValid ? yi : h - 1;
@@ -231,7 +204,6 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   int wy0 = kNoWin, wu0 = 0;  // placement of the LDS window, wave-uniform
   // the lanes whose evaluation counts in round 1 (current, left, up where a row above exists) and in round 2 (the probes)
   const unsigned long long lanesRound1 = __ballot(q == 0 || q == 1 || (q == 2 && hasUp)), lanesRound2 = __ballot(q < 2);
-  const unsigned long long lanesSpec = __ballot((q >> 2) < 3 && (q & 3) < 3 && ((q >> 2) != 2 || hasUp));  // (LPP 16)
 
   // getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464) of the tap (x + ax, y + ay) of this lane's pixel
   struct Cell { float mx, my; int x0, y0; };
@@ -325,48 +297,6 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     float ex, ey;
     if constexpr (LPP == 3) { float unused; tri_exchange(pe, q, ex, ey, unused); }
     else { ex = quad_bcast<0>(pe); ey = quad_bcast<1>(pe); }
-    const float nx = ex - cur, ny = ey - cur;
-    float ggx, ggy;
-    if (decltype(ieee)::value) {
-      ggx = nx / kEps;
-      ggy = ny / kEps;
-    } else {
-      ggx = fdiv_m(nx, kEps, fc.rcEps);
-      ggy = fdiv_m(ny, kEps, fc.rcEps);
-      tiny = tiny || min(tiny_key(fabsf(nx)), tiny_key(fabsf(ny))) < kTinyBits - 1u;
-    }
-    float2 res;
-    res.x = f.x - c.gradStep * ggx;
-    res.y = f.y - c.gradStep * ggy;
-    return res;
-  };
-
-  // (LPP 16) the same update, one round deep: every evaluation either round could ask for, then the reference's selection
-  auto update_spec = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool take,
-                         bool& tiny) -> float2 {
-    constexpr bool ST = decltype(steady)::value;
-    const int bank = q >> 2, role = q & 3;
-    const float2 cand = bank == 1 ? fl : (bank == 2 ? up : fo);
-    const float ax = cand.x + (role == 1 ? kEps : 0.0f), ay = cand.y + (role == 2 ? kEps : 0.0f);
-    const Cell k = cell_of(x, ax, ay);
-    const float e = ST ? evaluate(ieee, k, take, lanesSpec, rc, ax, ay, tiny)
-                       : evaluate(ieee, k, take && bank < 3 && role < 3 && (bank != 1 || xi > 0) && (bank != 2 || hasUp), ~0ull,
-                                  rc, ax, ay, tiny);
-    const float e0 = row_share<0>(e), e0x = row_share<1>(e), e0y = row_share<2>(e);
-    float e1 = row_share<4>(e);
-    const float e1x = row_share<5>(e), e1y = row_share<6>(e);
-    float e2 = row_share<8>(e);
-    const float e2x = row_share<9>(e), e2y = row_share<10>(e);
-    if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
-    if (!hasUp) e2 = kInf;            // no up proposal in the first row
-    const bool b1 = e1 < e0;
-    const float c1 = b1 ? e1 : e0;
-    const bool b2 = e2 < c1;
-    float2 f;
-    f.x = b2 ? up.x : (b1 ? fl.x : fo.x);
-    f.y = b2 ? up.y : (b1 ? fl.y : fo.y);
-    const float cur = b2 ? e2 : c1;
-    const float ex = b2 ? e2x : (b1 ? e1x : e0x), ey = b2 ? e2y : (b1 ? e1y : e0y);
     const float nx = ex - cur, ny = ey - cur;
     float ggx, ggy;
     if (decltype(ieee)::value) {
@@ -517,9 +447,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     // threshold keep their flow): bands whose first row is never updated — most bands of the pole flows — run
     // without waiting for anybody. Checked every kQNeed steps for kQNeed columns, or on demand after a stretch
     // of steps that did not need the band above (the columns passed meanwhile are dropped).
-    if (hasUpBand && (ST || s < w) && ((s & (kNeed - 1)) == kPhase || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
+    if (hasUpBand && (ST || s < w) && ((s & (kQNeed - 1)) == kQPhase || upFilled <= s) && (__ballot(rowValid && nrc.x == nrc.x) & 1ull)) {
       // through the column of the next scheduled check (which needs its own column like any other step)
-      const int need = min(((s + 1) | (kNeed - 1)) + 1, w), limit = s + kUpRing;
+      const int need = min(((s + 1) | (kQNeed - 1)) + 1, w), limit = s + kUpRing;
       if (upFilled < s) {
         upFilled = s;
         pending = false;
@@ -539,7 +469,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
           if (lane == 0) atomicExch(errflag, 1u);
         }
       }
-      if (upFilled < w && upFilled - s < 2 * kNeed + 8) issue();  // running low: taken at the next check
+      if (upFilled < w && upFilled - s < 2 * kQNeed + 8) issue();  // running low: taken at the next check
     }
     const float4 rc = nrc;
     const float2 fo = nfo;
@@ -553,8 +483,8 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);  // unclamped: out-of-range columns are inactive
     const bool upd = rc.x == rc.x;
     float2 up;
-    up.x = LPP == 3 ? from_row_above_t(upl.x, fl.x) : LPP == 16 ? from_row_above_s(upl.x, fl.x) : from_row_above_q(upl.x, fl.x);
-    up.y = LPP == 3 ? from_row_above_t(upl.y, fl.y) : LPP == 16 ? from_row_above_s(upl.y, fl.y) : from_row_above_q(upl.y, fl.y);
+    up.x = LPP == 3 ? from_row_above_t(upl.x, fl.x) : from_row_above_q(upl.x, fl.x);
+    up.y = LPP == 3 ? from_row_above_t(upl.y, fl.y) : from_row_above_q(upl.y, fl.y);
     // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
     // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
     // two rounds are skipped.
@@ -562,16 +492,13 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float2 alt = active ? fo : fl;
     float2 res = alt;
     if (__ballot(take) != 0ull) {
-      auto upd_px = [&](auto ieee, bool& tiny) -> float2 {
-        if constexpr (LPP == 16) return update_spec(ieee, steady, x, xi, rc, fo, fl, up, take, tiny);
-        else return update(ieee, steady, x, xi, rc, fo, fl, up, take, tiny);
-      };
-      bool tiny = false;
       if (FAST) {
-        res = upd_px(std::false_type{}, tiny);
-        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = upd_px(std::true_type{}, tiny);
+        bool tiny = false;
+        res = update(std::false_type{}, steady, x, xi, rc, fo, fl, up, take, tiny);
+        if (__builtin_expect(__ballot(tiny) != 0ull, 0)) res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, take, tiny);
       } else {
-        res = upd_px(std::true_type{}, tiny);
+        bool tiny = false;
+        res = update(std::true_type{}, steady, x, xi, rc, fo, fl, up, take, tiny);
       }
       res.x = take ? res.x : alt.x;
       res.y = take ? res.y : alt.y;
@@ -584,9 +511,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     fl = res;
     if (q == 0) s_res[r][s & (kQChunk - 1)] = res;
     S360_WAVE_SYNC();  // (read below by the publishing lanes and by the chunk's write-back)
-    if (publishes && ((s & (kPub - 1)) == kPub - 1 || (!ST && s == nsteps - 1))) {  // the last row's granules for the band below
-      const int xi0 = (s & ~(kPub - 1)) - (kQRows - 1) + lane;
-      if (ST ? lane < kPub : (lane < kPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1))) {
+    if (publishes && ((s & (kQPub - 1)) == kQPub - 1 || (!ST && s == nsteps - 1))) {  // the last row's granules for the band below
+      const int xi0 = (s & ~(kQPub - 1)) - (kQRows - 1) + lane;
+      if (ST ? lane < kQPub : (lane < kQPub && xi0 >= 0 && xi0 < w && xi0 <= s - (kQRows - 1))) {
         const float2 v = s_res[kQRows - 1][(xi0 + kQRows - 1) & (kQChunk - 1)];
         __hip_atomic_store(Hout + xi0, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -639,37 +566,30 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 // step for it: a launch that saturates the chip (the side flows of a batch of frame slots: thousands of bands) is
 // instruction-issue-bound and gains (30.3 against 27.2 Gpx/s on a saturated side level), a launch that is a dependency
 // chain (the pole flows: every band waits for its predecessor, about one band per SIMD) pays the longer step (33.1
-// against 34.3 Gpx/s); profiles/r03_v4_*. A launch of the latency mode (one frame's flows: the chip is far from full)
-// takes the 16-lane mapping, whose step is one round deep. The choice only depends on the launch's shape and mode, so
-// that the hand-off arena can be sized before the launch. S360_QUAD_LPP=3 / 4 / 16 overrides it (tests, tuning; the
-// results do not depend on it).
-static int quad_lpp(int h, int B, bool latency) {
+// against 34.3 Gpx/s); profiles/r03_v4_*. The choice only depends on the launch's shape, so that the hand-off arena can
+// be sized before the launch. S360_QUAD_LPP=3 / 4 overrides it (tests, tuning; the results do not depend on it).
+static int quad_lpp(int h, int B) {
   static const int forced = [] {
     const char* e = std::getenv("S360_QUAD_LPP");
-    const int v = e ? std::atoi(e) : 0;
-    return v == 3 || v == 4 || v == 16 ? v : 0;
+    return e && (e[0] == '3' || e[0] == '4') ? e[0] - '0' : 0;
   }();
   if (forced) return forced;
-  if (latency) return 16;
   return (long long)B * ((h + 15) / 16) >= 4096 ? 3 : 4;  // bands of 16 rows in the launch against 1024 SIMDs x 4
 }
-int sweep_quad_num_bands(int h, int B, bool latency) {
-  const int rows = quad_rows(quad_lpp(h, B, latency));
-  return (h + rows - 1) / rows;
-}
-size_t sweep_quad_handoff_bytes(int w, int h, int B, bool latency) {
-  return 256 + (size_t)B * sweep_quad_num_bands(h, B, latency) * w * sizeof(unsigned long long);
+int sweep_quad_num_bands(int h, int B) { const int rows = quad_rows(quad_lpp(h, B)); return (h + rows - 1) / rows; }
+size_t sweep_quad_handoff_bytes(int w, int h, int B) {
+  return 256 + (size_t)B * sweep_quad_num_bands(h, B) * w * sizeof(unsigned long long);
 }
 void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
-                       const PixFlowConsts& pc, bool fast, const unsigned* rowflags, bool latency) {
+                       const PixFlowConsts& pc, bool fast, const unsigned* rowflags) {
   const SweepConst c = make_sweep_const(pc, w, h);
   SweepFast fc;
   fc.rcCols = 1.0f / c.fcols;
   fc.rcRows = 1.0f / c.frows;
   fc.rcEps = 1.0f / 0.001f;
   fc.dbg = S360_DBG_FROM_ENV();  // developer tools only: 1 gathers always hit, 2 no waiting on the band above, 4 no write-back
-  const int nb = sweep_quad_num_bands(h, B, latency);
+  const int nb = sweep_quad_num_bands(h, B);
   // `handoff` must be all-ones (ticket counter in the first 256 bytes, then the granules): FlowEngine resets the
   // hand-off arena of all its sweep launches with one memset.
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
@@ -689,9 +609,7 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
 #define S360_LAUNCH_QUAD(F, L)                                                                                       \
   hipLaunchKernelGGL((k_sweep_quad<F, L>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
                      fc, nb, B, errflag, rowflags)
-  const int lpp = quad_lpp(h, B, latency);
-  if (lpp == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
-  else if (lpp == 16) { if (fast) S360_LAUNCH_QUAD(true, 16); else S360_LAUNCH_QUAD(false, 16); }
+  if (quad_lpp(h, B) == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
   else { if (fast) S360_LAUNCH_QUAD(true, 4); else S360_LAUNCH_QUAD(false, 4); }
 #undef S360_LAUNCH_QUAD
 }

@@ -38,6 +38,7 @@ def emu():
                                 out.ctypes.data_as(C.c_void_p), err, 512)
         assert rc == 0, err.value
         return out
+    run.lib = lib
     return run
 
 
@@ -77,3 +78,17 @@ def test_batch_over_shared_images_masked_rows_and_previous_frame(emu, mode):
     for k, (p, q) in enumerate(pairs):
         want = O.compute_optical_flow(nxt[p], nxt[q], "pixflow_low", "LEFT", first[k], imgs[p], imgs[q])
         assert np.array_equal(_bits(second[k]), _bits(want)), (mode, k)
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh,B", [(333, 200, 300, 180, 16), (150, 97, 135, 87, 4), (70, 40, 63, 36, 3), (9, 7, 8, 6, 2)])
+def test_pyramid_resize_tiles(emu, sw, sh, dw, dh, B):
+    """The pyramid's tiled resize (k_resize_linear_f32c1_tiled) with many tiles per plane, several plane groups and the
+    XCD-aware tile order active (>= 64 workgroups), ragged edges, and the smallest levels (which take the one-thread-per-
+    pixel kernel) against the oracle's resize."""
+    rng = np.random.RandomState(sw + dh)
+    src = rng.rand(B, sh, sw).astype(np.float32)
+    out = np.zeros((B, dh, dw), np.float32)
+    assert emu.lib.emu_resize_linear_planes(src.ctypes.data_as(C.c_void_p), sw, sh, B, dw, dh, out.ctypes.data_as(C.c_void_p)) == 0
+    for b in range(B):
+        want = O.resize_linear_f32(src[b], dw, dh)
+        assert np.array_equal(out[b].view(np.uint32), np.asarray(want, np.float32).reshape(dh, dw).view(np.uint32)), "plane %d" % b

@@ -48,3 +48,14 @@ extern "C" int emu_flow_batch(const uint8_t* images, int n_images, int w, int h,
     return -1;
   }
 }
+
+// The pyramid's resize on its own (B one-channel planes sw x sh -> dw x dh): sizes with many tiles per plane and enough
+// workgroups for the XCD-aware tile order to permute them — the frames the emulated tests can afford never get there.
+extern "C" int emu_resize_linear_planes(const float* src, int sw, int sh, int B, int dw, int dh, float* dst) {
+  try {
+    launch_resize_linear_f32(nullptr, src, sw, sh, (size_t)sw * sh, dst, dw, dh, (size_t)dw * dh, 1, B, 1.f, 0);
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}

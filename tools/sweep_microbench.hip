@@ -27,7 +27,7 @@ static FlowIdx make_idx(int B) {  // flow b: image b against image (b + B) mod 2
   CK(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
   return FlowIdx{d, d + B};
 }
-static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad (throughput mapping), 4 quad (latency mapping)*/, int reps) {
+static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, int reps) {
   const size_t n = (size_t)w * h;
   std::mt19937 rng(1234);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -53,7 +53,7 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad (thro
   CK(hipMalloc(&dG, hG.size() * 4));
   CK(hipMalloc(&drec, hrec.size() * 4));
   CK(hipMalloc(&dflow, hflow.size() * 4));
-  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), std::max(sweep_quad_handoff_bytes(w, h, B), sweep_quad_handoff_bytes(w, h, B, true)));
+  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   CK(hipMalloc(&hand, hb));
   CK(hipMalloc(&err, 8));
   CK(hipMemset(err, 0, 8));
@@ -76,7 +76,7 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad (thro
     if (mode == 2)
       launch_sweep_lock(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
     else
-      launch_sweep_quad(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast, nullptr, mode == 4);
+      launch_sweep_quad(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
   };
   once(1);
   CK(hipStreamSynchronize(st));
@@ -117,7 +117,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<void*> hand(NS);
   std::vector<unsigned*> err(NS);
   std::vector<hipStream_t> st(NS);
-  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), std::max(sweep_quad_handoff_bytes(w, h, B), sweep_quad_handoff_bytes(w, h, B, true)));
+  const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
     CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
@@ -139,8 +139,8 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   sweep_verify_divisors(st[0], d);
   auto once = [&](int k, int dir) {
     CK(hipMemsetAsync(hand[k], 0xFF, hb, st[k]));
-    if (mode >= 3)
-      launch_sweep_quad(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true, nullptr, mode == 4);
+    if (mode == 3)
+      launch_sweep_quad(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
     else
       launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
   };
@@ -239,12 +239,12 @@ int main(int argc, char** argv) {
   struct Cfg { int w, h, B; const char* name; };
   const Cfg cfgs[] = {{127, 27, 4, "polar L35"}, {613, 128, 4, "polar L20"}, {5040, 1052, 4, "polar L0"},
                       {27, 38, 28, "side L30"}, {140, 203, 28, "side L14"}, {607, 884, 28, "side L0"}};
-  printf("%-10s %6s %6s %3s | %9s | %9s | %9s | %9s |  us per launch of one flow batch alone\n", "config", "w", "h", "B", "lock", "lock ieee", "quad", "quad lat");
+  printf("%-10s %6s %6s %3s | %9s | %9s | %9s |  us per launch of one flow batch alone\n", "config", "w", "h", "B", "lock", "lock ieee", "quad");
   for (const Cfg& c : cfgs) {
     const int reps = c.w > 1000 ? 6 : 20;
-    printf("%-10s %6d %6d %3d | %9.1f | %9.1f | %9.1f | %9.1f |  lock us/step %.3f\n", c.name, c.w, c.h, c.B,
+    printf("%-10s %6d %6d %3d | %9.1f | %9.1f | %9.1f |  lock us/step %.3f\n", c.name, c.w, c.h, c.B,
            run(c.w, c.h, c.B, true, 2, reps), run(c.w, c.h, c.B, false, 2, reps), run(c.w, c.h, c.B, true, 3, reps),
-           run(c.w, c.h, c.B, true, 4, reps), run(c.w, c.h, c.B, true, 2, reps) / (c.w + 18));
+           run(c.w, c.h, c.B, true, 2, reps) / (c.w + 18));
     fflush(stdout);
   }
   return 0;
