@@ -246,12 +246,15 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   // loads (one in-order counter), i.e. for the next chunk's prefetches as well.
   // (`rel` && lane in `relLanes`: the lanes that matter. The part of the test that only depends on the lane's role is a
   // constant lane mask in SGPRs — as a per-lane boolean it cost an exec-mask detour of ~15 instructions per round)
-  auto evaluate = [&](auto ieee, const Cell& k, bool rel, unsigned long long relLanes, float4 rc, float ax, float ay,
+  // The test itself is scalar: two compares write their lane masks, the rest is 64-bit SALU (a ballot of a boolean that
+  // was combined from masks goes through a VGPR and back).
+  auto evaluate = [&](auto ieee, const Cell& k, unsigned long long relLanes, float4 rc, float ax, float ay,
                       bool& tiny) -> float {
     const int jy = k.y0 - wy0, ju = k.x0 + k.y0 - wu0;
-    const bool in = (unsigned)jy <= (unsigned)(kWinRows - 2) && (unsigned)ju <= (unsigned)(kWinCols - 3);
+    const bool outY = (unsigned)jy > (unsigned)(kWinRows - 2), outU = (unsigned)ju > (unsigned)(kWinCols - 3);
+    const bool in = !outY && !outU;
     S360_QSTAT(g_quad_rounds);
-    if (__builtin_expect((__ballot(rel && !in) & relLanes) != 0ull, 0)) {
+    if (__builtin_expect(((__ballot(outY) | __ballot(outU)) & relLanes) != 0ull, 0)) {
       S360_QSTAT(g_quad_fallbacks);
       float e = error_of(ieee, gather(k), k, rc, ax, ay, tiny);
 #ifndef S360_WAVE_EMULATION
@@ -259,7 +262,9 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #endif
       return e;
     }
-    const int off = in ? jy * kWinStride + ju : 0;  // (lanes that do not matter read slot 0)
+    // (lanes that do not matter read slot 0; the 24-bit multiply-add is a full-rate instruction, the 32-bit one the
+    // compiler picks for jy * kWinStride + ju — v_mad_u64_u32 — is not, and it sits in front of the LDS read)
+    const int off = in ? (int)__umul24((unsigned)jy, (unsigned)kWinStride) + ju : 0;
     const f4a8 ta = *reinterpret_cast<const f4a8*>(&s_win[off]);
     const f4a8 tb = *reinterpret_cast<const f4a8*>(&s_win[off + kWinStride + 1]);
     Texels tt;
@@ -273,10 +278,11 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
                     bool& tiny) -> float2 {
     constexpr bool ST = decltype(steady)::value;
     const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
-    const float ax = cand.x + 0.0f, ay = cand.y + 0.0f;
+    const float ax = cand.x, ay = cand.y;
     const Cell k = cell_of(x, ax, ay);
-    const float e = ST ? evaluate(ieee, k, take, lanesRound1, rc, ax, ay, tiny)
-                       : evaluate(ieee, k, take && (q == 0 || (q == 1 && xi > 0) || (q == 2 && hasUp)), ~0ull, rc, ax, ay, tiny);
+    const unsigned long long takeLanes = __ballot(take);
+    const float e = evaluate(ieee, k, ST ? takeLanes & lanesRound1 : __ballot(take && (q == 0 || (q == 1 && xi > 0) || (q == 2 && hasUp))),
+                             rc, ax, ay, tiny);
     float e0, e1, e2;
     if constexpr (LPP == 3) tri_exchange(e, q, e0, e1, e2);
     else { e0 = quad_bcast<0>(e); e1 = quad_bcast<1>(e); e2 = quad_bcast<2>(e); }
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
     const float cur = b2 ? e2 : c1;
     const float pax = f.x + (q == 0 ? kEps : 0.0f), pay = f.y + (q == 1 ? kEps : 0.0f);
     const Cell pk = cell_of(x, pax, pay);
-    const float pe = evaluate(ieee, pk, take, lanesRound2, rc, pax, pay, tiny);
+    const float pe = evaluate(ieee, pk, takeLanes & lanesRound2, rc, pax, pay, tiny);
     float ex, ey;
     if constexpr (LPP == 3) { float unused; tri_exchange(pe, q, ex, ey, unused); }
     else { ex = quad_bcast<0>(pe); ey = quad_bcast<1>(pe); }
