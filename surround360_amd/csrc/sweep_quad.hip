@@ -53,10 +53,7 @@ constexpr unsigned long long kEmptyGranuleQ = 0xFFFFFFFFFFFFFFFFull;
 // can hand it to the first pixel of the next DPP row; the values of a round are exchanged with row_shr / row_shl by 1 and
 // 2 and a select per role (a quad broadcast does not exist for groups of three): ~16 more instructions per step for 25 %
 // more pixels per step, and bands of 20 rows (20 % fewer bands and hand-offs per flow).
-// 2: a pixel is a lane pair, 32 rows per wave; round 1 takes two passes (current / left, then up), round 2 one: three
-// evaluation passes per step for 32 pixels instead of two for 16 or 20 — the fewest instructions per pixel, the longest step
-// and the largest staging footprint (records, flows and window of 32 rows): for launches that saturate the chip.
-constexpr int quad_rows(int lpp) { return lpp == 3 ? 20 : lpp == 2 ? 32 : 16; }
+constexpr int quad_rows(int lpp) { return lpp == 3 ? 20 : 16; }
 constexpr int kUpRing = 64;  // columns of the band above kept in LDS
 
 template <int K>
@@ -68,19 +65,6 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {  // row_shr:n (0x110 + n) / row_shl:n (0x100 + n); lanes without a source keep v
   const int i = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
-}
-template <int K>
-__device__ __forceinline__ float pair_bcast(float v) {  // (LPP 2) value of lane K of this lane's pair
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, K | (K << 2) | ((K + 2) << 4) | ((K + 2) << 6), 0xF, 0xF, true));
-}
-// (LPP 2) previous result of the row above = lane - 2: lane 15 of the previous DPP row into lanes 0..3 of rows 1..3
-// (row_bcast:15, bank 0), then row_shr:2 over it for lanes 2..15 (lanes 0 and 1 have no source and keep what they have:
-// the broadcast value, or `old` = the granule-fed value in the first pixel of the wave).
-__device__ __forceinline__ float from_row_above_p(float old, float v) {
-  int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x142, 0xE, 0x1, false);
-  r = __builtin_amdgcn_update_dpp(r, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, false);
-  return __builtin_bit_cast(float, r);
 }
 // (LPP 3) the values of the pixel's lanes 0, 1, 2 in every lane of the pixel: role q has its own value, takes the others
 // from 1 or 2 lanes to the left / right (the passive lane 15 computes garbage that nobody reads)
@@ -147,15 +131,8 @@ unsigned long long g_quad_rounds = 0, g_quad_fallbacks = 0, g_quad_chunks = 0, g
 #endif
 
 // Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
-// Two waves per SIMD is what the launch asks for (S360_QUAD_WAVES_PER_CU = 8): the register budget is told to the
-// compiler — the 2-lanes-per-pixel mapping wants 276 VGPRs, gets 256 and keeps its spills outside the steady loops.
-#ifdef S360_WAVE_EMULATION
-#define S360_TWO_WAVES_PER_SIMD
-#else
-#define S360_TWO_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
 template <bool FAST, int LPP>
-__global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
+__global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
@@ -212,8 +189,7 @@ __global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const
   }
   // r: row of the band; q: role in the pixel (0 current / x probe, 1 left / y probe, 2 up; 3: spare lane)
   const int l16 = lane & 15, g5 = min(l16 / 3, 4);
-  const int r = LPP == 3 ? (lane >> 4) * 5 + g5 : LPP == 2 ? lane >> 1 : lane >> 2;
-  const int q = LPP == 3 ? l16 - 3 * g5 : LPP == 2 ? lane & 1 : lane & 3;
+  const int r = LPP == 3 ? (lane >> 4) * 5 + g5 : lane >> 2, q = LPP == 3 ? l16 - 3 * g5 : lane & 3;
   const int yi = band * kQRows + r;
   const bool rowValid = yi < h;
   const int yic = rowValid ? yi : h - 1;
@@ -228,7 +204,6 @@ __global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const
   int wy0 = kNoWin, wu0 = 0;  // placement of the LDS window, wave-uniform
   // the lanes whose evaluation counts in round 1 (current, left, up where a row above exists) and in round 2 (the probes)
   const unsigned long long lanesRound1 = __ballot(q == 0 || q == 1 || (q == 2 && hasUp)), lanesRound2 = __ballot(q < 2);
-  const unsigned long long lanesUp = __ballot(q == 0 && hasUp);  // (LPP 2: the second pass of round 1)
 
   // getPixBilinear32FExtend's clamp + split (PixFlow.h:457-464) of the tap (x + ax, y + ay) of this lane's pixel
   struct Cell { float mx, my; int x0, y0; };
@@ -302,24 +277,15 @@ __global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const
   auto update = [&](auto ieee, auto steady, int x, int xi, float4 rc, float2 fo, float2 fl, float2 up, bool take,
                     bool& tiny) -> float2 {
     constexpr bool ST = decltype(steady)::value;
+    const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
+    const float ax = cand.x, ay = cand.y;
+    const Cell k = cell_of(x, ax, ay);
     const unsigned long long takeLanes = __ballot(take);
+    const float e = evaluate(ieee, k, ST ? takeLanes & lanesRound1 : __ballot(take && (q == 0 || (q == 1 && xi > 0) || (q == 2 && hasUp))),
+                             rc, ax, ay, tiny);
     float e0, e1, e2;
-    if constexpr (LPP == 2) {  // two passes: current | left in the pair's lanes, then up in both
-      const float2 cand = q == 0 ? fo : fl;
-      const float e = evaluate(ieee, cell_of(x, cand.x, cand.y), ST ? takeLanes : __ballot(take && (q == 0 || xi > 0)), rc,
-                               cand.x, cand.y, tiny);
-      e2 = evaluate(ieee, cell_of(x, up.x, up.y), takeLanes & lanesUp, rc, up.x, up.y, tiny);
-      e0 = pair_bcast<0>(e);
-      e1 = pair_bcast<1>(e);
-    } else {
-      const float2 cand = q == 0 ? fo : (q == 2 ? up : fl);
-      const float ax = cand.x, ay = cand.y;
-      const Cell k = cell_of(x, ax, ay);
-      const float e = evaluate(ieee, k, ST ? takeLanes & lanesRound1 : __ballot(take && (q == 0 || (q == 1 && xi > 0) || (q == 2 && hasUp))),
-                               rc, ax, ay, tiny);
-      if constexpr (LPP == 3) tri_exchange(e, q, e0, e1, e2);
-      else { e0 = quad_bcast<0>(e); e1 = quad_bcast<1>(e); e2 = quad_bcast<2>(e); }
-    }
+    if constexpr (LPP == 3) tri_exchange(e, q, e0, e1, e2);
+    else { e0 = quad_bcast<0>(e); e1 = quad_bcast<1>(e); e2 = quad_bcast<2>(e); }
     if (!ST && !(xi > 0)) e1 = kInf;  // no left proposal in the first column
     if (!hasUp) e2 = kInf;            // no up proposal in the first row
     // proposeFlowUpdate x2 in the reference's order, written as selects (with an index beside them the compiler would
@@ -336,7 +302,6 @@ __global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const
     const float pe = evaluate(ieee, pk, takeLanes & lanesRound2, rc, pax, pay, tiny);
     float ex, ey;
     if constexpr (LPP == 3) { float unused; tri_exchange(pe, q, ex, ey, unused); }
-    else if constexpr (LPP == 2) { ex = pair_bcast<0>(pe); ey = pair_bcast<1>(pe); }
     else { ex = quad_bcast<0>(pe); ey = quad_bcast<1>(pe); }
     const float nx = ex - cur, ny = ey - cur;
     float ggx, ggy;
@@ -524,8 +489,8 @@ __global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const
     const int x = ST ? xLane + s * xSign : (dir > 0 ? xi : w - 1 - xi);  // unclamped: out-of-range columns are inactive
     const bool upd = rc.x == rc.x;
     float2 up;
-    up.x = LPP == 3 ? from_row_above_t(upl.x, fl.x) : LPP == 2 ? from_row_above_p(upl.x, fl.x) : from_row_above_q(upl.x, fl.x);
-    up.y = LPP == 3 ? from_row_above_t(upl.y, fl.y) : LPP == 2 ? from_row_above_p(upl.y, fl.y) : from_row_above_q(upl.y, fl.y);
+    up.x = LPP == 3 ? from_row_above_t(upl.x, fl.x) : from_row_above_q(upl.x, fl.x);
+    up.y = LPP == 3 ? from_row_above_t(upl.y, fl.y) : from_row_above_q(upl.y, fl.y);
     // Pixels below the alpha threshold keep their flow (PixFlow.h:390 / :403): when none of the wave's 16 pixels is
     // updated at this step — whole bands of the pole flows, whose upper ~60 % the side cameras do not cover — the
     // two rounds are skipped.
@@ -612,14 +577,10 @@ __global__ __launch_bounds__(64) S360_TWO_WAVES_PER_SIMD void k_sweep_quad(const
 static int quad_lpp(int h, int B) {
   static const int forced = [] {
     const char* e = std::getenv("S360_QUAD_LPP");
-    return e && (e[0] == '2' || e[0] == '3' || e[0] == '4') ? e[0] - '0' : 0;
+    return e && (e[0] == '3' || e[0] == '4') ? e[0] - '0' : 0;
   }();
   if (forced) return forced;
-  static const int saturated = [] {  // S360_QUAD_LPP_SAT=2 / 3: the mapping of the launches that saturate the chip
-    const char* e = std::getenv("S360_QUAD_LPP_SAT");
-    return e && (e[0] == '2' || e[0] == '3') ? e[0] - '0' : 3;
-  }();
-  return (long long)B * ((h + 15) / 16) >= 4096 ? saturated : 4;  // bands of 16 rows in the launch against 1024 SIMDs x 4
+  return (long long)B * ((h + 15) / 16) >= 4096 ? 3 : 4;  // bands of 16 rows in the launch against 1024 SIMDs x 4
 }
 int sweep_quad_num_bands(int h, int B) { const int rows = quad_rows(quad_lpp(h, B)); return (h + rows - 1) / rows; }
 size_t sweep_quad_handoff_bytes(int w, int h, int B) {
@@ -654,8 +615,7 @@ void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float
 #define S360_LAUNCH_QUAD(F, L)                                                                                       \
   hipLaunchKernelGGL((k_sweep_quad<F, L>), dim3(grid), dim3(64), 0, st, rec, G, flow, H, hdr, w, h, bs, idx, dir, c, \
                      fc, nb, B, errflag, rowflags)
-  if (quad_lpp(h, B) == 2) { if (fast) S360_LAUNCH_QUAD(true, 2); else S360_LAUNCH_QUAD(false, 2); }
-  else if (quad_lpp(h, B) == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
+  if (quad_lpp(h, B) == 3) { if (fast) S360_LAUNCH_QUAD(true, 3); else S360_LAUNCH_QUAD(false, 3); }
   else { if (fast) S360_LAUNCH_QUAD(true, 4); else S360_LAUNCH_QUAD(false, 4); }
 #undef S360_LAUNCH_QUAD
 }

@@ -65,7 +65,7 @@ def test_lock_sizes(emulator, w, h):
 
 
 @pytest.mark.parametrize("w,h", [(3, 2), (16, 16), (31, 16), (32, 17), (33, 33), (48, 20), (47, 21), (64, 41), (200, 70)])
-@pytest.mark.parametrize("lpp", [2, 3, 4])
+@pytest.mark.parametrize("lpp", [3, 4])
 def test_quad_sizes(emulator, w, h, lpp):
     """Widths without, with exactly one and with several interior chunks (the first one is steps 16..31 / 32..47: w >= 32 /
     48); heights of exactly one band (16 / 20 rows), one row more, two bands and one row more."""
@@ -74,7 +74,7 @@ def test_quad_sizes(emulator, w, h, lpp):
 
 
 @pytest.mark.parametrize("mask", ["none", "random", "bands", "rows0", "most"])
-@pytest.mark.parametrize("lpp", [2, 3, 4])
+@pytest.mark.parametrize("lpp", [3, 4])
 def test_quad_lds_window(emulator, mask, lpp):
     """The bilinear taps of both rounds come from the LDS window of I1-gradient texels placed per chunk, and a wave one of
     whose taps leaves it gathers from global memory for that round (the generator's +-40 px outliers and +-2 px noise make
