@@ -1,19 +1,26 @@
 // sweep_quad.hip — throughput-oriented PixFlow propagation sweep for gfx950 ("quad").
 //
 // Same recurrence and same results as sweep_lock.hip (PixFlow.h:388-410), arranged for many flows / frames in
-// flight instead of for the latency of one flow. With the chip full of sweeps the limit is instruction issue (all
-// types: tools/issue_rate shows ~0.4 instructions per cycle per SIMD for VALU/SALU mixes however many waves share
-// the SIMD), so this variant minimises instructions per pixel update:
+// flight instead of for the latency of one flow. A wave's step is a latency chain (~280 mostly dependent instructions
+// at ~6 cycles each); with the chip full of sweeps a SIMD interleaves two of them (the staging registers and LDS of a
+// wave allow two waves per SIMD) and reaches ~0.33 of the ~0.4 instructions per cycle it sustains (tools/issue_rate),
+// so this variant minimises instructions per STEP (DESIGN.md section 5 has the measurements, including the mappings
+// with fewer instructions per pixel that were not faster):
 //   * 4 lanes per pixel, 16 rows per wave (row r handles column s - r at step s);
 //   * the reference's two dependent rounds are kept: round 1 evaluates the current / left / up proposals in lanes
 //     0..2 of the quad, round 2 the two finite-difference probes of the winner in lanes 0..1 — 5 evaluations instead
 //     of the lockstep kernel's 9;
-//   * the step itself is ~250 instructions (202 VALU); everything else is amortised: the band above is checked every
-//     4 steps with wave-uniform control (a poll returns up to 64 granules), results go to an LDS ring and are written
-//     back once per 16 steps (loads and stores retire in order through one counter on gfx950 — a global store per step
-//     sat in front of every gather), the last row's granules are published every 4 steps, and the rare operands
-//     outside the proven range of the fast division / square root re-run the whole update with the IEEE expansions
-//     (one branch per step instead of three). Per step this is 253 instructions against 484 before;
+//   * the step itself is ~280 instructions; everything else is amortised: the band above is checked every 4 steps
+//     with wave-uniform control (a poll returns up to 64 granules), results go to an LDS ring and are written back once
+//     per 16 steps, the last row's granules are published every 4 steps, and the rare operands outside the proven range
+//     of the fast division / square root re-run the whole update with the IEEE expansions (one branch per step instead
+//     of three);
+//   * the steady step contains no wait on the memory counter (loads and stores retire in order through one counter on
+//     gfx950): the next chunk's records / flows / window are requested so that the checks of the band above — the only
+//     consumers of a load inside a chunk — sit three steps behind them, and nothing that is pending on a cold path can
+//     look pending to the steady loops (ONE call site of win_issue, S360_VM_DRAIN behind the edge chunks: the
+//     compiler's wait-count pass otherwise drains the counter in every step, which is how the build profiled as
+//     r03_v8 ran);
 //   * no service waves, no barriers: a workgroup is ONE wave; other resident waves cover its memory latency. Left
 //     neighbour = registers, up neighbour = DPP (row_shr:4 / row_bcast:15), a band's first row takes the last row of
 //     the band above from 8-byte {fx,fy} granules in global memory (all-ones = not written; bands are ticketed in
@@ -32,9 +39,10 @@
 //     skips both rounds, a band waits for the band above only where its first row is updated, and a band without any
 //     updated pixel (per-row flags written by the record kernel) hands its last row on and leaves — 63 % of a pole
 //     flow's pixels are like that.
-// Measured (tools/sweep_microbench tp1, see tools/mb_experiment.sh): ~24 Gpx/s on saturated side levels (336 flows of
-// 607x884), ~22 Gpx/s on the 48 pole flows of a 12-frame batch; a single flow runs ~1.4x slower than with
-// sweep_lock.hip. FlowEngine picks this kernel in throughput mode (s360_set_sweep_mode).
+// Measured (tools/sweep_microbench tp1): 32.8 Gpx/s on saturated side levels (336 flows of 607x884, 3 lanes per pixel),
+// 37.0 Gpx/s on the 48 pole flows of a 12-frame batch (4 lanes per pixel); one frame's flows alone run as fast as with
+// sweep_lock.hip on the large levels and 5-30 % slower on the small ones (profiles/r03_v9_*). FlowEngine picks this kernel
+// in throughput mode (s360_set_sweep_mode).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
