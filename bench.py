@@ -22,11 +22,16 @@ Then, one context alone on the GPU (nothing else in flight, so kernel durations 
     gather, poles + composite on rank 0), per-kernel-family milliseconds, the warp/blend and flow-stencil kernels
     against the HBM roofline, and the same frame with the reference presets' sharpening 0.25;
   * `config2_flow_pair`: BASELINE configs[1], one 2048x2048 pair, both directions, GPU vs the CPU oracle;
-  * `video_stream`: configs[4] on one GPU — >= 32 DISTINCT frames of a rotating world with a moving disc, every frame
+  * `video_stream`: configs[4] on one GPU — 190 frames of a rotating world with a moving disc, every frame
     regularised toward its predecessor's device-resident flows, inputs fed from host memory through the upload stream
-    while the previous frame renders; with and without frame pipelining;
-  * `cpu_baseline`: the CPU oracle (an OpenCV-free port of the reference, kind "port") rendering the SAME 8K frame once
-    with the reference's thread shape (14 pair threads, then 4 pole threads), timed on the host cores (N=1 only).
+    while the previous frame renders; with and without frame pipelining; steady state over frames 10-189, and what the
+    reference's per-frame state files would add (`spill_ms_per_frame`);
+  * `end_to_end_files`: SURVEY 8d's "end-to-end incl. raw I/O" figure — the drop-in host program
+    (host/TestRenderStereoPanorama --num_frames) rendering the first frames of that stream from PNG files on disk to
+    equirect PNG files on disk, its last frame compared with the same chain rendered through the C ABI in this process;
+  * `cpu_baseline`: kind "reference" — the reference's own TestRenderStereoPanorama program (oracle/_ref) rendering the
+    SAME 8K frame once as a process on the host cores (N=1 only), its equirect compared with the GPU's; where oracle/_ref
+    is absent the CPU oracle port with the reference's thread shape (kind "port").
 
 Prints ONE JSON line on rank 0.
 """
@@ -94,6 +99,79 @@ def cpu_baseline_8k(side, top, bottom, rig_path=RIG, flags=None):
 
 
 REF_PROGRAM = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama")
+
+
+def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420):
+    """"state both the device-path fps and the end-to-end fps incl. raw I/O". The drop-in host program
+    (host/TestRenderStereoPanorama, the reference's binary name / flags / file layout) renders `frames` consecutive
+    frames as ONE stream from PNG files on disk to equirect PNG files on disk: 17 PNG decodes per frame, upload, render
+    with device-resident temporal state, download, 8192x8192 PNG encode, everything overlapped as --num_frames does it.
+    Returns the record (wall time of the whole process incl. HIP start-up and context creation, and the program's own
+    per-frame figure from its --v 1 runtime breakdown)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    if not os.path.exists(program):
+        return {"error": "%s not built" % os.path.relpath(program, ROOT)}
+    cams = json.load(open(rig_path))["cameras"]
+    side_ids = [c["id"] for c in cams if "side" in c.get("group", "")]
+    other = [c for c in cams if "side" not in c.get("group", "")]
+    top_id = max(other, key=lambda c: c["forward"][2])["id"]
+    bot_id = min(other, key=lambda c: c["forward"][2])["id"]
+    work = tempfile.mkdtemp(prefix="s360_e2e_")
+    try:
+        imgs, out = os.path.join(work, "rgb"), os.path.join(work, "out")
+        for cid in side_ids + [top_id, bot_id]:
+            os.makedirs(os.path.join(imgs, cid))
+        jobs = []
+        for k, (side, top, bottom) in enumerate(frames):
+            for cid, img in list(zip(side_ids, side)) + [(top_id, top), (bot_id, bottom)]:
+                jobs.append((np.asarray(img), os.path.join(imgs, cid, "%06d.png" % k)))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:  # (PIL's zlib releases the GIL)
+            list(ex.map(lambda j: Image.fromarray(np.ascontiguousarray(j[0][:, :, ::-1])).save(j[1], compress_level=1), jobs))
+        t_write = time.perf_counter() - t0
+        in_bytes = sum(os.path.getsize(j[1]) for j in jobs)
+        n = len(frames)
+        os.makedirs(os.path.join(out, "debug", "%06d" % (n - 1), "flow_images"))
+        os.makedirs(os.path.join(out, "flow", "%06d" % (n - 1)))
+        cmd = [program, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", "000000", "--num_frames", str(n),
+               "--output_data_dir", out, "--prev_frame_data_dir", "NONE", "--output_equirect_path", os.path.join(out, "eqr_%s.png"),
+               "--sharpening", repr(float(flags.get("sharpening", 0.0))), "--device", str(device), "--write_state=false", "--v", "1"]
+        for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
+            cmd += ["--" + k, str(flags[k])]
+        cmd += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+        outs = [os.path.join(out, "eqr_%06d.png" % k) for k in range(n)]
+        missing = [os.path.basename(o) for o in outs if not os.path.exists(o)]
+        if missing:
+            return {"error": "missing outputs: %s" % missing}
+        m = re.search(r"stream of\s+(\d+) frames:\s+([0-9.]+)\s+\(([0-9.]+) per frame", r.stderr)
+        Image.MAX_IMAGE_PIXELS = None
+        last = np.ascontiguousarray(np.asarray(Image.open(outs[-1]))[:, :, ::-1])
+        rec = {"program": os.path.relpath(program, ROOT), "frames": n, "process_wall_s": round(wall, 2),
+               "frames_per_s_process": n / wall,
+               "input_png_bytes_per_frame": in_bytes // n, "output_png_bytes_per_frame": sum(os.path.getsize(o) for o in outs) // n,
+               "dataset_write_s": round(t_write, 2),
+               "note": "END TO END incl. file I/O (SURVEY 8d): the drop-in host program reading 17 PNG files per frame from disk "
+                       "and writing one stereo equirect PNG per frame to disk, the frames as one stream (--num_frames: temporal "
+                       "regularisation, device-resident state, decode / upload / render / download / encode overlapped; PNG "
+                       "codec of host/png_io.hpp, inputs written by PIL at compression level 1). process_wall_s includes "
+                       "process start, HIP initialisation and context creation; ms_per_frame_stream is the program's own "
+                       "runtime breakdown (first render to last file, TRSP:964-971)"}
+        if m:
+            rec["ms_per_frame_stream"] = 1e3 * float(m.group(3))
+            rec["frames_per_s_stream"] = 1.0 / max(float(m.group(3)), 1e-9)
+        return rec, last
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def cpu_baseline_reference(side, top, bottom, rig_path=RIG, flags=None, timeout=900):
@@ -555,7 +633,8 @@ def main():
             emit()
         os._exit(0)
 
-    watchdog = threading.Timer(900.0, bail, args=("post-timed-region phases timed out",))
+    # (N > 1: only the sharded frame follows — seconds; a stuck RCCL exchange must not outlast the driver's patience)
+    watchdog = threading.Timer(900.0 if world == 1 else 300.0, bail, args=("post-timed-region phases timed out",))
     watchdog.daemon = True
     watchdog.start()
     try:
@@ -746,6 +825,23 @@ def main():
             except Exception as e:  # noqa: BLE001
                 video["spill"] = {"error": repr(e)}
             out["video_stream"] = video
+
+            # ---- the same stream END TO END through the drop-in host program: PNG files in, PNG files out ----
+            try:
+                n_e2e = min(8, n_distinct)
+                prog = os.path.join(ROOT, "tools", "emu", "TestRenderStereoPanorama") if dry else \
+                    os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+                res = host_program_stream([stream_frame(k) for k in range(n_e2e)], rig_path, flags, prog, device=local_rank)
+                if isinstance(res, tuple):
+                    rec, last_png = res
+                    _, eq_chain = stream(True, n_e2e, True)  # the same chain through the C ABI in this process
+                    rec["last_frame_equals_in_process_stream"] = bool(eq_chain.shape == last_png.shape and
+                                                                      np.array_equal(eq_chain, last_png))
+                    out["end_to_end_files"] = rec
+                else:
+                    out["end_to_end_files"] = res
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end_files"] = {"error": repr(e)}
 
             if not args.no_cpu_baseline:
                 ref = None
