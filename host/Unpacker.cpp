@@ -44,10 +44,10 @@ struct Footage {
   Header md{};
   size_t frame_size() const { return (size_t)md.width * md.height * md.bitsPerPixel / 8; }
   size_t frames() const { return (md.numberOfCameras && frame_size() && size >= 4096) ? (size - 4096) / frame_size() / md.numberOfCameras : 0; }
-  const uint8_t* frame(size_t f, size_t cam) const {
-    const uint8_t* p = base + 4096 + (md.numberOfCameras * f + cam) * frame_size();
-    if (p + frame_size() > base + size) throw std::runtime_error("frame out of range for " + path);
-    return p;
+  const uint8_t* frame(size_t f, size_t cam) const {  // (offsets, not pointers: nothing here may wrap around)
+    const size_t fs = frame_size(), avail = (size - 4096) / fs;  // whole frames in the file; open() made fs > 0
+    if (cam >= md.numberOfCameras || f >= avail / md.numberOfCameras) throw std::runtime_error("frame out of range for " + path);
+    return base + 4096 + (md.numberOfCameras * f + cam) * fs;
   }
   void open() {
     fd = ::open(path.c_str(), O_RDONLY);
@@ -60,6 +60,12 @@ struct Footage {
     if (a == MAP_FAILED) throw std::runtime_error("Error mmap'ing() file " + path);
     base = static_cast<const uint8_t*>(a);
     std::memcpy(&md, base, sizeof md);
+    // an untrusted header: sizes that no sensor has would wrap frame_size() around (BinaryFootageFile.cpp trusts them)
+    if (md.numberOfCameras != 0) {
+      if (md.width == 0 || md.height == 0 || md.width > 65536u || md.height > 65536u || md.numberOfCameras > 4096u)
+        throw std::runtime_error("implausible metadata (width / height / numberOfCameras) in " + path);
+      if (md.bitsPerPixel == 12 && (md.width & 1u)) throw std::runtime_error("12-bit frames need an even width: " + path);
+    }
     std::printf("Metadata:\nmagic = %x\ntimestamp = %u\nfileIndex = %u\nfileCount = %u\nwidth = %u\nheight = %u\nbpp = %u\nnumberOfCameras = %u\n",
                 md.magic, md.timestamp, md.fileIndex, md.fileCount, md.width, md.height, md.bitsPerPixel, md.numberOfCameras);
   }
@@ -133,6 +139,7 @@ int main(int argc, char** argv) {
     if (F[k].empty()) die(std::string("missing required command line argument: ") + k);
   const int device = std::atoi(F["device"].c_str());
   const long startFrame = std::atol(F["start_frame"].c_str()), frameCountFlag = std::atol(F["frame_count"].c_str());
+  if (startFrame < 0 || frameCountFlag < 0) die("--start_frame and --frame_count must not be negative");
 
   std::set<uint32_t> serials;
   std::mutex mu;

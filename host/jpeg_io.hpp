@@ -278,7 +278,7 @@ class Reader {
       long z1 = (z2 + z3) * F0541;
       long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
       z2 = v[0]; z3 = v[4];
-      long tmp0 = (z2 + z3) << CB, tmp1 = (z2 - z3) << CB;
+      long tmp0 = (z2 + z3) * (1l << CB), tmp1 = (z2 - z3) * (1l << CB);  // (a left shift of a negative value is undefined)
       const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
       tmp0 = v[7]; tmp1 = v[5]; tmp2 = v[3]; tmp3 = v[1];
       z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
@@ -302,7 +302,7 @@ class Reader {
       long z2 = w[2], z3 = w[6];
       long z1 = (z2 + z3) * F0541;
       long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
-      long tmp0 = (w[0] + w[4]) << CB, tmp1 = (w[0] - w[4]) << CB;
+      long tmp0 = (w[0] + w[4]) * (1l << CB), tmp1 = (w[0] - w[4]) * (1l << CB);
       const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
       tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
       z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;

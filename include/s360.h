@@ -121,7 +121,15 @@ int s360_pole_ramp(const s360_camera* cams, int n_cams, float out4[4]);
  * run in parallel. For throughput hand the pairs over together (s360_compute_optical_flow_batch, s360_frame_render):
  * 14 serialised single-pair calls cost 14 flow latencies. With concurrent callers read a failed call's message with
  * s360_last_error(NULL) (the calling thread's own last error); s360_last_error(ctx) is the context's most recent one. */
-/* cams: the whole rig (side cameras in rig order + pole cameras), as RigDescription holds it. */
+/* cams: the whole rig (side cameras in rig order + pole cameras), as RigDescription holds it.
+ * Flags whose frame cannot exist do not fail here — the operator-level entry points (flows, remaps, blends) do not
+ * depend on the frame geometry — but every s360_frame_* / frame-slot call of such a context fails with
+ * S360_ERR_INVALID_ARG and the reason (the reference runs into OpenCV's assertions inside the frame and aborts):
+ * eqr_width / eqr_height outside 1..65536, final_eqr_width / final_eqr_height outside 0..65536 (0 = no final resize) or
+ * leaving fewer than two output rows, a side projection / overlap / strip of zero pixels (s360_geometry), and flow
+ * images — overlap_image_width x cam_image_height for the sides, (eqr_width x 1.2) x pole rows for an enabled pole —
+ * below 2 x 2 pixels after the algorithm's entry downscale (4 x 4 for pixflow_low): the same floor
+ * s360_compute_optical_flow has. Unknown algorithm names fail here: S360_ERR_UNKNOWN_ALG. */
 int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams, const s360_params* params);
 void s360_destroy(s360_ctx* ctx);
 int s360_get_geometry(const s360_ctx* ctx, s360_geometry* out);

@@ -35,6 +35,14 @@ static int guard(s360_ctx* c, F&& f) {
     return S360_ERR_STATE;
   }
 }
+// s360_frame_* entry points: as guard, and refused when the context's flags describe no renderable frame (s360_create)
+template <typename F>
+static int frame_guard(s360_ctx* c, F&& f) {
+  return guard(c, [&] {
+    if (c && !c->frame_invalid.empty()) throw Error(S360_ERR_INVALID_ARG, c->frame_invalid);
+    f();
+  });
+}
 static void need(bool ok, const char* what) {
   if (!ok) throw Error(S360_ERR_INVALID_ARG, what);
 }
@@ -185,6 +193,30 @@ int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams,
     const double up[3] = {0, 0, 1}, down[3] = {0, 0, -1};
     c->top_idx = c->rig.find_by_direction(up);
     c->bottom_idx = c->rig.find_by_direction(down);
+    // Sizes no frame can have (the reference runs into OpenCV's assertions somewhere inside the frame, TRSP aborts):
+    // every stage indexes pixels with 32-bit integers and sizes its buffers from these numbers. The operator-level
+    // entry points (flows, remaps, blends) do not depend on them, so the context is still created; every s360_frame_*
+    // call of such a context fails with this message (frame_guard).
+    auto frame_needs = [&](bool ok, const char* what) {
+      if (!ok && c->frame_invalid.empty()) c->frame_invalid = what;
+    };
+    frame_needs(c->P.eqr_width >= 1 && c->P.eqr_height >= 1 && c->P.eqr_width <= 65536 && c->P.eqr_height <= 65536,
+                "eqr_width / eqr_height must be in 1..65536");
+    frame_needs(c->P.final_eqr_width >= 0 && c->P.final_eqr_height >= 0 && c->P.final_eqr_width <= 65536 && c->P.final_eqr_height <= 65536,
+                "final_eqr_width / final_eqr_height must be in 0..65536 (0 = no final resize)");
+    frame_needs(c->g.cam_image_width >= 1 && c->g.cam_image_height >= 1 && c->g.overlap_image_width >= 1 && c->g.num_novel_views >= 1,
+                "eqr_width / eqr_height too small for this rig: a side projection, its overlap or its strip would be empty");
+    frame_needs(c->g.out_width >= 1 && c->g.out_height >= 2, "final_eqr_width / final_eqr_height leave no output pixels");
+    {  // the flows of a frame run on overlap_image_width x cam_image_height and (eqr_width x 1.2) x pole rows images
+      const PixFlowConsts ps = pixflow_consts_by_name(c->P.side_flow_alg), pp = pixflow_consts_by_name(c->P.polar_flow_alg);
+      frame_needs(int(c->g.overlap_image_width * ps.downscaleFactor) >= 2 && int(c->g.cam_image_height * ps.downscaleFactor) >= 2,
+                  "eqr_width / eqr_height too small for this rig: the side flows need overlap images of at least 2 x 2 pixels after the entry downscale");
+      const int extW = int(float(c->P.eqr_width) * 1.2f);
+      frame_needs(!c->P.enable_top || c->top_idx < 0 || (int(extW * pp.downscaleFactor) >= 2 && int(c->g.top_rows * pp.downscaleFactor) >= 2),
+                  "eqr_width / eqr_height too small for this rig: the top pole flows need at least 2 x 2 pixels after the entry downscale");
+      frame_needs(!c->P.enable_bottom || c->bottom_idx < 0 || (int(extW * pp.downscaleFactor) >= 2 && int(c->g.bottom_rows * pp.downscaleFactor) >= 2),
+                  "eqr_width / eqr_height too small for this rig: the bottom pole flows need at least 2 x 2 pixels after the entry downscale");
+    }
     if (c->bottom_idx >= 0) c->ramp = pole_ramp(c->rig);
     { c->flow.reset(new FlowEngine(&c->prof)); c->flow->set_sweep_mode(c->sweep_mode); }
   });
@@ -497,27 +529,27 @@ int s360_sharpen(s360_ctx* c, uint8_t* bgr, int w, int h, float sharpening) {
 
 // ---- frame level ------------------------------------------------------------------------------------
 int s360_frame_upload_side(s360_ctx* c, int side_idx, const uint8_t* img, int w, int h, int channels) {
-  return guard(c, [&] { need(c && img && w > 0 && h > 0, "bad argument"); frame_upload_side(c, side_idx, img, w, h, channels); });
+  return frame_guard(c, [&] { need(c && img && w > 0 && h > 0, "bad argument"); frame_upload_side(c, side_idx, img, w, h, channels); });
 }
 int s360_frame_upload_top(s360_ctx* c, const uint8_t* bgr, int w, int h) {
-  return guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, true, bgr, w, h); });
+  return frame_guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, true, bgr, w, h); });
 }
 int s360_frame_upload_bottom(s360_ctx* c, const uint8_t* bgr, int w, int h) {
-  return guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, false, bgr, w, h); });
+  return frame_guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, false, bgr, w, h); });
 }
 int s360_frame_upload_raw(s360_ctx* c, s360_isp* isp, int camera, const uint16_t* raw16, int w, int h) {
-  return guard(c, [&] { need(c && isp && raw16 && w > 0 && h > 0, "bad argument"); frame_upload_raw(c, isp, camera, raw16, w, h); });
+  return frame_guard(c, [&] { need(c && isp && raw16 && w > 0 && h > 0, "bad argument"); frame_upload_raw(c, isp, camera, raw16, w, h); });
 }
 int s360_frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w,
                                    int h) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && bottom2 && mask && mask2 && w > 0 && h > 0, "bad argument");
     frame_upload_pole_removal(c, bottom2, mask, mask2, w, h);
   });
 }
 int s360_frame_set_prev_pole_removal(s360_ctx* c, const float* flow, const uint8_t* bottom_image, const uint8_t* bottom_image2,
                                      int w, int h) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && flow && bottom_image && bottom_image2 && w > 0 && h > 0, "bad argument");
     FrameState& F = frame_state(c);
     const size_t n = (size_t)w * h;
@@ -532,34 +564,34 @@ int s360_frame_set_prev_pole_removal(s360_ctx* c, const float* flow, const uint8
   });
 }
 int s360_frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev) {
-  return guard(c, [&] { need(c, "null ctx"); frame_render_pairs(c, p0, p1, use_prev); });
+  return frame_guard(c, [&] { need(c, "null ctx"); frame_render_pairs(c, p0, p1, use_prev); });
 }
 int s360_frame_finish(s360_ctx* c, int pole_mask, int use_prev) {
-  return guard(c, [&] { need(c, "null ctx"); frame_finish(c, pole_mask, use_prev); });
+  return frame_guard(c, [&] { need(c, "null ctx"); frame_finish(c, pole_mask, use_prev); });
 }
 int s360_frame_render(s360_ctx* c, int use_prev) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c, "null ctx");
     frame_render_pairs(c, 0, (int)c->rig.side.size(), use_prev);
     frame_finish(c, 15, use_prev);
   });
 }
 int s360_set_frame_slots(s360_ctx* c, int n) {
-  return guard(c, [&] { need(c, "null ctx"); set_frame_slots(c, n); });
+  return frame_guard(c, [&] { need(c, "null ctx"); set_frame_slots(c, n); });
 }
 int s360_select_frame_slot(s360_ctx* c, int k) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c, "null ctx");
     need(k >= 0 && k < (int)std::max<size_t>(c->slots.size(), 1), "frame slot out of range");
     c->slot = k;
   });
 }
 int s360_frame_render_batch(s360_ctx* c, int use_prev) {
-  return guard(c, [&] { need(c, "null ctx"); frame_render_batch(c, use_prev); });
+  return frame_guard(c, [&] { need(c, "null ctx"); frame_render_batch(c, use_prev); });
 }
 int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, const float* flow_r_to_l,
                              const uint8_t* overlap_l, const uint8_t* overlap_r) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && flow_l_to_r && flow_r_to_l && overlap_l && overlap_r, "bad argument");
     FrameState& F = frame_state(c);
     const int P = F.P;
@@ -585,7 +617,7 @@ int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, co
 }
 int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uint8_t* ext_side,
                              const uint8_t* ext_fisheye) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && flow && ext_side && ext_fisheye && unit >= 0 && unit < 4, "bad argument");
     FrameState& F = frame_state(c);
     const int extW = int(float(c->P.eqr_width) * 1.2f);
@@ -619,25 +651,25 @@ int s360_comm_destroy(s360_ctx* c) {
   return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); comm_destroy(c); });
 }
 int s360_frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
-  return guard(c, [&] { need(c && bounds, "null argument"); frame_gather_strips(c, bounds, root); });
+  return frame_guard(c, [&] { need(c && bounds, "null argument"); frame_gather_strips(c, bounds, root); });
 }
 int s360_frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask) {
-  return guard(c, [&] { need(c && bounds && need_mask, "null argument"); frame_exchange_strips(c, bounds, need_mask); });
+  return frame_guard(c, [&] { need(c && bounds && need_mask, "null argument"); frame_exchange_strips(c, bounds, need_mask); });
 }
 int s360_frame_gather_pole_layers(s360_ctx* c, const int owner[4], int root) {
-  return guard(c, [&] { need(c && owner, "null argument"); frame_gather_pole_layers(c, owner, root); });
+  return frame_guard(c, [&] { need(c && owner, "null argument"); frame_gather_pole_layers(c, owner, root); });
 }
 int s360_frame_pole_units(s360_ctx* c, int pole_mask, int use_prev) {
-  return guard(c, [&] { need(c, "null ctx"); frame_pole_units(c, pole_mask, use_prev); });
+  return frame_guard(c, [&] { need(c, "null ctx"); frame_pole_units(c, pole_mask, use_prev); });
 }
 int s360_frame_composite(s360_ctx* c, int pole_mask) {
-  return guard(c, [&] { need(c, "null ctx"); frame_composite(c, pole_mask); });
+  return frame_guard(c, [&] { need(c, "null ctx"); frame_composite(c, pole_mask); });
 }
 int s360_comm_loopback(s360_ctx* c, int src_pair, int dst_pair) {
   return guard(c, [&] { need(c, "null ctx"); comm_loopback(c, src_pair, dst_pair); });
 }
 int s360_frame_set_partition(s360_ctx* c, int p0, int p1) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c, "null ctx");
     FrameState& F = frame_state(c);
     need(p0 >= 0 && p1 <= F.P && p0 <= p1, "bad pair range");
@@ -648,7 +680,7 @@ int s360_frame_set_partition(s360_ctx* c, int p0, int p1) {
   });
 }
 int s360_frame_strip_ptr(s360_ctx* c, int eye, void** dev_ptr, size_t* bytes_per_pair) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && dev_ptr && (eye == 0 || eye == 1), "bad argument");
     FrameState& F = frame_state(c);
     const int P = F.P, camH = c->g.cam_image_height, stripW = c->P.eqr_width / P;
@@ -659,7 +691,7 @@ int s360_frame_strip_ptr(s360_ctx* c, int eye, void** dev_ptr, size_t* bytes_per
   });
 }
 int s360_frame_equirect_dev(s360_ctx* c, void** dev_ptr, size_t* bytes) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && dev_ptr, "bad argument");
     FrameState& F = frame_state(c);
     need(F.frames_done > 0, "no frame rendered yet");
@@ -668,7 +700,7 @@ int s360_frame_equirect_dev(s360_ctx* c, void** dev_ptr, size_t* bytes) {
   });
 }
 int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && out_bgr, "bad argument");
     FrameState& F = frame_state(c);
     need(F.frames_done > 0, "no frame rendered yet");
@@ -676,7 +708,7 @@ int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
   });
 }
 int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
     FrameState& F = frame_state(c);
     need(F.frames_done > age, "that frame has not been rendered");
@@ -696,12 +728,12 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
 }
 
 int s360_frame_cubemap(s360_ctx* c, int face_w, int face_h, const char* format, int whc[3], uint8_t* out_bgr) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && format && whc, "bad argument");
     const std::string f(format);
     if (f != "video" && f != "photo")  // CvUtil.cpp:134-137
       throw Error(S360_ERR_INVALID_ARG, "unexpected cubemap format: " + f + ". valid formats are: video,photo");
-    need(face_w > 0 && face_h > 0, "cubemap face size must be positive");
+    need(face_w > 0 && face_h > 0 && face_w <= 16384 && face_h <= 16384, "cubemap face size must be in 1..16384");
     whc[0] = f == "video" ? 3 * face_w : face_w;
     whc[1] = f == "video" ? 4 * face_h : 12 * face_h;
     whc[2] = 3;
@@ -713,7 +745,7 @@ int s360_frame_cubemap(s360_ctx* c, int face_w, int face_h, const char* format, 
   });
 }
 int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_t* dst) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && name && whc, "bad argument");
     FrameState& F = frame_state(c);
     const s360_geometry& g = c->g;
@@ -768,7 +800,7 @@ int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_
   });
 }
 int s360_frame_get_f32(s360_ctx* c, const char* name, int idx, int whc[3], float* dst) {
-  return guard(c, [&] {
+  return frame_guard(c, [&] {
     need(c && name && whc, "bad argument");
     FrameState& F = frame_state(c);
     const s360_geometry& g = c->g;

@@ -55,6 +55,7 @@ struct s360_ctx {
   std::unique_ptr<s360::FlowEngine> flow_pr;    // pole-removal flow between the two bottom cameras
   int sweep_mode = -1;  // -1 default (lockstep), 2 latency, 3 throughput (s360_set_sweep_mode)
   std::string err;
+  std::string frame_invalid;  // why the flags describe no renderable frame (s360_create); empty = fine
   // scratch for operator-level calls
   s360::DevBuf op_a, op_b, op_c, op_d, op_e, op_f;
   // Frame slots: slot 0 always exists; s360_set_frame_slots(n) adds more so that n independent frames (n streams of a

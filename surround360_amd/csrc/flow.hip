@@ -101,6 +101,10 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   Profiler& P = *prof_;
   dw_ = int(w * pc.downscaleFactor);
   dh_ = int(h * pc.downscaleFactor);
+  // every caller, not only the operator entry point (the frame stages come here directly): the sweep kernels' tap
+  // footprints and window placement assume at least 2 x 2 pixels at every pyramid level
+  if (dw_ < 2 || dh_ < 2)
+    throw Error(-1, "image too small for PixFlow: the reference's bilinear taps need a 2x2 image after the entry downscale (PixFlow.h:457-475)");
   const size_t n0 = (size_t)dw_ * dh_;
   lv_.build(dw_, dh_, pc.pyrScaleFactor);
   const int L = (int)lv_.w.size();

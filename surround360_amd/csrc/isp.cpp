@@ -48,6 +48,12 @@ double number_of(const JV& v, const char* key) {
   if (v.t != JV::NUM) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' holds a value that is not a number");
   return v.num;
 }
+// ... as an int (the reference's ToInt()); values no int holds are an error here, not undefined behaviour
+int int_of(const JV& v, const char* key) {
+  const double d = number_of(v, key);
+  if (!(d > -1e9 && d < 1e9)) throw Error(S360_ERR_IO, std::string("isp json: '") + key + "' is out of range");
+  return (int)d;
+}
 void vec3(const JV& o, const char* key, float* dst) {
   const JV* a = o.get(key);
   if (!a) return;
@@ -120,8 +126,8 @@ void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.
       for (int j = 0; j < 3; ++j) c->ccm[i * 3 + j] = (float)number_of(m->arr[i].arr[j], "ccm");
     }
   }
-  if (const JV* r = isp->get("stuckPixelRadius")) c->stuck_pixel_radius = 2 * (int)number_of(*r, "stuckPixelRadius");
-  if (const JV* r = isp->get("stuckPixelThreshold")) c->stuck_pixel_threshold = (int)number_of(*r, "stuckPixelThreshold");
+  if (const JV* r = isp->get("stuckPixelRadius")) c->stuck_pixel_radius = 2 * int_of(*r, "stuckPixelRadius");
+  if (const JV* r = isp->get("stuckPixelThreshold")) c->stuck_pixel_threshold = int_of(*r, "stuckPixelThreshold");
   if (const JV* r = isp->get("stuckPixelDarknessThreshold"))
     c->stuck_pixel_darkness_threshold = (float)number_of(*r, "stuckPixelDarknessThreshold");
   if (const JV* b = isp->get("bayerPattern")) {  // setup(): the first of these names the string contains

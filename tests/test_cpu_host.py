@@ -307,6 +307,46 @@ def test_unpacker_raw_path(tmp_path, bits):
     assert r.returncode != 0 and "Error opening file" in r.stderr
 
 
+def test_unpacker_rejects_hostile_headers(tmp_path):
+    """An untrusted .bin container: header fields that would wrap the frame-size arithmetic around (the reference's
+    BinaryFootageFile.cpp trusts them), an odd width with 12-bit packing, negative frame ranges — each an error message,
+    never a read outside the mapping."""
+    import struct
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "surround360_amd", "csrc"), "-j8", "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    exe = os.path.join(ROOT, "host", "Unpacker")
+    out, raw, isp = tmp_path / "rgb", tmp_path / "raw", tmp_path / "isp"
+    for d in (out, raw, isp):
+        d.mkdir()
+
+    def run(width, height, bpp, ncam, payload=4096, extra=()):
+        binp = tmp_path / "h.bin"
+        page = struct.pack("<8I", 0xfaceb00c, 0, 0, 1, width, height, bpp, ncam).ljust(4096, b"\0")
+        binp.write_bytes(page + bytes(payload))
+        return subprocess.run([exe, "--isp_dir", str(isp), "--output_dir", str(out), "--output_raw_dir", str(raw),
+                               "--bin_list", str(binp)] + list(extra), capture_output=True, text=True)
+    # width * height * bpp / 8 wraps to a small number in 64 bits: 2^31 * 2^31 * 8 / 8 = 2^62, times 12 wraps
+    for wd, ht, bpp in ((0x80000000, 0x80000000, 12), (0xffffffff, 0xffffffff, 8), (0, 16, 8), (16, 0, 8), (70000, 16, 8)):
+        r = run(wd, ht, bpp, 1)
+        assert r.returncode != 0 and "implausible metadata" in r.stderr, (wd, ht, bpp, r.stderr)
+    r = run(16, 16, 8, 100000)
+    assert r.returncode != 0 and "implausible metadata" in r.stderr
+    r = run(15, 4, 12, 1)
+    assert r.returncode != 0 and "even width" in r.stderr
+    r = run(16, 4, 7, 1)
+    assert r.returncode != 0 and "unsupported bits per pixel" in r.stderr
+    r = run(16, 4, 8, 1, extra=("--start_frame", "-1"))
+    assert r.returncode != 0 and "must not be negative" in r.stderr
+    r = run(16, 4, 8, 1, extra=("--frame_count", "-3"))
+    assert r.returncode != 0 and "must not be negative" in r.stderr
+    r = run(16, 4, 8, 0)  # "No cameras found...": accepted, nothing to do
+    assert r.returncode == 0 and "No cameras found" in r.stderr
+    r = run(64, 64, 8, 2, payload=64 * 64)  # not even one frame per camera
+    assert r.returncode != 0 and "larger than total number of frames" in r.stderr
+    r = run(16, 4, 8, 2, payload=16 * 4 * 2 * 3 + 17)  # three whole frames per camera and a ragged tail: the tail is ignored
+    assert r.returncode == 0 and len(os.listdir(raw)) == 1, r.stderr
+
+
 JPEG_SNIPPET = r'''
 #include "jpeg_io.hpp"
 int main(int argc, char** argv) {  // argv: in.jpg out.raw

@@ -171,6 +171,11 @@ def test_library_rejects_unsupported(s360lib):
         I.config_from_json('{"CameraIsp": {"ccm": [[1, 0], [0, 1]]}}')
     with pytest.raises(_capi.S360Error):
         I.config_from_json('{"CameraIsp": {"bayerPattern": "XYZW"}}')
+    for bad in ('{"CameraIsp": {"stuckPixelRadius": 1e999}}', '{"CameraIsp": {"stuckPixelThreshold": -1e300}}',
+                '{"CameraIsp": {"stuckPixelRadius": "2"}}', '{"CameraIsp": {"saturation": null}}',
+                '{"CameraIsp": {"gamma": [1, 2]}}', '{"CameraIsp": {"gamma": [1, 2, true]}}', '{"CameraIsp": {}} x'):
+        with pytest.raises(_capi.S360Error):  # (an int no int holds was undefined behaviour before the range check)
+            I.config_from_json(bad)
     c = I.config_from_json(isputil.CONFIG_MINIMAL, demosaic_filter=1)
     with pytest.raises(_capi.S360Error):
         I.config_tables(c)  # DCT demosaic

@@ -164,3 +164,59 @@ def test_operator_argument_errors(env):
         ctx.feather_alpha_channel(np.zeros((8, 8, 4), np.uint8), 41)  # erode size above the supported range
     with pytest.raises(R.S360Error):
         ctx.feather_alpha_channel(np.zeros((8, 8, 4), np.uint8), 16)  # even: GaussianBlur would refuse the kernel size
+
+
+def test_frame_calls_refuse_sizes_no_frame_can_have(rig_json, s360lib):
+    """Flags whose frame cannot exist — negative, zero or absurd eqr / final sizes, a projection, overlap or strip that
+    would be empty, flow images below 2 x 2 after the entry downscale: the context is created (its operator-level entry
+    points do not depend on the frame geometry) and every s360_frame_* call fails with S360_ERR_INVALID_ARG, where the
+    reference runs into OpenCV assertions inside the frame (TRSP aborts). Before these checks the first render of such
+    a context wrote outside its buffers."""
+    from surround360_amd import synth
+    rig = R.RigDescription(rig_json)
+    img = np.zeros((16, 16, 3), np.uint8)
+    i0, i1 = synth.flow_pair(24, 20, seed=3)
+    for kw in (dict(eqr_width=-14, eqr_height=64), dict(eqr_width=0, eqr_height=64), dict(eqr_width=28, eqr_height=0),
+               dict(eqr_width=28, eqr_height=-5), dict(eqr_width=1400000, eqr_height=64), dict(eqr_width=140, eqr_height=2000000000),
+               dict(eqr_width=28, eqr_height=2),    # cam_image_height 0
+               dict(eqr_width=14, eqr_height=64),   # overlap 2 px wide: 1 px after the x0.5 entry
+               dict(eqr_width=140, eqr_height=5),   # 2 rows
+               dict(eqr_width=140, eqr_height=64, final_eqr_width=-1, final_eqr_height=64),
+               dict(eqr_width=140, eqr_height=64, final_eqr_width=64, final_eqr_height=-1),
+               dict(eqr_width=140, eqr_height=64, final_eqr_width=64, final_eqr_height=1),
+               dict(eqr_width=140, eqr_height=64, final_eqr_width=70000, final_eqr_height=64)):
+        ctx = R.Context(rig, R.make_params(**kw))
+        try:
+            for call in (lambda: ctx.upload_frame([img]), lambda: ctx.render(), lambda: ctx.render_pairs(0, 2, False),
+                         lambda: ctx.set_frame_slots(2), lambda: ctx.equirect_dev()):
+                with pytest.raises(R.S360Error, match="eqr"):
+                    call()
+            assert ctx.compute_optical_flow(i0, i1, "pixflow_low", "LEFT").shape == (20, 24, 2)  # operators still work
+        finally:
+            ctx.close()
+    ctx = R.Context(rig, R.make_params(eqr_width=28, eqr_height=14))  # the smallest frame of this rig: overlap 4 x 6
+    g = ctx.geometry
+    assert (g.cam_image_width, g.cam_image_height, g.overlap_image_width, g.num_novel_views) == (6, 6, 4, 2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("eqr_w,eqr_h,cam,final,poles", [(28, 14, 64, (0, 0), 1), (42, 21, 64, (0, 0), 1), (70, 33, 64, (0, 0), 0),
+                                                         (28, 300, 64, (0, 0), 1), (28, 14, 8, (3, 2), 1), (140, 70, 4, (300, 300), 1)])
+def test_tiny_frames_equal_the_oracle(tmp_path, rig_json, oracle, s360lib, eqr_w, eqr_h, cam, final, poles):
+    """Whole frames at the small end of what s360_create accepts — overlap images 4 px wide, 6-row projections, 4 x 4
+    cameras magnified 35 times, a 3 x 2 output, feathers as large as the images allow: every pyramid is a single level
+    and every tile kernel runs partial tiles only. Stereo equirect byte for byte against the oracle."""
+    path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_tiny.json"), cam / 2048.0)
+    side, top, bottom = rigutil.frame_inputs(path, cam)
+    flags = dict(eqr_width=eqr_w, eqr_height=eqr_h, enable_top=poles, enable_bottom=poles, final_eqr_width=final[0],
+                 final_eqr_height=final[1], sharpening=0.25 if poles else 0.0, side_alpha_feather_size=min(7, cam // 2),
+                 std_alpha_feather_size=3)
+    cams, _ = oracle.load_rig(path)
+    want, _ = oracle.Frame(cams, oracle.make_params(**flags)).render(side, top, bottom)
+    ctx = R.Context(R.RigDescription(path), R.make_params(**flags))
+    try:
+        ctx.upload_frame(side, top, bottom)
+        ctx.render()
+        _same("tiny frame %dx%d" % (eqr_w, eqr_h), ctx.download_equirect(), want)
+    finally:
+        ctx.close()

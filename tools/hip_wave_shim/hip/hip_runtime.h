@@ -137,7 +137,10 @@ inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); retu
 inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
-inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
+inline int __mul24(int a, int b) {  // low 24 bits of each operand, sign-extended (shifts on the unsigned value: no undefined behaviour)
+  const int sa = (int)((unsigned)a << 8) >> 8, sb = (int)((unsigned)b << 8) >> 8;
+  return (int)((unsigned)sa * (unsigned)sb);
+}
 inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned long long)v) + 1 : 0; }
 using std::max;
 using std::min;
