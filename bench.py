@@ -294,7 +294,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import rigutil
         cam_size, world_h, pair_size = 256, 512, 150
-        rig_path = rigutil.scaled_rig_json(RIG, "/tmp/bench_dry_run_rig.json", cam_size / 2048.0)
+        rig_path = rigutil.scaled_rig_json(RIG, "/tmp/bench_dry_run_rig_%d.json" % rank, cam_size / 2048.0)
         flags.update(eqr_width=504, eqr_height=252, final_eqr_width=480, final_eqr_height=480)
 
         class _NoCuda:  # the handful of torch.cuda calls of this script

@@ -20,7 +20,8 @@ RIG_JSON = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
 # The product never looks at this variable.
 if os.environ.get("S360_TEST_EMULATED_LIB") == "1":
     from surround360_amd import _capi as _capi_for_emulation
-    _capi_for_emulation.LIB_PATH = os.path.join(ROOT, "tools", "libs360_emu.so")
+    # (S360_TEST_EMULATED_LIB_PATH: another build of the emulated library, e.g. tools/fuzz/libs360_asan.so)
+    _capi_for_emulation.LIB_PATH = os.environ.get("S360_TEST_EMULATED_LIB_PATH") or os.path.join(ROOT, "tools", "libs360_emu.so")
 
 
 def pytest_configure(config):

@@ -71,3 +71,24 @@ def test_sharded_frame_across_processes_gloo(tmp_path, emu_programs, world):
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "mp_sharded_frame.py")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "SHARDED_FRAME_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
+    """bench.py the way the driver launches it for N > 1 — `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2` — on the emulated library (S360_TEST_EMULATED_LIB=1: NOT a measurement; gloo for the timing reductions, the
+    RCCL stand-in between the two processes): one JSON line from rank 0 with n_gpus 2, every timed frame checked, and the
+    sharded single frame (pairs + pole units over both ranks, the two native exchanges) equal to the unsharded one."""
+    port = 31500 + os.getpid() % 2000
+    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), EMU_DEVICES="2", S360_TEST_EMULATED_LIB="1", S360_BENCH_BACKEND="gloo",
+               S360_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--slots", "1", "--inflight", "1"], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert "dry_run" in d and "errors" not in d
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["warmup"] == 0
+    assert d["checked"] is True and d["config"]["rccl_ranks"] == 2
+    assert d["single_frame"]["rccl_ranks"] == 2 and d["single_frame"]["equals_single_gpu_frame"] is True
