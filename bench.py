@@ -27,7 +27,7 @@ Then, one context alone on the GPU (nothing else in flight, so kernel durations 
     while the previous frame renders; with and without frame pipelining; steady state over frames 10-189, and what the
     reference's per-frame state files would add (`spill_ms_per_frame`);
   * `end_to_end_files`: SURVEY 8d's "end-to-end incl. raw I/O" figure — the drop-in host program
-    (host/TestRenderStereoPanorama --num_frames) rendering the first frames of that stream from PNG files on disk to
+    (host/TestRenderStereoPanorama --num_frames) rendering the first 14 frames of that stream from PNG files on disk to
     equirect PNG files on disk, its last frame compared with the same chain rendered through the C ABI in this process;
   * `cpu_baseline`: kind "reference" — the reference's own TestRenderStereoPanorama program (oracle/_ref) rendering the
     SAME 8K frame once as a process on the host cores (N=1 only), its equirect compared with the GPU's; where oracle/_ref
@@ -169,6 +169,17 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420)
         if m:
             rec["ms_per_frame_stream"] = 1e3 * float(m.group(3))
             rec["frames_per_s_stream"] = 1.0 / max(float(m.group(3)), 1e-9)
+        hm = re.search(r"host thread per frame:\s+decode ([0-9.]+)\s+upload\+enqueue ([0-9.]+)\s+wait\+fetch ([0-9.]+)\s+wait for the encoder ([0-9.]+)", r.stderr)
+        if hm:  # where the program's host thread spends a frame (its --v 1 breakdown, averages over all frames)
+            rec["host_thread_ms_per_frame"] = {"png_decode": 1e3 * float(hm.group(1)), "upload_and_enqueue": 1e3 * float(hm.group(2)),
+                                               "wait_for_gpu_and_fetch": 1e3 * float(hm.group(3)),
+                                               "wait_for_png_encoder": 1e3 * float(hm.group(4))}
+        if n >= 6:  # steady state: from the moment frame 2's file is complete to the last file's (the first frames pay
+            # for the spherical maps, buffer growth and kernel loading)
+            t = [os.stat(o).st_mtime_ns * 1e-9 for o in outs]
+            rec["ms_per_frame_steady"] = 1e3 * (t[-1] - t[2]) / (n - 3)
+            rec["frames_per_s_steady"] = (n - 3) / max(t[-1] - t[2], 1e-9)
+            rec["steady_note"] = "frames 3..%d: time between the completion of eqr_000002.png and of the last file" % (n - 1)
         return rec, last
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -828,7 +839,7 @@ def main():
 
             # ---- the same stream END TO END through the drop-in host program: PNG files in, PNG files out ----
             try:
-                n_e2e = min(8, n_distinct)
+                n_e2e = min(14, n_distinct)
                 prog = os.path.join(ROOT, "tools", "emu", "TestRenderStereoPanorama") if dry else \
                     os.path.join(ROOT, "host", "TestRenderStereoPanorama")
                 res = host_program_stream([stream_frame(k) for k in range(n_e2e)], rig_path, flags, prog, device=local_rank)

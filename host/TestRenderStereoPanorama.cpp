@@ -471,18 +471,25 @@ int main(int argc, char** argv) {
   std::thread encoder;  // PNG encode + write of frame k-1 while frame k renders
   std::string pendingPath;
   double renderEnd = renderStart, stateEnd = renderStart;
+  double tDecode = 0, tUpload = 0, tFetch = 0, tJoin = 0;  // where the host thread of a stream spends its time (--v 1)
   for (int k = 0; k < numFrames; ++k) {
     const bool last = k + 1 == numFrames;
     std::string nextName;
     if (!last) {  // feed frame k+1 behind frame k: the GPU never waits for the host
       nextName = next_frame_name(frame);
+      const double t0 = now_sec();
       FrameInputs nin = load_frame(J, nextName);
+      const double t1 = now_sec();
       upload_frame(J, nin);     // upload stream: overlaps frame k
       render_frame(J, true);    // temporal state stays on the device
+      tDecode += t1 - t0;
+      tUpload += now_sec() - t1;
     }
+    const double tf = now_sec();
     if (last) ck(s360_frame_download_equirect(J.ctx[0], equirect.data()), J.ctx[0]);
     else ck(s360_frame_download_equirect_of(J.ctx[0], 1, equirect.data()), J.ctx[0]);  // frame k, while k+1 renders
     renderEnd = now_sec();
+    tFetch += renderEnd - tf;
     // the reference writes the state of every frame; a stream only needs it to resume after its last frame
     if (F.b("write_state") && last) write_state(J, frame);
     stateEnd = now_sec();
@@ -493,7 +500,9 @@ int main(int argc, char** argv) {
       ck(s360_frame_cubemap(J.ctx[0], F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cubeImg.data()), J.ctx[0]);
       save_png(F.s("output_cubemap_path"), cubeImg.data(), whc[0], whc[1], 3);
     }
+    const double tj = now_sec();
     if (encoder.joinable()) encoder.join();
+    tJoin += now_sec() - tj;
     pending.swap(equirect);
     equirect.resize(pending.size());
     pendingPath = numFrames > 1 ? frame_path(F.s("output_equirect_path"), frame) : F.s("output_equirect_path");
@@ -513,6 +522,8 @@ int main(int argc, char** argv) {
     } else {
       std::fprintf(stderr, "stream of %d frames:      %.3f  (%.3f per frame: decode, upload, render, download, encode overlapped)\n",
                    numFrames, endTime - renderStart, (endTime - renderStart) / numFrames);
+      std::fprintf(stderr, "host thread per frame:   decode %.3f  upload+enqueue %.3f  wait+fetch %.3f  wait for the encoder %.3f\n",
+                   tDecode / numFrames, tUpload / numFrames, tFetch / numFrames, tJoin / numFrames);
     }
     std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
   }
