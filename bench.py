@@ -263,6 +263,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="timed region + check + roofline only (profiling runs)")
+    ap.add_argument("--e2e-only", type=int, default=0, metavar="N",
+                    help="only the end_to_end_files leg: N frames of the synthetic stream through the host program, PNG files "
+                         "in and out (a short GPU call while tuning the host side; prints that leg's record, not a bench line)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts in flight per GPU (one HIP stream + one submitting host thread each)")
     ap.add_argument("--slots", type=int, default=12,
@@ -336,6 +339,23 @@ def main():
         n_distinct = min(n_video, 48)
     wtex = synth.World(world_h, seed=360, device=dev)  # the same stream on every rank (the sharded frame needs identical inputs)
     rr = synth.RigRenderer(rig_path, wtex, cam_size)
+    if args.e2e_only > 0:
+        fr = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(args.e2e_only)]
+        del rr, wtex
+        torch.cuda.empty_cache()
+        prog = os.path.join(ROOT, "tools", "emu", "TestRenderStereoPanorama") if dry else os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+        res = host_program_stream(fr, rig_path, flags, prog, device=local_rank)
+        rec = res[0] if isinstance(res, tuple) else res
+        if isinstance(res, tuple):  # the same chain through the C ABI in this process
+            c1 = R.Context(rig, R.make_params(**flags), device=local_rank)
+            c1.set_frame_pipelining(True)
+            for k, f in enumerate(fr):
+                c1.upload_frame(*f)
+                c1.render(k > 0)
+            rec["last_frame_equals_in_process_stream"] = bool(np.array_equal(c1.download_equirect(), res[1]))
+            c1.close()
+        print(json.dumps({"end_to_end_files": rec}))
+        return
     frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_distinct))]
 
     def stream_frame(k):  # frame k of the stream: 0,1,..,n-1,n-2,..,1,0,1,.. over the distinct frames held
