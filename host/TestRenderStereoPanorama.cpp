@@ -469,9 +469,15 @@ int main(int argc, char** argv) {
   const double renderStart = now_sec();
   render_frame(J, prev != "NONE");
 
-  std::vector<uint8_t> equirect((size_t)g.out_width * g.out_height * 3), pending;
-  std::thread encoder;  // PNG encode + write of frame k-1 while frame k renders
-  std::string pendingPath;
+  // Up to two finished frames are PNG-encoded and written while the next one renders (one encoder per frame, parallel
+  // deflate inside it): an 8192 x 8192 file takes longer to encode and write than the frame takes to render.
+  const size_t outBytes = (size_t)g.out_width * g.out_height * 3;
+  constexpr int kEncoders = 2;
+  std::vector<uint8_t> outBuf[kEncoders + 1];
+  std::thread encoder[kEncoders + 1];  // encoder[i] owns outBuf[i] while it runs
+  for (auto& b : outBuf) b.resize(numFrames > 1 ? outBytes : 0);
+  outBuf[0].resize(outBytes);
+  int cur = 0;  // the buffer the next download goes to
   double renderEnd = renderStart, stateEnd = renderStart;
   double tDecode = 0, tUpload = 0, tFetch = 0, tJoin = 0;  // where the host thread of a stream spends its time (--v 1)
   // A stream decodes ahead: the PNGs of up to three coming frames are read and decoded by threads of their own (17 per
@@ -503,8 +509,8 @@ int main(int argc, char** argv) {
       tUpload += now_sec() - t1;
     }
     const double tf = now_sec();
-    if (last) ck(s360_frame_download_equirect(J.ctx[0], equirect.data()), J.ctx[0]);
-    else ck(s360_frame_download_equirect_of(J.ctx[0], 1, equirect.data()), J.ctx[0]);  // frame k, while k+1 renders
+    if (last) ck(s360_frame_download_equirect(J.ctx[0], outBuf[cur].data()), J.ctx[0]);
+    else ck(s360_frame_download_equirect_of(J.ctx[0], 1, outBuf[cur].data()), J.ctx[0]);  // frame k, while k+1 renders
     renderEnd = now_sec();
     tFetch += renderEnd - tf;
     // the reference writes the state of every frame; a stream only needs it to resume after its last frame
@@ -517,14 +523,16 @@ int main(int argc, char** argv) {
       ck(s360_frame_cubemap(J.ctx[0], F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cubeImg.data()), J.ctx[0]);
       save_png(F.s("output_cubemap_path"), cubeImg.data(), whc[0], whc[1], 3);
     }
+    const std::string outPath = numFrames > 1 ? frame_path(F.s("output_equirect_path"), frame) : F.s("output_equirect_path");
+    const uint8_t* px = outBuf[cur].data();
+    encoder[cur] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });  // TRSP:961
+    cur = numFrames > 1 ? (cur + 1) % (kEncoders + 1) : 0;
     const double tj = now_sec();
-    if (encoder.joinable()) encoder.join();
+    if (encoder[cur].joinable()) encoder[cur].join();  // the oldest encoder: its buffer takes the next frame
+    if (last)
+      for (auto& e : encoder)
+        if (e.joinable()) e.join();
     tJoin += now_sec() - tj;
-    pending.swap(equirect);
-    equirect.resize(pending.size());
-    pendingPath = numFrames > 1 ? frame_path(F.s("output_equirect_path"), frame) : F.s("output_equirect_path");
-    encoder = std::thread([&pending, pendingPath, &g] { save_png(pendingPath, pending.data(), g.out_width, g.out_height, 3); });  // TRSP:961
-    if (last) encoder.join();
     frame = nextName;
   }
   const double endTime = now_sec();
