@@ -169,11 +169,12 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420)
         if m:
             rec["ms_per_frame_stream"] = 1e3 * float(m.group(3))
             rec["frames_per_s_stream"] = 1.0 / max(float(m.group(3)), 1e-9)
-        hm = re.search(r"host thread per frame:\s+decode ([0-9.]+)\s+upload\+enqueue ([0-9.]+)\s+wait\+fetch ([0-9.]+)\s+wait for the encoder ([0-9.]+)", r.stderr)
+        hm = re.search(r"host thread per frame:\s+decode ([0-9.]+)\s+upload\+enqueue ([0-9.]+)\s+wait\+fetch ([0-9.]+)\s+wait for the encoder ([0-9.]+)\s+other (-?[0-9.]+)\s+of ([0-9.]+)", r.stderr)
         if hm:  # where the program's host thread spends a frame (its --v 1 breakdown, averages over all frames)
             rec["host_thread_ms_per_frame"] = {"png_decode": 1e3 * float(hm.group(1)), "upload_and_enqueue": 1e3 * float(hm.group(2)),
                                                "wait_for_gpu_and_fetch": 1e3 * float(hm.group(3)),
-                                               "wait_for_png_encoder": 1e3 * float(hm.group(4))}
+                                               "wait_for_png_encoder": 1e3 * float(hm.group(4)), "other": 1e3 * float(hm.group(5)),
+                                               "total": 1e3 * float(hm.group(6)), "note": "frames 3.. of the stream"}
         if n >= 6:  # steady state: from the moment frame 2's file is complete to the last file's (the first frames pay
             # for the spherical maps, buffer growth and kernel loading)
             t = [os.stat(o).st_mtime_ns * 1e-9 for o in outs]

@@ -480,6 +480,8 @@ int main(int argc, char** argv) {
   int cur = 0;  // the buffer the next download goes to
   double renderEnd = renderStart, stateEnd = renderStart;
   double tDecode = 0, tUpload = 0, tFetch = 0, tJoin = 0;  // where the host thread of a stream spends its time (--v 1)
+  double tSteadyStart = 0;                                  // ... from its fourth frame on (the first ones build maps and buffers)
+  int steadyFrames = 0;
   // A stream decodes ahead: the PNGs of up to three coming frames are read and decoded by threads of their own (17 per
   // frame) while this thread feeds and drains the GPU — decoding one 8K frame's inputs takes longer than rendering it.
   std::deque<std::future<FrameInputs>> decoding;
@@ -495,6 +497,8 @@ int main(int argc, char** argv) {
   decode_ahead();
   for (int k = 0; k < numFrames; ++k) {
     const bool last = k + 1 == numFrames;
+    if (k == 3 && numFrames > 4) { tDecode = tUpload = tFetch = tJoin = 0; tSteadyStart = now_sec(); }
+    if (k >= 3) ++steadyFrames;
     std::string nextName;
     if (!last) {  // feed frame k+1 behind frame k: the GPU never waits for the host
       nextName = next_frame_name(frame);
@@ -547,8 +551,11 @@ int main(int argc, char** argv) {
     } else {
       std::fprintf(stderr, "stream of %d frames:      %.3f  (%.3f per frame: decode, upload, render, download, encode overlapped)\n",
                    numFrames, endTime - renderStart, (endTime - renderStart) / numFrames);
-      std::fprintf(stderr, "host thread per frame:   decode %.3f  upload+enqueue %.3f  wait+fetch %.3f  wait for the encoder %.3f  (decode = waiting for the decode-ahead threads)\n",
-                   tDecode / numFrames, tUpload / numFrames, tFetch / numFrames, tJoin / numFrames);
+      const int nf = tSteadyStart > 0 ? steadyFrames : numFrames;
+      const double per = tSteadyStart > 0 ? (endTime - tSteadyStart) / nf : (endTime - renderStart) / nf;
+      std::fprintf(stderr, "host thread per frame:   decode %.3f  upload+enqueue %.3f  wait+fetch %.3f  wait for the encoder %.3f  other %.3f  of %.3f  (frames %d..%d; decode = waiting for the decode-ahead threads)\n",
+                   tDecode / nf, tUpload / nf, tFetch / nf, tJoin / nf, per - (tDecode + tUpload + tFetch + tJoin) / nf, per,
+                   numFrames - nf, numFrames - 1);
     }
     std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
   }
