@@ -9,6 +9,7 @@
 // Opt-in additions: --num_gpus G (one frame sharded over G GPUs, native RCCL strip gather) and --num_frames N (a
 // stream of N consecutive frames in one process: device-resident temporal state, overlapped I/O).
 #include <dirent.h>
+#include <malloc.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -19,6 +20,7 @@
 #include <deque>
 #include <future>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -147,6 +149,13 @@ pngio::Image load_png(const std::string& path, bool keep_alpha) {
     die(e.what());
   }
 }
+void load_png_into(const std::string& path, bool keep_alpha, pngio::Image& im) {
+  try {
+    jpegio::read_any_into(path, keep_alpha, im);
+  } catch (const std::exception& e) {
+    die(e.what());
+  }
+}
 void save_png(const std::string& path, const uint8_t* px, int w, int h, int c) {
   try {
     pngio::write(path, px, w, h, c);
@@ -198,8 +207,9 @@ void assign_pole_units(Job& J) {
   J.need[0] = 3;  // the root composites both eyes
 }
 
-FrameInputs load_frame(const Job& J, const std::string& frame) {
-  FrameInputs in;
+// `recycled`: the inputs of an earlier frame whose pixel buffers are reused (stream mode)
+FrameInputs load_frame(const Job& J, const std::string& frame, FrameInputs recycled = FrameInputs()) {
+  FrameInputs in = std::move(recycled);
   in.frame = frame;
   in.side.resize(J.P);
   const std::string imgs = J.F.s("imgs_dir");
@@ -207,11 +217,11 @@ FrameInputs load_frame(const Job& J, const std::string& frame) {
   for (int k = 0; k < J.P; ++k)
     th.emplace_back([&, k] {
       const std::string dir = imgs + "/" + J.cams[J.sideIdx[k]].id;
-      in.side[k] = load_png(dir + "/" + frame + image_extension(dir), false);
+      load_png_into(dir + "/" + frame + image_extension(dir), false, in.side[k]);
     });
-  if (J.prm.enable_top) th.emplace_back([&] { in.top = load_png(imgs + "/" + J.cams[J.ti].id + "/" + frame + ".png", false); });  // TRSP:652
+  if (J.prm.enable_top) th.emplace_back([&] { load_png_into(imgs + "/" + J.cams[J.ti].id + "/" + frame + ".png", false, in.top); });  // TRSP:652
   if (J.prm.enable_bottom) {
-    th.emplace_back([&] { in.bottom = load_png(imgs + "/" + J.cams[J.bi].id + "/" + frame + ".png", false); });  // TRSP:602
+    th.emplace_back([&] { load_png_into(imgs + "/" + J.cams[J.bi].id + "/" + frame + ".png", false, in.bottom); });  // TRSP:602
     if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:48-66
       const std::string masks = J.F.s("bottom_pole_masks_dir");
       th.emplace_back([&] { in.bottom2 = load_png(imgs + "/" + J.cams[J.b2].id + "/" + frame + ".png", false); });
@@ -395,6 +405,10 @@ std::string frame_path(const std::string& pattern, const std::string& frame) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  // glibc: keep freed blocks of up to 32 MB (decoded camera images, PNG scanline bands) in the heap instead of handing
+  // every one back to the kernel — a stream's decoder and encoder threads would spend their time in page faults
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
   Job J;
   Flags& F = J.F;
   F.parse(argc, argv);
@@ -487,10 +501,13 @@ int main(int argc, char** argv) {
   std::deque<std::future<FrameInputs>> decoding;
   std::string decodeCursor = frame;
   int decodesStarted = 0;
+  std::vector<FrameInputs> spare;  // uploaded frames: their pixel buffers go to the next decodes
   auto decode_ahead = [&] {
     while (decodesStarted < numFrames - 1 && decoding.size() < 3) {
       decodeCursor = next_frame_name(decodeCursor);
-      decoding.push_back(std::async(std::launch::async, [&J, name = decodeCursor] { return load_frame(J, name); }));
+      auto recycled = std::make_shared<FrameInputs>();
+      if (!spare.empty()) { *recycled = std::move(spare.back()); spare.pop_back(); }
+      decoding.push_back(std::async(std::launch::async, [&J, name = decodeCursor, recycled] { return load_frame(J, name, std::move(*recycled)); }));
       ++decodesStarted;
     }
   };
@@ -509,6 +526,7 @@ int main(int argc, char** argv) {
       const double t1 = now_sec();
       upload_frame(J, nin);     // upload stream: overlaps frame k
       render_frame(J, true);    // temporal state stays on the device
+      spare.push_back(std::move(nin));  // (the uploads have left these buffers: s360_frame_upload_* copy before they return)
       tDecode += t1 - t0;
       tUpload += now_sec() - t1;
     }

@@ -469,4 +469,14 @@ inline pngio::Image read_any(const std::string& path, bool keep_alpha) {
   return pngio::read(path, keep_alpha);
 }
 
+inline void read_any_into(const std::string& path, bool keep_alpha, pngio::Image& im) {  // ... into a recycled image
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("failed to load image: " + path);
+  uint8_t sig[2] = {0, 0};
+  const size_t got = std::fread(sig, 1, 2, f);
+  std::fclose(f);
+  if (got == 2 && sig[0] == 0xFF && sig[1] == 0xD8) im = read(path);
+  else pngio::read_into(path, keep_alpha, im);
+}
+
 }  // namespace jpegio

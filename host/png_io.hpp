@@ -72,7 +72,9 @@ inline void unfilter_paeth_px(uint8_t* cur, const uint8_t* prev, size_t stride) 
 // Every PNG the format defines is accepted, converted the way cv::imread's 8-bit decode does (grfmt_png.cpp):
 // bit depths 1/2/4 are expanded (grey scaled to 0..255, palette looked up), 16-bit samples keep their high byte
 // (png_set_strip_16), grey becomes B=G=R, Adam7-interlaced files are de-interlaced.
-inline Image read(const std::string& path, bool keep_alpha) {
+// `im` is overwritten; its pixel buffer is reused when it is large enough (a stream hands the previous frames' images
+// back to its decoders: 17 x 12.6 MB mapped, page-faulted and unmapped per frame cost more than the decoding).
+inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) throw std::runtime_error("failed to load image: " + path);
   std::vector<uint8_t> file;
@@ -123,7 +125,6 @@ inline Image read(const std::string& path, bool keep_alpha) {
     if (pw > 0 && ph > 0) total += (row_bytes(pw) + 1) * ph;
   }
   const bool has_alpha = ctype == 4 || ctype == 6 || (ctype == 3 && !trns.empty());
-  Image im;
   im.w = w; im.h = h; im.c = (keep_alpha && has_alpha) ? 4 : 3;
   im.px.resize((size_t)w * h * im.c);
   if (idat.empty()) throw std::runtime_error("corrupt PNG data: " + path);
@@ -227,6 +228,10 @@ inline Image read(const std::string& path, bool keep_alpha) {
     const int rc = inflate(&zs, Z_NO_FLUSH);
     if (rc != Z_STREAM_END || zs.avail_out != 1) throw std::runtime_error("corrupt PNG data: " + path);
   }
+}
+inline Image read(const std::string& path, bool keep_alpha) {
+  Image im;
+  read_into(path, keep_alpha, im);
   return im;
 }
 

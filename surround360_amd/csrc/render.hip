@@ -9,7 +9,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 
 #include "devmath.hpp"
 
@@ -187,21 +186,6 @@ static void ensure_upload_stream(s360_ctx* c) {
     S360_HIP(hipEventCreateWithFlags(&c->pinEv[i], hipEventDisableTiming));
   }
 }
-// the host-side copy into a pinned chunk: a camera image is 12.6 MB and a frame 17 of them, one thread moves that at
-// 3-4 GB/s next to the decoders of a stream — four threads per chunk of a megabyte or more
-static void staging_copy(void* dst, const void* src, size_t len) {
-  constexpr size_t kPiece = (size_t)1 << 20;
-  if (len < 4 * kPiece) { std::memcpy(dst, src, len); return; }
-  const size_t part = (len / 4 + 4095) & ~(size_t)4095;
-  std::thread th[3];
-  for (int t = 0; t < 3; ++t) {
-    const size_t o = (size_t)(t + 1) * part;
-    if (o < len) th[t] = std::thread([=] { std::memcpy((char*)dst + o, (const char*)src + o, std::min(part, len - o)); });
-  }
-  std::memcpy(dst, src, std::min(part, len));
-  for (auto& t : th)
-    if (t.joinable()) t.join();
-}
 // host -> device through the pinned ring on stUp; `src` may be reused as soon as this returns
 static void upload_bytes(s360_ctx* c, void* dst, const void* src, size_t bytes) {
   const char* s = static_cast<const char*>(src);
@@ -211,7 +195,7 @@ static void upload_bytes(s360_ctx* c, void* dst, const void* src, size_t bytes) 
     const int i = c->pinNext;
     c->pinNext = (i + 1) % s360_ctx::kPinChunks;
     if (c->pinUsed[i]) S360_HIP(hipEventSynchronize(c->pinEv[i]));  // the chunk's previous copy has left the host
-    staging_copy(c->pin[i], s + off, len);
+    std::memcpy(c->pin[i], s + off, len);
     S360_HIP(hipMemcpyAsync(d + off, c->pin[i], len, hipMemcpyHostToDevice, c->stUp));
     S360_HIP(hipEventRecord(c->pinEv[i], c->stUp));
     c->pinUsed[i] = true;
