@@ -113,6 +113,82 @@ def test_png_reader_bit_depths_and_interlace(tmp_path):
     assert subprocess.run([exe, str(bad), "0", str(tmp_path / "x.png")], capture_output=True).returncode != 0
 
 
+def test_png_reader_every_filter_type_across_bands(tmp_path):
+    """Scanlines filtered with all five PNG filter types in random order (PIL picks filters by heuristic, the hand-built
+    files above use none): pixel sizes 1, 3, 4, 6 and 8 bytes — 3 and 4 take the reader's SSE2 Paeth path — in images
+    taller than one of the reader's 256 KB inflate bands, so that a band's first row is predicted from the previous
+    band's last. Also: scanline data beyond the image, and a stream that ends early, are corrupt files."""
+    import struct
+    import zlib
+    src = tmp_path / "rt.cpp"
+    src.write_text(SNIPPET)
+    exe = str(tmp_path / "rt")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe, str(src), "-lz", "-lpthread"])
+    rng = np.random.default_rng(11)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    def filtered(rows, bpp):  # rows: list of bytes; returns the filtered scanlines incl. their filter-type bytes
+        out, prev = [], np.zeros(len(rows[0]), np.int32)
+        for r in rows:
+            cur = np.frombuffer(r, np.uint8).astype(np.int32)
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+            c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+            ft = int(rng.integers(0, 5))
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = a
+            elif ft == 2:
+                pred = prev
+            elif ft == 3:
+                pred = (a + prev) >> 1
+            else:
+                pp = a + prev - c
+                pa, pb, pc = np.abs(pp - a), np.abs(pp - prev), np.abs(pp - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            out.append(bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+            prev = cur
+        return out
+
+    def png(w, h, depth, ctype, lines, tail=b"", cut=0):
+        raw = b"".join(lines) + tail
+        z = zlib.compress(raw[:len(raw) - cut] if cut else raw, 1)
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b""))
+
+    for name, w, h, depth, ctype, ch in (("rgb", 601, 300, 8, 2, 3), ("rgba", 403, 330, 8, 6, 4), ("grey", 1111, 260, 8, 0, 1),
+                                         ("rgb16", 207, 240, 16, 2, 3), ("rgba16", 101, 350, 16, 6, 4), ("one_px_wide", 1, 700, 8, 2, 3)):
+        a = rng.integers(0, 1 << depth, (h, w, ch), dtype=np.uint16)
+        # smooth rows so that Paeth / Average see every branch, noise columns so that nothing is constant
+        a[:, :, 0] = (a[:, :, 0] // 7 + np.arange(w)[None, :] * 3) % (1 << depth)
+        rows = [(a[y].astype(">u2") if depth == 16 else a[y].astype(np.uint8)).tobytes() for y in range(h)]
+        bpp = ch * depth // 8
+        p = tmp_path / (name + ".png")
+        p.write_bytes(png(w, h, depth, ctype, filtered(rows, bpp)))
+        want8 = (a >> 8 if depth == 16 else a).astype(np.uint8)
+        pil = np.asarray(Image.open(p))
+        if depth == 8:  # the hand-filtered file is a valid PNG: libpng reads back the pixels it was made from
+            assert np.array_equal(pil.reshape(h, w, ch), want8), name
+        for keep in ("0", "1"):
+            out = str(p) + ".out.png"
+            dims = [int(v) for v in subprocess.check_output([exe, str(p), keep, out], text=True).split()]
+            wc = 4 if (keep == "1" and ch == 4) else 3
+            assert dims == [w, h, wc], name
+            got = np.asarray(Image.open(out))
+            want = np.repeat(want8, 3, 2) if ch == 1 else want8[..., :wc]
+            assert np.array_equal(got, want), (name, keep)
+    # more scanline data than the header's height, and less
+    a = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    lines = filtered([a[y].tobytes() for y in range(40)], 3)
+    for label, kw in (("extra", dict(tail=b"\0" * 151)), ("short", dict(cut=200))):
+        p = tmp_path / (label + ".png")
+        p.write_bytes(png(50, 40, 8, 2, lines, **kw))
+        r = subprocess.run([exe, str(p), "0", str(tmp_path / "x.png")], capture_output=True, text=True)
+        assert r.returncode != 0, label
+
+
 BANDS_SNIPPET = r'''
 #include "png_io.hpp"
 int main(int argc, char** argv) {  // argv: in.png out.png threads
