@@ -18,8 +18,9 @@ Then, one context alone on the GPU (nothing else in flight, so kernel durations 
     (48 B per pixel-level-sweep) / its average ISOLATED launch duration from HIP events on the library's
     stream / 8 TB/s; `aggregate_frac` is the same bytes over the wall time of the timed region (launches of up to
     `inflight` frames overlapping);
-  * `single_frame`: configs[2] as a latency (on N GPUs: configs[3] — 14 pairs sharded over the ranks, one RCCL strip
-    gather, poles + composite on rank 0), per-kernel-family milliseconds, the warp/blend and flow-stencil kernels
+  * `single_frame`: configs[2] as a latency (on N GPUs: configs[3] — pairs and pole units sharded over the ranks, the two
+    native RCCL exchanges, composite on rank 0 — run by a child process per rank on a rendezvous of its own, so that a
+    fault in that path cannot cost this line), per-kernel-family milliseconds, the warp/blend and flow-stencil kernels
     against the HBM roofline, and the same frame with the reference presets' sharpening 0.25;
   * `config2_flow_pair`: BASELINE configs[1], one 2048x2048 pair, both directions, GPU vs the CPU oracle;
   * `video_stream`: configs[4] on one GPU — 190 frames of a rotating world with a moving disc, every frame
@@ -264,6 +265,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="timed region + check + roofline only (profiling runs)")
+    ap.add_argument("--sharded-child", action="store_true",
+                    help="internal (N > 1): the configs[3] leg — one frame sharded over the ranks, the native RCCL exchanges — in "
+                         "a process of its own per rank, so that nothing it does can cost the parent's bench line")
     ap.add_argument("--e2e-only", type=int, default=0, metavar="N",
                     help="only the end_to_end_files leg: N frames of the synthetic stream through the host program, PNG files "
                          "in and out (a short GPU call while tuning the host side; prints that leg's record, not a bench line)")
@@ -356,6 +360,67 @@ def main():
             rec["last_frame_equals_in_process_stream"] = bool(np.array_equal(c1.download_equirect(), res[1]))
             c1.close()
         print(json.dumps({"end_to_end_files": rec}))
+        return
+    if args.sharded_child:
+        if os.environ.get("S360_BENCH_CHILD_ABORT") == str(rank):  # developer check of the isolation: this rank's child dies
+            os.abort()
+        # ---- configs[3]: one frame at a time, the 14 pairs and the 4 pole units sharded over the ranks ----
+        f0 = rr.frame_numpy(yaw_deg=0.0, disc_deg=10.0)  # the same frame on every rank (same seeds)
+        del rr, wtex
+        torch.cuda.empty_cache()
+        c1 = R.Context(rig, R.make_params(**flags), device=local_rank)
+        c1.set_sweep_mode("latency")
+        c1.upload_frame(*f0)
+        single0 = None
+        if rank == 0:  # the unsharded frame, for the comparison
+            c1.render(False)
+            single0 = c1.download_equirect()
+        bounds = parallel.partition_pairs(P, world)
+        p0, p1 = bounds[rank], bounds[rank + 1]
+        # the library's own RCCL communicator: rank 0 creates the id, torch.distributed only carries the 128 bytes
+        ids = [R.Context.comm_get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        c1.comm_init_rank(ids[0], rank, world)
+        owner = parallel.pole_owners(world)  # pole unit u on rank u (2-3 ranks: the two poles on ranks 0 / 1)
+        masks, needs = parallel.unit_masks(owner, world), parallel.strip_needs(owner, world)
+
+        def sharded():
+            c1.render_pairs(p0, p1, False)
+            c1.exchange_strips(bounds, needs)  # grouped ncclSend/ncclRecv on the context stream (comm.cpp)
+            if masks[rank] or rank == 0:
+                c1.pole_units(masks[rank], False)
+            c1.gather_pole_layers(owner, 0)    # second grouped exchange: the warped pole layers to the root
+            if rank == 0:
+                c1.composite(15)
+
+        def csync():
+            c1.synchronize()
+            torch.cuda.synchronize()
+            dist.barrier()
+        sharded()
+        csync()
+        n_single = 3
+        t1 = time.perf_counter()
+        for _ in range(n_single):
+            sharded()
+        csync()
+        dt1 = time.perf_counter() - t1
+        t = torch.tensor([dt1], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt1 = float(t.item())
+        if rank == 0:
+            ok = bool(np.array_equal(c1.download_equirect(), single0))
+            print(json.dumps({"single_frame": {
+                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), one native RCCL exchange (grouped "
+                        "ncclSend/ncclRecv, s360_frame_exchange_strips) handing the strips to the ranks that assemble an eye, the "
+                        "pole units on ranks %s, a second grouped exchange returning their warped layers to rank 0, which "
+                        "composites; run in a process of its own per rank beside the bench's resident contexts" % (world, bounds, owner),
+                "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9), "rccl_ranks": world,
+                "equals_single_gpu_frame": ok}}))
+            sys.stdout.flush()
+        dist.barrier()
+        c1.close()
+        dist.destroy_process_group()
         return
     frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_distinct))]
 
@@ -706,44 +771,25 @@ def main():
                 "warp_blend_roofline": wb, "flow_stencil_roofline": fs,
                 "throughput_kernel_alone_ms": tp_ms}
         else:
-            # the library's own RCCL communicator: rank 0 creates the id, torch.distributed only carries the 128 bytes
-            ids = [R.Context.comm_get_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init_rank(ids[0], rank, world)
-            ctx.set_sweep_mode("latency")
-
-            owner = parallel.pole_owners(world)  # pole unit u on rank u (2-3 ranks: the two poles on ranks 0 / 1)
-            masks, needs = parallel.unit_masks(owner, world), parallel.strip_needs(owner, world)
-
-            def sharded():
-                ctx.render_pairs(p0, p1, False)
-                ctx.exchange_strips(bounds, needs)  # grouped ncclSend/ncclRecv on the context stream (comm.cpp)
-                if masks[rank] or rank == 0:
-                    ctx.pole_units(masks[rank], False)
-                ctx.gather_pole_layers(owner, 0)    # second grouped exchange: the warped pole layers to the root
-                if rank == 0:
-                    ctx.composite(15)
-            sharded()
-            sync()
-            n_single = 3
-            t1 = time.perf_counter()
-            for _ in range(n_single):
-                sharded()
-            sync()
-            dt1 = time.perf_counter() - t1
-            t = torch.tensor([dt1], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt1 = float(t.item())
-            ok = None
+            # configs[3] (one frame sharded over the ranks, the native RCCL exchanges) runs in a CHILD process per rank, on a
+            # rendezvous of its own: that path has never run on more than one real GPU, and a crash or a stuck exchange in
+            # it must not cost the line measured above. Every rank starts its child here, right behind the timed region.
+            import subprocess
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1))
+            # (torchrun's workers rendezvous through the agent's store; the children make a store of their own: rank 0's
+            # child serves it on the new port)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+            for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_ERROR_FILE"):
+                env.pop(k, None)
+            cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--gpus", str(world)]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                rec = json.loads(lines[-1])["single_frame"] if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+            except subprocess.TimeoutExpired:
+                rec = {"error": "the sharded-frame processes did not finish in 240 s"}
             if rank == 0:
-                ok = bool(np.array_equal(ctx.download_equirect(), single0))
-            out["single_frame"] = {
-                "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), one native RCCL exchange (grouped "
-                        "ncclSend/ncclRecv, s360_frame_exchange_strips) handing the strips to the ranks that assemble an eye, the "
-                        "pole units on ranks %s, a second grouped exchange returning their warped layers to rank 0, which "
-                        "composites" % (world, bounds, owner),
-                "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9), "rccl_ranks": world,
-                "equals_single_gpu_frame": ok}
+                out["single_frame"] = rec
 
         if world == 1 and not args.no_extras:
             # ---- the same single frame without the sharpening pass (secondary; the presets all sharpen) ----
