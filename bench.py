@@ -599,9 +599,15 @@ def main():
             single0 = alone
         if not np.array_equal(alone, inflight_out[k]):
             mism.append(k)
-    checked = {"checked": not mism, "checked_frames": F * S, "mismatching_frames": mism,
-               "check": "equirect of every in-flight frame (throughput sweep kernel; %d context(s) x %d slot(s)) byte-compared "
-                        "with one context rendering the same inputs alone (latency sweep kernel)" % (F, S)}
+    n_mism_all = len(mism)
+    if dist is not None:  # the line is rank 0's: a mismatch on any rank must show in it
+        t = torch.tensor([float(len(mism))], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_mism_all = int(t.item())
+    checked = {"checked": n_mism_all == 0, "checked_frames": world * F * S, "mismatching_frames": mism,
+               "mismatching_frames_all_ranks": n_mism_all,
+               "check": "equirect of every in-flight frame of every rank (throughput sweep kernel; %d context(s) x %d slot(s) per "
+                        "GPU) byte-compared with one context rendering the same inputs alone (latency sweep kernel)" % (F, S)}
     del inflight_out
     ctx.upload_frame(*frames[0])
 

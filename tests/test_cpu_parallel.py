@@ -91,4 +91,5 @@ def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
     assert "dry_run" in d and "errors" not in d
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["warmup"] == 0
     assert d["checked"] is True and d["config"]["rccl_ranks"] == 2
+    assert d["checked_frames"] == 2 and d["mismatching_frames_all_ranks"] == 0  # 1 frame in flight per rank, both ranks counted
     assert d["single_frame"]["rccl_ranks"] == 2 and d["single_frame"]["equals_single_gpu_frame"] is True
