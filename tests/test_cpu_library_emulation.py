@@ -186,8 +186,7 @@ def test_emulated_program_reads_jpeg_camera_images(tmp_path, emu_programs):
 def test_bench_script_dry_run(emu_programs):
     """bench.py from its first line to its JSON line on the emulated library at toy sizes (S360_TEST_EMULATED_LIB=1: NOT a
     measurement): timed region with 2 contexts x 2 frame slots, the check of every timed frame, the isolated / single-frame
-    / sharpening / flow-pair / video-stream legs, the reference program as the CPU baseline, the ISP leg and the variants
-    leg with all ten switch-selected builds."""
+    / sharpening / flow-pair / video-stream / end-to-end-files legs, the reference program as the CPU baseline, the ISP leg."""
     import sys
     e = dict(os.environ, S360_TEST_EMULATED_LIB="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--slots", "2", "--inflight", "2",
@@ -197,4 +196,6 @@ def test_bench_script_dry_run(emu_programs):
     assert "dry_run" in d and "errors" not in d
     assert d["checked"] is True and d["cpu_baseline"]["checked_against_gpu"] is True and d["config2_flow_pair"]["checked"] is True
     assert d["isp"]["checked"] is True
-    assert d["variants"]["latency"]["identical_output"] is True and d["variants"]["throughput"]["identical_output"] is True
+    assert d["video_stream"]["frames"] >= 12 and "spill_ms_per_frame" in d["video_stream"]
+    e2e = d["end_to_end_files"]  # the host program from PNG files to PNG files, its last frame against the in-process chain
+    assert "error" not in e2e and e2e["last_frame_equals_in_process_stream"] is True and "host_thread_ms_per_frame" in e2e
