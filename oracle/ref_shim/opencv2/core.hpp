@@ -179,6 +179,7 @@ class Mat {
     store_.reset(new std::vector<uchar>((size_t)r * c * elemSize(type) + 64));  // uninitialised in OpenCV; zero here
     data = store_->data();
   }
+  void create(Size s, int type) { create(s.height, s.width, type); }  // cv::Mat::create(Size, int)
   bool isContinuous() const { return step == (size_t)cols * elemSize(type_); }
   static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
   static Mat zeros(Size s, int type) { return Mat(s.height, s.width, type); }
