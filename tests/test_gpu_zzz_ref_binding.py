@@ -29,7 +29,7 @@ def test_reference_program_with_the_integration_binding_on_the_gpu(tmp_path, nam
         pytest.skip("oracle/_ref/TestRenderStereoPanorama_hip is built where /root/reference exists (make -C oracle ref_binding)")
     rig = rigutil.scaled_rig_json(os.path.join(refprog.ROOT, "tests", "golden", "rig_17cam.json"),
                                   str(tmp_path / "rig_small.json"), refprog.CAM / 2048.0)
-    out = refprog.run_case(EXE, str(tmp_path), rig, name, timeout=300, more_args=flags)
+    out = refprog.run_case(EXE, str(tmp_path), rig, name, timeout=120, more_args=flags)
     got = refprog.digests(out, name)
     golden = json.load(open(refprog.GOLDEN))[name]
     differing = sorted(k for k in golden if got.get(k) != golden[k])
