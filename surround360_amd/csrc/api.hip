@@ -386,7 +386,7 @@ int s360_bicubic_remap_to_spherical(s360_ctx* c, uint8_t* dst, int dw, int dh, i
   return guard(c, [&] {
     need(c && dst && src && cam, "null argument");
     need((dc == 3 || dc == 4) && (sc == 3 || sc == 4), "channels must be 3 or 4");
-    need(!(sc == 4 && dc == 3), "4-channel source into 3-channel destination is not a reference use");
+    need(!(sc == 4 && dc == 3), "4-channel source: the reference's remap() re-creates the destination with the source's type (ImageWarper.cpp:173) - pass a 4-channel destination");
     FrameState& F = frame_state(c);
     const size_t sn = (size_t)sw * sh, dn = (size_t)dw * dh;
     c->op_a.ensure(dn * sizeof(float2));

@@ -47,25 +47,28 @@ def test_emulated_program_writes_what_the_reference_program_writes(tmp_path, emu
     assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
 
 
-@pytest.mark.parametrize("name,flags", [
-    ("two_frames", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip"]),
-    ("sharpen_cubemap_search", ["--side_flow_alg", "pixflow_search_20_hip", "--polar_flow_alg", "pixflow_low_hip"]),
-    ("pole_removal", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip", "--poleremoval_flow_alg", "pixflow_low_hip"])])
-def test_reference_program_with_the_integration_binding(tmp_path, emu_programs, name, flags):
+@pytest.mark.parametrize("exe_name,name,flags", [
+    ("TestRenderStereoPanorama_hip_emu", "two_frames", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip"]),
+    ("TestRenderStereoPanorama_ops_hip_emu", "sharpen_cubemap_search", ["--side_flow_alg", "pixflow_search_20_hip", "--polar_flow_alg", "pixflow_low_hip"]),
+    ("TestRenderStereoPanorama_ops_hip_emu", "pole_removal", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip",
+                                                              "--poleremoval_flow_alg", "pixflow_low_hip"])])
+def test_reference_program_with_the_integration_binding(tmp_path, emu_programs, exe_name, name, flags):
     """INTEGRATION.md section 1, executed. The REFERENCE'S OWN TestRenderStereoPanorama — its sources where they lie under
     /root/reference, compiled over the stand-ins of oracle/ref_shim — with the `PixFlowHip` subclass of its
     OpticalFlowInterface and the two extra names in its flow factory injected from oracle/ref_binding/ (nothing of the
     reference is modified or copied), linked against the library (here: its sources on the CPU emulation). With
     `--side_flow_alg pixflow_low_hip --polar_flow_alg pixflow_low_hip` every flow of the reference's frame — its 14 pair
     threads and 4 pole threads calling one shared context, temporal regularisation through the reference's own state
-    files — is computed by libs360, and the program writes exactly the files the unmodified reference program writes."""
-    if not os.path.isdir("/root/reference/surround360_render/source"):
-        exe = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama_hip_emu")
-        if not os.path.exists(exe):
-            pytest.skip("needs /root/reference to build the reference program from (make -C oracle ref_binding)")
-    else:
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/TestRenderStereoPanorama_hip_emu"])
-        exe = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama_hip_emu")
+    files — is computed by libs360, and the program writes exactly the files the unmodified reference program writes.
+    The `_ops_` program goes further down INTEGRATION.md's table: the reference's bicubicRemapToSpherical,
+    flattenLayersDeghostPreferBase, offsetHorizontalWrap and featherAlphaChannel are replaced as well (its ImageWarper.cpp /
+    CvUtil.cpp compiled with those four renamed, oracle/ref_binding/operators_hip.cpp in their place): projections, blends,
+    shifts, feathers and flows of the reference's frame all run through the C ABI."""
+    exe = os.path.join(ROOT, "oracle", "_ref", exe_name)
+    if os.path.isdir("/root/reference/surround360_render/source"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/" + exe_name])
+    elif not os.path.exists(exe):
+        pytest.skip("needs /root/reference to build the reference program from (make -C oracle ref_binding ref_binding_ops)")
     rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
                                   refprog.CAM / 2048.0)
     out = refprog.run_case(exe, str(tmp_path), rig, name, more_args=flags)

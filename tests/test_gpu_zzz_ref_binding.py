@@ -1,9 +1,10 @@
 """INTEGRATION.md section 1 on the hardware: the REFERENCE'S OWN TestRenderStereoPanorama (oracle/_ref/
-TestRenderStereoPanorama_hip: its sources compiled where they lie under /root/reference over oracle/ref_shim, with the
-PixFlowHip subclass and the two extra factory names of oracle/ref_binding/ injected, linked against surround360_amd/
-libs360.so; built by __graft_entry__.build() where the reference exists, travels to the GPU box prebuilt) run with
---side_flow_alg pixflow_low_hip --polar_flow_alg pixflow_low_hip: the reference's frame with every flow computed on the GPU
-by the reference's own 14 + 4 threads sharing one context, held to the digests of the unmodified reference program.
+TestRenderStereoPanorama_ops_hip: its sources compiled where they lie under /root/reference over oracle/ref_shim, with the
+PixFlowHip subclass, the two extra factory names and the four free functions of oracle/ref_binding/ injected, linked against
+surround360_amd/libs360.so; built by __graft_entry__.build() where the reference exists, travels to the GPU box prebuilt)
+run with --side_flow_alg pixflow_low_hip --polar_flow_alg pixflow_low_hip: the reference's frame with every projection,
+blend, shift, feather and flow computed on the GPU — the flows by the reference's own 14 + 4 threads sharing one context —
+held to the digests of the unmodified reference program.
 tests/test_cpu_library_emulation.py runs the same program against the library's CPU emulation (green).
 NOT YET A GATE: written after round 3's GPU minutes were spent, so its first hardware run is the driver's; until a
 round has seen it pass it is reported as xpass / xfail instead of failing the suite (sorted last for the same reason)."""
@@ -17,7 +18,7 @@ import rigutil
 
 pytestmark = pytest.mark.gpu
 
-EXE = os.path.join(refprog.ROOT, "oracle", "_ref", "TestRenderStereoPanorama_hip")
+EXE = os.path.join(refprog.ROOT, "oracle", "_ref", "TestRenderStereoPanorama_ops_hip")
 
 
 @pytest.mark.xfail(strict=False, reason="first hardware run of the reference program + binding (see the module docstring)")
@@ -26,7 +27,7 @@ EXE = os.path.join(refprog.ROOT, "oracle", "_ref", "TestRenderStereoPanorama_hip
     ("pole_removal", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip", "--poleremoval_flow_alg", "pixflow_low_hip"])])
 def test_reference_program_with_the_integration_binding_on_the_gpu(tmp_path, name, flags, s360lib):
     if not os.path.exists(EXE):
-        pytest.skip("oracle/_ref/TestRenderStereoPanorama_hip is built where /root/reference exists (make -C oracle ref_binding)")
+        pytest.skip("oracle/_ref/TestRenderStereoPanorama_ops_hip is built where /root/reference exists (make -C oracle ref_binding)")
     rig = rigutil.scaled_rig_json(os.path.join(refprog.ROOT, "tests", "golden", "rig_17cam.json"),
                                   str(tmp_path / "rig_small.json"), refprog.CAM / 2048.0)
     out = refprog.run_case(EXE, str(tmp_path), rig, name, timeout=120, more_args=flags)
