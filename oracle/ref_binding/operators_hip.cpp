@@ -1,7 +1,7 @@
 // oracle/ref_binding/operators_hip.cpp — TEST INFRASTRUCTURE. INTEGRATION.md section 1's table, executed: the reference's
 // free functions bicubicRemapToSpherical (SR/render/ImageWarper.cpp:143-174), flattenLayersDeghostPreferBase,
-// offsetHorizontalWrap and featherAlphaChannel (SR/util/CvUtil.cpp:93-115, 140-157, 224-260) with the reference's own
-// signatures, each one a call into include/s360.h. `make -C oracle ref_binding` compiles the reference's ImageWarper.cpp /
+// offsetHorizontalWrap, featherAlphaChannel (SR/util/CvUtil.cpp:93-115, 140-157, 224-260), saveFlowToFile and
+// readFlowFromFile (CvUtil.cpp:159-199) with the reference's own signatures, each one a call into include/s360.h. `make -C oracle ref_binding` compiles the reference's ImageWarper.cpp /
 // CvUtil.cpp with those four functions renamed (-D…=…_reference, per translation unit) and links this file in their
 // place, so that the reference's own TestRenderStereoPanorama projects, blends, shifts and feathers through the library
 // (_ops_hip / _ops_hip_emu binaries) and must still write the unmodified program's files.
@@ -71,6 +71,18 @@ Mat flattenLayersDeghostPreferBase(const Mat& bottomLayer, const Mat& topLayer) 
   ck(s360_flatten_layers_deghost_prefer_base(optical_flow::globalS360Ctx(), bottomLayer.data, topLayer.data, bottomLayer.cols,
                                              bottomLayer.rows, out.data));
   return out;
+}
+// saveFlowToFile / readFlowFromFile (SR/util/CvUtil.cpp:159-199): the reference's .bin container through the library's
+// byte-compatible writer and reader — the program's flow files and its --prev_frame_data_dir state go through them
+void saveFlowToFile(const Mat& flow, const string& filename) {
+  ck(s360_save_flow_to_file(filename.c_str(), (const float*)flow.data, flow.cols, flow.rows));
+}
+Mat readFlowFromFile(const string& filename) {
+  int w = 0, h = 0;
+  ck(s360_read_flow_from_file(filename.c_str(), nullptr, &w, &h, 0));  // size query
+  Mat flow(Size(w, h), CV_32FC2);
+  ck(s360_read_flow_from_file(filename.c_str(), (float*)flow.data, &w, &h, (size_t)w * h * 2));
+  return flow;
 }
 }  // namespace util
 }  // namespace surround360
