@@ -79,6 +79,25 @@ def test_reference_program_with_the_integration_binding(tmp_path, emu_programs, 
     assert not differing, "%d of %d files differ from the unmodified reference program's: %s" % (len(differing), len(golden), differing[:12])
 
 
+@pytest.mark.parametrize("name", list(refprog.RAW_CASES))
+def test_reference_raw2rgb_with_the_integration_binding(tmp_path, emu_programs, name):
+    """INTEGRATION.md section 3, executed: the reference's own Raw2Rgb program with the `CameraIspGpu` subclass of its
+    CameraIsp (oracle/ref_binding/CameraIspGpu.h) force-included and used in place of the base class — its flags, its JSON
+    reader, its PNG input and output — develops the image through s360_isp_* (here: the library's CPU emulation) and
+    writes the pixels the unmodified reference program writes."""
+    import hashlib
+    import isputil
+    exe = os.path.join(ROOT, "oracle", "_ref", "Raw2Rgb_hip_emu")
+    if os.path.isdir("/root/reference/surround360_render/source"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/Raw2Rgb_hip_emu"])
+    elif not os.path.exists(exe):
+        pytest.skip("needs /root/reference to build the reference program from (make -C oracle ref_binding_isp)")
+    _, outp = refprog.run_raw_case(exe, str(tmp_path), isputil.CONFIG_FULL, name)
+    a = refprog.png_pixels_bgr(outp)
+    digest = hashlib.sha256(repr((a.shape, str(a.dtype))).encode() + a.tobytes()).hexdigest()
+    assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
+
+
 def test_emulated_stream_mode_equals_the_reference_programs_chain(tmp_path, emu_programs):
     """--num_frames 3 (one process, device-resident temporal state, frame pipelining) against the equirects the
     reference's program writes when it is run three times, chained with --prev_frame_data_dir."""
