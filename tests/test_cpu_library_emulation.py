@@ -98,6 +98,20 @@ def test_reference_raw2rgb_with_the_integration_binding(tmp_path, emu_programs, 
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
 
 
+@pytest.mark.parametrize("script,seed,cases,ok", [("random_flow.py", 11, 24, "0 differ"), ("random_ops.py", 11, 60, "0 differ"),
+                                                  ("random_isp.py", 11, 40, "0 differ")])
+def test_random_calls_equal_the_oracle(emu_programs, script, seed, cases, ok):
+    """A seeded slice of the randomised differential campaigns of tools/fuzz (DESIGN.md section 2 has the full counts): flows of
+    random sizes / masks / hints / algorithms / previous-frame state through both sweep kernels, the other operator entry
+    points with random shapes and arguments, the ISP with random configurations — emulated library against the oracle."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz", script), os.path.join(ROOT, "tools", "libs360_emu.so"),
+                        str(seed), str(cases)], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("done") and ok in last and "DIFFER" not in r.stdout, r.stdout[-1500:]
+
+
 def test_emulated_stream_mode_equals_the_reference_programs_chain(tmp_path, emu_programs):
     """--num_frames 3 (one process, device-resident temporal state, frame pipelining) against the equirects the
     reference's program writes when it is run three times, chained with --prev_frame_data_dir."""
