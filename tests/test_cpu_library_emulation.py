@@ -48,7 +48,6 @@ def test_emulated_program_writes_what_the_reference_program_writes(tmp_path, emu
 
 
 @pytest.mark.parametrize("exe_name,name,flags", [
-    ("TestRenderStereoPanorama_hip_emu", "two_frames", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip"]),
     ("TestRenderStereoPanorama_ops_hip_emu", "sharpen_cubemap_search", ["--side_flow_alg", "pixflow_search_20_hip", "--polar_flow_alg", "pixflow_low_hip"]),
     ("TestRenderStereoPanorama_ops_hip_emu", "pole_removal", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip",
                                                               "--poleremoval_flow_alg", "pixflow_low_hip"])])
@@ -98,7 +97,7 @@ def test_reference_raw2rgb_with_the_integration_binding(tmp_path, emu_programs, 
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
 
 
-@pytest.mark.parametrize("script,seed,cases,ok", [("random_flow.py", 11, 24, "0 differ"), ("random_ops.py", 11, 60, "0 differ"),
+@pytest.mark.parametrize("script,seed,cases,ok", [("random_flow.py", 11, 12, "0 differ"), ("random_ops.py", 11, 60, "0 differ"),
                                                   ("random_isp.py", 11, 40, "0 differ")])
 def test_random_calls_equal_the_oracle(emu_programs, script, seed, cases, ok):
     """A seeded slice of the randomised differential campaigns of tools/fuzz (DESIGN.md section 2 has the full counts): flows of
