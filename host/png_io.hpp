@@ -289,12 +289,28 @@ inline void write_rows(const std::string& path, FillRow fill_row, int w, int h, 
   auto compress_band = [&](int bi) {
     Band& B = bands[bi];
     const int y0 = bi * rows_per_band, y1 = std::min(h, y0 + rows_per_band);
+    // Scanlines are filtered before they are deflated: Up (each byte minus the one above it) — Sub for the image's first
+    // row — costs one pass and, on camera-like content at deflate level 1, halves both the deflate time and the file
+    // (25 MB of the synthetic world: 12.1 MB in 616 ms unfiltered, 5.6 MB in 271 ms; libpng's writer, which cv::imwrite
+    // uses, picks a filter per row by heuristic). A band's first row needs the row above the band, which fill_row gives.
     std::vector<uint8_t> raw((size_t)(y1 - y0) * stride);
+    const size_t nb = stride - 1, px_bytes = (size_t)c * (depth / 8);
+    std::vector<uint8_t> rowA(nb), rowB(nb);
+    uint8_t *cur = rowA.data(), *prev = rowB.data();
+    if (y0 > 0) fill_row(y0 - 1, prev);
     uint8_t* o = raw.data();
     for (int y = y0; y < y1; ++y) {
-      *o++ = 0;  // filter type None
-      fill_row(y, o);
-      o += stride - 1;
+      fill_row(y, cur);
+      if (y == 0) {
+        *o++ = 1;  // Sub
+        for (size_t i = 0; i < std::min(px_bytes, nb); ++i) o[i] = cur[i];
+        for (size_t i = px_bytes; i < nb; ++i) o[i] = (uint8_t)(cur[i] - cur[i - px_bytes]);
+      } else {
+        *o++ = 2;  // Up
+        for (size_t i = 0; i < nb; ++i) o[i] = (uint8_t)(cur[i] - prev[i]);
+      }
+      o += nb;
+      std::swap(cur, prev);
     }
     B.raw = raw.size();
     B.adler = adler32(1L, raw.data(), (uInt)raw.size());

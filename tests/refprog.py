@@ -218,6 +218,40 @@ def run_raw_case(exe, work, config_json, name):
     return seen, outp
 
 
+def png_unfilter(rows, bpp):
+    """rows: H x (1 + stride) uint8 scanlines with their filter-type bytes, as inflated from a PNG's IDAT; returns the
+    H x stride unfiltered bytes (all five filter types; bpp = bytes per pixel)."""
+    h, stride = rows.shape[0], rows.shape[1] - 1
+    out = np.zeros((h, stride), np.int32)
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        ft, line = int(rows[y, 0]), rows[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:  # Sub, Average, Paeth: serial along the row, one pixel's bytes at a time
+            cur = np.zeros(stride, np.int32)
+            for i in range(0, stride, bpp):
+                a = cur[i - bpp:i] if i else np.zeros(bpp, np.int32)
+                b = prev[i:i + bpp]
+                c = prev[i - bpp:i] if i else np.zeros(bpp, np.int32)
+                if ft == 1:
+                    pred = a
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                elif ft == 4:
+                    pp = a + b - c
+                    pa, pb, pc = np.abs(pp - a), np.abs(pp - b), np.abs(pp - c)
+                    pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+                else:
+                    raise AssertionError("bad PNG filter type %d" % ft)
+                cur[i:i + bpp] = (line[i:i + bpp] + pred) & 255
+        out[y] = cur
+        prev = cur
+    return out.astype(np.uint8)
+
+
 def png_pixels_bgr(path):
     """8- or 16-bit RGB PNG -> H x W x 3 B,G,R array of the file's depth (PIL does not decode 16-bit RGB)."""
     import struct
@@ -236,6 +270,5 @@ def png_pixels_bgr(path):
         return np.asarray(Image.open(path))[:, :, ::-1]
     assert depth == 16 and ctype == 2
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 6)
-    assert not rows[:, 0].any()  # filter type 0 on every row (both writers emit that)
-    px = rows[:, 1:].reshape(h, w, 3, 2).astype(np.uint16)
+    px = png_unfilter(rows, 6).reshape(h, w, 3, 2).astype(np.uint16)
     return ((px[..., 0] << 8) | px[..., 1])[..., ::-1]
