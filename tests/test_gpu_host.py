@@ -7,6 +7,8 @@ import subprocess
 
 import numpy as np
 import pytest
+
+import refprog
 from PIL import Image
 
 import rigutil
@@ -14,6 +16,8 @@ import rigutil
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (developer switch of tests/conftest.py: with S360_TEST_EMULATED_LIB=1 the programs linked against the emulated library)
+HOST_DIR = os.path.join(ROOT, "tools", "emu") if os.environ.get("S360_TEST_EMULATED_LIB") == "1" else os.path.join(ROOT, "host")
 EQR_W, EQR_H, CAM = 1008, 504, 512
 
 
@@ -31,7 +35,7 @@ def _write_frame(imgs_dir, rig_path, frame, side, top, bottom):
 
 def test_two_frames_through_the_binary(tmp_path, rig_json, oracle, s360lib):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+    exe = os.path.join(HOST_DIR, "TestRenderStereoPanorama")
     rig_path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_small.json"), CAM / 2048.0)
     imgs, out = str(tmp_path / "rgb"), str(tmp_path / "out")
     os.makedirs(out)
@@ -89,7 +93,7 @@ def test_stream_mode_equals_chained_processes(tmp_path, rig_json, oracle, s360li
     equirect must equal the oracle's frame-by-frame chain, and the state written after the last frame must let a
     classic one-frame process continue the chain (--prev_frame_data_dir)."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+    exe = os.path.join(HOST_DIR, "TestRenderStereoPanorama")
     rig_path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_small.json"), CAM / 2048.0)
     imgs, out = str(tmp_path / "rgb"), str(tmp_path / "out")
     os.makedirs(out)
@@ -135,7 +139,7 @@ def test_stream_mode_equals_chained_processes(tmp_path, rig_json, oracle, s360li
 
 def test_bad_command_lines(tmp_path):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+    exe = os.path.join(HOST_DIR, "TestRenderStereoPanorama")
     r = subprocess.run([exe, "--rig_json_file", "x.json"], capture_output=True, text=True)
     assert r.returncode != 0 and "missing required command line argument" in r.stderr
     r = subprocess.run([exe, "--no_such_flag", "1"], capture_output=True, text=True)
@@ -146,7 +150,7 @@ def test_pole_removal_through_the_binary(tmp_path, rig_json, oracle, s360lib):
     """--enable_pole_removal --bottom_pole_masks_dir: two frames, the second regularised against the first one's
     flow_bottom_secondary.bin / bottomImage{,2}.png (PoleRemoval.cpp:95-126), output byte-exact vs the oracle."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "TestRenderStereoPanorama")
+    exe = os.path.join(HOST_DIR, "TestRenderStereoPanorama")
     rig_path = rigutil.scaled_rig_json(rig_json, str(tmp_path / "rig_small.json"), CAM / 2048.0)
     imgs_dir, out, masks = str(tmp_path / "rgb"), str(tmp_path / "out"), str(tmp_path / "masks")
     os.makedirs(out)
@@ -193,7 +197,7 @@ def test_optical_flow_harness(tmp_path, oracle, s360lib):
     against the oracle, "RUNTIME (sec)" logged per repetition, flows written in the reference's .bin format."""
     from surround360_amd import synth, render as R
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "TestOpticalFlow")
+    exe = os.path.join(HOST_DIR, "TestOpticalFlow")
     i0, i1 = synth.flow_pair(300, 260, seed=11)
     Image.fromarray(np.ascontiguousarray(i0[:, :, [2, 1, 0, 3]])).save(str(tmp_path / "left.png"))   # BGRA -> RGBA
     Image.fromarray(np.ascontiguousarray(i1[:, :, [2, 1, 0]])).save(str(tmp_path / "right.png"))     # no alpha: 255 added
@@ -216,7 +220,7 @@ def test_raw2rgb_binary(tmp_path, oracle, s360lib):
     import zlib
     import isputil
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    exe = os.path.join(ROOT, "host", "Raw2Rgb")
+    exe = os.path.join(HOST_DIR, "Raw2Rgb")
     w, h = 160, 96
     raw = isputil.bayer_frame(w, h, seed=4)
     cfgj = json.loads(isputil.CONFIG_FULL)
@@ -237,7 +241,8 @@ def test_raw2rgb_binary(tmp_path, oracle, s360lib):
                 idat += data[pos + 8:pos + 8 + n]
             pos += 12 + n
         ww, hh = ihdr[:2]
-        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(hh, 1 + ww * 6)[:, 1:].reshape(hh, ww, 3, 2).astype(np.uint16)
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(hh, 1 + ww * 6)
+        rows = refprog.png_unfilter(rows, 6).reshape(hh, ww, 3, 2).astype(np.uint16)  # (the writer filters its scanlines)
         return ((rows[..., 0] << 8) | rows[..., 1])[..., ::-1]  # RGB -> BGR
 
     for inp, bpp, dm, extra in (("in.png", 16, 2, []), ("in.raw", 8, 0, ["--disable_tone_curve"]),
