@@ -302,8 +302,8 @@ def main():
         else:
             dist.init_process_group(backend)
     # Developer dry run, NOT a bench configuration: S360_TEST_EMULATED_LIB=1 walks this whole script on a machine without
-    # a GPU — the library's sources compiled for the CPU (tools/libs360_emu.so), a rig scaled to 256x256 cameras, eqr
-    # 504x252, a handful of steps — to check the script's control flow. Its JSON line says "dry_run".
+    # a GPU — the library's sources compiled for the CPU (tools/libs360_emu.so), a rig scaled to 128x128 cameras, eqr
+    # 252x126, a handful of steps — to check the script's control flow. Its JSON line says "dry_run".
     dry = os.environ.get("S360_TEST_EMULATED_LIB") == "1"
     rig_path, cam_size, world_h, pair_size = RIG, 2048, 4096, 2048
     flags = dict(FLAGS_8K)
@@ -312,9 +312,9 @@ def main():
         _capi.LIB_PATH = os.path.join(ROOT, "tools", "libs360_emu.so")
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import rigutil
-        cam_size, world_h, pair_size = 256, 512, 150
+        cam_size, world_h, pair_size = 128, 256, 100
         rig_path = rigutil.scaled_rig_json(RIG, "/tmp/bench_dry_run_rig_%d.json" % rank, cam_size / 2048.0)
-        flags.update(eqr_width=504, eqr_height=252, final_eqr_width=480, final_eqr_height=480)
+        flags.update(eqr_width=252, eqr_height=126, final_eqr_width=240, final_eqr_height=240)
 
         class _NoCuda:  # the handful of torch.cuda calls of this script
             set_device = synchronize = empty_cache = staticmethod(lambda *a, **k: None)
