@@ -1,4 +1,5 @@
 """Whole frames with random flags (eqr sizes, camera sizes, poles, final resize, sharpening, feathers, eye distance, flow\nalgorithm, one or two chained frames) on an emulated build of the library against the oracle, byte for byte.\nusage: python tools/fuzz/random_parity.py <libs360 build> drive <seed> <cases>"""
+import os as _os; _os.makedirs('/tmp/s360_fuzz', exist_ok=True)
 import os, sys, json, subprocess, random
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 if len(sys.argv) > 2 and sys.argv[2] != 'drive':

@@ -1,3 +1,4 @@
+import os as _os; _os.makedirs('/tmp/s360_fuzz', exist_ok=True)
 import os, sys, subprocess, json
 ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 if len(sys.argv) > 2:
