@@ -102,7 +102,7 @@ def cpu_baseline_8k(side, top, bottom, rig_path=RIG, flags=None):
 REF_PROGRAM = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama")
 
 
-def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420):
+def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420, scratch=None):
     """"state both the device-path fps and the end-to-end fps incl. raw I/O". The drop-in host program
     (host/TestRenderStereoPanorama, the reference's binary name / flags / file layout) renders `frames` consecutive
     frames as ONE stream from PNG files on disk to equirect PNG files on disk: 17 PNG decodes per frame, upload, render
@@ -122,7 +122,7 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420)
     other = [c for c in cams if "side" not in c.get("group", "")]
     top_id = max(other, key=lambda c: c["forward"][2])["id"]
     bot_id = min(other, key=lambda c: c["forward"][2])["id"]
-    work = tempfile.mkdtemp(prefix="s360_e2e_")
+    work = tempfile.mkdtemp(prefix="s360_e2e_", dir=scratch)  # scratch: where the files live (None: the default temporary directory)
     try:
         imgs, out = os.path.join(work, "rgb"), os.path.join(work, "out")
         for cid in side_ids + [top_id, bot_id]:
@@ -921,6 +921,20 @@ def main():
                     _, eq_chain = stream(True, n_e2e, True)  # the same chain through the C ABI in this process
                     rec["last_frame_equals_in_process_stream"] = bool(eq_chain.shape == last_png.shape and
                                                                       np.array_equal(eq_chain, last_png))
+                    # the same with every file in memory (/dev/shm): what the program does when the scratch file system is not
+                    # the limit (tools/host_io_time measures that file system alone)
+                    try:
+                        import shutil as _sh
+                        if os.path.isdir("/dev/shm") and _sh.disk_usage("/dev/shm").free > (6 << 30):
+                            res2 = host_program_stream([stream_frame(k) for k in range(n_e2e)], rig_path, flags, prog,
+                                                       device=local_rank, scratch="/dev/shm")
+                            r2 = res2[0] if isinstance(res2, tuple) else res2
+                            rec["files_in_memory"] = {k: r2[k] for k in ("ms_per_frame_steady", "frames_per_s_steady", "ms_per_frame_stream",
+                                                                         "host_thread_ms_per_frame", "process_wall_s", "error") if k in r2}
+                            if isinstance(res2, tuple):
+                                rec["files_in_memory"]["same_last_frame"] = bool(np.array_equal(res2[1], last_png))
+                    except Exception as e:  # noqa: BLE001
+                        rec["files_in_memory"] = {"error": repr(e)}
                     out["end_to_end_files"] = rec
                 else:
                     out["end_to_end_files"] = res
