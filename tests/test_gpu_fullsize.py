@@ -302,3 +302,100 @@ def test_8k_cubemap_1536(frame8k_flags, fmt):
     want = frame8k_flags["of"].cubemap(1536, 1536, fmt)
     assert got.shape == ((4 * 1536, 3 * 1536, 3) if fmt == "video" else (12 * 1536, 1536, 3))
     _cmp("cubemap 1536 " + fmt, got, want)
+
+
+# ---- the other presets of batch_process_video.py:176-193 and BASELINE configs[0], with 2048^2 cameras (parity hole 2) ----
+# Every tile regime changes with the preset: pole rows 528 ... 1578, overlap widths 297 ... 910, strips of 147 ... 450
+# columns, and the 4k preset's eqr_height 1024 makes the final resize a 2x vertical UPSCALE (4200x1024 -> 4096x2048 per eye
+# pair) where every other preset shrinks.
+PRESETS = {
+    "3k": dict(eqr_width=3080, eqr_height=1540, final_eqr_width=3080, final_eqr_height=3080, sharpening=0.25),
+    "4k": dict(eqr_width=4200, eqr_height=1024, final_eqr_width=4096, final_eqr_height=2048, sharpening=0.25),
+    "6k": dict(eqr_width=6300, eqr_height=3072, final_eqr_width=6144, final_eqr_height=6144, sharpening=0.25),
+}
+
+
+@pytest.fixture(scope="module")
+def cams2048(rig_json, s360lib):
+    """Two consecutive 17-camera frames at 2048^2 (seed 362; world rotated 0.2 deg, the disc moved between them)."""
+    import torch
+    world = synth.World(4096, seed=362, device="cuda")
+    rr = synth.RigRenderer(rig_json, world, 2048)
+    frames = [rr.frame_numpy(yaw_deg=1.0 + 0.2 * k, disc_deg=25.0 + 0.5 * k) for k in range(2)]
+    del rr, world
+    torch.cuda.empty_cache()
+    return frames
+
+
+@pytest.mark.parametrize("preset", sorted(PRESETS))
+def test_preset_frame_2048_cameras(preset, cams2048, rig_json, oracle, gpu_rig):
+    """One frame of the preset from 2048^2 cameras, top + bottom on, sharpening 0.25: geometry, all 14 projections, two side
+    flows of each direction, all four pole flows and warped layers, both eyes and the stacked equirect against the threaded
+    oracle."""
+    flags = dict(PRESETS[preset], enable_top=1, enable_bottom=1)
+    side, top, bottom = cams2048[0]
+    cams, _ = oracle.load_rig(rig_json)
+    of = oracle.Frame(cams, oracle.make_params(**flags))
+    t0 = time.perf_counter()
+    want, _ = of.render(side, top, bottom, threaded=True)
+    print("oracle %s frame: %.1f s" % (preset, time.perf_counter() - t0))
+    ctx = R.Context(gpu_rig, R.make_params(**flags))
+    try:
+        ctx.keep_intermediates(True)
+        ctx.upload_frame(side, top, bottom)
+        ctx.render()
+        got = ctx.download_equirect()
+        g = ctx.geometry
+        assert g.num_novel_views * 14 == flags["eqr_width"]
+        print("%s: projection %dx%d, overlap %d, strip %d, pole rows %d/%d" % (
+            preset, g.cam_image_width, g.cam_image_height, g.overlap_image_width, g.num_novel_views, g.top_rows, g.bottom_rows))
+        for i in range(14):
+            _cmp("%s projection %d" % (preset, i), ctx.get_u8("projection", i), of.get_u8("projection", i))
+        for i in (1, 8):
+            _cmp("%s flow_l_to_r %d" % (preset, i), ctx.get_f32("flow_l_to_r", i), of.get_f32("flow_l_to_r", i))
+            _cmp("%s flow_r_to_l %d" % (preset, i), ctx.get_f32("flow_r_to_l", i), of.get_f32("flow_r_to_l", i))
+        _cmp(preset + " side_pano_l", ctx.get_u8("side_pano_l"), of.get_u8("side_pano_l"))
+        _cmp(preset + " side_pano_r", ctx.get_u8("side_pano_r"), of.get_u8("side_pano_r"))
+        for u in range(4):
+            _cmp("%s flow_pole %d" % (preset, u), ctx.get_f32("flow_pole", u), of.get_f32("flow_pole", u))
+            _cmp("%s pole_warped %d" % (preset, u), ctx.get_u8("pole_warped", u), of.get_u8("pole_warped", u))
+        _cmp(preset + " eye_l (sharpened)", ctx.get_u8("eye_l"), of.get_u8("eye_l"))
+        _cmp(preset + " eye_r (sharpened)", ctx.get_u8("eye_r"), of.get_u8("eye_r"))
+        assert got.shape == (flags["final_eqr_height"], flags["final_eqr_width"], 3)
+        _cmp(preset + " stereo equirect", got, want)
+        assert got.std() > 5
+    finally:
+        ctx.close()
+
+
+def test_config1_two_chained_frames_2058(cams2048, rig_json, oracle, gpu_rig):
+    """BASELINE configs[0] as SURVEY 8(d) substitutes it: --eqr_width 2058 --eqr_height 1029 --enable_top --enable_bottom,
+    every other flag at its gflags default — so the final resize of TRSP:938-952 runs with the DEFAULT --final_eqr_width 3480
+    --final_eqr_height 960: each 2058x1029 eye is stretched to 3480 columns and squeezed to 480 rows, a shape no preset has —,
+    2048^2 cameras, two frames, the second one with --prev_frame_data_dir semantics (temporal regularisation toward frame 1's
+    flows and images)."""
+    flags = dict(eqr_width=2058, eqr_height=1029, enable_top=1, enable_bottom=1)
+    cams, _ = oracle.load_rig(rig_json)
+    of = oracle.Frame(cams, oracle.make_params(**flags))
+    ctx = R.Context(gpu_rig, R.make_params(**flags))
+    try:
+        ctx.keep_intermediates(True)
+        g = ctx.geometry
+        assert (g.cam_image_width, g.cam_image_height, g.overlap_image_width, g.num_novel_views) == (444, 444, 297, 147)
+        assert (g.top_rows, g.bottom_rows) == (528, 528)  # SURVEY.md §8 size table, 2K column
+        for k in range(2):
+            side, top, bottom = cams2048[k]
+            want, _ = of.render(side, top, bottom, use_prev=k > 0, threaded=True)
+            ctx.upload_frame(side, top, bottom)
+            ctx.render(use_prev=k > 0)
+            for i in range(14):
+                _cmp("2058 frame %d flow_l_to_r %d" % (k, i), ctx.get_f32("flow_l_to_r", i), of.get_f32("flow_l_to_r", i))
+                _cmp("2058 frame %d flow_r_to_l %d" % (k, i), ctx.get_f32("flow_r_to_l", i), of.get_f32("flow_r_to_l", i))
+            for u in range(4):
+                _cmp("2058 frame %d flow_pole %d" % (k, u), ctx.get_f32("flow_pole", u), of.get_f32("flow_pole", u))
+            got = ctx.download_equirect()
+            _cmp("2058 frame %d eye_l" % k, ctx.get_u8("eye_l"), of.get_u8("eye_l"))
+            assert got.shape == (960, 3480, 3)
+            _cmp("2058x1029 -> 3480x960 stereo equirect, frame %d" % k, got, want)
+    finally:
+        ctx.close()

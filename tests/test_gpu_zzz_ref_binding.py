@@ -6,8 +6,8 @@ run with --side_flow_alg pixflow_low_hip --polar_flow_alg pixflow_low_hip: the r
 blend, shift, feather and flow computed on the GPU — the flows by the reference's own 14 + 4 threads sharing one context —
 held to the digests of the unmodified reference program.
 tests/test_cpu_library_emulation.py runs the same program against the library's CPU emulation (green).
-NOT YET A GATE: written after round 3's GPU minutes were spent, so its first hardware run is the driver's; until a
-round has seen it pass it is reported as xpass / xfail instead of failing the suite (sorted last for the same reason)."""
+A GATE since round 4: the driver's MI355X passed all five cases at the end of round 3 (GPUTEST_r03.json: 5 xpassed), so a
+difference is a failure of the suite now."""
 import json
 import os
 
@@ -21,7 +21,6 @@ pytestmark = pytest.mark.gpu
 EXE = os.path.join(refprog.ROOT, "oracle", "_ref", "TestRenderStereoPanorama_ops_hip")
 
 
-@pytest.mark.xfail(strict=False, reason="first hardware run of the reference program + binding (see the module docstring)")
 @pytest.mark.parametrize("name,flags", [
     ("two_frames", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip"]),
     ("pole_removal", ["--side_flow_alg", "pixflow_low_hip", "--polar_flow_alg", "pixflow_low_hip", "--poleremoval_flow_alg", "pixflow_low_hip"])])
@@ -37,7 +36,6 @@ def test_reference_program_with_the_integration_binding_on_the_gpu(tmp_path, nam
     assert not differing, "%d of %d files differ from the unmodified reference program's: %s" % (len(differing), len(golden), differing[:12])
 
 
-@pytest.mark.xfail(strict=False, reason="first hardware run of the reference Raw2Rgb + binding (see the module docstring)")
 @pytest.mark.parametrize("name", list(refprog.RAW_CASES))
 def test_reference_raw2rgb_with_the_integration_binding_on_the_gpu(tmp_path, name, s360lib):
     """the reference's Raw2Rgb with the CameraIspGpu subclass (oracle/ref_binding/CameraIspGpu.h)."""
