@@ -35,7 +35,7 @@ std::vector<uint8_t> load_bgra(const std::string& path, int* w, int* h) {
   }
   *w = im.w;
   *h = im.h;
-  if (im.c == 4) return im.px;
+  if (im.c == 4) return std::vector<uint8_t>(im.px.begin(), im.px.end());
   std::vector<uint8_t> out((size_t)im.w * im.h * 4);  // cvtColor(BGR2BGRA): alpha = 255 (TestOpticalFlow.cpp:60-66)
   for (size_t i = 0, n = (size_t)im.w * im.h; i < n; ++i) {
     out[4 * i] = im.px[3 * i];

@@ -467,7 +467,13 @@ int main(int argc, char** argv) {
     if (s360_comm_init_all(J.ctx.data(), G) < 0) die(s360_last_error(nullptr));
     for (int r = 0; r < G; ++r) ck(s360_frame_set_partition(J.ctx[r], J.bounds[r], J.bounds[r + 1]), J.ctx[r]);
   }
-  if (numFrames > 1) ck(s360_set_frame_pipelining(J.ctx[0], 1), J.ctx[0]);  // pole stage of frame k overlaps side stage of k+1
+  if (numFrames > 1) {
+    ck(s360_set_frame_pipelining(J.ctx[0], 1), J.ctx[0]);  // pole stage of frame k overlaps side stage of k+1
+    // a stream's decoders write into page-locked memory: the uploads are DMA transfers straight from the decoded images
+    // (set once, before the first image exists; every pngio::Image of this process then lives in such memory)
+    pngio::g_pixel_alloc = s360_host_alloc;
+    pngio::g_pixel_free = s360_host_free;
+  }
 
   const s360_geometry& g = J.g;
   const std::string prev = F.s("prev_frame_data_dir");
@@ -486,8 +492,10 @@ int main(int argc, char** argv) {
   // Up to two finished frames are PNG-encoded and written while the next one renders (one encoder per frame, parallel
   // deflate inside it): an 8192 x 8192 file takes longer to encode and write than the frame takes to render.
   const size_t outBytes = (size_t)g.out_width * g.out_height * 3;
-  constexpr int kEncoders = 2;
-  std::vector<uint8_t> outBuf[kEncoders + 1];
+  constexpr int kEncoders = 3;
+  // (page-locked in stream mode: the finished frame comes back in one DMA transfer instead of through the runtime's
+  // staging buffers — 201 MB per 8K frame)
+  pngio::Pixels outBuf[kEncoders + 1];
   std::thread encoder[kEncoders + 1];  // encoder[i] owns outBuf[i] while it runs
   for (auto& b : outBuf) b.resize(numFrames > 1 ? outBytes : 0);
   outBuf[0].resize(outBytes);
@@ -502,6 +510,7 @@ int main(int argc, char** argv) {
   std::string decodeCursor = frame;
   int decodesStarted = 0;
   std::vector<FrameInputs> spare;  // uploaded frames: their pixel buffers go to the next decodes
+  std::vector<FrameInputs> leaving;  // enqueued uploads may still read these (page-locked buffers are sent in place)
   auto decode_ahead = [&] {
     while (decodesStarted < numFrames - 1 && decoding.size() < 3) {
       decodeCursor = next_frame_name(decodeCursor);
@@ -526,13 +535,18 @@ int main(int argc, char** argv) {
       const double t1 = now_sec();
       upload_frame(J, nin);     // upload stream: overlaps frame k
       render_frame(J, true);    // temporal state stays on the device
-      spare.push_back(std::move(nin));  // (the uploads have left these buffers: s360_frame_upload_* copy before they return)
+      leaving.push_back(std::move(nin));  // (sent in place: recycled once the uploads have run, below)
       tDecode += t1 - t0;
       tUpload += now_sec() - t1;
     }
     const double tf = now_sec();
     if (last) ck(s360_frame_download_equirect(J.ctx[0], outBuf[cur].data()), J.ctx[0]);
     else ck(s360_frame_download_equirect_of(J.ctx[0], 1, outBuf[cur].data()), J.ctx[0]);  // frame k, while k+1 renders
+    if (!leaving.empty()) {  // frame k is complete, so frame k+1's uploads (enqueued before it rendered) are long done
+      ck(s360_frame_uploads_complete(J.ctx[0]), J.ctx[0]);
+      for (auto& fi : leaving) spare.push_back(std::move(fi));
+      leaving.clear();
+    }
     renderEnd = now_sec();
     tFetch += renderEnd - tf;
     // the reference writes the state of every frame; a stream only needs it to resume after its last frame

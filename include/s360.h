@@ -215,6 +215,16 @@ int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
  * call waits for THAT frame only and copies on a stream of its own, so frame k can be fetched and encoded while frame
  * k+1 renders:  upload(k+1); render(k+1); download_equirect_of(age 1) -> frame k. */
 int s360_frame_download_equirect_of(s360_ctx* ctx, int age, uint8_t* out_bgr);
+/* Page-locked host buffers for streaming hosts (what the reference's per-frame loop has no need for: its cv::Mat pixels
+ * never leave the host, RigDescription.cpp:80-108 / TRSP:961). An image passed to s360_frame_upload_* from such a buffer is
+ * sent straight from it — no staging copy inside the library, the call returns in microseconds — and must then stay
+ * untouched until s360_frame_uploads_complete(ctx) has returned; a download into such a buffer is one DMA transfer.
+ * s360_frame_download_equirect_of and s360_frame_uploads_complete release the context's lock while they wait for the
+ * device, so that a second host thread can upload and enqueue the next frame meanwhile (one fetching thread per context).
+ * s360_host_alloc returns NULL on failure (s360_last_error(NULL) says why). */
+void* s360_host_alloc(size_t bytes);
+void s360_host_free(void* p);
+int s360_frame_uploads_complete(s360_ctx* ctx);
 /* Stereo cubemap of the last rendered frame (convertSphericalToCubemapBicubicRemap + stackOutputCubemapFaces,
  * SR/render/ImageWarper.cpp:95-141, SR/util/CvUtil.cpp:117-138, TRSP:917-935): format "video" (3 x 2 faces per eye,
  * flipped) or "photo" (6 faces stacked). whc receives width/height/3; out_bgr may be NULL for a size query. */

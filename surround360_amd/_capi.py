@@ -81,6 +81,7 @@ SYMBOLS = [
     "s360_frame_download_equirect_of", "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch",
     "s360_isp_config_defaults", "s360_isp_config_from_json", "s360_isp_create", "s360_isp_destroy", "s360_isp_process",
     "s360_isp_config_tables", "s360_isp_process_packed", "s360_frame_upload_raw",
+    "s360_host_alloc", "s360_host_free", "s360_frame_uploads_complete",
 ]
 
 _lib = None
@@ -101,6 +102,10 @@ def lib():
         L.s360_camera_usable_pixels_radius.restype = C.c_float
         L.s360_stream.restype = C.c_void_p
         L.s360_stream.argtypes = [C.c_void_p]
+        L.s360_host_alloc.restype = C.c_void_p
+        L.s360_host_alloc.argtypes = [C.c_size_t]
+        L.s360_host_free.restype = None
+        L.s360_host_free.argtypes = [C.c_void_p]
         L.s360_isp_config_defaults.restype = None
         L.s360_isp_destroy.restype = None
         L.s360_isp_destroy.argtypes = [C.c_void_p]

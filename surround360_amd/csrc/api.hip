@@ -16,6 +16,21 @@ using namespace s360;
 
 static thread_local std::string g_err;
 
+// buffers handed out by s360_host_alloc (page-locked host memory)
+namespace {
+std::mutex g_pinMu;
+std::vector<std::pair<const char*, size_t>> g_pinBlocks;
+}  // namespace
+namespace s360 {
+bool host_is_pinned(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pinMu);
+  const char* q = static_cast<const char*>(p);
+  for (const auto& b : g_pinBlocks)
+    if (q >= b.first && q + bytes <= b.first + b.second) return true;
+  return false;
+}
+}  // namespace s360
+
 template <typename F>
 static int guard(s360_ctx* c, F&& f) {
   // thread-safe per context: concurrent callers of one context are serialised here
@@ -31,6 +46,30 @@ static int guard(s360_ctx* c, F&& f) {
     return e.code;
   } catch (const std::exception& e) {
     (c ? c->err : g_err) = e.what();
+    g_err = e.what();
+    return S360_ERR_STATE;
+  }
+}
+// Entry points that BLOCK on the device (a finished frame's download, waiting for uploads) give the context back while
+// they wait: f receives the held lock and may unlock / relock it around the wait, so that another host thread can feed
+// the next frame meanwhile (a stream's uploader beside the thread that fetches and encodes).
+template <typename F>
+static int guard_l(s360_ctx* c, F&& f) {
+  std::unique_lock<std::recursive_mutex> lk(c->mu);
+  try {
+    c->make_current();
+    if (!c->frame_invalid.empty()) throw Error(S360_ERR_INVALID_ARG, c->frame_invalid);
+    f(lk);
+    if (!lk.owns_lock()) lk.lock();
+    return S360_OK;
+  } catch (const Error& e) {
+    if (!lk.owns_lock()) lk.lock();
+    c->err = e.what();
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    if (!lk.owns_lock()) lk.lock();
+    c->err = e.what();
     g_err = e.what();
     return S360_ERR_STATE;
   }
@@ -181,6 +220,7 @@ int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams,
     c->device = device;
     S360_HIP(hipSetDevice(device));
     S360_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    c->st_user = c->st;
     c->prof.st = c->st;
     c->rig.all.assign(cams, cams + n_cams);
     c->rig.finalize();
@@ -246,6 +286,8 @@ void s360_destroy(s360_ctx* c) {
   }
   if (c->evPoleSrcFree) (void)hipEventDestroy(c->evPoleSrcFree);
   if (c->stDown) (void)hipStreamDestroy(c->stDown);
+  if (c->evDown) (void)hipEventDestroy(c->evDown);
+  if (c->evUpHost) (void)hipEventDestroy(c->evUpHost);
   if (c->stUp) {
     (void)hipStreamDestroy(c->stUp);
     (void)hipEventDestroy(c->evUploaded);
@@ -262,7 +304,7 @@ int s360_get_geometry(const s360_ctx* c, s360_geometry* out) {
   *out = c->g;
   return S360_OK;
 }
-void* s360_stream(s360_ctx* c) { return c ? (void*)c->st : nullptr; }
+void* s360_stream(s360_ctx* c) { return c ? (void*)c->st_user : nullptr; }  // (immutable after s360_create: no lock needed)
 int s360_synchronize(s360_ctx* c) {
   return guard(c, [&] {
     need(c, "null ctx");
@@ -708,8 +750,9 @@ int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
   });
 }
 int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
-  return frame_guard(c, [&] {
-    need(c && out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
+  if (!c) return S360_ERR_INVALID_ARG;
+  return guard_l(c, [&](std::unique_lock<std::recursive_mutex>& lk) {
+    need(out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
     FrameState& F = frame_state(c);
     need(F.frames_done > age, "that frame has not been rendered");
     need(age == 0 || (c->pipeline && F.outBGR[F.out_cur ^ 1].p), "age 1 needs s360_set_frame_pipelining (two output buffers)");
@@ -717,13 +760,56 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     // wait for THAT frame only (its event sits behind its last kernel), then copy on a stream of its own so that the
     // transfer does not queue behind the kernels of the frame enqueued after it
     if (!c->stDown) S360_HIP(hipStreamCreateWithFlags(&c->stDown, hipStreamNonBlocking));
+    if (!c->evDown) S360_HIP(hipEventCreateWithFlags(&c->evDown, hipEventDisableTiming | hipEventBlockingSync));
     S360_HIP(hipStreamWaitEvent(c->stDown, F.outDone[b], 0));
     S360_HIP(hipMemcpyAsync(out_bgr, F.outBGR[b].p, (size_t)c->g.out_width * c->g.out_height * 3, hipMemcpyDeviceToHost, c->stDown));
-    S360_HIP(hipStreamSynchronize(c->stDown));
+    S360_HIP(hipEventRecord(c->evDown, c->stDown));
+    const hipEvent_t ev = c->evDown;
+    const unsigned* errw = F.outErr[b];
+    // The wait is most of a frame long: the context is free meanwhile (the next frame's uploads and enqueue need it).
+    // One fetching thread per context: evDown is re-recorded by the next call.
+    lk.unlock();
+    const hipError_t rc = hipEventSynchronize(ev);
+    lk.lock();
+    S360_HIP(rc);
     // the frame's sweep error words were snapshotted in front of outDone[b] (render.hpp): a timed-out banded sweep
     // fails THIS frame's download, before the host hands the pixels to an encoder
-    if (F.outErr[b] && (F.outErr[b][0] | F.outErr[b][1] | F.outErr[b][2]))
+    if (errw && (errw[0] | errw[1] | errw[2]))
       throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
+  });
+}
+/* ---- page-locked host buffers for streaming hosts ---- */
+void* s360_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    g_err = "s360_host_alloc: hipHostMalloc failed";
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_pinMu);
+  g_pinBlocks.emplace_back(static_cast<const char*>(p), bytes);
+  return p;
+}
+void s360_host_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pinMu);
+    for (size_t i = 0; i < g_pinBlocks.size(); ++i)
+      if (g_pinBlocks[i].first == p) { g_pinBlocks.erase(g_pinBlocks.begin() + i); break; }
+  }
+  (void)hipHostFree(p);
+}
+int s360_frame_uploads_complete(s360_ctx* c) {
+  if (!c) return S360_ERR_INVALID_ARG;
+  return guard_l(c, [&](std::unique_lock<std::recursive_mutex>& lk) {
+    if (!c->haveUploaded) return;
+    if (!c->evUpHost) S360_HIP(hipEventCreateWithFlags(&c->evUpHost, hipEventDisableTiming | hipEventBlockingSync));
+    S360_HIP(hipEventRecord(c->evUpHost, c->stUp));
+    const hipEvent_t ev = c->evUpHost;
+    lk.unlock();
+    const hipError_t rc = hipEventSynchronize(ev);
+    lk.lock();
+    S360_HIP(rc);
   });
 }
 

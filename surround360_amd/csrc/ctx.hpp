@@ -20,6 +20,9 @@ struct s360_ctx {
   mutable std::recursive_mutex mu;
   int device = 0;
   hipStream_t st = nullptr;
+  // what s360_stream() hands out: the stream created with the context, never swapped (frame_finish replaces `st` by `st2`
+  // for its own duration when frame pipelining is on)
+  hipStream_t st_user = nullptr;
   // Frame pipelining (s360_set_frame_pipelining): the pole stage / composite (frame_finish) runs on st2 so that it
   // overlaps the side stage (frame_render_pairs) of the NEXT frame of a video stream. The two stages share three
   // things, each guarded by an event: the strips, the pole source images, and the order side(k) -> finish(k).
@@ -33,6 +36,8 @@ struct s360_ctx {
   // conversion kernels wait until the previous frame's projections have read the source images).
   hipStream_t stUp = nullptr;
   hipStream_t stDown = nullptr;  // s360_frame_download_equirect_of: device -> host copy of a finished frame
+  hipEvent_t evDown = nullptr;   // ... and what its host thread sleeps on with the context lock released
+  hipEvent_t evUpHost = nullptr; // s360_frame_uploads_complete
   static constexpr int kPinChunks = 4;
   static constexpr size_t kPinChunkBytes = (size_t)8 << 20;
   void* pin[kPinChunks] = {nullptr, nullptr, nullptr, nullptr};

@@ -186,10 +186,16 @@ static void ensure_upload_stream(s360_ctx* c) {
     S360_HIP(hipEventCreateWithFlags(&c->pinEv[i], hipEventDisableTiming));
   }
 }
-// host -> device through the pinned ring on stUp; `src` may be reused as soon as this returns
+// host -> device through the pinned ring on stUp; `src` may be reused as soon as this returns — unless it lies in a
+// buffer from s360_host_alloc: then the copy is enqueued straight from it (no staging copy, no waiting for ring chunks:
+// the call costs microseconds) and the buffer must stay untouched until s360_frame_uploads_complete has returned.
 static void upload_bytes(s360_ctx* c, void* dst, const void* src, size_t bytes) {
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
+  if (host_is_pinned(src, bytes)) {
+    S360_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stUp));
+    return;
+  }
   for (size_t off = 0; off < bytes; off += s360_ctx::kPinChunkBytes) {
     const size_t len = std::min(s360_ctx::kPinChunkBytes, bytes - off);
     const int i = c->pinNext;

@@ -105,4 +105,7 @@ std::vector<int> feather_gauss_taps(int erode_size);
 void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flow, int cols, int rows, int extW,
                         uchar4* warped_out /*cols x eqrH*/, int eqrH);
 
+// api.hip: does [p, p + bytes) lie in a buffer from s360_host_alloc (page-locked: uploads need no staging copy)?
+bool host_is_pinned(const void* p, size_t bytes);
+
 }  // namespace s360

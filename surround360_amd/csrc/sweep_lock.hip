@@ -98,8 +98,14 @@ typedef float f2n __attribute__((ext_vector_type(2)));
 // across steps; __syncthreads()/the s_barrier builtin would drain them on gfx9-class targets).
 #ifdef S360_WAVE_EMULATION
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+__device__ __forceinline__ void wg_barrier_taps_in_flight() { __syncthreads(); }
 #else
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The same with the wave's LAST TWO LDS instructions — the two ds_read2_b64 of the window taps, issued right in front of
+// it — still in flight: a wave's LDS instructions complete in order, so everything it wrote for the other waves is done
+// when at most two are outstanding, and the taps' latency hides behind the barrier like the gathers' did. (The loops hold
+// no scalar memory loads, the other user of that counter: checked in the ISA.)
+__device__ __forceinline__ void wg_barrier_taps_in_flight() { asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory"); }
 #endif
 
 template <int K>
@@ -189,7 +195,8 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     // the lanes whose evaluation is read by the selection (steady steps; elsewhere the left proposal depends on the column)
     const unsigned long long lanesRel = __ballot(role < 3 && (bank == 0 || bank == 1 || (bank == 2 && hasUp)));
     int wy0 = kLNoWin, wu0 = 0;  // placement of this chunk's window (wave-uniform)
-    const f2n* winBuf = &s_win[j][0][0];
+    int winOff = 0;  // texel offset of this chunk's buffer in s_win[j] (an index, not a pointer: a pointer variable into LDS
+                     // that is re-assigned in the loop degrades to a generic one, and the taps to flat loads)
     auto step = [&](auto steady, int t) {
       constexpr bool ST = decltype(steady)::value;
       TS(0);
@@ -198,7 +205,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         const int2 wp = s_winpos[j][(s >> 4) & 1];
         wy0 = __builtin_amdgcn_readfirstlane(wp.x);
         wu0 = __builtin_amdgcn_readfirstlane(wp.y);
-        winBuf = &s_win[j][(s >> 4) & 1][0];
+        winOff = ((s >> 4) & 1) * (kLWinRows * kLWinStride);
       }
       const bool run = ST || (s >= 0 && s < nsteps && !S360_DBG(fc, 16));
       const LkIn in = nin;
@@ -218,6 +225,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       float2 up;
       float ax, ay, xR, yR;
       f4a8 ta, tb;
+      bool tapsInFlight = false;
       if (any) {
         // up neighbour in every lane (needed by the selection below)
         up.x = from_row_above<0xF>(upl.x, fl.x);
@@ -247,18 +255,27 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
           ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
         } else if (__builtin_expect((__ballot(outw) & rel) == 0ull, 1) && !S360_DBG(fc, 256)) {
           // (lanes that do not matter read slot 0; 24-bit multiply-add: full rate)
-          const int off = outw ? 0 : (int)__umul24((unsigned)jy, (unsigned)kLWinStride) + ju;
-          ta = *reinterpret_cast<const f4a8*>(winBuf + off);
-          tb = *reinterpret_cast<const f4a8*>(winBuf + off + kLWinStride + 1);
+          const int off = winOff + (outw ? 0 : (int)__umul24((unsigned)jy, (unsigned)kLWinStride) + ju);
+          const f2n* wbase = &s_win[j][0][0];
+          ta = *reinterpret_cast<const f4a8*>(wbase + off);
+          tb = *reinterpret_cast<const f4a8*>(wbase + off + kLWinStride + 1);
+          tapsInFlight = true;
         } else {
           S360_LSTAT(g_lock_fallbacks);
           const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
           ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
           tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
+#ifndef S360_WAVE_EMULATION
+          // (keeps the two paths apart: with identical tails the compiler sinks the loads into the join block and reads
+          // through a generic pointer — flat loads, which wait on the vector-memory path even when the window hits.
+          // The rare path waits for its gathers here instead of behind the barrier.)
+          asm volatile("; window miss: texels from global memory" : "+v"(ta), "+v"(tb));
+#endif
         }
       }
       TS(1);
-      wg_barrier();
+      if (tapsInFlight) wg_barrier_taps_in_flight();
+      else wg_barrier();
       TS(2);
       // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
       // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.

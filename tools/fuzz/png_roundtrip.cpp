@@ -11,7 +11,7 @@ int main() {
     for (auto& v : px) v = (it & 1) ? (uint8_t)rng() : (uint8_t)((&v - px.data()) / 7);
     pngio::write("/tmp/s360_fuzz/rt.png", px.data(), w, h, c, 1, th);
     pngio::Image im = pngio::read("/tmp/s360_fuzz/rt.png", true);
-    ++n; if (im.w != w || im.h != h || im.c != c || im.px != px) { ++bad; printf("MISMATCH %d x %d x %d threads %d\n", w, h, c, th); }
+    ++n; if (im.w != w || im.h != h || im.c != c || !(im.px.size() == px.size() && std::equal(px.begin(), px.end(), im.px.begin()))) { ++bad; printf("MISMATCH %d x %d x %d threads %d\n", w, h, c, th); }
     if (it % 9 == 0) {  // 16-bit RGB
       std::vector<uint16_t> p16((size_t)w * h * 3); for (auto& v : p16) v = (uint16_t)rng();
       pngio::write16("/tmp/s360_fuzz/rt16.png", p16.data(), w, h, 1, th);

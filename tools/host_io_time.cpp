@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     auto t0 = clk::now();
     pngio::Image im = pngio::read(f, false);
     auto t1 = clk::now();
-    std::printf("PNG decode from %-9s %.0f ms (%d x %d)%s\n", (d + ":").c_str(), ms(t0, t1), im.w, im.h, im.px == px ? "" : "  MISMATCH");
+    std::printf("PNG decode from %-9s %.0f ms (%d x %d)%s\n", (d + ":").c_str(), ms(t0, t1), im.w, im.h, (im.px.size() == px.size() && std::equal(px.begin(), px.end(), im.px.begin())) ? "" : "  MISMATCH");
     std::remove(f.c_str());
   }
 }
