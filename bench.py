@@ -737,8 +737,58 @@ def main():
         os._exit(0)
 
     # (N > 1: only the sharded frame follows — seconds; a stuck RCCL exchange must not outlast the driver's patience)
-    watchdog = threading.Timer(900.0 if world == 1 else 300.0, bail, args=("post-timed-region phases timed out",))
+    watchdog = threading.Timer(900.0 if world == 1 else 420.0, bail, args=("post-timed-region phases timed out",))
     watchdog.daemon = True
+
+    def stream(pipelined, n_frames, fetch, frame_of=None, barrier_at_lead=False):
+        """One stream the way a streaming host runs it (host/TestRenderStereoPanorama --num_frames): the next frame's
+        images are put into page-locked buffers by a second host thread (there: the PNG decoders write into them),
+        uploaded in place, and the finished equirect of frame k-1 comes back into a page-locked buffer while frame k
+        renders (the library releases the context while that call waits)."""
+        ctx.set_frame_pipelining(pipelined)
+        eq = R.pinned_empty((g.out_height, g.out_width, 3)) if fetch else None
+        lead = min(10, n_frames - 2)
+        up = 0.0
+        t2 = None
+        frame_of = frame_of or stream_frame
+        f0 = frame_of(0)
+        ring = [([R.pinned_empty(a.shape) for a in f0[0]], R.pinned_empty(f0[1].shape), R.pinned_empty(f0[2].shape))
+                for _ in range(3)]
+
+        def stage(k):
+            side, top, bottom = frame_of(k)
+            dst = ring[k % 3]
+            for d, a in zip(dst[0], side):
+                np.copyto(d, a)
+            np.copyto(dst[1], top)
+            np.copyto(dst[2], bottom)
+        with ThreadPoolExecutor(1) as feeder:
+            fut = feeder.submit(stage, 0)
+            for k in range(n_frames):
+                if k == lead:  # frames 0..lead-1 are the run-in (the first has no temporal state, buffers are sized)
+                    sync(barrier=barrier_at_lead)
+                    up = 0.0
+                    t2 = time.perf_counter()
+                tu = time.perf_counter()
+                fut.result()
+                if k + 1 < n_frames:
+                    ctx.uploads_complete()  # (the buffer of frame k+1 was last read by frame k-2's uploads)
+                    fut = feeder.submit(stage, k + 1)
+                ctx.upload_frame(*ring[k % 3])  # page-locked: sent in place on the upload stream; overlaps frame k-1
+                up += time.perf_counter() - tu
+                ctx.render(k > 0)
+                if fetch and k > 0:  # frame k-1 comes back while k renders
+                    ctx.download_equirect_of(1, eq)
+            if fetch:
+                eq = np.array(ctx.download_equirect())
+            sync(barrier=False)
+        n = n_frames - lead
+        ms = 1e3 * (time.perf_counter() - t2) / n
+        ctx.set_frame_pipelining(False)
+        ctx.uploads_complete()
+        return {"frames": n_frames, "steady_state_frames": n, "ms_per_frame": ms, "frames_per_s": 1e3 / ms,
+                "host_upload_ms_per_frame": 1e3 * up / n, "equirect_fetched_per_frame": bool(fetch)}, eq
+
     watchdog.start()
     try:
         # ---- one frame at a time (configs[2] on 1 GPU; configs[3] = pairs sharded + strip gather on N GPUs) ----
@@ -796,6 +846,38 @@ def main():
                 rec = {"error": "the sharded-frame processes did not finish in 240 s"}
             if rank == 0:
                 out["single_frame"] = rec
+            # ---- configs[4] on N GPUs, the honest form: ONE stream cannot use more than one GPU (its pole flows are one serial
+            # chain per frame and every frame needs its predecessor's flows: DESIGN.md sections 5 and 7), N streams use N —
+            # every rank runs a stream of its own on its GPU at the same time (what host/TestRenderStereoPanorama
+            # --num_streams N does in one process); no collective, the ranks only meet for the barrier and the figures ----
+            if not args.no_extras:
+                try:
+                    n_multi = max(14, min(args.video_frames, 40))
+                    held = len(frames)
+
+                    def ring_frame(k):  # the frames held in host memory walked forwards and backwards
+                        if held < 2:
+                            return frames[0]
+                        m = k % (2 * (held - 1))
+                        return frames[m if m < held else 2 * (held - 1) - m]
+                    ctx.set_sweep_mode("latency")
+                    lead = min(10, n_multi - 2)
+                    rec_r, _ = stream(True, n_multi, True, frame_of=lambda k: ring_frame(k + rank), barrier_at_lead=True)
+                    ms_r = rec_r["ms_per_frame"]
+                    tms = torch.tensor([ms_r], dtype=torch.float64, device=red_dev)
+                    allms = [torch.zeros_like(tms) for _ in range(world)]
+                    dist.all_gather(allms, tms)
+                    per = [float(t.item()) for t in allms]
+                    if rank == 0:
+                        out["video_stream"] = {
+                            "mode": "%d streams, one per GPU, at the same time: each %d frames with temporal regularisation, frame "
+                                    "pipelining, inputs uploaded from host memory and the finished equirect fetched while the next "
+                                    "frame renders; steady state = frames %d..%d; no collective" % (world, n_multi, lead, n_multi - 1),
+                            "streams": world, "ms_per_frame_of_each_stream": [round(v, 2) for v in per],
+                            "frames_per_s": sum(1e3 / v for v in per), "frames_per_s_per_stream": [round(1e3 / v, 3) for v in per]}
+                except Exception as e:  # noqa: BLE001
+                    if rank == 0:
+                        out["video_stream"] = {"error": repr(e)}
 
         if world == 1 and not args.no_extras:
             # ---- the same single frame without the sharpening pass (secondary; the presets all sharpen) ----
@@ -844,31 +926,6 @@ def main():
 
             # ---- BASELINE configs[4] on one GPU: one video stream of 190 frames (Building-20 shape),
             # temporal regularisation, steady state over frames 10..N-1, the finished frame fetched while the next renders ----
-            def stream(pipelined, n_frames, fetch):
-                ctx.set_frame_pipelining(pipelined)
-                eq = np.empty((g.out_height, g.out_width, 3), np.uint8) if fetch else None
-                lead = min(10, n_frames - 2)
-                up = 0.0
-                t2 = None
-                for k in range(n_frames):
-                    if k == lead:  # frames 0..lead-1 are the run-in (the first has no temporal state, buffers are sized)
-                        sync(barrier=False)
-                        up = 0.0
-                        t2 = time.perf_counter()
-                    tu = time.perf_counter()
-                    ctx.upload_frame(*stream_frame(k))  # host memory -> pinned ring -> upload stream; overlaps frame k-1
-                    up += time.perf_counter() - tu
-                    ctx.render(k > 0)
-                    if fetch and k > 0:  # what host/TestRenderStereoPanorama --num_frames does: frame k-1 comes back while k renders
-                        eq = ctx.download_equirect_of(1)
-                if fetch:
-                    eq = ctx.download_equirect()
-                sync(barrier=False)
-                n = n_frames - lead
-                ms = 1e3 * (time.perf_counter() - t2) / n
-                ctx.set_frame_pipelining(False)
-                return {"frames": n_frames, "steady_state_frames": n, "ms_per_frame": ms, "frames_per_s": 1e3 / ms,
-                        "host_upload_ms_per_frame": 1e3 * up / n, "equirect_fetched_per_frame": bool(fetch)}, eq
             ctx.set_sweep_mode("latency")
             video = {"mode": "one stream of %d frames (%d distinct in host memory%s; world rotating 0.2 deg/frame, one moving disc); "
                              "frame k regularised toward frame k-1's device-resident flows and images; inputs uploaded from host "

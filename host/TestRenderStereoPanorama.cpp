@@ -53,7 +53,13 @@ struct Flags {
          // --num_frames N: frames frame_number .. +N-1 as ONE stream in this process (temporal state stays on the
          // device, decode/upload/render/download/encode overlapped); output_equirect_path must contain %s or {frame}
          // (the state files are written after the LAST frame only: that is what a later run resumes from)
-         {"num_frames", "1"}};
+         {"num_frames", "1"},
+         // --num_streams S: the --num_frames frames as S independent streams, stream s = the s-th contiguous segment of the
+         // frame range on GPU device + s (modulo the GPUs there are) — exactly what S invocations with that segment's
+         // --frame_number / --num_frames on S GPUs produce (each segment's first frame has no previous frame, except the
+         // first one's --prev_frame_data_dir), in one process. One stream cannot use more than one GPU: its pole flows
+         // are one serial chain per frame and every frame needs its predecessor's flows
+         {"num_streams", "1"}};
   }
   static bool is_bool(const std::string& k) {
     static const char* b[] = {"save_debug_images", "enable_top", "enable_bottom", "enable_pole_removal", "logtostderr",
@@ -404,14 +410,11 @@ std::string frame_path(const std::string& pattern, const std::string& frame) {
 
 }  // namespace
 
-int main(int argc, char** argv) {
-  // glibc: keep freed blocks of up to 32 MB (decoded camera images, PNG scanline bands) in the heap instead of handing
-  // every one back to the kernel — a stream's decoder and encoder threads would spend their time in page faults
-  mallopt(M_MMAP_THRESHOLD, 32 << 20);
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+// One job = what one invocation of the reference's program does, or (--num_frames) one stream of consecutive frames.
+static int run_job(const Flags& flags) {
   Job J;
+  J.F = flags;
   Flags& F = J.F;
-  F.parse(argc, argv);
   require_arg(F.s("rig_json_file"), "rig_json_file");  // TRSP:717-721
   require_arg(F.s("imgs_dir"), "imgs_dir");
   require_arg(F.s("frame_number"), "frame_number");
@@ -469,10 +472,6 @@ int main(int argc, char** argv) {
   }
   if (numFrames > 1) {
     ck(s360_set_frame_pipelining(J.ctx[0], 1), J.ctx[0]);  // pole stage of frame k overlaps side stage of k+1
-    // a stream's decoders write into page-locked memory: the uploads are DMA transfers straight from the decoded images
-    // (set once, before the first image exists; every pngio::Image of this process then lives in such memory)
-    pngio::g_pixel_alloc = s360_host_alloc;
-    pngio::g_pixel_free = s360_host_free;
   }
 
   const s360_geometry& g = J.g;
@@ -520,6 +519,21 @@ int main(int argc, char** argv) {
       ++decodesStarted;
     }
   };
+  if (numFrames > 1) {
+    // Page-locking memory costs ~0.4 ms per MB: the buffers of the frames that will be in flight (three decoding ahead, one
+    // uploading, one whose uploads may still run) are made once, here, while the GPU works on frame 0 — not by the decoder
+    // threads of the first frames one image at a time (they serialise on the runtime's allocation lock: measured, the host
+    // thread of a 20-frame stream waited 71 ms per frame for its decoders).
+    for (int i = 0; i < 4 && i < numFrames - 1; ++i) {
+      FrameInputs fi;
+      fi.side.resize(in.side.size());
+      for (size_t k = 0; k < in.side.size(); ++k) fi.side[k].px.resize(in.side[k].px.size());
+      fi.top.px.resize(in.top.px.size());
+      fi.bottom.px.resize(in.bottom.px.size());
+      fi.bottom2.px.resize(in.bottom2.px.size());
+      spare.push_back(std::move(fi));
+    }
+  }
   decode_ahead();
   for (int k = 0; k < numFrames; ++k) {
     const bool last = k + 1 == numFrames;
@@ -559,7 +573,9 @@ int main(int argc, char** argv) {
       ck(s360_frame_cubemap(J.ctx[0], F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cubeImg.data()), J.ctx[0]);
       save_png(F.s("output_cubemap_path"), cubeImg.data(), whc[0], whc[1], 3);
     }
-    const std::string outPath = numFrames > 1 ? frame_path(F.s("output_equirect_path"), frame) : F.s("output_equirect_path");
+    // (%s / {frame} in the path stands for the frame name — needed by streams, harmless for a single frame: a stream
+    // segment of one frame is named like the others)
+    const std::string outPath = frame_path(F.s("output_equirect_path"), frame);
     const uint8_t* px = outBuf[cur].data();
     encoder[cur] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });  // TRSP:961
     cur = numFrames > 1 ? (cur + 1) % (kEncoders + 1) : 0;
@@ -592,5 +608,42 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
   }
   for (s360_ctx* c : J.ctx) s360_destroy(c);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  // glibc: keep freed blocks of up to 32 MB (decoded camera images, PNG scanline bands) in the heap instead of handing
+  // every one back to the kernel — a stream's decoder and encoder threads would spend their time in page faults
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  Flags F;
+  F.parse(argc, argv);
+  const int streams = std::max(1, F.i("num_streams")), frames = std::max(1, F.i("num_frames"));
+  if (frames > 1) {
+    // a stream's decoders write into page-locked memory: the uploads are DMA transfers straight from the decoded images
+    // (set once, before the first image exists; every pngio::Image of this process then lives in such memory)
+    pngio::g_pixel_alloc = s360_host_alloc;
+    pngio::g_pixel_free = s360_host_free;
+  }
+  if (streams == 1) return run_job(F);
+  if (F.i("num_gpus") > 1) die("--num_streams and --num_gpus are separate modes");
+  if (streams > frames) die("--num_streams: more streams than frames");
+  require_arg(F.s("frame_number"), "frame_number");
+  const int devices = s360_device_count();
+  if (devices < 1) die("no HIP device");
+  std::vector<std::thread> th;
+  std::string first = F.s("frame_number");
+  for (int s = 0; s < streams; ++s) {
+    const int n = frames / streams + (s < frames % streams ? 1 : 0);
+    Flags Fs = F;
+    Fs.v["num_streams"] = "1";
+    Fs.v["frame_number"] = first;
+    Fs.v["num_frames"] = std::to_string(n);
+    Fs.v["device"] = std::to_string((F.i("device") + s) % devices);
+    if (s > 0) Fs.v["prev_frame_data_dir"] = "NONE";
+    th.emplace_back([Fs] { run_job(Fs); });  // (errors abort the process, like the reference's)
+    for (int k = 0; k < n; ++k) first = next_frame_name(first);
+  }
+  for (auto& t : th) t.join();
   return 0;
 }

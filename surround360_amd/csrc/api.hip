@@ -781,7 +781,7 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
 /* ---- page-locked host buffers for streaming hosts ---- */
 void* s360_host_alloc(size_t bytes) {
   void* p = nullptr;
-  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
     g_err = "s360_host_alloc: hipHostMalloc failed";
     return nullptr;

@@ -28,6 +28,21 @@ def _u8(a):
     return np.ascontiguousarray(a, np.uint8)
 
 
+def pinned_empty(shape, dtype=np.uint8):
+    """A numpy array in page-locked host memory (s360_host_alloc): images uploaded from such an array are sent in place (and
+    must stay untouched until Context.uploads_complete() has returned), a download into one is a single DMA transfer.
+    Freed with the array."""
+    import weakref
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib().s360_host_alloc(max(n, 1))
+    if not p:
+        raise MemoryError("s360_host_alloc(%d) failed: %s" % (n, lib().s360_last_error(None).decode()))
+    raw = (C.c_uint8 * max(n, 1)).from_address(p)
+    arr = np.frombuffer(raw, np.uint8, n).view(dtype).reshape(shape)
+    weakref.finalize(raw, lib().s360_host_free, p)
+    return arr
+
+
 class VrCamException(S360Error):
     """The reference's exception type for bad arguments / unknown algorithms (VrCamException.h:18-23)."""
 
@@ -310,12 +325,19 @@ class Context:
         self._ck(lib().s360_frame_download_equirect(self.h, _p(out)))
         return out
 
-    def download_equirect_of(self, age):
-        """age 0: the frame enqueued last; 1: the one before (fetched while the last one still renders)."""
+    def download_equirect_of(self, age, out=None):
+        """age 0: the frame enqueued last; 1: the one before (fetched while the last one still renders). `out`: a buffer to
+        fetch into (pinned_empty: one DMA transfer); the context's lock is released while the call waits for the frame."""
         g = self.geometry
-        out = np.empty((g.out_height, g.out_width, 3), np.uint8)
+        if out is None:
+            out = np.empty((g.out_height, g.out_width, 3), np.uint8)
+        assert out.shape == (g.out_height, g.out_width, 3) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
         self._ck(lib().s360_frame_download_equirect_of(self.h, int(age), _p(out)))
         return out
+
+    def uploads_complete(self):
+        """Blocks until every upload enqueued so far has left its host buffer (needed for buffers from pinned_empty only)."""
+        self._ck(lib().s360_frame_uploads_complete(self.h))
 
     def set_sweep_mode(self, mode):
         """'latency' (default) or 'throughput' — which sweep kernel PixFlow uses (bit-identical results)."""

@@ -135,16 +135,18 @@ def run_case(exe, work, rig_path, name, timeout=900, more_args=(), env=None):
     return out
 
 
-def run_stream(exe, work, rig_path, name, timeout=900):
+def run_stream(exe, work, rig_path, name, timeout=900, first=0, count=None, more_args=(), env=None):
     """The frames of a case as ONE stream in one process (host/TestRenderStereoPanorama --num_frames N: temporal state kept
-    on the device, frame pipelining, overlapped I/O); returns the output directory. Equirects eqr_<frame>.png as run_case."""
+    on the device, frame pipelining, overlapped I/O); returns the output directory. Equirects eqr_<frame>.png as run_case.
+    `first` / `count`: only that part of the case's frames (all inputs are written); `more_args`: e.g. --num_streams."""
     frames, extra = CASES[name]
     imgs, out, mdir = write_inputs(work, rig_path, frames)
-    cmd = [exe, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", frames[0], "--num_frames", str(len(frames)),
+    count = len(frames) - first if count is None else count
+    cmd = [exe, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", frames[first], "--num_frames", str(count),
            "--output_data_dir", out, "--output_equirect_path", os.path.join(out, "eqr_%s.png"),
            "--eqr_width", str(EQR_W), "--eqr_height", str(EQR_H), "--final_eqr_width", str(FINAL),
-           "--final_eqr_height", str(FINAL)] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+           "--final_eqr_height", str(FINAL)] + extra + list(more_args)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, "%s as a stream: rc %d\n%s" % (name, r.returncode, r.stderr[-2000:])
     return out
 

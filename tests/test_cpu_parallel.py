@@ -83,7 +83,7 @@ def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
                S360_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--slots", "1", "--inflight", "1"], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+                        "--slots", "1", "--inflight", "1", "--video-frames", "14"], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
@@ -93,3 +93,40 @@ def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
     assert d["checked"] is True and d["config"]["rccl_ranks"] == 2
     assert d["checked_frames"] == 2 and d["mismatching_frames_all_ranks"] == 0  # 1 frame in flight per rank, both ranks counted
     assert d["single_frame"]["rccl_ranks"] == 2 and d["single_frame"]["equals_single_gpu_frame"] is True
+    # configs[4] on N GPUs: one stream per rank
+    v = d["video_stream"]
+    assert "error" not in v and v["streams"] == 2 and len(v["ms_per_frame_of_each_stream"]) == 2 and v["frames_per_s"] > 0
+
+
+def test_two_streams_on_two_gpus_equal_two_single_runs(tmp_path, emu_programs):
+    """BASELINE configs[4] on N GPUs, the honest form: a stream cannot use more than one GPU, N streams use
+    N. host/TestRenderStereoPanorama --num_frames 3 --num_streams 2 on two (emulated) devices renders frames 7-8 as a stream
+    on device 0 and frame 9 as a stream of its own on device 1 — and writes, file for file, what two separate invocations
+    with those frame ranges write: equirects of all three frames, the state files behind the last frame of each stream."""
+    import hashlib
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
+                                  refprog.CAM / 2048.0)
+    exe = os.path.join(emu_programs, "TestRenderStereoPanorama")
+    name = "three_frames_sharpened"
+    frames = refprog.CASES[name][0]
+    env = dict(os.environ, EMU_DEVICES="2")
+    both = refprog.run_stream(exe, str(tmp_path / "both"), rig, name, more_args=["--num_streams", "2", "--v", "1"], env=env)
+    one = refprog.run_stream(exe, str(tmp_path / "one"), rig, name, first=0, count=2)
+    two = refprog.run_stream(exe, str(tmp_path / "two"), rig, name, first=2, count=1)
+
+    def files(root, frame):
+        d = {"eqr": refprog._digest_png(os.path.join(root, "eqr_%s.png" % frame))}
+        for folder in (os.path.join(root, "flow", frame), os.path.join(root, "debug", frame, "flow_images")):
+            if os.path.isdir(folder):
+                for fn in sorted(os.listdir(folder)):
+                    p = os.path.join(folder, fn)
+                    d[fn] = refprog._digest_png(p) if fn.endswith(".png") else hashlib.sha256(open(p, "rb").read()).hexdigest()
+        return d
+    for f, single in ((frames[0], one), (frames[1], one), (frames[2], two)):
+        a, b = files(both, f), files(single, f)
+        assert a == b, "frame %s: %s" % (f, sorted(k for k in set(a) | set(b) if a.get(k) != b.get(k))[:8])
+    assert len(files(both, frames[1])) > 30 and len(files(both, frames[2])) > 30  # the state behind each stream's last frame
+    # and the first stream's frames are the reference program's chain (frame 9 of the chain has a predecessor, the segment's has not)
+    golden = json.load(open(refprog.GOLDEN))[name]
+    for f in frames[:2]:
+        assert files(both, f)["eqr"] == golden["eqr_%s" % f], f

@@ -87,7 +87,7 @@ typedef void* hipStream_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventBlockingSync = 1, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventBlockingSync = 1, hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 // everything is synchronous here: a kernel has run when its launch returns, copies are memcpy, streams and events are names
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { const char* e = std::getenv("EMU_DEVICES"); *n = e && std::atoi(e) > 0 ? std::atoi(e) : 1; return hipSuccess; }  // EMU_DEVICES: emulated GPUs (multi-GPU host program runs)
