@@ -619,7 +619,9 @@ int main(int argc, char** argv) {
   Flags F;
   F.parse(argc, argv);
   const int streams = std::max(1, F.i("num_streams")), frames = std::max(1, F.i("num_frames"));
-  if (frames > 1) {
+  // (S360_HOST_PINNED=0: developer switch for timing the two ways against each other; the pixels do not depend on it)
+  const char* pinEnv = std::getenv("S360_HOST_PINNED");
+  if (frames > 1 && !(pinEnv && pinEnv[0] == '0')) {
     // a stream's decoders write into page-locked memory: the uploads are DMA transfers straight from the decoded images
     // (set once, before the first image exists; every pngio::Image of this process then lives in such memory)
     pngio::g_pixel_alloc = s360_host_alloc;

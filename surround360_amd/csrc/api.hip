@@ -16,6 +16,18 @@ using namespace s360;
 
 static thread_local std::string g_err;
 
+// live contexts by uid
+namespace {
+std::mutex g_ctxMu;
+std::vector<unsigned long long> g_ctxLive;
+unsigned long long g_ctxNext = 0;
+}  // namespace
+namespace s360 {
+bool context_alive(unsigned long long uid) {
+  std::lock_guard<std::mutex> lk(g_ctxMu);
+  return std::find(g_ctxLive.begin(), g_ctxLive.end(), uid) != g_ctxLive.end();
+}
+}  // namespace s360
 // buffers handed out by s360_host_alloc (page-locked host memory)
 namespace {
 std::mutex g_pinMu;
@@ -84,6 +96,12 @@ static int frame_guard(s360_ctx* c, F&& f) {
 }
 static void need(bool ok, const char* what) {
   if (!ok) throw Error(S360_ERR_INVALID_ARG, what);
+}
+// The sharded frame's split phases (exchange / pole units / gather / composite: comm.cpp) enqueue their RCCL calls on the
+// main stream while frame pipelining runs the pole stage and the composite on the second one: nothing orders the two, so
+// the combination is refused instead of racing (a stream keeps its temporal state on ONE GPU anyway: DESIGN.md section 7).
+static void no_pipelining(s360_ctx* c) {
+  if (c->pipeline) throw Error(S360_ERR_STATE, "the sharded (multi-GPU) frame is not available while frame pipelining is on (s360_set_frame_pipelining)");
 }
 static void h2d(s360_ctx* c, void* d, const void* h, size_t n) {
   S360_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->st));
@@ -264,6 +282,11 @@ int s360_create(s360_ctx** out, int device, const s360_camera* cams, int n_cams,
     delete c;
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_ctxMu);
+    c->uid = ++g_ctxNext;
+    g_ctxLive.push_back(c->uid);
+  }
   *out = c;
   return S360_OK;
 }
@@ -273,6 +296,10 @@ void s360_destroy(s360_ctx* c) {
   if (c->stUp) (void)hipStreamSynchronize(c->stUp);
   if (c->st) (void)hipStreamSynchronize(c->st);
   if (c->st2) (void)hipStreamSynchronize(c->st2);
+  {  // (behind the waits: an ISP object bound to this context may be taken over by another one from here on)
+    std::lock_guard<std::mutex> lk(g_ctxMu);
+    g_ctxLive.erase(std::remove(g_ctxLive.begin(), g_ctxLive.end(), c->uid), g_ctxLive.end());
+  }
   comm_destroy(c);
   c->slots.clear();
   c->flow.reset();
@@ -286,6 +313,10 @@ void s360_destroy(s360_ctx* c) {
   }
   if (c->evPoleSrcFree) (void)hipEventDestroy(c->evPoleSrcFree);
   if (c->stDown) (void)hipStreamDestroy(c->stDown);
+  for (s360_ctx::PackedCache* pc : {&c->sidePk, &c->topPk, &c->botPk})
+    for (auto& e : pc->e)
+      if (e->ready) (void)hipEventDestroy(e->ready);
+  if (c->evMaps) (void)hipEventDestroy(c->evMaps);
   if (c->evDown) (void)hipEventDestroy(c->evDown);
   if (c->evUpHost) (void)hipEventDestroy(c->evUpHost);
   if (c->stUp) {
@@ -693,19 +724,19 @@ int s360_comm_destroy(s360_ctx* c) {
   return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); comm_destroy(c); });
 }
 int s360_frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
-  return frame_guard(c, [&] { need(c && bounds, "null argument"); frame_gather_strips(c, bounds, root); });
+  return frame_guard(c, [&] { need(c && bounds, "null argument"); no_pipelining(c); frame_gather_strips(c, bounds, root); });
 }
 int s360_frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask) {
-  return frame_guard(c, [&] { need(c && bounds && need_mask, "null argument"); frame_exchange_strips(c, bounds, need_mask); });
+  return frame_guard(c, [&] { need(c && bounds && need_mask, "null argument"); no_pipelining(c); frame_exchange_strips(c, bounds, need_mask); });
 }
 int s360_frame_gather_pole_layers(s360_ctx* c, const int owner[4], int root) {
-  return frame_guard(c, [&] { need(c && owner, "null argument"); frame_gather_pole_layers(c, owner, root); });
+  return frame_guard(c, [&] { need(c && owner, "null argument"); no_pipelining(c); frame_gather_pole_layers(c, owner, root); });
 }
 int s360_frame_pole_units(s360_ctx* c, int pole_mask, int use_prev) {
-  return frame_guard(c, [&] { need(c, "null ctx"); frame_pole_units(c, pole_mask, use_prev); });
+  return frame_guard(c, [&] { need(c, "null ctx"); no_pipelining(c); frame_pole_units(c, pole_mask, use_prev); });
 }
 int s360_frame_composite(s360_ctx* c, int pole_mask) {
-  return frame_guard(c, [&] { need(c, "null ctx"); frame_composite(c, pole_mask); });
+  return frame_guard(c, [&] { need(c, "null ctx"); no_pipelining(c); frame_composite(c, pole_mask); });
 }
 int s360_comm_loopback(s360_ctx* c, int src_pair, int dst_pair) {
   return guard(c, [&] { need(c, "null ctx"); comm_loopback(c, src_pair, dst_pair); });
@@ -774,8 +805,13 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     S360_HIP(rc);
     // the frame's sweep error words were snapshotted in front of outDone[b] (render.hpp): a timed-out banded sweep
     // fails THIS frame's download, before the host hands the pixels to an encoder
-    if (errw && (errw[0] | errw[1] | errw[2]))
+    if (errw && (errw[0] | errw[1] | errw[2])) {
+      // reported once: the engines' cumulative error words are reset, so that the frames enqueued from now on are judged on
+      // their own sweeps (frames already in flight carry the snapshot they took)
+      for (FlowEngine* e : {c->flow.get(), c->flow_pole.get(), c->flow_pr.get()})
+        if (e) (void)e->take_error(c->st);
       throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
+    }
   });
 }
 /* ---- page-locked host buffers for streaming hosts ---- */

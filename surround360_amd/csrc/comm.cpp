@@ -187,7 +187,10 @@ void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root) {
     if (owner[u] < 0 || owner[u] == root) continue;
     const size_t bytes = (size_t)W * (u < 2 ? c->g.top_rows : c->g.bottom_rows) * sizeof(uchar4);
     if (me == owner[u]) rc = R.Send(F.poleWarped[u].p, bytes, ncclUint8, root, (ncclComm_t)c->comm, c->st);
-    else if (me == root) rc = R.Recv(F.poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
+    else if (me == root) {
+      rc = R.Recv(F.poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
+      F.poleFrame[u] = F.frames_done;  // this frame's layer (frame_composite refuses an earlier frame's)
+    }
   }
   const ncclResult_t rc2 = R.GroupEnd();
   nccl_ck(rc, "ncclSend/ncclRecv");

@@ -106,4 +106,7 @@ struct ProfScope {
   ~ProfScope() { p.end(h); }
 };
 
+// api.hip: is the context with this uid (s360_ctx::uid, unique per process) still alive?
+bool context_alive(unsigned long long uid);
+
 }  // namespace s360

@@ -19,6 +19,7 @@ struct s360_ctx {
   // execute one after the other in lock order. Recursive: batch entry points call the single-pair ones.
   mutable std::recursive_mutex mu;
   int device = 0;
+  unsigned long long uid = 0;  // unique per process, never reused (what an ISP object binds to)
   hipStream_t st = nullptr;
   // what s360_stream() hands out: the stream created with the context, never swapped (frame_finish replaces `st` by `st2`
   // for its own duration when frame pipelining is on)
@@ -72,8 +73,13 @@ struct s360_ctx {
   s360::DevBuf sideMaps, topMap, botMap;
   // the same maps as the packed remap reads them (render_kernels.hip): per destination pixel one dword, per 64x16 tile
   // the box of source pixels; they also depend on the SOURCE size, so they are (re)built when that is first seen
-  struct PackedMap { s360::DevBuf packed, tiles; int sw = -1, sh = -1; };
-  PackedMap sidePk, topPk, botPk;
+  // (a small cache per map, keyed by the source size: slots or streams whose input sizes alternate do not re-pack, and a
+  // new size never rebuilds buffers another stream of the context may still read; `ready` orders the users after the pack
+  // kernel without a host wait)
+  struct PackedMap { s360::DevBuf packed, tiles; int sw = -1, sh = -1; hipEvent_t ready = nullptr; };
+  struct PackedCache { std::vector<std::unique_ptr<PackedMap>> e; };
+  PackedCache sidePk, topPk, botPk;
   bool maps_ready = false;
+  hipEvent_t evMaps = nullptr;  // behind the kernels that built the float maps (the pack kernels may run on another stream)
   void make_current() const { S360_HIP(hipSetDevice(device)); }
 };

@@ -344,10 +344,13 @@ void* isp_raw_buffer(s360_isp* o, int inW, int inH) {
   o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
   return o->dRaw.p;
 }
-const void* isp_enqueue_on(s360_isp* o, hipStream_t st, int inW, int inH) {
-  if (o->boundStream && o->boundStream != st)
+const void* isp_enqueue_on(s360_isp* o, hipStream_t st, unsigned long long ctxUid, int inW, int inH) {
+  // Bound to the CONTEXT (its uid, never reused), not to the value of its stream handle: once that context has been
+  // destroyed — s360_destroy waits for its upload stream, so nothing of it still runs on this object's buffers — the
+  // object may feed another one; while it lives, a second context is refused.
+  if (o->boundCtx && o->boundCtx != ctxUid && context_alive(o->boundCtx))
     throw Error(S360_ERR_STATE, "an ISP object feeds ONE context (s360_frame_upload_raw): create one per context");
-  o->boundStream = st;
+  o->boundCtx = ctxUid;
   isp_enqueue(o, st, inW, inH);
   return o->dOut.p;
 }

@@ -44,7 +44,7 @@ struct s360_isp {
   int curveNext = 0;
   // s360_frame_upload_raw runs this object's kernels on a context's upload stream over the buffers above: the object
   // belongs to the first context it is used with (another context's stream would race on dRaw / dPlane / ...)
-  hipStream_t boundStream = nullptr;
+  unsigned long long boundCtx = 0;  // uid of the context this object feeds (s360_frame_upload_raw); 0 = none yet
   std::string err;
 };
 
@@ -58,5 +58,5 @@ void isp_process(s360_isp* o, const uint16_t* raw16, int w, int h, void* out);
 void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int w, int h, void* out);
 void isp_release(s360_isp* o);
 void* isp_raw_buffer(s360_isp* o, int inW, int inH);
-const void* isp_enqueue_on(s360_isp* o, hipStream_t st, int inW, int inH);
+const void* isp_enqueue_on(s360_isp* o, hipStream_t st, unsigned long long ctxUid, int inW, int inH);
 }  // namespace s360

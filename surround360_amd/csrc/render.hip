@@ -265,7 +265,7 @@ void frame_upload_raw(s360_ctx* c, s360_isp* isp, int which, const uint16_t* raw
   const int w = inW / isp->cfg.resize, h = inH / isp->cfg.resize;
   const size_t n = (size_t)w * h;
   upload_bytes(c, isp_raw_buffer(isp, inW, inH), raw16, (size_t)inW * inH * sizeof(uint16_t));
-  const void* out16 = isp_enqueue_on(isp, c->stUp, inW, inH);
+  const void* out16 = isp_enqueue_on(isp, c->stUp, c->uid, inW, inH);
   F.staging.ensure(n * 4);
   launch_u16_high_byte(c->stUp, static_cast<const unsigned short*>(out16), F.staging.as<uint8_t>(), n * 3);
   if (which >= 0) {  // as frame_upload_side from the staging buffer
@@ -404,19 +404,36 @@ static void ensure_maps(s360_ctx* c) {
     build_spherical_map(c, c->botMap.as<float2>(), c->P.eqr_width, g.bottom_rows, cam, 0.f, (float)(2.0f * M_PI),
                         (float)(-(M_PI / 2.0f)), (float)(-(M_PI / 2.0f - camera_get_fov(&cam))));
   }
+  S360_HIP(hipEventCreateWithFlags(&c->evMaps, hipEventDisableTiming));
+  S360_HIP(hipEventRecord(c->evMaps, c->st));
   c->maps_ready = true;
 }
 
-// coordinates + tile boxes of a cached map for sources of sw x sh (once per rig and source size)
-static void ensure_packed(s360_ctx* c, s360_ctx::PackedMap& pk, const float2* map, int sw, int sh, int dw, int dh, int batch,
-                          hipStream_t st) {
-  if (pk.sw == sw && pk.sh == sh) return;
+// coordinates + tile boxes of a cached map for sources of sw x sh (once per rig and source size): the entry for that size,
+// its users on `st` ordered behind the pack kernel by an event (no host wait in the frame's enqueue path)
+static s360_ctx::PackedMap& ensure_packed(s360_ctx* c, s360_ctx::PackedCache& cache, const float2* map, int sw, int sh, int dw, int dh,
+                                          int batch, hipStream_t st) {
+  for (auto& e : cache.e)
+    if (e->sw == sw && e->sh == sh) {
+      S360_HIP(hipStreamWaitEvent(st, e->ready, 0));
+      return *e;
+    }
+  if (cache.e.size() >= 4) {  // (never seen in practice: a fifth source size for one map. Nothing may still read the oldest entry)
+    S360_HIP(hipDeviceSynchronize());
+    if (cache.e.front()->ready) (void)hipEventDestroy(cache.e.front()->ready);
+    cache.e.erase(cache.e.begin());
+  }
+  if (c->evMaps) S360_HIP(hipStreamWaitEvent(st, c->evMaps, 0));
+  cache.e.emplace_back(new s360_ctx::PackedMap());
+  s360_ctx::PackedMap& pk = *cache.e.back();
   pk.packed.ensure((size_t)batch * dw * dh * sizeof(unsigned));
   pk.tiles.ensure((size_t)batch * remap_packed_tiles(dw, dh) * 16);
   launch_remap_pack_map(st, map, sw, sh, dw, dh, pk.packed.as<unsigned>(), pk.tiles.p, batch);
-  S360_HIP(hipStreamSynchronize(st));  // (once; later frames may use these from another of the context's streams)
+  S360_HIP(hipEventCreateWithFlags(&pk.ready, hipEventDisableTiming));
+  S360_HIP(hipEventRecord(pk.ready, st));
   pk.sw = sw;
   pk.sh = sh;
+  return pk;
 }
 
 // Side stage for pairs [p0,p1) of a set of frame slots: per slot the projections of the cameras those pairs touch and
@@ -478,10 +495,10 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
         if (!need[i]) { ++i; continue; }
         int j = i;
         while (j < P && need[j]) ++j;
-        ensure_packed(c, c->sidePk, c->sideMaps.as<float2>(), F.srcW, F.srcH, camW, camH, P, st);
+        s360_ctx::PackedMap& pk = ensure_packed(c, c->sidePk, c->sideMaps.as<float2>(), F.srcW, F.srcH, camW, camH, P, st);
         launch_remap_cubic_u8c4_packed(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, c->sideMaps.as<float2>() + pn * i,
-                                       c->sidePk.packed.as<unsigned>() + pn * i,
-                                       (const char*)c->sidePk.tiles.p + 16 * remap_packed_tiles(camW, camH) * i,
+                                       pk.packed.as<unsigned>() + pn * i,
+                                       (const char*)pk.tiles.p + 16 * remap_packed_tiles(camW, camH) * i,
                                        F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
         i = j;
       }
@@ -681,9 +698,9 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         if (!F.have_top) throw Error(S360_ERR_STATE, "top image not uploaded");
         F.topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
         const int yfs = rowsT - 1 - c->P.std_alpha_feather_size;
-        ensure_packed(c, c->topPk, c->topMap.as<float2>(), F.topW, F.topH, W, rowsT, 1, st);
+        s360_ctx::PackedMap& pk = ensure_packed(c, c->topPk, c->topMap.as<float2>(), F.topW, F.topH, W, rowsT, 1, st);
         launch_remap_cubic_u8c4_packed(st, F.topSrc.as<uchar4>(), F.topW, F.topH, c->topMap.as<float2>(),
-                                       c->topPk.packed.as<unsigned>(), c->topPk.tiles.p, F.topSph.as<uchar4>(), W, rowsT,
+                                       pk.packed.as<unsigned>(), pk.tiles.p, F.topSph.as<uchar4>(), W, rowsT,
                                        F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xs, extW);
       }
@@ -693,14 +710,14 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         const int yfs = rowsB - 1 - c->P.std_alpha_feather_size;
         if (c->P.enable_pole_removal) {  // TRSP:569-597: the bottom source is the merge of the two bottom cameras
           dev_pole_removal(c, F, use_prev != 0);
-          ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
+          s360_ctx::PackedMap& pk = ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
           launch_remap_cubic_u8c4_packed(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
-                                         c->botPk.packed.as<unsigned>(), c->botPk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
+                                         pk.packed.as<unsigned>(), pk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
                                          F.tab.dev, 2, yfs, c->P.std_alpha_feather_size);
         } else {
-          ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
+          s360_ctx::PackedMap& pk = ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
           launch_remap_cubic_u8c4_packed(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
-                                         c->botPk.packed.as<unsigned>(), c->botPk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
+                                         pk.packed.as<unsigned>(), pk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
                                          F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         }
         launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xs, extW);
@@ -780,6 +797,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
             F.poleWarped[u].ensure(en * sizeof(uchar4));
             dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xs, F.poleFlows[cur].as<float2>() + u * xs, W, rowsOf(u), extW,
                                F.poleWarped[u].as<uchar4>(), H);
+            F.poleFrame[u] = F.frames_done;
           }
       }
       F.extW = extW;
@@ -794,8 +812,8 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       ProfScope ps(prof, "flatten");  // TRSP:864-885
       F.panoTmp.ensure(en * sizeof(uchar4));
       for (int u = 0; u < 4; ++u)
-        if ((composite_mask & (1 << u)) && !F.poleWarped[u].p)
-          throw Error(S360_ERR_STATE, "composite: the warped layer of pole unit " + std::to_string(u) + " is neither computed nor received");
+        if ((composite_mask & (1 << u)) && (!F.poleWarped[u].p || F.poleFrame[u] != F.frames_done))  // (an earlier frame's layer is not this frame's)
+          throw Error(S360_ERR_STATE, "composite: the warped layer of pole unit " + std::to_string(u) + " of this frame is neither computed nor received");
       for (int e = 0; e < 2; ++e) {
         if (composite_mask & (1 << e)) {
           launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 0,

@@ -52,6 +52,7 @@ struct FrameState {
   unsigned* outErr[2] = {nullptr, nullptr};
   int out_cur = 0;           // buffer of the most recently ENQUEUED frame
   long long frames_done = 0;  // frames enqueued so far
+  long long poleFrame[4] = {-1, -1, -1, -1};  // the frame (value of frames_done) pole unit u's warped layer was computed / received for
   ~FrameState() {
     for (auto& e : outDone) if (e) (void)hipEventDestroy(e);
     for (auto& p : outErr) if (p) (void)hipHostFree(p);

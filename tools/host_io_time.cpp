@@ -8,6 +8,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <dlfcn.h>
 #include "../host/png_io.hpp"
 using clk = std::chrono::steady_clock;
 static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
@@ -48,5 +49,42 @@ int main(int argc, char** argv) {
     auto t1 = clk::now();
     std::printf("PNG decode from %-9s %.0f ms (%d x %d)%s\n", (d + ":").c_str(), ms(t0, t1), im.w, im.h, (im.px.size() == px.size() && std::equal(px.begin(), px.end(), im.px.begin())) ? "" : "  MISMATCH");
     std::remove(f.c_str());
+  }
+  // page-locked memory (s360_host_alloc) against the heap as the place decoded pixels go: a camera image's decode writes and
+  // re-reads its rows (unfilter), 17 decoders at once
+  void* lib = dlopen(argc > 2 ? argv[2] : "surround360_amd/libs360.so", RTLD_NOW);
+  if (lib) {
+    auto alloc = (void* (*)(size_t))dlsym(lib, "s360_host_alloc");
+    auto release = (void (*)(void*))dlsym(lib, "s360_host_free");
+    const std::string f = "/dev/shm/s360_io_cam.png";
+    pngio::write(f, px.data(), 2048, 2048, 3, 1, 0);
+    for (int pinned = 0; pinned < 2 && alloc; ++pinned) {
+      pngio::g_pixel_alloc = pinned ? alloc : nullptr;
+      pngio::g_pixel_free = pinned ? release : nullptr;
+      {
+        std::vector<pngio::Image> im(17);
+        for (int rep = 0; rep < 2; ++rep) {  // (the second pass decodes into the buffers of the first: what a stream does)
+          auto t0 = clk::now();
+          std::vector<std::thread> th;
+          for (int k = 0; k < 17; ++k) th.emplace_back([&, k] { pngio::read_into(f, false, im[k]); });
+          for (auto& t : th) t.join();
+          auto t1 = clk::now();
+          std::printf("17 x 2048^2 PNG decode, 17 threads, %s memory, pass %d: %.0f ms\n", pinned ? "page-locked" : "heap", rep, ms(t0, t1));
+        }
+        pngio::Pixels a((size_t)64 << 20), b((size_t)64 << 20);
+        auto t0 = clk::now();
+        std::memcpy(a.data(), px.data(), a.size());
+        auto t1 = clk::now();
+        std::memcpy(b.data(), a.data(), a.size());
+        auto t2 = clk::now();
+        std::printf("memcpy 64 MB heap -> %s: %.1f GB/s; %s -> %s: %.1f GB/s\n", pinned ? "page-locked" : "heap", 0.0671 / (ms(t0, t1) / 1e3),
+                    pinned ? "page-locked" : "heap", pinned ? "page-locked" : "heap", 0.0671 / (ms(t1, t2) / 1e3));
+      }
+    }
+    pngio::g_pixel_alloc = nullptr;
+    pngio::g_pixel_free = nullptr;
+    std::remove(f.c_str());
+  } else {
+    std::printf("(libs360.so not found: page-locked decode not timed)\n");
   }
 }
