@@ -162,9 +162,13 @@ void load_png_into(const std::string& path, bool keep_alpha, pngio::Image& im) {
     die(e.what());
   }
 }
+// Deflate threads of one PNG encoder. A stream keeps up to three encoders running beside 51 decoder threads and the HIP
+// runtime's own threads, which feed the GPU its ~1000 launches per frame: unbounded (one thread per 2 MB band, ~100 for an 8K
+// equirect) the encoders crowd those out and the GPU waits for its host.
+static int g_png_threads = 0;  // 0 = one per band, up to the hardware threads
 void save_png(const std::string& path, const uint8_t* px, int w, int h, int c) {
   try {
-    pngio::write(path, px, w, h, c);
+    pngio::write(path, px, w, h, c, 1, g_png_threads);
   } catch (const std::exception& e) {
     die(e.what());
   }
@@ -491,13 +495,14 @@ static int run_job(const Flags& flags) {
   // Up to two finished frames are PNG-encoded and written while the next one renders (one encoder per frame, parallel
   // deflate inside it): an 8192 x 8192 file takes longer to encode and write than the frame takes to render.
   const size_t outBytes = (size_t)g.out_width * g.out_height * 3;
-  constexpr int kEncoders = 3;
+  constexpr int kMaxEncoders = 4;
+  const char* encEnv = std::getenv("S360_ENCODERS");  // (developer switch)
+  const int kEncoders = std::max(1, std::min(kMaxEncoders, encEnv ? std::atoi(encEnv) : 3));
   // (page-locked in stream mode: the finished frame comes back in one DMA transfer instead of through the runtime's
   // staging buffers — 201 MB per 8K frame)
-  pngio::Pixels outBuf[kEncoders + 1];
-  std::thread encoder[kEncoders + 1];  // encoder[i] owns outBuf[i] while it runs
-  for (auto& b : outBuf) b.resize(numFrames > 1 ? outBytes : 0);
-  outBuf[0].resize(outBytes);
+  pngio::Pixels outBuf[kMaxEncoders + 1];
+  std::thread encoder[kMaxEncoders + 1];  // encoder[i] owns outBuf[i] while it runs
+  for (int i = 0; i <= kEncoders; ++i) outBuf[i].resize(numFrames > 1 || i == 0 ? outBytes : 0);
   int cur = 0;  // the buffer the next download goes to
   double renderEnd = renderStart, stateEnd = renderStart;
   double tDecode = 0, tUpload = 0, tFetch = 0, tJoin = 0;  // where the host thread of a stream spends its time (--v 1)
@@ -619,6 +624,11 @@ int main(int argc, char** argv) {
   Flags F;
   F.parse(argc, argv);
   const int streams = std::max(1, F.i("num_streams")), frames = std::max(1, F.i("num_frames"));
+  if (frames > 1) {
+    const char* e = std::getenv("S360_PNG_THREADS");  // (developer switch)
+    const int hw = (int)std::thread::hardware_concurrency();
+    g_png_threads = e ? std::atoi(e) : std::max(4, hw / 8);
+  }
   // (S360_HOST_PINNED=0: developer switch for timing the two ways against each other; the pixels do not depend on it)
   const char* pinEnv = std::getenv("S360_HOST_PINNED");
   if (frames > 1 && !(pinEnv && pinEnv[0] == '0')) {

@@ -295,12 +295,18 @@ inline void chunk(OutFile& f, const char* type, const uint8_t* data, size_t len)
   f.put(c, 4);
 }
 
-// px: B,G,R(,A) rows. Filter "up"/"sub" is skipped (type 0) — encode speed matters more than size here: the 8192x8192
-// equirect is 201 MB of scanlines and a single zlib stream at level 1 takes ~6 s on one core, 35x the GPU time of the
-// frame. The scanlines are therefore deflated in parallel (pigz-style): bands of rows become independent raw-deflate
-// streams that end with a sync flush (byte-aligned, no final block) — concatenated they are ONE valid deflate stream;
-// the zlib header and the Adler-32 of the whole image (adler32_combine of the bands) are added around them.
+// px: B,G,R(,A) rows. Encode speed matters more than size here: the 8192x8192 equirect is 201 MB of scanlines, and a stream
+// has one to encode every ~110 ms beside 17 camera images to decode. The scanlines are deflated in parallel (pigz-style):
+// bands of rows become independent raw-deflate streams that end with a sync flush (byte-aligned, no final block) —
+// concatenated they are ONE valid deflate stream; the zlib header and the Adler-32 of the whole image (adler32_combine of
+// the bands) are added around them. Filter and deflate settings are those of cv::imwrite's PngEncoder at its defaults
+// (Sub on every row, Z_BEST_SPEED, Z_RLE): measured on an 8K frame of the synthetic world's kind of content with 4 threads,
+// Sub + Z_RLE 0.60 s / 90 MB against 1.6 s / 107 MB for Up + the default strategy (tools/host_io_time) — the end-to-end
+// stream was bound by exactly this CPU time (profiles/r04_v2_end_to_end_*).
 // fill_row(y, dst) writes the (w * c * depth / 8) bytes of scanline y in PNG order (R,G,B(,A); 16-bit samples big-endian).
+// (experiment switches of tools/host_io_time; the writer's defaults are what the measurements chose)
+inline int g_write_strategy = Z_RLE;  // zlib strategy
+inline int g_write_filter = 1;        // 1 Sub on every row (what cv::imwrite's PngEncoder sets), 2 Up (Sub on the first row)
 template <typename FillRow>
 inline void write_rows(const std::string& path, FillRow fill_row, int w, int h, int c, int depth, int level, int max_threads) {
   if (c != 3 && c != 4) throw std::runtime_error("png write: 3 or 4 channels only");
@@ -313,19 +319,18 @@ inline void write_rows(const std::string& path, FillRow fill_row, int w, int h, 
   auto compress_band = [&](int bi) {
     Band& B = bands[bi];
     const int y0 = bi * rows_per_band, y1 = std::min(h, y0 + rows_per_band);
-    // Scanlines are filtered before they are deflated: Up (each byte minus the one above it) — Sub for the image's first
-    // row — costs one pass and, on camera-like content at deflate level 1, halves both the deflate time and the file
-    // (25 MB of the synthetic world: 12.1 MB in 616 ms unfiltered, 5.6 MB in 271 ms; libpng's writer, which cv::imwrite
-    // uses, picks a filter per row by heuristic). A band's first row needs the row above the band, which fill_row gives.
+    // Scanlines are filtered before they are deflated (Sub: each byte minus the one a pixel to its left; g_write_filter 2:
+    // Up, whose first row of a band needs the row above the band, which fill_row gives).
     std::vector<uint8_t> raw((size_t)(y1 - y0) * stride);
     const size_t nb = stride - 1, px_bytes = (size_t)c * (depth / 8);
     std::vector<uint8_t> rowA(nb), rowB(nb);
     uint8_t *cur = rowA.data(), *prev = rowB.data();
-    if (y0 > 0) fill_row(y0 - 1, prev);
+    const bool sub = g_write_filter == 1;
+    if (y0 > 0 && !sub) fill_row(y0 - 1, prev);
     uint8_t* o = raw.data();
     for (int y = y0; y < y1; ++y) {
       fill_row(y, cur);
-      if (y == 0) {
+      if (y == 0 || sub) {
         *o++ = 1;  // Sub
         for (size_t i = 0; i < std::min(px_bytes, nb); ++i) o[i] = cur[i];
         for (size_t i = px_bytes; i < nb; ++i) o[i] = (uint8_t)(cur[i] - cur[i - px_bytes]);
@@ -340,7 +345,7 @@ inline void write_rows(const std::string& path, FillRow fill_row, int w, int h, 
     B.adler = adler32(1L, raw.data(), (uInt)raw.size());
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { B.ok = false; return; }
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, g_write_strategy) != Z_OK) { B.ok = false; return; }
     B.z.resize(deflateBound(&zs, (uLong)raw.size()) + 64);
     zs.next_in = raw.data();
     zs.avail_in = (uInt)raw.size();

@@ -570,13 +570,39 @@ __global__ __launch_bounds__(256) void k_crop_overlaps(const uchar4* __restrict_
   out[((size_t)j * camH + y) * overlapW + x] = proj[((size_t)cam * camH + y) * camW + x0 + x];
 }
 
+// remap_cubic_f32c2_at for a sample whose y coordinate is an INTEGER — every sample of renderLazyNovelView's flow remap:
+// the lazy buffer's rows are (float)v (TRSP:279-283), so the fraction index of y is 0 and the bicubic weights of rows 0, 2
+// and 3 are (+-)0 * cx[q], the weights of row 1 are 1 * cx[q] (cubic_coeffs(0) = {0, 1, 0, 0} exactly; the 2-D table is
+// cy[r] * cx[q]). The reference still forms all sixteen products: twelve of them are +-0 (flows are finite), its sum
+// o = row0; o += row1; o += row2; o += row3 therefore equals row 1's four-term sum — also when that is a zero, whose sign
+// nobody downstream can see (x + 0*t, sqrt(f.x^2 + f.y^2)). One row of taps is loaded instead of four: 2 of the 8 16-byte
+// loads and 8 of the 32 multiply-adds per sample. Samples whose taps touch the border, or with a fractional y, take
+// the general function.
+__device__ __forceinline__ float2 remap_cubic_f32c2_introw_at(const float2* __restrict__ src, int sw, int sh, float mx,
+                                                              float my, const float* __restrict__ tab) {
+  int sx, sy, fxy;
+  remap_coord(mx, my, &sx, &sy, &fxy);
+  const unsigned width1 = sw - 3 > 0 ? sw - 3 : 0, height1 = sh - 3 > 0 ? sh - 3 : 0;
+  if ((fxy >> 5) == 0 && (unsigned)sx < width1 && (unsigned)sy < height1) {
+    typedef float f4a8_ __attribute__((ext_vector_type(4), aligned(8)));
+    const f4a8_* V = reinterpret_cast<const f4a8_*>(src + (size_t)(sy + 1) * sw + sx);
+    const f4a8_ ab = V[0], cd = V[1];
+    const float4 wr = *reinterpret_cast<const float4*>(tab + fxy * 16 + 4);  // row 1 of the 4x4 weights: 1 * cx[q]
+    float2 o;
+    o.x = ab.x * wr.x + ab.z * wr.y + cd.x * wr.z + cd.z * wr.w;
+    o.y = ab.y * wr.x + ab.w * wr.y + cd.y * wr.z + cd.w * wr.w;
+    return o;
+  }
+  return remap_cubic_f32c2_at(src, sw, sh, mx, my, tab);
+}
+
 // ------------------------------------------------------------------------------------------
 // One lazily rendered novel-view sample (renderLazyNovelView, NovelView.cpp:174-224).
 struct LazySample { uchar4 c; float mag; };
 __device__ __forceinline__ LazySample lazy_sample(const uchar4* __restrict__ img, const float2* __restrict__ flow,
                                                   int ow, int oh, float xs, float ys, float t,
                                                   const DevTables& T) {
-  const float2 f = remap_cubic_f32c2_at(flow, ow, oh, xs, ys, T.bicubic_f);
+  const float2 f = remap_cubic_f32c2_introw_at(flow, ow, oh, xs, ys, T.bicubic_f);
   const float wx = xs + f.x * t, wy = ys + f.y * t;
   LazySample s;
   s.c = remap_cubic_u8c4_at(img, ow, oh, wx, wy, T.bicubic_i);
@@ -609,13 +635,18 @@ __device__ __forceinline__ uchar4 combine_lazy(uchar4 cL, uchar4 cR, float flowM
                      (unsigned char)trunc_u8((float)cL.y * wL + (float)cR.y * wR),
                      (unsigned char)trunc_u8((float)cL.z * wL + (float)cR.z * wR), 255);
 }
-// grid: (ceil(stripW/64), camH, 2*(p1-p0)); z = 2*pairLocal + eye
-__global__ __launch_bounds__(64) void k_novel_view(const uchar4* __restrict__ overlaps,
-                                                   const float2* __restrict__ flows, uchar4* __restrict__ strips,
-                                                   NovelViewParams nv, int p0, DevTables T) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
-  if (u >= nv.stripW) return;
-  const int j = (int)(blockIdx.z >> 1), pair = p0 + j, eye = blockIdx.z & 1;
+// A workgroup renders a 64 x 4 tile of one eye's strip of one pair (grid: (ceil(stripW/64), ceil(camH/4), 2*(p1-p0)),
+// z = 2*pairLocal + eye), the tiles taken in XCD-aware order: the bicubic footprints of vertically adjacent rows overlap
+// by three rows, and a tile's neighbours meet in the same L2 (one wave per 64-pixel row segment in launch order fetched
+// 3-5 x the images' and flows' bytes through the fabric: profiles/r03_v10_pmc_fetch_write.txt).
+constexpr int NV_TW = 64, NV_TH = 4;
+__global__ __launch_bounds__(NV_TW* NV_TH) void k_novel_view(const uchar4* __restrict__ overlaps,
+                                                             const float2* __restrict__ flows, uchar4* __restrict__ strips,
+                                                             NovelViewParams nv, int p0, DevTables T) {
+  const TileId tile = xcd_tile();
+  const int u = tile.x * NV_TW + (threadIdx.x & (NV_TW - 1)), v = tile.y * NV_TH + (threadIdx.x >> 6);
+  if (u >= nv.stripW || v >= nv.camH) return;
+  const int j = (int)(tile.z >> 1), pair = p0 + j, eye = tile.z & 1;
   const size_t isz = (size_t)nv.overlapW * nv.camH;
   const uchar4* imgL = overlaps + isz * j;
   const uchar4* imgR = overlaps + isz * (nv.numLocal + j);
@@ -1575,8 +1606,8 @@ void launch_crop_overlaps(hipStream_t st, const uchar4* proj, int camW, int camH
 void launch_novel_view(hipStream_t st, const uchar4* overlaps, const float2* flows, uchar4* strips,
                        const NovelViewParams& nv, int p0, int p1, const DevTables& T) {
   if (p1 <= p0) return;
-  hipLaunchKernelGGL(k_novel_view, dim3(cdiv(nv.stripW, 64), nv.camH, 2 * (p1 - p0)), dim3(64), 0, st, overlaps, flows,
-                     strips, nv, p0, T);
+  hipLaunchKernelGGL(k_novel_view, dim3(cdiv(nv.stripW, NV_TW), cdiv(nv.camH, NV_TH), 2 * (p1 - p0)), dim3(NV_TW * NV_TH), 0, st,
+                     overlaps, flows, strips, nv, p0, T);
 }
 void launch_assemble_pano(hipStream_t st, const uchar4* strips_eye, int P, int camH, int stripW, float offset,
                           uchar4* pano, int eqrW, int eqrH) {

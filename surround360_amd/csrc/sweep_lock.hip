@@ -30,6 +30,17 @@
 // lines the coming pixels will sample so that the compute waves' bilinear gathers hit L1; wave NW+1 ("hand-off")
 // polls the granules of the band above and publishes the band's last row. The compute waves' memory queue
 // only ever holds their own gathers.
+//
+// Measured and NOT adopted (round 4; profiles/r04_v1_lock_window_*): the LDS window of I1-gradient texels that the
+// throughput kernel uses (sweep_quad.hip), here filled per chunk by the bulk service wave, the taps as two ds_read2_b64 kept
+// in flight across the barrier (s_waitcnt lgkmcnt(2)), global gathers as the per-step fallback. Bit-exact, and on the same
+// box slower than this kernel: 8K frame 136.2 against 133.3 ms (sweeps 120.2 / 117.2), stream 111.5 against 108.9 ms per
+// frame, micro-benchmark within 1 % on the large levels and 4-8 % slower on the small ones. The gathers it replaces already hit
+// L1 — the bulk wave touches the lines the coming pixels will sample — and their latency sits behind the barrier; what the
+// window adds (placement reductions and six loads per chunk in the service wave that shares a SIMD with a compute wave,
+// the window test in front of every tap) costs more than the ~100 cycles of L1-against-LDS latency it saves. The "290
+// cycles waiting for gathers" of round 3's instrumented build were an artefact of its timestamps (s_memtime returns
+// through the same counter as the LDS reads).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -42,14 +53,6 @@
 #include "sweep_common.hpp"
 
 namespace s360 {
-
-#ifdef S360_WAVE_EMULATION
-// developer statistics (CPU emulation only): lane-steps that evaluated / that left the window for global memory
-unsigned long long g_lock_rounds = 0, g_lock_fallbacks = 0;
-#define S360_LSTAT(v) __atomic_fetch_add(&(v), 1ull, __ATOMIC_RELAXED)
-#else
-#define S360_LSTAT(v)
-#endif
 
 namespace {
 
@@ -69,21 +72,6 @@ constexpr unsigned long long kEmptyGranule = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kLag = 5;     // steps between consecutive compute waves of a workgroup (>= 5: see preload below)
 constexpr int kRingK = 32;  // LDS ring depth in steps (two chunks)
 constexpr int kChunk = 16;  // steps per bulk-service transfer (16 steps x 4 rows = 64 lanes)
-// The LDS window of I1-gradient texels (one per compute wave, double-buffered by chunk; same coordinates as in
-// sweep_quad.hip): a wave's four rows lag one column per row, so x + y is the same for the four pixels of a step and spans
-// 16 values over a chunk. LDS row jy holds image row wy0 + jy, column ju holds image column (wu0 + ju) - (wy0 + jy); a
-// bilinear cell (x0, y0) is inside iff 0 <= y0 - wy0 <= kLWinRows - 2 and 0 <= x0 + y0 - wu0 <= kLWinCols - 3, and its
-// texels are [jy][ju], [jy][ju + 1], [jy + 1][ju + 1], [jy + 1][ju + 2]. The bulk service wave places the window of chunk
-// cc + 1 around the cells that chunk's incoming flows point at (it holds the chunk's records in registers anyway), loads it
-// with six coalesced 8-byte loads per lane and commits it — texels and placement — 13 steps into chunk cc; the compute
-// wave's gather round then is two ds_read2_b64 (~100 cycles, in front of the barrier) instead of two L1/L2 gathers
-// (500+ cycles, 290 of them exposed behind the barrier). A wave any of whose relevant taps leaves the window gathers from
-// global memory at that step: same texels, same bits.
-constexpr int kLWinRows = 12;  // 4 rows + the cell's second row + slack
-constexpr int kLWinCols = 32;
-constexpr int kLWinStride = 34;  // texels per LDS row (68 dwords: the four rows of a step on distinct banks)
-constexpr int kLNoWin = 0x3fffffff;
-constexpr int kWinCommitPhase = 12;  // (t - 1) & 15 of the workgroup's clock: every request of the events is >= 4 steps old
 
 struct __attribute__((aligned(16))) LkIn {
   float4 rec;   // {I0x (NaN: pixel not updated), I0y, blurredFlow.x, blurredFlow.y}
@@ -98,14 +86,8 @@ typedef float f2n __attribute__((ext_vector_type(2)));
 // across steps; __syncthreads()/the s_barrier builtin would drain them on gfx9-class targets).
 #ifdef S360_WAVE_EMULATION
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
-__device__ __forceinline__ void wg_barrier_taps_in_flight() { __syncthreads(); }
 #else
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// The same with the wave's LAST TWO LDS instructions — the two ds_read2_b64 of the window taps, issued right in front of
-// it — still in flight: a wave's LDS instructions complete in order, so everything it wrote for the other waves is done
-// when at most two are outstanding, and the taps' latency hides behind the barrier like the gathers' did. (The loops hold
-// no scalar memory loads, the other user of that counter: checked in the ISA.)
-__device__ __forceinline__ void wg_barrier_taps_in_flight() { asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory"); }
 #endif
 
 template <int K>
@@ -140,10 +122,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
   __shared__ LkIn s_in[NW][kRingK][4];
   __shared__ float2 s_out[NW][kRingK][4];
   __shared__ float2 s_up0[kRingK];
-  __shared__ f2n s_win[NW][2][kLWinRows * kLWinStride];
-  __shared__ int2 s_winpos[NW][2];
   __shared__ unsigned s_ticket;
-  static_assert(kLag * (NW - 1) + 4 + 4 <= kWinCommitPhase + 1 && kWinCommitPhase <= 13, "window commit must sit in the quiet steps");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_ticket = atomicAdd(hdr, 1u) + 1u;  // the counter starts at 0xFFFFFFFF (memset 0xFF)
@@ -192,21 +171,10 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     const float2* upBase = j == 0 ? &s_up0[0] : &s_out[j > 0 ? j - 1 : 0][0][3];
     const int upStride = j == 0 ? 1 : 4, upShift = j == 0 ? 0 : 3;
     const int xLane = dir > 0 ? -rr : w - 1 + rr, xSign = dir > 0 ? 1 : -1;
-    // the lanes whose evaluation is read by the selection (steady steps; elsewhere the left proposal depends on the column)
-    const unsigned long long lanesRel = __ballot(role < 3 && (bank == 0 || bank == 1 || (bank == 2 && hasUp)));
-    int wy0 = kLNoWin, wu0 = 0;  // placement of this chunk's window (wave-uniform)
-    int winOff = 0;  // texel offset of this chunk's buffer in s_win[j] (an index, not a pointer: a pointer variable into LDS
-                     // that is re-assigned in the loop degrades to a generic one, and the taps to flat loads)
     auto step = [&](auto steady, int t) {
       constexpr bool ST = decltype(steady)::value;
       TS(0);
       const int s = t - kLag * j;
-      if ((s & (kChunk - 1)) == 0 && s >= 0 && s < nsteps) {  // a new chunk: its window was committed >= 2 barriers ago
-        const int2 wp = s_winpos[j][(s >> 4) & 1];
-        wy0 = __builtin_amdgcn_readfirstlane(wp.x);
-        wu0 = __builtin_amdgcn_readfirstlane(wp.y);
-        winOff = ((s >> 4) & 1) * (kLWinRows * kLWinStride);
-      }
       const bool run = ST || (s >= 0 && s < nsteps && !S360_DBG(fc, 16));
       const LkIn in = nin;
       const float2 upl = nup;
@@ -225,7 +193,6 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       float2 up;
       float ax, ay, xR, yR;
       f4a8 ta, tb;
-      bool tapsInFlight = false;
       if (any) {
         // up neighbour in every lane (needed by the selection below)
         up.x = from_row_above<0xF>(upl.x, fl.x);
@@ -246,36 +213,16 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         const int x0 = (int)mx, y0 = (int)my;
         xR = __builtin_amdgcn_fractf(mx);
         yR = __builtin_amdgcn_fractf(my);
-        const int jy = y0 - wy0, ju = x0 + y0 - wu0;
-        const bool outw = (unsigned)jy > (unsigned)(kLWinRows - 2) || (unsigned)ju > (unsigned)(kLWinCols - 3);
-        const unsigned long long rel = ST ? __ballot(take) & lanesRel
-                                          : __ballot(take && role < 3 && (bank == 0 || (bank == 1 && xi > 0) || (bank == 2 && hasUp)));
-        S360_LSTAT(g_lock_rounds);
-        if (S360_DBG(fc, 64)) {  // (timing experiment: 64 = no gathers)
-          ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
-        } else if (__builtin_expect((__ballot(outw) & rel) == 0ull, 1) && !S360_DBG(fc, 256)) {
-          // (lanes that do not matter read slot 0; 24-bit multiply-add: full rate)
-          const int off = winOff + (outw ? 0 : (int)__umul24((unsigned)jy, (unsigned)kLWinStride) + ju);
-          const f2n* wbase = &s_win[j][0][0];
-          ta = *reinterpret_cast<const f4a8*>(wbase + off);
-          tb = *reinterpret_cast<const f4a8*>(wbase + off + kLWinStride + 1);
-          tapsInFlight = true;
-        } else {
-          S360_LSTAT(g_lock_fallbacks);
-          const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+        const unsigned boff = (unsigned)(__umul24(y0, w) + x0) << 3;
+        if (!S360_DBG(fc, 64)) {  // (timing experiment: 64 = no gathers)
           ta = *reinterpret_cast<const f4a8*>(G1b0 + boff);
           tb = *reinterpret_cast<const f4a8*>(G1b1 + boff);
-#ifndef S360_WAVE_EMULATION
-          // (keeps the two paths apart: with identical tails the compiler sinks the loads into the join block and reads
-          // through a generic pointer — flat loads, which wait on the vector-memory path even when the window hits.
-          // The rare path waits for its gathers here instead of behind the barrier.)
-          asm volatile("; window miss: texels from global memory" : "+v"(ta), "+v"(tb));
-#endif
+        } else {
+          ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
         }
       }
       TS(1);
-      if (tapsInFlight) wg_barrier_taps_in_flight();
-      else wg_barrier();
+      wg_barrier();
       TS(2);
       // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
       // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.
@@ -377,6 +324,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     const int st = lane & 15, rr = lane >> 4;
     const f4n* __restrict__ recN = reinterpret_cast<const f4n*>(rec);
     const f2n* __restrict__ flowN = reinterpret_cast<const f2n*>(flow);
+    const unsigned* __restrict__ G1w = reinterpret_cast<const unsigned*>(G1);
     int rowOff[NW];
     bool rowOk[NW];
     float rowY[NW];
@@ -391,6 +339,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     }
     f4n rRec[NW];
     f2n rFlow[NW];
+    unsigned sink = 0, pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
     const int nchunks = (nsteps + kChunk - 1) / kChunk;
     auto load_chunk = [&](int j, int cidx) {
       const int x = col(cidx * kChunk + st - rr);
@@ -409,79 +358,37 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       const int xi = sidx - rr;
       if (rowOk[j] && xi >= 0 && xi < w && sidx < nsteps) flow[rowOff[j] + col(xi)] = s_out[j][sidx & (kRingK - 1)][rr];
     };
-    // The window of the chunk whose records / flows are in rRec / rFlow (chunk C of compute wave j): placed around the
-    // cells its incoming flows point at — pixels that are not updated do not count, a chunk without updated pixels gets no
-    // window — and requested as six coalesced 8-byte loads per lane (two window rows per wave-wide load).
-    f2n wv[NW][kLWinRows / 2];
-    int wpy[NW], wpu[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) { wpy[j] = kLNoWin; wpu[j] = 0; }
-    const char* __restrict__ G1b = reinterpret_cast<const char*>(G1);
-    auto win_issue = [&](int j, int C) {
-      const int sidx = C * kChunk + st, xi = sidx - rr;
-      int ymin = 0x7fffffff, umin = 0x7fffffff, ymax = -1, umax = -1;
-      if (rowOk[j] && xi >= 0 && xi < w && sidx < nsteps && rRec[j].x == rRec[j].x) {
-        const float mx = __builtin_amdgcn_fmed3f((float)col(xi) + (rFlow[j].x + 0.0f), 0.0f, c.wm2);
-        const float my = __builtin_amdgcn_fmed3f(rowY[j] + (rFlow[j].y + 0.0f), 0.0f, c.hm2);
-        const int x0 = (int)mx, y0 = (int)my;
-        ymin = ymax = y0;
-        umin = umax = x0 + y0;
-      }
-      // wave-wide minima / maxima: inside the 16-lane DPP rows by row_shr 1, 2, 4, 8 (lane 15 of a row then holds the row's
-      // value), across the four rows by v_readlane and scalar min / max
-      auto row_red = [&](int v, bool mx) -> int {
-#define S360_ROW_SHR_STEP(SH)                                                                                      \
-  {                                                                                                                \
-    const int o = __builtin_amdgcn_update_dpp(v, v, 0x110 + SH, 0xF, 0xF, false); /* lanes without a source keep v */ \
-    v = mx ? max(v, o) : min(v, o);                                                                                \
-  }
-        S360_ROW_SHR_STEP(1) S360_ROW_SHR_STEP(2) S360_ROW_SHR_STEP(4) S360_ROW_SHR_STEP(8)
-#undef S360_ROW_SHR_STEP
-        const int a = __builtin_amdgcn_readlane(v, 15), b2 = __builtin_amdgcn_readlane(v, 31);
-        const int c2 = __builtin_amdgcn_readlane(v, 47), d = __builtin_amdgcn_readlane(v, 63);
-        return mx ? max(max(a, b2), max(c2, d)) : min(min(a, b2), min(c2, d));
-      };
-      ymin = row_red(ymin, false); umin = row_red(umin, false);
-      ymax = row_red(ymax, true); umax = row_red(umax, true);
-      wpy[j] = kLNoWin;
-      if (ymax < ymin) return;
-      wpy[j] = ymin - max(0, (kLWinRows - (ymax - ymin + 2)) >> 1);
-      wpu[j] = umin - max(0, (kLWinCols - (umax - umin + 3)) >> 1);
-      const int jc = lane & 31, jr = lane >> 5;
-#pragma unroll
-      for (int i = 0; i < kLWinRows / 2; ++i) {
-        const int Y = wpy[j] + 2 * i + jr, X = wpu[j] + jc - Y;
-        wv[j][i] = *reinterpret_cast<const f2n*>(G1b + ((unsigned)(__umul24(min(max(Y, 0), h - 1), w) + min(max(X, 0), w - 1)) << 3));
-      }
-    };
-    auto win_commit = [&](int j, int C) {  // texels and placement of chunk C's window -> LDS (buffer C & 1)
-      if (wpy[j] != kLNoWin) {
-        const int jc = lane & 31, jr = lane >> 5;
-#pragma unroll
-        for (int i = 0; i < kLWinRows / 2; ++i) s_win[j][C & 1][(2 * i + jr) * kLWinStride + jc] = wv[j][i];
-      }
-      if (lane == 0) s_winpos[j][C & 1] = make_int2(wpy[j], wpu[j]);
-    };
     // The service work of compute wave j entering chunk cc (chunk cc-1 is complete and its ring slots are free) is
-    // spread over consecutive steps, so that no step's share outlasts the compute waves' own step: this wave
+    // spread over four consecutive steps, so that no step's share outlasts the compute waves' own step: this wave
     // shares a SIMD with a compute wave at lower priority, and the whole workgroup waits for it at every barrier
     // (one 150-instruction event per chunk cost ~0.9 us on the steps it fell on, ~15 % of the sweep).
-    //   phase 0: chunk cc+1 (in registers since the previous event) -> LDS ring
-    //   phase 1: placement of chunk cc+1's window, its loads requested
-    //   phase 2: chunk cc+2 -> registers            phase 3: results of chunk cc-1 -> global memory
-    // and, for all compute waves at once at a quiet step of the workgroup's clock (kWinCommitPhase: everything requested
-    // above is >= 4 steps old, so that the wait in front of it costs nothing): chunk cc+1's window -> LDS.
+    //   phase 0: chunk cc+1 (in registers since the previous event) -> LDS ring, and where its pixels will sample
+    //            I1's gradients (predicted by the blurred flow and by the current flow)
+    //   phase 1: chunk cc+2 -> registers            phase 2: results of chunk cc-1 -> global memory
+    //   phase 3: touch the predicted gradient lines, so that the compute waves' gathers find them in L1
+    int po[NW][4];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) po[j][0] = po[j][1] = po[j][2] = po[j][3] = 0;
     auto phase = [&](int j, int cc, int ph) {
       if (S360_DBG(fc, 8)) return;
       const bool wr = cc + 1 < nchunks;
       if (ph == 0) {
-        if (wr) write_chunk(j, cc + 1);
+        if (wr) {
+          const float xf = (float)col((cc + 1) * kChunk + st - rr);
+          const Foot fa = footprint(w, xf + rRec[j].z, rowY[j] + rRec[j].w, c);
+          const Foot fb = footprint(w, xf + rFlow[j].x, rowY[j] + rFlow[j].y, c);
+          po[j][0] = 2 * fa.off; po[j][1] = 2 * (fa.off + w); po[j][2] = 2 * fb.off; po[j][3] = 2 * (fb.off + w);
+          write_chunk(j, cc + 1);
+        }
       } else if (ph == 1) {
-        if (wr) win_issue(j, cc + 1);
-      } else if (ph == 2) {
         if (cc + 2 < nchunks) load_chunk(j, cc + 2);
-      } else {
+      } else if (ph == 2) {
         if (cc >= 1) flush_chunk(j, cc - 1);
+      } else {
+        sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;  // previous round (long since landed)
+        if (wr && !S360_DBG(fc, 4)) {
+          pf0 = G1w[po[j][0]]; pf1 = G1w[po[j][1]]; pf2 = G1w[po[j][2]]; pf3 = G1w[po[j][3]];
+        }
       }
     };
     // prologue: chunk 0 into LDS, chunk 1 into registers
@@ -491,8 +398,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
     for (int j = 0; j < NW; ++j) {
       phase(j, -1, 0);
       phase(j, -1, 1);
-      win_commit(j, 0);  // (waits for the window's loads: nothing runs yet)
-      phase(j, -1, 2);
+      phase(j, -1, 3);
     }
     for (int t = -1; t < T; ++t) {
       wg_barrier();
@@ -502,24 +408,17 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         const int ph = (s - 1) & (kChunk - 1);
         if (s >= 1 && ph < 4) phase(j, (s - 1) >> 4, ph);
       }
-      // A commit at iteration t is visible to the compute waves behind the barrier of iteration t + 1, i.e. to the tap
-      // reads of step t + 2: wave 0 enters chunk cc + 1 at t = 16 (cc + 1), the others kLag steps later each.
-      if (t >= 1 && ((t - 1) & (kChunk - 1)) == kWinCommitPhase && !S360_DBG(fc, 8)) {
-        const int C = ((t - 1) >> 4) + 1;
-        if (C < nchunks) {
-#pragma unroll
-          for (int j = 0; j < NW; ++j) win_commit(j, C);
-        }
-      }
     }
     wg_barrier();
-    // epilogue: the chunks the loop did not reach (chunk cc-1 is flushed at local step 16 cc + 4)
+    // epilogue: the chunks the loop did not reach (chunk cc-1 is flushed at local step 16 cc + 3)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int sl = T - 1 - kLag * j;
-      const int done = sl >= 4 ? ((sl - 4) >> 4) : 0;  // chunks [0, done) were flushed in the loop
+      const int done = sl >= 3 ? ((sl - 3) >> 4) : 0;  // chunks [0, done) were flushed in the loop
       for (int cidx = done; cidx < nchunks; ++cidx) flush_chunk(j, cidx);
     }
+    sink ^= pf0 ^ pf1 ^ pf2 ^ pf3;
+    if (sink == 0x9e3779b9u && lane == 0) hdr[1] = sink;  // keeps the prefetch loads alive; never true in practice
     return;
   }
 

@@ -56,4 +56,5 @@ stream = 1e3 * (time.perf_counter() - t) / (n - 6)
 digest = int(np.asarray(ctx.download_equirect(), np.uint64).sum())
 print("%s: single frame %.2f ms (sweeps %.2f ms), stream %.2f ms per frame, checksum %d" % (
     os.path.basename(_capi.LIB_PATH), single, pr.get("flow_sweep", (0, 0))[0] / 2, stream, digest))
+print("  kernel families, ms per frame: " + ", ".join("%s %.3f" % (k, v[0] / 2) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][0])))
 ctx.close()

@@ -35,6 +35,22 @@ int main(int argc, char** argv) {
     std::printf("fwrite + fclose of 82 MB to %-9s %.0f ms (%.0f MB/s)\n", (d + ":").c_str(), ms(t0, t1), 82.0 * 1.048576 / (ms(t0, t1) / 1e3));
     std::remove(f.c_str());
   }
+  for (int strat : {Z_DEFAULT_STRATEGY, Z_RLE, Z_HUFFMAN_ONLY})
+    for (int filt : {2, 1}) {
+      pngio::g_write_strategy = strat;
+      pngio::g_write_filter = filt;
+      const std::string f = "/dev/shm/s360_io_time_v.png";
+      auto t0 = clk::now();
+      pngio::write(f, px.data(), w, h, 3, 1, 4);
+      auto t1 = clk::now();
+      FILE* fp = std::fopen(f.c_str(), "rb"); std::fseek(fp, 0, SEEK_END); const long n = std::ftell(fp); std::fclose(fp);
+      pngio::Image im = pngio::read(f, false);
+      std::printf("strategy %d filter %s, 4 threads: %.0f ms, %.1f MB%s\n", strat, filt == 1 ? "Sub" : "Up", ms(t0, t1), n / 1048576.0,
+                  (im.px.size() == px.size() && std::equal(px.begin(), px.end(), im.px.begin())) ? "" : "  MISMATCH");
+      std::remove(f.c_str());
+    }
+  pngio::g_write_strategy = Z_RLE;
+  pngio::g_write_filter = 1;
   for (const std::string& d : {dir, std::string("/dev/shm")}) {
     const std::string f = d + "/s360_io_time.png";
     for (int threads : {0, 16, 4}) {
@@ -58,7 +74,9 @@ int main(int argc, char** argv) {
     auto release = (void (*)(void*))dlsym(lib, "s360_host_free");
     const std::string f = "/dev/shm/s360_io_cam.png";
     pngio::write(f, px.data(), 2048, 2048, 3, 1, 0);
-    for (int pinned = 0; pinned < 2 && alloc; ++pinned) {
+    void* probe = alloc ? alloc(4096) : nullptr;  // (no HIP device: only the heap is timed)
+    if (probe) release(probe);
+    for (int pinned = 0; pinned < (probe ? 2 : 1) && alloc; ++pinned) {
       pngio::g_pixel_alloc = pinned ? alloc : nullptr;
       pngio::g_pixel_free = pinned ? release : nullptr;
       {

@@ -19,7 +19,6 @@
 
 using namespace s360;
 namespace s360 { extern unsigned long long g_quad_rounds, g_quad_fallbacks, g_quad_chunks, g_quad_fills; }
-namespace s360 { extern unsigned long long g_lock_rounds, g_lock_fallbacks; }
 
 namespace {
 PixFlowConsts consts() {  // OpticalFlowFactory.h:26-41
@@ -159,8 +158,6 @@ int main(int argc, char** argv) {
     if (kernel == "quad" && g_quad_rounds)
       std::printf("quad window: %llu rounds, fallback fraction %.4f , %llu chunks, %llu fills\n", g_quad_rounds / 64,
                   (double)g_quad_fallbacks / (double)g_quad_rounds, g_quad_chunks / 64, g_quad_fills / 64);
-    if (kernel == "lock" && g_lock_rounds)
-      std::printf("lock window: %llu lane-steps, fallback fraction %.4f\n", g_lock_rounds, (double)g_lock_fallbacks / (double)g_lock_rounds);
     flow = want;  // the backward sweep continues from the forward sweep's result, as in the pipeline
   }
   return 0;
