@@ -54,6 +54,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SWEEP_BYTES_PER_PX = 48  # a sweep reads 40 B + writes 8 B per pixel-level
 
 
+def host_cpus():
+    """CPUs this process may use: os.cpu_count() cut down to the control group's quota (the GPU boxes are containers with 16 CPUs
+    of a 256-thread host: /sys/fs/cgroup/cpu.max = 1600000 100000)."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max" and int(p) > 0:
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = max(1, min(n, q // p))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
 def pyramid_levels(w, h):
     """PixFlow.h:477-491 on the x0.5 downscaled input."""
     cw, ch = int(w * 0.5), int(h * 0.5)
@@ -90,7 +109,7 @@ def cpu_baseline_8k(side, top, bottom, rig_path=RIG, flags=None):
     sec = time.time() - t0
     st = f.stage_seconds()
     return out, {"value": 1.0 / sec, "unit": "frames/s", "cores": 18, "kind": "port",
-                 "host_cores_available": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
+                 "host_cores_available": host_cpus(), "host_hardware_threads": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
                  "stage_seconds": {k: round(v, 2) for k, v in st.items()},
                  "sample": "CPU restatement of Surround360 (OpenCV-free oracle, -O3, no FMA): ONE full 8K frame of the bench "
                            "workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low), reference thread shape = 14 "
@@ -239,7 +258,7 @@ def cpu_baseline_reference(side, top, bottom, rig_path=RIG, flags=None, timeout=
         Image.MAX_IMAGE_PIXELS = None
         got = np.ascontiguousarray(np.asarray(Image.open(eqr))[:, :, ::-1])
         return got, {"value": 1.0 / sec, "unit": "frames/s", "cores": max(1, peak - 1), "kind": "reference",
-                     "host_cores_available": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
+                     "host_cores_available": host_cpus(), "host_hardware_threads": os.cpu_count() or 1, "seconds_per_frame": round(sec, 2),
                      "sample": "the reference's own TestRenderStereoPanorama program (its sources compiled over stand-ins for "
                                "OpenCV / Eigen / folly / gflags / glog: oracle/_ref, built with the optimisation flags of the reference's own CMakeLists.txt:34 (-O3 -mavx -funroll-loops), no FMA) rendering ONE full 8K frame of "
                                "the bench workload (eqr 8400x4096 -> 8192x8192, top+bottom, pixflow_low, sharpening as benched) as one process: 17 PNG "

@@ -164,7 +164,8 @@ void load_png_into(const std::string& path, bool keep_alpha, pngio::Image& im) {
 }
 // Deflate threads of one PNG encoder. A stream keeps up to three encoders running beside 51 decoder threads and the HIP
 // runtime's own threads, which feed the GPU its ~1000 launches per frame: unbounded (one thread per 2 MB band, ~100 for an 8K
-// equirect) the encoders crowd those out and the GPU waits for its host.
+// equirect) the encoders crowd those out and the GPU waits for its host — on the GPU boxes the process has 16 CPUs of a
+// 256-thread machine (profiles/r04_v2_end_to_end_*).
 static int g_png_threads = 0;  // 0 = one per band, up to the hardware threads
 void save_png(const std::string& path, const uint8_t* px, int w, int h, int c) {
   try {
@@ -626,8 +627,8 @@ int main(int argc, char** argv) {
   const int streams = std::max(1, F.i("num_streams")), frames = std::max(1, F.i("num_frames"));
   if (frames > 1) {
     const char* e = std::getenv("S360_PNG_THREADS");  // (developer switch)
-    const int hw = (int)std::thread::hardware_concurrency();
-    g_png_threads = e ? std::atoi(e) : std::max(4, hw / 8);
+    // three encoders and 51 decoder threads share the CPUs the process may use: half of them per encoder
+    g_png_threads = e ? std::atoi(e) : std::max(2, pngio::available_cpus() / 2);
   }
   // (S360_HOST_PINNED=0: developer switch for timing the two ways against each other; the pixels do not depend on it)
   const char* pinEnv = std::getenv("S360_HOST_PINNED");

@@ -314,6 +314,7 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   if (o->dev.sharpen) {
     o->dLp.ensure(n * 3 * sizeof(float));
     o->dScratch.ensure(n * 3 * sizeof(float));
+    o->dState.ensure((size_t)3 * std::max(w, h) * sizeof(float));
   }
   IspFrameBufs B;
   B.plane = o->dPlane.as<float>();
@@ -323,6 +324,7 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   B.img = o->dImg.as<float>();
   B.lp = o->dLp.as<float>();
   B.scratch = o->dScratch.as<float>();
+  B.state = o->dState.as<float>();
   B.flag = o->dFlag.as<unsigned char>();
   B.curveH = cur->h_.as<float>();
   B.curveV = cur->v_.as<float>();

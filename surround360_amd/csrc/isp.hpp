@@ -18,7 +18,7 @@ struct IspDev {
   float noiseCore, amount[3], maxVal, alpha;
 };
 struct IspFrameBufs {
-  float *plane, *gV, *gH, *green, *img, *lp, *scratch;
+  float *plane, *gV, *gH, *green, *img, *lp, *scratch, *state;  // state: 3 * max(w, h) floats (IIR hand-over between passes)
   unsigned char* flag;
   const float *curveH, *curveV, *lut;
   const unsigned long long* exptab;
@@ -36,7 +36,7 @@ struct s360_isp {
   s360_isp_config cfg;
   s360::IspDev dev;
   std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
-  s360::DevBuf dLut, dExp, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dOut, dPacked;
+  s360::DevBuf dLut, dExp, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dState, dOut, dPacked;
   // vignette curves per output size (curveHAtPixel / curveVAtPixel): a rig's side and pole cameras may differ in
   // resolution, so a few sizes are kept instead of rebuilding (and synchronising the upload stream) at every switch
   struct Curves { int w = -1, h = -1; s360::DevBuf h_, v_; };

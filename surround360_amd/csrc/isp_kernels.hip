@@ -241,43 +241,126 @@ __global__ __launch_bounds__(256) void k_isp_color(const float* __restrict__ p, 
 }
 
 // ---- IIR low pass (Filter.h:38-90): v = ip * (1 - alpha) + v * alpha along the row, then back; reflected ends -------
-// One thread per (row, channel): `scratch` holds the causal pass ([rows][w][3]); the anticausal pass writes lp.
-__global__ __launch_bounds__(64) void k_isp_iir_rows(const float* __restrict__ img, float* __restrict__ scratch,
-                                                     float* __restrict__ lp, int w, int h, float alpha, float maxVal) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= h * 3) return;
-  const int i = t / 3, k = t - i * 3;
-  const float* src = img + (size_t)i * w * 3 + k;
-  float* buf = scratch + (size_t)i * w * 3 + k;
-  float* dst = lp + (size_t)i * w * 3 + k;
+// A first-order recurrence per (row, channel) — then per (column, channel) — that bit-exactness forbids re-associating: 6144
+// chains of 2048 dependent steps for a 2048^2 image. What can be taken away is everything that is not the chain. Each
+// direction is two kernels (causal, then anticausal continuing from the causal pass's last value, handed over in `state`:
+// a kernel boundary makes the intermediate image visible).
+//   * rows: the first version walked a row with one thread per (row, channel): every load of a wave touched 64 different
+//     rows, 0.97 ms per image. Now a wave owns 21 rows (63 chains) and takes them in tiles of 64 positions: the tile — 21
+//     segments of 192 consecutive floats — comes in as coalesced loads (the next tile's are requested before this one is
+//     walked), is transposed through LDS (row stride 195 floats: the 63 lanes of a step fall on 63 different banks), walked
+//     in place, and leaves as coalesced stores;
+//   * columns: a chain per thread is already coalesced (consecutive threads = consecutive floats of a row), but every step
+//     waited for its own load, 1.28 ms per image; now the loads of the next 32 rows are in flight while 32 steps run.
+// Measured per 2048^2 image: profiles/r04_v3_isp_kernel_stats.txt.
+constexpr int IR_ROWS = 21, IR_T = 64, IR_STRIDE = 195, IR_Q = IR_ROWS * 3;  // IR_Q wave-wide loads per tile
+// causal (ANTI false): in = image, out[m] = state after consuming in[reflect(m + 1)], m = 0 .. w-1, starting from in[0];
+// anticausal (ANTI true): in = the causal pass's output, out[m] = clamp(state after consuming in[reflect(m - 1)]), m = w-1 .. 0
+template <bool ANTI>
+__global__ __launch_bounds__(64) void k_isp_iir_rows_t(const float* __restrict__ in, float* __restrict__ out,
+                                                       float* __restrict__ state, int w, int h, float alpha, float maxVal) {
+  __shared__ float s_t[IR_ROWS * IR_STRIDE];
+  const int lane = threadIdx.x;
+  const int r = lane / 3, k = lane - 3 * r;  // this lane's chain (lane 63 has none)
+  const int row0 = blockIdx.x * IR_ROWS;
+  const int i = row0 + r;
+  const bool chain = lane < IR_Q && i < h;
   const float ia = 1.0f - alpha;
-  float v = src[0];
-  for (int j = 1; j <= w; ++j) {
-    v = src[(size_t)reflecti(j, w) * 3] * ia + v * alpha;
-    buf[(size_t)reflecti(j - 1, w) * 3] = v;
+  const size_t pitch = (size_t)w * 3;
+  float v = 0.0f;
+  if (chain) v = ANTI ? state[(size_t)i * 3 + k] : in[(size_t)i * pitch + k];
+  const int ntiles = (w + IR_T - 1) / IR_T;
+  float regs[IR_Q];
+  // element q * 64 + lane of a tile = row q / 3, float (q % 3) * 64 + lane of its 192-float segment
+  auto request = [&](int tile) {
+    const int m0 = tile * IR_T;
+#pragma unroll
+    for (int q = 0; q < IR_Q; ++q) {
+      const int rr = q / 3, e = (q % 3) * 64 + lane;
+      const int p = e / 3, ch = e - 3 * p;
+      int pos = m0 + p + (ANTI ? -1 : 1);
+      pos = reflecti(pos, w);
+      pos = min(max(pos, 0), w - 1);  // (positions behind the image's end are never walked)
+      const int ii = min(row0 + rr, h - 1);
+      regs[q] = in[(size_t)ii * pitch + (size_t)pos * 3 + ch];
+    }
+  };
+  request(ANTI ? ntiles - 1 : 0);
+  for (int tt = 0; tt < ntiles; ++tt) {
+    const int tile = ANTI ? ntiles - 1 - tt : tt;
+    const int m0 = tile * IR_T;
+    __syncthreads();  // (the previous tile has left LDS)
+#pragma unroll
+    for (int q = 0; q < IR_Q; ++q) s_t[(q / 3) * IR_STRIDE + (q % 3) * 64 + lane] = regs[q];
+    __syncthreads();
+    if (tt + 1 < ntiles) request(ANTI ? tile - 1 : tile + 1);  // in flight while this tile is walked
+    if (chain) {
+      float* t = &s_t[r * IR_STRIDE + k];
+      const int n = min(IR_T, w - m0);
+      if (n == IR_T) {
+#pragma unroll 8
+        for (int pp = 0; pp < IR_T; ++pp) {
+          const int p = ANTI ? IR_T - 1 - pp : pp;
+          v = t[3 * p] * ia + v * alpha;
+          t[3 * p] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+        }
+      } else {
+        for (int pp = 0; pp < n; ++pp) {
+          const int p = ANTI ? n - 1 - pp : pp;
+          v = t[3 * p] * ia + v * alpha;
+          t[3 * p] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IR_Q; ++q) {
+      const int rr = q / 3, e = (q % 3) * 64 + lane;
+      const int p = e / 3;
+      if (row0 + rr < h && m0 + p < w) out[(size_t)(row0 + rr) * pitch + (size_t)m0 * 3 + e] = s_t[rr * IR_STRIDE + e];
+    }
   }
-  for (int j = w - 2; j >= -1; --j) {
-    v = buf[(size_t)reflecti(j, w) * 3] * ia + v * alpha;
-    dst[(size_t)(j + 1) * 3] = clampf(v, 0.0f, maxVal);
-  }
+  if (!ANTI && chain) state[(size_t)i * 3 + k] = v;
 }
-// One thread per (column, channel), in place on lp (the causal pass reads every row before the anticausal pass
-// rewrites it); consecutive threads are consecutive floats of a row: coalesced.
-__global__ __launch_bounds__(256) void k_isp_iir_cols(float* __restrict__ lp, float* __restrict__ scratch, int w, int h,
-                                                      float alpha, float maxVal) {
+// One thread per (column, channel); IC_U rows per batch of loads, the next batch in flight while this one is walked.
+// In place on `img` is allowed for the anticausal pass only (it reads `in`, a different buffer).
+constexpr int IC_U = 32;
+template <bool ANTI>
+__global__ __launch_bounds__(64) void k_isp_iir_cols_t(const float* __restrict__ in, float* __restrict__ out,
+                                                       float* __restrict__ state, int w, int h, float alpha, float maxVal) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= w * 3) return;
   const size_t pitch = (size_t)w * 3;
   const float ia = 1.0f - alpha;
-  float v = lp[t];
-  for (int i = 1; i <= h; ++i) {
-    v = lp[(size_t)reflecti(i, h) * pitch + t] * ia + v * alpha;
-    scratch[(size_t)reflecti(i - 1, h) * pitch + t] = v;
+  float v = ANTI ? state[t] : in[t];
+  float cur[IC_U], nxt[IC_U];
+  const int nb = (h + IC_U - 1) / IC_U;
+  auto request = [&](int b, float* dst) {
+    const int m0 = b * IC_U;
+#pragma unroll
+    for (int u = 0; u < IC_U; ++u) {
+      int pos = reflecti(m0 + u + (ANTI ? -1 : 1), h);
+      pos = min(max(pos, 0), h - 1);
+      dst[u] = in[(size_t)pos * pitch + t];
+    }
+  };
+  request(ANTI ? nb - 1 : 0, cur);
+  for (int bb = 0; bb < nb; ++bb) {
+    const int b = ANTI ? nb - 1 - bb : bb;
+    const int m0 = b * IC_U;
+    if (bb + 1 < nb) request(ANTI ? b - 1 : b + 1, nxt);
+#pragma unroll
+    for (int uu = 0; uu < IC_U; ++uu) {
+      const int u = ANTI ? IC_U - 1 - uu : uu;
+      if (m0 + u < h) {
+        v = cur[u] * ia + v * alpha;
+        out[(size_t)(m0 + u) * pitch + t] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < IC_U; ++u) cur[u] = nxt[u];
   }
-  for (int i = h - 2; i >= -1; --i) {
-    v = scratch[(size_t)reflecti(i, h) * pitch + t] * ia + v * alpha;
-    lp[(size_t)(i + 1) * pitch + t] = clampf(v, 0.0f, maxVal);
-  }
+  if (!ANTI) state[t] = v;
 }
 
 // ---- unsharp mask with noise coring (Filter.h:92-126) + output conversion (CameraIsp.h:1275-1299) ----------------------
@@ -318,10 +401,12 @@ void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int 
   }
   const unsigned gp = (unsigned)((n + 255) / 256);
   if (d.sharpen) {
-    hipLaunchKernelGGL(k_isp_iir_rows, dim3((h * 3 + 63) / 64), dim3(64), 0, st, B.img, B.scratch, B.lp, w, h, d.alpha,
-                       d.maxVal);
-    hipLaunchKernelGGL(k_isp_iir_cols, dim3((w * 3 + 255) / 256), dim3(256), 0, st, B.lp, B.scratch, w, h, d.alpha,
-                       d.maxVal);
+    // rows: img -> scratch (causal) -> lp (anticausal, clamped); columns: lp -> scratch -> lp
+    const dim3 gr((h + IR_ROWS - 1) / IR_ROWS), gc((w * 3 + 63) / 64);
+    hipLaunchKernelGGL((k_isp_iir_rows_t<false>), gr, dim3(64), 0, st, B.img, B.scratch, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_rows_t<true>), gr, dim3(64), 0, st, B.scratch, B.lp, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_cols_t<false>), gc, dim3(64), 0, st, B.lp, B.scratch, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_cols_t<true>), gc, dim3(64), 0, st, B.scratch, B.lp, B.state, w, h, d.alpha, d.maxVal);
     if (d.outputBpp == 8)
       hipLaunchKernelGGL((k_isp_finish<true, unsigned char>), dim3(gp), dim3(256), 0, st, B.img, B.lp, n, d, B.exptab,
                          (unsigned char*)out);

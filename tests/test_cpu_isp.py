@@ -210,7 +210,10 @@ def test_library_vignette_curves(s360lib):
 
 # ---- the HIP kernels themselves, emulated on the CPU (developer tool: tools/hip_cpu_shim, tools/isp_emulate.cpp) ----
 @pytest.mark.parametrize("case", [("full", 64, 48, 16, 2, 1, 0, 0), ("full", 70, 50, 8, 0, 1, 0, 0),
-                                  ("grbg", 96, 64, 16, 2, 2, 0, 25)], ids=_case_id)
+                                  ("grbg", 96, 64, 16, 2, 2, 0, 25),
+                                  # several 64-position tiles + a remainder, more than 21 rows per wave / 32 rows per batch (the
+                                  # tiled IIR passes); a width below one tile
+                                  ("full", 150, 70, 16, 2, 1, 0, 0), ("full", 40, 34, 8, 2, 1, 0, 0)], ids=_case_id)
 def test_kernels_emulated_on_cpu(oracle, s360lib, case):
     """isp_kernels.hip + isp.cpp compiled with g++ over a stand-in for the HIP runtime, one std::thread per GPU thread:
     the kernels' indexing and float arithmetic (IEEE on both sides, -ffp-contract=off) against the oracle, here where no
