@@ -138,7 +138,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     fastOk = sweep_verify_divisors(st, divs);
   }
-  rec_.ensure(B * n0 * sizeof(float4));
+  rec_.ensure(B * n0 * sizeof(float2));
   // Band hand-off granules + ticket counters of every sweep launch of this call (2 per level): one arena, reset to
   // all-ones ("not written") by ONE memset instead of one per launch.
   auto handoff_bytes = [&](int l) {
@@ -224,18 +224,18 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
       }
     }
     {
-      ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweep records
-      launch_blur_to_records(st, cur, rec_.as<float4>(), wl, hl, nl, B, tFlow, G_.as<float2>(), LA(l), idx,
+      ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweeps' half-records
+      launch_blur_to_records(st, cur, rec_.as<float2>(), wl, hl, nl, B, tFlow, LA(l), idx,
                              reinterpret_cast<unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
     }
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
       void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
       if (sweep_mode_ == 3)
-        launch_sweep_quad(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+        launch_sweep_quad(st, rec_.as<float2>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
       else
-        launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+        launch_sweep_lock(st, rec_.as<float2>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk);
     };
     sweep(cur, +1);

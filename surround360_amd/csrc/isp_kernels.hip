@@ -322,8 +322,11 @@ __global__ __launch_bounds__(64) void k_isp_iir_rows_t(const float* __restrict__
   }
   if (!ANTI && chain) state[(size_t)i * 3 + k] = v;
 }
-// One thread per (column, channel); IC_U rows per batch of loads, the next batch in flight while this one is walked.
-// In place on `img` is allowed for the anticausal pass only (it reads `in`, a different buffer).
+// One thread per (column, channel); IC_U rows per batch of loads, two register banks: while one batch is walked the
+// next one is in flight. A batch's loads are requested in the order the walk consumes them (loads retire in order through one
+// counter: the anticausal pass walks upwards, and a first version that requested its rows top-down waited for the whole batch
+// — and, through a register copy, for the NEXT batch — at every step: 0.47 ms per image against 0.16 for the causal pass).
+// 32 rows per batch: the counter has six bits, and a slot's wait must name the 31 + 32 younger requests behind it exactly.
 constexpr int IC_U = 32;
 template <bool ANTI>
 __global__ __launch_bounds__(64) void k_isp_iir_cols_t(const float* __restrict__ in, float* __restrict__ out,
@@ -333,32 +336,50 @@ __global__ __launch_bounds__(64) void k_isp_iir_cols_t(const float* __restrict__
   const size_t pitch = (size_t)w * 3;
   const float ia = 1.0f - alpha;
   float v = ANTI ? state[t] : in[t];
-  float cur[IC_U], nxt[IC_U];
+  float bankA[IC_U], bankB[IC_U];
   const int nb = (h + IC_U - 1) / IC_U;
+  auto block_of = [&](int bb) { return ANTI ? nb - 1 - bb : bb; };
+  // slot uu of a bank = the uu-th row the walk takes: row m0 + uu (causal) / m0 + IC_U - 1 - uu (anticausal)
   auto request = [&](int b, float* dst) {
     const int m0 = b * IC_U;
 #pragma unroll
-    for (int u = 0; u < IC_U; ++u) {
-      int pos = reflecti(m0 + u + (ANTI ? -1 : 1), h);
-      pos = min(max(pos, 0), h - 1);
-      dst[u] = in[(size_t)pos * pitch + t];
+    for (int uu = 0; uu < IC_U; ++uu) {
+      const int row = m0 + (ANTI ? IC_U - 1 - uu : uu);
+      int pos = reflecti(row + (ANTI ? -1 : 1), h);
+      pos = min(max(pos, 0), h - 1);  // (rows behind the image's end are never walked)
+      dst[uu] = in[(size_t)pos * pitch + t];
     }
   };
-  request(ANTI ? nb - 1 : 0, cur);
-  for (int bb = 0; bb < nb; ++bb) {
-    const int b = ANTI ? nb - 1 - bb : bb;
+  auto walk = [&](int b, const float* src) {
     const int m0 = b * IC_U;
-    if (bb + 1 < nb) request(ANTI ? b - 1 : b + 1, nxt);
+    if (m0 + IC_U <= h) {
+      float res[IC_U];
 #pragma unroll
-    for (int uu = 0; uu < IC_U; ++uu) {
-      const int u = ANTI ? IC_U - 1 - uu : uu;
-      if (m0 + u < h) {
-        v = cur[u] * ia + v * alpha;
-        out[(size_t)(m0 + u) * pitch + t] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+      for (int uu = 0; uu < IC_U; ++uu) {
+        v = src[uu] * ia + v * alpha;
+        res[uu] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+      }
+      // (stores behind the walk: issued between the steps they would count as younger requests and push the waits
+      // beyond what the counter can name)
+#pragma unroll
+      for (int uu = 0; uu < IC_U; ++uu) out[(size_t)(m0 + (ANTI ? IC_U - 1 - uu : uu)) * pitch + t] = res[uu];
+    } else {
+#pragma unroll
+      for (int uu = 0; uu < IC_U; ++uu) {
+        const int row = m0 + (ANTI ? IC_U - 1 - uu : uu);
+        if (row < h) {
+          v = src[uu] * ia + v * alpha;
+          out[(size_t)row * pitch + t] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < IC_U; ++u) cur[u] = nxt[u];
+  };
+  request(block_of(0), bankA);
+  for (int bb = 0; bb < nb; bb += 2) {
+    if (bb + 1 < nb) request(block_of(bb + 1), bankB);
+    walk(block_of(bb), bankA);
+    if (bb + 2 < nb) request(block_of(bb + 2), bankA);
+    if (bb + 1 < nb) walk(block_of(bb + 1), bankB);
   }
   if (!ANTI) state[t] = v;
 }

@@ -140,7 +140,7 @@ unsigned long long g_quad_rounds = 0, g_quad_fallbacks = 0, g_quad_chunks = 0, g
 
 // Persistent waves: the grid is capped (launch_sweep_quad) and a wave that finishes a band takes the next ticket.
 template <bool FAST, int LPP>
-__global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ recAll, const float2* __restrict__ G,
+__global__ __launch_bounds__(64) void k_sweep_quad(const float2* __restrict__ recAll, const float2* __restrict__ G,
                                                    float2* __restrict__ flowAll, unsigned long long* __restrict__ HAll,
                                                    unsigned* __restrict__ hdr, int w, int h, size_t bs, FlowIdx idx,
                                                    int dir, SweepConst c, SweepFast fc, int nb, int B,
@@ -168,7 +168,10 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   const float2* __restrict__ G1 = G + bs * (size_t)__builtin_amdgcn_readfirstlane(idx.i1[b]);  // (wave-uniform: keeps the base in SGPRs)
   const char* __restrict__ G1b0 = reinterpret_cast<const char*>(G1);
   const char* __restrict__ G1b1 = reinterpret_cast<const char*>(G1 + w);
-  const float4* __restrict__ rec = recAll + bs * b;
+  // a pixel's record {I0x | NaN = not updated, I0y, blurredFlow} comes from two planes: I0's gradient (the gradient kernel's
+  // plane of image i0[b]) and the half-record the 15x15 blur wrote {blurredFlow.x | NaN, blurredFlow.y}
+  const float2* __restrict__ rec = recAll + bs * b;
+  const float2* __restrict__ G0 = G + bs * (size_t)__builtin_amdgcn_readfirstlane(idx.i0[b]);
   float2* __restrict__ flow = flowAll + bs * b;
   unsigned long long* __restrict__ H = HAll + (size_t)b * nb * w;
   const unsigned long long* Hin = H + (size_t)band * w;
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
   // The next chunk's records / flows: its kQRows x 16 pixel-steps are dealt to the lanes as items — item i of a lane is
   // row 4 i + (lane >> 4), step lane & 15, i.e. a wave-wide load covers 16 consecutive pixels of four rows — and go
   // through native vector types, which stay in VGPRs through the lambdas' captures (HIP's float4 struct went to scratch).
-  f4r cr[kItems];
+  f2r cg[kItems], cb[kItems];  // I0's gradient, half-record
   f2r cf[kItems];
   const int ioStep = lane & 15;
   int ioOff[kItems];   // y * w of the item's row (clamped rows: never used, see ioOk)
@@ -370,14 +373,17 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
       const int xc = col(sbase + ioStep - (4 * i + (lane >> 4)));
-      cr[i] = *reinterpret_cast<const f4r*>(rec + ioOff[i] + xc);
+      cg[i] = *reinterpret_cast<const f2r*>(G0 + ioOff[i] + xc);
+      cb[i] = *reinterpret_cast<const f2r*>(rec + ioOff[i] + xc);
       cf[i] = *reinterpret_cast<const f2r*>(flow + ioOff[i] + xc);
     }
   };
   auto chunk_store = [&]() {
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-      f4r rv = cr[i];
+      f4r rv;
+      rv.x = cb[i].x == cb[i].x ? cg[i].x : __int_as_float(0x7fc00000);  // (the NaN of a pixel that is not updated moves to .x)
+      rv.y = cg[i].y; rv.z = cb[i].x; rv.w = cb[i].y;
       if (!ioOk[i]) rv.x = __int_as_float(0x7fc00000);  // rows below the image: "not updated", like a pixel below the alpha threshold
       *reinterpret_cast<f4r*>(&s_rec[4 * i + (lane >> 4)][ioStep]) = rv;
       *reinterpret_cast<f2r*>(&s_res[4 * i + (lane >> 4)][ioStep]) = cf[i];
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float4* __restrict__ re
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
       const int xi = sbase + ioStep - (4 * j + (lane >> 4));
-      if (ioOk[j] && xi >= 0 && xi < w && cr[j].x == cr[j].x) {
+      if (ioOk[j] && xi >= 0 && xi < w && cb[j].x == cb[j].x) {
         const int yiJ = band * kQRows + 4 * j + (lane >> 4);
         const Cell k = cell_of_row(dir > 0 ? xi : w - 1 - xi, (float)(dir > 0 ? yiJ : h - 1 - yiJ), cf[j].x + 0.0f, cf[j].y + 0.0f);
         ymin = min(ymin, k.y0); ymax = max(ymax, k.y0);
@@ -594,7 +600,7 @@ int sweep_quad_num_bands(int h, int B) { const int rows = quad_rows(quad_lpp(h, 
 size_t sweep_quad_handoff_bytes(int w, int h, int B) {
   return 256 + (size_t)B * sweep_quad_num_bands(h, B) * w * sizeof(unsigned long long);
 }
-void launch_sweep_quad(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
+void launch_sweep_quad(hipStream_t st, const float2* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast, const unsigned* rowflags) {
   const SweepConst c = make_sweep_const(pc, w, h);

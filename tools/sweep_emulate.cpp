@@ -129,6 +129,18 @@ int main(int argc, char** argv) {
         flow[bs * b + (size_t)y * w + x] = f;
       }
   }
+  // What the kernels read: per flow the half-records {blurredFlow.x | NaN = not updated, blurredFlow.y}; I0's gradient is the
+  // gradient plane of image i0[b] = b (the same planes the OTHER flows sample as their I1) — the records' .x .y take it
+  std::vector<float2> half(bs * B);
+  for (int b = 0; b < B; ++b)
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+      float4& r = rec[bs * b + i];
+      const float2 g0 = G[bs * i0[b] + i];
+      const bool masked = r.x != r.x;
+      r.x = masked ? kNaN : g0.x;
+      r.y = g0.y;
+      half[bs * b + i] = make_float2(masked ? kNaN : r.z, r.w);
+    }
   for (int dir : {1, -1}) {
     want = flow;
     for (int b = 0; b < B; ++b) reference_sweep(rec.data() + bs * b, G.data() + bs * i1[b], want.data() + bs * b, w, h, dir, c);
@@ -137,10 +149,10 @@ int main(int argc, char** argv) {
     FlowIdx idx{i0.data(), i1.data()};
     if (kernel == "lock") {
       std::vector<unsigned char> handoff(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), 0xFF);
-      launch_sweep_lock(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast);
+      launch_sweep_lock(nullptr, half.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast);
     } else {
       std::vector<unsigned char> handoff(sweep_quad_handoff_bytes(w, h, B), 0xFF);
-      launch_sweep_quad(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,
+      launch_sweep_quad(nullptr, half.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,
                         useRowflags ? rowflags.data() : nullptr);
     }
     size_t bad = 0, changed = 0;

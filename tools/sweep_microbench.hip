@@ -27,6 +27,17 @@ static FlowIdx make_idx(int B) {  // flow b: image b against image (b + B) mod 2
   CK(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
   return FlowIdx{d, d + B};
 }
+// what the kernels read per flow and pixel: {blurredFlow.x | NaN = not updated, blurredFlow.y}; hrec keeps round 3's four floats
+// {I0x | NaN, I0y, blurredFlow} for the generator's sake (I0's gradient now comes from the gradient plane of image i0[b])
+static std::vector<float> half_records(const std::vector<float>& hrec) {
+  std::vector<float> hh(hrec.size() / 2);
+  for (size_t i = 0; i < hrec.size() / 4; ++i) {
+    const bool masked = hrec[4 * i] != hrec[4 * i];
+    hh[2 * i] = masked ? __builtin_nanf("") : hrec[4 * i + 2];
+    hh[2 * i + 1] = hrec[4 * i + 3];
+  }
+  return hh;
+}
 static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, int reps) {
   const size_t n = (size_t)w * h;
   std::mt19937 rng(1234);
@@ -51,14 +62,15 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, in
   void* hand;
   unsigned* err;
   CK(hipMalloc(&dG, hG.size() * 4));
-  CK(hipMalloc(&drec, hrec.size() * 4));
+  const std::vector<float> hhalf = half_records(hrec);
+  CK(hipMalloc(&drec, hhalf.size() * 4));
   CK(hipMalloc(&dflow, hflow.size() * 4));
   const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   CK(hipMalloc(&hand, hb));
   CK(hipMalloc(&err, 8));
   CK(hipMemset(err, 0, 8));
   CK(hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(drec, hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(drec, hhalf.data(), hhalf.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dflow, hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
   FlowIdx idx = make_idx(B);
   PixFlowConsts pc{0.9f, 0.001f, 0.01f, 0.01f, 0.5f, 0.5f, 0};
@@ -74,9 +86,9 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, in
   auto once = [&](int dir) {
     CK(hipMemsetAsync(hand, 0xFF, hb, st));  // (the library resets one arena per flow call instead)
     if (mode == 2)
-      launch_sweep_lock(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
+      launch_sweep_lock(st, (const float2*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
     else
-      launch_sweep_quad(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
+      launch_sweep_quad(st, (const float2*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
   };
   once(1);
   CK(hipStreamSynchronize(st));
@@ -119,7 +131,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   std::vector<hipStream_t> st(NS);
   const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
-    CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
+    CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 2)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
     CK(hipMalloc(&dA[k], 2 * B * n * 4)); CK(hipMalloc(&dbl[k], B * n * 8));
     {
@@ -129,7 +141,7 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
       CK(hipMemcpy(dbl[k], bl.data(), bl.size() * 4, hipMemcpyHostToDevice));
     }
     CK(hipMemcpy(dG[k], hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(drec[k], hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+    { const std::vector<float> hhalf = half_records(hrec); CK(hipMemcpy(drec[k], hhalf.data(), hhalf.size() * 4, hipMemcpyHostToDevice)); }
     CK(hipMemcpy(dflow[k], hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
     CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
   }
@@ -140,9 +152,9 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   auto once = [&](int k, int dir) {
     CK(hipMemsetAsync(hand[k], 0xFF, hb, st[k]));
     if (mode == 3)
-      launch_sweep_quad(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+      launch_sweep_quad(st[k], (const float2*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
     else
-      launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+      launch_sweep_lock(st[k], (const float2*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
   };
   for (int k = 0; k < NS; ++k) once(k, 1);
   CK(hipDeviceSynchronize());
