@@ -138,7 +138,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     fastOk = sweep_verify_divisors(st, divs);
   }
-  rec_.ensure(B * n0 * sizeof(float2));
+  rec_.ensure(B * n0 * (sweep_mode_ == 3 ? sizeof(float2) : sizeof(float4)));  // half-records / full records (flow_kernels.hpp)
   // Band hand-off granules + ticket counters of every sweep launch of this call (2 per level): one arena, reset to
   // all-ones ("not written") by ONE memset instead of one per launch.
   auto handoff_bytes = [&](int l) {
@@ -225,7 +225,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     {
       ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweeps' half-records
-      launch_blur_to_records(st, cur, rec_.as<float2>(), wl, hl, nl, B, tFlow, LA(l), idx,
+      launch_blur_to_records(st, cur, rec_.p, wl, hl, nl, B, tFlow, sweep_mode_ == 3 ? nullptr : G_.as<float2>(), LA(l), idx,
                              reinterpret_cast<unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
     }
     auto sweep = [&](float2* fl, int dir) {
@@ -235,7 +235,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
         launch_sweep_quad(st, rec_.as<float2>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
       else
-        launch_sweep_lock(st, rec_.as<float2>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+        launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk);
     };
     sweep(cur, +1);

@@ -125,7 +125,11 @@ __global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, 
 //        single-channel plane, computed while the tile is loaded (PixFlow.h:356-366 without the intermediate image).
 // SRC 2: the source is the INTER_LINEAR upscale (resize + scalar multiply, PixFlow.h:176-177) of a smaller image,
 //        evaluated while the tile is loaded: the full-resolution intermediate of the final flow blur never exists.
-// EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453). EPI 2: store the sweeps' half-record
+// EPI 0: store. EPI 1: lowAlphaFlowDiffusion blend (PixFlow.h:444-453). EPI 3: store the sweep record
+//        {I0x | NaN when the pixel is not updated, I0y, blurred.x, blurred.y} instead of the blurred flow (latency sweep kernel:
+//        its bulk service wave shares a SIMD with a compute wave, and one 16-byte load per pixel is what it can afford —
+//        with half-records a single 8K frame took 134.8 instead of 132.9 ms, profiles/r04_v3_frame_time_halfrec.txt).
+//        EPI 2 (throughput sweep kernel): store the sweeps' half-record
 //        {blurred.x | NaN when the pixel is not updated (PixFlow.h:390), blurred.y}; the other half of what a sweep reads per
 //        pixel is I0's gradient, which the gradient kernel has already written (round 3 wrote a 16-byte record {I0x | NaN, I0y,
 //        blurred} here and re-read the gradient to do so: 40 bytes of traffic per pixel-level for an 8-byte result, now 24).
@@ -141,7 +145,7 @@ template <int R, int CN, int EPI, int SRC, int SB_TW = 64, int SB_TH = 16, int N
 __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
                                                  size_t bs /*elements of CN floats per batch*/, BlurTaps taps,
                                                  const float* __restrict__ A, FlowIdx idx,
-                                                 const float2* __restrict__ Gp, float2* __restrict__ rec,
+                                                 const float2* __restrict__ Gp, void* __restrict__ recv,
                                                  float* const* __restrict__ dst_tab, UpSrc up,
                                                  unsigned* __restrict__ rowflags) {
   constexpr int IW = SB_TW + 2 * R, IH = SB_TH + 2 * R;
@@ -152,22 +156,25 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   const TileId tile = xcd_tile();  // neighbouring tiles (shared halo) on the same XCD's L2
   const int tx0 = tile.x * SB_TW, ty0 = tile.y * SB_TH;
   const int vecEnd = ((w * CN) / 8) * 8;
-  // EPI 1 / 2: the epilogue's operands (the two alphas) of this thread's column task are
+  // EPI 1 / 2 / 3: the epilogue's operands (the two alphas, EPI 3 also I0's gradient) of this thread's column task are
   // requested NOW, in front of the tile load, instead of after the column pass: the kernel spent 80 % of its wave time
   // waiting (profiles/r03_v5_pmc_sq.txt) and this was the second of its two exposed memory round trips per tile.
   constexpr int kColTasks = SB_TW * (SB_TH / 4);
   static_assert(EPI == 0 || kColTasks <= NT, "one column task per thread when the epilogue is prefetched");
   float pa0[4] = {0.f, 0.f, 0.f, 0.f}, pa1[4] = {0.f, 0.f, 0.f, 0.f};
+  float2 pg[4];
   if (EPI != 0 && tid < kColTasks) {
     const int lx = tid % SB_TW, ly0 = (tid / SB_TW) * 4, gx = tx0 + lx;
     const size_t b0 = bs * idx.i0[tile.z], b1 = bs * idx.i1[tile.z];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const int gy = ty0 + ly0 + o;
+      pg[o] = make_float2(0.f, 0.f);
       if (gx < w && gy < h) {
         const size_t off = (size_t)gy * w + gx;
         pa0[o] = A[b0 + off];
         pa1[o] = A[b1 + off];
+        if (EPI == 3) pg[o] = Gp[b0 + off];
       }
     }
   }
@@ -312,9 +319,12 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
 #pragma unroll
         for (int k = 0; k < CN; ++k) outv[o][k] = cc * outv[o][k] + (1.0f - cc) * s_in[ly0 + o + R][lx + R][k];
       }
-      if (EPI == 2) {
+      if (EPI == 2 || EPI == 3) {
         const bool upd = pa0[o] > 0.9f && pa1[o] > 0.9f;
-        rec[bs * tile.z + off] = make_float2(upd ? outv[o][0] : __int_as_float(0x7fc00000), outv[o][CN - 1]);
+        if (EPI == 2)
+          static_cast<float2*>(recv)[bs * tile.z + off] = make_float2(upd ? outv[o][0] : __int_as_float(0x7fc00000), outv[o][CN - 1]);
+        else
+          static_cast<float4*>(recv)[bs * tile.z + off] = make_float4(upd ? pg[o].x : __int_as_float(0x7fc00000), pg[o].y, outv[o][0], outv[o][CN - 1]);
         // rows with at least one updated pixel (all-ones = none: the sweeps let bands without any leave at once)
         if (rowflags && upd) rowflags[(size_t)tile.z * h + gy] = 0u;
       } else {
@@ -719,7 +729,7 @@ void launch_motion(hipStream_t st, const uchar4* cur, const uchar4* prev, size_t
 }
 template <int R, int CN, int EPI, int SRC>
 static void launch_sepblur_t(hipStream_t st, const float* src, float* dst, int w, int h, size_t bs, int B,
-                             const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, float2* rec,
+                             const BlurTaps& t, const float* A, const FlowIdx& idx, const float2* Gp, void* rec,
                              float* const* dst_tab = nullptr, const UpSrc& up = UpSrc{}, unsigned* rowflags = nullptr) {
   dim3 blk(64, 4);
   if constexpr (R == 7) {  // 15x15: 32x32 tile — 29 KB of LDS, 1.44x row-pass halo work (64x16: 35 KB, 1.9x; measured 30 % slower);
@@ -762,12 +772,14 @@ void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, s
   if (t.r != 1) throw std::runtime_error("launch_gradients: 3x3 kernel expected");
   launch_sepblur_t<1, 2, 0, 1>(st, I, (float*)G, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
 }
-// 15x15 Gaussian of the flow written as the sweeps' half-records {blurred.x | NaN = not updated, blurred.y} (blurredFlow is
-// only read by the sweeps; the other half of a pixel's record is I0's gradient in the gradient planes)
-void launch_blur_to_records(hipStream_t st, const float2* flow, float2* rec, int w, int h, size_t bs, int B,
-                            const BlurTaps& t, const float* A, const FlowIdx& idx, unsigned* rowflags) {
+// 15x15 Gaussian of the flow written straight into what the sweeps read (blurredFlow is only read by them): half-records
+// {blurred.x | NaN = not updated, blurred.y} for the throughput kernel — the other half of a pixel's record is I0's gradient in
+// the gradient planes — or, with G given, full records {I0x | NaN, I0y, blurred.x, blurred.y} for the latency kernel
+void launch_blur_to_records(hipStream_t st, const float2* flow, void* rec, int w, int h, size_t bs, int B,
+                            const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx, unsigned* rowflags) {
   if (t.r != 7) throw std::runtime_error("launch_blur_to_records: 15x15 kernel expected");
-  launch_sepblur_t<7, 2, 2, 0>(st, (const float*)flow, nullptr, w, h, bs, B, t, A, idx, nullptr, rec, nullptr, UpSrc{}, rowflags);
+  if (G) launch_sepblur_t<7, 2, 3, 0>(st, (const float*)flow, nullptr, w, h, bs, B, t, A, idx, G, rec, nullptr, UpSrc{}, rowflags);
+  else launch_sepblur_t<7, 2, 2, 0>(st, (const float*)flow, nullptr, w, h, bs, B, t, A, idx, nullptr, rec, nullptr, UpSrc{}, rowflags);
 }
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale) {

@@ -40,8 +40,10 @@ void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, in
 void launch_upscale_blur(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw, int dh,
                          size_t dbs, int B, float post_scale, const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t);
-void launch_blur_to_records(hipStream_t st, const float2* flow, float2* rec, int w, int h, size_t bs, int B,
-                            const BlurTaps& t, const float* A, const FlowIdx& idx, unsigned* rowflags = nullptr);
+// G == nullptr: half-records (float2, throughput sweep kernel); G given: full records (float4, latency sweep kernel)
+void launch_blur_to_records(hipStream_t st, const float2* flow, void* rec, int w, int h, size_t bs, int B,
+                            const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx,
+                            unsigned* rowflags = nullptr);
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale);
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
@@ -54,15 +56,17 @@ void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, in
 int sweep_lock_waves();  // compute waves per workgroup of this process (4 unless S360_LOCK_NW says 2 or 8)
 int sweep_lock_num_wgs(int h, int nw);
 size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw);
-// rec: per flow and pixel {blurredFlow.x | NaN = not updated, blurredFlow.y} (launch_blur_to_records); G: the gradient planes
-// per IMAGE — a flow's records are completed with plane idx.i0[b] (I0's gradient), its taps sample plane idx.i1[b]
-void launch_sweep_lock(hipStream_t st, const float2* rec, const float2* G, float2* flow, void* handoff,
+// rec: per flow and pixel {I0x | NaN = not updated, I0y, blurredFlow} (launch_blur_to_records with G); G: the gradient planes
+// per IMAGE — a flow's taps sample plane idx.i1[b]
+void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast);
 // true when the kernel's fast exact division may be used for all of these divisors (checked on the device, cached)
 bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& divisors);
 // throughput-oriented sweep (sweep_quad.hip): one wave per workgroup, 16 rows x 4 or 20 rows x 3 lanes per pixel, two rounds
 size_t sweep_quad_handoff_bytes(int w, int h, int B);
+// rec: per flow and pixel the HALF-record {blurredFlow.x | NaN = not updated, blurredFlow.y} (launch_blur_to_records without G);
+// a pixel's record is completed with I0's gradient from plane idx.i0[b] of G
 void launch_sweep_quad(hipStream_t st, const float2* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast, const unsigned* rowflags = nullptr);

@@ -823,14 +823,39 @@ __global__ __launch_bounds__(256) void k_erode_cross_fixed(const uchar4* __restr
     const uint4* __restrict__ img4 = reinterpret_cast<const uint4*>(img);
     constexpr int GH = (HW + 1 + 3) / 4;  // groups per row pair: columns [x0 - E - 1, x0 - E - 1 + 4 GH)
     static_assert(4 * GH <= HWP + 4, "s_h row too short");
-    for (int t = tid; t < (ERF_TH / 2) * GH; t += 256) {
-      const int j = t / GH, g = t - j * GH;
+    // Two phases per tile part: every group this thread brings in is REQUESTED first, then all of them go to LDS. As one
+    // loop (load, use, store, next) the 7 + 16 iterations were as many serialised memory round trips per tile — and
+    // most tiles are constant and leave right after the load (the same change the flow stencils got in round 3).
+    constexpr int N1 = (ERF_TH / 2) * GH, IT1 = (N1 + 255) / 256;
+    uint4 q0[IT1], q1[IT1];
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+      const int t = tid + 256 * it;
+      const int j = min(t, N1 - 1) / GH, g = min(t, N1 - 1) - j * GH;
       const int gx = x0 - E - 1 + 4 * g, gy = y0 + 2 * j;
-      uint4 p0 = make_uint4(~0u, ~0u, ~0u, ~0u), p1 = p0;
-      if (gx >= 0 && gx < w) {
-        if (gy < h) p0 = img4[((size_t)gy * w + gx) >> 2];
-        if (gy + 1 < h) p1 = img4[((size_t)(gy + 1) * w + gx) >> 2];
+      q0[it] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      q1[it] = q0[it];
+      if (t < N1 && gx >= 0 && gx < w) {
+        if (gy < h) q0[it] = img4[((size_t)gy * w + gx) >> 2];
+        if (gy + 1 < h) q1[it] = img4[((size_t)(gy + 1) * w + gx) >> 2];
       }
+    }
+    constexpr int N2 = VH * (ERF_TW / 4), IT2 = (N2 + 255) / 256;
+    uint4 qv[IT2];
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+      const int t = tid + 256 * it;
+      const int ly = min(t, N2 - 1) / (ERF_TW / 4), g = min(t, N2 - 1) - ly * (ERF_TW / 4);
+      const int gx = x0 + 4 * g, gy = y0 - E + ly;
+      qv[it] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (t < N2 && gx < w && gy >= 0 && gy < h) qv[it] = img4[((size_t)gy * w + gx) >> 2];
+    }
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+      const int t = tid + 256 * it;
+      if (t >= N1) continue;
+      const int j = t / GH, g = t - j * GH;
+      const uint4 p0 = q0[it], p1 = q1[it];
       const unsigned a0[4] = {p0.x >> 24, p0.y >> 24, p0.z >> 24, p0.w >> 24};
       const unsigned a1[4] = {p1.x >> 24, p1.y >> 24, p1.z >> 24, p1.w >> 24};
 #pragma unroll
@@ -842,11 +867,12 @@ __global__ __launch_bounds__(256) void k_erode_cross_fixed(const uchar4* __restr
         }
       }
     }
-    for (int t = tid; t < VH * (ERF_TW / 4); t += 256) {
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+      const int t = tid + 256 * it;
+      if (t >= N2) continue;
       const int ly = t / (ERF_TW / 4), g = t - ly * (ERF_TW / 4);
-      const int gx = x0 + 4 * g, gy = y0 - E + ly;
-      uint4 p = make_uint4(~0u, ~0u, ~0u, ~0u);
-      if (gx < w && gy >= 0 && gy < h) p = img4[((size_t)gy * w + gx) >> 2];
+      const uint4 p = qv[it];
       const unsigned v = (p.x >> 24) | ((p.y >> 24) << 8) | ((p.z >> 24) << 16) | (p.w & 0xff000000u);
       same = same && v == ref * 0x01010101u;
       *reinterpret_cast<unsigned*>(&s_v[ly][4 * g]) = v;
@@ -1020,18 +1046,30 @@ __global__ __launch_bounds__(256) void k_gauss_u8_fixed(const uint8_t* __restric
   if ((w & 3) == 0 && (R & 3) == 3) {
     // four bytes per load: groups start at x0 - R - 1 (a multiple of 4) and lie entirely inside or outside the row
     constexpr int GW = (IW + 1 + 3) / 4;
-    for (int t = threadIdx.x; t < IH * GW; t += 256) {
-      const int ly = t / GW, g = t - ly * GW;
+    // (requested together, then stored: see k_erode_cross_fixed)
+    constexpr int NG = IH * GW, ITG = (NG + 255) / 256;
+    unsigned q[ITG];
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      const int ly = min(t, NG - 1) / GW, g = min(t, NG - 1) - ly * GW;
       const uint8_t* row = a + (size_t)reflect101(y0 - R + ly, h) * w;
       const int gx = x0 - R - 1 + 4 * g;
-      unsigned v4;
       if (gx >= 0 && gx < w) {
-        v4 = *reinterpret_cast<const unsigned*>(row + gx);
+        q[it] = *reinterpret_cast<const unsigned*>(row + gx);
       } else {
-        v4 = 0;
+        unsigned v4 = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v4 |= (unsigned)row[reflect101(gx + k, w)] << (8 * k);
+        q[it] = v4;
       }
+    }
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      if (t >= NG) continue;
+      const int ly = t / GW, g = t - ly * GW;
+      const unsigned v4 = q[it];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int lx = 4 * g + k - 1, v = (int)((v4 >> (8 * k)) & 0xffu);

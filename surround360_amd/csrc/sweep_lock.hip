@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_verify_div(const float* __restrict__ cs
 }
 
 template <int NW, bool FAST>
-__global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float2* __restrict__ rec,
+__global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __restrict__ rec,
                                                               const float2* __restrict__ G, float2* __restrict__ flow,
                                                               unsigned long long* __restrict__ H,
                                                               unsigned* __restrict__ hdr, int w, int h, size_t bs,
@@ -131,7 +131,6 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float2* __re
   const int wgband = (int)(tk / (unsigned)B), b = (int)(tk - (unsigned)wgband * (unsigned)B);
   if (wgband >= nwg) return;
   const float2* __restrict__ G1 = G + bs * idx.i1[b];
-  const float2* __restrict__ G0 = G + bs * idx.i0[b];  // I0's gradient: with the half-record {blurredFlow.x | NaN, blurredFlow.y} a pixel's record
   rec += bs * b;
   flow += bs * b;
   H += (size_t)b * nwg * w;
@@ -323,8 +322,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float2* __re
     // One event per compute wave every 16 steps (staggered by kLag). An event first consumes what was issued at
     // earlier events (>= kLag steps old: no stall), then issues new loads/stores and returns without waiting.
     const int st = lane & 15, rr = lane >> 4;
-    const f2n* __restrict__ recN = reinterpret_cast<const f2n*>(rec);
-    const f2n* __restrict__ g0N = reinterpret_cast<const f2n*>(G0);
+    const f4n* __restrict__ recN = reinterpret_cast<const f4n*>(rec);
     const f2n* __restrict__ flowN = reinterpret_cast<const f2n*>(flow);
     const unsigned* __restrict__ G1w = reinterpret_cast<const unsigned*>(G1);
     int rowOff[NW];
@@ -339,20 +337,18 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float2* __re
       rowOff[j] = y * w;
       rowY[j] = (float)y;
     }
-    f4n rRec[NW];  // .z .w: the half-record as loaded, .x .y: I0's gradient (the NaN moves to .x when the chunk goes to LDS)
+    f4n rRec[NW];
     f2n rFlow[NW];
     unsigned sink = 0, pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
     const int nchunks = (nsteps + kChunk - 1) / kChunk;
     auto load_chunk = [&](int j, int cidx) {
       const int x = col(cidx * kChunk + st - rr);
-      const f2n hb = __builtin_nontemporal_load(recN + rowOff[j] + x);
-      const f2n g0 = g0N[rowOff[j] + x];  // (also sampled as I1's gradient by the flow of the other direction: not streamed past the caches)
-      rRec[j].x = g0.x; rRec[j].y = g0.y; rRec[j].z = hb.x; rRec[j].w = hb.y;
+      rRec[j] = __builtin_nontemporal_load(recN + rowOff[j] + x);
       rFlow[j] = __builtin_nontemporal_load(flowN + rowOff[j] + x);
     };
     auto write_chunk = [&](int j, int cidx) {
       LkIn v;
-      v.rec = make_float4(rRec[j].z == rRec[j].z ? rRec[j].x : __int_as_float(0x7fc00000), rRec[j].y, rRec[j].z, rRec[j].w);
+      v.rec = make_float4(rRec[j].x, rRec[j].y, rRec[j].z, rRec[j].w);
       v.flow = make_float2(rFlow[j].x, rFlow[j].y);
       v.pad = make_float2(0.f, 0.f);
       s_in[j][(cidx * kChunk + st) & (kRingK - 1)][rr] = v;
@@ -494,7 +490,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float2* __re
     bool wantPoll = false;
     if (hasUpWg) {
       const int y0 = dir > 0 ? rows0 : h - 1 - rows0;
-      const float2* __restrict__ rec0 = rec + (size_t)y0 * w;
+      const float4* __restrict__ rec0 = rec + (size_t)y0 * w;
       const float m0 = rec0[col(0)].x, m1 = rec0[col(1)].x;  // (the LDS ring is not filled yet)
       if (m0 == m0 || m1 == m1) {
         ensure(min(w, 2), 26);
@@ -597,7 +593,7 @@ bool sweep_verify_divisors(hipStream_t st, const std::vector<float>& cs) {
 }
 
 template <int NW, bool FAST>
-static void launch_lock_t(hipStream_t st, const float2* rec, const float2* G, float2* flow, unsigned long long* H,
+static void launch_lock_t(hipStream_t st, const float4* rec, const float2* G, float2* flow, unsigned long long* H,
                           unsigned* hdr, unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                           const SweepConst& c, const SweepFast& fc, int nwg) {
   hipLaunchKernelGGL((k_sweep_lock<NW, FAST>), dim3(nwg * B), dim3((NW + 2) * 64), 0, st, rec, G, flow, H, hdr, w,
@@ -609,7 +605,7 @@ static void launch_lock_t(hipStream_t st, const float2* rec, const float2* G, fl
 // specialised steady-state steps 117.0 ms, 8 waves 186 ms; the other builds are gone.)
 int sweep_lock_waves() { return 2; }
 
-void launch_sweep_lock(hipStream_t st, const float2* rec, const float2* G, float2* flow, void* handoff,
+void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast) {
   constexpr int nw = 2;

@@ -19,5 +19,6 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
     python tools/rocpd_pmc.py /tmp/s360_prof/sq/sq_results.db $c | head -22; echo
   done
 } > profiles/${TAG}_pmc_sq.txt 2>> $O/sq.log
+python tools/valu_busy.py /tmp/s360_prof/sq/sq_results.db > profiles/${TAG}_valu_busy.txt 2>> $O/sq.log
 cp profiles/${TAG}_* profiles/sweep_traffic.json $O/ 2>/dev/null
 ls $O

@@ -149,7 +149,7 @@ int main(int argc, char** argv) {
     FlowIdx idx{i0.data(), i1.data()};
     if (kernel == "lock") {
       std::vector<unsigned char> handoff(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), 0xFF);
-      launch_sweep_lock(nullptr, half.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast);
+      launch_sweep_lock(nullptr, rec.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast);
     } else {
       std::vector<unsigned char> handoff(sweep_quad_handoff_bytes(w, h, B), 0xFF);
       launch_sweep_quad(nullptr, half.data(), G.data(), got.data(), handoff.data(), &errflag, w, h, bs, B, idx, dir, pc, fast,

@@ -63,14 +63,17 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, in
   unsigned* err;
   CK(hipMalloc(&dG, hG.size() * 4));
   const std::vector<float> hhalf = half_records(hrec);
-  CK(hipMalloc(&drec, hhalf.size() * 4));
+  float* dhalf;
+  CK(hipMalloc(&drec, hrec.size() * 4));
+  CK(hipMalloc(&dhalf, hhalf.size() * 4));
   CK(hipMalloc(&dflow, hflow.size() * 4));
   const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   CK(hipMalloc(&hand, hb));
   CK(hipMalloc(&err, 8));
   CK(hipMemset(err, 0, 8));
   CK(hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(drec, hhalf.data(), hhalf.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(drec, hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dhalf, hhalf.data(), hhalf.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dflow, hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
   FlowIdx idx = make_idx(B);
   PixFlowConsts pc{0.9f, 0.001f, 0.01f, 0.01f, 0.5f, 0.5f, 0};
@@ -86,9 +89,9 @@ static float run(int w, int h, int B, bool fast, int mode /*2 lock, 3 quad*/, in
   auto once = [&](int dir) {
     CK(hipMemsetAsync(hand, 0xFF, hb, st));  // (the library resets one arena per flow call instead)
     if (mode == 2)
-      launch_sweep_lock(st, (const float2*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
+      launch_sweep_lock(st, (const float4*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
     else
-      launch_sweep_quad(st, (const float2*)drec, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
+      launch_sweep_quad(st, (const float2*)dhalf, (const float2*)dG, (float2*)dflow, hand, err, w, h, n, B, idx, dir, pc, fast);
   };
   once(1);
   CK(hipStreamSynchronize(st));
@@ -125,13 +128,13 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
       for (int y = 0; y < rows; ++y)
         for (int x = 0; x < w; ++x) hrec[4 * ((size_t)b * n + (size_t)y * w + x)] = __builtin_nanf("");
   }
-  std::vector<float*> dG(NS), drec(NS), dflow(NS), dA(NS), dbl(NS);
+  std::vector<float*> dG(NS), drec(NS), dhalf(NS), dflow(NS), dA(NS), dbl(NS);
   std::vector<void*> hand(NS);
   std::vector<unsigned*> err(NS);
   std::vector<hipStream_t> st(NS);
   const size_t hb = std::max(sweep_lock_handoff_bytes(w, h, B, sweep_lock_waves()), sweep_quad_handoff_bytes(w, h, B));
   for (int k = 0; k < NS; ++k) {
-    CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 2)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
+    CK(hipMalloc(&dG[k], hG.size() * 4)); CK(hipMalloc(&drec[k], hrec.size() * 4)); CK(hipMalloc(&dhalf[k], hrec.size() * 2)); CK(hipMalloc(&dflow[k], hflow.size() * 4));
     CK(hipMalloc(&hand[k], hb)); CK(hipMalloc(&err[k], 8)); CK(hipMemset(err[k], 0, 8));
     CK(hipMalloc(&dA[k], 2 * B * n * 4)); CK(hipMalloc(&dbl[k], B * n * 8));
     {
@@ -141,7 +144,8 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
       CK(hipMemcpy(dbl[k], bl.data(), bl.size() * 4, hipMemcpyHostToDevice));
     }
     CK(hipMemcpy(dG[k], hG.data(), hG.size() * 4, hipMemcpyHostToDevice));
-    { const std::vector<float> hhalf = half_records(hrec); CK(hipMemcpy(drec[k], hhalf.data(), hhalf.size() * 4, hipMemcpyHostToDevice)); }
+    CK(hipMemcpy(drec[k], hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+    { const std::vector<float> hhalf = half_records(hrec); CK(hipMemcpy(dhalf[k], hhalf.data(), hhalf.size() * 4, hipMemcpyHostToDevice)); }
     CK(hipMemcpy(dflow[k], hflow.data(), hflow.size() * 4, hipMemcpyHostToDevice));
     CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
   }
@@ -152,9 +156,9 @@ static float throughput(int w, int h, int B, int mode, int NS, int reps) {
   auto once = [&](int k, int dir) {
     CK(hipMemsetAsync(hand[k], 0xFF, hb, st[k]));
     if (mode == 3)
-      launch_sweep_quad(st[k], (const float2*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+      launch_sweep_quad(st[k], (const float2*)dhalf[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
     else
-      launch_sweep_lock(st[k], (const float2*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
+      launch_sweep_lock(st[k], (const float4*)drec[k], (const float2*)dG[k], (float2*)dflow[k], hand[k], err[k], w, h, n, B, idx, dir, pc, true);
   };
   for (int k = 0; k < NS; ++k) once(k, 1);
   CK(hipDeviceSynchronize());
