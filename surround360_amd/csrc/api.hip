@@ -302,6 +302,7 @@ void s360_destroy(s360_ctx* c) {
   }
   comm_destroy(c);
   c->slots.clear();
+  c->slotScratch.reset();
   c->flow.reset();
   c->flow_pole.reset();
   c->flow_pr.reset();
@@ -877,9 +878,9 @@ int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_
     int w = 0, h = 0, ch = 4;
     const int nloc = F.side_p1 - F.side_p0;
     if (n == "projection") {
-      need(idx >= 0 && idx < P && F.proj.p, "projection not available");
+      need(idx >= 0 && idx < P && F.sc->proj.p, "projection not available");
       w = g.cam_image_width; h = g.cam_image_height;
-      src = F.proj.as<uchar4>() + (size_t)w * h * idx;
+      src = F.sc->proj.as<uchar4>() + (size_t)w * h * idx;
     } else if (n == "overlap_l" || n == "overlap_r") {
       need(idx >= F.side_p0 && idx < F.side_p1 && F.overlaps[F.last_side].p, "overlap not available");
       w = g.overlap_image_width; h = g.cam_image_height;
@@ -890,11 +891,11 @@ int s360_frame_get_u8(s360_ctx* c, const char* name, int idx, int whc[3], uint8_
       need(F.panoDbg[e].p, "enable keep_intermediates before rendering");
       w = W; h = H; src = F.panoDbg[e].p;
     } else if (n == "top_spherical") {
-      need(F.topSph.p, "not available"); w = W; h = g.top_rows; src = F.topSph.p;
+      need(F.sc->topSph.p, "not available"); w = W; h = g.top_rows; src = F.sc->topSph.p;
     } else if (n == "bottom_spherical") {
-      need(F.botSph.p, "not available"); w = W; h = g.bottom_rows; src = F.botSph.p;
+      need(F.sc->botSph.p, "not available"); w = W; h = g.bottom_rows; src = F.sc->botSph.p;
     } else if (n == "pole_warped") {
-      need(idx >= 0 && idx < 4 && F.poleWarped[idx].p, "not available"); w = W; h = H; src = F.poleWarped[idx].p;
+      need(idx >= 0 && idx < 4 && F.sc->poleWarped[idx].p, "not available"); w = W; h = H; src = F.sc->poleWarped[idx].p;
     } else if (n == "extended_side" || n == "extended_fisheye") {
       need(idx >= 0 && idx < 4 && F.extImgs[F.last_pole].p, "not available");
       w = F.extW; h = idx < 2 ? F.poleRowsT : F.poleRowsB;

@@ -173,10 +173,10 @@ void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root) {
     if (owner[u] >= nr) throw Error(S360_ERR_INVALID_ARG, "owner: not a rank");
     if (owner[u] < 0 || owner[u] == root) continue;
     const size_t bytes = (size_t)W * (u < 2 ? c->g.top_rows : c->g.bottom_rows) * sizeof(uchar4);
-    if (me == owner[u] && !F.poleWarped[u].p) throw Error(S360_ERR_STATE, "pole unit " + std::to_string(u) + " has not been run on its owner");
+    if (me == owner[u] && !F.sc->poleWarped[u].p) throw Error(S360_ERR_STATE, "pole unit " + std::to_string(u) + " has not been run on its owner");
     if (me == root) {
-      F.poleWarped[u].ensure(en);
-      S360_HIP(hipMemsetAsync(F.poleWarped[u].as<uint8_t>() + bytes, 0, en - bytes, c->st));
+      F.sc->poleWarped[u].ensure(en);
+      S360_HIP(hipMemsetAsync(F.sc->poleWarped[u].as<uint8_t>() + bytes, 0, en - bytes, c->st));
     }
     if (me == owner[u] || me == root) ++todo;
   }
@@ -186,9 +186,9 @@ void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root) {
   for (int u = 0; u < 4 && rc == ncclSuccess; ++u) {
     if (owner[u] < 0 || owner[u] == root) continue;
     const size_t bytes = (size_t)W * (u < 2 ? c->g.top_rows : c->g.bottom_rows) * sizeof(uchar4);
-    if (me == owner[u]) rc = R.Send(F.poleWarped[u].p, bytes, ncclUint8, root, (ncclComm_t)c->comm, c->st);
+    if (me == owner[u]) rc = R.Send(F.sc->poleWarped[u].p, bytes, ncclUint8, root, (ncclComm_t)c->comm, c->st);
     else if (me == root) {
-      rc = R.Recv(F.poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
+      rc = R.Recv(F.sc->poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
       F.poleFrame[u] = F.frames_done;  // this frame's layer (frame_composite refuses an earlier frame's)
     }
   }

@@ -10,7 +10,8 @@
 #include "rig.hpp"
 
 namespace s360 {
-struct FrameState;  // render.hip
+struct FrameState;   // render.hpp
+struct SlotScratch;  // render.hpp: buffers shared by the frame slots of a context
 }
 
 struct s360_ctx {
@@ -68,6 +69,7 @@ struct s360_ctx {
   // multi-stream job) are rendered by ONE launch sequence with the flows of all of them in the same batched kernels
   // (s360_frame_render_batch). Uploads / getters / downloads act on the selected slot.
   std::vector<std::shared_ptr<s360::FrameState>> slots;
+  std::shared_ptr<s360::SlotScratch> slotScratch;
   int slot = 0;
   // warp maps of bicubicRemapToSpherical per rig camera: depend only on rig + sizes, shared by all slots
   s360::DevBuf sideMaps, topMap, botMap;

@@ -152,6 +152,8 @@ FrameState& frame_state(s360_ctx* c) {
   std::shared_ptr<FrameState>& f = c->slots[c->slot];
   if (!f) {
     f = std::make_shared<FrameState>();
+    if (!c->slotScratch) c->slotScratch = std::make_shared<SlotScratch>();
+    f->sc = c->slotScratch;
     f->P = (int)c->rig.side.size();
     f->tab.build(c->st, c->P.std_alpha_feather_size);
   }
@@ -462,7 +464,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
       if (!((F.side_uploaded >> p) & 1) || !((F.side_uploaded >> ((p + 1) % P)) & 1))
         throw Error(S360_ERR_STATE, "side image of camera " + std::to_string(((F.side_uploaded >> p) & 1) ? (p + 1) % P : p) +
                                         " not uploaded (needed by pair " + std::to_string(p) + ")");
-    F.proj.ensure(P * pn * sizeof(uchar4));
+    F.sc->proj.ensure(P * pn * sizeof(uchar4));
     F.strips.ensure((size_t)2 * P * camH * stripW * sizeof(uchar4));
     Fs.push_back(&F);
   }
@@ -499,7 +501,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
         launch_remap_cubic_u8c4_packed(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, c->sideMaps.as<float2>() + pn * i,
                                        pk.packed.as<unsigned>() + pn * i,
                                        (const char*)pk.tiles.p + 16 * remap_packed_tiles(camW, camH) * i,
-                                       F.proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
+                                       F.sc->proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
         i = j;
       }
     }
@@ -508,7 +510,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
     F.sideFlows[cur].ensure(2 * n * on * sizeof(float2));
     {
       ProfScope ps(prof, "crop_overlaps");
-      launch_crop_overlaps(st, F.proj.as<uchar4>(), camW, camH, P, ow, F.overlaps[cur].as<uchar4>(), p0, p1);
+      launch_crop_overlaps(st, F.sc->proj.as<uchar4>(), camW, camH, P, ow, F.overlaps[cur].as<uchar4>(), p0, p1);
     }
   }
   if (c->evSideSrcFree) {  // the next frame's side images may be converted into sideSrc from here on
@@ -599,14 +601,14 @@ void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flo
   pw.phiRampStart = c->ramp.phiRampStart;
   pw.phiMid = c->ramp.phiMid;
   pw.phiRampEnd = c->ramp.phiRampEnd;
-  F.warpedExt.ensure((size_t)extW * rows * sizeof(uchar4));
+  F.sc->warpedExt.ensure((size_t)extW * rows * sizeof(uchar4));
   // two kernels: this frame's warp as packed coordinates + tile boxes, then the packed remap (1.00 against 1.24 ms per
   // 8K frame for the one-kernel form, profiles/r03_v2_*)
-  F.warpPacked.ensure((size_t)extW * rows * sizeof(unsigned));
-  F.warpTiles.ensure(remap_packed_tiles(extW, rows) * 16);
-  launch_pole_warp_packed(c->st, extFisheye, flow, F.warpedExt.as<uchar4>(), pw, F.tab.dev, F.warpPacked.as<unsigned>(),
-                          F.warpTiles.p);
-  launch_pole_finish(c->st, F.warpedExt.as<uchar4>(), warped_out, eqrH, pw);
+  F.sc->warpPacked.ensure((size_t)extW * rows * sizeof(unsigned));
+  F.sc->warpTiles.ensure(remap_packed_tiles(extW, rows) * 16);
+  launch_pole_warp_packed(c->st, extFisheye, flow, F.sc->warpedExt.as<uchar4>(), pw, F.tab.dev, F.sc->warpPacked.as<unsigned>(),
+                          F.sc->warpTiles.p);
+  launch_pole_finish(c->st, F.sc->warpedExt.as<uchar4>(), warped_out, eqrH, pw);
 }
 
 namespace {
@@ -631,7 +633,7 @@ struct FinishStream {
 // Pole stage + composite of a set of frame slots: per slot panorama assembly, pole projections and the flow inputs of
 // the enabled pole units; then the pole flows of ALL slots in one FlowEngine batch (two when the top and bottom pole
 // projections differ in height); then per slot warp, composite, sharpen / final resize / stacking.
-// `phases`: 1 = panorama assembly + the pole units of `pole_mask` (their warped layers stay in F.poleWarped), 2 = composite
+// `phases`: 1 = panorama assembly + the pole units of `pole_mask` (their warped layers stay in F.sc->poleWarped), 2 = composite
 // of the layers of `composite_mask` (computed here or received: frame_gather_pole_layers) + sharpen / resize / stack.
 // s360_frame_finish is both phases with the same mask; a frame whose pole units are spread over GPUs
 // runs phase 1 on every owner and phase 2 on the root.
@@ -672,7 +674,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     }
     if (!F.strips.p) throw Error(S360_ERR_STATE, "no strips rendered for this frame");
     for (int e = 0; e < 2; ++e) F.pano[e].ensure(en * sizeof(uchar4));
-    F.panoTmp.ensure(en * sizeof(uchar4));
+    F.sc->panoTmp.ensure(en * sizeof(uchar4));
     {
       ProfScope ps(prof, "assemble_pano");  // TRSP:380-384, 806-807
       const float sh = g.zero_parallax_novel_view_shift_pixels;
@@ -696,44 +698,44 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       ProfScope ps(prof, "project_pole");
       if (pole_mask & 3) {
         if (!F.have_top) throw Error(S360_ERR_STATE, "top image not uploaded");
-        F.topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
+        F.sc->topSph.ensure((size_t)W * rowsT * sizeof(uchar4));
         const int yfs = rowsT - 1 - c->P.std_alpha_feather_size;
         s360_ctx::PackedMap& pk = ensure_packed(c, c->topPk, c->topMap.as<float2>(), F.topW, F.topH, W, rowsT, 1, st);
         launch_remap_cubic_u8c4_packed(st, F.topSrc.as<uchar4>(), F.topW, F.topH, c->topMap.as<float2>(),
-                                       pk.packed.as<unsigned>(), pk.tiles.p, F.topSph.as<uchar4>(), W, rowsT,
+                                       pk.packed.as<unsigned>(), pk.tiles.p, F.sc->topSph.as<uchar4>(), W, rowsT,
                                        F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
-        launch_extend_wrap(st, F.topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xs, extW);
+        launch_extend_wrap(st, F.sc->topSph.as<uchar4>(), nullptr, W, rowsT, ext + 4 * xs, extW);
       }
       if (pole_mask & 12) {
         if (!F.have_bottom) throw Error(S360_ERR_STATE, "bottom image not uploaded");
-        F.botSph.ensure((size_t)W * rowsB * sizeof(uchar4));
+        F.sc->botSph.ensure((size_t)W * rowsB * sizeof(uchar4));
         const int yfs = rowsB - 1 - c->P.std_alpha_feather_size;
         if (c->P.enable_pole_removal) {  // TRSP:569-597: the bottom source is the merge of the two bottom cameras
           dev_pole_removal(c, F, use_prev != 0);
           s360_ctx::PackedMap& pk = ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
           launch_remap_cubic_u8c4_packed(st, F.prMerged.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
-                                         pk.packed.as<unsigned>(), pk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
+                                         pk.packed.as<unsigned>(), pk.tiles.p, F.sc->botSph.as<uchar4>(), W, rowsB,
                                          F.tab.dev, 2, yfs, c->P.std_alpha_feather_size);
         } else {
           s360_ctx::PackedMap& pk = ensure_packed(c, c->botPk, c->botMap.as<float2>(), F.poleW, F.poleH, W, rowsB, 1, st);
           launch_remap_cubic_u8c4_packed(st, F.botSrc.as<uchar4>(), F.poleW, F.poleH, c->botMap.as<float2>(),
-                                         pk.packed.as<unsigned>(), pk.tiles.p, F.botSph.as<uchar4>(), W, rowsB,
+                                         pk.packed.as<unsigned>(), pk.tiles.p, F.sc->botSph.as<uchar4>(), W, rowsB,
                                          F.tab.dev, 1, yfs, c->P.std_alpha_feather_size);
         }
-        launch_extend_wrap(st, F.botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xs, extW);
+        launch_extend_wrap(st, F.sc->botSph.as<uchar4>(), nullptr, W, rowsB, ext + 5 * xs, extW);
       }
     }
     {
       ProfScope ps(prof, "pole_prepare");
       if (pole_mask & 12) {
         for (int e = 0; e < 2; ++e) {
-          F.panoFlip[e].ensure(en * sizeof(uchar4));
-          launch_flip_both(st, F.pano[e].as<uchar4>(), F.panoFlip[e].as<uchar4>(), W, H, rowsB);  // TRSP:842-843 (only the rows the pole unit reads)
+          F.sc->panoFlip[e].ensure(en * sizeof(uchar4));
+          launch_flip_both(st, F.pano[e].as<uchar4>(), F.sc->panoFlip[e].as<uchar4>(), W, H, rowsB);  // TRSP:842-843 (only the rows the pole unit reads)
         }
       }
       for (int u = 0; u < 4; ++u)
         if (pole_mask & (1 << u)) {
-          const uchar4* side = (u < 2) ? F.pano[u & 1].as<uchar4>() : F.panoFlip[u & 1].as<uchar4>();
+          const uchar4* side = (u < 2) ? F.pano[u & 1].as<uchar4>() : F.sc->panoFlip[u & 1].as<uchar4>();
           dev_feather_alpha_to_ext(c, side, W, rowsOf(u), ext + u * xs, extW);
         }
     }
@@ -794,9 +796,9 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         ProfScope ps(prof, "pole_warp");
         for (int u = 0; u < 4; ++u)
           if (pole_mask & (1 << u)) {
-            F.poleWarped[u].ensure(en * sizeof(uchar4));
+            F.sc->poleWarped[u].ensure(en * sizeof(uchar4));
             dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xs, F.poleFlows[cur].as<float2>() + u * xs, W, rowsOf(u), extW,
-                               F.poleWarped[u].as<uchar4>(), H);
+                               F.sc->poleWarped[u].as<uchar4>(), H);
             F.poleFrame[u] = F.frames_done;
           }
       }
@@ -810,22 +812,22 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     if (!(phases & 2)) continue;
     {
       ProfScope ps(prof, "flatten");  // TRSP:864-885
-      F.panoTmp.ensure(en * sizeof(uchar4));
+      F.sc->panoTmp.ensure(en * sizeof(uchar4));
       for (int u = 0; u < 4; ++u)
-        if ((composite_mask & (1 << u)) && (!F.poleWarped[u].p || F.poleFrame[u] != F.frames_done))  // (an earlier frame's layer is not this frame's)
+        if ((composite_mask & (1 << u)) && (!F.sc->poleWarped[u].p || F.poleFrame[u] != F.frames_done))  // (an earlier frame's layer is not this frame's)
           throw Error(S360_ERR_STATE, "composite: the warped layer of pole unit " + std::to_string(u) + " of this frame is neither computed nor received");
       for (int e = 0; e < 2; ++e) {
         if (composite_mask & (1 << e)) {
-          launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 0,
+          launch_flatten(st, F.pano[e].as<uchar4>(), F.sc->poleWarped[e].as<uchar4>(), F.sc->panoTmp.as<uchar4>(), W, H, 0,
                          F.tab.dev);
-          std::swap(F.pano[e].p, F.panoTmp.p);
-          std::swap(F.pano[e].cap, F.panoTmp.cap);
+          std::swap(F.pano[e].p, F.sc->panoTmp.p);
+          std::swap(F.pano[e].cap, F.sc->panoTmp.cap);
         }
         if (composite_mask & (4 << e)) {
-          launch_flatten(st, F.pano[e].as<uchar4>(), F.poleWarped[2 + e].as<uchar4>(), F.panoTmp.as<uchar4>(), W, H, 1,
+          launch_flatten(st, F.pano[e].as<uchar4>(), F.sc->poleWarped[2 + e].as<uchar4>(), F.sc->panoTmp.as<uchar4>(), W, H, 1,
                          F.tab.dev);
-          std::swap(F.pano[e].p, F.panoTmp.p);
-          std::swap(F.pano[e].cap, F.panoTmp.cap);
+          std::swap(F.pano[e].p, F.sc->panoTmp.p);
+          std::swap(F.pano[e].cap, F.sc->panoTmp.cap);
         }
       }
     }
@@ -870,9 +872,9 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       for (int e = 0; e < 2; ++e) {
         uchar4* eye = F.pano[e].as<uchar4>();
         if (resize) {
-          F.eyeFinal[e].ensure((size_t)outW * eyeH * sizeof(uchar4));
-          launch_resize_cubic_u8c4(st, eye, W, H, en, F.eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);
-          eye = F.eyeFinal[e].as<uchar4>();
+          F.sc->eyeFinal[e].ensure((size_t)outW * eyeH * sizeof(uchar4));
+          launch_resize_cubic_u8c4(st, eye, W, H, en, F.sc->eyeFinal[e].as<uchar4>(), outW, eyeH, (size_t)outW * eyeH, 1);
+          eye = F.sc->eyeFinal[e].as<uchar4>();
         }
         launch_pack_bgr(st, eye, outW, eyeH, F.outBGR[ob].as<uint8_t>() + (size_t)e * outW * eyeH * 3);
       }

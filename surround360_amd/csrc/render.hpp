@@ -1,5 +1,6 @@
 // render.hpp — device-resident per-frame pipeline state (renderStereoPanorama, TRSP:716-972).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -20,26 +21,39 @@ struct Tables {
 void build_spherical_map(s360_ctx* c, float2* map, int dw, int dh, const s360_camera& cam, float l, float r, float t,
                          float b);
 
+// Buffers a frame only needs INSIDE one of its own kernel sequences — produced and consumed between two neighbouring
+// launches of the same slot — are shared by all frame slots of a context (the slots of a batch take their per-slot kernels
+// one after the other on one stream): the side projections (dead once the overlaps are cropped), the flipped panoramas
+// and pole projections (dead once the extended flow inputs exist), the pole warp's intermediates and warped layers (dead
+// once composited), the composite's ping-pong buffer, the resized eyes (dead once packed). 1.7 GB per 8K slot that 13 of
+// 14 slots no longer hold: 2 x 16 slots fit where 2 x 14 did. With several slots the getters of these intermediates
+// (s360_frame_get_u8 "projection", "top_spherical", "bottom_spherical", "pole_warped") show the slot rendered last.
+struct SlotScratch {
+  DevBuf proj;
+  DevBuf panoFlip[2], panoTmp;
+  DevBuf topSph, botSph;
+  DevBuf warpedExt, poleWarped[4];
+  DevBuf warpPacked, warpTiles;  // this frame's pole warp as packed coordinates + tile boxes (launch_pole_warp_packed)
+  DevBuf eyeFinal[2];
+};
+
 struct FrameState {
   Tables tab;
+  std::shared_ptr<SlotScratch> sc;  // the context's (frame_state())
   int P = 0;                       // number of side cameras / pairs
   int srcW = 0, srcH = 0;
   int topW = 0, topH = 0, poleW = 0, poleH = 0;  // top camera image; bottom camera image (poleW/poleH: also pole removal)
   unsigned long long side_uploaded = 0;          // bit i: side camera i has an image (cleared by nothing: images persist)
   bool have_side = false, have_top = false, have_bottom = false;
   DevBuf staging, sideSrc, topSrc, botSrc;
-  DevBuf proj;
   DevBuf overlaps[2], sideFlows[2];  // [cur/prev] temporal double buffer
   int side_p0 = 0, side_p1 = 0;       // pairs held by overlaps/sideFlows (local partition)
   bool partition_declared = false;    // s360_frame_set_partition was called (set_prev_side then fills that block)
   DevBuf strips;                      // [2][P][camH][stripW]
-  DevBuf pano[2], panoFlip[2], panoTmp;
-  DevBuf topSph, botSph;
+  DevBuf pano[2];
   DevBuf a8a, a8b, gtmp;
   DevBuf extImgs[2], poleFlows[2];    // [cur/prev]; slots: ext 0-3 side units, 4 top fisheye, 5 bottom fisheye
-  DevBuf warpedExt, poleWarped[4];
-  DevBuf warpPacked, warpTiles;  // this frame's pole warp as packed coordinates + tile boxes (launch_pole_warp_packed)
-  DevBuf eyeFinal[2], sharpLp[2], sharpBuf[2];
+  DevBuf sharpLp[2], sharpBuf[2];
   // Stacked equirect of the last two frames (alternating): a streaming host downloads frame k from one buffer while
   // frame k+1 is composited into the other (s360_frame_download_equirect_of). outDone[i] is recorded behind the
   // kernels that fill outBGR[i].
