@@ -360,6 +360,7 @@ int s360_set_frame_pipelining(s360_ctx* c, int on) {
     }
     c->pipeline = on != 0;
     c->haveStripsFree = false;
+    flow_engines_follow_pipelining(c);  // (the streams are idle: the finish stage's engines change buffer sets)
   });
 }
 int s360_set_sharpening(s360_ctx* c, double sharpening) {
@@ -578,7 +579,7 @@ int s360_pole_to_side_flow(s360_ctx* c, const uint8_t* side, const uint8_t* pole
     uchar4* ext = c->op_c.as<uchar4>();
     dev_feather_alpha_to_ext(c, c->op_a.as<uchar4>(), W, pole_rows, ext, extW);
     launch_extend_wrap(c->st, c->op_b.as<uchar4>(), nullptr, W, pole_rows, ext + xn, extW);
-    if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
+    (void)flow_engine(c, 1);
     FlowBatch fb;
     fb.add_images(ext, 2, xn);
     fb.add_flow(0, 1, c->op_d.as<float2>());

@@ -99,6 +99,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   for (int b = 0; b < B; ++b)
     if (batch.i0[b] < 0 || batch.i0[b] >= N || batch.i1[b] < 0 || batch.i1[b] >= N) throw Error(-1, "FlowEngine: image index out of range");
   Profiler& P = *prof_;
+  FlowBufs& M = *bufs_;
   dw_ = int(w * pc.downscaleFactor);
   dh_ = int(h * pc.downscaleFactor);
   // every caller, not only the operator entry point (the frame stages come here directly): the sweep kernels' tap
@@ -118,12 +119,12 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   idx.i0 = reinterpret_cast<const int*>(tab + 2 * N + 2 * B);
   idx.i1 = idx.i0 + B;
 
-  down_.ensure(N * n0 * sizeof(uchar4));
-  gray_.ensure(N * n0 * sizeof(float));
-  pyrI_.ensure(2 * N * lv_.total * sizeof(float));  // per level: N grey planes, then N alpha planes
-  G_.ensure(N * n0 * sizeof(float2));
-  flowA_.ensure(B * n0 * sizeof(float2));
-  flowB_.ensure(B * n0 * sizeof(float2));
+  M.down.ensure(N * n0 * sizeof(uchar4));
+  M.gray.ensure(N * n0 * sizeof(float));
+  M.pyrI.ensure(2 * N * lv_.total * sizeof(float));  // per level: N grey planes, then N alpha planes
+  M.G.ensure(N * n0 * sizeof(float2));
+  M.flowA.ensure(B * n0 * sizeof(float2));
+  M.flowB.ensure(B * n0 * sizeof(float2));
   if (sweep_fast_ < 0) {
     const char* d = std::getenv("S360_SWEEP_DIV");  // "ieee": IEEE division / sqrt expansions instead of the verified fast ones (same bits)
     sweep_fast_ = !(d && std::string(d) == "ieee");
@@ -138,7 +139,7 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     fastOk = sweep_verify_divisors(st, divs);
   }
-  rec_.ensure(B * n0 * (sweep_mode_ == 3 ? sizeof(float2) : sizeof(float4)));  // half-records / full records (flow_kernels.hpp)
+  M.rec.ensure(B * n0 * (sweep_mode_ == 3 ? sizeof(float2) : sizeof(float4)));  // half-records / full records (flow_kernels.hpp)
   // Band hand-off granules + ticket counters of every sweep launch of this call (2 per level): one arena, reset to
   // all-ones ("not written") by ONE memset instead of one per launch.
   auto handoff_bytes = [&](int l) {
@@ -150,13 +151,13 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   auto rowflag_bytes = [&](int l) { return ((size_t)B * lv_.h[l] * sizeof(unsigned) + 255) & ~(size_t)255; };
   std::vector<size_t> hoff(L + 1, 0);
   for (int l = 0; l < L; ++l) hoff[l + 1] = hoff[l] + 2 * handoff_bytes(l) + rowflag_bytes(l);
-  handoff_.ensure(hoff[L]);
-  S360_HIP(hipMemsetAsync(handoff_.p, 0xFF, hoff[L], st));
+  M.handoff.ensure(hoff[L]);
+  S360_HIP(hipMemsetAsync(M.handoff.p, 0xFF, hoff[L], st));
   if (!err_.p) {
     err_.ensure(sizeof(unsigned));
     S360_HIP(hipMemsetAsync(err_.p, 0, sizeof(unsigned), st));
   }
-  float* pyrI = pyrI_.as<float>();
+  float* pyrI = M.pyrI.as<float>();
   auto LI = [&](int l) { return pyrI + (size_t)2 * N * lv_.off[l]; };
   auto LA = [&](int l) { return pyrI + (size_t)2 * N * lv_.off[l] + (size_t)N * lv_.w[l] * lv_.h[l]; };
 
@@ -164,9 +165,9 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
                  tFinal = gaussian_taps(3, 1.0f);
   {
     ProfScope ps(P, "flow_entry");
-    launch_resize_cubic_u8c4(st, nullptr, w, h, 0, down_.as<uchar4>(), dw_, dh_, n0, N, imageTab);
-    launch_gray_alpha(st, down_.as<uchar4>(), n0, n0, gray_.as<float>(), LA(0), n0, N);
-    launch_sepblur(st, gray_.as<float>(), LI(0), dw_, dh_, 1, n0, N, tPre);
+    launch_resize_cubic_u8c4(st, nullptr, w, h, 0, M.down.as<uchar4>(), dw_, dh_, n0, N, imageTab);
+    launch_gray_alpha(st, M.down.as<uchar4>(), n0, n0, M.gray.as<float>(), LA(0), n0, N);
+    launch_sepblur(st, M.gray.as<float>(), LI(0), dw_, dh_, 1, n0, N, tPre);
   }
   {
     ProfScope ps(P, "flow_pyramid");
@@ -181,13 +182,13 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   float* motionPyr = nullptr;
   if (usePrev) {
     ProfScope ps(P, "flow_prev");
-    prevdown_.ensure(N * n0 * sizeof(uchar4));
-    prevPyr_.ensure(B * lv_.total * sizeof(float2));
-    motionPyr_.ensure(N * lv_.total * sizeof(float));
-    prevPyr = prevPyr_.as<float2>();
-    motionPyr = motionPyr_.as<float>();
-    launch_resize_cubic_u8c4(st, nullptr, w, h, 0, prevdown_.as<uchar4>(), dw_, dh_, n0, N, prevImageTab);
-    launch_motion(st, down_.as<uchar4>(), prevdown_.as<uchar4>(), n0, n0, motionPyr, n0, N);
+    M.prevdown.ensure(N * n0 * sizeof(uchar4));
+    M.prevPyr.ensure(B * lv_.total * sizeof(float2));
+    M.motionPyr.ensure(N * lv_.total * sizeof(float));
+    prevPyr = M.prevPyr.as<float2>();
+    motionPyr = M.motionPyr.as<float>();
+    launch_resize_cubic_u8c4(st, nullptr, w, h, 0, M.prevdown.as<uchar4>(), dw_, dh_, n0, N, prevImageTab);
+    launch_motion(st, M.down.as<uchar4>(), M.prevdown.as<uchar4>(), n0, n0, motionPyr, n0, N);
     // prevFlowDownscaled = resize(prevFlow) * (rows_down / rows_full)  (PixFlow.h:103-104)
     launch_resize_cubic_f32c2(st, nullptr, w, h, 0, prevPyr, dw_, dh_, n0, B, float(dh_) / float(h), prevFlowTab);
     for (int l = 1; l < L; ++l) {
@@ -203,8 +204,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
                        float(lv_.h[l]) / float(lv_.h[0]));
   }
 
-  float2* cur = flowA_.as<float2>();
-  float2* oth = flowB_.as<float2>();
+  float2* cur = M.flowA.as<float2>();
+  float2* oth = M.flowB.as<float2>();
   const float invPyr = 1.0f / pc.pyrScaleFactor;
   if (capture_levels) capture_levels->clear();
   for (int l = L - 1; l >= 0; --l) {
@@ -212,30 +213,30 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     const size_t nl = (size_t)wl * hl;
     {
       ProfScope ps(P, "flow_gradients");
-      launch_gradients(st, LI(l), G_.as<float2>(), wl, hl, nl, N, tGrad);
+      launch_gradients(st, LI(l), M.G.as<float2>(), wl, hl, nl, N, tGrad);
     }
     if (l == L - 1) {
       S360_HIP(hipMemsetAsync(cur, 0, B * nl * sizeof(float2), st));
       if (pc.maxPercentage > 0 && hint != 0) {
         ProfScope ps(P, "flow_search_init");
-        I1eq_.ensure(B * nl * sizeof(float));
+        M.I1eq.ensure(B * nl * sizeof(float));
         const int dist = (24 * pc.maxPercentage + 50) / 100;
-        launch_search_init(st, LI(l), LA(l), wl, hl, nl, B, idx, cur, hint, dist, I1eq_.as<float>());
+        launch_search_init(st, LI(l), LA(l), wl, hl, nl, B, idx, cur, hint, dist, M.I1eq.as<float>());
       }
     }
     {
       ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweeps' half-records
-      launch_blur_to_records(st, cur, rec_.p, wl, hl, nl, B, tFlow, sweep_mode_ == 3 ? nullptr : G_.as<float2>(), LA(l), idx,
-                             reinterpret_cast<unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
+      launch_blur_to_records(st, cur, M.rec.p, wl, hl, nl, B, tFlow, sweep_mode_ == 3 ? nullptr : M.G.as<float2>(), LA(l), idx,
+                             reinterpret_cast<unsigned*>((char*)M.handoff.p + hoff[l] + 2 * handoff_bytes(l)));
     }
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
-      void* ho = (char*)handoff_.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
+      void* ho = (char*)M.handoff.p + hoff[l] + (dir > 0 ? 0 : handoff_bytes(l));
       if (sweep_mode_ == 3)
-        launch_sweep_quad(st, rec_.as<float2>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
-                          fastOk, reinterpret_cast<const unsigned*>((char*)handoff_.p + hoff[l] + 2 * handoff_bytes(l)));
+        launch_sweep_quad(st, M.rec.as<float2>(), M.G.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+                          fastOk, reinterpret_cast<const unsigned*>((char*)M.handoff.p + hoff[l] + 2 * handoff_bytes(l)));
       else
-        launch_sweep_lock(st, rec_.as<float4>(), G_.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
+        launch_sweep_lock(st, M.rec.as<float4>(), M.G.as<float2>(), fl, ho, err_.as<unsigned>(), wl, hl, nl, B, idx, dir, pc,
                           fastOk);
     };
     sweep(cur, +1);

@@ -4,6 +4,7 @@
 // sequence (PixFlow.h:81-183). Flow b matches image idx.i0[b] against idx.i1[b]; all
 // per-image work (downscale, grey/alpha, pyramids, gradients) is done once per image.
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -41,12 +42,23 @@ struct FlowBatch {
   }
 };
 
+// The device buffers of a compute() call: all of them are dead when the call's last kernel has run (the flows go to the
+// batch's own output pointers), so engines whose calls can never overlap — the side, pole and pole-removal engines of a
+// context without frame pipelining: one stream, one after the other — share ONE set, each buffer as large as its largest user
+// (grow-only): 1.25 GB per 8K frame slot that the side engine no longer holds beside the pole engine's 2.4 GB.
+struct FlowBufs {
+  DevBuf down, prevdown, gray, pyrI, G, flowA, flowB, prevFlowDown, prevPyr, motionPyr, I1eq, rec, handoff;
+};
+
 class FlowEngine {
  public:
-  explicit FlowEngine(Profiler* prof) : prof_(prof) {}
+  explicit FlowEngine(Profiler* prof) : prof_(prof), bufs_(std::make_shared<FlowBufs>()) {}
+  // use another engine's buffer set from now on (the caller guarantees that the two never compute at the same time)
+  void share_buffers(const std::shared_ptr<FlowBufs>& b) { bufs_ = b; }
+  const std::shared_ptr<FlowBufs>& buffers() const { return bufs_; }
   void compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatch& batch, int w, int h, int hint);
   // debugging taps for parity tests (valid after compute() + stream sync)
-  const uchar4* dbg_down() const { return down_.as<uchar4>(); }
+  const uchar4* dbg_down() const { return bufs_->down.as<uchar4>(); }
   const FlowLevels& levels() const { return lv_; }
   int dw() const { return dw_; }
   int dh() const { return dh_; }
@@ -63,8 +75,8 @@ class FlowEngine {
   TabSlot tabs_[4];
   int tab_next_ = 0;
   const unsigned long long* batch_tables(hipStream_t st, const FlowBatch& b);
-  DevBuf down_, prevdown_, gray_, pyrI_, G_, flowA_, flowB_, prevFlowDown_, prevPyr_, motionPyr_, I1eq_, rec_,
-      handoff_, err_;
+  std::shared_ptr<FlowBufs> bufs_;
+  DevBuf err_;
   int sweep_mode_ = 2;      // 2: lockstep kernel (latency, default), 3: quad kernel (throughput)
   int sweep_fast_ = -1;     // verified fast division / sqrt in the sweeps; S360_SWEEP_DIV=ieee selects the IEEE expansions (same bits)
 

@@ -159,6 +159,28 @@ FrameState& frame_state(s360_ctx* c) {
   }
   return *f;
 }
+void flow_engines_follow_pipelining(s360_ctx* c) {
+  if (!c->flow) return;
+  std::shared_ptr<FlowBufs> finish = c->flow->buffers();
+  if (c->pipeline) {
+    // a set of their own for the engines of the finish stage (kept once made: a stream switches pipelining on once)
+    if (c->flow_pole && c->flow_pole->buffers() != c->flow->buffers()) finish = c->flow_pole->buffers();
+    else if (c->flow_pr && c->flow_pr->buffers() != c->flow->buffers()) finish = c->flow_pr->buffers();
+    else finish = std::make_shared<FlowBufs>();
+  }
+  if (c->flow_pole) c->flow_pole->share_buffers(finish);
+  if (c->flow_pr) c->flow_pr->share_buffers(finish);
+}
+FlowEngine& flow_engine(s360_ctx* c, int which) {
+  std::unique_ptr<FlowEngine>& e = which == 0 ? c->flow : which == 1 ? c->flow_pole : c->flow_pr;
+  if (!e) {
+    if (which != 0) (void)flow_engine(c, 0);
+    e.reset(new FlowEngine(&c->prof));
+    e->set_sweep_mode(c->sweep_mode);
+    flow_engines_follow_pipelining(c);
+  }
+  return *e;
+}
 void set_frame_slots(s360_ctx* c, int n) {
   if (n < 1 || n > 64) throw Error(S360_ERR_INVALID_ARG, "frame slots must be 1..64");
   S360_HIP(hipStreamSynchronize(c->st));
@@ -362,7 +384,7 @@ static void dev_pole_removal(s360_ctx* c, FrameState& F, bool use_prev) {
     if (flip180) launch_flip_both(st, t2, img2, w, h, h);
   }
   {
-    if (!c->flow_pr) { c->flow_pr.reset(new FlowEngine(&c->prof)); c->flow_pr->set_sweep_mode(c->sweep_mode); }
+    (void)flow_engine(c, 2);
     const std::string alg = c->P.poleremoval_flow_alg[0] ? c->P.poleremoval_flow_alg : "pixflow_low";
     FlowBatch fb;
     fb.add_images(img1, 2, n);
@@ -521,7 +543,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
     // NovelViewGeneratorAsymmetricFlow::prepare (NovelView.cpp:270-299): flowLtoR = flow(I0=L, I1=R, LEFT),
     // flowRtoL = flow(I0=R, I1=L, RIGHT). Both hints only matter for pixflow_search_20; the batch is split by
     // hint in that case. Per slot: images [L_0..L_{n-1}, R_0..R_{n-1}], flows [LtoR_0.., RtoL_0..].
-    if (!c->flow) { c->flow.reset(new FlowEngine(&c->prof)); c->flow->set_sweep_mode(c->sweep_mode); }
+    (void)flow_engine(c, 0);
     const PixFlowConsts pc = pixflow_consts_by_name(c->P.side_flow_alg);
     auto build = [&](bool ltor, bool rtol) {
       FlowBatch fb;
@@ -750,7 +772,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       c->havePoleSrcFree = true;
     }
     // computeOpticalFlow(extendedSide, extendedFisheye, ..., DOWN) for every enabled unit (TRSP:438-448)
-    if (!c->flow_pole) { c->flow_pole.reset(new FlowEngine(&c->prof)); c->flow_pole->set_sweep_mode(c->sweep_mode); }
+    (void)flow_engine(c, 1);
     const PixFlowConsts pc = pixflow_consts_by_name(c->P.polar_flow_alg);
     auto run = [&](int mask, int rows) {
       if (!mask) return;
@@ -833,28 +855,31 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     }
   }
   if (!(phases & 2)) return;
-  // sharpenThread for both eyes of EVERY slot in one set of launches (TRSP:901-915 runs the two eyes on two threads): the
+  // sharpenThread for the eyes of several slots per set of launches (TRSP:901-915 runs the two eyes on two threads): the
   // IIR passes are one serial chain per (row, channel) — the 2 x 4096 rows of one frame are 512 waves, half a wave per
-  // SIMD — so a batch of slots is sharpened together (12 slots: 6 waves per SIMD cover each other's dependent chains)
+  // SIMD — so the slots of a batch are sharpened in groups of four (8 images: 2 waves per SIMD cover each other's
+  // dependent chains), group after group, all groups through the same scratch (SlotScratch)
   if (c->P.sharpening > 0.0) {
     ProfScope ps(prof, "finish");
-    std::vector<uchar4*> imgs, lps;
-    std::vector<float*> scr;
+    std::vector<uchar4*> imgs;
     for (int k : slotIds) {
       SlotScope ss(c, k);
       FrameState& F = frame_state(c);
-      for (int e = 0; e < 2; ++e) {
-        F.sharpLp[e].ensure(en * sizeof(uchar4));
-        F.sharpBuf[e].ensure(sharpen_scratch_bytes(W, H));
-        imgs.push_back(F.pano[e].as<uchar4>());
-        lps.push_back(F.sharpLp[e].as<uchar4>());
-        scr.push_back(F.sharpBuf[e].as<float>());
-      }
+      for (int e = 0; e < 2; ++e) imgs.push_back(F.pano[e].as<uchar4>());
     }
-    const int per = sharpen_max_images();
-    for (size_t i = 0; i < imgs.size(); i += per) {
+    SlotScratch& S = *c->slotScratch;
+    const int per = std::min(sharpen_max_images(), (int)SlotScratch::kSharpenGroup);
+    uchar4* lps[SlotScratch::kSharpenGroup];
+    float* scr[SlotScratch::kSharpenGroup];
+    for (int i = 0; i < per && i < (int)imgs.size(); ++i) {
+      S.sharpLp[i].ensure(en * sizeof(uchar4));
+      S.sharpBuf[i].ensure(sharpen_scratch_bytes(W, H));
+      lps[i] = S.sharpLp[i].as<uchar4>();
+      scr[i] = S.sharpBuf[i].as<float>();
+    }
+    for (size_t i = 0; i < imgs.size(); i += per) {  // (group after group on this stream: the scratch is the group's)
       const int n = (int)std::min<size_t>(per, imgs.size() - i);
-      launch_sharpen_many(st, imgs.data() + i, lps.data() + i, scr.data() + i, n, W, H, 1.0f + (float)c->P.sharpening);
+      launch_sharpen_many(st, imgs.data() + i, lps, scr, n, W, H, 1.0f + (float)c->P.sharpening);
     }
   }
   for (int k : slotIds) {

@@ -35,6 +35,11 @@ struct SlotScratch {
   DevBuf warpedExt, poleWarped[4];
   DevBuf warpPacked, warpTiles;  // this frame's pole warp as packed coordinates + tile boxes (launch_pole_warp_packed)
   DevBuf eyeFinal[2];
+  // the sharpen passes' low-pass image and float scratch for ONE group of kSharpenGroup images: the eyes of a batch are
+  // sharpened group after group on one stream (8 images = 4 slots' eyes are 2 waves per SIMD in the row passes: enough to
+  // cover each other's dependent chains), so the 1.1 GB per 8K slot these were is 4.4 GB per context
+  static constexpr int kSharpenGroup = 8;
+  DevBuf sharpLp[kSharpenGroup], sharpBuf[kSharpenGroup];
 };
 
 struct FrameState {
@@ -53,7 +58,7 @@ struct FrameState {
   DevBuf pano[2];
   DevBuf a8a, a8b, gtmp;
   DevBuf extImgs[2], poleFlows[2];    // [cur/prev]; slots: ext 0-3 side units, 4 top fisheye, 5 bottom fisheye
-  DevBuf sharpLp[2], sharpBuf[2];
+
   // Stacked equirect of the last two frames (alternating): a streaming host downloads frame k from one buffer while
   // frame k+1 is composited into the other (s360_frame_download_equirect_of). outDone[i] is recorded behind the
   // kernels that fill outBGR[i].
@@ -122,5 +127,11 @@ void dev_pole_unit_post(s360_ctx* c, const uchar4* extFisheye, const float2* flo
 
 // api.hip: does [p, p + bytes) lie in a buffer from s360_host_alloc (page-locked: uploads need no staging copy)?
 bool host_is_pinned(const void* p, size_t bytes);
+
+// The context's flow engines (created on first use). which: 0 side / operator-level, 1 pole, 2 pole removal. Without frame
+// pipelining the three never compute at the same time (one stream) and share one set of device buffers (flow.hpp FlowBufs);
+// with it the finish stage runs on its own stream, and the pole / pole-removal engines get a set of their own.
+FlowEngine& flow_engine(s360_ctx* c, int which);
+void flow_engines_follow_pipelining(s360_ctx* c);  // after c->pipeline changed (streams idle)
 
 }  // namespace s360
