@@ -6,10 +6,11 @@ PixFlow flows, novel-view strips, panorama assembly, 4 pole flows + warps, compo
 8192x8192 — everything renderStereoPanorama does between decoded inputs and the stacked equirect
 (TestRenderStereoPanorama.cpp:716-972). Inputs are uploaded to HBM before the timed region.
 
-Timed region (`value`): every rank renders K independent frames of BASELINE.json configs[2] with up to `--inflight`
-frames in flight on its GPU (one context + HIP stream each, every context holds a DIFFERENT frame of the synthetic
-stream; a single frame is latency-bound by PixFlow's raster-order sweeps and leaves most of the chip idle, DESIGN.md
-§5/§7). Per-GPU work is fixed => "scaling": "weak"; `value` is the aggregate over all ranks. After the timed region
+Timed region (`value`): every rank renders independent frames of BASELINE.json configs[2]: `--inflight` contexts (2; one
+HIP stream and one submitting host thread each) x `--slots` frame slots (22: the frames of a context go through ONE launch
+sequence, their flows in the same batched kernels), every slot a DIFFERENT frame of the synthetic stream — 44 frames
+resident in 251 GB of HBM (a single frame is latency-bound by PixFlow's raster-order sweeps and leaves most of the chip
+idle; the pole flows' serial chain costs a batch the same whatever it holds: DESIGN.md sections 5 - 7). A step = one batch. Per-GPU work is fixed => "scaling": "weak"; `value` is the aggregate over all ranks. After the timed region
 every context's equirect is downloaded and byte-compared with the render of the same inputs by one context alone
 (`checked`).
 
@@ -24,9 +25,10 @@ Then, one context alone on the GPU (nothing else in flight, so kernel durations 
     against the HBM roofline, and the same frame with the reference presets' sharpening 0.25;
   * `config2_flow_pair`: BASELINE configs[1], one 2048x2048 pair, both directions, GPU vs the CPU oracle;
   * `video_stream`: configs[4] on one GPU — 190 frames of a rotating world with a moving disc, every frame
-    regularised toward its predecessor's device-resident flows, inputs fed from host memory through the upload stream
-    while the previous frame renders; with and without frame pipelining; steady state over frames 10-189, and what the
-    reference's per-frame state files would add (`spill_ms_per_frame`);
+    regularised toward its predecessor's device-resident flows, inputs fed from page-locked host buffers on the upload
+    stream while the previous frame renders, the finished frame fetched while the next one renders; with and without
+    frame pipelining; steady state over frames 10-189, and what the reference's per-frame state files would add
+    (`spill_ms_per_frame`); on N GPUs: one such stream per rank at the same time (a stream cannot use more than one GPU);
   * `end_to_end_files`: SURVEY 8d's "end-to-end incl. raw I/O" figure — the drop-in host program
     (host/TestRenderStereoPanorama --num_frames) rendering the first 14 frames of that stream from PNG files on disk to
     equirect PNG files on disk, its last frame compared with the same chain rendered through the C ABI in this process;
@@ -292,7 +294,7 @@ def main():
                          "in and out (a short GPU call while tuning the host side; prints that leg's record, not a bench line)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="contexts in flight per GPU (one HIP stream + one submitting host thread each)")
-    ap.add_argument("--slots", type=int, default=12,
+    ap.add_argument("--slots", type=int, default=22,
                     help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
                          "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
     ap.add_argument("--video-frames", type=int, default=190,

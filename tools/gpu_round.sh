@@ -8,9 +8,9 @@ O=gpurun_out/$TAG; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1
 grep -E "passed|failed|error" $O/pytest.log | tail -2
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-bash tools/make_profiles.sh $TAG 12 > $O/make_profiles.log 2>&1
+bash tools/make_profiles.sh $TAG ${SLOTS:-22} > $O/make_profiles.log 2>&1
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-ISO="python bench.py --inflight 1 --slots 12 --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+ISO="python bench.py --inflight 1 --slots ${SLOTS:-22} --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d /tmp/s360_prof/sq -o sq -- $ISO > $O/sq.log 2>&1
 {
   echo "# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT on: $ISO"
