@@ -322,8 +322,10 @@ int s360_set_sweep_mode(s360_ctx* ctx, const char* mode);
  * s360_frame_finish (pole units, composite: TRSP:811-960) is enqueued on a second HIP stream and overlaps the side
  * stage (s360_frame_render_pairs: projection, flows, novel views, TRSP:320-384) of the NEXT frame; the three buffers
  * the two stages share are ordered by events inside the library. Results are unchanged. Calls that return data
- * (download, get_*, cubemap) and s360_synchronize wait for both streams. Not meant for the sharded (multi-GPU) frame,
- * whose strip gather runs on s360_stream(). */
+ * (download, get_*, cubemap) and s360_synchronize wait for both streams. The sharded (multi-GPU) frame's split phases
+ * (s360_frame_exchange_strips / _gather_strips / _pole_units / _gather_pole_layers / _composite) enqueue their exchanges on
+ * s360_stream() and are refused with S360_ERR_STATE while pipelining is on: nothing would order them against the second
+ * stream (a stream keeps its temporal state on one GPU anyway). */
 int s360_set_frame_pipelining(s360_ctx* ctx, int on);
 
 /* ---- measurement -------------------------------------------------------------------------- */

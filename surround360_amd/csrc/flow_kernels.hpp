@@ -14,7 +14,7 @@ struct BlurTaps {  // centre tap k[0] and the r symmetric taps k[1..r]
 // Which image planes a flow of the batch uses: flow b matches image i0[b] (I0) against i1[b] (I1).
 // The 14 side pairs need only 28 image pyramids for 28 flows (LtoR and RtoL share them). Device arrays of B ints
 // (a batch can hold the flows of many frames).
-constexpr int kMaxFlows = 1024;
+constexpr int kMaxFlows = 2048;  // (a limit of the tables only: the batch is the z dimension of the launches)
 struct FlowIdx {
   const int* i0;
   const int* i1;

@@ -137,3 +137,21 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
     code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)  # comments may mention where pointers come from
     assert "torch" not in code and "hip/" not in code and "hipStream" not in code and "#include <std" in code
+
+
+def test_page_locked_buffers_without_a_device(s360lib):
+    """s360_host_alloc / s360_host_free / s360_frame_uploads_complete (round 4: streaming hosts) where no HIP device is attached:
+    the allocation fails loudly (NULL + a message: there is no silent pageable fallback), freeing NULL is a no-op, a NULL
+    context is an argument error."""
+    import ctypes as C
+    if s360lib.s360_device_count() > 0:
+        p = s360lib.s360_host_alloc(1 << 20)
+        assert p
+        s360lib.s360_host_free(p)
+    else:
+        assert not s360lib.s360_host_alloc(1 << 20)
+        assert b"s360_host_alloc" in s360lib.s360_last_error(None)
+    assert not s360lib.s360_host_alloc(0)
+    s360lib.s360_host_free(None)
+    assert s360lib.s360_frame_uploads_complete(None) < 0
+    assert s360lib.s360_frame_download_equirect_of(None, 0, C.c_void_p()) < 0
