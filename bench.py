@@ -326,7 +326,7 @@ def main():
     # a GPU — the library's sources compiled for the CPU (tools/libs360_emu.so), a rig scaled to 128x128 cameras, eqr
     # 252x126, a handful of steps — to check the script's control flow. Its JSON line says "dry_run".
     dry = os.environ.get("S360_TEST_EMULATED_LIB") == "1"
-    rig_path, cam_size, world_h, pair_size = RIG, 2048, 4096, 2048
+    rig_path, cam_size, world_h, pair_size = RIG, 2048, 8192, 2048
     flags = dict(FLAGS_8K)
     if dry:
         from surround360_amd import _capi
@@ -351,7 +351,8 @@ def main():
     S = max(1, args.slots)
     # ---- synthetic stream: one seeded equirect world (noise + near objects at 2 m / 5 m), rendered
     # through the 17 rig cameras on the GPU; frame k = world rotated by 0.2 deg * k, one disc moving 0.5 deg per frame.
-    # (The world is 8192x4096: the 16384x8192 of §8d needs 3 GB for the texture + depth alone; stated in `data`.)
+    # (The world is the 16384x8192 texture SURVEY 8d names — 2.1 GB of texture + depth on the device while the frames are
+    # rendered, freed before the contexts are made; rounds 1-3 used 8192x4096.)
     n_video = 0 if (args.no_extras or world > 1) else max(args.video_frames, 12)
     # distinct frames kept in host memory for the stream leg: all of them if the host has room (17 x 12.6 MB each),
     # otherwise a ring walked forwards and backwards (consecutive frames still differ by one step of motion)
@@ -718,12 +719,12 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded 8192x4096 equirect world through the 17-camera rig, 2048x2048 inputs; every in-flight "
-                "context holds a different frame of the stream)",
-        "config": {"workload": "BASELINE configs[2]: full 17-cam synthetic frame (2048x2048 inputs rendered from a seeded "
-                               "8192x4096 equirect world; SURVEY 8d names 16384x8192), eqr 8400x4096 -> stereo 8192x8192, "
+        "data": "synthetic (seeded %dx%d equirect world through the 17-camera rig, 2048x2048 inputs; every in-flight "
+                "context holds a different frame of the stream)" % (2 * world_h, world_h),
+        "config": {"workload": "BASELINE configs[2]: full 17-cam synthetic frame (2048x2048 inputs rendered from the seeded "
+                               "%dx%d equirect world of SURVEY 8d), eqr 8400x4096 -> stereo 8192x8192, "
                                "top+bottom poles, pixflow_low, sharpening 0.25 (the reference's 8k preset, "
-                               "batch_process_video.py:194-199)",
+                               "batch_process_video.py:194-199)" % (2 * world_h, world_h),
                    "parallelism": "frames: %d GPU(s) x %d contexts x %d slots, no collective" % (world, F, S),
                    "parallelism_note": "independent frames: each GPU renders whole frames, %d contexts in flight per GPU (one HIP "
                                        "stream each) of %d frame slots, no data-path collective" % (F, S),
