@@ -274,3 +274,34 @@ def png_pixels_bgr(path):
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 6)
     px = png_unfilter(rows, 6).reshape(h, w, 3, 2).astype(np.uint16)
     return ((px[..., 0] << 8) | px[..., 1])[..., ::-1]
+
+
+def check_two_streams(exe, tmp_path, env=None):
+    """`exe --num_frames 3 --num_streams 2` against two single invocations with the two segments (frames 7-8, frame 9): every
+    equirect and the state files behind each stream's last frame, file for file; the first stream's frames against the
+    reference program's chain. Used on the CPU emulation (two emulated devices) and on the GPU box (both streams on its GPU)."""
+    import rigutil
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
+                                  CAM / 2048.0)
+    name = "three_frames_sharpened"
+    frames = CASES[name][0]
+    both = run_stream(exe, str(tmp_path / "both"), rig, name, more_args=["--num_streams", "2", "--v", "1"], env=env)
+    one = run_stream(exe, str(tmp_path / "one"), rig, name, first=0, count=2, env=env)
+    two = run_stream(exe, str(tmp_path / "two"), rig, name, first=2, count=1, env=env)
+
+    def files(root, frame):
+        d = {"eqr": _digest_png(os.path.join(root, "eqr_%s.png" % frame))}
+        for folder in (os.path.join(root, "flow", frame), os.path.join(root, "debug", frame, "flow_images")):
+            if os.path.isdir(folder):
+                for fn in sorted(os.listdir(folder)):
+                    p = os.path.join(folder, fn)
+                    d[fn] = _digest_png(p) if fn.endswith(".png") else hashlib.sha256(open(p, "rb").read()).hexdigest()
+        return d
+    for f, single in ((frames[0], one), (frames[1], one), (frames[2], two)):
+        a, b = files(both, f), files(single, f)
+        assert a == b, "frame %s: %s" % (f, sorted(k for k in set(a) | set(b) if a.get(k) != b.get(k))[:8])
+    assert len(files(both, frames[1])) > 30 and len(files(both, frames[2])) > 30  # the state behind each stream's last frame
+    # and the first stream's frames are the reference program's chain (frame 9 of the chain has a predecessor, the segment's has not)
+    golden = json.load(open(GOLDEN))[name]
+    for f in frames[:2]:
+        assert files(both, f)["eqr"] == golden["eqr_%s" % f], f

@@ -103,30 +103,4 @@ def test_two_streams_on_two_gpus_equal_two_single_runs(tmp_path, emu_programs):
     N. host/TestRenderStereoPanorama --num_frames 3 --num_streams 2 on two (emulated) devices renders frames 7-8 as a stream
     on device 0 and frame 9 as a stream of its own on device 1 — and writes, file for file, what two separate invocations
     with those frame ranges write: equirects of all three frames, the state files behind the last frame of each stream."""
-    import hashlib
-    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
-                                  refprog.CAM / 2048.0)
-    exe = os.path.join(emu_programs, "TestRenderStereoPanorama")
-    name = "three_frames_sharpened"
-    frames = refprog.CASES[name][0]
-    env = dict(os.environ, EMU_DEVICES="2")
-    both = refprog.run_stream(exe, str(tmp_path / "both"), rig, name, more_args=["--num_streams", "2", "--v", "1"], env=env)
-    one = refprog.run_stream(exe, str(tmp_path / "one"), rig, name, first=0, count=2)
-    two = refprog.run_stream(exe, str(tmp_path / "two"), rig, name, first=2, count=1)
-
-    def files(root, frame):
-        d = {"eqr": refprog._digest_png(os.path.join(root, "eqr_%s.png" % frame))}
-        for folder in (os.path.join(root, "flow", frame), os.path.join(root, "debug", frame, "flow_images")):
-            if os.path.isdir(folder):
-                for fn in sorted(os.listdir(folder)):
-                    p = os.path.join(folder, fn)
-                    d[fn] = refprog._digest_png(p) if fn.endswith(".png") else hashlib.sha256(open(p, "rb").read()).hexdigest()
-        return d
-    for f, single in ((frames[0], one), (frames[1], one), (frames[2], two)):
-        a, b = files(both, f), files(single, f)
-        assert a == b, "frame %s: %s" % (f, sorted(k for k in set(a) | set(b) if a.get(k) != b.get(k))[:8])
-    assert len(files(both, frames[1])) > 30 and len(files(both, frames[2])) > 30  # the state behind each stream's last frame
-    # and the first stream's frames are the reference program's chain (frame 9 of the chain has a predecessor, the segment's has not)
-    golden = json.load(open(refprog.GOLDEN))[name]
-    for f in frames[:2]:
-        assert files(both, f)["eqr"] == golden["eqr_%s" % f], f
+    refprog.check_two_streams(os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, dict(os.environ, EMU_DEVICES="2"))

@@ -54,3 +54,13 @@ def test_hip_raw2rgb_writes_what_the_reference_program_writes(tmp_path, name, s3
     a = refprog.png_pixels_bgr(outp)
     digest = hashlib.sha256(repr((a.shape, str(a.dtype))).encode() + a.tobytes()).hexdigest()
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
+
+
+def test_two_streams_in_one_process(tmp_path, s360lib):
+    """host/TestRenderStereoPanorama --num_frames 3 --num_streams 2 (BASELINE configs[4] on N GPUs: one stream per GPU; on a
+    one-GPU box both streams share the device, each with a context, host thread and temporal state of its own) writes file for
+    file what two separate invocations with the two frame ranges write, and the first stream's frames are the reference
+    program's chain (tests/test_cpu_parallel.py runs the same check on the emulation with two devices)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(refprog.ROOT, "host"), "-s"])
+    refprog.check_two_streams(os.path.join(refprog.ROOT, "host", "TestRenderStereoPanorama"), tmp_path)
