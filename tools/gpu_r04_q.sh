@@ -4,11 +4,11 @@
 cd "$(dirname "$0")/.."
 O=gpurun_out/r04_q; mkdir -p $O
 {
-echo "# side level 607x884, 168 flows, one stream (Gpx/s)"
-echo -n "LPP3 two waves (default)  : "; S360_QUAD_LPP=3 timeout 100 tools/sweep_microbench tp1 607 884 168 1 3
-echo -n "LPP4 two waves            : "; S360_QUAD_LPP=4 timeout 100 tools/sweep_microbench tp1 607 884 168 1 3
-echo -n "LPP4 three waves (occ3)   : "; S360_QUAD_OCC3=1 timeout 100 tools/sweep_microbench tp1 607 884 168 1 3
-echo -n "LPP4 occ3, 8 waves per CU : "; S360_QUAD_OCC3=1 S360_QUAD_WAVES_PER_CU=8 timeout 100 tools/sweep_microbench tp1 607 884 168 1 3
+echo "# side level 607x884, 112 flows, one stream (Gpx/s)"
+echo -n "LPP3 two waves (default)  : "; S360_QUAD_LPP=3 timeout 100 tools/sweep_microbench tp1 607 884 112 1 3
+echo -n "LPP4 two waves            : "; S360_QUAD_LPP=4 timeout 100 tools/sweep_microbench tp1 607 884 112 1 3
+echo -n "LPP4 three waves (occ3)   : "; S360_QUAD_OCC3=1 timeout 100 tools/sweep_microbench tp1 607 884 112 1 3
+echo -n "LPP4 occ3, 8 waves per CU : "; S360_QUAD_OCC3=1 S360_QUAD_WAVES_PER_CU=8 timeout 100 tools/sweep_microbench tp1 607 884 112 1 3
 echo "# pole level 5040x1052, 24 flows, 55 % of the rows masked"
 echo -n "LPP4 two waves (default)  : "; S360_MB_MASKROWS=0.55 timeout 100 tools/sweep_microbench tp1 5040 1052 24 1 3
 echo -n "LPP4 three waves (occ3=2) : "; S360_MB_MASKROWS=0.55 S360_QUAD_OCC3=2 timeout 100 tools/sweep_microbench tp1 5040 1052 24 1 3
