@@ -52,10 +52,3 @@ def default_throughput_digest(s360lib):
 
 def test_throughput_equals_latency_kernel(default_throughput_digest):
     assert _flows_digest() == default_throughput_digest
-
-
-def test_three_waves_per_simd_build_equals_default(default_throughput_digest):
-    """S360_QUAD_OCC3=2: every throughput launch runs the build of the same kernel text whose register allocation is held to
-    three waves per SIMD (sweep_quad.hip; off by default until it has been timed). Same text, other registers, spills at the
-    band and chunk boundaries: the flows must not change."""
-    assert _flows_digest(TEST_SWEEP_MODE="throughput", S360_QUAD_OCC3="2") == default_throughput_digest

@@ -7,8 +7,7 @@
 A loop is a backward branch (s_cbranch_* / s_branch to a label that was defined earlier in the same function); its body is the
 text between the label and the branch. Per loop: instructions, VALU / SALU / LDS / global / scratch instructions, and the
 `s_waitcnt vmcnt(..)` it contains — the sweep kernels' steady steps must have none (loads and stores retire through one in-order
-counter on gfx950: a wait inside the step waits for the next chunk's prefetches), and a build that spills
-must not touch scratch there either. Per kernel: VGPRs, SGPR / VGPR spills, scratch and LDS bytes, waves per SIMD from the
+counter on gfx950: a wait inside the step waits for the next chunk's prefetches), and no scratch access. Per kernel: VGPRs, SGPR / VGPR spills, scratch and LDS bytes, waves per SIMD from the
 metadata the compiler wrote. tests/test_cpu_isa.py holds the product's sweep kernels to that.
 """
 import argparse
