@@ -1,5 +1,7 @@
-// Raw2Rgb — the reference's raw-to-RGB converter (source/camera_isp/Raw2Rgb.cpp) on the GPU, non-accelerated (soft
-// ISP) path: --input_image_path (an 8-/16-bit greyscale PNG, or a headerless 16-bit ".raw" whose size comes from the
+// Raw2Rgb — the reference's raw-to-RGB converter (source/camera_isp/Raw2Rgb.cpp) on the GPU. Without --accelerate the soft
+// ISP (CameraIsp.h, Raw2Rgb.cpp:441-456; pinned to the reference compiled); with --accelerate [--fast] the arithmetic of
+// CameraIspPipe (Raw2Rgb.cpp:427-440: --demosaic_filter is not read there, --resize must be 1; restated from CameraIspGen.cpp,
+// not pinned — include/s360.h, s360_isp_config.pipe). --input_image_path (an 8-/16-bit greyscale PNG, or a headerless 16-bit ".raw" whose size comes from the
 // configuration's "width"/"height", Raw2Rgb.cpp:395-404), --isp_config_path (the ISP JSON), --output_image_path (8- or
 // 16-bit RGB PNG by --output_bpp), --demosaic_filter (0 bilinear, 2 edge-aware; 1 = DCT is not available), --resize,
 // --disable_tone_curve, --black_level_offset. 8-bit inputs are widened like convert8bitTo16bit (v << 8 | v,
@@ -81,6 +83,8 @@ int main(int argc, char** argv) {
   cfg.resize = std::atoi(F["resize"].c_str());
   cfg.disable_tone_curve = tone_off ? 1 : 0;
   cfg.black_level_offset = std::atoi(F["black_level_offset"].c_str());
+  const auto on = [&](const char* k) { return F[k] == "true" || F[k] == "1"; };
+  cfg.pipe = on("accelerate") ? (on("fast") ? 2 : 1) : 0;  // CameraIspPipe(json, FLAGS_fast, FLAGS_output_bpp), Raw2Rgb.cpp:427-428
   if (s360_isp_config_from_json(json.c_str(), &cfg) < 0) die(s360_last_error(nullptr));
 
   // input: ".raw" = headerless 16-bit samples (readRaw), anything else is decoded as a greyscale image of unchanged depth

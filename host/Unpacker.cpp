@@ -7,7 +7,9 @@
 //     <output_dir>/<serial>/<frame>.png (Unpacker.cpp:136-183),
 // then renames <output_dir>/<serial> to cam0, cam1, ... in serial order (Unpacker.cpp:203-219). One host thread per
 // camera like the reference's std::async tasks; each camera owns one ISP object (the reference builds one per frame).
-// The arithmetic is the soft ISP's (s360_isp_process_packed), not the Halide pipeline's.
+// The ISP is the reference Unpacker's: CameraIspPipe(json, fast = false, 16 bits) (Unpacker.cpp:165-183), i.e. the accelerated
+// pipeline's arithmetic (s360_isp_config.pipe = 1: restated from CameraIspGen.cpp, not pinned — include/s360.h). --soft_isp
+// runs the frames through the soft CameraIsp arithmetic instead (pinned bit for bit to CameraIsp.h).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -122,7 +124,7 @@ std::string frame_path(const std::string& dir, uint32_t serial, size_t frame, co
 
 int main(int argc, char** argv) {
   std::map<std::string, std::string> F = {{"isp_dir", ""}, {"output_dir", ""}, {"output_raw_dir", ""}, {"bin_list", ""},
-                                          {"start_frame", "0"}, {"frame_count", "0"}, {"device", "0"}, {"log_dir", ""},
+                                          {"start_frame", "0"}, {"frame_count", "0"}, {"device", "0"}, {"soft_isp", "false"}, {"log_dir", ""},
                                           {"stderrthreshold", "0"}, {"v", "0"}, {"logbuflevel", "0"}};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -131,6 +133,7 @@ int main(int argc, char** argv) {
     std::string key = a, val;
     const size_t eq = a.find('=');
     if (eq != std::string::npos) { key = a.substr(0, eq); val = a.substr(eq + 1); }
+    else if (key == "soft_isp") val = "true";  // (a boolean flag)
     else { if (i + 1 >= argc) die("flag '" + key + "' is missing its argument"); val = argv[++i]; }
     if (!F.count(key)) { std::fprintf(stderr, "ERROR: unknown command line flag '%s'\n", key.c_str()); return 1; }
     F[key] = val;
@@ -203,6 +206,7 @@ int main(int argc, char** argv) {
               s360_isp_config cfg;
               s360_isp_config_defaults(&cfg);
               cfg.output_bpp = 16;  // kOutputBpp (Unpacker.cpp:167)
+              cfg.pipe = (F["soft_isp"] == "true" || F["soft_isp"] == "1") ? 0 : 1;  // CameraIspPipe, kFast = false (:166-168)
               if (s360_isp_config_from_json(ss.str().c_str(), &cfg) < 0) throw std::runtime_error(s360_last_error(nullptr));
               if (s360_isp_create(&isp, device, &cfg) < 0) throw std::runtime_error(s360_last_error(nullptr));
               ispSerial = serial;

@@ -338,8 +338,10 @@ int s360_profile_get(s360_ctx* ctx, char* names_out, size_t names_cap, float* ms
 int s360_save_flow_to_file(const char* path, const float* flow, int w, int h);
 int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, size_t cap_floats);
 
-/* ---- soft ISP: 16-bit Bayer raw -> BGR ---------------------------------
- * Replaces the non-accelerated path of Raw2Rgb (SR/camera_isp/Raw2Rgb.cpp:441-456 -> CameraIsp.h): black level,
+/* ---- ISP: 16-bit Bayer raw -> BGR --------------------------------------
+ * Both arithmetics of the reference (s360_isp_config.pipe): the soft CameraIsp described here and, from round 4, the
+ * accelerated CameraIspPipe (camera_isp/CameraIspPipe.h, CameraIspGen.cpp).
+ * pipe = 0 replaces the non-accelerated path of Raw2Rgb (SR/camera_isp/Raw2Rgb.cpp:441-456 -> CameraIsp.h): black level,
  * anti-vignetting, white balance, clamp + stretch, demosaic (bilinear or edge-aware), composite CCM + tone-curve LUT,
  * IIR unsharp mask, 8- or 16-bit output. Independent of s360_ctx (no rig is involved).
  * Not available: FREQUENCY_DM_FILTER (demosaic_filter 1; cv::dct) -> S360_ERR_INVALID_ARG.
@@ -370,6 +372,14 @@ typedef struct s360_isp_config {
   /* removeStuckPixels (CameraIsp.h:1024-1104), read when stuck_pixel_radius > 0 */
   int32_t stuck_pixel_threshold;
   float stuck_pixel_darkness_threshold;
+  /* Which of the reference's two ISP arithmetics runs: 0 = CameraIsp (CameraIsp.h; Raw2Rgb without --accelerate), PINNED bit
+   * for bit to the reference compiled here; 1 = CameraIspPipe (CameraIspPipe.h: the Halide pipeline of CameraIspGen.cpp —
+   * what Unpacker.cpp:176-183 runs and Raw2Rgb --accelerate), 2 = its `fast` variant (bilinear demosaic, no vignetting, no
+   * sharpening; Raw2Rgb --accelerate --fast). 1 and 2 are written from the generator's source and are NOT pinned: Halide
+   * cannot be built here, so a real build may differ at rounding level (it may contract a * b + c).
+   * With 1 / 2: resize must be 1, demosaic_filter and the stuck-pixel fields are not read (the pipeline has neither), and
+   * only GBRG and RGGB exist — any other bayer_pattern runs as GBRG, as CameraIspPipe::runPipe does (CameraIspPipe.h:133-141). */
+  int32_t pipe;
 } s360_isp_config;
 /* CameraIsp(json, output_bpp) defaults (CameraIsp.h:440-462) + Raw2Rgb's flag defaults. */
 void s360_isp_config_defaults(s360_isp_config* cfg);
@@ -387,13 +397,36 @@ int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* o
 /* The same from the sensor's packed bytes as Unpacker reads them from a .bin container (Unpacker.cpp:136-143;
  * RawConverter::convert8Frame / convert12Frame, RawConverter.cpp:15-59): bits 8 (w * h bytes) or 12 (3 * w / 2 bytes
  * per row, even w); widened to 16 bits on the device, then as s360_isp_process.
- * NOT the reference Unpacker's pixels: camera_isp/Unpacker.cpp:24,178 instantiates CameraIspPipe, the Halide-generated
- * pipeline, whose arithmetic differs from the soft CameraIsp (CameraIsp.h) and cannot be built or restated here (no
- * Halide). This entry point — and host/Unpacker on top of it — runs the SOFT-ISP arithmetic, the one Raw2Rgb runs
- * without --accelerate (Raw2Rgb.cpp:441-456), pinned bit for bit to CameraIsp.h compiled from the reference.
- * Also not available (S360_ERR_INVALID_ARG): demosaic_filter 1 = FREQUENCY_DM_FILTER (CameraIsp.h:1175-1192, needs
+ * The reference's Unpacker runs CameraIspPipe(json, fast = false, 16 bits) (Unpacker.cpp:176-183): an ISP object created
+ * with pipe = 1 runs that pipeline's arithmetic as restated from its generator (not pinned, see s360_isp_config.pipe); with
+ * pipe = 0 the frames go through the soft CameraIsp arithmetic, pinned bit for bit to CameraIsp.h compiled from the
+ * reference. host/Unpacker takes the first by default like the reference and the second with --soft_isp.
+ * Not available with pipe = 0 (S360_ERR_INVALID_ARG): demosaic_filter 1 = FREQUENCY_DM_FILTER (CameraIsp.h:1175-1192, needs
  * cv::dct) and stuck-pixel removal with a threshold for which the reference's pass is not a no-op (see s360_isp_config). */
 int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr);
+/* The functions Halide generates from camera_isp/CameraIspGen.cpp — CameraIspGen8, CameraIspGen16, CameraIspGenFast8,
+ * CameraIspGenFast16 (argument list CameraIspGen.cpp:704-712; called by CameraIspPipe::runPipe, CameraIspPipe.h:143-175) — as
+ * one entry point: the reference's own FFI boundary of the accelerated ISP. EVERY parameter is the caller's, in the units the
+ * generated functions take them (black levels in 16-bit counts, the two vignette tables and the truncated tone table as
+ * CameraIspPipe::initPipe builds them, the composite CCM as CameraIsp::setup leaves it); `isp` (created with pipe != 0, any
+ * configuration) only lends its device, stream and buffers. INTEGRATION.md section 3 shows the four generated
+ * functions written over this call, with which the reference's unmodified CameraIspPipe.h and Unpacker.cpp compile and run.
+ * Arithmetic: see s360_isp_config.pipe (not pinned). */
+typedef struct s360_camera_isp_gen_args {
+  const uint16_t* input;        /* height rows of input_stride uint16 (buffer_t stride[1]) */
+  int32_t input_stride, width, height;
+  const float* vignette_h;      /* [width][3]  (vignetteTableH(c, x)) */
+  const float* vignette_v;      /* [height][3] */
+  float black_level[3], white_balance_gain[3], clamp_min[3], clamp_max[3], sharpening[3]; /* R, G, B */
+  float sharpening_support, noise_core;
+  const float* ccm;             /* 3 x 3 row-major (ccm(i, j) = ccm[i + 3 j]) */
+  const void* tone_table;       /* [4096][3] uint8 (output_bpp 8) or uint16 (16) */
+  int32_t bgr;                  /* BGR: output channel c takes channel 2 - c */
+  int32_t bayer_pattern;        /* 0 GBRG, 1 RGGB */
+  int32_t fast, output_bpp;     /* which of the four functions */
+  void* output;                 /* [height][width][3] uint8 / uint16, interleaved (set_stride(0, 3)) */
+} s360_camera_isp_gen_args;
+int s360_isp_pipe_generated(s360_isp* isp, const s360_camera_isp_gen_args* args);
 /* A camera's raw Bayer frame through the ISP straight into a frame's source slot, on the context's upload stream and
  * without leaving the device — the reference's chain through files (Unpacker writes the ISP's 16-bit result as a PNG,
  * RigDescription::loadSideCameraImages / imread decodes it to 8 bits = its high byte). camera: side index, or

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "isp.h"
+#include "isp_pipe.h"
 #include "render.h"
 
 using namespace orc;
@@ -400,6 +401,16 @@ int orc_isp_config_size() { return (int)sizeof(IspConfig); }
 int orc_isp_run(const IspConfig* cfg, const uint16_t* raw, int w, int h, void* out, char* err, int err_cap) {
   try {
     ispRun(*cfg, raw, w, h, out);
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; }
+    return -1;
+  }
+}
+// the accelerated ISP's arithmetic (isp_pipe.h; CameraIspGen.cpp restated, parity unpinned). fast: CameraIspGenFast
+int orc_isp_pipe_run(const IspConfig* cfg, int fast, const uint16_t* raw, int w, int h, void* out, char* err, int err_cap) {
+  try {
+    ispPipeRun(*cfg, fast != 0, raw, w, h, out);
     return 0;
   } catch (const std::exception& e) {
     if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; }

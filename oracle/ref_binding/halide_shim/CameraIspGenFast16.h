@@ -1,0 +1,5 @@
+// oracle/ref_binding/halide_shim/CameraIspGenFast16.h — TEST INFRASTRUCTURE: the header Halide's compile_to_static_library("CameraIspGenFast16", ..)
+// writes (CameraIspGen.cpp:720-728), with the function implemented over libs360 instead of generated (camera_isp_gen_s360.h).
+#pragma once
+#include "camera_isp_gen_s360.h"
+S360_HALIDE_GENERATED(CameraIspGenFast16, 1, 16)

@@ -36,6 +36,31 @@ bool imwrite(const std::string& path, const Mat& img0, const std::vector<int>&) 
     }
     return true;
   }
+  if (img.type() == CV_16UC1 && path.size() > 4 && path.find(".tif", path.size() - 5) != std::string::npos) {
+    // the raw frames Unpacker keeps (Unpacker.cpp:145-152): a baseline little-endian TIFF, one strip, no compression
+    try {
+      pngio::OutFile f(path);
+      const uint32_t w = (uint32_t)img.cols, h = (uint32_t)img.rows, nbytes = w * h * 2, ifd = 8 + nbytes;
+      const uint8_t hdr[8] = {'I', 'I', 42, 0, (uint8_t)ifd, (uint8_t)(ifd >> 8), (uint8_t)(ifd >> 16), (uint8_t)(ifd >> 24)};
+      f.put(hdr, 8);
+      f.put(img.data, nbytes);
+      const uint32_t tags[9][4] = {{256, 4, 1, w}, {257, 4, 1, h}, {258, 3, 1, 16}, {259, 3, 1, 1}, {262, 3, 1, 1},
+                                   {273, 4, 1, 8}, {277, 3, 1, 1}, {278, 4, 1, h}, {279, 4, 1, nbytes}};
+      std::vector<uint8_t> d(2 + 12 * 9 + 4, 0);
+      d[0] = 9;
+      for (int i = 0; i < 9; ++i) {
+        uint8_t* e = &d[2 + 12 * i];
+        const uint16_t id = (uint16_t)tags[i][0], ty = (uint16_t)tags[i][1];
+        std::memcpy(e, &id, 2); std::memcpy(e + 2, &ty, 2); std::memcpy(e + 4, &tags[i][2], 4);
+        if (ty == 3) { const uint16_t v = (uint16_t)tags[i][3]; std::memcpy(e + 8, &v, 2); } else std::memcpy(e + 8, &tags[i][3], 4);
+      }
+      f.put(d.data(), d.size());
+      f.close();
+    } catch (const std::exception&) {
+      return false;
+    }
+    return true;
+  }
   if (img.depth() != CV_8U) shim::unsupported("imwrite of this depth");
   try {
     if (img.channels() == 1) {

@@ -1074,6 +1074,12 @@ int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w
     isp_process_packed(isp, frame, bits, w, h, out_bgr);
   });
 }
+int s360_isp_pipe_generated(s360_isp* isp, const s360_camera_isp_gen_args* args) {
+  return guard(nullptr, [&] {
+    need(isp && args, "null argument");
+    isp_pipe_generated(isp, *args);
+  });
+}
 int s360_isp_config_tables(const s360_isp_config* cfg, float* ccm9, float* lut, int w, int h, float* curve_h,
                            float* curve_v) {
   return guard(nullptr, [&] {

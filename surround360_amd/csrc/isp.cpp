@@ -100,6 +100,7 @@ void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.
   c->resize = flags.resize;
   c->disable_tone_curve = flags.disable_tone_curve;
   c->black_level_offset = flags.black_level_offset;
+  c->pipe = flags.pipe;
   const std::string s(text);
   JP p{s.data(), s.data() + s.size()};
   const JV root = p.document();
@@ -145,11 +146,15 @@ void isp_config_from_json(const char* text, s360_isp_config* c) {  // CameraIsp.
 // (CameraIsp::setup, buildToneCurveLut, addBlackLevelOffset). No device involved.
 void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut) {
   if (cfg.output_bpp != 8 && cfg.output_bpp != 16) throw Error(S360_ERR_INVALID_ARG, "output_bpp must be 8 or 16");
-  if (cfg.demosaic_filter == 1) throw Error(S360_ERR_INVALID_ARG, "demosaic_filter 1 (DCT) is not supported");
-  if (cfg.demosaic_filter != 0 && cfg.demosaic_filter != 2) throw Error(S360_ERR_INVALID_ARG, "expecting Demosaic filter in [0,2]");
+  if (cfg.pipe < 0 || cfg.pipe > 2) throw Error(S360_ERR_INVALID_ARG, "pipe must be 0 (CameraIsp), 1 (CameraIspPipe) or 2 (CameraIspPipe, fast)");
+  // CameraIspPipe has neither a demosaic filter choice nor stuck-pixel removal, and no resize: Raw2Rgb --accelerate sizes its
+  // output by --resize and lets the pipeline write the full frame into it (Raw2Rgb.cpp:421-437) — refused here
+  if (cfg.pipe && cfg.resize != 1) throw Error(S360_ERR_INVALID_ARG, "the accelerated pipeline (CameraIspPipe) has no resize");
+  if (!cfg.pipe && cfg.demosaic_filter == 1) throw Error(S360_ERR_INVALID_ARG, "demosaic_filter 1 (DCT) is not supported");
+  if (cfg.demosaic_filter < 0 || cfg.demosaic_filter > 2) throw Error(S360_ERR_INVALID_ARG, "expecting Demosaic filter in [0,2]");
   if (cfg.resize != 1 && cfg.resize != 2 && cfg.resize != 4 && cfg.resize != 8)
     throw Error(S360_ERR_INVALID_ARG, "expecting a resize value of 1, 2, 4, or 8. got " + std::to_string(cfg.resize));
-  if (cfg.stuck_pixel_radius > 0) {
+  if (cfg.stuck_pixel_radius > 0 && !cfg.pipe) {
     // removeStuckPixels' loop condition `k <= region.size() - stuckPixelThreshold` (size_t arithmetic, CameraIsp.h:1090-1092)
     // is false from the start for 2 <= threshold <= region.size(): the pass is a no-op. The smallest region is a red /
     // blue pixel's: the same-colour sites of a (2 R + 1)^2 window, R = stuck_pixel_radius = 2 x the JSON value.
@@ -220,6 +225,78 @@ void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut) 
   }
 }
 
+static void pipe_enqueue(s360_isp* o, hipStream_t st, const IspPipeDev& d, int w, int h, const float* vigH, const float* vigV,
+                         const unsigned short* toneTab);
+// The scalar preamble of the generated pipeline (CameraIspGen.cpp:318-337, 569-571, 605) from the parameters it is called with
+static void pipe_preamble(IspPipeDev& p, const float* black, const float* wb, const float* cmin, const float* cmax,
+                          const float* sharpening, float support, float noiseCore, const float* ccm9) {
+  const float maxRaw = float((1 << 16) - 1);
+  for (int k = 0; k < 3; ++k) {
+    const float minRaw = black[k];
+    const float rangeRaw = maxRaw - minRaw;
+    p.bias[k] = minRaw + cmin[k] * rangeRaw / wb[k];
+    p.invRange[k] = wb[k] / (rangeRaw * (cmax[k] - cmin[k]));
+    p.amount[k] = 1.0f + sharpening[k];
+  }
+  std::memcpy(p.ccm, ccm9, sizeof p.ccm);
+  p.alpha = powf(support, 1.0f / 4.0f);
+  p.noiseCore = noiseCore;
+  p.maxVal = float((1 << p.outputBpp) - 1);
+}
+// What CameraIspPipe hands its generated pipeline (CameraIspPipe.h:131-176) and what the generator's preamble derives from
+// it (CameraIspGen.cpp:318-337, 569-571, 605): float arithmetic in the written order.
+void isp_derive_pipe(const s360_isp_config& cfg, const IspDev& d, IspPipeDev& p) {
+  std::memset(&p, 0, sizeof p);
+  p.pattern = cfg.bayer_pattern == 0 ? 1 : 0;  // "GBRG" -> 0, else "RGGB" -> 1, else 0 (runPipe)
+  p.fast = cfg.pipe == 2;
+  p.outputBpp = cfg.output_bpp;
+  p.swizzle = 1;  // getImage(.., swizzle = true)
+  float black[3];
+  for (int k = 0; k < 3; ++k) black[k] = cfg.black_level[k] + float(cfg.black_level_offset);  // addBlackLevelOffset
+  pipe_preamble(p, black, cfg.white_balance_gain, cfg.clamp_min, cfg.clamp_max, cfg.sharpening, cfg.sharpening_support,
+                cfg.noise_core, d.ccm);
+}
+
+// The generated functions themselves (s360_isp_pipe_generated): every parameter comes from the caller, the object lends its
+// stream and buffers.
+void isp_pipe_generated(s360_isp* o, const s360_camera_isp_gen_args& a) {
+  if (!o->cfg.pipe) throw Error(S360_ERR_STATE, "s360_isp_pipe_generated needs an ISP object created with pipe = 1 or 2");
+  if (!a.input || !a.output || !a.vignette_h || !a.vignette_v || !a.ccm || !a.tone_table) throw Error(S360_ERR_INVALID_ARG, "null argument");
+  if (a.output_bpp != 8 && a.output_bpp != 16) throw Error(S360_ERR_INVALID_ARG, "output_bpp must be 8 or 16");
+  if (a.width < 16 || a.height < 16) throw Error(S360_ERR_INVALID_ARG, "image too small for the accelerated pipeline (needs at least 16x16)");
+  if (a.input_stride < a.width) throw Error(S360_ERR_INVALID_ARG, "input_stride is smaller than width");
+  if (a.bayer_pattern != 0 && a.bayer_pattern != 1) throw Error(S360_ERR_INVALID_ARG, "bayer_pattern is 0 (GBRG) or 1 (RGGB) at this level");
+  S360_HIP(hipSetDevice(o->device));
+  const int w = a.width, h = a.height;
+  IspPipeDev d;
+  std::memset(&d, 0, sizeof d);
+  d.pattern = a.bayer_pattern;
+  d.fast = a.fast != 0;
+  d.outputBpp = a.output_bpp;
+  d.swizzle = a.bgr != 0;
+  pipe_preamble(d, a.black_level, a.white_balance_gain, a.clamp_min, a.clamp_max, a.sharpening, a.sharpening_support, a.noise_core, a.ccm);
+  std::vector<unsigned short> tt((size_t)4096 * 3);
+  for (size_t i = 0; i < tt.size(); ++i)
+    tt[i] = a.output_bpp == 8 ? static_cast<const unsigned char*>(a.tone_table)[i] : static_cast<const unsigned short*>(a.tone_table)[i];
+  o->dRaw.ensure((size_t)w * h * sizeof(uint16_t));
+  o->dGenH.ensure((size_t)w * 3 * sizeof(float));
+  o->dGenV.ensure((size_t)h * 3 * sizeof(float));
+  o->dGenTone.ensure(tt.size() * sizeof(unsigned short));
+  if (a.input_stride == w) {
+    S360_HIP(hipMemcpyAsync(o->dRaw.p, a.input, (size_t)w * h * 2, hipMemcpyHostToDevice, o->st));
+  } else {  // (a padded buffer_t: row by row)
+    for (int y = 0; y < h; ++y)
+      S360_HIP(hipMemcpyAsync(o->dRaw.as<uint16_t>() + (size_t)y * w, a.input + (size_t)y * a.input_stride, (size_t)w * 2,
+                              hipMemcpyHostToDevice, o->st));
+  }
+  S360_HIP(hipMemcpyAsync(o->dGenH.p, a.vignette_h, (size_t)w * 3 * sizeof(float), hipMemcpyHostToDevice, o->st));
+  S360_HIP(hipMemcpyAsync(o->dGenV.p, a.vignette_v, (size_t)h * 3 * sizeof(float), hipMemcpyHostToDevice, o->st));
+  S360_HIP(hipMemcpyAsync(o->dGenTone.p, tt.data(), tt.size() * sizeof(unsigned short), hipMemcpyHostToDevice, o->st));
+  pipe_enqueue(o, o->st, d, w, h, o->dGenH.as<float>(), o->dGenV.as<float>(), o->dGenTone.as<unsigned short>());
+  S360_HIP(hipMemcpyAsync(a.output, o->dOut.p, (size_t)w * h * 3 * (a.output_bpp == 8 ? 1 : 2), hipMemcpyDeviceToHost, o->st));
+  S360_HIP(hipStreamSynchronize(o->st));
+}
+
 void isp_vignette_curves(const s360_isp_config& cfg, int w, int h, std::vector<float>& ch, std::vector<float>& cv) {
   const int maxDimension = std::max(w, h);  // curveHAtPixel / curveVAtPixel (CameraIsp.h:709-715)
   ch.resize((size_t)w * 3);
@@ -250,6 +327,14 @@ void isp_init(s360_isp* o, int device, const s360_isp_config& cfg) {
     std::memcpy(&u, &v, 8);
     tab[i] = u - ((unsigned long long)i << 47);
   }
+  if (cfg.pipe) {
+    isp_derive_pipe(cfg, o->dev, o->pipe);
+    std::vector<unsigned short> tt(o->lut.size());  // `const int r = toneCurveLut[i][0]` into the 8- / 16-bit table (CameraIspPipe.h:67-81)
+    for (size_t i = 0; i < tt.size(); ++i) tt[i] = (unsigned short)(int)o->lut[i];
+    o->dToneTab.ensure(tt.size() * sizeof(unsigned short));
+    S360_HIP(hipMemcpyAsync(o->dToneTab.p, tt.data(), tt.size() * sizeof(unsigned short), hipMemcpyHostToDevice, o->st));
+    S360_HIP(hipStreamSynchronize(o->st));  // (tt goes out of scope)
+  }
   o->dExp.ensure(sizeof tab);
   S360_HIP(hipMemcpyAsync(o->dExp.p, tab, sizeof tab, hipMemcpyHostToDevice, o->st));
   S360_HIP(hipStreamSynchronize(o->st));
@@ -277,13 +362,44 @@ void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int inW, in
   isp_run_uploaded(o, inW, inH, out);
 }
 
+// The accelerated pipeline on the frame in dRaw: buffers, launch; the result is left in dOut.
+static void pipe_enqueue(s360_isp* o, hipStream_t st, const IspPipeDev& d, int w, int h, const float* vigH, const float* vigV,
+                         const unsigned short* toneTab) {
+  const size_t n = (size_t)w * h;
+  o->dOut.ensure(n * 3 * (d.outputBpp == 8 ? 1 : 2));
+  o->dPlane.ensure((size_t)(w + 16) * (h + 16) * sizeof(float));
+  o->dImg.ensure(n * 3 * sizeof(float));
+  if (!d.fast) {
+    o->dFlag.ensure((size_t)(w + 12) * (h + 12));
+    o->dGreen.ensure((size_t)(w + 4) * (h + 4) * sizeof(float));
+    o->dLp.ensure(n * 3 * sizeof(float));
+    o->dScratch.ensure(n * 3 * sizeof(float));
+    o->dState.ensure((size_t)3 * std::max(w, h) * sizeof(float));
+  }
+  IspPipeBufs P;
+  P.site = o->dPlane.as<float>();
+  P.green = o->dGreen.as<float>();
+  P.tone = o->dImg.as<float>();
+  P.low = o->dLp.as<float>();
+  P.scratch = o->dScratch.as<float>();
+  P.state = o->dState.as<float>();
+  P.flag = o->dFlag.as<unsigned char>();
+  P.vigH = vigH;
+  P.vigV = vigV;
+  P.toneTab = toneTab;
+  P.exptab = o->dExp.as<unsigned long long>();
+  isp_pipe_launch(st, d, o->dRaw.as<unsigned short>(), w, h, P, o->dOut.p);
+  S360_HIP(hipGetLastError());
+}
+
 // Enqueues the ISP of the frame already in dRaw on `st`; the result (B,G,R, 8 or 16 bit) is left in dOut.
 static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   const s360_isp_config& cfg = o->cfg;
   const int w = inW / cfg.resize, h = inH / cfg.resize;
   // the 9x9 homogeneity window and the reflected +-2 taps index up to 4 pixels past an edge (the reference reads out
-  // of bounds below that size)
+  // of bounds below that size); the pipeline mirrors 8 pixels beyond every edge
   if (w < 8 || h < 8) throw Error(S360_ERR_INVALID_ARG, "image too small for the ISP (needs at least 8x8 after resize)");
+  if (cfg.pipe && (w < 16 || h < 16)) throw Error(S360_ERR_INVALID_ARG, "image too small for the accelerated pipeline (needs at least 16x16)");
   const size_t n = (size_t)w * h;
   s360_isp::Curves* cur = nullptr;
   for (auto& cv : o->curves)
@@ -293,6 +409,8 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
     o->curveNext = (o->curveNext + 1) % 4;
     std::vector<float> ch, cv;
     isp_vignette_curves(cfg, w, h, ch, cv);
+    if (cfg.pipe)  // initPipe stores curveHAtPixel's v[0], v[2], v[1] (CameraIspPipe.h:84-90); the vertical table is straight
+      for (int j = 0; j < w; ++j) std::swap(ch[(size_t)j * 3 + 1], ch[(size_t)j * 3 + 2]);
     cur->h_.ensure(ch.size() * sizeof(float));
     cur->v_.ensure(cv.size() * sizeof(float));
     S360_HIP(hipMemcpyAsync(cur->h_.p, ch.data(), ch.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -302,6 +420,10 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
     cur->h = h;
   }
   const size_t outBytes = n * 3 * (cfg.output_bpp == 8 ? 1 : 2);
+  if (cfg.pipe) {
+    pipe_enqueue(o, st, o->pipe, w, h, cur->h_.as<float>(), cur->v_.as<float>(), o->dToneTab.as<unsigned short>());
+    return;
+  }
   o->dPlane.ensure(n * sizeof(float));
   o->dImg.ensure(n * 3 * sizeof(float));
   o->dOut.ensure(outBytes);

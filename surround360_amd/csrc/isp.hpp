@@ -23,6 +23,23 @@ struct IspFrameBufs {
   const float *curveH, *curveV, *lut;
   const unsigned long long* exptab;
 };
+// the accelerated pipeline's arithmetic (CameraIspPipe / CameraIspGen.cpp; isp_kernels.hip, second half)
+struct IspPipeDev {
+  int pattern;  // 0 GBRG, 1 RGGB (CameraIspPipe::runPipe knows no other, CameraIspPipe.h:133-141)
+  int fast, outputBpp, swizzle;
+  float bias[3], invRange[3];  // A (x - B) of black level, white balance and clamp (CameraIspGen.cpp:318-337)
+  float ccm[9];                // composite CCM x 4095
+  float alpha, noiseCore, amount[3], maxVal;
+};
+struct IspPipeBufs {
+  float *site, *green, *tone, *low, *scratch, *state;  // site: (w + 16) x (h + 16); green: (w + 4) x (h + 4); tone / low / scratch: h x w x 3
+  unsigned char* flag;                                  // (w + 12) x (h + 12)
+  const float *vigH, *vigV;                             // [w][3] (curve columns 0, 2, 1: CameraIspPipe.h:88-89), [h][3]
+  const unsigned short* toneTab;                        // [4096][3]: the tone curve truncated to the output type
+  const unsigned long long* exptab;
+};
+void isp_pipe_launch(hipStream_t st, const IspPipeDev& d, const unsigned short* raw, int w, int h, const IspPipeBufs& B,
+                     void* out);
 void isp_launch_unpack(hipStream_t st, const unsigned char* frame, int bits, int w, int h, unsigned short* out);
 void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int inW, int inH, const IspFrameBufs& B,
                 void* out);
@@ -35,7 +52,10 @@ struct s360_isp {
   hipStream_t st = nullptr;
   s360_isp_config cfg;
   s360::IspDev dev;
+  s360::IspPipeDev pipe;  // used instead of `dev` when cfg.pipe != 0
   std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
+  s360::DevBuf dToneTab;  // pipe: [4096][3] uint16
+  s360::DevBuf dGenH, dGenV, dGenTone;  // s360_isp_pipe_generated: the caller's tables
   s360::DevBuf dLut, dExp, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dState, dOut, dPacked;
   // vignette curves per output size (curveHAtPixel / curveVAtPixel): a rig's side and pole cameras may differ in
   // resolution, so a few sizes are kept instead of rebuilding (and synchronising the upload stream) at every switch
@@ -52,10 +72,12 @@ namespace s360 {
 void isp_config_defaults(s360_isp_config* c);
 void isp_config_from_json(const char* text, s360_isp_config* c);
 void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut);
+void isp_derive_pipe(const s360_isp_config& cfg, const IspDev& d, IspPipeDev& p);
 void isp_vignette_curves(const s360_isp_config& cfg, int w, int h, std::vector<float>& ch, std::vector<float>& cv);
 void isp_init(s360_isp* o, int device, const s360_isp_config& cfg);
 void isp_process(s360_isp* o, const uint16_t* raw16, int w, int h, void* out);
 void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int w, int h, void* out);
+void isp_pipe_generated(s360_isp* o, const s360_camera_isp_gen_args& a);
 void isp_release(s360_isp* o);
 void* isp_raw_buffer(s360_isp* o, int inW, int inH);
 const void* isp_enqueue_on(s360_isp* o, hipStream_t st, unsigned long long ctxUid, int inW, int inH);

@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) void k_isp_color(const float* __restrict__ p, 
 constexpr int IR_ROWS = 21, IR_T = 64, IR_STRIDE = 195, IR_Q = IR_ROWS * 3;  // IR_Q wave-wide loads per tile
 // causal (ANTI false): in = image, out[m] = state after consuming in[reflect(m + 1)], m = 0 .. w-1, starting from in[0];
 // anticausal (ANTI true): in = the causal pass's output, out[m] = clamp(state after consuming in[reflect(m - 1)]), m = w-1 .. 0
-template <bool ANTI>
+// PIPE: the accelerated pipeline's variant of the same recurrence (CameraIspGen.cpp:451-500, `lp`): the chain starts AT the
+// first element (which keeps its value), consumes in[m] instead of in[reflect(m +- 1)], and nothing is clamped.
+template <bool ANTI, bool PIPE>
 __global__ __launch_bounds__(64) void k_isp_iir_rows_t(const float* __restrict__ in, float* __restrict__ out,
                                                        float* __restrict__ state, int w, int h, float alpha, float maxVal) {
   __shared__ float s_t[IR_ROWS * IR_STRIDE];
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(64) void k_isp_iir_rows_t(const float* __restrict__
     for (int q = 0; q < IR_Q; ++q) {
       const int rr = q / 3, e = (q % 3) * 64 + lane;
       const int p = e / 3, ch = e - 3 * p;
-      int pos = m0 + p + (ANTI ? -1 : 1);
+      int pos = m0 + p + (PIPE ? 0 : ANTI ? -1 : 1);
       pos = reflecti(pos, w);
       pos = min(max(pos, 0), w - 1);  // (positions behind the image's end are never walked)
       const int ii = min(row0 + rr, h - 1);
@@ -297,18 +299,18 @@ __global__ __launch_bounds__(64) void k_isp_iir_rows_t(const float* __restrict__
     if (chain) {
       float* t = &s_t[r * IR_STRIDE + k];
       const int n = min(IR_T, w - m0);
-      if (n == IR_T) {
+      if (n == IR_T && !(PIPE && tt == 0)) {
 #pragma unroll 8
         for (int pp = 0; pp < IR_T; ++pp) {
           const int p = ANTI ? IR_T - 1 - pp : pp;
           v = t[3 * p] * ia + v * alpha;
-          t[3 * p] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+          t[3 * p] = ANTI && !PIPE ? clampf(v, 0.0f, maxVal) : v;
         }
       } else {
         for (int pp = 0; pp < n; ++pp) {
           const int p = ANTI ? n - 1 - pp : pp;
-          v = t[3 * p] * ia + v * alpha;
-          t[3 * p] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+          if (!(PIPE && m0 + p == (ANTI ? w - 1 : 0))) v = t[3 * p] * ia + v * alpha;  // (PIPE: the chain's first element stays)
+          t[3 * p] = ANTI && !PIPE ? clampf(v, 0.0f, maxVal) : v;
         }
       }
     }
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(64) void k_isp_iir_rows_t(const float* __restrict__
 // — and, through a register copy, for the NEXT batch — at every step: 0.47 ms per image against 0.16 for the causal pass).
 // 32 rows per batch: the counter has six bits, and a slot's wait must name the 31 + 32 younger requests behind it exactly.
 constexpr int IC_U = 32;
-template <bool ANTI>
+template <bool ANTI, bool PIPE>
 __global__ __launch_bounds__(64) void k_isp_iir_cols_t(const float* __restrict__ in, float* __restrict__ out,
                                                        float* __restrict__ state, int w, int h, float alpha, float maxVal) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,19 +347,19 @@ __global__ __launch_bounds__(64) void k_isp_iir_cols_t(const float* __restrict__
 #pragma unroll
     for (int uu = 0; uu < IC_U; ++uu) {
       const int row = m0 + (ANTI ? IC_U - 1 - uu : uu);
-      int pos = reflecti(row + (ANTI ? -1 : 1), h);
+      int pos = reflecti(row + (PIPE ? 0 : ANTI ? -1 : 1), h);
       pos = min(max(pos, 0), h - 1);  // (rows behind the image's end are never walked)
       dst[uu] = in[(size_t)pos * pitch + t];
     }
   };
   auto walk = [&](int b, const float* src) {
     const int m0 = b * IC_U;
-    if (m0 + IC_U <= h) {
+    if (m0 + IC_U <= h && !(PIPE && (ANTI ? m0 + IC_U == h : m0 == 0))) {
       float res[IC_U];
 #pragma unroll
       for (int uu = 0; uu < IC_U; ++uu) {
         v = src[uu] * ia + v * alpha;
-        res[uu] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+        res[uu] = ANTI && !PIPE ? clampf(v, 0.0f, maxVal) : v;
       }
       // (stores behind the walk: issued between the steps they would count as younger requests and push the waits
       // beyond what the counter can name)
@@ -368,8 +370,8 @@ __global__ __launch_bounds__(64) void k_isp_iir_cols_t(const float* __restrict__
       for (int uu = 0; uu < IC_U; ++uu) {
         const int row = m0 + (ANTI ? IC_U - 1 - uu : uu);
         if (row < h) {
-          v = src[uu] * ia + v * alpha;
-          out[(size_t)row * pitch + t] = ANTI ? clampf(v, 0.0f, maxVal) : v;
+          if (!(PIPE && row == (ANTI ? h - 1 : 0))) v = src[uu] * ia + v * alpha;  // (PIPE: the chain's first element stays)
+          out[(size_t)row * pitch + t] = ANTI && !PIPE ? clampf(v, 0.0f, maxVal) : v;
         }
       }
     }
@@ -424,10 +426,10 @@ void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int 
   if (d.sharpen) {
     // rows: img -> scratch (causal) -> lp (anticausal, clamped); columns: lp -> scratch -> lp
     const dim3 gr((h + IR_ROWS - 1) / IR_ROWS), gc((w * 3 + 63) / 64);
-    hipLaunchKernelGGL((k_isp_iir_rows_t<false>), gr, dim3(64), 0, st, B.img, B.scratch, B.state, w, h, d.alpha, d.maxVal);
-    hipLaunchKernelGGL((k_isp_iir_rows_t<true>), gr, dim3(64), 0, st, B.scratch, B.lp, B.state, w, h, d.alpha, d.maxVal);
-    hipLaunchKernelGGL((k_isp_iir_cols_t<false>), gc, dim3(64), 0, st, B.lp, B.scratch, B.state, w, h, d.alpha, d.maxVal);
-    hipLaunchKernelGGL((k_isp_iir_cols_t<true>), gc, dim3(64), 0, st, B.scratch, B.lp, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_rows_t<false, false>), gr, dim3(64), 0, st, B.img, B.scratch, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_rows_t<true, false>), gr, dim3(64), 0, st, B.scratch, B.lp, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_cols_t<false, false>), gc, dim3(64), 0, st, B.lp, B.scratch, B.state, w, h, d.alpha, d.maxVal);
+    hipLaunchKernelGGL((k_isp_iir_cols_t<true, false>), gc, dim3(64), 0, st, B.scratch, B.lp, B.state, w, h, d.alpha, d.maxVal);
     if (d.outputBpp == 8)
       hipLaunchKernelGGL((k_isp_finish<true, unsigned char>), dim3(gp), dim3(256), 0, st, B.img, B.lp, n, d, B.exptab,
                          (unsigned char*)out);
@@ -442,6 +444,216 @@ void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int 
       hipLaunchKernelGGL((k_isp_finish<false, unsigned short>), dim3(gp), dim3(256), 0, st, B.img, nullptr, n, d,
                          B.exptab, (unsigned short*)out);
   }
+}
+
+// ======================================================================================================================
+// The ACCELERATED ISP's arithmetic: CameraIspPipe (camera_isp/CameraIspPipe.h), i.e. the Halide pipeline that
+// camera_isp/CameraIspGen.cpp generates — what the reference's Unpacker always runs (Unpacker.cpp:24,176-183) and Raw2Rgb runs
+// with --accelerate (Raw2Rgb.cpp:427-440). Written from the generator's source, function by function; Halide cannot be built
+// here, so this arithmetic is NOT pinned against the reference (include/s360.h and DESIGN.md section 8 say what may differ at
+// rounding level). Same structure as the soft ISP above, other details: the image is extended by mirroring WITHOUT boundary
+// logic in the stencils — the site plane is computed for 8 pixels beyond every edge (raw: mirror_interior, vignette tables:
+// mirror_image, site colour from the virtual coordinate: CameraIspGen.cpp:674-680), the flags for 6, green for 2 —; black
+// level, white balance and clamp are one A (x - B); the horizontal vignette table has its green and blue columns swapped
+// (CameraIspPipe.h:88-89); the low pass runs along y first, starts at the first element and clamps nothing; the noise gain of
+// output channel c is read at c while everything else is read at the swizzled channel (CameraIspGen.cpp:529-537).
+//   k_pipe_site<FAST>   raw16 -> the extended Bayer plane in [0, 1]
+//   k_pipe_flag         dH <= dV on the plane extended by 6
+//   k_pipe_green        9 x 9 vote (LDS, separable sums) -> green on the plane extended by 2
+//   k_pipe_color<FAST>  red / blue (through r - g, b - g; or the bilinear demosaic), CCM, 12-bit index, tone table
+//   k_isp_iir_cols_t / k_isp_iir_rows_t <.., PIPE>   the low pass (the kernels above with the pipeline's chain ends)
+//   k_pipe_finish       unsharp mask with noise coring, or (FAST) the swizzled store
+constexpr int PP = 8, PF = 6, PG = 2;  // how far beyond the image the site plane / the flags / green are computed
+__device__ __forceinline__ int mirror_interior(int x, int n) { return x < 0 ? -x : x >= n ? 2 * n - 2 - x : x; }
+__device__ __forceinline__ int mirror_image(int x, int n) { return x < 0 ? -x - 1 : x >= n ? 2 * n - 1 - x : x; }
+// site colours (CameraIspGen.cpp:44-67; pattern 0 = GBRG, 1 = RGGB): 0 red, 1 green, 2 blue. (x, y) may be negative.
+__device__ __forceinline__ int pipe_colour(int pattern, int x, int y) {
+  const int px = x & 1, py = y & 1;
+  if (pattern == 0) return px == py ? 1 : (px == 0 ? 0 : 2);  // G B / R G
+  return px != py ? 1 : (px == 0 ? 0 : 2);                     // R G / G B
+}
+// green on a red row (greenRedPixel): the site's horizontal neighbours are red
+__device__ __forceinline__ bool pipe_green_red(int pattern, int x, int y) {
+  return pattern == 0 ? ((x & 1) == 1 && (y & 1) == 1) : ((x & 1) == 1 && (y & 1) == 0);
+}
+__device__ __forceinline__ float pavg(float a, float b) { return (a + b) * 0.5f; }
+__device__ __forceinline__ float pabsd(float a, float b) { return a > b ? a - b : b - a; }
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_pipe_site(const unsigned short* __restrict__ raw, int w, int h, IspPipeDev d,
+                                                   const float* __restrict__ vigH, const float* __restrict__ vigV,
+                                                   float* __restrict__ site) {
+  const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;  // coordinates in the extended plane
+  if (X >= w + 2 * PP) return;
+  const int x = X - PP, y = Y - PP;
+  const int k = pipe_colour(d.pattern, x, y);
+  float v = ((float)raw[(size_t)mirror_interior(y, h) * w + mirror_interior(x, w)] - d.bias[k]) * d.invRange[k];
+  if (!FAST) v *= vigH[mirror_image(x, w) * 3 + k] * vigV[mirror_image(y, h) * 3 + k];
+  site[(size_t)Y * (w + 2 * PP) + X] = fmaxf(fminf(v, 1.0f), 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_pipe_flag(const float* __restrict__ site, int w, int h, IspPipeDev d,
+                                                   unsigned char* __restrict__ flag) {
+  const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;  // coordinates in the plane extended by PF
+  if (X >= w + 2 * PF) return;
+  const int x = X - PF, y = Y - PF;
+  const int sp = w + 2 * PP;
+  const float* c = site + (size_t)(y + PP) * sp + (x + PP);
+  const float s0 = c[0];
+  float dV, dH;
+  if (pipe_colour(d.pattern, x, y) == 1) {
+    dV = pavg(pabsd(c[2 * sp], s0), pabsd(c[-2 * sp], s0));
+    dH = pavg(pabsd(c[2], s0), pabsd(c[-2], s0));
+  } else {
+    dV = pavg(pabsd(c[sp], c[-sp]), pabsd(c[2 * sp] + c[-2 * sp], 2.0f * s0));
+    dH = pavg(pabsd(c[1], c[-1]), pabsd(c[2] + c[-2], 2.0f * s0));
+  }
+  flag[(size_t)Y * (w + 2 * PF) + X] = dH <= dV ? 1 : 0;
+}
+
+__global__ __launch_bounds__(GP_T * GP_T / 4) void k_pipe_green(const unsigned char* __restrict__ flag,
+                                                                const float* __restrict__ site, int w, int h, IspPipeDev d,
+                                                                float* __restrict__ green) {
+  __shared__ unsigned char s_f[GP_T + 8][GP_T + 8];
+  __shared__ unsigned char s_r[GP_T + 8][GP_T];  // horizontal 9-sums
+  // output (X, Y) of the plane extended by PG = image pixel (X - PG, Y - PG); its window starts at flag-plane (X, Y)
+  const int X0 = blockIdx.x * GP_T, Y0 = blockIdx.y * GP_T, tid = threadIdx.x;
+  const int fw = w + 2 * PF, fh = h + 2 * PF;
+  for (int t = tid; t < (GP_T + 8) * (GP_T + 8); t += GP_T * GP_T / 4) {
+    const int ly = t / (GP_T + 8), lx = t - ly * (GP_T + 8);
+    s_f[ly][lx] = flag[(size_t)min(Y0 + ly, fh - 1) * fw + min(X0 + lx, fw - 1)];  // (clamped entries feed no output)
+  }
+  __syncthreads();
+  for (int t = tid; t < (GP_T + 8) * GP_T; t += GP_T * GP_T / 4) {
+    const int ly = t / GP_T, lx = t - ly * GP_T;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s += s_f[ly][lx + k];
+    s_r[ly][lx] = (unsigned char)s;
+  }
+  __syncthreads();
+  const int sp = w + 2 * PP;
+  for (int t = tid; t < GP_T * GP_T; t += GP_T * GP_T / 4) {
+    const int ly = t / GP_T, lx = t - ly * GP_T;
+    const int X = X0 + lx, Y = Y0 + ly;
+    if (X >= w + 2 * PG || Y >= h + 2 * PG) continue;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cnt += s_r[ly + k][lx];
+    const int x = X - PG, y = Y - PG;
+    const float* c = site + (size_t)(y + PP) * sp + (x + PP);
+    float g = c[0];
+    if (pipe_colour(d.pattern, x, y) != 1) {
+      if (cnt < 81 / 2) g = pavg(c[sp], c[-sp]) + (2.0f * c[0] - c[2 * sp] - c[-2 * sp]) * 0.25f;  // gV
+      else g = pavg(c[1], c[-1]) + (2.0f * c[0] - c[2] - c[-2]) * 0.25f;                           // gH
+    }
+    green[(size_t)Y * (w + 2 * PG) + X] = g;
+  }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_pipe_color(const float* __restrict__ site, const float* __restrict__ green, int w,
+                                                    int h, IspPipeDev d, const unsigned short* __restrict__ toneTab,
+                                                    float* __restrict__ tone /*[h][w][3] r,g,b*/) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const int sp = w + 2 * PP, gp = w + 2 * PG;
+  const float* c = site + (size_t)(y + PP) * sp + (x + PP);
+  const int col = pipe_colour(d.pattern, x, y);
+  const bool gr = pipe_green_red(d.pattern, x, y);
+  float r, g, b;
+  if (FAST) {  // bilinearDemosaic (CameraIspGen.cpp:112-160)
+    const float vert = pavg(c[-sp], c[sp]), horz = pavg(c[-1], c[1]);
+    const float cross = pavg(pavg(c[-1], c[1]), pavg(c[-sp], c[sp]));
+    const float diag = pavg(pavg(c[-sp - 1], c[-sp + 1]), pavg(c[sp - 1], c[sp + 1]));
+    if (col == 1) {
+      g = c[0];
+      r = gr ? horz : vert;
+      b = gr ? vert : horz;
+    } else {
+      g = cross;
+      r = col == 0 ? c[0] : diag;
+      b = col == 0 ? diag : c[0];
+    }
+  } else {  // edgeAwareDemosaic's r and b (CameraIspGen.cpp:235-262): box filters of (colour - green), green added back
+    const float* q = green + (size_t)(y + PG) * gp + (x + PG);
+    auto D = [&](int dx, int dy) { return c[dy * sp + dx] - q[dy * gp + dx]; };
+    g = q[0];
+    const float fifth = 1.0f / 5.0f, sixth = 1.0f / 6.0f;  // (a float division by a constant is a multiplication in Halide)
+    if (col != 1) {
+      const float own = (D(0, 0) + D(0, 2) + D(0, -2) + D(2, 0) + D(-2, 0)) * fifth + g;
+      const float dia = (D(1, 1) + D(1, -1) + D(-1, 1) + D(-1, -1)) * 0.25f + g;
+      r = col == 0 ? own : dia;
+      b = col == 0 ? dia : own;
+    } else {
+      const float cols = (D(-1, -2) + D(-1, 0) + D(-1, 2) + D(1, -2) + D(1, 0) + D(1, 2)) * sixth + g;
+      const float rows = (D(-2, -1) + D(0, -1) + D(2, -1) + D(-2, 1) + D(0, 1) + D(2, 1)) * sixth + g;
+      r = gr ? cols : rows;
+      b = gr ? rows : cols;
+    }
+  }
+  float* o = tone + ((size_t)y * w + x) * 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // applyCCM (:429-449), toneTable (:599)
+    const float v = d.ccm[k * 3] * r + d.ccm[k * 3 + 1] * g + d.ccm[k * 3 + 2] * b;
+    const int idx = (int)fmaxf(fminf(v, 4095.0f), 0.0f);
+    o[k] = (float)toneTab[idx * 3 + k];
+  }
+}
+
+// applyUnsharpMask (CameraIspGen.cpp:502-547) and the output cast; FAST: ispOutput = toneCorrected at the swizzled channel
+template <bool FAST, typename OUT>
+__global__ __launch_bounds__(256) void k_pipe_finish(const float* __restrict__ tone, const float* __restrict__ low, size_t n,
+                                                     IspPipeDev d, const unsigned long long* __restrict__ exptab,
+                                                     OUT* __restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float t[3], l[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    t[k] = tone[p * 3 + k];
+    l[k] = FAST ? 0.0f : low[p * 3 + k];
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const int cp = d.swizzle ? 2 - ch : ch;
+    float v = t[cp];
+    if (!FAST) {
+      const float hpC = t[ch] - l[ch];
+      const float ng = 1.0f - expf_glibc_neg(-((hpC * hpC) * d.noiseCore), exptab);
+      const float hp = t[cp] - l[cp];
+      v = fmaxf(fminf(l[cp] + hp * ng * d.amount[cp], d.maxVal), 0.0f);
+    }
+    out[p * 3 + ch] = (OUT)(int)v;
+  }
+}
+
+void isp_pipe_launch(hipStream_t st, const IspPipeDev& d, const unsigned short* raw, int w, int h, const IspPipeBufs& B,
+                     void* out) {
+  const size_t n = (size_t)w * h;
+  const dim3 row(256);
+  if (d.fast) hipLaunchKernelGGL((k_pipe_site<true>), dim3((w + 2 * PP + 255) / 256, h + 2 * PP), row, 0, st, raw, w, h, d, B.vigH, B.vigV, B.site);
+  else hipLaunchKernelGGL((k_pipe_site<false>), dim3((w + 2 * PP + 255) / 256, h + 2 * PP), row, 0, st, raw, w, h, d, B.vigH, B.vigV, B.site);
+  const dim3 grd((w + 255) / 256, h);
+  const unsigned gp = (unsigned)((n + 255) / 256);
+  if (d.fast) {
+    hipLaunchKernelGGL((k_pipe_color<true>), grd, row, 0, st, B.site, nullptr, w, h, d, B.toneTab, B.tone);
+    if (d.outputBpp == 8) hipLaunchKernelGGL((k_pipe_finish<true, unsigned char>), dim3(gp), row, 0, st, B.tone, nullptr, n, d, B.exptab, (unsigned char*)out);
+    else hipLaunchKernelGGL((k_pipe_finish<true, unsigned short>), dim3(gp), row, 0, st, B.tone, nullptr, n, d, B.exptab, (unsigned short*)out);
+    return;
+  }
+  hipLaunchKernelGGL(k_pipe_flag, dim3((w + 2 * PF + 255) / 256, h + 2 * PF), row, 0, st, B.site, w, h, d, B.flag);
+  hipLaunchKernelGGL(k_pipe_green, dim3((w + 2 * PG + GP_T - 1) / GP_T, (h + 2 * PG + GP_T - 1) / GP_T), dim3(GP_T * GP_T / 4), 0,
+                     st, B.flag, B.site, w, h, d, B.green);
+  hipLaunchKernelGGL((k_pipe_color<false>), grd, row, 0, st, B.site, B.green, w, h, d, B.toneTab, B.tone);
+  // lowPass0 = lp along y, lowPass = lp along x (CameraIspGen.cpp:515-518): tone -> scratch (causal) -> low (anticausal), twice
+  const dim3 gr((h + IR_ROWS - 1) / IR_ROWS), gc((w * 3 + 63) / 64);
+  hipLaunchKernelGGL((k_isp_iir_cols_t<false, true>), gc, dim3(64), 0, st, B.tone, B.scratch, B.state, w, h, d.alpha, d.maxVal);
+  hipLaunchKernelGGL((k_isp_iir_cols_t<true, true>), gc, dim3(64), 0, st, B.scratch, B.low, B.state, w, h, d.alpha, d.maxVal);
+  hipLaunchKernelGGL((k_isp_iir_rows_t<false, true>), gr, dim3(64), 0, st, B.low, B.scratch, B.state, w, h, d.alpha, d.maxVal);
+  hipLaunchKernelGGL((k_isp_iir_rows_t<true, true>), gr, dim3(64), 0, st, B.scratch, B.low, B.state, w, h, d.alpha, d.maxVal);
+  if (d.outputBpp == 8) hipLaunchKernelGGL((k_pipe_finish<false, unsigned char>), dim3(gp), row, 0, st, B.tone, B.low, n, d, B.exptab, (unsigned char*)out);
+  else hipLaunchKernelGGL((k_pipe_finish<false, unsigned short>), dim3(gp), row, 0, st, B.tone, B.low, n, d, B.exptab, (unsigned short*)out);
 }
 
 }  // namespace s360

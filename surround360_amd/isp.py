@@ -1,7 +1,9 @@
-"""Host-side mirror of the reference's soft ISP interface over the C ABI of libs360 (include/s360.h, s360_isp_*):
+"""Host-side mirror of the reference's ISP interface over the C ABI of libs360 (include/s360.h, s360_isp_*):
 
   CameraIsp(json, output_bpp) + the Raw2Rgb flags     SR/camera_isp/CameraIsp.h:425-607, Raw2Rgb.cpp:25-39, 441-456
   load_image + get_image                              CameraIsp.h:831-854, 1275-1299
+  CameraIspPipe(json, fast, output_bpp)               SR/camera_isp/CameraIspPipe.h (pipe=PIPE / PIPE_FAST: the Halide
+                                                      pipeline's arithmetic restated from CameraIspGen.cpp, not pinned)
 
 Everything computes on the GPU; numpy arrays stand in for cv::Mat (H x W uint16 raw, H x W x 3 BGR out)."""
 import ctypes as C
@@ -12,14 +14,15 @@ from . import _capi
 from ._capi import IspConfig, check, lib
 
 BILINEAR_DM_FILTER, FREQUENCY_DM_FILTER, EDGE_AWARE_DM_FILTER = 0, 1, 2
+SOFT, PIPE, PIPE_FAST = 0, 1, 2  # s360_isp_config.pipe: CameraIsp / CameraIspPipe / CameraIspPipe(fast = true)
 
 
 def config_from_json(json_text, output_bpp=8, demosaic_filter=EDGE_AWARE_DM_FILTER, resize=1, disable_tone_curve=False,
-                     black_level_offset=0):
-    """The CameraIsp constructor's reading of an ISP configuration text, plus the Raw2Rgb flags."""
+                     black_level_offset=0, pipe=SOFT):
+    """The CameraIsp constructor's reading of an ISP configuration text, plus the Raw2Rgb flags (pipe: --accelerate / --fast)."""
     c = IspConfig()
     lib().s360_isp_config_defaults(C.byref(c))
-    c.output_bpp, c.demosaic_filter, c.resize = output_bpp, demosaic_filter, resize
+    c.output_bpp, c.demosaic_filter, c.resize, c.pipe = output_bpp, demosaic_filter, resize, pipe
     c.disable_tone_curve, c.black_level_offset = int(bool(disable_tone_curve)), black_level_offset
     check(lib().s360_isp_config_from_json(json_text.encode(), C.byref(c)))
     return c

@@ -478,6 +478,18 @@ def isp_run(cfg, raw):
     return out
 
 
+def isp_pipe_run(cfg, raw, fast=False):
+    """oracle restatement of the accelerated ISP (oracle/isp_pipe.h: CameraIspGen.cpp, parity unpinned): raw -> H x W x 3 BGR.
+    cfg.resize / cfg.demosaicFilter play no part."""
+    raw = np.ascontiguousarray(raw, np.uint16)
+    assert lib().orc_isp_config_size() == C.sizeof(IspConfigC)
+    out = np.zeros(raw.shape + (3,), np.uint8 if cfg.outputBpp == 8 else np.uint16)
+    err = C.create_string_buffer(256)
+    if lib().orc_isp_pipe_run(C.byref(cfg), int(bool(fast)), _p(raw), raw.shape[1], raw.shape[0], _p(out), err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+    return out
+
+
 def isp_tables(cfg):
     ccm, lut = np.zeros(9, np.float32), np.zeros((4096, 3), np.float32)
     lib().orc_isp_tables(C.byref(cfg), _p(ccm), _p(lut))

@@ -188,6 +188,15 @@ RAW_CASES = {
 }
 
 
+# Raw2Rgb --accelerate: the reference's CameraIspPipe (its Halide pipeline; not buildable here, so no golden digests — these cases
+# are compared between the reference's program on the library, the host program and the oracle's restatement)
+PIPE_RAW_CASES = {
+    "accelerate_bpp16": (16, ["--output_bpp", "16", "--accelerate"]),
+    "accelerate_fast_bpp8_black20": (16, ["--output_bpp", "8", "--accelerate", "--fast", "--black_level_offset", "20"]),
+    "accelerate_png8_bpp8_no_tone_curve": (8, ["--output_bpp", "8", "--accelerate", "--disable_tone_curve"]),
+}
+
+
 def bayer_frame_int(w, h, seed, pattern="GBRG"):
     """H x W uint16 Bayer mosaic of an integer-generated texture (full 16-bit range: v * 257)."""
     tex = _texture(h, w, seed).astype(np.uint16) * 257
@@ -201,7 +210,7 @@ def bayer_frame_int(w, h, seed, pattern="GBRG"):
 
 def run_raw_case(exe, work, config_json, name):
     """Writes the input PNG (16-bit, or the high bytes as an 8-bit PNG) and runs the program; returns (raw16 the ISP sees, output path)."""
-    depth, flags = RAW_CASES[name]
+    depth, flags = RAW_CASES[name] if name in RAW_CASES else PIPE_RAW_CASES[name]
     os.makedirs(work, exist_ok=True)
     raw = bayer_frame_int(RAW_W, RAW_H, 77)
     cfg = os.path.join(work, "isp.json")

@@ -97,6 +97,50 @@ def test_reference_raw2rgb_with_the_integration_binding(tmp_path, emu_programs, 
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
 
 
+def _build_ref(target):
+    exe = os.path.join(ROOT, "oracle", "_ref", target)
+    if os.path.isdir("/root/reference/surround360_render/source"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/" + target])
+    elif not os.path.exists(exe):
+        pytest.skip("needs /root/reference to build the reference program from (make -C oracle ref_binding_pipe)")
+    return exe
+
+
+def check_pipe_raw_case(exe, host_exe, work, name):
+    """The reference's Raw2Rgb --accelerate on the library == host/Raw2Rgb --accelerate == the oracle's restatement."""
+    import isputil
+    depth, flags = refprog.PIPE_RAW_CASES[name]
+    seen, outp = refprog.run_raw_case(exe, os.path.join(work, "ref"), isputil.CONFIG_FULL, name)
+    a = refprog.png_pixels_bgr(outp)
+    _, outh = refprog.run_raw_case(host_exe, os.path.join(work, "host"), isputil.CONFIG_FULL, name)
+    assert np.array_equal(a, refprog.png_pixels_bgr(outh)), name
+    bpp = int(flags[flags.index("--output_bpp") + 1])
+    cfg = O.isp_config_from_json(isputil.CONFIG_FULL, bpp, 2, 1, int("--disable_tone_curve" in flags),
+                                 20 if "--black_level_offset" in flags else 0)
+    want = O.isp_pipe_run(cfg, seen, fast="--fast" in flags)
+    assert a.shape == want.shape and a.dtype == want.dtype and np.array_equal(a, want), name
+
+
+@pytest.mark.parametrize("name", list(refprog.PIPE_RAW_CASES))
+def test_reference_raw2rgb_accelerated_on_the_library(tmp_path, emu_programs, name):
+    """The reference's ACCELERATED ISP with nothing of it changed: Raw2Rgb.cpp (-DUSE_HALIDE) and CameraIspPipe.h compiled where
+    they lie, the four functions Halide would generate (CameraIspGen8 / 16 / Fast8 / Fast16) provided by
+    oracle/ref_binding/halide_shim over s360_isp_pipe_generated. The reference's own code builds the vignette tables, the tone
+    table, the CCM and the parameter list; the library (here: its CPU emulation) only runs the pipeline. The picture equals
+    host/Raw2Rgb --accelerate's and the oracle's — which pins everything of the accelerated path EXCEPT the generated
+    arithmetic itself (oracle/isp_pipe.h says what that leaves open)."""
+    check_pipe_raw_case(_build_ref("Raw2Rgb_pipe_hip_emu"), os.path.join(emu_programs, "Raw2Rgb"), str(tmp_path), name)
+
+
+@pytest.mark.parametrize("bits", [12, 8])
+def test_reference_unpacker_on_the_library(tmp_path, emu_programs, bits):
+    """The reference's own Unpacker (Unpacker.cpp, BinaryFootageFile.cpp, RawConverter.cpp, CameraIspPipe.h, unmodified) over the
+    same four functions: container parsing, 12-bit unpacking, one CameraIspPipe per frame, 16-bit PNGs, camN renaming — the
+    files host/Unpacker writes and the oracle's pixels."""
+    from test_gpu_zz_unpacker import check_unpacker
+    check_unpacker(_build_ref("Unpacker_hip_emu"), tmp_path, O, bits, soft=False)
+
+
 @pytest.mark.parametrize("script,seed,cases,ok", [("random_flow.py", 11, 12, "0 differ"), ("random_ops.py", 11, 60, "0 differ"),
                                                   ("random_isp.py", 11, 40, "0 differ")])
 def test_random_calls_equal_the_oracle(emu_programs, script, seed, cases, ok):
@@ -132,10 +176,11 @@ def test_emulated_raw2rgb_writes_what_the_reference_program_writes(tmp_path, emu
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
 
 
+@pytest.mark.parametrize("soft", [False, True], ids=["pipe", "soft_isp"])
 @pytest.mark.parametrize("bits", [12, 8])
-def test_emulated_unpacker(tmp_path, emu_programs, bits):
+def test_emulated_unpacker(tmp_path, emu_programs, bits, soft):
     from test_gpu_zz_unpacker import check_unpacker
-    check_unpacker(os.path.join(emu_programs, "Unpacker"), tmp_path, O, bits)
+    check_unpacker(os.path.join(emu_programs, "Unpacker"), tmp_path, O, bits, soft)
 
 
 def test_emulated_optical_flow_harness(tmp_path, emu_programs):

@@ -258,3 +258,16 @@ def test_raw2rgb_binary(tmp_path, oracle, s360lib):
                                                           20 if rs == 2 else 0), raw)
         got = png16(out) if bpp == 16 else np.asarray(Image.open(out))[:, :, ::-1]
         assert np.array_equal(got, want), (inp, bpp)
+    # --accelerate [--fast]: CameraIspPipe's arithmetic (Raw2Rgb.cpp:427-440) against its restatement (oracle/isp_pipe.h, not pinned)
+    for bpp, fast, extra in ((16, False, []), (8, True, ["--black_level_offset=20"])):
+        out = str(tmp_path / ("out_acc_%d.png" % bpp))
+        r = subprocess.run([exe, "--input_image_path", str(tmp_path / "in.png"), "--output_image_path", out, "--isp_config_path",
+                            cfg_path, "--output_bpp", str(bpp), "--accelerate"] + (["--fast"] if fast else []) + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        want = oracle.isp_pipe_run(oracle.isp_config_from_json(json.dumps(cfgj), bpp, 2, 1, 0, 20 if extra else 0), raw, fast=fast)
+        got = png16(out) if bpp == 16 else np.asarray(Image.open(out))[:, :, ::-1]
+        assert np.array_equal(got, want), ("accelerate", bpp)
+    r = subprocess.run([exe, "--input_image_path", str(tmp_path / "in.png"), "--output_image_path", str(tmp_path / "x.png"),
+                        "--isp_config_path", cfg_path, "--accelerate", "--resize", "2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "resize" in r.stderr

@@ -36,6 +36,62 @@ def test_isp_equals_oracle(oracle, s360lib, case):
     assert np.array_equal(again, got)
 
 
+PIPE_CASES = [  # (config, w, h, bpp, fast, disable_tone_curve, black_level_offset)
+    ("full", 128, 96, 16, 0, 0, 0), ("full", 130, 70, 8, 0, 0, 0), ("full", 96, 64, 16, 1, 0, 0), ("full", 200, 136, 8, 1, 0, 25),
+    ("empty", 61, 47, 16, 0, 1, 3), ("minimal", 70, 50, 8, 0, 0, 0), ("grbg", 100, 84, 16, 0, 0, 0), ("grbg", 64, 64, 16, 1, 0, 0),
+    ("full", 640, 480, 16, 0, 0, 0), ("empty", 333, 257, 8, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=lambda c: "%s-%dx%d-bpp%d-fast%d-t%d-o%d" % c)
+def test_accelerated_pipeline_equals_its_oracle(oracle, s360lib, case):
+    """s360_isp_config.pipe = 1 / 2: the arithmetic of the reference's CameraIspPipe (the Halide pipeline of CameraIspGen.cpp —
+    Unpacker, Raw2Rgb --accelerate) against its CPU restatement, oracle/isp_pipe.h. PARITY UNPINNED: both follow the generator's
+    source, neither can be checked against a Halide build here; this test holds the HIP kernels to the restatement bit for bit
+    (two separately written evaluations: the oracle recurses through the generator's functions at virtual coordinates, the
+    kernels stage extended planes)."""
+    from surround360_amd import isp as I
+    name, w, h, bpp, fast, tone, off = case
+    js = isputil.CONFIGS[name]
+    raw = isputil.bayer_frame(w, h, seed=w + 5 * h, pattern="RGGB" if name == "full" else "GBRG")
+    want = oracle.isp_pipe_run(oracle.isp_config_from_json(js, bpp, 2, 1, tone, off), raw, fast=bool(fast))
+    isp = I.CameraIsp(I.config_from_json(js, bpp, 2, 1, tone, off, pipe=I.PIPE_FAST if fast else I.PIPE))
+    try:
+        got = isp.get_image(raw)
+        again = isp.get_image(raw)
+    finally:
+        isp.close()
+    assert got.shape == want.shape and got.dtype == want.dtype and want.std() > 5
+    if not np.array_equal(got, want):
+        d = got.astype(np.int64) - want.astype(np.int64)
+        bad = np.argwhere(d != 0)
+        raise AssertionError("%d of %d samples differ, max |d| %d, first at %s" % (len(bad), d.size, np.abs(d).max(), bad[0].tolist()))
+    assert np.array_equal(again, got)
+
+
+def test_accelerated_pipeline_domain(oracle, s360lib):
+    """What the pipeline does not have is refused, what it ignores is ignored: no resize; the demosaic filter and the stuck-pixel
+    fields are not read; a pattern other than GBRG / RGGB runs as GBRG (CameraIspPipe.h:133-141)."""
+    from surround360_amd import _capi, isp as I
+    js = isputil.CONFIG_FULL
+    with pytest.raises(_capi.S360Error, match="resize"):
+        I.CameraIsp(I.config_from_json(js, 16, 2, 2, pipe=I.PIPE))
+    raw = isputil.bayer_frame(96, 80, seed=9)
+    want = oracle.isp_pipe_run(oracle.isp_config_from_json(js, 16), raw)
+    for dm, sj in ((1, js), (0, isputil.stuck_pixel_config(1, 1, 0.5))):
+        isp = I.CameraIsp(I.config_from_json(sj, 16, dm, 1, pipe=I.PIPE))
+        try:
+            assert np.array_equal(isp.get_image(raw), want)
+        finally:
+            isp.close()
+    # BGGR ("minimal") and GBRG give the same picture
+    a = oracle.isp_pipe_run(oracle.isp_config_from_json(isputil.CONFIG_MINIMAL, 8), raw)
+    import json
+    j = json.loads(isputil.CONFIG_MINIMAL)
+    j["CameraIsp"]["bayerPattern"] = "GBRG"
+    assert np.array_equal(a, oracle.isp_pipe_run(oracle.isp_config_from_json(json.dumps(j), 8), raw))
+
+
 def test_isp_with_stuck_pixel_radius(oracle, s360lib):
     """stuckPixelRadius > 0 with the shipped configurations' stuckPixelThreshold 5: the reference's removeStuckPixels is
     then a no-op (its loop condition, CameraIsp.h:1090-1092; pinned against CameraIsp.h compiled in tests/test_cpu_isp.py)

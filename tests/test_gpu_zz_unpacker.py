@@ -1,5 +1,6 @@
 """host/Unpacker end to end on the GPU: a synthetic two-camera capture container -> per-serial ISP configurations ->
-16-bit PNGs, bit-exact against the oracle (RawConverter + soft ISP), raw TIFFs beside them, camN renaming.
+16-bit PNGs, bit-exact against the oracle (RawConverter + the accelerated pipeline's restatement by default like the
+reference's Unpacker, the pinned soft ISP with --soft_isp), raw TIFFs beside them, camN renaming.
 Sorted last on purpose: written after round 2's GPU minutes were spent, its first hardware run is the round-end suite
 (everything it calls — s360_isp_process_packed, the 16-bit PNG writer — is covered by earlier tests)."""
 import json
@@ -38,13 +39,14 @@ def _png16_bgr(path):
     return ((px[..., 0] << 8) | px[..., 1])[..., ::-1]
 
 
+@pytest.mark.parametrize("soft", [False, True], ids=["pipe", "soft_isp"])
 @pytest.mark.parametrize("bits", [12, 8])
-def test_unpacker_binary(tmp_path, oracle, s360lib, bits):
+def test_unpacker_binary(tmp_path, oracle, s360lib, bits, soft):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
-    check_unpacker(os.path.join(ROOT, "host", "Unpacker"), tmp_path, oracle, bits)
+    check_unpacker(os.path.join(ROOT, "host", "Unpacker"), tmp_path, oracle, bits, soft)
 
 
-def check_unpacker(exe, tmp_path, oracle, bits):
+def check_unpacker(exe, tmp_path, oracle, bits, soft=True):
     """(also run by tests/test_cpu_library_emulation.py on the program linked against the emulated library)"""
     w, h, nf = 128, 96, 3
     serials = [17430921, 16241093]
@@ -58,7 +60,7 @@ def check_unpacker(exe, tmp_path, oracle, bits):
     for s, js in zip(serials, configs):
         (ispd / ("%d.json" % s)).write_text(js)
     r = subprocess.run([exe, "--isp_dir", str(ispd), "--output_dir", str(out), "--output_raw_dir", str(raw),
-                        "--bin_list", str(binp)], capture_output=True, text=True)
+                        "--bin_list", str(binp)] + (["--soft_isp"] if soft else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     order = sorted(range(2), key=lambda c: serials[c])  # cam0 = the smallest serial number
     assert sorted(os.listdir(out)) == ["cam0", "cam1"]
@@ -68,6 +70,7 @@ def check_unpacker(exe, tmp_path, oracle, bits):
         for f in range(nf):
             raw16 = oracle.isp_unpack_frame(written[f][cam], bits, w, h)
             got = _png16_bgr(str(out / ("cam%d" % n) / ("%06d.png" % f)))
-            assert np.array_equal(got, oracle.isp_run(ocfg, raw16)), (bits, cam, f)
+            want = oracle.isp_run(ocfg, raw16) if soft else oracle.isp_pipe_run(ocfg, raw16)  # (pipe: CameraIspPipe, not pinned)
+            assert np.array_equal(got, want), (bits, cam, f)
             tiff = np.array(Image.open(str(raw / str(serials[cam]) / ("%06d.tiff" % f))))
             assert np.array_equal(tiff, raw16)

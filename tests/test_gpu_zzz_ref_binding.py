@@ -48,3 +48,24 @@ def test_reference_raw2rgb_with_the_integration_binding_on_the_gpu(tmp_path, nam
     a = refprog.png_pixels_bgr(outp)
     digest = hashlib.sha256(repr((a.shape, str(a.dtype))).encode() + a.tobytes()).hexdigest()
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
+
+
+@pytest.mark.parametrize("name", list(refprog.PIPE_RAW_CASES))
+def test_reference_raw2rgb_accelerated_on_the_gpu(tmp_path, name, oracle, s360lib):
+    """The reference's Raw2Rgb --accelerate / CameraIspPipe.h, unmodified, over oracle/ref_binding/halide_shim (the four functions
+    Halide would generate, written over s360_isp_pipe_generated): tests/test_cpu_library_emulation.py has the description."""
+    from test_cpu_library_emulation import check_pipe_raw_case
+    exe = os.path.join(refprog.ROOT, "oracle", "_ref", "Raw2Rgb_pipe_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/Raw2Rgb_pipe_hip is built where /root/reference exists (make -C oracle ref_binding_pipe)")
+    check_pipe_raw_case(exe, os.path.join(refprog.ROOT, "host", "Raw2Rgb"), str(tmp_path), name)
+
+
+@pytest.mark.parametrize("bits", [12, 8])
+def test_reference_unpacker_on_the_gpu(tmp_path, bits, oracle, s360lib):
+    """The reference's own Unpacker with its CameraIspPipe on the library."""
+    from test_gpu_zz_unpacker import check_unpacker
+    exe = os.path.join(refprog.ROOT, "oracle", "_ref", "Unpacker_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/Unpacker_hip is built where /root/reference exists (make -C oracle ref_binding_pipe)")
+    check_unpacker(exe, tmp_path, oracle, bits, soft=False)

@@ -35,9 +35,10 @@ def main():
     raws = [isputil.bayer_frame(SZ, SZ, seed=k) for k in range(3)]
     res = {"input": "16-bit Bayer frames 2048x2048, every configuration key set, IIR sharpening on "
                     "(CameraIsp.h through Raw2Rgb.cpp:441-456)"}
-    for key, bpp, dm in (("ms_per_image_bpp16_edge_aware", 16, 2), ("ms_per_image_bpp8_edge_aware", 8, 2),
-                         ("ms_per_image_bpp8_bilinear", 8, 0)):
-        isp = I.CameraIsp(I.config_from_json(js, bpp, dm), device=args.device)
+    for key, bpp, dm, pipe in (("ms_per_image_bpp16_edge_aware", 16, 2, 0), ("ms_per_image_bpp8_edge_aware", 8, 2, 0),
+                               ("ms_per_image_bpp8_bilinear", 8, 0, 0), ("ms_per_image_bpp16_pipe", 16, 2, 1),
+                               ("ms_per_image_bpp8_pipe_fast", 8, 2, 2)):  # pipe: CameraIspPipe's arithmetic (Unpacker, --accelerate)
+        isp = I.CameraIsp(I.config_from_json(js, bpp, dm, pipe=pipe), device=args.device)
         isp.get_image(raws[0])
         t = time.perf_counter()
         for k in range(6):
@@ -45,7 +46,7 @@ def main():
         res[key] = round(1e3 * (time.perf_counter() - t) / 6, 3)
         isp.close()
         if not args.json:
-            print("2048x2048 bpp%d dm%d: %.2f ms per image incl. PCIe both ways" % (bpp, dm, res[key]), flush=True)
+            print("2048x2048 bpp%d dm%d pipe%d: %.2f ms per image incl. PCIe both ways" % (bpp, dm, pipe, res[key]), flush=True)
     if not args.no_cpu:
         import oracle_lib as O
         t = time.perf_counter()
@@ -56,6 +57,14 @@ def main():
         isp.close()
         if not args.json:
             print("oracle 2048x2048 bpp16 dm2: %.2f s; equal to GPU: %s" % (res["cpu_seconds_per_image"], res["checked"]))
+        t = time.perf_counter()
+        want = O.isp_pipe_run(O.isp_config_from_json(js, 16, 2), raws[0])
+        res["pipe_cpu_seconds_per_image"] = round(time.perf_counter() - t, 3)
+        isp = I.CameraIsp(I.config_from_json(js, 16, 2, pipe=I.PIPE), device=args.device)
+        res["pipe_checked"] = bool(np.array_equal(isp.get_image(raws[0]), want))
+        isp.close()
+        if not args.json:
+            print("oracle 2048x2048 bpp16 pipe: %.2f s; equal to GPU: %s" % (res["pipe_cpu_seconds_per_image"], res["pipe_checked"]))
     # a whole frame from raw images: 17 x upload_raw + render (latency sweep kernel), frames back to back
     rig_path = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
     flags = dict(eqr_width=8400, eqr_height=4096, enable_top=1, enable_bottom=1, final_eqr_width=8192, final_eqr_height=8192)
