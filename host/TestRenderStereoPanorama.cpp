@@ -19,14 +19,17 @@
 #include <cstring>
 #include <deque>
 #include <future>
+#include <fstream>
 #include <map>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../include/s360.h"
 #include "jpeg_io.hpp"
+#include "footage.hpp"
 #include "png_io.hpp"
 
 namespace {
@@ -59,11 +62,17 @@ struct Flags {
          // --frame_number / --num_frames on S GPUs produce (each segment's first frame has no previous frame, except the
          // first one's --prev_frame_data_dir), in one process. One stream cannot use more than one GPU: its pole flows
          // are one serial chain per frame and every frame needs its predecessor's flows
-         {"num_streams", "1"}};
+         {"num_streams", "1"},
+         // --bin_list a.bin,b.bin --isp_dir D: the cameras' frames come straight from the capture's .bin containers through the
+         // ISP on the device ("the ISP feeding the GPU directly from .bin") instead of imgs_dir/<cam>/<frame>.png:
+         // what `Unpacker --bin_list .. --isp_dir D --output_dir imgs_dir` followed by this program writes, with no file in
+         // between. Cameras map as Unpacker names them: the n-th smallest serial number is the rig's camera "cam<n>"; D holds
+         // <serial>.json; frame_number is the frame's index in the containers. --soft_isp as in host/Unpacker.
+         {"bin_list", ""}, {"isp_dir", ""}, {"soft_isp", "false"}};
   }
   static bool is_bool(const std::string& k) {
     static const char* b[] = {"save_debug_images", "enable_top", "enable_bottom", "enable_pole_removal", "logtostderr",
-                              "alsologtostderr", "write_state"};
+                              "alsologtostderr", "write_state", "soft_isp"};
     for (auto s : b)
       if (k == s) return true;
     return false;
@@ -180,6 +189,14 @@ struct FrameInputs {
   std::string frame;
   std::vector<pngio::Image> side;
   pngio::Image top, bottom, bottom2, mask1, mask2;
+  long binFrame = -1;  // --bin_list: the frame's index in the containers (nothing is decoded on the host)
+};
+// --bin_list: where a rig camera's frames are, and the ISP that develops them
+struct BinCamera {
+  const footage::Footage* file = nullptr;
+  size_t cam = 0;
+  uint32_t serial = 0;
+  s360_isp* isp = nullptr;
 };
 
 struct Job {
@@ -194,6 +211,9 @@ struct Job {
   int owner[4] = {-1, -1, -1, -1};  // GPU of pole unit u (top_left, top_right, bottom_left, bottom_right); -1 = not enabled
   std::vector<int> unitMask, need;  // per GPU: its pole units; the eyes whose complete strips it assembles
   int extW = 0;
+  std::vector<std::unique_ptr<footage::Footage>> bins;  // --bin_list
+  std::map<std::string, BinCamera> binCam;              // rig camera id -> its frames
+  bool from_bins() const { return !bins.empty(); }
   s360_ctx* owner_ctx(int u) const { return ctx[owner[u] < 0 ? 0 : owner[u]]; }
   int bottom_gpu() const { return owner[2] >= 0 ? owner[2] : 0; }
 };
@@ -222,6 +242,12 @@ void assign_pole_units(Job& J) {
 FrameInputs load_frame(const Job& J, const std::string& frame, FrameInputs recycled = FrameInputs()) {
   FrameInputs in = std::move(recycled);
   in.frame = frame;
+  if (J.from_bins()) {  // the frames stay where they are (mmap); upload_frame sends their packed bytes
+    char* end = nullptr;
+    in.binFrame = std::strtol(frame.c_str(), &end, 10);
+    if (end == frame.c_str() || *end || in.binFrame < 0) die("--bin_list: frame_number must be a frame index, got '" + frame + "'");
+    return in;
+  }
   in.side.resize(J.P);
   const std::string imgs = J.F.s("imgs_dir");
   std::vector<std::thread> th;
@@ -252,6 +278,23 @@ FrameInputs load_frame(const Job& J, const std::string& frame, FrameInputs recyc
 // every GPU gets the side images its pairs touch and the pole images of its pole units (asynchronous: upload stream)
 void upload_frame(const Job& J, const FrameInputs& in) {
   const int G = (int)J.ctx.size();
+  if (J.from_bins()) {
+    auto send = [&](const std::string& id, int camera) {
+      const BinCamera& bc = J.binCam.at(id);
+      const footage::Header& md = bc.file->md;
+      const uint8_t* fr = nullptr;
+      try {
+        fr = bc.file->frame((size_t)in.binFrame, bc.cam);
+      } catch (const std::exception& e) {
+        die(e.what());
+      }
+      ck(s360_frame_upload_packed(J.ctx[0], bc.isp, camera, fr, (int)md.bitsPerPixel, (int)md.width, (int)md.height), J.ctx[0]);
+    };
+    for (int k = 0; k < J.P; ++k) send(J.cams[J.sideIdx[k]].id, k);
+    if (J.prm.enable_top) send(J.cams[J.ti].id, S360_CAMERA_TOP);
+    if (J.prm.enable_bottom) send(J.cams[J.bi].id, S360_CAMERA_BOTTOM);
+    return;
+  }
   for (int r = 0; r < G; ++r) {
     std::vector<char> need(J.P, 0);
     for (int p = J.bounds[r]; p < J.bounds[r + 1]; ++p) need[p] = need[(p + 1) % J.P] = 1;
@@ -415,13 +458,73 @@ std::string frame_path(const std::string& pattern, const std::string& frame) {
 
 }  // namespace
 
+// --bin_list: opens the containers, finds every camera's serial number (the second word of its frames), names the cameras
+// like Unpacker (Unpacker.cpp:203-219: directories sorted by serial number become cam0, cam1, ...) and creates one ISP per
+// rig camera from <isp_dir>/<serial>.json — the arithmetic Unpacker runs (CameraIspPipe at 16 bits; --soft_isp: CameraIsp).
+static void open_bins(Job& J) {
+  const Flags& F = J.F;
+  if (J.ctx.size() != 1) die("--bin_list feeds one GPU (an ISP object feeds one context): not with --num_gpus");
+  if (J.prm.enable_pole_removal) die("--bin_list is not available with --enable_pole_removal");
+  std::istringstream list(F.s("bin_list"));
+  std::string path;
+  std::map<uint32_t, std::pair<const footage::Footage*, size_t>> bySerial;
+  try {
+    while (std::getline(list, path, ',')) {
+      std::unique_ptr<footage::Footage> ff(new footage::Footage);
+      ff->path = path;
+      ff->open(false);
+      if (ff->md.numberOfCameras == 0) continue;
+      if (ff->md.bitsPerPixel != 8 && ff->md.bitsPerPixel != 12) throw std::runtime_error("unsupported bits per pixel in " + path);
+      for (size_t cam = 0; cam < ff->md.numberOfCameras; ++cam) {
+        uint32_t serial;
+        std::memcpy(&serial, ff->frame(0, cam) + 4, 4);
+        bySerial[serial] = {ff.get(), cam};
+      }
+      J.bins.push_back(std::move(ff));
+    }
+  } catch (const std::exception& e) {
+    die(e.what());
+  }
+  if (J.bins.empty()) die("--bin_list: no camera in " + F.s("bin_list"));
+  size_t ordinal = 0;
+  for (const auto& kv : bySerial) {
+    BinCamera bc;
+    bc.file = kv.second.first;
+    bc.cam = kv.second.second;
+    bc.serial = kv.first;
+    J.binCam["cam" + std::to_string(ordinal++)] = bc;
+  }
+  auto want = [&](int idx) {
+    const std::string id = J.cams[idx].id;
+    auto it = J.binCam.find(id);
+    if (it == J.binCam.end()) die("--bin_list: the containers hold " + std::to_string(J.binCam.size()) + " cameras, none becomes '" + id + "'");
+    BinCamera& bc = it->second;
+    if (bc.isp) return;
+    const std::string json_path = F.s("isp_dir") + "/" + std::to_string(bc.serial) + ".json";
+    std::ifstream js(json_path);
+    if (!js) die("--bin_list: no ISP configuration " + json_path);
+    std::stringstream ss;
+    ss << js.rdbuf();
+    s360_isp_config cfg;
+    s360_isp_config_defaults(&cfg);
+    cfg.output_bpp = 16;                  // kOutputBpp (Unpacker.cpp:167)
+    cfg.pipe = F.b("soft_isp") ? 0 : 1;   // CameraIspPipe, kFast = false (Unpacker.cpp:166-168)
+    if (s360_isp_config_from_json(ss.str().c_str(), &cfg) < 0) die(s360_last_error(nullptr));
+    if (s360_isp_create(&bc.isp, F.i("device"), &cfg) < 0) die(s360_last_error(nullptr));
+  };
+  for (int k = 0; k < J.P; ++k) want(J.sideIdx[k]);
+  if (J.prm.enable_top) want(J.ti);
+  if (J.prm.enable_bottom) want(J.bi);
+}
+
 // One job = what one invocation of the reference's program does, or (--num_frames) one stream of consecutive frames.
 static int run_job(const Flags& flags) {
   Job J;
   J.F = flags;
   Flags& F = J.F;
   require_arg(F.s("rig_json_file"), "rig_json_file");  // TRSP:717-721
-  require_arg(F.s("imgs_dir"), "imgs_dir");
+  if (F.s("bin_list").empty()) require_arg(F.s("imgs_dir"), "imgs_dir");
+  else require_arg(F.s("isp_dir"), "isp_dir");
   require_arg(F.s("frame_number"), "frame_number");
   require_arg(F.s("output_data_dir"), "output_data_dir");
   require_arg(F.s("output_equirect_path"), "output_equirect_path");
@@ -478,6 +581,7 @@ static int run_job(const Flags& flags) {
   if (numFrames > 1) {
     ck(s360_set_frame_pipelining(J.ctx[0], 1), J.ctx[0]);  // pole stage of frame k overlaps side stage of k+1
   }
+  if (!F.s("bin_list").empty()) open_bins(J);
 
   const s360_geometry& g = J.g;
   const std::string prev = F.s("prev_frame_data_dir");
@@ -613,6 +717,8 @@ static int run_job(const Flags& flags) {
     }
     std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
   }
+  for (auto& kv : J.binCam)
+    if (kv.second.isp) s360_isp_destroy(kv.second.isp);
   for (s360_ctx* c : J.ctx) s360_destroy(c);
   return 0;
 }

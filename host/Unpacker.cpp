@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../include/s360.h"
+#include "footage.hpp"
 #include "png_io.hpp"
 
 namespace {
@@ -37,45 +38,7 @@ namespace {
   std::fprintf(stderr, "Terminated with exception: %s\n", m.c_str());
   std::abort();
 }
-struct Header { uint32_t magic, timestamp, fileIndex, fileCount, width, height, bitsPerPixel, numberOfCameras; };
-struct Footage {
-  std::string path;
-  int fd = -1;
-  const uint8_t* base = nullptr;
-  size_t size = 0;
-  Header md{};
-  size_t frame_size() const { return (size_t)md.width * md.height * md.bitsPerPixel / 8; }
-  size_t frames() const { return (md.numberOfCameras && frame_size() && size >= 4096) ? (size - 4096) / frame_size() / md.numberOfCameras : 0; }
-  const uint8_t* frame(size_t f, size_t cam) const {  // (offsets, not pointers: nothing here may wrap around)
-    const size_t fs = frame_size(), avail = (size - 4096) / fs;  // whole frames in the file; open() made fs > 0
-    if (cam >= md.numberOfCameras || f >= avail / md.numberOfCameras) throw std::runtime_error("frame out of range for " + path);
-    return base + 4096 + (md.numberOfCameras * f + cam) * fs;
-  }
-  void open() {
-    fd = ::open(path.c_str(), O_RDONLY);
-    if (fd == -1) throw std::runtime_error("Error opening file " + path + ": " + std::strerror(errno));
-    struct stat st;
-    if (fstat(fd, &st) < 0) throw std::runtime_error("Error retrieving stat() information for file " + path);
-    size = (size_t)st.st_size;
-    if (size < 4096) throw std::runtime_error("not a footage file (shorter than its metadata page): " + path);
-    void* a = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (a == MAP_FAILED) throw std::runtime_error("Error mmap'ing() file " + path);
-    base = static_cast<const uint8_t*>(a);
-    std::memcpy(&md, base, sizeof md);
-    // an untrusted header: sizes that no sensor has would wrap frame_size() around (BinaryFootageFile.cpp trusts them)
-    if (md.numberOfCameras != 0) {
-      if (md.width == 0 || md.height == 0 || md.width > 65536u || md.height > 65536u || md.numberOfCameras > 4096u)
-        throw std::runtime_error("implausible metadata (width / height / numberOfCameras) in " + path);
-      if (md.bitsPerPixel == 12 && (md.width & 1u)) throw std::runtime_error("12-bit frames need an even width: " + path);
-    }
-    std::printf("Metadata:\nmagic = %x\ntimestamp = %u\nfileIndex = %u\nfileCount = %u\nwidth = %u\nheight = %u\nbpp = %u\nnumberOfCameras = %u\n",
-                md.magic, md.timestamp, md.fileIndex, md.fileCount, md.width, md.height, md.bitsPerPixel, md.numberOfCameras);
-  }
-  ~Footage() {
-    if (base) munmap(const_cast<uint8_t*>(base), size);
-    if (fd != -1) ::close(fd);
-  }
-};
+using footage::Footage;
 // RawConverter::convert8Frame / convert12Frame on the host, for the raw dump only (the ISP widens on the device)
 void widen(const uint8_t* frame, int bits, int w, int h, std::vector<uint16_t>& out) {
   out.resize((size_t)w * h);

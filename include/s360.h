@@ -438,6 +438,11 @@ int s360_isp_pipe_generated(s360_isp* isp, const s360_camera_isp_gen_args* args)
 #define S360_CAMERA_TOP (-1)
 #define S360_CAMERA_BOTTOM (-2)
 int s360_frame_upload_raw(s360_ctx* ctx, s360_isp* isp, int camera, const uint16_t* raw16, int w, int h);
+/* The same from the sensor's packed bytes as a capture's .bin container holds them (BinaryFootageFile::getFrame; bits 8 or 12
+ * as in s360_isp_process_packed): Unpacker's and the renderer's work on one frame of one camera without a file in between —
+ * "the ISP feeding the GPU directly from .bin" (SURVEY.md 8f row 4). host/TestRenderStereoPanorama --bin_list does this for
+ * every camera of a frame. */
+int s360_frame_upload_packed(s360_ctx* ctx, s360_isp* isp, int camera, const uint8_t* frame, int bits, int w, int h);
 /* The host-side tables of a configuration (no device needed; what s360_isp_create uploads): ccm9 = composite CCM x 4095
  * (CameraIsp::setup), lut = 4096 x 3 floats (buildToneCurveLut), curve_h = w x 3 and curve_v = h x 3 vignette gains of
  * a w x h frame (curveHAtPixel / curveVAtPixel; either may be NULL). */

@@ -613,7 +613,14 @@ int s360_frame_upload_bottom(s360_ctx* c, const uint8_t* bgr, int w, int h) {
   return frame_guard(c, [&] { need(c && bgr && w > 0 && h > 0, "bad argument"); frame_upload_pole(c, false, bgr, w, h); });
 }
 int s360_frame_upload_raw(s360_ctx* c, s360_isp* isp, int camera, const uint16_t* raw16, int w, int h) {
-  return frame_guard(c, [&] { need(c && isp && raw16 && w > 0 && h > 0, "bad argument"); frame_upload_raw(c, isp, camera, raw16, w, h); });
+  return frame_guard(c, [&] { need(c && isp && raw16 && w > 0 && h > 0, "bad argument"); frame_upload_raw(c, isp, camera, raw16, 16, w, h); });
+}
+int s360_frame_upload_packed(s360_ctx* c, s360_isp* isp, int camera, const uint8_t* frame, int bits, int w, int h) {
+  return frame_guard(c, [&] {
+    need(c && isp && frame && w > 0 && h > 0, "bad argument");
+    need(bits == 8 || bits == 12, "packed frames are 8 or 12 bits per pixel");
+    frame_upload_raw(c, isp, camera, frame, bits, w, h);
+  });
 }
 int s360_frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w,
                                    int h) {

@@ -468,6 +468,19 @@ void* isp_raw_buffer(s360_isp* o, int inW, int inH) {
   o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
   return o->dRaw.p;
 }
+// ... and for a frame that arrives as the sensor's packed bytes (a capture container's frame): the caller copies them into
+// this buffer on its stream, isp_unpack_on widens them into dRaw there (RawConverter.cpp:15-59)
+void* isp_packed_buffer(s360_isp* o, int bits, int inW, int inH) {
+  if (bits != 8 && bits != 12) throw Error(S360_ERR_INVALID_ARG, "packed frames are 8 or 12 bits per pixel");
+  if (bits == 12 && (inW & 1)) throw Error(S360_ERR_INVALID_ARG, "12-bit packed frames need an even width");
+  o->dPacked.ensure(isp_packed_bytes(bits, inW, inH));
+  o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
+  return o->dPacked.p;
+}
+size_t isp_packed_bytes(int bits, int inW, int inH) { return bits == 8 ? (size_t)inW * inH : (size_t)inH * (3 * (size_t)inW / 2); }
+void isp_unpack_on(s360_isp* o, hipStream_t st, int bits, int inW, int inH) {
+  isp_launch_unpack(st, o->dPacked.as<unsigned char>(), bits, inW, inH, o->dRaw.as<unsigned short>());
+}
 const void* isp_enqueue_on(s360_isp* o, hipStream_t st, unsigned long long ctxUid, int inW, int inH) {
   // Bound to the CONTEXT (its uid, never reused), not to the value of its stream handle: once that context has been
   // destroyed — s360_destroy waits for its upload stream, so nothing of it still runs on this object's buffers — the

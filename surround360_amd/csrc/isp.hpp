@@ -80,5 +80,8 @@ void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int w, int 
 void isp_pipe_generated(s360_isp* o, const s360_camera_isp_gen_args& a);
 void isp_release(s360_isp* o);
 void* isp_raw_buffer(s360_isp* o, int inW, int inH);
+void* isp_packed_buffer(s360_isp* o, int bits, int inW, int inH);
+size_t isp_packed_bytes(int bits, int inW, int inH);
+void isp_unpack_on(s360_isp* o, hipStream_t st, int bits, int inW, int inH);
 const void* isp_enqueue_on(s360_isp* o, hipStream_t st, unsigned long long ctxUid, int inW, int inH);
 }  // namespace s360

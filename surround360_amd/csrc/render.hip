@@ -279,7 +279,8 @@ void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h) 
 // directly"): what the reference does through files — Unpacker writes the ISP's 16-bit result as a PNG, the renderer's
 // imread decodes it to 8 bits, i.e. keeps the high byte — happens on the upload stream without leaving the device.
 // which: side index, -1 top, -2 bottom.
-void frame_upload_raw(s360_ctx* c, s360_isp* isp, int which, const uint16_t* raw16, int inW, int inH) {
+// bits: 16 = raw16 samples; 8 / 12 = the sensor's packed bytes as a capture container holds them (widened on the device).
+void frame_upload_raw(s360_ctx* c, s360_isp* isp, int which, const void* raw, int bits, int inW, int inH) {
   if (isp->cfg.output_bpp != 16)
     throw Error(S360_ERR_INVALID_ARG, "uploading through the ISP needs output_bpp 16 (the reference's chain stores 16-bit PNGs and imread keeps their high byte)");
   if (isp->device != c->device) throw Error(S360_ERR_INVALID_ARG, "the ISP object lives on another device");
@@ -288,7 +289,12 @@ void frame_upload_raw(s360_ctx* c, s360_isp* isp, int which, const uint16_t* raw
   ensure_upload_stream(c);
   const int w = inW / isp->cfg.resize, h = inH / isp->cfg.resize;
   const size_t n = (size_t)w * h;
-  upload_bytes(c, isp_raw_buffer(isp, inW, inH), raw16, (size_t)inW * inH * sizeof(uint16_t));
+  if (bits == 16) {
+    upload_bytes(c, isp_raw_buffer(isp, inW, inH), raw, (size_t)inW * inH * sizeof(uint16_t));
+  } else {
+    upload_bytes(c, isp_packed_buffer(isp, bits, inW, inH), raw, isp_packed_bytes(bits, inW, inH));
+    isp_unpack_on(isp, c->stUp, bits, inW, inH);
+  }
   const void* out16 = isp_enqueue_on(isp, c->stUp, c->uid, inW, inH);
   F.staging.ensure(n * 4);
   launch_u16_high_byte(c->stUp, static_cast<const unsigned short*>(out16), F.staging.as<uint8_t>(), n * 3);

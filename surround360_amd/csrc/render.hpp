@@ -93,7 +93,7 @@ struct FrameState {
 FrameState& frame_state(s360_ctx* c);
 void frame_upload_side(s360_ctx* c, int idx, const uint8_t* img, int w, int h, int ch);
 void frame_upload_pole(s360_ctx* c, bool top, const uint8_t* bgr, int w, int h);
-void frame_upload_raw(s360_ctx* c, struct s360_isp* isp, int which, const uint16_t* raw16, int inW, int inH);
+void frame_upload_raw(s360_ctx* c, struct s360_isp* isp, int which, const void* raw, int bits, int inW, int inH);
 void frame_upload_pole_removal(s360_ctx* c, const uint8_t* bottom2, const uint8_t* mask, const uint8_t* mask2, int w, int h);
 void frame_render_pairs(s360_ctx* c, int p0, int p1, int use_prev);
 void frame_finish(s360_ctx* c, int pole_mask, int use_prev);

@@ -244,6 +244,11 @@ class Context:
         r = np.ascontiguousarray(raw16, np.uint16)
         self._ck(lib().s360_frame_upload_raw(self.h, isp.h, int(camera), _p(r), r.shape[1], r.shape[0]))
 
+    def upload_packed(self, isp, camera, frame, bits, w, h):
+        """The same from the sensor's packed bytes of one w x h frame (8 or 12 bits per pixel, as in a capture's .bin container)."""
+        fr = np.ascontiguousarray(frame, np.uint8)
+        self._ck(lib().s360_frame_upload_packed(self.h, isp.h, int(camera), _p(fr), int(bits), int(w), int(h)))
+
     def upload_pole_removal(self, bottom2, mask, mask2):
         """Secondary bottom camera image + the two red pole masks (BGR) for enable_pole_removal (PoleRemoval.cpp:48-66)."""
         b2, m1, m2 = _u8(bottom2), _u8(mask), _u8(mask2)

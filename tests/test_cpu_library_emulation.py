@@ -183,6 +183,14 @@ def test_emulated_unpacker(tmp_path, emu_programs, bits, soft):
     check_unpacker(os.path.join(emu_programs, "Unpacker"), tmp_path, O, bits, soft)
 
 
+@pytest.mark.parametrize("soft", [False, True], ids=["pipe", "soft_isp"])
+def test_emulated_renderer_fed_from_the_capture_containers(tmp_path, emu_programs, soft):
+    """host/TestRenderStereoPanorama --bin_list --isp_dir ("the ISP feeding the GPU directly from .bin") against
+    Unpacker -> PNG files -> renderer: the same equirects, two chained frames and the two frames as a stream."""
+    from test_gpu_zz_unpacker import check_bin_list
+    check_bin_list(os.path.join(emu_programs, "Unpacker"), os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, soft=soft)
+
+
 def test_emulated_optical_flow_harness(tmp_path, emu_programs):
     """host/TestOpticalFlow --mode test (BASELINE configs[1]'s harness) on a small pair: both directions against the oracle."""
     from surround360_amd import synth

@@ -74,3 +74,60 @@ def check_unpacker(exe, tmp_path, oracle, bits, soft=True):
             assert np.array_equal(got, want), (bits, cam, f)
             tiff = np.array(Image.open(str(raw / str(serials[cam]) / ("%06d.tiff" % f))))
             assert np.array_equal(tiff, raw16)
+
+
+def check_bin_list(unpacker_exe, trsp_exe, tmp_path, bits=12, soft=False):
+    """host/TestRenderStereoPanorama --bin_list: the capture's containers -> ISP -> stereo frame on the device, against the
+    chain through files (host/Unpacker writes 16-bit PNGs, the renderer reads them back): the same equirects, for two chained
+    frames and for the two frames as one stream. (Also run by tests/test_cpu_library_emulation.py on the emulated programs.)"""
+    import rigutil
+    cam = refprog.CAM
+    rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"), cam / 2048.0)
+    ids = [c["id"] for c in json.load(open(rig))["cameras"]]
+    n = len(ids)
+    assert sorted(ids) == sorted("cam%d" % k for k in range(n))
+    serials = [40000 + 7 * k for k in range(n)]  # ascending: Unpacker's cam<k> is the k-th smallest serial number
+    configs = [isputil.CONFIG_GRBG_NOSHARP if k % 3 else isputil.CONFIG_FULL for k in range(n)]
+    pats = ["GRBG" if k % 3 else "RGGB" for k in range(n)]
+    frames = [[isputil.bayer_frame(cam, cam, seed=100 * f + k, pattern=pats[k]) for k in range(n)] for f in range(2)]
+    binp = tmp_path / "0.bin"
+    isputil.footage_file(str(binp), frames, bits, serials)
+    ispd, imgs = tmp_path / "isp", tmp_path / "imgs"
+    ispd.mkdir()
+    imgs.mkdir()
+    for s, js in zip(serials, configs):
+        (ispd / ("%d.json" % s)).write_text(js)
+    soft_flag = ["--soft_isp"] if soft else []
+    r = subprocess.run([unpacker_exe, "--isp_dir", str(ispd), "--output_dir", str(imgs), "--bin_list", str(binp)] + soft_flag,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    common = ["--rig_json_file", rig, "--eqr_width", str(refprog.EQR_W), "--eqr_height", str(refprog.EQR_H), "--final_eqr_width",
+              str(refprog.FINAL), "--final_eqr_height", str(refprog.FINAL), "--enable_top", "--enable_bottom", "--sharpening", "0.25"]
+
+    def run(tag, src, frame, prev, extra=()):
+        out = tmp_path / tag
+        for d in (out, out / "flow", out / "debug", out / "flow" / frame, out / "debug" / frame, out / "debug" / frame / "flow_images"):
+            d.mkdir(exist_ok=True)
+        cmd = [trsp_exe] + common + src + ["--frame_number", frame, "--output_data_dir", str(out), "--prev_frame_data_dir", prev,
+                                           "--output_equirect_path", str(out / "eqr_{frame}.png")] + list(extra)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, "%s: rc %d\n%s" % (tag, r.returncode, r.stderr[-2000:])
+        return out
+
+    files = ["--imgs_dir", str(imgs)]
+    bins = ["--bin_list", str(binp), "--isp_dir", str(ispd)] + soft_flag
+    a = run("files", files, "000000", "NONE", ["--output_equirect_path", str(tmp_path / "files" / "eqr_000000.png")])
+    run("files", files, "000001", "000000", ["--output_equirect_path", str(tmp_path / "files" / "eqr_000001.png")])
+    b = run("bins", bins, "000000", "NONE", ["--output_equirect_path", str(tmp_path / "bins" / "eqr_000000.png")])
+    run("bins", bins, "000001", "000000", ["--output_equirect_path", str(tmp_path / "bins" / "eqr_000001.png")])
+    c = run("stream", bins, "000000", "NONE", ["--num_frames", "2"])
+    for f in ("000000", "000001"):
+        want = refprog.png_pixels_bgr(str(a / ("eqr_%s.png" % f)))
+        assert want.std() > 5
+        assert np.array_equal(refprog.png_pixels_bgr(str(b / ("eqr_%s.png" % f))), want), ("bins", f)
+        assert np.array_equal(refprog.png_pixels_bgr(str(c / ("eqr_%s.png" % f))), want), ("stream", f)
+
+
+def test_renderer_fed_from_the_capture_containers(tmp_path, oracle, s360lib):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    check_bin_list(os.path.join(ROOT, "host", "Unpacker"), os.path.join(ROOT, "host", "TestRenderStereoPanorama"), tmp_path)
