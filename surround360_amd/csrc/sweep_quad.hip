@@ -615,10 +615,11 @@ void launch_sweep_quad(hipStream_t st, const float2* rec, const float2* G, float
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
   // S360_QUAD_WAVES_PER_CU: persistent waves per CU of one launch (tuning only; the results do not depend on it)
-  static const int perCu = [] {
+  // (read at every launch: tools/overlap_probe.py changes it inside one process)
+  const int perCu = [] {
     const char* e = std::getenv("S360_QUAD_WAVES_PER_CU");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : 8;  // (181 VGPRs: two waves per SIMD)
+    return v > 0 ? v : 8;  // (two waves per SIMD)
   }();
   static const int cus = [] {
     int dev = 0, n = 256;
