@@ -1,4 +1,4 @@
-"""The soft ISP with random configurations (every JSON key drawn at random, four Bayer patterns, bilinear / edge-aware
+"""Both ISP arithmetics (the soft CameraIsp and the accelerated CameraIspPipe, s360_isp_config.pipe) with random configurations (every JSON key drawn at random, four Bayer patterns, bilinear / edge-aware
 demosaic, resize 1..8, 8- / 16-bit output, tone curve on / off, black-level offsets) and random image sizes on an emulated
 build of the library against the oracle, bit for bit.
 usage: python tools/fuzz/random_isp.py <libs360 build> <seed> <cases>"""
@@ -36,12 +36,15 @@ for i in range(n):
     js = json.dumps({"CameraIsp": c})
     kw = dict(output_bpp=random.choice([8, 16]), demosaic_filter=random.choice([0, 2]), resize=random.choice([1, 1, 2, 4, 8]),
               disable_tone_curve=random.choice([0, 0, 1]), black_level_offset=random.choice([0, 0, 20, -15]))
+    pipe = random.choice([0, 0, 1, 1, 2])  # 1 / 2: the accelerated pipeline's arithmetic (CameraIspPipe; resize 1, odd sizes too)
+    if pipe: kw["resize"] = 1
     r = kw["resize"]
     w = 2 * r * random.randint(4, max(4, 120 // r)); h = 2 * r * random.randint(4, max(4, 80 // r))
+    if pipe: w, h = random.randint(16, 150), random.randint(16, 110)
     raw = rng.integers(0, 65536, (h, w), dtype=np.uint16)
     if random.random() < .3: raw = (raw // 64) * 64 + 5000 // (1 + i % 3)  # darker, banded
     try:
-        cfg = I.config_from_json(js, **kw)
+        cfg = I.config_from_json(js, pipe=pipe, **kw)
         isp = I.CameraIsp(cfg)
     except _capi.S360Error as e:
         rej += 1
@@ -53,9 +56,9 @@ for i in range(n):
         rej += 1; isp.close()
         reasons[str(e)[:70]] = reasons.get(str(e)[:70], 0) + 1
         continue
-    want = O.isp_run(O.isp_config_from_json(js, **kw), raw)
+    want = O.isp_pipe_run(O.isp_config_from_json(js, **kw), raw, fast=pipe == 2) if pipe else O.isp_run(O.isp_config_from_json(js, **kw), raw)
     if got.shape != want.shape or got.dtype != want.dtype or not np.array_equal(got, want):
         bad += 1
-        print("DIFFER", i, w, h, kw, js[:200], flush=True)
+        print("DIFFER", i, w, h, pipe, kw, js[:200], flush=True)
     isp.close()
 print("done: %d cases, %d refused by the library %s, %d differ" % (n, rej, reasons, bad))
