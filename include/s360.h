@@ -348,10 +348,10 @@ int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, 
  * Stuck-pixel removal (CameraIsp.h:1024-1104) with a non-zero radius: the reference's loop over the sorted region,
  *     for (int k = region.size() - 1; k <= region.size() - stuckPixelThreshold; k--)        (:1090-1092)
  * compares size_t values, so for 2 <= stuckPixelThreshold <= (stuckPixelRadius + 1)^2 (the population of a red / blue
- * region; the shipped configurations say 5) its condition is false at once and the pass changes nothing: such
- * configurations are accepted and are exactly that no-op (pinned against CameraIsp.h compiled: tests/test_cpu_isp.py).
- * Thresholds outside that range make the pass a serial in-place median filter of the dark regions in boustrophedon
- * order; those are rejected with S360_ERR_INVALID_ARG. */
+ * region; the shipped configurations say 5) its condition is false at once and the pass changes nothing. Thresholds outside
+ * that range make the pass a serial in-place median filter of the dark regions in boustrophedon order; both are reproduced
+ * (pinned against CameraIsp.h compiled: tests/test_cpu_isp.py), the second as the raster-order recurrence it is — exact, and
+ * as slow as a recurrence is where most pixels change. stuck_pixel_radius up to 6 (JSON 3: a 13 x 13 window). */
 #define S360_ISP_MAX_CURVE_POINTS 16
 typedef struct s360_isp_config {
   /* the "CameraIsp" JSON object as the constructor stores it (CameraIsp.h:425-607): doubles narrowed to float */
@@ -402,7 +402,7 @@ int s360_isp_process(s360_isp* isp, const uint16_t* raw16, int w, int h, void* o
  * pipe = 0 the frames go through the soft CameraIsp arithmetic, pinned bit for bit to CameraIsp.h compiled from the
  * reference. host/Unpacker takes the first by default like the reference and the second with --soft_isp.
  * Not available with pipe = 0 (S360_ERR_INVALID_ARG): demosaic_filter 1 = FREQUENCY_DM_FILTER (CameraIsp.h:1175-1192, needs
- * cv::dct) and stuck-pixel removal with a threshold for which the reference's pass is not a no-op (see s360_isp_config). */
+ * cv::dct; the reference transforms planes it never initialised). */
 int s360_isp_process_packed(s360_isp* isp, const uint8_t* frame, int bits, int w, int h, void* out_bgr);
 /* The functions Halide generates from camera_isp/CameraIspGen.cpp — CameraIspGen8, CameraIspGen16, CameraIspGenFast8,
  * CameraIspGenFast16 (argument list CameraIspGen.cpp:704-712; called by CameraIspPipe::runPipe, CameraIspPipe.h:143-175) — as

@@ -154,16 +154,8 @@ void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut) 
   if (cfg.demosaic_filter < 0 || cfg.demosaic_filter > 2) throw Error(S360_ERR_INVALID_ARG, "expecting Demosaic filter in [0,2]");
   if (cfg.resize != 1 && cfg.resize != 2 && cfg.resize != 4 && cfg.resize != 8)
     throw Error(S360_ERR_INVALID_ARG, "expecting a resize value of 1, 2, 4, or 8. got " + std::to_string(cfg.resize));
-  if (cfg.stuck_pixel_radius > 0 && !cfg.pipe) {
-    // removeStuckPixels' loop condition `k <= region.size() - stuckPixelThreshold` (size_t arithmetic, CameraIsp.h:1090-1092)
-    // is false from the start for 2 <= threshold <= region.size(): the pass is a no-op. The smallest region is a red /
-    // blue pixel's: the same-colour sites of a (2 R + 1)^2 window, R = stuck_pixel_radius = 2 x the JSON value.
-    const long long nmin = (long long)(cfg.stuck_pixel_radius + 1) * (cfg.stuck_pixel_radius + 1);
-    if (cfg.stuck_pixel_threshold < 2 || cfg.stuck_pixel_threshold > nmin)
-      throw Error(S360_ERR_INVALID_ARG, "stuck-pixel removal with stuckPixelThreshold " + std::to_string(cfg.stuck_pixel_threshold) +
-                                            ": outside 2.." + std::to_string(nmin) + " the reference's pass is a serial in-place median "
-                                            "filter of the dark regions (CameraIsp.h:1024-1104), which is not available");
-  }
+  if (cfg.stuck_pixel_radius > 7 && !cfg.pipe)
+    throw Error(S360_ERR_INVALID_ARG, "stuckPixelRadius above 3 (a window wider than 15 x 15) is not supported");
   if (cfg.bayer_pattern < 0 || cfg.bayer_pattern > 3) throw Error(S360_ERR_INVALID_ARG, "bayer_pattern must be 0..3");
   if (cfg.n_vignette_h < 1 || cfg.n_vignette_h > S360_ISP_MAX_CURVE_POINTS || cfg.n_vignette_v < 1 ||
       cfg.n_vignette_v > S360_ISP_MAX_CURVE_POINTS)
@@ -188,6 +180,18 @@ void isp_derive(const s360_isp_config& cfg, IspDev& d, std::vector<float>& lut) 
     d.amount[k] = 1.0f + cfg.sharpening[k];
   }
   d.sharpen = cfg.sharpening[0] != 0.0 && cfg.sharpening[1] != 0.0 && cfg.sharpening[2] != 0.0;
+  // removeStuckPixels' loop over the sorted region, `k <= region.size() - stuckPixelThreshold` in size_t arithmetic
+  // (CameraIsp.h:1090-1092), is false from the start for 2 <= threshold <= region.size(): the pass then changes nothing.
+  // The smallest region is a red / blue pixel's — the same-colour sites of a (2 R + 1)^2 window, R = stuck_pixel_radius =
+  // 2 x the JSON value: (R + 1)^2 — so thresholds of 2 .. (R + 1)^2 (the shipped 5 included) need no kernel at all; any
+  // other threshold makes the pass a serial in-place median filter of the dark regions, which k_isp_stuck runs.
+  d.stuckR = 0;
+  if (cfg.stuck_pixel_radius > 0) {
+    const long long nmin = (long long)(cfg.stuck_pixel_radius + 1) * (cfg.stuck_pixel_radius + 1);
+    if (cfg.stuck_pixel_threshold < 2 || cfg.stuck_pixel_threshold > nmin) d.stuckR = cfg.stuck_pixel_radius;
+  }
+  d.stuckThr = cfg.stuck_pixel_threshold;
+  d.stuckDark = cfg.stuck_pixel_darkness_threshold;
   d.noiseCore = cfg.noise_core;
   d.maxVal = (1 << cfg.output_bpp) - 1.0f;
   d.alpha = powf(cfg.sharpening_support, 1.0f / 4.0f);
@@ -399,6 +403,7 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   // the 9x9 homogeneity window and the reflected +-2 taps index up to 4 pixels past an edge (the reference reads out
   // of bounds below that size); the pipeline mirrors 8 pixels beyond every edge
   if (w < 8 || h < 8) throw Error(S360_ERR_INVALID_ARG, "image too small for the ISP (needs at least 8x8 after resize)");
+  if (o->dev.stuckR > 0 && !cfg.pipe && w > 65536) throw Error(S360_ERR_INVALID_ARG, "stuck-pixel removal: images wider than 65536 are not supported");
   if (cfg.pipe && (w < 16 || h < 16)) throw Error(S360_ERR_INVALID_ARG, "image too small for the accelerated pipeline (needs at least 16x16)");
   const size_t n = (size_t)w * h;
   s360_isp::Curves* cur = nullptr;
@@ -433,6 +438,7 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
     o->dGreen.ensure(n * sizeof(float));
     o->dFlag.ensure(n);
   }
+  if (o->dev.stuckR > 0) o->dStuck.ensure((size_t)w * 5 + 16);
   if (o->dev.sharpen) {
     o->dLp.ensure(n * 3 * sizeof(float));
     o->dScratch.ensure(n * 3 * sizeof(float));
@@ -448,6 +454,8 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   B.scratch = o->dScratch.as<float>();
   B.state = o->dState.as<float>();
   B.flag = o->dFlag.as<unsigned char>();
+  B.stuckCand = o->dStuck.as<float>();
+  B.stuckAct = o->dStuck.as<unsigned char>() + (size_t)w * 4;
   B.curveH = cur->h_.as<float>();
   B.curveV = cur->v_.as<float>();
   B.lut = o->dLut.as<float>();

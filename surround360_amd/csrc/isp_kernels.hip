@@ -8,6 +8,7 @@
 //
 // Kernels (all HBM-bound streaming / small-stencil passes over planes of 4 B per pixel):
 //   k_isp_front        raw16 -> normalised Bayer plane (box resize, black level, vignette curves, white balance, clamp)
+//   k_isp_stuck        removeStuckPixels where it changes pixels (a serial in-place pass: one workgroup, see the kernel)
 //   k_isp_green_cand   vertical / horizontal green candidates and the "horizontal is smoother" flag
 //   k_isp_green_pick   9x9 vote over the flags -> the green plane
 //   k_isp_color<DM>    red / blue by constant-hue interpolation (or the bilinear demosaic), composite CCM, tone LUT
@@ -176,6 +177,108 @@ __global__ __launch_bounds__(GP_T * GP_T / 4) void k_isp_green_pick(const unsign
     for (int k = 0; k < 9; ++k) cnt += s_r[ly + k][lx];
     const size_t o = (size_t)y * w + x;
     green[o] = cnt < 40 ? gV[o] : gH[o];  // hCount < diameterSquared / 2
+  }
+}
+
+// ---- removeStuckPixels (CameraIsp.h:1024-1104) where it changes pixels -----------------------------------------------
+// For 2 <= stuckPixelThreshold <= the region's population the reference's pass is a no-op (isp.cpp) and this kernel is not
+// launched. Otherwise every pixel whose same-colour neighbourhood is dark takes that neighbourhood's median — IN PLACE and in
+// boustrophedon order, so a pixel sees the new values of the pixels before it: a recurrence without a parallel order (row
+// i + 1 is walked against the direction of row i; its first pixel's window holds the pixels row i finished last). What can be
+// taken out of the chain is everything that does not depend on it: ONE workgroup walks the rows; for a row, all threads first
+// evaluate every pixel against the image as it stands (rows above final, this row and the rows below untouched) — phase A —,
+// then thread 0 takes the row in scan order in stretches of 64 positions — phase B —: a stretch in which phase A found nothing to
+// write and which lies more than R columns behind the last changed pixel is skipped, a pixel farther than R columns from the
+// last changed pixel of its row takes phase A's verdict (its window has not changed), any other pixel is evaluated again
+// on the current values. Exact for every configuration; fast where few pixels change (the use the pass was written for), a
+// serial walk where every pixel does (a dark image with a threshold of 0 or 1: the reference's own cost there).
+constexpr int kStuckMaxRegion = 113;  // same-colour sites of a 15 x 15 window (R <= 7)
+struct StuckEval { bool write; float value; };
+__device__ inline StuckEval stuck_evaluate(const float* __restrict__ plane, int w, int h, const IspDev& d, int R, int thr,
+                                           float dark, int i, int j) {
+  const bool tr = is_red(d, i, j), tg = is_green(d, i, j);
+  float v[kStuckMaxRegion];
+  int n = 0;
+  float mean = 0.0f;
+  for (int y = -R; y <= R; ++y) {
+    const int ip = reflecti(i + y, h);
+    for (int x = -R; x <= R; ++x) {
+      const int jp = reflecti(j + x, w);
+      const bool pr = is_red(d, ip, jp), pg = is_green(d, ip, jp);
+      if ((pr && tr) || (pg && tg) || (!pr && !pg && !tr && !tg)) {
+        const float p = plane[(size_t)ip * w + jp];
+        mean += p;
+        if (n < kStuckMaxRegion) v[n] = p;
+        ++n;
+      }
+    }
+  }
+  mean /= float(n);
+  StuckEval e;
+  e.write = false;
+  e.value = 0.0f;
+  // `for (k = n - 1; k <= n - threshold; k--)` in size_t arithmetic: entered (and then always ending at the centre pixel) iff
+  // threshold <= 1 or threshold > n
+  if (!(mean < dark) || (thr >= 2 && thr <= n)) return e;
+  // the median VALUE sorted[n / 2]: n / 2 + 1 rounds of selecting the smallest remaining value
+  float m = 0.0f;
+  for (int r = 0; r <= n / 2; ++r) {
+    int at = r;
+    for (int k = r + 1; k < n; ++k)
+      if (v[k] < v[at]) at = k;
+    m = v[at];
+    v[at] = v[r];
+    v[r] = m;
+  }
+  e.write = true;
+  e.value = m;
+  return e;
+}
+__global__ __launch_bounds__(1024) void k_isp_stuck(float* __restrict__ plane, int w, int h, IspDev d, int R, int thr, float dark,
+                                                     float* __restrict__ cand, unsigned char* __restrict__ act) {
+  __shared__ unsigned char s_any[1024];  // per stretch of 64 scan positions: phase A found something to write (w <= 65536)
+  const int tid = threadIdx.x;
+  for (int i = 0; i < h; ++i) {
+    const bool even = (i & 1) == 0;
+    for (int c = tid; c < 1024; c += blockDim.x) s_any[c] = 0;
+    __syncthreads();
+    // ---- phase A: every pixel of the row but the scan's last one (`j != jEnd`, CameraIsp.h:1054) against the current image
+    for (int j = tid; j < w; j += blockDim.x) {
+      StuckEval e;
+      e.write = false;
+      e.value = 0.0f;
+      if (j != (even ? w - 1 : 0)) e = stuck_evaluate(plane, w, h, d, R, thr, dark, i, j);
+      cand[j] = e.value;
+      act[j] = e.write ? 1 : 0;
+      if (e.write) s_any[(even ? j : w - 1 - j) >> 6] = 1;  // (every writer stores the same value)
+    }
+    __syncthreads();
+    // ---- phase B: thread 0 walks the row in scan order — a serial chain, more threads could only repeat it
+    if (tid == 0) {
+      int lastDirty = -0x3fffffff;  // scan position of the last pixel of this row whose value changed
+      for (int base = 0; base < w - 1; base += 64) {
+        if (!s_any[base >> 6] && base - lastDirty > R) continue;
+        const int end = min(base + 64, w - 1);
+        for (int t = base; t < end; ++t) {
+          const int j = even ? t : w - 1 - t;
+          StuckEval e;
+          if (t - lastDirty <= R) {
+            e = stuck_evaluate(plane, w, h, d, R, thr, dark, i, j);
+          } else {
+            e.write = act[j] != 0;
+            e.value = cand[j];
+          }
+          if (e.write) {
+            float* px = plane + (size_t)i * w + j;
+            if (__float_as_uint(*px) != __float_as_uint(e.value)) {
+              *px = e.value;
+              lastDirty = t;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -414,6 +517,9 @@ void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int 
   const size_t n = (size_t)w * h;
   const dim3 row(256), grd((w + 255) / 256, h);
   hipLaunchKernelGGL(k_isp_front, grd, row, 0, st, raw, inW, inH, B.plane, w, h, d, B.curveH, B.curveV);
+  if (d.stuckR > 0)  // removeStuckPixels where it changes pixels (isp_derive leaves stuckR 0 where it is the reference's no-op)
+    hipLaunchKernelGGL(k_isp_stuck, dim3(1), dim3(1024), 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand,
+                       B.stuckAct);
   if (d.demosaic == 0) {
     hipLaunchKernelGGL((k_isp_color<0>), grd, row, 0, st, B.plane, nullptr, w, h, d, B.lut, B.img);
   } else {

@@ -70,7 +70,8 @@ def test_shipped_configurations(ref, cfg):
 
 # (radius, threshold, darkness threshold, does the reference's pass change pixels?)
 STUCK = [(1, 5, 0.5, False), (1, 2, 0.9, False), (2, 9, 0.9, False), (1, 9, 0.9, False),  # 2 <= threshold <= region: no-op
-         (1, 1, 0.5, True), (1, 0, 0.9, True), (1, 10, 0.9, True), (2, 26, 0.5, True), (1, -3, 0.9, True)]
+         (1, 1, 0.5, True), (1, 0, 0.9, True), (1, 10, 0.9, True), (2, 26, 0.5, True), (1, -3, 0.9, True),
+         (2, 1, 2.0, True), (3, 0, 0.4, True)]  # (darkness 2.0: every pixel is filtered)
 
 
 @pytest.mark.parametrize("radius,thr,dark,active", STUCK)
@@ -90,9 +91,11 @@ def test_stuck_pixel_removal_equals_compiled_reference(ref, radius, thr, dark, a
     assert np.array_equal(want, off) == (not active)
 
 
-def test_library_accepts_the_stuck_pixel_no_op_and_rejects_the_filter(oracle, s360lib):
+def test_library_accepts_the_stuck_pixel_configurations(oracle, s360lib):
     """libs360's host side: a configuration whose stuck-pixel pass is the reference's no-op derives the same tables as with
-    radius 0; one whose pass would filter is refused with a message."""
+    radius 0; one whose pass filters is accepted too since round 4 (k_isp_stuck runs it; tests/test_gpu_isp.py, and on the
+    emulation tests/test_cpu_library_emulation.py, hold it to the oracle for the cases above); a window wider than 15 x 15 is
+    refused with a message."""
     from surround360_amd import isp as I
     ok = I.config_from_json(isputil.stuck_pixel_config(1, 5, 0.11), 16)
     assert (ok.stuck_pixel_radius, ok.stuck_pixel_threshold) == (2, 5) and abs(ok.stuck_pixel_darkness_threshold - 0.11) < 1e-6
@@ -100,8 +103,9 @@ def test_library_accepts_the_stuck_pixel_no_op_and_rejects_the_filter(oracle, s3
     for a, b in zip(I.config_tables(ok)[:2], I.config_tables(base)[:2]):
         assert np.array_equal(a, b)
     for thr in (1, 0, 10, -3):
-        with pytest.raises(Exception, match="stuck"):
-            I.config_tables(I.config_from_json(isputil.stuck_pixel_config(1, thr, 0.5), 16))
+        I.config_tables(I.config_from_json(isputil.stuck_pixel_config(1, thr, 0.5), 16))
+    with pytest.raises(Exception, match="stuckPixelRadius"):
+        I.config_tables(I.config_from_json(isputil.stuck_pixel_config(4, 1, 0.5), 16))
 
 
 def test_tables(oracle):

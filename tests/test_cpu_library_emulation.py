@@ -176,8 +176,7 @@ def test_emulated_raw2rgb_writes_what_the_reference_program_writes(tmp_path, emu
     assert digest == json.load(open(refprog.GOLDEN))["raw2rgb"][name]
 
 
-@pytest.mark.parametrize("soft", [False, True], ids=["pipe", "soft_isp"])
-@pytest.mark.parametrize("bits", [12, 8])
+@pytest.mark.parametrize("bits,soft", [(12, False), (8, False), (12, True)], ids=["12-pipe", "8-pipe", "12-soft_isp"])
 def test_emulated_unpacker(tmp_path, emu_programs, bits, soft):
     from test_gpu_zz_unpacker import check_unpacker
     check_unpacker(os.path.join(emu_programs, "Unpacker"), tmp_path, O, bits, soft)
@@ -188,7 +187,8 @@ def test_emulated_renderer_fed_from_the_capture_containers(tmp_path, emu_program
     """host/TestRenderStereoPanorama --bin_list --isp_dir ("the ISP feeding the GPU directly from .bin") against
     Unpacker -> PNG files -> renderer: the same equirects, two chained frames and the two frames as a stream."""
     from test_gpu_zz_unpacker import check_bin_list
-    check_bin_list(os.path.join(emu_programs, "Unpacker"), os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, soft=soft)
+    check_bin_list(os.path.join(emu_programs, "Unpacker"), os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, soft=soft,
+                   chain=not soft)  # (the soft ISP: one frame — only the ISP differs between the two)
 
 
 def test_emulated_optical_flow_harness(tmp_path, emu_programs):

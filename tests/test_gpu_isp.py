@@ -92,22 +92,33 @@ def test_accelerated_pipeline_domain(oracle, s360lib):
     assert np.array_equal(a, oracle.isp_pipe_run(oracle.isp_config_from_json(json.dumps(j), 8), raw))
 
 
-def test_isp_with_stuck_pixel_radius(oracle, s360lib):
-    """stuckPixelRadius > 0 with the shipped configurations' stuckPixelThreshold 5: the reference's removeStuckPixels is
-    then a no-op (its loop condition, CameraIsp.h:1090-1092; pinned against CameraIsp.h compiled in tests/test_cpu_isp.py)
-    and the library accepts the configuration; a threshold for which the pass would filter is refused."""
+# (radius, threshold, darkness threshold): tests/test_cpu_isp.py pins the oracle to the reference's CameraIsp.h compiled for these
+STUCK_CASES = [(1, 5, 0.11), (1, 1, 0.5), (1, 0, 0.9), (1, 10, 0.9), (2, 26, 0.5), (1, -3, 0.9), (2, 1, 2.0), (3, 0, 0.4)]
+
+
+@pytest.mark.parametrize("case", STUCK_CASES, ids=lambda c: "r%d-t%d-d%g" % c)
+def test_isp_with_stuck_pixel_radius(oracle, s360lib, case):
+    """removeStuckPixels (CameraIsp.h:1024-1104). With the shipped configurations' threshold (5) the reference's pass is a no-op
+    (its loop condition, :1090-1092) and no kernel runs; with a threshold of 0, 1, a negative one or one above the region's
+    population it is an IN-PLACE median filter of the dark regions in boustrophedon order — a recurrence k_isp_stuck walks
+    row by row (round 4; refused before). Darkness 2.0: every pixel is filtered, every pixel depends on its predecessor."""
     from surround360_amd import isp as I
-    js = isputil.stuck_pixel_config(1, 5, 0.11)
-    raw = isputil.bayer_frame(160, 120, seed=4)
-    raw[40:60, 10:30] //= 8
-    want = oracle.isp_run(oracle.isp_config_from_json(js, 16), raw)
-    isp = I.CameraIsp(I.config_from_json(js, 16))
-    try:
-        assert np.array_equal(isp.get_image(raw), want)
-    finally:
-        isp.close()
-    with pytest.raises(Exception, match="stuck"):
-        I.CameraIsp(I.config_from_json(isputil.stuck_pixel_config(1, 1, 0.5), 16))
+    radius, thr, dark = case
+    js = isputil.stuck_pixel_config(radius, thr, dark)
+    for (w, h, seed) in ((160, 120, 4), (97, 61, 5)):
+        raw = isputil.bayer_frame(w, h, seed=seed)
+        raw[10:14, 20:24] = 65535  # a few hot sites in dark surroundings
+        raw[40:60, 10:30] //= 8
+        want = oracle.isp_run(oracle.isp_config_from_json(js, 16), raw)
+        isp = I.CameraIsp(I.config_from_json(js, 16))
+        try:
+            got = isp.get_image(raw)
+        finally:
+            isp.close()
+        assert np.array_equal(got, want), "%s %dx%d: %d samples differ" % (case, w, h, int((got != want).sum()))
+    if thr == 1 and radius == 1:  # the pass did something
+        off = oracle.isp_run(oracle.isp_config_from_json(isputil.stuck_pixel_config(0, thr, dark), 16), raw)
+        assert not np.array_equal(off, want)
 
 
 def test_isp_two_sizes_one_object(oracle, s360lib):

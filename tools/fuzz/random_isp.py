@@ -32,7 +32,9 @@ for i in range(n):
     if random.random() < .5: c["lowKeyBoost"] = v3(-0.4, 0.4)
     if random.random() < .5: c["highKeyBoost"] = v3(-0.4, 0.4)
     if random.random() < .6: c["gamma"] = v3(0.3, 1.2)
-    if random.random() < .3: c.update(stuckPixelRadius=random.randint(0, 2), stuckPixelThreshold=random.randint(2, 5), stuckPixelDarknessThreshold=0.1)
+    if random.random() < .4:  # thresholds 2..: the reference's no-op; 0, 1, negative or above the region: its in-place median filter
+        c.update(stuckPixelRadius=random.randint(0, 3), stuckPixelThreshold=random.choice([5, 2, 1, 0, -2, 30, 12]),
+                 stuckPixelDarknessThreshold=random.choice([0.1, 0.5, 2.0]))
     js = json.dumps({"CameraIsp": c})
     kw = dict(output_bpp=random.choice([8, 16]), demosaic_filter=random.choice([0, 2]), resize=random.choice([1, 1, 2, 4, 8]),
               disable_tone_curve=random.choice([0, 0, 1]), black_level_offset=random.choice([0, 0, 20, -15]))
