@@ -438,7 +438,7 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
     o->dGreen.ensure(n * sizeof(float));
     o->dFlag.ensure(n);
   }
-  if (o->dev.stuckR > 0) o->dStuck.ensure((size_t)w * 5 + 16);
+  if (o->dev.stuckR > 0) o->dStuck.ensure((n + w) * 5 + (size_t)w * 4 + 64);
   if (o->dev.sharpen) {
     o->dLp.ensure(n * 3 * sizeof(float));
     o->dScratch.ensure(n * 3 * sizeof(float));
@@ -454,8 +454,11 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   B.scratch = o->dScratch.as<float>();
   B.state = o->dState.as<float>();
   B.flag = o->dFlag.as<unsigned char>();
-  B.stuckCand = o->dStuck.as<float>();
-  B.stuckAct = o->dStuck.as<unsigned char>() + (size_t)w * 4;
+  B.stuckCand0 = o->dStuck.as<float>();  // floats: n (image), w (row); ints: w; bytes: n, w
+  B.stuckCand = B.stuckCand0 + n;
+  B.stuckDirty = reinterpret_cast<int*>(B.stuckCand + w);
+  B.stuckAct0 = reinterpret_cast<unsigned char*>(B.stuckDirty + w);
+  B.stuckAct = B.stuckAct0 + n;
   B.curveH = cur->h_.as<float>();
   B.curveV = cur->v_.as<float>();
   B.lut = o->dLut.as<float>();

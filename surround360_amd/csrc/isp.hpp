@@ -21,8 +21,9 @@ struct IspDev {
 };
 struct IspFrameBufs {
   float *plane, *gV, *gH, *green, *img, *lp, *scratch, *state;  // state: 3 * max(w, h) floats (IIR hand-over between passes)
-  unsigned char *flag, *stuckAct;  // stuckAct / stuckCand: one row (k_isp_stuck)
-  float* stuckCand;
+  unsigned char *flag, *stuckAct, *stuckAct0;  // k_isp_stuck: stuckAct / stuckCand one row, stuckAct0 / stuckCand0 the image
+  float *stuckCand, *stuckCand0;
+  int* stuckDirty;  // one row
   const float *curveH, *curveV, *lut;
   const unsigned long long* exptab;
 };
@@ -58,7 +59,7 @@ struct s360_isp {
   s360::IspPipeDev pipe;  // used instead of `dev` when cfg.pipe != 0
   std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
   s360::DevBuf dToneTab;  // pipe: [4096][3] uint16
-  s360::DevBuf dStuck;  // k_isp_stuck: w floats + w bytes
+  s360::DevBuf dStuck;  // k_isp_stuck: n + w floats, w ints, n + w bytes
   s360::DevBuf dGenH, dGenV, dGenTone;  // s360_isp_pipe_generated: the caller's tables
   s360::DevBuf dLut, dExp, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dState, dOut, dPacked;
   // vignette curves per output size (curveHAtPixel / curveVAtPixel): a rig's side and pole cameras may differ in

@@ -185,13 +185,15 @@ __global__ __launch_bounds__(GP_T * GP_T / 4) void k_isp_green_pick(const unsign
 // launched. Otherwise every pixel whose same-colour neighbourhood is dark takes that neighbourhood's median — IN PLACE and in
 // boustrophedon order, so a pixel sees the new values of the pixels before it: a recurrence without a parallel order (row
 // i + 1 is walked against the direction of row i; its first pixel's window holds the pixels row i finished last). What can be
-// taken out of the chain is everything that does not depend on it: ONE workgroup walks the rows; for a row, all threads first
-// evaluate every pixel against the image as it stands (rows above final, this row and the rows below untouched) — phase A —,
-// then thread 0 takes the row in scan order in stretches of 64 positions — phase B —: a stretch in which phase A found nothing to
-// write and which lies more than R columns behind the last changed pixel is skipped, a pixel farther than R columns from the
-// last changed pixel of its row takes phase A's verdict (its window has not changed), any other pixel is evaluated again
-// on the current values. Exact for every configuration; fast where few pixels change (the use the pass was written for), a
-// serial walk where every pixel does (a dark image with a threshold of 0 or 1: the reference's own cost there).
+// taken out of the chain is everything that does not depend on it. k_isp_stuck_pre evaluates every pixel against the ORIGINAL
+// image with the whole chip; then ONE workgroup (k_isp_stuck) walks the rows. For a row, all its threads first settle every
+// pixel's verdict against the image as it stands — the pre-pass's where no changed pixel lies within R rows and columns (a
+// per-column "last changed row" is kept), a fresh evaluation otherwise — phase A —, then thread 0 takes the row in scan order
+// in stretches of 64 positions — phase B —: a stretch in which phase A found nothing to write and which lies more than R
+// columns behind the row's last changed pixel is skipped, a pixel farther than R columns from it takes phase A's verdict
+// (its window has not changed), any other pixel is evaluated again on the current values. Exact for every configuration; fast
+// where few pixels change (the use the pass was written for), a serial walk where every pixel does (a dark image with a
+// threshold of 0 or 1).
 constexpr int kStuckMaxRegion = 113;  // same-colour sites of a 15 x 15 window (R <= 7)
 struct StuckEval { bool write; float value; };
 __device__ inline StuckEval stuck_evaluate(const float* __restrict__ plane, int w, int h, const IspDev& d, int R, int thr,
@@ -234,20 +236,38 @@ __device__ inline StuckEval stuck_evaluate(const float* __restrict__ plane, int 
   e.value = m;
   return e;
 }
+// every pixel against the ORIGINAL image, all workgroups at once: the verdict holds for every pixel that no changed pixel comes near
+__global__ __launch_bounds__(256) void k_isp_stuck_pre(const float* __restrict__ plane, int w, int h, IspDev d, int R, int thr,
+                                                        float dark, float* __restrict__ cand0, unsigned char* __restrict__ act0) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= w) return;
+  StuckEval e;
+  e.write = false;
+  e.value = 0.0f;
+  if (j != ((i & 1) == 0 ? w - 1 : 0)) e = stuck_evaluate(plane, w, h, d, R, thr, dark, i, j);  // (`j != jEnd`, CameraIsp.h:1054)
+  cand0[(size_t)i * w + j] = e.value;
+  act0[(size_t)i * w + j] = e.write ? 1 : 0;
+}
 __global__ __launch_bounds__(1024) void k_isp_stuck(float* __restrict__ plane, int w, int h, IspDev d, int R, int thr, float dark,
-                                                     float* __restrict__ cand, unsigned char* __restrict__ act) {
+                                                     const float* __restrict__ cand0, const unsigned char* __restrict__ act0,
+                                                     float* __restrict__ cand, unsigned char* __restrict__ act,
+                                                     int* __restrict__ dirtyRow) {
   __shared__ unsigned char s_any[1024];  // per stretch of 64 scan positions: phase A found something to write (w <= 65536)
   const int tid = threadIdx.x;
+  for (int j = tid; j < w; j += blockDim.x) dirtyRow[j] = -0x3fffffff;  // the last row in which column j changed
+  __syncthreads();
   for (int i = 0; i < h; ++i) {
     const bool even = (i & 1) == 0;
     for (int c = tid; c < 1024; c += blockDim.x) s_any[c] = 0;
     __syncthreads();
-    // ---- phase A: every pixel of the row but the scan's last one (`j != jEnd`, CameraIsp.h:1054) against the current image
+    // ---- phase A: the pre-pass's verdict, or — within R rows and columns of a changed pixel — the pixel against the current image
     for (int j = tid; j < w; j += blockDim.x) {
+      bool near = false;
+      for (int x = -R; x <= R; ++x) near = near || dirtyRow[min(max(j + x, 0), w - 1)] >= i - R;
       StuckEval e;
-      e.write = false;
-      e.value = 0.0f;
-      if (j != (even ? w - 1 : 0)) e = stuck_evaluate(plane, w, h, d, R, thr, dark, i, j);
+      e.write = act0[(size_t)i * w + j] != 0;
+      e.value = cand0[(size_t)i * w + j];
+      if (near && j != (even ? w - 1 : 0)) e = stuck_evaluate(plane, w, h, d, R, thr, dark, i, j);
       cand[j] = e.value;
       act[j] = e.write ? 1 : 0;
       if (e.write) s_any[(even ? j : w - 1 - j) >> 6] = 1;  // (every writer stores the same value)
@@ -273,6 +293,7 @@ __global__ __launch_bounds__(1024) void k_isp_stuck(float* __restrict__ plane, i
             if (__float_as_uint(*px) != __float_as_uint(e.value)) {
               *px = e.value;
               lastDirty = t;
+              dirtyRow[j] = i;
             }
           }
         }
@@ -518,8 +539,11 @@ void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int 
   const dim3 row(256), grd((w + 255) / 256, h);
   hipLaunchKernelGGL(k_isp_front, grd, row, 0, st, raw, inW, inH, B.plane, w, h, d, B.curveH, B.curveV);
   if (d.stuckR > 0)  // removeStuckPixels where it changes pixels (isp_derive leaves stuckR 0 where it is the reference's no-op)
-    hipLaunchKernelGGL(k_isp_stuck, dim3(1), dim3(1024), 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand,
-                       B.stuckAct);
+  {
+    hipLaunchKernelGGL(k_isp_stuck_pre, grd, row, 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand0, B.stuckAct0);
+    hipLaunchKernelGGL(k_isp_stuck, dim3(1), dim3(1024), 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand0,
+                       B.stuckAct0, B.stuckCand, B.stuckAct, B.stuckDirty);
+  }
   if (d.demosaic == 0) {
     hipLaunchKernelGGL((k_isp_color<0>), grd, row, 0, st, B.plane, nullptr, w, h, d, B.lut, B.img);
   } else {
