@@ -1,4 +1,5 @@
 #!/bin/bash
+# (S360_QUAD_OCC3 selected a second build of the kernel that was removed after this measurement: DESIGN.md section 5, profiles/r04_v5_*)
 # The throughput sweep kernel held to three waves per SIMD (k_sweep_quad_occ3, S360_QUAD_OCC3) against the default, same box:
 # micro-benchmark of a saturating side level and of a pole level, then the bench line (timed region + check) with and without.
 cd "$(dirname "$0")/.."

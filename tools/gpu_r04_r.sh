@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the k_sweep_quad_occ3 build was removed after this measurement: DESIGN.md section 5, profiles/r04_v5_*)
 # How much does a wave more per SIMD buy the throughput sweep? One build (k_sweep_quad_occ3: its spill code is in every arm) at
 # 4 / 8 / 12 persistent waves per CU = 1 / 2 / 3 per SIMD, on a launch with enough flows to keep twelve per CU busy (224 flows x
 # up to 23 bands in flight each), and the default build at 4 / 8.

@@ -7,8 +7,8 @@
 A loop is a backward branch (s_cbranch_* / s_branch to a label that was defined earlier in the same function); its body is the
 text between the label and the branch. Per loop: instructions, VALU / SALU / LDS / global / scratch instructions, and the
 `s_waitcnt vmcnt(..)` it contains — the sweep kernels' steady steps must have none (loads and stores retire through one in-order
-counter on gfx950: a wait inside the step waits for the next chunk's prefetches), and no scratch access. Per kernel: VGPRs, SGPR / VGPR spills, scratch and LDS bytes, waves per SIMD from the
-metadata the compiler wrote. tests/test_cpu_isa.py holds the product's sweep kernels to that.
+counter on gfx950: a wait inside the step waits for the next chunk's prefetches), and no scratch access.
+Per kernel: VGPRs, scratch and LDS bytes, waves per SIMD from the metadata the compiler wrote. tests/test_cpu_isa.py holds the product's sweep kernels to that.
 """
 import argparse
 import re
@@ -74,7 +74,7 @@ def loops_of(lines):
                     if bop == "s_waitcnt" and "vmcnt" in brest:
                         waits.append(re.search(r"vmcnt\((\d+)\)", brest).group(1))
                 out.append({"label": tgt, "start": labels[tgt], "end": i, "insts": len(body), **cnt, "vmcnt_waits": waits})
-    # innermost first: drop nothing, but mark loops that contain another loop
+    # mark the loops that contain another loop
     for a in out:
         a["contains_loop"] = any(b is not a and a["start"] <= b["start"] and b["end"] <= a["end"] for b in out)
     return out
@@ -90,8 +90,6 @@ def kernel_meta(text):
             if mm:
                 d[k] = int(mm.group(1))
         meta[m.group(1)] = d
-    for m in re.finditer(r"; Kernel info:.*?(?=\n\s*\.)", text, re.S):
-        pass
     # the comment block the compiler writes behind every kernel
     for m in re.finditer(r"\.Lfunc_end\d+:\s*\n\s*\.size\s+(\S+),.*?; Occupancy: (\d+)", text, re.S):
         meta.setdefault(m.group(1), {})["occupancy"] = int(m.group(2))
