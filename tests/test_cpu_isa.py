@@ -1,4 +1,4 @@
-"""What the sweep kernels' speed rests on and only the ISA shows, checked without a GPU: hipcc cross-compiles sweep_quad.hip with
+"""What the throughput sweep kernel's speed rests on and only the ISA shows, checked without a GPU: hipcc cross-compiles sweep_quad.hip with
 the product's flags, tools/isa_loops.py reads the loops out of the assembly.
   * The steady step of the throughput kernel (two loops per build: steps 0..11 of a chunk and its last four) holds no wait on
     the memory counter — loads and stores retire in order through one counter on gfx950, so a wait there waits for the next

@@ -6,9 +6,10 @@
 
 A loop is a backward branch (s_cbranch_* / s_branch to a label that was defined earlier in the same function); its body is the
 text between the label and the branch. Per loop: instructions, VALU / SALU / LDS / global / scratch instructions, and the
-`s_waitcnt vmcnt(..)` it contains — the sweep kernels' steady steps must have none (loads and stores retire through one in-order
+`s_waitcnt vmcnt(..)` it contains — the throughput sweep kernel's steady steps must have none (loads and stores retire through one in-order
 counter on gfx950: a wait inside the step waits for the next chunk's prefetches), and no scratch access.
-Per kernel: VGPRs, scratch and LDS bytes, waves per SIMD from the metadata the compiler wrote. tests/test_cpu_isa.py holds the product's sweep kernels to that.
+Per kernel: VGPRs, scratch and LDS bytes, waves per SIMD from the metadata the compiler wrote. tests/test_cpu_isa.py holds k_sweep_quad to that (the latency kernel, k_sweep_lock, gathers from
+global memory inside its step by design: its compute waves do wait there).
 """
 import argparse
 import re
