@@ -69,6 +69,53 @@ def test_accelerated_pipeline_equals_its_oracle(oracle, s360lib, case):
     assert np.array_equal(again, got)
 
 
+def test_generated_functions_entry_point(oracle, s360lib):
+    """s360_isp_pipe_generated — the signature of the functions Halide generates (CameraIspPipe.h:143-175) — fed the way
+    CameraIspPipe::initPipe / runPipe feed it (tables from the configuration, black levels in 16-bit counts, the horizontal
+    vignette table with its columns 0, 2, 1), from a row-padded input buffer: the picture of the configuration-level call."""
+    import ctypes as C
+    from surround360_amd import _capi, isp as I
+
+    class Args(C.Structure):
+        _fields_ = [("input", C.c_void_p), ("input_stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                    ("vignette_h", C.c_void_p), ("vignette_v", C.c_void_p), ("black_level", C.c_float * 3),
+                    ("white_balance_gain", C.c_float * 3), ("clamp_min", C.c_float * 3), ("clamp_max", C.c_float * 3),
+                    ("sharpening", C.c_float * 3), ("sharpening_support", C.c_float), ("noise_core", C.c_float), ("ccm", C.c_void_p),
+                    ("tone_table", C.c_void_p), ("bgr", C.c_int32), ("bayer_pattern", C.c_int32), ("fast", C.c_int32),
+                    ("output_bpp", C.c_int32), ("output", C.c_void_p)]
+
+    w, h, stride = 150, 90, 192
+    raw = isputil.bayer_frame(w, h, seed=21, pattern="RGGB")
+    padded = np.full((h, stride), 12345, np.uint16)
+    padded[:, :w] = raw
+    for bpp, fast, off in ((16, 0, 0), (8, 1, 20)):
+        cfg = I.config_from_json(isputil.CONFIG_FULL, bpp, 2, 1, 0, off, pipe=I.PIPE_FAST if fast else I.PIPE)
+        isp = I.CameraIsp(cfg)
+        try:
+            want = isp.get_image(raw)
+            ccm, lut, ch, cv = I.config_tables(cfg, w, h)
+            ch = np.ascontiguousarray(ch[:, [0, 2, 1]])  # (sic: CameraIspPipe.h:88-89)
+            tone = np.ascontiguousarray(lut.astype(np.int32).astype(np.uint8 if bpp == 8 else np.uint16))
+            ccm = np.ascontiguousarray(ccm, np.float32)
+            out = np.zeros((h, w, 3), np.uint8 if bpp == 8 else np.uint16)
+            a = Args()
+            a.input, a.input_stride, a.width, a.height = padded.ctypes.data, stride, w, h
+            a.vignette_h, a.vignette_v, a.ccm, a.tone_table, a.output = ch.ctypes.data, cv.ctypes.data, ccm.ctypes.data, tone.ctypes.data, out.ctypes.data
+            for k in range(3):
+                a.black_level[k] = cfg.black_level[k] + off
+                a.white_balance_gain[k], a.clamp_min[k], a.clamp_max[k] = cfg.white_balance_gain[k], cfg.clamp_min[k], cfg.clamp_max[k]
+                a.sharpening[k] = cfg.sharpening[k]
+            a.sharpening_support, a.noise_core = cfg.sharpening_support, cfg.noise_core
+            a.bgr, a.bayer_pattern, a.fast, a.output_bpp = 1, 1, fast, bpp  # RGGB
+            f = _capi.lib().s360_isp_pipe_generated
+            f.restype, f.argtypes = C.c_int, None
+            assert f(isp.h, C.byref(a)) >= 0, _capi.lib().s360_last_error(None)
+            assert np.array_equal(out, want), (bpp, fast)
+            assert np.array_equal(want, oracle.isp_pipe_run(oracle.isp_config_from_json(isputil.CONFIG_FULL, bpp, 2, 1, 0, off), raw, fast=bool(fast)))
+        finally:
+            isp.close()
+
+
 def test_accelerated_pipeline_domain(oracle, s360lib):
     """What the pipeline does not have is refused, what it ignores is ignored: no resize; the demosaic filter and the stuck-pixel
     fields are not read; a pattern other than GBRG / RGGB runs as GBRG (CameraIspPipe.h:133-141)."""
