@@ -39,7 +39,7 @@ def test_isp_equals_oracle(oracle, s360lib, case):
 PIPE_CASES = [  # (config, w, h, bpp, fast, disable_tone_curve, black_level_offset)
     ("full", 128, 96, 16, 0, 0, 0), ("full", 130, 70, 8, 0, 0, 0), ("full", 96, 64, 16, 1, 0, 0), ("full", 200, 136, 8, 1, 0, 25),
     ("empty", 61, 47, 16, 0, 1, 3), ("minimal", 70, 50, 8, 0, 0, 0), ("grbg", 100, 84, 16, 0, 0, 0), ("grbg", 64, 64, 16, 1, 0, 0),
-    ("full", 640, 480, 16, 0, 0, 0), ("empty", 333, 257, 8, 0, 0, 0),
+    ("full", 640, 480, 16, 0, 0, 0), ("empty", 333, 257, 8, 0, 0, 0), ("full", 2048, 2048, 16, 0, 0, 0),  # (the cameras' size)
 ]
 
 
