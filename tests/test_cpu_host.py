@@ -242,6 +242,13 @@ def test_required_flags_and_unknown_flags():
     assert r.returncode == 1 and "unknown command line flag" in r.stderr
     r = subprocess.run([exe, "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--eqr_width" in r.stdout and "--prev_frame_data_dir" in r.stdout
+    assert "--bin_list" in r.stdout and "--isp_dir" in r.stdout
+    # --bin_list replaces imgs_dir and needs the ISP configurations (the renderer fed from the capture's containers)
+    rig = os.path.join(ROOT, "tests", "golden", "rig_17cam.json")
+    r = subprocess.run([exe, "--rig_json_file", rig, "--frame_number", "000000"], capture_output=True, text=True)
+    assert r.returncode != 0 and "imgs_dir" in r.stderr
+    r = subprocess.run([exe, "--rig_json_file", rig, "--bin_list", "a.bin", "--frame_number", "000000"], capture_output=True, text=True)
+    assert r.returncode != 0 and "isp_dir" in r.stderr and "imgs_dir" not in r.stderr
 
 
 def test_optical_flow_harness_flags(tmp_path):
