@@ -841,6 +841,19 @@ def main():
                     nbytes = 12 * (28 * side_px + 6 * pole_px) if k == "flow_gradients" else b * pxl
                     gbs = nbytes / (ms * 1e-3) / 1e9
                     fs[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            # Beside each HBM fraction the kernel family's SQ "VALU busy" figure from the committed counter pass (profiles/valu_busy.json;
+            # not measured by this run): a VALU-bound kernel is then shown at its bound rather than asserted to be there.
+            vb_note = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "valu_busy.json")) as f:
+                    vbj = json.load(f)
+                for group in (wb, fs):
+                    for k, rec in group.items():
+                        if k in vbj["families"]:
+                            rec["valu_busy_profiled"] = vbj["families"][k]["valu_busy"]
+                vb_note = vbj["source"]
+            except Exception:  # noqa: BLE001 - an annotation only
+                pass
             non_sweep = sum(v[0] for k, v in lat_prof.items() if k != "flow_sweep")
             out["single_frame"] = {
                 "mode": "configs[2]: one frame at a time, all pairs on 1 GPU, latency sweep kernel",
@@ -851,7 +864,7 @@ def main():
                           "us_per_diagonal_step": 1e3 * lat_prof.get("flow_sweep", (0, 0))[0] / n_diag},
                 "kernel_ms_non_sweep": round(non_sweep, 3),
                 "kernel_ms_per_frame": {k: round(v[0], 3) for k, v in sorted(lat_prof.items(), key=lambda kv: -kv[1][0])},
-                "warp_blend_roofline": wb, "flow_stencil_roofline": fs,
+                "warp_blend_roofline": wb, "flow_stencil_roofline": fs, "valu_busy_profiled_source": vb_note,
                 "throughput_kernel_alone_ms": tp_ms}
         else:
             # configs[3] (one frame sharded over the ranks, the native RCCL exchanges) runs in a CHILD process per rank, on a
