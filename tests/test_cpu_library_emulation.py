@@ -188,7 +188,8 @@ def test_emulated_renderer_fed_from_the_capture_containers(tmp_path, emu_program
     Unpacker -> PNG files -> renderer: the same equirects, two chained frames and the two frames as a stream."""
     from test_gpu_zz_unpacker import check_bin_list
     check_bin_list(os.path.join(emu_programs, "Unpacker"), os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, soft=soft,
-                   chain=not soft)  # (the soft ISP: one frame — only the ISP differs between the two)
+                   chain=not soft,  # (the soft ISP: one frame — only the ISP differs between the two)
+                   two_devices_env=None if soft else dict(os.environ, EMU_DEVICES="2"))
 
 
 def test_emulated_optical_flow_harness(tmp_path, emu_programs):

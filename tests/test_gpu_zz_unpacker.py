@@ -76,7 +76,7 @@ def check_unpacker(exe, tmp_path, oracle, bits, soft=True):
             assert np.array_equal(tiff, raw16)
 
 
-def check_bin_list(unpacker_exe, trsp_exe, tmp_path, bits=12, soft=False, chain=True):
+def check_bin_list(unpacker_exe, trsp_exe, tmp_path, bits=12, soft=False, chain=True, two_devices_env=None):
     """host/TestRenderStereoPanorama --bin_list: the capture's containers -> ISP -> stereo frame on the device, against the
     chain through files (host/Unpacker writes 16-bit PNGs, the renderer reads them back): the same equirects, for two chained
     frames and for the two frames as one stream. (Also run by tests/test_cpu_library_emulation.py on the emulated programs.)"""
@@ -104,13 +104,13 @@ def check_bin_list(unpacker_exe, trsp_exe, tmp_path, bits=12, soft=False, chain=
     common = ["--rig_json_file", rig, "--eqr_width", str(refprog.EQR_W), "--eqr_height", str(refprog.EQR_H), "--final_eqr_width",
               str(refprog.FINAL), "--final_eqr_height", str(refprog.FINAL), "--enable_top", "--enable_bottom", "--sharpening", "0.25"]
 
-    def run(tag, src, frame, prev, extra=()):
+    def run(tag, src, frame, prev, extra=(), env=None):
         out = tmp_path / tag
         for d in (out, out / "flow", out / "debug", out / "flow" / frame, out / "debug" / frame, out / "debug" / frame / "flow_images"):
             d.mkdir(exist_ok=True)
         cmd = [trsp_exe] + common + src + ["--frame_number", frame, "--output_data_dir", str(out), "--prev_frame_data_dir", prev,
                                            "--output_equirect_path", str(out / "eqr_{frame}.png")] + list(extra)
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, "%s: rc %d\n%s" % (tag, r.returncode, r.stderr[-2000:])
         return out
 
@@ -130,6 +130,11 @@ def check_bin_list(unpacker_exe, trsp_exe, tmp_path, bits=12, soft=False, chain=
         want = refprog.png_pixels_bgr(str(a / ("eqr_%s.png" % f)))
         assert np.array_equal(refprog.png_pixels_bgr(str(b / ("eqr_%s.png" % f))), want), ("bins", f)
         assert np.array_equal(refprog.png_pixels_bgr(str(c / ("eqr_%s.png" % f))), want), ("stream", f)
+    if two_devices_env:  # --num_streams 2: frame 0 on one device, frame 1 as a stream of its own on the next (each opens the containers)
+        alone = run("bins1", bins, "000001", "NONE", ["--output_equirect_path", str(tmp_path / "bins1" / "eqr_000001.png")])
+        d = run("streams2", bins, "000000", "NONE", ["--num_frames", "2", "--num_streams", "2"], env=two_devices_env)
+        assert np.array_equal(refprog.png_pixels_bgr(str(d / "eqr_000000.png")), refprog.png_pixels_bgr(str(a / "eqr_000000.png")))
+        assert np.array_equal(refprog.png_pixels_bgr(str(d / "eqr_000001.png")), refprog.png_pixels_bgr(str(alone / "eqr_000001.png")))
 
 
 def test_renderer_fed_from_the_capture_containers(tmp_path, oracle, s360lib):
