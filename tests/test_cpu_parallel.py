@@ -51,16 +51,34 @@ def emu_programs():
 def test_sharded_program_writes_what_the_reference_program_writes(tmp_path, emu_programs, name, gpus):
     """--num_gpus G: pairs in blocks (8 ranks: 2,2,2,2,2,2,1,1), the strips exchanged once, the pole units on their owners
     (with their temporal state across the chained frames), the warped layers gathered, the composite on rank 0 — the 140
-    (134) files of the case, digest for digest the reference program's."""
+    (134) files of the case, digest for digest the reference program's. The RCCL stand-in runs in its STRICT mode
+    (EMU_RCCL_STRICT=1: no buffering — a send completes only against a receive its peer has posted in a group executing at the same
+    time, so ranks whose groups are ordered differently time out here instead of hanging on a real node; the probe below shows
+    that it tells the two apart)."""
     rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
                                   refprog.CAM / 2048.0)
     out = refprog.run_case(os.path.join(emu_programs, "TestRenderStereoPanorama"), str(tmp_path), rig, name,
-                           more_args=["--num_gpus", str(gpus)], env={"EMU_DEVICES": str(gpus)})
+                           more_args=["--num_gpus", str(gpus)], env={"EMU_DEVICES": str(gpus), "EMU_RCCL_STRICT": "1"})
     got = refprog.digests(out, name)
     golden = json.load(open(refprog.GOLDEN))[name]
     assert sorted(got) == sorted(golden)
     differing = sorted(k for k in golden if got[k] != golden[k])
     assert not differing, "%d of %d files differ from the reference program's: %s" % (len(differing), len(golden), differing[:12])
+
+
+def test_rccl_stand_in_strict_mode_detects_mismatched_group_order(tmp_path):
+    """tests/aux/rccl_strict_probe.cpp: two ranks that each send in one group and receive in the next pass the buffered mailbox —
+    and hang on real RCCL; the strict mode reports them. Send and receive in one group pass both."""
+    exe = str(tmp_path / "probe")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "tools", "hip_wave_shim"),
+                           os.path.join(ROOT, "tests", "aux", "rccl_strict_probe.cpp"),
+                           os.path.join(ROOT, "tools", "hip_wave_shim", "rccl_emu.cpp"), "-o", exe])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("EMU_RCCL")}
+    strict = dict(env, EMU_RCCL_STRICT="1", EMU_RCCL_STRICT_SECONDS="1")
+    assert subprocess.run([exe, "good"], env=env).returncode == 0
+    assert subprocess.run([exe, "bad"], env=env).returncode == 0       # the buffered stand-in cannot see it
+    assert subprocess.run([exe, "good"], env=strict).returncode == 0
+    assert subprocess.run([exe, "bad"], env=strict).returncode != 0    # the strict one does
 
 
 @pytest.mark.parametrize("world", [3])  # (world 2 as processes: test_bench_script_two_ranks_dry_run below)

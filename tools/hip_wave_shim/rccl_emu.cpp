@@ -7,6 +7,10 @@
 // With EMU_RCCL_DIR set, communicators made by ncclCommInitRank use files in that directory as the mailbox instead
 // (message k from src to dst = <dir>/<id>_<src>_<dst>_<k>, written under a temporary name and renamed), so that the ranks
 // can be separate PROCESSES — one per rank under torch.distributed.run, as on a real node.
+// EMU_RCCL_STRICT=1 (in-process transport): nothing is buffered. A send completes only against a receive that its peer has
+// posted in the group it is executing AT THE SAME TIME (a rendezvous, like RCCL's point-to-point kernels, which run on both
+// sides at once): ranks whose groups are ordered differently — A: {send to B} then {recv from B}, B the same towards A —
+// pass the buffered mailbox and hang on a real node; here they time out after EMU_RCCL_STRICT_SECONDS (20) with a message.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #undef dlopen
@@ -30,10 +34,18 @@
 #include <vector>
 
 namespace {
+struct Active {  // strict mode: an operation of a group that is executing right now
+  int src, dst;
+  bool send;
+  void* p;
+  size_t n;
+  bool done = false, mismatch = false;
+};
 struct Group {
   int n = 0;
   std::mutex mu;
   std::condition_variable cv;
+  std::deque<std::shared_ptr<Active>> active;  // strict mode, in posting order
   std::map<std::pair<int, int>, std::deque<std::vector<unsigned char>>> box;  // (src, dst) -> messages in order
   int joined = 0;
 };
@@ -80,8 +92,61 @@ ncclResult_t run_files(const std::vector<Op>& ops) {
     }
   return ncclSuccess;
 }
+// strict mode: post every operation of the group, pair my receives with the peers' posted sends (in order per peer) and wait
+// until all of mine — sends included — have been paired; nothing outlives the call
+ncclResult_t run_strict(const std::vector<Op>& ops) {
+  if (ops.empty()) return ncclSuccess;
+  Group& g = *ops[0].c->g;
+  const int me = ops[0].c->rank;
+  const char* se = std::getenv("EMU_RCCL_STRICT_SECONDS");
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(se ? std::atoi(se) : 20);
+  std::vector<std::shared_ptr<Active>> mine;
+  std::unique_lock<std::mutex> lk(g.mu);
+  for (const Op& o : ops) {
+    auto a = std::make_shared<Active>();
+    a->src = o.send ? me : o.peer;
+    a->dst = o.send ? o.peer : me;
+    a->send = o.send;
+    a->p = o.p;
+    a->n = o.n;
+    g.active.push_back(a);
+    mine.push_back(a);
+  }
+  g.cv.notify_all();
+  ncclResult_t res = ncclSuccess;
+  for (;;) {
+    for (auto& r : mine) {
+      if (r->send || r->done) continue;
+      for (auto& sdr : g.active)  // the earliest send of that peer to me that nobody has taken
+        if (sdr->send && !sdr->done && sdr->src == r->src && sdr->dst == me) {
+          if (sdr->n != r->n) r->mismatch = sdr->mismatch = true;
+          else std::memcpy(r->p, sdr->p, r->n);
+          r->done = sdr->done = true;
+          break;
+        }
+    }
+    g.cv.notify_all();
+    bool all = true;
+    for (auto& a : mine) all = all && a->done;
+    if (all) break;
+    if (g.cv.wait_until(lk, deadline) == std::cv_status::timeout) {
+      t_err = "emulated RCCL (strict): rank " + std::to_string(me) + " waited for a peer that never posted the matching operation in a "
+              "group executing at the same time — on a real node this exchange hangs (mismatched group order between ranks?)";
+      res = ncclInternalError;
+      break;
+    }
+  }
+  for (auto& a : mine) {
+    if (a->mismatch && res == ncclSuccess) { t_err = "emulated ncclRecv: size mismatch between send and receive"; res = ncclInvalidArgument; }
+    for (auto it = g.active.begin(); it != g.active.end(); ++it)
+      if (it->get() == a.get()) { g.active.erase(it); break; }
+  }
+  return res;
+}
 ncclResult_t run(const std::vector<Op>& ops) {
   if (!ops.empty() && !ops[0].c->dir.empty()) return run_files(ops);
+  static const bool strict = [] { const char* e = std::getenv("EMU_RCCL_STRICT"); return e && e[0] == '1'; }();
+  if (strict) return run_strict(ops);
   for (const Op& o : ops)
     if (o.send) {
       Group& g = *o.c->g;
