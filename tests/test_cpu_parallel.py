@@ -67,11 +67,11 @@ def test_sharded_program_writes_what_the_reference_program_writes(tmp_path, emu_
 
 
 def test_rccl_stand_in_strict_mode_detects_mismatched_group_order(tmp_path):
-    """tests/aux/rccl_strict_probe.cpp: two ranks that each send in one group and receive in the next pass the buffered mailbox —
+    """tests/probes/rccl_strict_probe.cpp: two ranks that each send in one group and receive in the next pass the buffered mailbox —
     and hang on real RCCL; the strict mode reports them. Send and receive in one group pass both."""
     exe = str(tmp_path / "probe")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "tools", "hip_wave_shim"),
-                           os.path.join(ROOT, "tests", "aux", "rccl_strict_probe.cpp"),
+                           os.path.join(ROOT, "tests", "probes", "rccl_strict_probe.cpp"),
                            os.path.join(ROOT, "tools", "hip_wave_shim", "rccl_emu.cpp"), "-o", exe])
     env = {k: v for k, v in os.environ.items() if not k.startswith("EMU_RCCL")}
     strict = dict(env, EMU_RCCL_STRICT="1", EMU_RCCL_STRICT_SECONDS="1")
