@@ -84,7 +84,7 @@ def test_rccl_stand_in_strict_mode_detects_mismatched_group_order(tmp_path):
 @pytest.mark.parametrize("world", [3])  # (world 2 as processes: test_bench_script_two_ranks_dry_run below)
 def test_sharded_frame_across_processes_gloo(tmp_path, emu_programs, world):
     port = 29500 + os.getpid() % 2000 + world
-    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), OMP_NUM_THREADS="1")
+    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), EMU_RCCL_STRICT="1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "mp_sharded_frame.py")], capture_output=True, text=True, env=env, timeout=900)
@@ -97,7 +97,7 @@ def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
     RCCL stand-in between the two processes): one JSON line from rank 0 with n_gpus 2, every timed frame checked, and the
     sharded single frame (pairs + pole units over both ranks, the two native exchanges) equal to the unsharded one."""
     port = 31500 + os.getpid() % 2000
-    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), EMU_DEVICES="2", S360_TEST_EMULATED_LIB="1", S360_BENCH_BACKEND="gloo",
+    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), EMU_RCCL_STRICT="1", EMU_DEVICES="2", S360_TEST_EMULATED_LIB="1", S360_BENCH_BACKEND="gloo",
                S360_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",

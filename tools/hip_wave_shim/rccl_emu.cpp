@@ -7,7 +7,7 @@
 // With EMU_RCCL_DIR set, communicators made by ncclCommInitRank use files in that directory as the mailbox instead
 // (message k from src to dst = <dir>/<id>_<src>_<dst>_<k>, written under a temporary name and renamed), so that the ranks
 // can be separate PROCESSES — one per rank under torch.distributed.run, as on a real node.
-// EMU_RCCL_STRICT=1 (in-process transport): nothing is buffered. A send completes only against a receive that its peer has
+// EMU_RCCL_STRICT=1 (both transports): nothing is buffered. A send completes only against a receive that its peer has
 // posted in the group it is executing AT THE SAME TIME (a rendezvous, like RCCL's point-to-point kernels, which run on both
 // sides at once): ranks whose groups are ordered differently — A: {send to B} then {recv from B}, B the same towards A —
 // pass the buffered mailbox and hang on a real node; here they time out after EMU_RCCL_STRICT_SECONDS (20) with a message.
@@ -68,7 +68,39 @@ thread_local std::string t_err;
 std::string msg_path(const ncclComm* c, int src, int dst, unsigned k) {
   return c->dir + "/" + c->id + "_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(k);
 }
+bool strict_mode() {
+  static const bool on = [] { const char* e = std::getenv("EMU_RCCL_STRICT"); return e && e[0] == '1'; }();
+  return on;
+}
+int strict_seconds() {
+  const char* se = std::getenv("EMU_RCCL_STRICT_SECONDS");
+  return se ? std::atoi(se) : 20;
+}
 ncclResult_t run_files(const std::vector<Op>& ops) {
+  if (strict_mode()) {
+    // rendezvous through files: every receive of the group first announces itself (<message>.rdy); a send writes its message
+    // only once the receive it pairs with has been announced — i.e. while the peer is inside a group that holds it
+    std::map<std::pair<const ncclComm*, int>, unsigned> nrecv, nsend;  // operations of THIS group per (communicator, peer) so far
+    for (const Op& o : ops)
+      if (!o.send) {
+        const std::string rdy = msg_path(o.c, o.peer, o.c->rank, o.c->got[o.peer] + nrecv[{o.c, o.peer}]++) + ".rdy";
+        FILE* f = std::fopen(rdy.c_str(), "wb");
+        if (f) std::fclose(f);
+      }
+    for (const Op& o : ops)
+      if (o.send) {
+        const std::string rdy = msg_path(o.c, o.c->rank, o.peer, o.c->sent[o.peer] + nsend[{o.c, o.peer}]++) + ".rdy";
+        bool seen = false;
+        for (int tries = 0; tries < strict_seconds() * 1000 && !(seen = access(rdy.c_str(), F_OK) == 0); ++tries)
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (!seen) {
+          t_err = "emulated RCCL (strict): rank " + std::to_string(o.c->rank) + " sends to rank " + std::to_string(o.peer) +
+                  ", which posts no matching receive in a group executing at the same time — on a real node this exchange hangs";
+          return ncclInternalError;
+        }
+        std::remove(rdy.c_str());
+      }
+  }
   for (const Op& o : ops)
     if (o.send) {
       const std::string path = msg_path(o.c, o.c->rank, o.peer, o.c->sent[o.peer]++), tmp = path + ".part";
@@ -98,8 +130,7 @@ ncclResult_t run_strict(const std::vector<Op>& ops) {
   if (ops.empty()) return ncclSuccess;
   Group& g = *ops[0].c->g;
   const int me = ops[0].c->rank;
-  const char* se = std::getenv("EMU_RCCL_STRICT_SECONDS");
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(se ? std::atoi(se) : 20);
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(strict_seconds());
   std::vector<std::shared_ptr<Active>> mine;
   std::unique_lock<std::mutex> lk(g.mu);
   for (const Op& o : ops) {
@@ -145,8 +176,7 @@ ncclResult_t run_strict(const std::vector<Op>& ops) {
 }
 ncclResult_t run(const std::vector<Op>& ops) {
   if (!ops.empty() && !ops[0].c->dir.empty()) return run_files(ops);
-  static const bool strict = [] { const char* e = std::getenv("EMU_RCCL_STRICT"); return e && e[0] == '1'; }();
-  if (strict) return run_strict(ops);
+  if (strict_mode()) return run_strict(ops);
   for (const Op& o : ops)
     if (o.send) {
       Group& g = *o.c->g;
