@@ -407,7 +407,7 @@ int orc_isp_run(const IspConfig* cfg, const uint16_t* raw, int w, int h, void* o
     return -1;
   }
 }
-// the accelerated ISP's arithmetic (isp_pipe.h; CameraIspGen.cpp restated, parity unpinned). fast: CameraIspGenFast
+// the accelerated ISP's arithmetic (isp_pipe.h; CameraIspGen.cpp restated and pinned to that generator executed, oracle/_ref/libref_isppipe.so). fast: CameraIspGenFast
 int orc_isp_pipe_run(const IspConfig* cfg, int fast, const uint16_t* raw, int w, int h, void* out, char* err, int err_cap) {
   try {
     ispPipeRun(*cfg, fast != 0, raw, w, h, out);

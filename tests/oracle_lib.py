@@ -479,7 +479,7 @@ def isp_run(cfg, raw):
 
 
 def isp_pipe_run(cfg, raw, fast=False):
-    """oracle restatement of the accelerated ISP (oracle/isp_pipe.h: CameraIspGen.cpp, parity unpinned): raw -> H x W x 3 BGR.
+    """oracle restatement of the accelerated ISP (oracle/isp_pipe.h: CameraIspGen.cpp; pinned to the generator executed — ref_isp_pipe_run below): raw -> H x W x 3 BGR.
     cfg.resize / cfg.demosaicFilter play no part."""
     raw = np.ascontiguousarray(raw, np.uint16)
     assert lib().orc_isp_config_size() == C.sizeof(IspConfigC)
@@ -512,6 +512,29 @@ def ref_isp_run(json_text, raw, output_bpp=8, demosaic_filter=2, resize=1, disab
     return out
 
 
+def ref_isp_pipe_lib():
+    """oracle/_ref/libref_isppipe.so — the reference's Halide generator camera_isp/CameraIspGen.cpp EXECUTED over
+    oracle/ref_shim/halide_eval (a lazy evaluator of the Halide front end), under its CameraIspPipe.h (oracle/ref_ispgen.cpp,
+    ref_isppipe.cpp)."""
+    return ref_lib("isppipe")
+
+
+def ref_isp_pipe_run(json_text, raw, output_bpp=8, fast=False, disable_tone_curve=0, black_level_offset=0, unpacker=False,
+                     bits_per_pixel=16):
+    """The accelerated ISP as the reference's programs run it: Raw2Rgb --accelerate [--fast] (Raw2Rgb.cpp:427-440), or with
+    unpacker=True Unpacker's call sequence (Unpacker.cpp:176-183: 16-bit output, full pipeline, tone map on). raw -> H x W x 3 BGR."""
+    raw = np.ascontiguousarray(raw, np.uint16)
+    h, w = raw.shape
+    if unpacker:
+        output_bpp, fast = 16, False
+    out = np.zeros((h, w, 3), np.uint8 if output_bpp == 8 else np.uint16)
+    err = C.create_string_buffer(512)
+    if ref_isp_pipe_lib().ref_isp_pipe_run(int(bool(unpacker)), json_text.encode(), _p(raw), w, h, output_bpp, int(bool(fast)),
+                                           disable_tone_curve, black_level_offset, bits_per_pixel, _p(out), err, 512) != 0:
+        raise RuntimeError(err.value.decode())
+    return out
+
+
 def isp_packed_bytes(bits, w, h):
     return w * h if bits == 8 else h * (3 * w // 2)
 
@@ -536,7 +559,7 @@ _REF_LIBS = {}
 
 
 def ref_lib(name):
-    """oracle/_ref/libref_<name>.so ("isp", "pixflow", "render") or None."""
+    """oracle/_ref/libref_<name>.so ("isp", "isppipe", "pixflow", "render") or None."""
     so = os.path.join(ORACLE_DIR, "_ref", "libref_%s.so" % name)
     if name not in _REF_LIBS:
         if os.path.isdir("/root/reference/surround360_render/source/optical_flow"):

@@ -1,7 +1,10 @@
-"""Soft ISP: the oracle restatement (oracle/isp.h) against the reference's own CameraIsp.h
+"""The ISP. Soft ISP: the oracle restatement (oracle/isp.h) against the reference's own CameraIsp.h
 compiled from /root/reference over a container-only OpenCV stand-in (oracle/_ref/libref_isp.so), and against the
-committed outputs of that library (tests/golden/isp_golden.npz). This is the one part of the oracle that is PINNED:
-every ISP arithmetic operation checked here is the reference's source, executed."""
+committed outputs of that library (tests/golden/isp_golden.npz): every ISP arithmetic operation checked there is the
+reference's source, executed. Accelerated ISP (round 5): the oracle restatement (oracle/isp_pipe.h) against the reference's
+Halide GENERATOR, camera_isp/CameraIspGen.cpp, executed as it lies over a lazy evaluator of the Halide front end
+(oracle/ref_shim/halide_eval/Halide.h) under the reference's own CameraIspPipe.h (oracle/_ref/libref_isppipe.so), and against
+that library's committed outputs (tests/golden/isp_pipe_golden.npz)."""
 import os
 
 import numpy as np
@@ -66,6 +69,81 @@ def test_shipped_configurations(ref, cfg):
     for bpp in (8, 16):
         got = ref.isp_run(ref.isp_config_from_json(js, bpp), raw)
         assert np.array_equal(got, ref.ref_isp_run(js, raw, bpp)), (cfg, bpp)
+
+
+# ---- the accelerated ISP: oracle/isp_pipe.h against the executed generator ------------------------------------------------------------
+PIPE_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "isp_pipe_golden.npz")
+PIPE_CASES = [  # (config, w, h, bpp, fast, disable_tone_curve, black_level_offset, unpacker); the first eleven = tests/test_gpu_isp.py's
+    ("full", 128, 96, 16, 0, 0, 0, 0), ("full", 130, 70, 8, 0, 0, 0, 0), ("full", 96, 64, 16, 1, 0, 0, 0), ("full", 200, 136, 8, 1, 0, 25, 0),
+    ("empty", 61, 47, 16, 0, 1, 3, 0), ("minimal", 70, 50, 8, 0, 0, 0, 0), ("grbg", 100, 84, 16, 0, 0, 0, 0), ("grbg", 64, 64, 16, 1, 0, 0, 0),
+    ("full", 640, 480, 16, 0, 0, 0, 0), ("empty", 333, 257, 8, 0, 0, 0, 0),
+    ("full", 128, 96, 8, 0, 1, 40, 0), ("minimal", 71, 51, 16, 1, 0, 0, 0), ("empty", 64, 64, 8, 1, 1, 0, 0), ("grbg", 33, 17, 8, 0, 0, 7, 0),
+    ("full", 128, 96, 16, 0, 0, 0, 1), ("minimal", 70, 50, 16, 0, 0, 0, 1),  # Unpacker's call sequence (16 bits, full pipeline)
+]
+
+
+def _pipe_id(c):
+    return "%s-%dx%d-bpp%d-fast%d-t%d-o%d-u%d" % c
+
+
+def _pipe_raw(case):
+    name, w, h = case[:3]
+    return isputil.bayer_frame(w, h, seed=w + 5 * h, pattern="RGGB" if name == "full" else "GBRG")  # (as tests/test_gpu_isp.py)
+
+
+@pytest.fixture(scope="module")
+def refpipe(oracle):
+    if oracle.ref_isp_pipe_lib() is None:
+        pytest.skip("oracle/_ref/libref_isppipe.so not built (needs /root/reference)")
+    return oracle
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=_pipe_id)
+def test_pipe_restatement_equals_executed_generator(refpipe, case):
+    """oracle/isp_pipe.h == CameraIspGen.cpp executed under CameraIspPipe.h, bit for bit: 8 / 16 bits x full / fast, both patterns the
+    pipeline knows (and two it runs as GBRG), odd sizes, tone curve off, black-level offsets, Raw2Rgb's and Unpacker's call order."""
+    name, w, h, bpp, fast, tone, off, unp = case
+    js, raw = isputil.CONFIGS[name], _pipe_raw(case)
+    got = refpipe.isp_pipe_run(refpipe.isp_config_from_json(js, bpp, 2, 1, tone, off), raw, fast=bool(fast))
+    want = refpipe.ref_isp_pipe_run(js, raw, bpp, bool(fast), tone, off, unpacker=bool(unp))
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want), "%d of %d samples differ" % ((got != want).sum(), got.size)
+    assert want.std() > 3
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=_pipe_id)
+def test_pipe_restatement_equals_golden(oracle, case):
+    """The same where /root/reference is absent: the executed generator's outputs, committed by tests/golden/make_isp_pipe_golden.py."""
+    name, w, h, bpp, fast, tone, off, unp = case
+    g = np.load(PIPE_GOLDEN)
+    got = oracle.isp_pipe_run(oracle.isp_config_from_json(isputil.CONFIGS[name], bpp, 2, 1, tone, off), _pipe_raw(case), fast=bool(fast))
+    assert np.array_equal(got, g[_pipe_id(case)])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIG_DIR), reason="reference checkout not present")
+@pytest.mark.parametrize("cfg", ["cmosis_fujinon.json", "cmosis_sunex.json", "passthrough.json"])
+def test_pipe_shipped_configurations(refpipe, cfg):
+    js = open(os.path.join(REF_CONFIG_DIR, cfg)).read()
+    raw = isputil.bayer_frame(192, 144, seed=5)
+    for bpp, fast in ((8, 0), (16, 0), (16, 1)):
+        got = refpipe.isp_pipe_run(refpipe.isp_config_from_json(js, bpp), raw, fast=bool(fast))
+        assert np.array_equal(got, refpipe.ref_isp_pipe_run(js, raw, bpp, bool(fast))), (cfg, bpp, fast)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIG_DIR), reason="reference checkout not present")
+def test_pipe_comparison_resolves_a_rounding_choice(refpipe):
+    """The comparison above is sharp enough to see ONE rounding decision: the evaluator run with a constant float division kept as a
+    division (the one reading of Halide this repo takes from memory: its simplifier turns x / 5.0f into x * 0.2f) no longer equals
+    the restatement — in a handful of samples, by one count of the tone table's input."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import oracle_lib as O, isputil, test_cpu_isp as T\n"
+            "case = T.PIPE_CASES[0]; js = isputil.CONFIGS[case[0]]; raw = T._pipe_raw(case)\n"
+            "a = O.ref_isp_pipe_run(js, raw, 16, False); b = O.isp_pipe_run(O.isp_config_from_json(js, 16), raw)\n"
+            "print(int((a != b).sum()), a.size)" % os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HALIDE_EVAL_TRUE_DIVISION="1")
+    n, size = map(int, subprocess.check_output([sys.executable, "-c", code], env=env).split())
+    assert 0 < n < size // 20, (n, size)
 
 
 # (radius, threshold, darkness threshold, does the reference's pass change pixels?)

@@ -1,5 +1,7 @@
 """Soft ISP on the GPU (s360_isp_*; isp_kernels.hip) against the oracle restatement (oracle/isp.h), which is pinned to
 the reference's own CameraIsp.h (tests/test_cpu_isp.py). Bit-exact: 8- and 16-bit outputs compare as integers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -46,10 +48,11 @@ PIPE_CASES = [  # (config, w, h, bpp, fast, disable_tone_curve, black_level_offs
 @pytest.mark.parametrize("case", PIPE_CASES, ids=lambda c: "%s-%dx%d-bpp%d-fast%d-t%d-o%d" % c)
 def test_accelerated_pipeline_equals_its_oracle(oracle, s360lib, case):
     """s360_isp_config.pipe = 1 / 2: the arithmetic of the reference's CameraIspPipe (the Halide pipeline of CameraIspGen.cpp —
-    Unpacker, Raw2Rgb --accelerate) against its CPU restatement, oracle/isp_pipe.h. PARITY UNPINNED: both follow the generator's
-    source, neither can be checked against a Halide build here; this test holds the HIP kernels to the restatement bit for bit
-    (two separately written evaluations: the oracle recurses through the generator's functions at virtual coordinates, the
-    kernels stage extended planes)."""
+    Unpacker, Raw2Rgb --accelerate) against its CPU restatement, oracle/isp_pipe.h, and — where the case is among the committed
+    ones — against the outputs of the reference's generator itself, executed over a Halide front-end evaluator in the build
+    container (tests/golden/isp_pipe_golden.npz; tests/test_cpu_isp.py holds the restatement to the same executed generator). Two
+    separately written evaluations meet here: the oracle recurses through the generator's functions at virtual coordinates, the
+    kernels stage extended planes."""
     from surround360_amd import isp as I
     name, w, h, bpp, fast, tone, off = case
     js = isputil.CONFIGS[name]
@@ -67,6 +70,11 @@ def test_accelerated_pipeline_equals_its_oracle(oracle, s360lib, case):
         bad = np.argwhere(d != 0)
         raise AssertionError("%d of %d samples differ, max |d| %d, first at %s" % (len(bad), d.size, np.abs(d).max(), bad[0].tolist()))
     assert np.array_equal(again, got)
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "isp_pipe_golden.npz"))
+    key = "%s-%dx%d-bpp%d-fast%d-t%d-o%d-u0" % case
+    assert key in golden or (w, h) == (2048, 2048)
+    if key in golden:
+        assert np.array_equal(got, golden[key]), "differs from the executed generator's output"
 
 
 def test_generated_functions_entry_point(oracle, s360lib):
