@@ -63,6 +63,9 @@ struct Flags {
          // first one's --prev_frame_data_dir), in one process. One stream cannot use more than one GPU: its pole flows
          // are one serial chain per frame and every frame needs its predecessor's flows
          {"num_streams", "1"},
+         // ... on at most this many GPUs (0 = all there are). Streams that share a GPU are rendered as the FRAME SLOTS of one
+         // context: frame k of all of them in one launch sequence, every stream's temporal state resident in its slot
+         {"stream_gpus", "0"},
          // --bin_list a.bin,b.bin --isp_dir D: the cameras' frames come straight from the capture's .bin containers through the
          // ISP on the device ("the ISP feeding the GPU directly from .bin") instead of imgs_dir/<cam>/<frame>.png:
          // what `Unpacker --bin_list .. --isp_dir D --output_dir imgs_dir` followed by this program writes, with no file in
@@ -517,9 +520,8 @@ static void open_bins(Job& J) {
   if (J.prm.enable_bottom) want(J.bi);
 }
 
-// One job = what one invocation of the reference's program does, or (--num_frames) one stream of consecutive frames.
-static int run_job(const Flags& flags) {
-  Job J;
+// Flags -> rig, parameters, required arguments (TRSP:717-721): common to a job and to a batch of streams
+static void init_job(Job& J, const Flags& flags) {
   J.F = flags;
   Flags& F = J.F;
   require_arg(F.s("rig_json_file"), "rig_json_file");  // TRSP:717-721
@@ -528,8 +530,6 @@ static int run_job(const Flags& flags) {
   require_arg(F.s("frame_number"), "frame_number");
   require_arg(F.s("output_data_dir"), "output_data_dir");
   require_arg(F.s("output_equirect_path"), "output_equirect_path");
-  const int verbose = F.i("v");
-  const double startTime = now_sec();
 
   J.cams.resize(64);
   J.ncams = s360_rig_load_json(F.s("rig_json_file").c_str(), J.cams.data(), (int)J.cams.size());
@@ -560,6 +560,16 @@ static int run_job(const Flags& flags) {
   if (prm.enable_top && (J.ti = s360_rig_find_top(J.cams.data(), J.ncams)) < 0) die("no top camera in the rig");
   if (prm.enable_bottom && (J.bi = s360_rig_find_bottom(J.cams.data(), J.ncams)) < 0) die("no bottom camera in the rig");
   if (prm.enable_pole_removal) J.b2 = s360_rig_find_bottom2(J.cams.data(), J.ncams);
+}
+
+// One job = what one invocation of the reference's program does, or (--num_frames) one stream of consecutive frames.
+static int run_job(const Flags& flags) {
+  Job J;
+  const double startTime = now_sec();
+  init_job(J, flags);
+  Flags& F = J.F;
+  s360_params& prm = J.prm;
+  const int verbose = F.i("v");
 
   // ---- GPUs: --num_gpus G uses devices device .. device+G-1 (never more GPUs than pairs)
   const int G = std::max(1, std::min(F.i("num_gpus"), J.P));
@@ -723,6 +733,130 @@ static int run_job(const Flags& flags) {
   return 0;
 }
 
+// --num_streams with more streams than GPUs: the streams that share a GPU are the FRAME SLOTS of one context there. Step k renders
+// frame k of every stream that still has one as ONE launch sequence (s360_frame_render_slots): per-frame kernels slot by slot, the
+// 28 side flows of every stream in one batch of the flow kernels, the 4 pole flows of every stream in another — each frame
+// regularised toward its own stream's device-resident previous flows and images (TRSP:215-235, 421-436; PixFlow.h:101-118,
+// 185-193). A single stream is bound by the latency of its pole flows' serial chain; S of them in one
+// launch sequence share that chain's time. Every stream writes, file for file, what an invocation of its own with that segment's
+// --frame_number / --num_frames writes: its equirects, and the state files behind its last frame.
+// While step k renders, step k+1's images are decoded (one task per stream, one thread per camera inside it) and uploaded, and
+// step k-1's equirects are PNG-encoded.
+struct Segment { std::string first; int n = 0; std::string prev = "NONE"; };
+static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs, int device) {
+  Job J;
+  const double startTime = now_sec();
+  init_job(J, flags);
+  Flags& F = J.F;
+  const int verbose = F.i("v");
+  if (!F.s("bin_list").empty()) die("--bin_list is not available with several streams per GPU");
+  if (F.i("cubemap_width") > 0 && F.i("cubemap_height") > 0 && !F.s("output_cubemap_path").empty())
+    die("--output_cubemap_path is not available with --num_streams");
+  const int S = (int)segs.size();
+  J.ctx.assign(1, nullptr);
+  if (s360_create(&J.ctx[0], device, J.cams.data(), J.ncams, &J.prm) < 0) die(s360_last_error(nullptr));
+  s360_ctx* ctx = J.ctx[0];
+  ck(s360_get_geometry(ctx, &J.g), ctx);
+  J.extW = int(float(J.prm.eqr_width) * 1.2f);
+  J.bounds = {0, J.P};
+  assign_pole_units(J);
+  ck(s360_set_frame_slots(ctx, S), ctx);
+  ck(s360_set_sweep_mode(ctx, "throughput"), ctx);  // many flows per launch: the kernel with the fewest instructions per pixel
+  const s360_geometry& g = J.g;
+  const size_t outBytes = (size_t)g.out_width * g.out_height * 3;
+
+  int steps = 0;
+  for (const Segment& sg : segs) steps = std::max(steps, sg.n);
+  std::vector<std::string> name(S);  // the frame stream s renders in the current step
+  for (int s = 0; s < S; ++s) name[s] = segs[s].first;
+  std::vector<FrameInputs> cur(S), spare(S);
+  std::vector<std::future<FrameInputs>> decoding(S);
+  auto start_decode = [&](int k) {  // step k's frames
+    for (int s = 0; s < S; ++s)
+      if (k < segs[s].n) {
+        auto recycled = std::make_shared<FrameInputs>(std::move(spare[s]));
+        std::string nm = segs[s].first;
+        for (int i = 0; i < k; ++i) nm = next_frame_name(nm);
+        decoding[s] = std::async(std::launch::async, [&J, nm, recycled] { return load_frame(J, nm, std::move(*recycled)); });
+      }
+  };
+  auto upload_step = [&](int k, std::vector<FrameInputs>& into) {
+    for (int s = 0; s < S; ++s)
+      if (k < segs[s].n) {
+        into[s] = decoding[s].get();
+        ck(s360_select_frame_slot(ctx, s), ctx);
+        upload_frame(J, into[s]);
+      }
+  };
+  auto render_step = [&](int k) {
+    std::vector<int> resumed, rest;
+    for (int s = 0; s < S; ++s)
+      if (k < segs[s].n) (k == 0 && segs[s].prev != "NONE" ? resumed : rest).push_back(s);
+    for (int s : resumed) {  // a stream whose first frame resumes from state files: that slot alone, with its state
+      ck(s360_select_frame_slot(ctx, s), ctx);
+      load_prev_state(J, segs[s].prev);
+      ck(s360_frame_render_slots(ctx, &s, 1, 1), ctx);
+    }
+    if (!rest.empty()) ck(s360_frame_render_slots(ctx, rest.data(), (int)rest.size(), k > 0 ? 1 : 0), ctx);
+  };
+  std::vector<pngio::Pixels> outBuf(S);
+  for (auto& b : outBuf) b.resize(outBytes);
+  std::vector<std::thread> encoder(S);
+  double tGpuWait = 0, tEncWait = 0, tDecWait = 0;
+  start_decode(0);
+  std::vector<FrameInputs> next(S);
+  upload_step(0, cur);
+  render_step(0);
+  start_decode(1);
+  for (int k = 0; k < steps; ++k) {
+    // step k+1's images go to the device while step k renders (the uploads wait, on their own stream, for step k's projections)
+    double t0 = now_sec();
+    if (k + 1 < steps) upload_step(k + 1, next);
+    double t1 = now_sec();
+    tDecWait += t1 - t0;
+    for (auto& e : encoder)
+      if (e.joinable()) e.join();  // step k-1's files are written: their buffers take step k's frames
+    double t2 = now_sec();
+    tEncWait += t2 - t1;
+    for (int s = 0; s < S; ++s)
+      if (k < segs[s].n) {
+        ck(s360_select_frame_slot(ctx, s), ctx);
+        ck(s360_frame_download_equirect(ctx, outBuf[s].data()), ctx);  // (the first one waits for the step)
+        if (F.b("write_state") && k + 1 == segs[s].n) write_state(J, name[s]);
+      }
+    tGpuWait += now_sec() - t2;
+    if (k + 1 < steps) {
+      ck(s360_frame_uploads_complete(ctx), ctx);
+      render_step(k + 1);
+    }
+    for (int s = 0; s < S; ++s)
+      if (k < segs[s].n) {
+        const std::string outPath = frame_path(F.s("output_equirect_path"), name[s]);
+        const uint8_t* px = outBuf[s].data();
+        encoder[s] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });
+        name[s] = next_frame_name(name[s]);
+        spare[s] = std::move(cur[s]);  // its uploads have run (s360_frame_uploads_complete above, or the step is over)
+      }
+    std::swap(cur, next);
+    if (k + 2 < steps) start_decode(k + 2);
+  }
+  for (auto& e : encoder)
+    if (e.joinable()) e.join();
+  const double endTime = now_sec();
+  if (verbose >= 1) {
+    int frames = 0;
+    for (const Segment& sg : segs) frames += sg.n;
+    std::fprintf(stderr, "--- Runtime breakdown (sec) ---\n");
+    std::fprintf(stderr, "%d streams as frame slots of one context, %d steps, %d frames: %.3f  (%.3f per frame)\n", S, steps, frames,
+                 endTime - startTime, (endTime - startTime) / frames);
+    std::fprintf(stderr, "host thread per step:    decode + upload %.3f  wait for the encoders %.3f  wait for the GPU + fetch %.3f\n",
+                 tDecWait / steps, tEncWait / steps, tGpuWait / steps);
+    std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
+  }
+  s360_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   // glibc: keep freed blocks of up to 32 MB (decoded camera images, PNG scanline bands) in the heap instead of handing
   // every one back to the kernel — a stream's decoder and encoder threads would spend their time in page faults
@@ -750,18 +884,35 @@ int main(int argc, char** argv) {
   require_arg(F.s("frame_number"), "frame_number");
   const int devices = s360_device_count();
   if (devices < 1) die("no HIP device");
-  std::vector<std::thread> th;
+  // stream s = the s-th contiguous segment; streams go round the GPUs (--stream_gpus limits them); a GPU with one stream runs it
+  // as a job (frame pipelining inside the stream), a GPU with several runs them as the frame slots of one context
+  const int useDev = std::max(1, std::min(devices, F.i("stream_gpus") > 0 ? F.i("stream_gpus") : devices));
+  std::vector<std::vector<Segment>> perDev(useDev);
   std::string first = F.s("frame_number");
   for (int s = 0; s < streams; ++s) {
-    const int n = frames / streams + (s < frames % streams ? 1 : 0);
-    Flags Fs = F;
-    Fs.v["num_streams"] = "1";
-    Fs.v["frame_number"] = first;
-    Fs.v["num_frames"] = std::to_string(n);
-    Fs.v["device"] = std::to_string((F.i("device") + s) % devices);
-    if (s > 0) Fs.v["prev_frame_data_dir"] = "NONE";
-    th.emplace_back([Fs] { run_job(Fs); });  // (errors abort the process, like the reference's)
-    for (int k = 0; k < n; ++k) first = next_frame_name(first);
+    Segment sg;
+    sg.first = first;
+    sg.n = frames / streams + (s < frames % streams ? 1 : 0);
+    sg.prev = s == 0 ? F.s("prev_frame_data_dir") : "NONE";
+    perDev[s % useDev].push_back(sg);
+    for (int k = 0; k < sg.n; ++k) first = next_frame_name(first);
+  }
+  const int perEncoder = std::max(1, (int)perDev[0].size());  // encoders running at once per GPU
+  if (perEncoder > 1) g_png_threads = std::max(1, pngio::available_cpus() / std::min(perEncoder * useDev, 8));
+  std::vector<std::thread> th;
+  for (int d = 0; d < useDev; ++d) {
+    const int dev = (F.i("device") + d) % devices;
+    if (perDev[d].size() == 1) {
+      Flags Fs = F;
+      Fs.v["num_streams"] = "1";
+      Fs.v["frame_number"] = perDev[d][0].first;
+      Fs.v["num_frames"] = std::to_string(perDev[d][0].n);
+      Fs.v["device"] = std::to_string(dev);
+      Fs.v["prev_frame_data_dir"] = perDev[d][0].prev;
+      th.emplace_back([Fs] { run_job(Fs); });  // (errors abort the process, like the reference's)
+    } else if (!perDev[d].empty()) {
+      th.emplace_back([&F, &perDev, d, dev] { run_stream_batch(F, perDev[d], dev); });
+    }
   }
   for (auto& t : th) t.join();
   return 0;

@@ -261,10 +261,15 @@ int s360_frame_set_prev_pole_removal(s360_ctx* ctx, const float* flow, const uin
  * s360_frame_render_batch renders all of them: per-frame kernels slot by slot, the side flows of every slot in one
  * batch of the flow kernels (n x 28 flows per launch), the pole flows of every slot in another (n x 4). Every slot's
  * result equals s360_frame_render on it. use_prev applies each slot's own device-resident temporal state (a batch
- * uses it only if every slot has one). */
+ * uses it only if every slot has one). s360_frame_render_slots is the same for a subset of the slots (ascending, distinct): the
+ * streams of a job that still have a frame to render when the others have ended, or the one stream whose first frame resumes from
+ * state files while the others start without (host/TestRenderStereoPanorama --num_streams on one GPU: the reference's
+ * batch_process_video.py workload, frame k of every stream regularised toward its frame k-1, TRSP:215-235, 421-436, as ONE launch
+ * sequence per step). */
 int s360_set_frame_slots(s360_ctx* ctx, int n);
 int s360_select_frame_slot(s360_ctx* ctx, int k);
 int s360_frame_render_batch(s360_ctx* ctx, int use_prev);
+int s360_frame_render_slots(s360_ctx* ctx, const int* slots, int n, int use_prev);
 
 /* ---- multi-GPU: one frame sharded by side pairs, ONE RCCL exchange ------------------
  * Replaces the per-pair thread fan-out + join + stackHorizontal of TRSP:320-335, 354-384 when the pairs of a frame are

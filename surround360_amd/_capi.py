@@ -79,7 +79,7 @@ SYMBOLS = [
     "s360_profile_enable", "s360_profile_get", "s360_save_flow_to_file", "s360_read_flow_from_file",
     "s360_comm_get_unique_id", "s360_comm_init_rank", "s360_comm_init_all", "s360_comm_destroy",
     "s360_frame_gather_strips", "s360_frame_exchange_strips", "s360_frame_pole_units", "s360_frame_gather_pole_layers", "s360_frame_composite", "s360_comm_loopback", "s360_frame_set_partition",
-    "s360_frame_download_equirect_of", "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch",
+    "s360_frame_download_equirect_of", "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch", "s360_frame_render_slots",
     "s360_isp_config_defaults", "s360_isp_config_from_json", "s360_isp_create", "s360_isp_destroy", "s360_isp_process",
     "s360_isp_config_tables", "s360_isp_process_packed", "s360_frame_upload_raw", "s360_frame_upload_packed", "s360_isp_pipe_generated",
     "s360_host_alloc", "s360_host_free", "s360_frame_uploads_complete",

@@ -671,6 +671,12 @@ int s360_select_frame_slot(s360_ctx* c, int k) {
 int s360_frame_render_batch(s360_ctx* c, int use_prev) {
   return frame_guard(c, [&] { need(c, "null ctx"); frame_render_batch(c, use_prev); });
 }
+int s360_frame_render_slots(s360_ctx* c, const int* slots, int n, int use_prev) {
+  return frame_guard(c, [&] {
+    need(c && slots && n > 0, "bad argument");
+    frame_render_slots(c, slots, n, use_prev);
+  });
+}
 int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, const float* flow_r_to_l,
                              const uint8_t* overlap_l, const uint8_t* overlap_r) {
   return frame_guard(c, [&] {

@@ -941,6 +941,17 @@ void frame_render_batch(s360_ctx* c, int use_prev) {
   finish_stage(c, ids, 15, use_prev);
 }
 
+void frame_render_slots(s360_ctx* c, const int* slots, int n, int use_prev) {
+  if (c->pipeline) throw Error(S360_ERR_STATE, "frame pipelining and batched slots are separate modes");
+  const int have = (int)std::max<size_t>(c->slots.size(), 1);
+  std::vector<int> ids(slots, slots + n);
+  for (int k = 0; k < n; ++k)
+    if (ids[k] < 0 || ids[k] >= have || (k > 0 && ids[k] <= ids[k - 1]))
+      throw Error(S360_ERR_INVALID_ARG, "frame slots must be distinct, ascending and below the number of slots");
+  side_stage(c, ids, 0, (int)c->rig.side.size(), use_prev);
+  finish_stage(c, ids, 15, use_prev);
+}
+
 // ---- cubemap output (TRSP:917-935) -------------------------------------------------------------------------------
 // Face warp maps of convertSphericalToCubemapBicubicRemap (ImageWarper.cpp:26-128): float arithmetic with the host's
 // acosf / sqrt exactly as the reference evaluates it; depends only on the sizes, so it is built once and cached.

@@ -103,6 +103,7 @@ void frame_composite(s360_ctx* c, int pole_mask);
 // all slots at once: per-frame kernels slot by slot, the side flows of all slots in one FlowEngine batch, the pole
 // flows of all slots in another
 void frame_render_batch(s360_ctx* c, int use_prev);
+void frame_render_slots(s360_ctx* c, const int* slots, int n, int use_prev);  // ... a subset of them (ascending, distinct)
 void set_frame_slots(s360_ctx* c, int n);
 // stereo cubemap of the last finished frame into F.cubeOut; returns its width/height through ow/oh
 void frame_cubemap(s360_ctx* c, int face_w, int face_h, bool video, int* ow, int* oh);

@@ -265,6 +265,11 @@ class Context:
     def render_batch(self, use_prev=False):
         self._ck(lib().s360_frame_render_batch(self.h, int(use_prev)))
 
+    def render_slots(self, slots, use_prev=False):
+        """s360_frame_render_slots: the given frame slots (ascending) as one batch."""
+        arr = (C.c_int * len(slots))(*slots)
+        self._ck(lib().s360_frame_render_slots(self.h, arr, len(slots), int(use_prev)))
+
     def render(self, use_prev=False):
         self._ck(lib().s360_frame_render(self.h, int(use_prev)))
 

@@ -285,18 +285,24 @@ def png_pixels_bgr(path):
     return ((px[..., 0] << 8) | px[..., 1])[..., ::-1]
 
 
-def check_two_streams(exe, tmp_path, env=None):
+def check_two_streams(exe, tmp_path, env=None, more_args=(), streams=2):
     """`exe --num_frames 3 --num_streams 2` against two single invocations with the two segments (frames 7-8, frame 9): every
     equirect and the state files behind each stream's last frame, file for file; the first stream's frames against the
-    reference program's chain. Used on the CPU emulation (two emulated devices) and on the GPU box (both streams on its GPU)."""
+    reference program's chain. Used on the CPU emulation (two emulated devices) and on the GPU box (both streams on its GPU:
+    there, and with --stream_gpus 1 anywhere, the streams are the frame slots of ONE context). streams=3: three streams of one
+    frame each."""
     import rigutil
     rig = rigutil.scaled_rig_json(os.path.join(ROOT, "tests", "golden", "rig_17cam.json"), str(tmp_path / "rig_small.json"),
                                   CAM / 2048.0)
     name = "three_frames_sharpened"
     frames = CASES[name][0]
-    both = run_stream(exe, str(tmp_path / "both"), rig, name, more_args=["--num_streams", "2", "--v", "1"], env=env)
-    one = run_stream(exe, str(tmp_path / "one"), rig, name, first=0, count=2, env=env)
-    two = run_stream(exe, str(tmp_path / "two"), rig, name, first=2, count=1, env=env)
+    both = run_stream(exe, str(tmp_path / "both"), rig, name, more_args=["--num_streams", str(streams), "--v", "1"] + list(more_args), env=env)
+    segments = [(0, 2), (2, 1)] if streams == 2 else [(0, 1), (1, 1), (2, 1)]
+    singles = {}
+    for first, count in segments:
+        out = run_stream(exe, str(tmp_path / ("seg%d" % first)), rig, name, first=first, count=count, env=env)
+        for k in range(first, first + count):
+            singles[frames[k]] = out
 
     def files(root, frame):
         d = {"eqr": _digest_png(os.path.join(root, "eqr_%s.png" % frame))}
@@ -306,11 +312,12 @@ def check_two_streams(exe, tmp_path, env=None):
                     p = os.path.join(folder, fn)
                     d[fn] = _digest_png(p) if fn.endswith(".png") else hashlib.sha256(open(p, "rb").read()).hexdigest()
         return d
-    for f, single in ((frames[0], one), (frames[1], one), (frames[2], two)):
-        a, b = files(both, f), files(single, f)
+    for f in frames:
+        a, b = files(both, f), files(singles[f], f)
         assert a == b, "frame %s: %s" % (f, sorted(k for k in set(a) | set(b) if a.get(k) != b.get(k))[:8])
-    assert len(files(both, frames[1])) > 30 and len(files(both, frames[2])) > 30  # the state behind each stream's last frame
+    for first, count in segments:  # the state behind each stream's last frame
+        assert len(files(both, frames[first + count - 1])) > 30
     # and the first stream's frames are the reference program's chain (frame 9 of the chain has a predecessor, the segment's has not)
     golden = json.load(open(GOLDEN))[name]
-    for f in frames[:2]:
+    for f in frames[:segments[0][1]]:
         assert files(both, f)["eqr"] == golden["eqr_%s" % f], f

@@ -122,3 +122,14 @@ def test_two_streams_on_two_gpus_equal_two_single_runs(tmp_path, emu_programs):
     on device 0 and frame 9 as a stream of its own on device 1 — and writes, file for file, what two separate invocations
     with those frame ranges write: equirects of all three frames, the state files behind the last frame of each stream."""
     refprog.check_two_streams(os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, dict(os.environ, EMU_DEVICES="2"))
+
+
+@pytest.mark.parametrize("streams", [2, 3])
+def test_streams_sharing_a_gpu_are_frame_slots_of_one_context(tmp_path, emu_programs, streams):
+    """host/TestRenderStereoPanorama --num_streams S --stream_gpus 1: the streams are the frame slots of ONE context, frame k of
+    every stream that still has one in one launch sequence (s360_frame_render_slots) with each stream's own device-resident
+    temporal state — the reference's real workload (every preset chains frames, batch_process_video.py:157-158) as a batch. File
+    for file what S separate --num_frames invocations write; 2 streams of unequal length (the second step renders a subset of the
+    slots), 3 streams of one frame."""
+    refprog.check_two_streams(os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, dict(os.environ, EMU_DEVICES="2"),
+                              more_args=["--stream_gpus", "1"], streams=streams)
