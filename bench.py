@@ -278,6 +278,142 @@ FLOW_STENCIL_B_PER_PXLEVEL = {"flow_gradients": 24, "flow_blur15": 16, "flow_med
                               "flow_upscale": 16}
 
 
+def streams_batched(R, rig, flags, device, frames, args, dry, g):
+    """bench.py's `video_streams_batched` leg: 2 contexts x S frame slots, one stream per slot (stream s = the synthetic video
+    entered at another frame, walked forwards and backwards over the distinct frames held), every step a render_batch(use_prev)
+    per context on device-resident temporal state, the step's inputs sent in place from page-locked host memory on the upload
+    stream while the previous step renders. Steady state = the steps behind 4 run-in steps. Then EVERY stream's last frame is
+    byte-compared with the same stream rendered frame by frame in a context of its own (latency sweep kernel, s360_frame_render)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    F = 2
+    run_in, timed = 4, max(2, args.stream_steps)
+    n_steps = run_in + timed
+    free_b, total_b = (0, 0) if dry else torch.cuda.mem_get_info(device)
+    # page-locked ring of distinct frames (read-only: any number of slots may send the same buffers)
+    n_ring = min(len(frames), 4 if dry else 24)
+    ring = []
+    for k in range(n_ring):
+        side, top, bottom = frames[k]
+        ps = [R.pinned_empty(a.shape) for a in side]
+        for d, a in zip(ps, side):
+            np.copyto(d, a)
+        pt, pb = R.pinned_empty(top.shape), R.pinned_empty(bottom.shape)
+        np.copyto(pt, top)
+        np.copyto(pb, bottom)
+        ring.append((ps, pt, pb))
+
+    def frame_of(stream, k):  # stream s enters the video 3 s frames in (the period below is even and not a multiple of 3)
+        m = (k + (3 if n_ring > 8 else 1) * stream) % max(2 * (n_ring - 1), 1)
+        return ring[m if m < n_ring else 2 * (n_ring - 1) - m]
+
+    S = args.stream_slots
+    if S <= 0:  # measured at 8K: 5.7 GB per slot + 2.6 GB for the second halves of its temporal double buffers, 6 GB per context
+        S = 2 if dry else max(1, int((0.90 * total_b / 1e9 / F - 6.5) / 8.4))
+    rec = {}
+    for attempt in range(4):
+        ctxs = []
+        try:
+            ctxs = [R.Context(rig, R.make_params(**flags), device=device) for _ in range(F)]
+            for c in ctxs:
+                c.set_frame_slots(S)
+                c.set_sweep_mode("throughput")
+
+            def step(ci, k):
+                c = ctxs[ci]
+                for j in range(S):
+                    c.select_frame_slot(j)
+                    c.upload_frame(*frame_of(ci * S + j, k))  # page-locked: sent in place, behind the previous step's projections
+                c.render_batch(k > 0)
+
+            def sync():
+                for c in ctxs:
+                    c.synchronize()
+                if not dry:
+                    torch.cuda.synchronize()
+            with ThreadPoolExecutor(F) as pool:
+                for k in range(run_in):
+                    list(pool.map(lambda ci: step(ci, k), range(F)))
+                sync()
+                used = 0 if dry else (total_b - torch.cuda.mem_get_info(device)[0]) / 1e9
+                t0 = time.perf_counter()
+                for k in range(run_in, n_steps):
+                    list(pool.map(lambda ci: step(ci, k), range(F)))
+                sync()
+                dt = time.perf_counter() - t0
+            break
+        except R.S360Error as e:  # did not fit: fewer slots
+            for c in ctxs:
+                try:
+                    c.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            if not dry:
+                torch.cuda.empty_cache()
+            rec.setdefault("retries", []).append("%d slots: %s" % (S, str(e)[:120]))
+            if S <= 1 or attempt == 3:
+                raise
+            S = max(1, S - 2)
+    last = []
+    for c in ctxs:
+        for j in range(S):
+            c.select_frame_slot(j)
+            last.append(np.array(c.download_equirect()))
+    # the A13 kernels' share: one more step with the per-family events (perturbs the launch stream: not part of the timing)
+    prof = {}
+    for c in ctxs:
+        c.profile_enable(True)
+    with ThreadPoolExecutor(F) as pool:
+        list(pool.map(lambda ci: step(ci, n_steps), range(F)))
+    for c in ctxs:
+        c.synchronize()
+        for k, v in c.profile_get().items():
+            prof[k] = prof.get(k, 0.0) + v[0]
+        c.profile_enable(False)
+        c.close()
+    if not dry:
+        torch.cuda.empty_cache()
+    tot = sum(prof.values()) or 1.0
+    # ---- every stream alone: W contexts of one slot, one stream after the other in each, latency kernel ----
+    W = 2 if dry else 8
+    t1 = time.perf_counter()
+    alone_ctx = [R.Context(rig, R.make_params(**flags), device=device) for _ in range(W)]
+
+    def alone(w):
+        c, res = alone_ctx[w], {}
+        c.set_sweep_mode("latency")
+        for s in range(w, F * S, W):
+            for k in range(n_steps):
+                c.upload_frame(*frame_of(s, k))
+                c.render(k > 0)
+            res[s] = np.array_equal(c.download_equirect(), last[s])
+        return res
+    ok = {}
+    with ThreadPoolExecutor(W) as pool:
+        for r in pool.map(alone, range(W)):
+            ok.update(r)
+    for c in alone_ctx:
+        c.close()
+    bad = sorted(s for s, v in ok.items() if not v)
+    distinct = len({hash(a[::64, ::64].tobytes()) for a in last})
+    rec.update({
+        "mode": "%d streams = 2 contexts x %d frame slots, one stream per slot; every step one s360_frame_render_batch(use_prev=1) per "
+                "context: frame k of every stream regularised toward its own device-resident frame k-1 (both halves of every slot's "
+                "temporal double buffers resident); inputs sent in place from page-locked host memory on the upload stream while the "
+                "previous step renders; sharpening %.2f; steady state = steps %d..%d" % (F * S, S, flags["sharpening"], run_in, n_steps - 1),
+        "streams": F * S, "slots_per_context": S, "steps": timed, "frames": timed * F * S,
+        "frames_per_s": timed * F * S / dt, "ms_per_step": 1e3 * dt / timed, "ms_per_frame": 1e3 * dt / (timed * F * S),
+        "hbm_used_GB": round(used, 1), "distinct_frames_in_ring": n_ring,
+        "temporal_kernels_share_in_flight": round(prof.get("flow_prev", 0.0) / tot, 4),
+        "kernel_ms_per_frame_in_flight": {k: round(v / (F * S), 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1])},
+        "checked": len(ok) == F * S and not bad, "checked_streams": len(ok), "mismatching_streams": bad,
+        "distinct_last_frames": distinct,
+        "check": "the last frame (frame %d) of EVERY stream byte-compared with the same stream rendered frame by frame in a context of "
+                 "its own (one slot, latency sweep kernel, s360_frame_render(use_prev)); %d such contexts at a time" % (n_steps - 1, W),
+        "check_seconds": round(time.perf_counter() - t1, 1)})
+    return rec
+
+
 def main():
     t_process = time.perf_counter()
     ap = argparse.ArgumentParser()
@@ -297,6 +433,10 @@ def main():
     ap.add_argument("--slots", type=int, default=22,
                     help="frame slots per context: S independent frames rendered by ONE launch sequence with their flows "
                          "in the same batched kernels (s360_frame_render_batch); a step is then one batch of S frames")
+    ap.add_argument("--stream-slots", type=int, default=0,
+                    help="video_streams_batched leg: streams (frame slots) per context; 0 = as many as fit with both halves of "
+                         "every slot's temporal double buffers resident")
+    ap.add_argument("--stream-steps", type=int, default=8, help="video_streams_batched leg: timed steps (after 4 run-in steps)")
     ap.add_argument("--video-frames", type=int, default=190,
                     help="frames of the configs[4] stream leg (SURVEY 8d: 190, steady state over frames 10-189)")
     args = ap.parse_args()
@@ -1063,6 +1203,20 @@ def main():
                 out["isp"] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
             except Exception as e:  # noqa: BLE001
                 out["isp"] = {"error": repr(e)}
+
+            # ---- the reference's REAL workload as a batch (round 5): every preset renders frame k with --prev_frame_data_dir
+            # (batch_process_video.py:157-158, TRSP:215-235, 421-436, PixFlow.h:101-118, 185-193). S streams in the frame slots of
+            # two contexts, every step ONE s360_frame_render_batch(use_prev=1) per context: frame k of every stream regularised
+            # toward its own stream's device-resident previous flows and images (the A13 kernels at every pyramid level, both
+            # halves of every slot's temporal double buffers resident). The headline's frames have no predecessor; these do. Last
+            # leg of the run, in fresh contexts (the others are closed first): nothing it does can cost the lines above.
+            try:
+                ctx.close()
+                torch.cuda.empty_cache()
+                out["video_streams_batched"] = streams_batched(R, rig, flags, local_rank, frames, args, dry, g)
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                out["video_streams_batched"] = {"error": repr(e), "trace": traceback.format_exc()[-500:]}
 
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         import traceback

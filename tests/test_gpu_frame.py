@@ -190,6 +190,29 @@ def test_frame_slots_batch_equals_single(setup):
             _cmp("batched temporal flow_r_to_l slot %d" % k, cb.get_f32("flow_r_to_l", 6), want[k][3])
         with pytest.raises(R.S360Error):
             cb.select_frame_slot(3)
+        # a third step for slots 0 and 2 only (s360_frame_render_slots: streams of unequal length): slot 1 keeps its frame
+        keep = {}
+        cb.select_frame_slot(1)
+        keep[1] = cb.download_equirect()
+        c1 = R.Context(rig, R.make_params(**setup["flags"]))
+        try:
+            for k in (0, 2):
+                for i, f in enumerate((f0[k], f1[k], f0[k])):
+                    c1.upload_frame(*f)
+                    c1.render(use_prev=i > 0)
+                keep[k] = c1.download_equirect()
+        finally:
+            c1.close()
+        for k in (0, 2):
+            cb.select_frame_slot(k)
+            cb.upload_frame(*f0[k])
+        cb.render_slots([0, 2], use_prev=True)
+        for k in range(3):
+            cb.select_frame_slot(k)
+            _cmp("subset step, slot %d" % k, cb.download_equirect(), keep[k])
+        for bad in ([2, 0], [0, 0], [3], [-1]):
+            with pytest.raises(R.S360Error):
+                cb.render_slots(bad)
     finally:
         cb.close()
 

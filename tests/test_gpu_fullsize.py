@@ -219,6 +219,48 @@ def test_config5_late_frame_of_a_chain(frame8k, gpu_rig):
         _cmp("frame 4 of the pipelined stream", pip.download_equirect(), want)
     finally:
         pip.close()
+    frame8k["chain_want"] = want
+
+
+def test_config5_batched_chained_streams(frame8k, gpu_rig):
+    """The reference's real workload as a batch (round 5): THREE 8K streams in the three frame slots of one context, four steps of
+    s360_frame_render_batch(use_prev=1) — every frame regularised toward ITS OWN stream's device-resident previous flows and images
+    (batch_process_video.py:157-158, PixFlow.h:101-118, 185-193), both halves of every slot's temporal double buffers in use, the
+    throughput sweep kernel, the last step as a subset of the slots (s360_frame_render_slots). Stream 0 is the chain of the test
+    above: its fourth frame must equal the ORACLE's; streams 1 and 2 (other frame orders) must equal a context of their own
+    rendering them frame by frame with the latency kernel."""
+    fr = frame8k["frames"]
+    order = [[0, 1, 2, 3], [1, 2, 3, 2], [3, 2, 1]]  # stream 2 ends one step early
+    cb = R.Context(gpu_rig, R.make_params(**FLAGS_8K))
+    c1 = R.Context(gpu_rig, R.make_params(**FLAGS_8K))
+    try:
+        cb.set_frame_slots(3)
+        cb.set_sweep_mode("throughput")
+        last = {}
+        for k in range(4):
+            live = [s for s in range(3) if k < len(order[s])]
+            for s in live:
+                cb.select_frame_slot(s)
+                cb.upload_frame(*fr[order[s][k]])
+            if len(live) == 3:
+                cb.render_batch(use_prev=k > 0)
+            else:
+                cb.render_slots(live, use_prev=True)
+            for s in range(3):
+                if k + 1 == len(order[s]):
+                    cb.select_frame_slot(s)
+                    last[s] = cb.download_equirect()
+        assert "chain_want" in frame8k, "runs behind test_config5_late_frame_of_a_chain"
+        _cmp("batched stream 0, frame 4 (against the oracle's chain)", last[0], frame8k["chain_want"])
+        for s in (1, 2):
+            for k, f in enumerate(order[s]):
+                c1.upload_frame(*fr[f])
+                c1.render(use_prev=k > 0)
+            _cmp("batched stream %d, last frame" % s, last[s], c1.download_equirect())
+        assert not np.array_equal(last[1], last[0])
+    finally:
+        cb.close()
+        c1.close()
 
 
 # ---- the flag-gated rows at the 8k preset (VERDICT r02 "parity gap 1": green used to mean green at 1/16 size) ----
