@@ -203,6 +203,42 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420,
             rec["ms_per_frame_steady"] = 1e3 * (t[-1] - t[2]) / (n - 3)
             rec["frames_per_s_steady"] = (n - 3) / max(t[-1] - t[2], 1e-9)
             rec["steady_note"] = "frames 3..%d: time between the completion of eqr_000002.png and of the last file" % (n - 1)
+        # ---- ONE frame per process: how the caller the drop-in exists for runs it (batch_process_video.py:29-62 starts the
+        # program once per frame, every frame with --prev_frame_data_dir and the state files written for the next one) ----
+        try:
+            def one(frame, prev):
+                os.makedirs(os.path.join(out, "debug", frame, "flow_images"), exist_ok=True)
+                os.makedirs(os.path.join(out, "flow", frame), exist_ok=True)
+                c1 = [program, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", frame, "--output_data_dir", out,
+                      "--prev_frame_data_dir", prev, "--output_equirect_path", os.path.join(out, "single_%s.png" % frame),
+                      "--sharpening", repr(float(flags.get("sharpening", 0.0))), "--device", str(device), "--v", "1"]
+                for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
+                    c1 += ["--" + k, str(flags[k])]
+                c1 += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
+                t1 = time.perf_counter()
+                r1 = subprocess.run(c1, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
+                w1 = time.perf_counter() - t1
+                if r1.returncode != 0:
+                    raise RuntimeError("rc %d: %s" % (r1.returncode, r1.stderr[-300:]))
+                lines = [ln.strip() for ln in r1.stderr.splitlines() if re.match(r"^(load|previous|GPU render|state files|equirect PNG|TOTAL)", ln.strip())]
+                return w1, lines
+            w0, b0 = one("000000", "NONE")
+            w1, b1 = one("000001", "000000")
+            st = os.path.join(out, "flow", "000001")
+            rec["single_invocation"] = {
+                "wall_s": round(w1, 3), "first_frame_wall_s": round(w0, 3), "breakdown": b1,
+                "state_bytes_read": sum(os.path.getsize(os.path.join(out, "flow", "000000", f)) for f in os.listdir(os.path.join(out, "flow", "000000"))) +
+                sum(os.path.getsize(os.path.join(out, "debug", "000000", "flow_images", f)) for f in os.listdir(os.path.join(out, "debug", "000000", "flow_images"))),
+                "state_files_written": len(os.listdir(st)) + len(os.listdir(os.path.join(out, "debug", "000001", "flow_images"))),
+                "note": "one process per frame, process start to exit: frame 1 with --prev_frame_data_dir (28 + 4 flow files and 36 state "
+                        "images of frame 0 read, frame 1's written: TRSP:201-255, 413-452), 17 PNG inputs, one 8192x8192 equirect PNG; "
+                        "the stream figures above are what a caller gets that keeps the process (--num_frames)"}
+            same = np.asarray(Image.open(os.path.join(out, "single_000001.png")))[:, :, ::-1]
+            if n >= 2:
+                chain = np.asarray(Image.open(outs[1]))[:, :, ::-1]
+                rec["single_invocation"]["equals_stream_frame"] = bool(np.array_equal(same, chain))
+        except Exception as e:  # noqa: BLE001
+            rec["single_invocation"] = {"error": repr(e)}
         return rec, last
     finally:
         shutil.rmtree(work, ignore_errors=True)

@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -317,28 +318,70 @@ void upload_frame(const Job& J, const FrameInputs& in) {
 
 const char* const kEyeNames[4] = {"top_left", "top_right", "bottom_left", "bottom_right"};
 
-// previous frame's state from files (TRSP:215-235, 421-436), each pair to the GPU that renders it
+// fn(0) .. fn(n - 1) on up to `workers` threads (file reads / PNG codecs of the per-frame state: 68 files per frame)
+template <class Fn>
+void parallel_items(int n, int workers, Fn fn) {
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int w = 0; w < std::max(1, std::min(workers, n)); ++w)
+    th.emplace_back([&] {
+      for (int i = next++; i < n; i = next++) fn(i);
+    });
+  for (auto& t : th) t.join();
+}
+int state_workers() { return std::max(2, std::min(16, pngio::available_cpus())); }
+
+// previous frame's state from files (TRSP:215-235, 421-436), each pair to the GPU that renders it. The 68 files of an 8K frame
+// (1.2 GB of flows, 0.9 GB of images behind their PNG coding) are read and decoded by a pool of threads — the reference reads
+// them inside its per-pair / per-unit threads, TRSP:215-235 —, then handed to the library in order.
 void load_prev_state(const Job& J, const std::string& prev) {
   const s360_geometry& g = J.g;
   const std::string outData = J.F.s("output_data_dir");
   const std::string flowPrevDir = outData + "/flow/" + prev, imgPrevDir = outData + "/debug/" + prev + "/flow_images/";
   const size_t on = (size_t)g.overlap_image_width * g.cam_image_height;
-  std::vector<float> fl(on * 2), fr(on * 2);
+  struct PairState { std::vector<float> fl, fr; pngio::Image L, R; };
+  struct UnitState { std::vector<float> pf; pngio::Image S, Fi; bool on = false; };
+  std::vector<PairState> pairs(J.P);
+  UnitState units[4];
+  for (int u = 0; u < 4; ++u) units[u].on = !((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom));
+  parallel_items(J.P + 4, state_workers(), [&](int item) {
+    if (item < J.P) {
+      const int i = item;
+      PairState& ps = pairs[i];
+      ps.fl.resize(on * 2);
+      ps.fr.resize(on * 2);
+      int w = 0, h = 0;
+      if (s360_read_flow_from_file((flowPrevDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), ps.fl.data(), &w, &h, ps.fl.size()) < 0 ||
+          w != g.overlap_image_width || h != g.cam_image_height)
+        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
+      if (s360_read_flow_from_file((flowPrevDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), ps.fr.data(), &w, &h, ps.fr.size()) < 0 ||
+          w != g.overlap_image_width || h != g.cam_image_height)
+        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
+      ps.L = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_L.png", true);
+      ps.R = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_R.png", true);
+      if (ps.L.c != 4 || ps.R.c != 4 || ps.L.w != g.overlap_image_width || ps.L.h != g.cam_image_height || ps.R.w != ps.L.w || ps.R.h != ps.L.h)
+        die("previous overlap images have the wrong size/channels");
+    } else {
+      const int u = item - J.P;
+      UnitState& us = units[u];
+      if (!us.on) return;
+      const int rows = u < 2 ? g.top_rows : g.bottom_rows;
+      us.pf.resize((size_t)J.extW * rows * 2);
+      int w = 0, h = 0;
+      if (s360_read_flow_from_file((flowPrevDir + "/flow_" + kEyeNames[u] + ".bin").c_str(), us.pf.data(), &w, &h, us.pf.size()) < 0 || w != J.extW || h != rows)
+        die(std::string("bad previous pole flow file: ") + kEyeNames[u]);
+      us.S = load_png(imgPrevDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png", true);
+      us.Fi = load_png(imgPrevDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png", true);
+      if (us.S.c != 4 || us.Fi.c != 4 || us.S.w != J.extW || us.S.h != rows || us.Fi.w != J.extW || us.Fi.h != rows)
+        die("previous extended pole images have the wrong size/channels");
+    }
+  });
   for (size_t r = 0; r < J.ctx.size(); ++r) {
     ck(s360_frame_set_partition(J.ctx[r], J.bounds[r], J.bounds[r + 1]), J.ctx[r]);
     for (int i = J.bounds[r]; i < J.bounds[r + 1]; ++i) {
-      int w = 0, h = 0;
-      if (s360_read_flow_from_file((flowPrevDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), &w, &h, fl.size()) < 0 ||
-          w != g.overlap_image_width || h != g.cam_image_height)
-        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
-      if (s360_read_flow_from_file((flowPrevDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fr.data(), &w, &h, fr.size()) < 0 ||
-          w != g.overlap_image_width || h != g.cam_image_height)
-        die("bad previous flow file for pair " + std::to_string(i) + ": " + s360_last_error(nullptr));
-      const pngio::Image L = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_L.png", true);
-      const pngio::Image R = load_png(imgPrevDir + "/overlap_" + std::to_string(i) + "_R.png", true);
-      if (L.c != 4 || R.c != 4 || L.w != g.overlap_image_width || L.h != g.cam_image_height || R.w != L.w || R.h != L.h)
-        die("previous overlap images have the wrong size/channels");
-      ck(s360_frame_set_prev_side(J.ctx[r], i, fl.data(), fr.data(), L.px.data(), R.px.data()), J.ctx[r]);
+      PairState& ps = pairs[i];
+      ck(s360_frame_set_prev_side(J.ctx[r], i, ps.fl.data(), ps.fr.data(), ps.L.px.data(), ps.R.px.data()), J.ctx[r]);
+      ps = PairState();
     }
   }
   if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:95-110
@@ -355,17 +398,10 @@ void load_prev_state(const Job& J, const std::string& prev) {
     ck(s360_frame_set_prev_pole_removal(root, pf.data(), b1.px.data(), b2.px.data(), w, h), root);
   }
   for (int u = 0; u < 4; ++u) {
-    if ((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom)) continue;
-    const int rows = u < 2 ? g.top_rows : g.bottom_rows;
-    std::vector<float> pf((size_t)J.extW * rows * 2);
-    int w = 0, h = 0;
-    if (s360_read_flow_from_file((flowPrevDir + "/flow_" + kEyeNames[u] + ".bin").c_str(), pf.data(), &w, &h, pf.size()) < 0 || w != J.extW || h != rows)
-      die(std::string("bad previous pole flow file: ") + kEyeNames[u]);
-    const pngio::Image S = load_png(imgPrevDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png", true);
-    const pngio::Image Fi = load_png(imgPrevDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png", true);
-    if (S.c != 4 || Fi.c != 4 || S.w != J.extW || S.h != rows || Fi.w != J.extW || Fi.h != rows)
-      die("previous extended pole images have the wrong size/channels");
-    ck(s360_frame_set_prev_pole(J.owner_ctx(u), u, pf.data(), S.px.data(), Fi.px.data()), J.owner_ctx(u));  // a unit's state lives where it runs
+    UnitState& us = units[u];
+    if (!us.on) continue;
+    ck(s360_frame_set_prev_pole(J.owner_ctx(u), u, us.pf.data(), us.S.px.data(), us.Fi.px.data()), J.owner_ctx(u));  // a unit's state lives where it runs
+    us = UnitState();
   }
 }
 
@@ -392,55 +428,69 @@ void render_frame(const Job& J, bool usePrev) {
   for (auto& t : th) t.join();
 }
 
-// state for the next frame: always written by the reference (TRSP:201-208, 247-255, 413-416, 451-452)
+// state for the next frame: always written by the reference (TRSP:201-208, 247-255, 413-416, 451-452). Fetched from the device
+// in order, PNG-coded / written by a pool of threads (36 images and 32 flow files per 8K frame: 2 GB).
 void write_state(const Job& J, const std::string& frame) {
   const s360_geometry& g = J.g;
   const std::string outData = J.F.s("output_data_dir");
   const std::string flowDir = outData + "/flow/" + frame, flowImagesDir = outData + "/debug/" + frame + "/flow_images";
   mkdirs(flowDir);
   mkdirs(flowImagesDir);
-  int whc[3];
-  const size_t on = (size_t)g.overlap_image_width * g.cam_image_height;
-  std::vector<uint8_t> img(on * 4);
-  std::vector<float> fl(on * 2);
+  struct Item { std::string path; std::vector<uint8_t> img; std::vector<float> fl; int w = 0, h = 0; };
+  std::vector<Item> items;
+  auto get_img = [&](s360_ctx* c, const char* what, int idx, const std::string& path) {
+    int whc[3];
+    ck(s360_frame_get_u8(c, what, idx, whc, nullptr), c);
+    Item it;
+    it.path = path; it.w = whc[0]; it.h = whc[1];
+    it.img.resize((size_t)whc[0] * whc[1] * 4);
+    ck(s360_frame_get_u8(c, what, idx, whc, it.img.data()), c);
+    items.push_back(std::move(it));
+  };
+  auto get_flow = [&](s360_ctx* c, const char* what, int idx, const std::string& path) {
+    int whc[3];
+    ck(s360_frame_get_f32(c, what, idx, whc, nullptr), c);
+    Item it;
+    it.path = path; it.w = whc[0]; it.h = whc[1];
+    it.fl.resize((size_t)whc[0] * whc[1] * 2);
+    ck(s360_frame_get_f32(c, what, idx, whc, it.fl.data()), c);
+    items.push_back(std::move(it));
+  };
   for (size_t r = 0; r < J.ctx.size(); ++r) {
     s360_ctx* c = J.ctx[r];
     for (int i = J.bounds[r]; i < J.bounds[r + 1]; ++i) {
-      ck(s360_frame_get_u8(c, "overlap_l", i, whc, img.data()), c);
-      save_png(flowImagesDir + "/overlap_" + std::to_string(i) + "_L.png", img.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_u8(c, "overlap_r", i, whc, img.data()), c);
-      save_png(flowImagesDir + "/overlap_" + std::to_string(i) + "_R.png", img.data(), whc[0], whc[1], 4);
-      ck(s360_frame_get_f32(c, "flow_l_to_r", i, whc, fl.data()), c);
-      ck(s360_save_flow_to_file((flowDir + "/flowLtoR_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
-      ck(s360_frame_get_f32(c, "flow_r_to_l", i, whc, fl.data()), c);
-      ck(s360_save_flow_to_file((flowDir + "/flowRtoL_" + std::to_string(i) + ".bin").c_str(), fl.data(), whc[0], whc[1]), nullptr);
+      get_img(c, "overlap_l", i, flowImagesDir + "/overlap_" + std::to_string(i) + "_L.png");
+      get_img(c, "overlap_r", i, flowImagesDir + "/overlap_" + std::to_string(i) + "_R.png");
+      get_flow(c, "flow_l_to_r", i, flowDir + "/flowLtoR_" + std::to_string(i) + ".bin");
+      get_flow(c, "flow_r_to_l", i, flowDir + "/flowRtoL_" + std::to_string(i) + ".bin");
     }
   }
   if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
     s360_ctx* root = J.ctx[J.bottom_gpu()];
-    ck(s360_frame_get_u8(root, "bottom_image", 0, whc, nullptr), root);
-    std::vector<uint8_t> bimg((size_t)whc[0] * whc[1] * 4);
-    std::vector<float> bfl((size_t)whc[0] * whc[1] * 2);
-    ck(s360_frame_get_u8(root, "bottom_image", 0, whc, bimg.data()), root);
-    save_png(flowImagesDir + "/bottomImage.png", bimg.data(), whc[0], whc[1], 4);
-    ck(s360_frame_get_u8(root, "bottom_image2", 0, whc, bimg.data()), root);
-    save_png(flowImagesDir + "/bottomImage2.png", bimg.data(), whc[0], whc[1], 4);
-    ck(s360_frame_get_f32(root, "flow_bottom_secondary", 0, whc, bfl.data()), root);
-    ck(s360_save_flow_to_file((flowDir + "/flow_bottom_secondary.bin").c_str(), bfl.data(), whc[0], whc[1]), nullptr);
+    get_img(root, "bottom_image", 0, flowImagesDir + "/bottomImage.png");
+    get_img(root, "bottom_image2", 0, flowImagesDir + "/bottomImage2.png");
+    get_flow(root, "flow_bottom_secondary", 0, flowDir + "/flow_bottom_secondary.bin");
   }
   for (int u = 0; u < 4; ++u) {
     if ((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom)) continue;
-    const int rows = u < 2 ? g.top_rows : g.bottom_rows;
-    std::vector<uint8_t> e((size_t)J.extW * rows * 4);
-    std::vector<float> pf((size_t)J.extW * rows * 2);
     s360_ctx* root = J.owner_ctx(u);
-    ck(s360_frame_get_u8(root, "extended_side", u, whc, e.data()), root);
-    save_png(flowImagesDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
-    ck(s360_frame_get_u8(root, "extended_fisheye", u, whc, e.data()), root);
-    save_png(flowImagesDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png", e.data(), whc[0], whc[1], 4);
-    ck(s360_frame_get_f32(root, "flow_pole", u, whc, pf.data()), root);
-    ck(s360_save_flow_to_file((flowDir + "/flow_" + kEyeNames[u] + ".bin").c_str(), pf.data(), whc[0], whc[1]), nullptr);
+    get_img(root, "extended_side", u, flowImagesDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png");
+    get_img(root, "extended_fisheye", u, flowImagesDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png");
+    get_flow(root, "flow_pole", u, flowDir + "/flow_" + kEyeNames[u] + ".bin");
   }
+  parallel_items((int)items.size(), state_workers(), [&](int k) {
+    Item& it = items[k];
+    if (!it.img.empty()) {
+      try {
+        pngio::write(it.path, it.img.data(), it.w, it.h, 4, 1, 1);  // (one deflate thread each: the pool is the parallelism)
+      } catch (const std::exception& e) {
+        die(e.what());
+      }
+    } else {
+      ck(s360_save_flow_to_file(it.path.c_str(), it.fl.data(), it.w, it.h), nullptr);
+    }
+    it = Item();
+  });
 }
 
 // "000123" + 1 -> "000124" (same width); frame names of the reference's datasets are zero-padded decimal numbers
@@ -570,6 +620,12 @@ static int run_job(const Flags& flags) {
   Flags& F = J.F;
   s360_params& prm = J.prm;
   const int verbose = F.i("v");
+  const double rigTime = now_sec();
+  // the first frame's 17 images are decoded (one thread per camera) while HIP starts up and the context is made: a process
+  // per frame — how batch_process_video.py:29-62 runs the program — pays both for every frame
+  std::string frame = F.s("frame_number");
+  std::future<FrameInputs> firstDecode;
+  if (F.s("bin_list").empty()) firstDecode = std::async(std::launch::async, [&J, frame] { return load_frame(J, frame); });
 
   // ---- GPUs: --num_gpus G uses devices device .. device+G-1 (never more GPUs than pairs)
   const int G = std::max(1, std::min(F.i("num_gpus"), J.P));
@@ -599,8 +655,9 @@ static int run_job(const Flags& flags) {
   if (numFrames > 1 && cube) die("--output_cubemap_path is not available with --num_frames > 1");
 
   // ---- frame 0: decode, upload, previous-frame state from files, render
-  std::string frame = F.s("frame_number");
-  FrameInputs in = load_frame(J, frame);
+  const double ctxTime = now_sec();
+  FrameInputs in = firstDecode.valid() ? firstDecode.get() : load_frame(J, frame);
+  const double decodeTime = now_sec();
   upload_frame(J, in);
   const double loadTime = now_sec();
   if (prev != "NONE") load_prev_state(J, prev);
@@ -683,7 +740,13 @@ static int run_job(const Flags& flags) {
     }
     renderEnd = now_sec();
     tFetch += renderEnd - tf;
-    // the reference writes the state of every frame; a stream only needs it to resume after its last frame
+    // (%s / {frame} in the path stands for the frame name — needed by streams, harmless for a single frame: a stream
+    // segment of one frame is named like the others)
+    const std::string outPath = frame_path(F.s("output_equirect_path"), frame);
+    const uint8_t* px = outBuf[cur].data();
+    encoder[cur] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });  // TRSP:961
+    // the reference writes the state of every frame; a stream only needs it to resume after its last frame. (Beside the
+    // equirect's encoder, not in front of it.)
     if (F.b("write_state") && last) write_state(J, frame);
     stateEnd = now_sec();
     if (last && cube) {  // optional stereo cubemap (TRSP:917-935)
@@ -693,11 +756,6 @@ static int run_job(const Flags& flags) {
       ck(s360_frame_cubemap(J.ctx[0], F.i("cubemap_width"), F.i("cubemap_height"), F.s("cubemap_format").c_str(), whc, cubeImg.data()), J.ctx[0]);
       save_png(F.s("output_cubemap_path"), cubeImg.data(), whc[0], whc[1], 3);
     }
-    // (%s / {frame} in the path stands for the frame name — needed by streams, harmless for a single frame: a stream
-    // segment of one frame is named like the others)
-    const std::string outPath = frame_path(F.s("output_equirect_path"), frame);
-    const uint8_t* px = outBuf[cur].data();
-    encoder[cur] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });  // TRSP:961
     cur = numFrames > 1 ? (cur + 1) % (kEncoders + 1) : 0;
     const double tj = now_sec();
     if (encoder[cur].joinable()) encoder[cur].join();  // the oldest encoder: its buffer takes the next frame
@@ -710,12 +768,13 @@ static int run_job(const Flags& flags) {
   const double endTime = now_sec();
   if (verbose >= 1) {  // the reference's VLOG(1) runtime breakdown, TRSP:964-971
     std::fprintf(stderr, "--- Runtime breakdown (sec) ---\n");
-    std::fprintf(stderr, "load + decode + upload:  %.3f\n", loadTime - startTime);
+    std::fprintf(stderr, "load + decode + upload:  %.3f  (flags + rig %.3f, HIP start-up + context %.3f beside the PNG decodes, waiting for them %.3f, upload %.3f)\n",
+                 loadTime - startTime, rigTime - startTime, ctxTime - rigTime, decodeTime - ctxTime, loadTime - decodeTime);
     std::fprintf(stderr, "previous-frame state:    %.3f\n", renderStart - loadTime);
     if (numFrames == 1) {
       std::fprintf(stderr, "GPU render + download:   %.3f  (%d GPU%s)\n", renderEnd - renderStart, G, G > 1 ? "s, RCCL strip gather" : "");
-      std::fprintf(stderr, "state files:             %.3f\n", stateEnd - renderEnd);
-      std::fprintf(stderr, "equirect PNG encode:     %.3f\n", endTime - stateEnd);
+      std::fprintf(stderr, "state files:             %.3f  (beside the equirect's PNG encoder)\n", stateEnd - renderEnd);
+      std::fprintf(stderr, "equirect PNG encode:     %.3f  (what was left of it)\n", endTime - stateEnd);
     } else {
       std::fprintf(stderr, "stream of %d frames:      %.3f  (%.3f per frame: decode, upload, render, download, encode overlapped)\n",
                    numFrames, endTime - renderStart, (endTime - renderStart) / numFrames);
