@@ -11,16 +11,20 @@
 #include <dirent.h>
 #include <malloc.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <future>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -179,6 +183,7 @@ void load_png_into(const std::string& path, bool keep_alpha, pngio::Image& im) {
 // runtime's own threads, which feed the GPU its ~1000 launches per frame: unbounded (one thread per 2 MB band, ~100 for an 8K
 // equirect) the encoders crowd those out and the GPU waits for its host — on the GPU boxes the process has 16 CPUs of a
 // 256-thread machine (profiles/r04_v2_end_to_end_*).
+static bool g_fast_exit = false;
 static int g_png_threads = 0;  // 0 = one per band, up to the hardware threads
 void save_png(const std::string& path, const uint8_t* px, int w, int h, int c) {
   try {
@@ -331,6 +336,71 @@ void parallel_items(int n, int workers, Fn fn) {
 }
 int state_workers() { return std::max(2, std::min(16, pngio::available_cpus())); }
 
+// tasks pushed by one thread, run by a pool (the state files of a frame are coded and written while the next ones are fetched)
+class TaskQueue {
+ public:
+  explicit TaskQueue(int workers) {
+    for (int w = 0; w < std::max(1, workers); ++w)
+      th_.emplace_back([this] {
+        for (;;) {
+          std::function<void()> t;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return closed_ || !q_.empty(); });
+            if (q_.empty()) return;
+            t = std::move(q_.front());
+            q_.pop_front();
+          }
+          t();
+        }
+      });
+  }
+  void push(std::function<void()> t) {
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(t)); }
+    cv_.notify_one();
+  }
+  ~TaskQueue() {
+    { std::lock_guard<std::mutex> lk(mu_); closed_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+ private:
+  std::deque<std::function<void()>> q_;
+  bool closed_ = false;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::thread> th_;
+};
+
+// fn(i) for i in [0, n) on a pool of threads in the background; wait(i) blocks until item i is done (the caller consumes the
+// items in order while the later ones are still being produced)
+class ItemPool {
+ public:
+  template <class Fn>
+  ItemPool(int n, int workers, Fn fn) : done_(n) {
+    for (auto& d : done_) d.store(false);
+    for (int w = 0; w < std::max(1, std::min(workers, n)); ++w)
+      th_.emplace_back([this, n, fn] {
+        for (int i = next_++; i < n; i = next_++) {
+          fn(i);
+          { std::lock_guard<std::mutex> lk(mu_); done_[i].store(true); }
+          cv_.notify_all();
+        }
+      });
+  }
+  void wait(int i) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return done_[i].load(); });
+  }
+  ~ItemPool() { for (auto& t : th_) t.join(); }
+ private:
+  std::vector<std::atomic<bool>> done_;
+  std::atomic<int> next_{0};
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::thread> th_;
+};
+
 // previous frame's state from files (TRSP:215-235, 421-436), each pair to the GPU that renders it. The 68 files of an 8K frame
 // (1.2 GB of flows, 0.9 GB of images behind their PNG coding) are read and decoded by a pool of threads — the reference reads
 // them inside its per-pair / per-unit threads, TRSP:215-235 —, then handed to the library in order.
@@ -344,7 +414,9 @@ void load_prev_state(const Job& J, const std::string& prev) {
   std::vector<PairState> pairs(J.P);
   UnitState units[4];
   for (int u = 0; u < 4; ++u) units[u].on = !((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom));
-  parallel_items(J.P + 4, state_workers(), [&](int item) {
+  // the pole units' files first (the largest: 85 MB images, 170 MB flows), then the pairs in the order they are handed over
+  ItemPool pool(J.P + 4, state_workers(), [&](int it) {
+    const int item = it < 4 ? J.P + it : it - 4;
     if (item < J.P) {
       const int i = item;
       PairState& ps = pairs[i];
@@ -379,6 +451,7 @@ void load_prev_state(const Job& J, const std::string& prev) {
   for (size_t r = 0; r < J.ctx.size(); ++r) {
     ck(s360_frame_set_partition(J.ctx[r], J.bounds[r], J.bounds[r + 1]), J.ctx[r]);
     for (int i = J.bounds[r]; i < J.bounds[r + 1]; ++i) {
+      pool.wait(4 + i);  // (handed to the device while the later pairs are still being read)
       PairState& ps = pairs[i];
       ck(s360_frame_set_prev_side(J.ctx[r], i, ps.fl.data(), ps.fr.data(), ps.L.px.data(), ps.R.px.data()), J.ctx[r]);
       ps = PairState();
@@ -399,6 +472,7 @@ void load_prev_state(const Job& J, const std::string& prev) {
   }
   for (int u = 0; u < 4; ++u) {
     UnitState& us = units[u];
+    pool.wait(u);
     if (!us.on) continue;
     ck(s360_frame_set_prev_pole(J.owner_ctx(u), u, us.pf.data(), us.S.px.data(), us.Fi.px.data()), J.owner_ctx(u));  // a unit's state lives where it runs
     us = UnitState();
@@ -431,31 +505,57 @@ void render_frame(const Job& J, bool usePrev) {
 // state for the next frame: always written by the reference (TRSP:201-208, 247-255, 413-416, 451-452). Fetched from the device
 // in order, PNG-coded / written by a pool of threads (36 images and 32 flow files per 8K frame: 2 GB).
 void write_state(const Job& J, const std::string& frame) {
-  const s360_geometry& g = J.g;
   const std::string outData = J.F.s("output_data_dir");
   const std::string flowDir = outData + "/flow/" + frame, flowImagesDir = outData + "/debug/" + frame + "/flow_images";
   mkdirs(flowDir);
   mkdirs(flowImagesDir);
   struct Item { std::string path; std::vector<uint8_t> img; std::vector<float> fl; int w = 0, h = 0; };
-  std::vector<Item> items;
+  TaskQueue coders(state_workers());  // (joined when this function returns: every file is complete then)
+  auto hand_over = [&](std::shared_ptr<Item> it) {
+    coders.push([it] {
+      if (!it->img.empty()) {
+        try {
+          pngio::write(it->path, it->img.data(), it->w, it->h, 4, 1, 1);  // (one deflate thread each: the pool is the parallelism)
+        } catch (const std::exception& e) {
+          die(e.what());
+        }
+      } else {
+        ck(s360_save_flow_to_file(it->path.c_str(), it->fl.data(), it->w, it->h), nullptr);
+      }
+    });
+  };
   auto get_img = [&](s360_ctx* c, const char* what, int idx, const std::string& path) {
     int whc[3];
     ck(s360_frame_get_u8(c, what, idx, whc, nullptr), c);
-    Item it;
-    it.path = path; it.w = whc[0]; it.h = whc[1];
-    it.img.resize((size_t)whc[0] * whc[1] * 4);
-    ck(s360_frame_get_u8(c, what, idx, whc, it.img.data()), c);
-    items.push_back(std::move(it));
+    auto it = std::make_shared<Item>();
+    it->path = path; it->w = whc[0]; it->h = whc[1];
+    it->img.resize((size_t)whc[0] * whc[1] * 4);
+    ck(s360_frame_get_u8(c, what, idx, whc, it->img.data()), c);
+    hand_over(std::move(it));
   };
   auto get_flow = [&](s360_ctx* c, const char* what, int idx, const std::string& path) {
     int whc[3];
     ck(s360_frame_get_f32(c, what, idx, whc, nullptr), c);
-    Item it;
-    it.path = path; it.w = whc[0]; it.h = whc[1];
-    it.fl.resize((size_t)whc[0] * whc[1] * 2);
-    ck(s360_frame_get_f32(c, what, idx, whc, it.fl.data()), c);
-    items.push_back(std::move(it));
+    auto it = std::make_shared<Item>();
+    it->path = path; it->w = whc[0]; it->h = whc[1];
+    it->fl.resize((size_t)whc[0] * whc[1] * 2);
+    ck(s360_frame_get_f32(c, what, idx, whc, it->fl.data()), c);
+    hand_over(std::move(it));
   };
+  // the pole units first: their images (85 MB each at 8K) take longest to code
+  for (int u = 0; u < 4; ++u) {
+    if ((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom)) continue;
+    s360_ctx* root = J.owner_ctx(u);
+    get_img(root, "extended_side", u, flowImagesDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png");
+    get_img(root, "extended_fisheye", u, flowImagesDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png");
+    get_flow(root, "flow_pole", u, flowDir + "/flow_" + kEyeNames[u] + ".bin");
+  }
+  if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
+    s360_ctx* root = J.ctx[J.bottom_gpu()];
+    get_img(root, "bottom_image", 0, flowImagesDir + "/bottomImage.png");
+    get_img(root, "bottom_image2", 0, flowImagesDir + "/bottomImage2.png");
+    get_flow(root, "flow_bottom_secondary", 0, flowDir + "/flow_bottom_secondary.bin");
+  }
   for (size_t r = 0; r < J.ctx.size(); ++r) {
     s360_ctx* c = J.ctx[r];
     for (int i = J.bounds[r]; i < J.bounds[r + 1]; ++i) {
@@ -465,32 +565,6 @@ void write_state(const Job& J, const std::string& frame) {
       get_flow(c, "flow_r_to_l", i, flowDir + "/flowRtoL_" + std::to_string(i) + ".bin");
     }
   }
-  if (J.prm.enable_pole_removal) {  // PoleRemoval.cpp:118-126 (kSaveDataNextFrame, TRSP:581)
-    s360_ctx* root = J.ctx[J.bottom_gpu()];
-    get_img(root, "bottom_image", 0, flowImagesDir + "/bottomImage.png");
-    get_img(root, "bottom_image2", 0, flowImagesDir + "/bottomImage2.png");
-    get_flow(root, "flow_bottom_secondary", 0, flowDir + "/flow_bottom_secondary.bin");
-  }
-  for (int u = 0; u < 4; ++u) {
-    if ((u < 2 && !J.prm.enable_top) || (u >= 2 && !J.prm.enable_bottom)) continue;
-    s360_ctx* root = J.owner_ctx(u);
-    get_img(root, "extended_side", u, flowImagesDir + "/extendedSideSpherical_" + kEyeNames[u] + ".png");
-    get_img(root, "extended_fisheye", u, flowImagesDir + "/extendedFisheyeSpherical_" + kEyeNames[u] + ".png");
-    get_flow(root, "flow_pole", u, flowDir + "/flow_" + kEyeNames[u] + ".bin");
-  }
-  parallel_items((int)items.size(), state_workers(), [&](int k) {
-    Item& it = items[k];
-    if (!it.img.empty()) {
-      try {
-        pngio::write(it.path, it.img.data(), it.w, it.h, 4, 1, 1);  // (one deflate thread each: the pool is the parallelism)
-      } catch (const std::exception& e) {
-        die(e.what());
-      }
-    } else {
-      ck(s360_save_flow_to_file(it.path.c_str(), it.fl.data(), it.w, it.h), nullptr);
-    }
-    it = Item();
-  });
 }
 
 // "000123" + 1 -> "000124" (same width); frame names of the reference's datasets are zero-padded decimal numbers
@@ -937,7 +1011,20 @@ int main(int argc, char** argv) {
     pngio::g_pixel_alloc = s360_host_alloc;
     pngio::g_pixel_free = s360_host_free;
   }
-  if (streams == 1) return run_job(F);
+  if (streams == 1) {
+    // One frame per process is how the reference's caller runs this program (batch_process_video.py:29-62). Every file is closed
+    // and every device result fetched when run_job returns; freeing 12 GB of device memory buffer by buffer and unloading the
+    // runtime only to exit costs ~0.2 s per frame, so the process leaves at once (S360_CLEAN_EXIT=1: tear down, e.g. under a
+    // leak checker).
+    const char* ce = std::getenv("S360_CLEAN_EXIT");
+    g_fast_exit = frames == 1 && !(ce && ce[0] == '1');
+    const int rc = run_job(F);
+    if (g_fast_exit) {
+      std::fflush(nullptr);
+      _exit(rc);
+    }
+    return rc;
+  }
   if (F.i("num_gpus") > 1) die("--num_streams and --num_gpus are separate modes");
   if (streams > frames) die("--num_streams: more streams than frames");
   require_arg(F.s("frame_number"), "frame_number");

@@ -26,7 +26,9 @@ struct Footage {
   size_t frame_size() const { return (size_t)md.width * md.height * md.bitsPerPixel / 8; }
   size_t frames() const { return (md.numberOfCameras && frame_size() && size >= 4096) ? (size - 4096) / frame_size() / md.numberOfCameras : 0; }
   const uint8_t* frame(size_t f, size_t cam) const {  // (offsets, not pointers: nothing here may wrap around)
-    const size_t fs = frame_size(), avail = (size - 4096) / fs;  // whole frames in the file; open() made fs > 0
+    const size_t fs = frame_size();
+    if (fs < 8) throw std::runtime_error("no frames (bits per pixel / sizes of the header) in " + path);  // (the serial number is bytes 4..7)
+    const size_t avail = (size - 4096) / fs;  // whole frames in the file
     if (cam >= md.numberOfCameras || f >= avail / md.numberOfCameras) throw std::runtime_error("frame out of range for " + path);
     return base + 4096 + (md.numberOfCameras * f + cam) * fs;
   }
@@ -45,7 +47,9 @@ struct Footage {
     if (md.numberOfCameras != 0) {
       if (md.width == 0 || md.height == 0 || md.width > 65536u || md.height > 65536u || md.numberOfCameras > 4096u)
         throw std::runtime_error("implausible metadata (width / height / numberOfCameras) in " + path);
+      if (md.bitsPerPixel != 8 && md.bitsPerPixel != 12) throw std::runtime_error("unsupported bits per pixel (8 and 12 exist) in " + path);
       if (md.bitsPerPixel == 12 && (md.width & 1u)) throw std::runtime_error("12-bit frames need an even width: " + path);
+      if (frame_size() < 8) throw std::runtime_error("implausible metadata (a frame of fewer than 8 bytes) in " + path);
     }
     if (verbose) std::printf("Metadata:\nmagic = %x\ntimestamp = %u\nfileIndex = %u\nfileCount = %u\nwidth = %u\nheight = %u\nbpp = %u\nnumberOfCameras = %u\n",
                 md.magic, md.timestamp, md.fileIndex, md.fileCount, md.width, md.height, md.bitsPerPixel, md.numberOfCameras);

@@ -213,7 +213,11 @@ int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
  * one process): the stacked equirect of the last two frames is kept. age 0 = the frame enqueued last, age 1 = the one
  * before (needs s360_set_frame_pipelining, which is what makes the library alternate between two output buffers); the
  * call waits for THAT frame only and copies on a stream of its own, so frame k can be fetched and encoded while frame
- * k+1 renders:  upload(k+1); render(k+1); download_equirect_of(age 1) -> frame k. */
+ * k+1 renders:  upload(k+1); render(k+1); download_equirect_of(age 1) -> frame k.
+ * Contract for a feeder thread that runs ahead of the fetching thread (the call releases the context's lock while it waits): a
+ * frame can be fetched while it is the last or the last-but-one ENQUEUED frame, i.e. the fetch of frame k must be CALLED before
+ * frame k+2 is enqueued; from then on the library orders things itself — the frame that reuses k's output buffer (k+2) waits on
+ * the device for k's transfer, and k's sweep error words travel with its pixels. One fetching thread per context. */
 int s360_frame_download_equirect_of(s360_ctx* ctx, int age, uint8_t* out_bgr);
 /* Page-locked host buffers for streaming hosts (what the reference's per-frame loop has no need for: its cv::Mat pixels
  * never leave the host, RigDescription.cpp:80-108 / TRSP:961). An image passed to s360_frame_upload_* from such a buffer is
@@ -356,7 +360,11 @@ int s360_read_flow_from_file(const char* path, float* flow_out, int* w, int* h, 
  * region; the shipped configurations say 5) its condition is false at once and the pass changes nothing. Thresholds outside
  * that range make the pass a serial in-place median filter of the dark regions in boustrophedon order; both are reproduced
  * (pinned against CameraIsp.h compiled: tests/test_cpu_isp.py), the second as the raster-order recurrence it is — exact, and
- * as slow as a recurrence is where most pixels change. stuck_pixel_radius up to 6 (JSON 3: a 13 x 13 window). */
+ * as slow as a recurrence is where most pixels change. stuck_pixel_radius up to 6 (JSON 3: a 13 x 13 window).
+ * COST of that second case (measured, 2048 x 2048): ~7.5 us per CHANGED pixel — one thread gathers and sorts a window behind the
+ * previous one — i.e. 45 ms with 15 000 changed pixels, 2.2 s with a million. The reference's DEFAULT threshold, 0, is such a
+ * case ("always write" wherever the neighbourhood is dark): a dark frame walks every pixel. The pass runs on the stream the
+ * object is used on — s360_frame_upload_raw: the context's upload stream, which then stalls for that long. */
 #define S360_ISP_MAX_CURVE_POINTS 16
 typedef struct s360_isp_config {
   /* the "CameraIsp" JSON object as the constructor stores it (CameraIsp.h:425-607): doubles narrowed to float */

@@ -319,6 +319,7 @@ void s360_destroy(s360_ctx* c) {
       if (e->ready) (void)hipEventDestroy(e->ready);
   if (c->evMaps) (void)hipEventDestroy(c->evMaps);
   if (c->evDown) (void)hipEventDestroy(c->evDown);
+  if (c->downErr) (void)hipHostFree(c->downErr);
   if (c->evUpHost) (void)hipEventDestroy(c->evUpHost);
   if (c->stUp) {
     (void)hipStreamDestroy(c->stUp);
@@ -807,11 +808,19 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     // transfer does not queue behind the kernels of the frame enqueued after it
     if (!c->stDown) S360_HIP(hipStreamCreateWithFlags(&c->stDown, hipStreamNonBlocking));
     if (!c->evDown) S360_HIP(hipEventCreateWithFlags(&c->evDown, hipEventDisableTiming | hipEventBlockingSync));
+    if (!c->downErr) {
+      S360_HIP(hipHostMalloc((void**)&c->downErr, 4 * sizeof(unsigned), hipHostMallocDefault));
+      std::memset(c->downErr, 0, 4 * sizeof(unsigned));
+    }
+    if (!F.downRead[b]) S360_HIP(hipEventCreateWithFlags(&F.downRead[b], hipEventDisableTiming));
     S360_HIP(hipStreamWaitEvent(c->stDown, F.outDone[b], 0));
     S360_HIP(hipMemcpyAsync(out_bgr, F.outBGR[b].p, (size_t)c->g.out_width * c->g.out_height * 3, hipMemcpyDeviceToHost, c->stDown));
+    // the frame's error words travel with it (a later frame's finish stage rewrites outErr[b] as soon as downRead[b] has fired)
+    if (F.outErr[b]) S360_HIP(hipMemcpyAsync(c->downErr, F.outErr[b], 3 * sizeof(unsigned), hipMemcpyHostToHost, c->stDown));
+    S360_HIP(hipEventRecord(F.downRead[b], c->stDown));
     S360_HIP(hipEventRecord(c->evDown, c->stDown));
     const hipEvent_t ev = c->evDown;
-    const unsigned* errw = F.outErr[b];
+    const unsigned* errw = F.outErr[b] ? c->downErr : nullptr;  // (nothing of the slot is touched after the lock is back: it may be gone)
     // The wait is most of a frame long: the context is free meanwhile (the next frame's uploads and enqueue need it).
     // One fetching thread per context: evDown is re-recorded by the next call.
     lk.unlock();

@@ -190,6 +190,7 @@ void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root) {
     else if (me == root) {
       rc = R.Recv(F.sc->poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
       F.poleFrame[u] = F.frames_done;  // this frame's layer (frame_composite refuses an earlier frame's)
+      F.sc->poleOwner[u] = &F;
     }
   }
   const ncclResult_t rc2 = R.GroupEnd();

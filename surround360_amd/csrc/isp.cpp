@@ -261,6 +261,13 @@ void isp_derive_pipe(const s360_isp_config& cfg, const IspDev& d, IspPipeDev& p)
                 cfg.noise_core, d.ccm);
 }
 
+// An object that feeds a live context (s360_frame_upload_raw / _packed: its kernels run on THAT context's upload stream over this
+// object's buffers) cannot develop images on its own stream at the same time: the two streams would race on dRaw / dOut.
+static void refuse_while_feeding(const s360_isp* o, const char* what) {
+  if (o->boundCtx && context_alive(o->boundCtx))
+    throw Error(S360_ERR_STATE, std::string(what) + ": this ISP object feeds a context (s360_frame_upload_raw); use another object, or destroy that context first");
+}
+
 // The generated functions themselves (s360_isp_pipe_generated): every parameter comes from the caller, the object lends its
 // stream and buffers.
 void isp_pipe_generated(s360_isp* o, const s360_camera_isp_gen_args& a) {
@@ -270,6 +277,7 @@ void isp_pipe_generated(s360_isp* o, const s360_camera_isp_gen_args& a) {
   if (a.width < 16 || a.height < 16) throw Error(S360_ERR_INVALID_ARG, "image too small for the accelerated pipeline (needs at least 16x16)");
   if (a.input_stride < a.width) throw Error(S360_ERR_INVALID_ARG, "input_stride is smaller than width");
   if (a.bayer_pattern != 0 && a.bayer_pattern != 1) throw Error(S360_ERR_INVALID_ARG, "bayer_pattern is 0 (GBRG) or 1 (RGGB) at this level");
+  refuse_while_feeding(o, "s360_isp_pipe_generated");
   S360_HIP(hipSetDevice(o->device));
   const int w = a.width, h = a.height;
   IspPipeDev d;
@@ -346,8 +354,8 @@ void isp_init(s360_isp* o, int device, const s360_isp_config& cfg) {
 
 static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out);
 static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH);
-
 void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out) {
+  refuse_while_feeding(o, "s360_isp_process");
   S360_HIP(hipSetDevice(o->device));
   o->dRaw.ensure((size_t)inW * inH * sizeof(uint16_t));
   S360_HIP(hipMemcpyAsync(o->dRaw.p, raw16, (size_t)inW * inH * sizeof(uint16_t), hipMemcpyHostToDevice, o->st));
@@ -357,6 +365,7 @@ void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out
 void isp_process_packed(s360_isp* o, const uint8_t* frame, int bits, int inW, int inH, void* out) {
   if (bits != 8 && bits != 12) throw Error(S360_ERR_INVALID_ARG, "packed frames are 8 or 12 bits per pixel");
   if (bits == 12 && (inW & 1)) throw Error(S360_ERR_INVALID_ARG, "12-bit packed frames need an even width");
+  refuse_while_feeding(o, "s360_isp_process_packed");
   S360_HIP(hipSetDevice(o->device));
   const size_t bytes = bits == 8 ? (size_t)inW * inH : (size_t)inH * (3 * (size_t)inW / 2);
   o->dPacked.ensure(bytes);

@@ -828,6 +828,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
             dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xs, F.poleFlows[cur].as<float2>() + u * xs, W, rowsOf(u), extW,
                                F.sc->poleWarped[u].as<uchar4>(), H);
             F.poleFrame[u] = F.frames_done;
+            F.sc->poleOwner[u] = &F;
           }
       }
       F.extW = extW;
@@ -842,7 +843,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       ProfScope ps(prof, "flatten");  // TRSP:864-885
       F.sc->panoTmp.ensure(en * sizeof(uchar4));
       for (int u = 0; u < 4; ++u)
-        if ((composite_mask & (1 << u)) && (!F.sc->poleWarped[u].p || F.poleFrame[u] != F.frames_done))  // (an earlier frame's layer is not this frame's)
+        if ((composite_mask & (1 << u)) && (!F.sc->poleWarped[u].p || F.poleFrame[u] != F.frames_done || F.sc->poleOwner[u] != &F))  // (an earlier frame's, or another slot's, layer is not this frame's)
           throw Error(S360_ERR_STATE, "composite: the warped layer of pole unit " + std::to_string(u) + " of this frame is neither computed nor received");
       for (int e = 0; e < 2; ++e) {
         if (composite_mask & (1 << e)) {
@@ -899,6 +900,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       const int ob = c->pipeline ? F.out_cur ^ 1 : F.out_cur;
       F.outBGR[ob].ensure((size_t)outW * outH * 3);
       if (!F.outDone[ob]) S360_HIP(hipEventCreateWithFlags(&F.outDone[ob], hipEventDisableTiming));
+      if (F.downRead[ob]) S360_HIP(hipStreamWaitEvent(st, F.downRead[ob], 0));  // a fetch of the frame this buffer held may still run
       const bool resize = (outW != W) || (eyeH != H);
       for (int e = 0; e < 2; ++e) {
         uchar4* eye = F.pano[e].as<uchar4>();

@@ -33,6 +33,8 @@ struct SlotScratch {
   DevBuf panoFlip[2], panoTmp;
   DevBuf topSph, botSph;
   DevBuf warpedExt, poleWarped[4];
+  const void* poleOwner[4] = {nullptr, nullptr, nullptr, nullptr};  // the slot (FrameState) whose frame poleWarped[u] holds: with the
+                                                                    // split phases two slots could interleave (frame_composite checks)
   DevBuf warpPacked, warpTiles;  // this frame's pole warp as packed coordinates + tile boxes (launch_pole_warp_packed)
   DevBuf eyeFinal[2];
   // the sharpen passes' low-pass image and float scratch for ONE group of kSharpenGroup images: the eyes of a batch are
@@ -69,11 +71,16 @@ struct FrameState {
   // that renders behind it (the words are cumulative, so a non-zero value may also come from that next frame's side
   // flows — either way the stream's results are invalid from here on)
   unsigned* outErr[2] = {nullptr, nullptr};
+  // s360_frame_download_equirect_of releases the context while it waits: downRead[i] is recorded on the download stream behind
+  // its copy of outBGR[i] / outErr[i], and the finish stage that next writes buffer i waits for it (a feeder two frames ahead of
+  // the fetching thread must not overwrite a frame that is still being transferred)
+  hipEvent_t downRead[2] = {nullptr, nullptr};
   int out_cur = 0;           // buffer of the most recently ENQUEUED frame
   long long frames_done = 0;  // frames enqueued so far
   long long poleFrame[4] = {-1, -1, -1, -1};  // the frame (value of frames_done) pole unit u's warped layer was computed / received for
   ~FrameState() {
     for (auto& e : outDone) if (e) (void)hipEventDestroy(e);
+    for (auto& e : downRead) if (e) (void)hipEventDestroy(e);
     for (auto& p : outErr) if (p) (void)hipHostFree(p);
   }
   int cur_side = 0, cur_pole = 0, last_side = 0, last_pole = 0;

@@ -398,167 +398,124 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
   }
 }
 
-// Round 5. (1) The alpha mode is a template parameter: mode 1 (3-channel source: the pole projections) evaluates three channels
-// — a quarter of the tap arithmetic of a 17.7 Mpx image was computed and then overwritten with 255. (2) The 32 KB table of
-// 2-D bicubic weights lives in LDS: as a per-pixel fetch from global memory at a data-dependent address (32 bytes per pixel
-// behind the barrier, through an L1 the source boxes stream through) it was an exposed round trip per pixel group; it cannot
-// be loaded per 64 x 16 tile either (32 bytes per pixel again), so (3) workgroups are PERSISTENT: min(tiles, 3 per CU —
-// 48 KB of LDS each) workgroups load the table once and walk the tiles, each XCD's workgroups striding through that XCD's
-// contiguous run of tiles (xcd_tile's order, neighbouring boxes on one L2). The rounding constant is the accumulators'
-// start value. Same bits as before: integer arithmetic, order-independent.
-struct PackedTileWalk {  // tile i of workgroup b out of G; T tiles in all (x fastest, then y, then image)
-  unsigned k, j, W, start, count;
-  __device__ __forceinline__ PackedTileWalk(unsigned b, unsigned G, unsigned T) {
-    if (T >= 64 && (G & 7u) == 0) {
-      k = b & 7u; j = b >> 3; W = G >> 3;
-      const unsigned n = T >> 3, rem = T & 7u;
-      start = k * n + (k < rem ? k : rem);
-      count = n + (k < rem ? 1u : 0u);
-    } else {
-      k = 0; j = b; W = G; start = 0; count = T;
-    }
-  }
-};
-
+// Round 5: the alpha mode is a template parameter — mode 1 (3-channel source: the pole projections) evaluates three channels; a
+// quarter of the tap arithmetic of a 17.7 Mpx image was computed and then overwritten with 255 — and the rounding constant is
+// the accumulators' start value. Measured and NOT adopted (profiles/r05_v2_persistent_remap_warp_blend.json): the 32 KB weight
+// table in LDS under persistent workgroups (3 per CU, 48 KB of LDS each, each XCD's workgroups striding through its contiguous
+// run of tiles): side projections 0.422 against 0.332 ms per 8K frame, pole projections 0.332 / 0.269, pole warp 1.051 / 0.813 —
+// twelve waves per CU whose load -> barrier -> taps phases line up hide less than the 32 resident waves of this form do, whose
+// weight rows come out of L1 / L2.
 template <class MapFn, int ALPHA>
 __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const uchar4* __restrict__ src, int sw, int sh,
                                                                          const unsigned* __restrict__ packed,
-                                                                         const int4* __restrict__ tiles, MapFn mapfn0,
-                                                                         uchar4* __restrict__ dst0, int dw, int dh,
+                                                                         const int4* __restrict__ tiles, MapFn mapfn,
+                                                                         uchar4* __restrict__ dst, int dw, int dh,
                                                                          const short* __restrict__ tab,
                                                                          int yFeatherStart, int featherSize, size_t sbs,
-                                                                         size_t dbs, int tilesX, int tilesY, int batch) {
+                                                                         size_t dbs, int tilesPerImage) {
+  const TileId tile = xcd_tile();  // neighbouring tiles (overlapping source boxes) on the same XCD's L2
+  src += sbs * tile.z;
+  dst += dbs * tile.z;
+  packed += dbs * tile.z;
+  mapfn.advance(dbs * tile.z);
   __shared__ uchar4 s_tile[PT_CAP];
-  __shared__ uint4 s_tab[2048];  // [1024][16] int16 weights
-  const int tid = threadIdx.y * PT_W + threadIdx.x;
-  {
-    const uint4* t4 = reinterpret_cast<const uint4*>(tab);
-    uint4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = t4[tid + 256 * i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s_tab[tid + 256 * i] = v[i];
-  }
-  const unsigned tilesPerImage = (unsigned)tilesX * tilesY;
-  const PackedTileWalk walk(blockIdx.x, gridDim.x, tilesPerImage * (unsigned)batch);
-  constexpr int NCH = ALPHA == 1 ? 3 : 4;
-  for (unsigned it = walk.j; it < walk.count; it += walk.W) {
-    const unsigned Pt = walk.start + it;
-    const unsigned tz = Pt / tilesPerImage, tr = Pt - tz * tilesPerImage;
-    const unsigned ty = tr / (unsigned)tilesX, tx = tr - ty * (unsigned)tilesX;
-    const uchar4* srcI = src + sbs * tz;
-    uchar4* dst = dst0 + dbs * tz;
-    const unsigned* pkI = packed + dbs * tz;
-    const int4 box = tiles[Pt];  // (uniform)
-    const int bx0 = box.x, by0 = box.y, bw = box.z, bh = box.w;
-    const int x = tx * PT_W + threadIdx.x;
-    unsigned pk[4] = {0u, 0u, 0u, 0u};
-    if (bh > 0 && x < dw) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int y = ty * PT_H + threadIdx.y + PT_TY * k;
-        if (y < dh) pk[k] = pkI[(size_t)y * dw + x];
-      }
-    }
-    if (bh > 0) {  // the tile's source box, zero outside the image (BORDER_CONSTANT): requested together with the coordinates
-      // eight pixels (4 rows x 2 column groups) are requested before the first goes to LDS: as load-store pairs in a
-      // runtime loop the ~7 pixels of a thread were as many serialised memory round trips
-      const unsigned* S32 = reinterpret_cast<const unsigned*>(srcI);
-      unsigned* T32 = reinterpret_cast<unsigned*>(s_tile);
-      for (int ly0 = threadIdx.y; ly0 < bh; ly0 += 4 * PT_TY)
-        for (int lx0 = threadIdx.x; lx0 < bw; lx0 += 2 * PT_W) {
-          unsigned v[4][2];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ly = ly0 + j * PT_TY, gy = by0 + ly;
-            const bool rowIn = ly < bh && gy >= 0 && gy < sh;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int lx = lx0 + i * PT_W, gx = bx0 + lx;
-              v[j][i] = (rowIn && lx < bw && gx >= 0 && gx < sw) ? S32[(size_t)gy * sw + gx] : 0u;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int ly = ly0 + j * PT_TY;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int lx = lx0 + i * PT_W;
-              if (ly < bh && lx < bw) T32[ly * bw + lx] = v[j][i];
-            }
-          }
-        }
-    }
-    __syncthreads();  // the box (and, the first time, the weight table) is in LDS
+  const int4 box = tiles[(size_t)tilesPerImage * tile.z + (size_t)tile.y * gridDim.x + tile.x];  // (uniform)
+  const int bx0 = box.x, by0 = box.y, bw = box.z, bh = box.w;
+  const int x = tile.x * PT_W + threadIdx.x;
+  unsigned pk[4] = {0u, 0u, 0u, 0u};
+  if (bh > 0 && x < dw) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int y = ty * PT_H + threadIdx.y + PT_TY * k;
-      if (x >= dw || y >= dh) continue;
-      uchar4 o = make_uchar4(0, 0, 0, 0);
-      if (bh > 0) {
-        if (pk[k] & 0x80000000u) {
-          const int rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
-          const uint4 wa = s_tab[(pk[k] & 1023u) * 2], wb = s_tab[(pk[k] & 1023u) * 2 + 1];
-          const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-          const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + ry * bw + rx;
-          int acc[4] = {1 << 14, 1 << 14, 1 << 14, 1 << 14};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned p0 = T[r * bw], p1 = T[r * bw + 1], p2 = T[r * bw + 2], p3 = T[r * bw + 3];
-            const s16x2 w01 = __builtin_bit_cast(s16x2, wq[2 * r]), w23 = __builtin_bit_cast(s16x2, wq[2 * r + 1]);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-              const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
-              const s16x2 lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p1, p0, sel));
-              const s16x2 hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p3, p2, sel));
-              acc[ch] = __builtin_amdgcn_sdot2(lo, w01, acc[ch], false);
-              acc[ch] = __builtin_amdgcn_sdot2(hi, w23, acc[ch], false);
-            }
-          }
-          o = make_uchar4((unsigned char)sat_u8(acc[0] >> 15), (unsigned char)sat_u8(acc[1] >> 15),
-                          (unsigned char)sat_u8(acc[2] >> 15), NCH == 4 ? (unsigned char)sat_u8(acc[3] >> 15) : (unsigned char)0);
-        }
-      } else if (bh < 0) {  // box too large for LDS: per-tap gather through the map itself
-        MapFn mapfn = mapfn0;
-        mapfn.advance(dbs * tz);
-        const float2 m = mapfn(x, y);
-        int sx, sy, fxy;
-        remap_coord(m.x, m.y, &sx, &sy, &fxy);
-        if (!(sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0)) o = remap_cubic_u8c4_at(srcI, sw, sh, m.x, m.y, tab);
-      }
-      if (ALPHA == 1) {
-        // remap ran on 3 channels, cvtColor BGR2BGRA sets 255, the feather loop overwrites the last rows
-        int a = 255;
-        if (y >= yFeatherStart) {
-          const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
-          a = (int)(unsigned char)(255.0f * alpha);
-        }
-        o.w = (unsigned char)a;
-      } else if (ALPHA == 2) {
-        // 4-channel source (pole removal result): the interpolated alpha is kept, the feather rows take the minimum
-        // (TRSP:625-634)
-        if (y >= yFeatherStart) {
-          const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
-          const unsigned char a = (unsigned char)(255.0f * alpha);
-          o.w = o.w < a ? o.w : a;
-        }
-      }
-      dst[(size_t)y * dw + x] = o;
+      const int y = tile.y * PT_H + threadIdx.y + PT_TY * k;
+      if (y < dh) pk[k] = packed[(size_t)y * dw + x];
     }
-    __syncthreads();  // every tap of this tile has been read: the next box may overwrite it
   }
-}
-
-// workgroups of one packed-remap launch: three per CU (48 KB of LDS each), a multiple of 8 so that each XCD's share is whole
-static unsigned packed_remap_grid(size_t tiles) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = n > 0 ? n : 256;
+  if (bh > 0) {  // the tile's source box, zero outside the image (BORDER_CONSTANT): requested together with the coordinates
+    // eight pixels (4 rows x 2 column groups) are requested before the first goes to LDS: as load-store pairs in a
+    // runtime loop the ~7 pixels of a thread were as many serialised memory round trips
+    const unsigned* S32 = reinterpret_cast<const unsigned*>(src);
+    unsigned* T32 = reinterpret_cast<unsigned*>(s_tile);
+    for (int ly0 = threadIdx.y; ly0 < bh; ly0 += 4 * PT_TY)
+      for (int lx0 = threadIdx.x; lx0 < bw; lx0 += 2 * PT_W) {
+        unsigned v[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ly = ly0 + j * PT_TY, gy = by0 + ly;
+          const bool rowIn = ly < bh && gy >= 0 && gy < sh;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int lx = lx0 + i * PT_W, gx = bx0 + lx;
+            v[j][i] = (rowIn && lx < bw && gx >= 0 && gx < sw) ? S32[(size_t)gy * sw + gx] : 0u;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ly = ly0 + j * PT_TY;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int lx = lx0 + i * PT_W;
+            if (ly < bh && lx < bw) T32[ly * bw + lx] = v[j][i];
+          }
+        }
+      }
+    __syncthreads();
   }
-  const size_t g = (size_t)cus * 3;
-  return (unsigned)(tiles < g ? tiles : g);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = tile.y * PT_H + threadIdx.y + PT_TY * k;
+    if (x >= dw || y >= dh) continue;
+    uchar4 o = make_uchar4(0, 0, 0, 0);
+    if (bh > 0) {
+      if (pk[k] & 0x80000000u) {
+        const int rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
+        // (the weight rows are fetched here, per pixel: requesting all four in front of the barrier cost 30 VGPRs and
+        // measured 10 % slower, profiles/r03_v7 vs r3i)
+        const uint4* w4 = reinterpret_cast<const uint4*>(tab + (pk[k] & 1023u) * 16);
+        const uint4 wa = w4[0], wb = w4[1];
+        const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + ry * bw + rx;
+        int acc[4] = {1 << 14, 1 << 14, 1 << 14, 1 << 14};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned p0 = T[r * bw], p1 = T[r * bw + 1], p2 = T[r * bw + 2], p3 = T[r * bw + 3];
+          const s16x2 w01 = __builtin_bit_cast(s16x2, wq[2 * r]), w23 = __builtin_bit_cast(s16x2, wq[2 * r + 1]);
+#pragma unroll
+          for (int ch = 0; ch < (ALPHA == 1 ? 3 : 4); ++ch) {
+            const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
+            const s16x2 lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p1, p0, sel));
+            const s16x2 hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p3, p2, sel));
+            acc[ch] = __builtin_amdgcn_sdot2(lo, w01, acc[ch], false);
+            acc[ch] = __builtin_amdgcn_sdot2(hi, w23, acc[ch], false);
+          }
+        }
+        o = make_uchar4((unsigned char)sat_u8(acc[0] >> 15), (unsigned char)sat_u8(acc[1] >> 15), (unsigned char)sat_u8(acc[2] >> 15),
+                        ALPHA == 1 ? (unsigned char)0 : (unsigned char)sat_u8(acc[3] >> 15));
+      }
+    } else if (bh < 0) {  // box too large for LDS: per-tap gather through the map itself
+      const float2 m = mapfn(x, y);
+      int sx, sy, fxy;
+      remap_coord(m.x, m.y, &sx, &sy, &fxy);
+      if (!(sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0)) o = remap_cubic_u8c4_at(src, sw, sh, m.x, m.y, tab);
+    }
+    if (ALPHA == 1) {
+      // remap ran on 3 channels, cvtColor BGR2BGRA sets 255, the feather loop overwrites the last rows
+      int a = 255;
+      if (y >= yFeatherStart) {
+        const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
+        a = (int)(unsigned char)(255.0f * alpha);
+      }
+      o.w = (unsigned char)a;
+    } else if (ALPHA == 2) {
+      // 4-channel source (pole removal result): the interpolated alpha is kept, the feather rows take the minimum
+      // (TRSP:625-634)
+      if (y >= yFeatherStart) {
+        const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
+        const unsigned char a = (unsigned char)(255.0f * alpha);
+        o.w = o.w < a ? o.w : a;
+      }
+    }
+    dst[(size_t)y * dw + x] = o;
+  }
 }
 
 // ---- pole removal (PoleRemoval.cpp:32-188) -------------------------------------------------------------------
@@ -1661,19 +1618,19 @@ void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, i
                                     const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
                                     int yFeatherStart, int featherSize, int batch) {
   MapFromBuffer mf{map, dw};
-  const int tx = cdiv(dw, PT_W), ty = cdiv(dh, PT_H);
-  const dim3 grid(packed_remap_grid((size_t)tx * ty * batch)), block(PT_W, PT_TY);
+  const dim3 grid(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), block(PT_W, PT_TY);
   const int4* t4 = reinterpret_cast<const int4*>(tiles);
   const size_t sbs = (size_t)sw * sh, dbs = (size_t)dw * dh;
+  const int nt = (int)remap_packed_tiles(dw, dh);
   if (alpha_mode == 1)
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, tx, ty, batch);
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
   else if (alpha_mode == 2)
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 2>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, tx, ty, batch);
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
   else
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, tx, ty, batch);
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
 }
 void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
                           const DevTables& T) {
@@ -1746,9 +1703,9 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
   const int nt = (int)remap_packed_tiles(pw.extW, pw.rows);
   hipLaunchKernelGGL((k_remap_pack<MapFromPoleFlow>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1), dim3(PT_W, PT_TY), 0, st,
                      mf, pw.extW, pw.rows, pw.extW, pw.rows, packed, reinterpret_cast<int4*>(tiles), (size_t)0, nt);
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(packed_remap_grid((size_t)nt)), dim3(PT_W, PT_TY), 0, st,
-                     extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf, warpedExt, pw.extW, pw.rows,
-                     T.bicubic_i, 0, 1, (size_t)0, (size_t)0, cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1);
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
+                     dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
+                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   if ((pw.cols & 3) == 0 && (pw.extW & 3) == 0 && pw.cols + ((pw.maxBlendX + 3) & ~3) <= pw.extW &&

@@ -236,9 +236,11 @@ def test_raw_frames_straight_into_the_renderer(tmp_path, rig_json, oracle, s360l
         got = b.download_equirect()
         assert want.std() > 5
         assert np.array_equal(got, want), "%d bytes differ" % int((got != want).sum())
+        from surround360_amd import _capi
+        with pytest.raises(_capi.S360Error):  # the object feeds context b (its kernels run on b's upload stream over its buffers)
+            isp.get_image(raws[0])
         isp8 = I.CameraIsp(I.config_from_json(js, 8))
         try:
-            from surround360_amd import _capi
             with pytest.raises(_capi.S360Error):
                 b.upload_raw(isp8, 0, raws[0])  # an 8-bit ISP is not the reference's chain
         finally:

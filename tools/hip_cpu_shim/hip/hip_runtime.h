@@ -35,7 +35,7 @@ extern thread_local dim3 blockDim, gridDim;
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0 };
-enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 enum { hipStreamNonBlocking = 1 };
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return hipSuccess; }

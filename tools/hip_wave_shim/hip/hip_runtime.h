@@ -85,7 +85,7 @@ void launch(std::function<void()> body, dim3 grid, dim3 block);
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0 };
-enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventBlockingSync = 1, hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 // everything is synchronous here: a kernel has run when its launch returns, copies are memcpy, streams and events are names
