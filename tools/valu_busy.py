@@ -41,11 +41,17 @@ def main():
         dm = {n: n for n in names}
     out = {}
     for n, a in agg.items():
-        if "SQ_ACTIVE_INST_VALU" not in a or a["ns"] <= 0:
+        if ("SQ_ACTIVE_INST_VALU" not in a and "SQ_INSTS_VALU" not in a) or a["ns"] <= 0:
             continue
         cyc = a["ns"] * clock  # ns x GHz = cycles
-        rec = {"launches": a["launches"], "ms": round(a["ns"] / 1e6, 3),
-               "valu_busy": round(a["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * cyc), 4)}
+        rec = {"launches": a["launches"], "ms": round(a["ns"] / 1e6, 3)}
+        if "SQ_ACTIVE_INST_VALU" in a:
+            rec["valu_busy"] = round(a["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * cyc), 4)
+        if "SQ_INSTS_VALU" in a:  # executed wave-level VALU instructions
+            rec["valu_insts_per_launch"] = round(a["SQ_INSTS_VALU"] / a["launches"], 1)
+            for extra in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+                if extra in a:
+                    rec[extra.lower()[3:] + "_per_launch"] = round(a[extra] / a["launches"], 1)
         if "SQ_ACTIVE_INST_LDS" in a:
             rec["lds_busy"] = round(a["SQ_ACTIVE_INST_LDS"] * 4.0 / (simds * cyc), 4)
         if "SQ_WAVE_CYCLES" in a and a["SQ_WAVE_CYCLES"] > 0:
@@ -58,7 +64,7 @@ def main():
     print("# VALU busy = SQ_ACTIVE_INST_VALU x 4 / (%d SIMDs x duration x %.1f GHz); one SQ pass" % (simds, clock))
     print("%-72s %8s %10s %9s %9s %8s %8s" % ("kernel", "launches", "ms", "VALU busy", "LDS busy", "waiting", "issuing"))
     for n, r in sorted(out.items(), key=lambda kv: -kv[1]["ms"]):
-        print("%-72s %8d %10.3f %9.3f %9s %8s %8s" % (n[:72], r["launches"], r["ms"], r["valu_busy"], r.get("lds_busy", "-"),
+        print("%-72s %8d %10.3f %9s %9s %8s %8s" % (n[:72], r["launches"], r["ms"], r.get("valu_busy", "-"), r.get("lds_busy", "-"),
                                                   r.get("wave_time_waiting", "-"), r.get("wave_time_issuing", "-")))
 
 
