@@ -288,6 +288,10 @@ int s360_comm_get_unique_id(void* id_out /* S360_COMM_ID_BYTES */);
 int s360_comm_init_rank(s360_ctx* ctx, const void* id, int rank, int nranks);
 int s360_comm_init_all(s360_ctx* const* ctxs, int n);
 int s360_comm_destroy(s360_ctx* ctx);
+/* The file the RCCL entry points were resolved from (librccl is loaded on first use: S360_RCCL_LIB=<path> in the environment
+ * names it outright; otherwise by soname — a process that already holds an RCCL, e.g. torch's copy, shares it — then
+ * /opt/rocm/lib). S360_RCCL_VERBOSE=1 prints it to stderr once. NULL (and s360_last_error) when no librccl can be loaded. */
+const char* s360_comm_library_path(void);
 /* bounds: nranks + 1 non-decreasing pair indices from 0 to n_side. */
 int s360_frame_gather_strips(s360_ctx* ctx, const int* bounds, int root);
 /* The pole units on several GPUs as well (SURVEY §8e second stage; the reference runs its four poleToSideFlowThread

@@ -730,6 +730,11 @@ int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uin
 int s360_comm_get_unique_id(void* id_out) {
   return guard(nullptr, [&] { need(id_out, "null argument"); comm_unique_id(id_out); });
 }
+const char* s360_comm_library_path(void) {
+  const char* p = nullptr;
+  (void)guard(nullptr, [&] { p = comm_library_path(); });
+  return p;
+}
 int s360_comm_init_rank(s360_ctx* c, const void* id, int rank, int nranks) {
   return guard(c, [&] { need(c && id, "null argument"); comm_init_rank(c, id, rank, nranks); });
 }

@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -33,15 +35,23 @@ struct Rccl {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  std::string err;
+  std::string err, path;
 };
 Rccl& rccl() {
   static Rccl R;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (R.h) break;
+    // S360_RCCL_LIB names the library outright (a node whose default is not the one to use); otherwise by soname — in a process
+    // that already holds an RCCL (torch ships its own copy) that one is shared, which is what one process wants —, then ROCm's
+    const char* forced = std::getenv("S360_RCCL_LIB");
+    if (forced && forced[0]) {
+      R.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+      if (!R.h) { R.err = std::string("S360_RCCL_LIB=") + forced + ": " + dlerror(); return; }
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (R.h) break;
+      }
     }
     if (!R.h) { R.err = std::string("librccl not found: ") + dlerror(); return; }
     auto sym = [&](const char* n) { void* p = dlsym(R.h, n); if (!p) R.err = std::string("librccl lacks ") + n; return p; };
@@ -54,6 +64,10 @@ Rccl& rccl() {
     R.Send = (decltype(R.Send))sym("ncclSend");
     R.Recv = (decltype(R.Recv))sym("ncclRecv");
     R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    Dl_info di;
+    if (R.GetUniqueId && dladdr((void*)R.GetUniqueId, &di) && di.dli_fname) R.path = di.dli_fname;
+    const char* v = std::getenv("S360_RCCL_VERBOSE");
+    if (v && v[0] == '1') std::fprintf(stderr, "libs360: RCCL entry points from %s\n", R.path.empty() ? "?" : R.path.c_str());
   });
   if (!R.err.empty()) throw Error(S360_ERR_STATE, R.err);
   return R;
@@ -63,6 +77,11 @@ void nccl_ck(ncclResult_t r, const char* what) {
 }
 }  // namespace
 
+const char* comm_library_path() {
+  static std::string p;
+  p = rccl().path;
+  return p.c_str();
+}
 void comm_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == S360_COMM_ID_BYTES, "ncclUniqueId size");
   ncclUniqueId id;

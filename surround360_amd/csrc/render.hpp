@@ -117,6 +117,7 @@ void frame_cubemap(s360_ctx* c, int face_w, int face_h, bool video, int* ow, int
 
 // RCCL strip gather of the sharded frame (comm.cpp)
 void comm_unique_id(void* id128);
+const char* comm_library_path();  // the file the RCCL entry points were resolved from (S360_RCCL_LIB overrides the search)
 void comm_init_rank(s360_ctx* c, const void* id128, int rank, int nranks);
 void comm_init_all(s360_ctx* const* ctxs, int n);
 void comm_destroy(s360_ctx* c);

@@ -155,3 +155,17 @@ def test_page_locked_buffers_without_a_device(s360lib):
     s360lib.s360_host_free(None)
     assert s360lib.s360_frame_uploads_complete(None) < 0
     assert s360lib.s360_frame_download_equirect_of(None, 0, C.c_void_p()) < 0
+
+
+def test_rccl_library_resolution(s360lib):
+    """s360_comm_library_path: librccl is loaded on first use and the file the entry points came from is reported (the
+    hardware-day checklist, tools/gpu_multi.sh, prints it first); S360_RCCL_LIB names another one, and a wrong name is an error
+    with the reason, not a silent fall-back to the default."""
+    import subprocess
+    import sys
+    p = s360lib.s360_comm_library_path()
+    assert p and b"rccl" in p, p
+    code = ("import ctypes as C; L = C.CDLL(%r); L.s360_comm_library_path.restype = C.c_char_p; L.s360_last_error.restype = C.c_char_p;"
+            "p = L.s360_comm_library_path(); print(p, L.s360_last_error(None))" % os.path.join(ROOT, "surround360_amd", "libs360.so"))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, S360_RCCL_LIB="/nonexistent/librccl.so"), text=True)
+    assert out.startswith("None") and "S360_RCCL_LIB=/nonexistent/librccl.so" in out, out

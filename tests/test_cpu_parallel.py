@@ -133,3 +133,13 @@ def test_streams_sharing_a_gpu_are_frame_slots_of_one_context(tmp_path, emu_prog
     slots), 3 streams of one frame."""
     refprog.check_two_streams(os.path.join(emu_programs, "TestRenderStereoPanorama"), tmp_path, dict(os.environ, EMU_DEVICES="2"),
                               more_args=["--stream_gpus", "1"], streams=streams)
+
+
+def test_hardware_day_checklist_walks_on_the_emulation(emu_programs):
+    """tools/gpu_multi.sh's checklist for an N-GPU node (tools/multi_gpu_check.py: which librccl, comm_init_all + loopback on every
+    rank, a two-frame sharded render against the reference program's digests; on hardware also bench.py --gpus N), its first
+    three steps on two emulated devices with the strict RCCL stand-in: the script itself must not be what fails on the day."""
+    import sys
+    e = dict(os.environ, S360_TEST_EMULATED_LIB="1", EMU_DEVICES="2", EMU_RCCL_STRICT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multi_gpu_check.py"), "2"], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and "all steps passed on 2 GPUs" in r.stdout and "0 differ" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
