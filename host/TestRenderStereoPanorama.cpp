@@ -515,7 +515,8 @@ void write_state(const Job& J, const std::string& frame) {
     coders.push([it] {
       if (!it->img.empty()) {
         try {
-          pngio::write(it->path, it->img.data(), it->w, it->h, 4, 1, 1);  // (one deflate thread each: the pool is the parallelism)
+          // (the pool is the parallelism; only the pole units' 85 MB images get deflate threads of their own)
+          pngio::write(it->path, it->img.data(), it->w, it->h, 4, 1, it->img.size() > ((size_t)32 << 20) ? 4 : 1);
         } catch (const std::exception& e) {
           die(e.what());
         }

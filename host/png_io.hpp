@@ -98,13 +98,22 @@ inline void unfilter_paeth_px(uint8_t* cur, const uint8_t* prev, size_t stride) 
 // (png_set_strip_16), grey becomes B=G=R, Adam7-interlaced files are de-interlaced.
 // `im` is overwritten; its pixel buffer is reused when it is large enough (a stream hands the previous frames' images
 // back to its decoders: 17 x 12.6 MB mapped, page-faulted and unmapped per frame cost more than the decoding).
+inline int g_read_threads = 0;  // threads of the parallel band reader (0: by the image's size, up to 8; < 0: sequential reader only)
 inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) throw std::runtime_error("failed to load image: " + path);
   std::vector<uint8_t> file;
+  if (std::fseek(f, 0, SEEK_END) == 0) {  // the whole file in one read (state images are up to 85 MB)
+    const long sz = std::ftell(f);
+    std::rewind(f);
+    if (sz > 0) {
+      file.resize((size_t)sz);
+      file.resize(std::fread(file.data(), 1, (size_t)sz, f));
+    }
+  }
   uint8_t buf[1 << 16];
   size_t n;
-  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);  // (a source that cannot seek, or grew)
   std::fclose(f);
   static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
   if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw std::runtime_error("not a PNG file: " + path);
@@ -112,6 +121,8 @@ inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
   int w = 0, h = 0, depth = 0, ctype = -1, interlace = 0;
   bool have_ihdr = false;
   std::vector<uint8_t> idat, plte, trns;
+  std::vector<std::pair<size_t, size_t>> idat_chunks;  // (offset, length) in `file`
+  int band_rows = 0;                                   // "sbNd": this writer's independent bands (write_rows)
   while (pos + 12 <= file.size()) {
     const uint32_t len = be32(&file[pos]);
     const char* type = (const char*)&file[pos + 4];
@@ -126,7 +137,8 @@ inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
       have_ihdr = true;
     } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
     else if (!std::memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
-    else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+    else if (!std::memcmp(type, "sbNd", 4) && len == 4) band_rows = (int)std::min<uint32_t>(be32(data), 65535u);
+    else if (!std::memcmp(type, "IDAT", 4)) idat_chunks.emplace_back(pos + 8, (size_t)len);
     else if (!std::memcmp(type, "IEND", 4)) break;
     pos += 12 + len;
   }
@@ -151,6 +163,53 @@ inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
   const bool has_alpha = ctype == 4 || ctype == 6 || (ctype == 3 && !trns.empty());
   im.w = w; im.h = h; im.c = (keep_alpha && has_alpha) ? 4 : 3;
   im.px.resize((size_t)w * h * im.c);
+  // A file of this writer (write_rows with the Sub filter): the zlib header in an IDAT chunk of its own, then one IDAT chunk per
+  // band of `band_rows` scanlines, each an independent sync-flushed raw-deflate segment, every scanline filtered with Sub — said
+  // by the private ancillary chunk "sbNd". Such bands are inflated, unfiltered and converted IN PARALLEL (a frame's state images
+  // are up to 85 MB of scanlines each, and one zlib stream inflates on one thread). Anything unexpected — another band count, a
+  // filter that needs the row above, a segment that does not inflate to its size — falls back to the sequential reader below.
+  if (g_read_threads >= 0 && band_rows > 0 && !interlace && depth == 8 && (ctype == 2 || ctype == 6) && idat_chunks.size() >= 3 &&
+      idat_chunks[0].second == 2 && idat_chunks.back().second == 4 && (int)idat_chunks.size() - 2 == (h + band_rows - 1) / band_rows) {
+    const int nb = (int)idat_chunks.size() - 2;  // (zlib header, the bands, Adler-32)
+    const size_t stride = row_bytes(w), line = stride + 1;
+    const int want = g_read_threads > 0 ? g_read_threads : (int)std::min<size_t>(8, std::max<size_t>(1, total / ((size_t)8 << 20)));
+    const int nthreads = std::max(1, std::min(want, nb));
+    std::atomic<int> next(0);
+    std::atomic<bool> bad(false);
+    auto worker = [&] {
+      std::vector<uint8_t> buf;
+      for (int bi = next.fetch_add(1); bi < nb && !bad.load(); bi = next.fetch_add(1)) {
+        const int y0 = bi * band_rows, rows = std::min(band_rows, h - y0);
+        buf.resize((size_t)rows * line);
+        z_stream z2;
+        std::memset(&z2, 0, sizeof z2);
+        if (inflateInit2(&z2, -15) != Z_OK) { bad = true; return; }
+        z2.next_in = &file[idat_chunks[bi + 1].first];
+        z2.avail_in = (uInt)idat_chunks[bi + 1].second;
+        z2.next_out = buf.data();
+        z2.avail_out = (uInt)buf.size();
+        const int rc = inflate(&z2, Z_SYNC_FLUSH);
+        const bool ok = (rc == Z_OK || rc == Z_STREAM_END) && z2.avail_out == 0 && (z2.avail_in == 0 || rc == Z_STREAM_END);
+        inflateEnd(&z2);
+        if (!ok) { bad = true; return; }
+        for (int r = 0; r < rows; ++r) {
+          uint8_t* cur = buf.data() + (size_t)r * line + 1;
+          if (cur[-1] == 1) { for (size_t i = (size_t)fbpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - fbpp]); }
+          else if (cur[-1] != 0) { bad = true; return; }
+          uint8_t* o = &im.px[(size_t)(y0 + r) * w * im.c];
+          const uint8_t* sp = cur;
+          if (im.c == 3) for (int px = 0; px < w; ++px, sp += sc, o += 3) { o[0] = sp[2]; o[1] = sp[1]; o[2] = sp[0]; }
+          else for (int px = 0; px < w; ++px, sp += 4, o += 4) { o[0] = sp[2]; o[1] = sp[1]; o[2] = sp[0]; o[3] = sp[3]; }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    if (!bad.load()) return;
+  }
+  for (const auto& ch : idat_chunks) idat.insert(idat.end(), file.begin() + ch.first, file.begin() + ch.first + ch.second);
   if (idat.empty()) throw std::runtime_error("corrupt PNG data: " + path);
   // The zlib stream is inflated a band of scanlines at a time and each band is unfiltered and converted while it is
   // still in cache (a 2048 x 2048 camera image is 12.6 MB of scanlines; 17 of them are decoded at once per frame).
@@ -405,6 +464,11 @@ inline void write_rows(const std::string& path, FillRow fill_row, int w, int h, 
   put32(ihdr, (uint32_t)w); put32(ihdr + 4, (uint32_t)h);
   ihdr[8] = (uint8_t)depth; ihdr[9] = c == 3 ? 2 : 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
   chunk(f, "IHDR", ihdr, 13);
+  if (g_write_filter == 1 && depth == 8) {  // what lets read_into take the bands in parallel (ancillary, private, safe to copy)
+    uint8_t br[4];
+    put32(br, (uint32_t)rows_per_band);
+    chunk(f, "sbNd", br, 4);
+  }
   // zlib stream = header, the bands' deflate data, Adler-32; one IDAT chunk per piece
   static const uint8_t zhdr[2] = {0x78, 0x01};
   chunk(f, "IDAT", zhdr, 2);
@@ -464,9 +528,17 @@ inline std::vector<uint16_t> read_gray(const std::string& path, int* w_out, int*
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) throw std::runtime_error("failed to load image: " + path);
   std::vector<uint8_t> file;
+  if (std::fseek(f, 0, SEEK_END) == 0) {  // the whole file in one read (state images are up to 85 MB)
+    const long sz = std::ftell(f);
+    std::rewind(f);
+    if (sz > 0) {
+      file.resize((size_t)sz);
+      file.resize(std::fread(file.data(), 1, (size_t)sz, f));
+    }
+  }
   uint8_t buf[1 << 16];
   size_t n;
-  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);  // (a source that cannot seek, or grew)
   std::fclose(f);
   static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
   if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw std::runtime_error("not a PNG file: " + path);
