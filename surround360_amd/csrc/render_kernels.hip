@@ -400,11 +400,17 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
 
 // Round 5: the alpha mode is a template parameter — mode 1 (3-channel source: the pole projections) evaluates three channels; a
 // quarter of the tap arithmetic of a 17.7 Mpx image was computed and then overwritten with 255 — and the rounding constant is
-// the accumulators' start value. Measured and NOT adopted (profiles/r05_v2_persistent_remap_warp_blend.json): the 32 KB weight
-// table in LDS under persistent workgroups (3 per CU, 48 KB of LDS each, each XCD's workgroups striding through its contiguous
-// run of tiles): side projections 0.422 against 0.332 ms per 8K frame, pole projections 0.332 / 0.269, pole warp 1.051 / 0.813 —
-// twelve waves per CU whose load -> barrier -> taps phases line up hide less than the 32 resident waves of this form do, whose
-// weight rows come out of L1 / L2.
+// the accumulators' start value: side projections 0.332 -> 0.300 ms per 8K frame, pole projections 0.269 -> 0.261, pole warp
+// 0.813 -> 0.793.
+// Measured twice and NOT adopted: the 32 KB weight table in LDS. It has to be loaded once per workgroup, not once per 64 x 16 tile
+// (that would be the same 32 bytes per pixel again), i.e. PERSISTENT workgroups — 3 per CU at 48 KB of LDS, each XCD's
+// workgroups striding through its contiguous run of tiles. (1) As it stands, load -> barrier -> taps -> barrier per tile: 0.422 /
+// 0.332 / 1.051 ms (profiles/r05_v2_persistent_remap_warp_blend.json). (2) With the next tile's packed coordinates and source
+// box in flight into registers while this tile's taps run (NI x NJ dwords per thread, the record of the tile after that on its
+// way; rows / columns beyond the pattern loaded when the tile is stored): 0.384 / 0.286 / 0.979 ms against 0.300 / 0.261 /
+// 0.793 of this form on the same box (profiles/r05_v4_remap_persistent_prefetch_ab.json). Twelve waves per CU whose phases line
+// up leave the VALUs idle more than the weight rows' trips to L1 / L2 cost the 32 resident waves of this form (VALU 63 % / 53 %
+// busy, profiles/r05_v3_valu_busy.txt); both variants were bit-exact on the emulation and on the GPU and are gone.
 template <class MapFn, int ALPHA>
 __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const uchar4* __restrict__ src, int sw, int sh,
                                                                          const unsigned* __restrict__ packed,
@@ -516,213 +522,6 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
     }
     dst[(size_t)y * dw + x] = o;
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Packed bicubic remap, PERSISTENT form with the next tile's loads in flight (round 5). The one-workgroup-per-tile kernel above
-// keeps its VALUs 57 % busy: every pixel fetches its 32-byte weight row from global memory at a data-dependent address (64
-// lanes, up to 64 cache lines per load instruction: the texture-address path is what its waves queue for), and a tile's
-// memory phase and its taps meet at a barrier. Here the 32 KB weight table lives in LDS (loaded once per workgroup:
-// workgroups are persistent, 3 per CU at 48 KB of LDS each, each XCD's workgroups striding through that XCD's contiguous run
-// of tiles), and a workgroup software-pipelines its tiles: while tile t's taps run out of LDS, tile t+1's packed coordinates
-// and source box (NI x NJ dwords per thread: a 64 NI x 4 NJ box) are in flight into registers and tile t+2's box record is on
-// its way; the LDS tile is rewritten between two barriers. (Without the prefetch the same kernel was SLOWER than the
-// one-workgroup-per-tile form — 0.422 against 0.332 ms for the side projections of an 8K frame: twelve waves per CU whose
-// phases line up hide nothing of each other.) Rows / columns of a box beyond the prefetched pattern are loaded when the tile
-// is stored. Integer arithmetic throughout: same bits as the other forms.
-struct PackedTileWalk {  // tile i of workgroup b out of G; T tiles in all (x fastest, then y, then image)
-  unsigned j, W, start, count;
-  __device__ __forceinline__ PackedTileWalk(unsigned b, unsigned G, unsigned T) {
-    if (T >= 64 && (G & 7u) == 0) {
-      const unsigned k = b & 7u, n = T >> 3, rem = T & 7u;
-      j = b >> 3; W = G >> 3;
-      start = k * n + (k < rem ? k : rem);
-      count = n + (k < rem ? 1u : 0u);
-    } else {
-      j = b; W = G; start = 0; count = T;
-    }
-  }
-};
-
-template <class MapFn, int ALPHA, int NI, int NJ>
-__global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed_p(const uchar4* __restrict__ src, int sw, int sh,
-                                                                           const unsigned* __restrict__ packed,
-                                                                           const int4* __restrict__ tiles, MapFn mapfn0,
-                                                                           uchar4* __restrict__ dst0, int dw, int dh,
-                                                                           const short* __restrict__ tab, int yFeatherStart,
-                                                                           int featherSize, size_t sbs, size_t dbs, int tilesX,
-                                                                           int tilesY, int batch) {
-  __shared__ unsigned s_tile[PT_CAP];
-  __shared__ uint4 s_tab[2048];  // [1024][16] int16 weights
-  const int tid = threadIdx.y * PT_W + threadIdx.x;
-  {
-    const uint4* t4 = reinterpret_cast<const uint4*>(tab);
-    uint4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = t4[tid + 256 * i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s_tab[tid + 256 * i] = v[i];
-  }
-  const unsigned tilesPerImage = (unsigned)tilesX * tilesY;
-  const PackedTileWalk walk(blockIdx.x, gridDim.x, tilesPerImage * (unsigned)batch);
-  constexpr int NCH = ALPHA == 1 ? 3 : 4;
-  const unsigned* S32all = reinterpret_cast<const unsigned*>(src);
-  struct Tile { int4 box; unsigned tz, tx, ty; };
-  auto tile_of = [&](unsigned it, int4 rec) {
-    const unsigned Pt = walk.start + it;
-    Tile t;
-    t.box = rec;
-    t.tz = Pt / tilesPerImage;
-    const unsigned tr = Pt - t.tz * tilesPerImage;
-    t.ty = tr / (unsigned)tilesX;
-    t.tx = tr - t.ty * (unsigned)tilesX;
-    return t;
-  };
-  unsigned pkN[4], vN[NJ][NI];
-  // request tile t's packed coordinates and the part of its box the NI x NJ pattern covers (no waiting here)
-  auto issue = [&](const Tile& t) {
-    const int bx0 = t.box.x, by0 = t.box.y, bw = t.box.z, bh = t.box.w;
-    const int x = t.tx * PT_W + threadIdx.x;
-    const unsigned* pkI = packed + dbs * t.tz;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int y = t.ty * PT_H + threadIdx.y + PT_TY * k;
-      pkN[k] = (bh > 0 && x < dw && y < dh) ? pkI[(size_t)y * dw + x] : 0u;
-    }
-    const unsigned* S32 = S32all + sbs * t.tz;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int ly = threadIdx.y + j * PT_TY, gy = by0 + ly;
-      const bool rowIn = bh > 0 && ly < bh && gy >= 0 && gy < sh;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int lx = threadIdx.x + i * PT_W, gx = bx0 + lx;
-        vN[j][i] = (rowIn && lx < bw && gx >= 0 && gx < sw) ? S32[(size_t)gy * sw + gx] : 0u;
-      }
-    }
-  };
-  unsigned itI = walk.j;  // the next tile to request
-  int4 recI = itI < walk.count ? tiles[walk.start + itI] : make_int4(0, 0, 0, 0);
-  Tile nextT = tile_of(itI, recI);
-  if (itI < walk.count) issue(nextT);
-  itI += walk.W;
-  recI = itI < walk.count ? tiles[walk.start + itI] : make_int4(0, 0, 0, 0);
-  for (unsigned it = walk.j; it < walk.count; it += walk.W) {
-    const Tile cur = nextT;
-    const int bx0 = cur.box.x, by0 = cur.box.y, bw = cur.box.z, bh = cur.box.w;
-    unsigned pk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pk[k] = pkN[k];
-    if (bh > 0) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int ly = threadIdx.y + j * PT_TY;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int lx = threadIdx.x + i * PT_W;
-          if (ly < bh && lx < bw) s_tile[ly * bw + lx] = vN[j][i];
-        }
-      }
-      if (bh > NJ * PT_TY || bw > NI * PT_W) {  // what the pattern does not cover (uniform; a quarter of the side tiles at 8K)
-        const unsigned* S32 = S32all + sbs * cur.tz;
-        for (int ly = threadIdx.y; ly < bh; ly += PT_TY)
-          for (int lx = threadIdx.x; lx < bw; lx += PT_W) {
-            if (ly < NJ * PT_TY && lx < NI * PT_W) continue;
-            const int gy = by0 + ly, gx = bx0 + lx;
-            s_tile[ly * bw + lx] = (gy >= 0 && gy < sh && gx >= 0 && gx < sw) ? S32[(size_t)gy * sw + gx] : 0u;
-          }
-      }
-    }
-    __syncthreads();  // the box (and, the first time, the weight table) is in LDS
-    if (itI < walk.count) {
-      nextT = tile_of(itI, recI);
-      issue(nextT);
-    }
-    itI += walk.W;
-    recI = itI < walk.count ? tiles[walk.start + itI] : make_int4(0, 0, 0, 0);
-    uchar4* dst = dst0 + dbs * cur.tz;
-    const int x = cur.tx * PT_W + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int y = cur.ty * PT_H + threadIdx.y + PT_TY * k;
-      if (x >= dw || y >= dh) continue;
-      uchar4 o = make_uchar4(0, 0, 0, 0);
-      if (bh > 0) {
-        if (pk[k] & 0x80000000u) {
-          const int rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
-          const uint4 wa = s_tab[(pk[k] & 1023u) * 2], wb = s_tab[(pk[k] & 1023u) * 2 + 1];
-          const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-          const unsigned* T = s_tile + ry * bw + rx;
-          int acc[4] = {1 << 14, 1 << 14, 1 << 14, 1 << 14};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned p0 = T[r * bw], p1 = T[r * bw + 1], p2 = T[r * bw + 2], p3 = T[r * bw + 3];
-            const s16x2 w01 = __builtin_bit_cast(s16x2, wq[2 * r]), w23 = __builtin_bit_cast(s16x2, wq[2 * r + 1]);
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-              const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
-              const s16x2 lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p1, p0, sel));
-              const s16x2 hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p3, p2, sel));
-              acc[ch] = __builtin_amdgcn_sdot2(lo, w01, acc[ch], false);
-              acc[ch] = __builtin_amdgcn_sdot2(hi, w23, acc[ch], false);
-            }
-          }
-          o = make_uchar4((unsigned char)sat_u8(acc[0] >> 15), (unsigned char)sat_u8(acc[1] >> 15), (unsigned char)sat_u8(acc[2] >> 15),
-                          NCH == 4 ? (unsigned char)sat_u8(acc[3] >> 15) : (unsigned char)0);
-        }
-      } else if (bh < 0) {  // box too large for LDS: per-tap gather through the map itself
-        MapFn mapfn = mapfn0;
-        mapfn.advance(dbs * cur.tz);
-        const float2 m = mapfn(x, y);
-        int sx, sy, fxy;
-        remap_coord(m.x, m.y, &sx, &sy, &fxy);
-        if (!(sx >= sw || sx + 4 <= 0 || sy >= sh || sy + 4 <= 0)) o = remap_cubic_u8c4_at(src + sbs * cur.tz, sw, sh, m.x, m.y, tab);
-      }
-      if (ALPHA == 1) {
-        int a = 255;
-        if (y >= yFeatherStart) {
-          const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
-          a = (int)(unsigned char)(255.0f * alpha);
-        }
-        o.w = (unsigned char)a;
-      } else if (ALPHA == 2) {
-        if (y >= yFeatherStart) {
-          const float alpha = 1.0f - (float)(y - yFeatherStart) / (float)featherSize;
-          const unsigned char a = (unsigned char)(255.0f * alpha);
-          o.w = o.w < a ? o.w : a;
-        }
-      }
-      dst[(size_t)y * dw + x] = o;
-    }
-    __syncthreads();  // every tap of this tile has been read: the next box may overwrite it
-  }
-}
-
-// workgroups of one persistent packed-remap launch: three per CU (48 KB of LDS each), a multiple of 8 (each XCD's share is whole)
-static unsigned packed_remap_grid(size_t tiles) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = n > 0 ? n : 256;
-  }
-  const size_t g = (size_t)cus * 3;
-  return (unsigned)(tiles < g ? tiles : g);
-}
-// -DS360_REMAP_TEST_PATTERN (CPU emulation builds of the tests only): a prefetch pattern of 64 x 8 source pixels, so that toy-sized
-// frames exercise the rows and columns the pattern does not cover
-#ifdef S360_REMAP_TEST_PATTERN
-#define S360_PF_SIDE 1, 2
-#define S360_PF_POLE 1, 2
-#else
-#define S360_PF_SIDE 2, 8
-#define S360_PF_POLE 1, 8
-#endif
-// S360_REMAP_PERSISTENT=0: the one-workgroup-per-tile form (tuning / A-B only; the results do not depend on it)
-static bool packed_remap_persistent() {
-  static int v = -1;
-  if (v < 0) { const char* e = std::getenv("S360_REMAP_PERSISTENT"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
 }
 
 // ---- pole removal (PoleRemoval.cpp:32-188) -------------------------------------------------------------------
@@ -1825,27 +1624,10 @@ void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, i
                                     const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
                                     int yFeatherStart, int featherSize, int batch) {
   MapFromBuffer mf{map, dw};
-  const int tx = cdiv(dw, PT_W), ty = cdiv(dh, PT_H);
-  const dim3 block(PT_W, PT_TY);
+  const dim3 grid(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), block(PT_W, PT_TY);
   const int4* t4 = reinterpret_cast<const int4*>(tiles);
   const size_t sbs = (size_t)sw * sh, dbs = (size_t)dw * dh;
   const int nt = (int)remap_packed_tiles(dw, dh);
-  if (packed_remap_persistent()) {
-    const dim3 grid(packed_remap_grid((size_t)nt * batch));
-    // the side projections' boxes are ~70 x 28 source pixels (a 128 x 32 pattern), the pole projections' ~20 x 20 (8400 columns from
-    // a 2048-pixel camera: 64 x 32)
-    if (alpha_mode == 1)
-      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed_p<MapFromBuffer, 1, S360_PF_POLE>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, tx, ty, batch);
-    else if (alpha_mode == 2)
-      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed_p<MapFromBuffer, 2, S360_PF_POLE>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, tx, ty, batch);
-    else
-      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed_p<MapFromBuffer, 0, S360_PF_SIDE>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, tx, ty, batch);
-    return;
-  }
-  const dim3 grid(tx, ty, batch);
   if (alpha_mode == 1)
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
                        T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
@@ -1927,14 +1709,9 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
   const int nt = (int)remap_packed_tiles(pw.extW, pw.rows);
   hipLaunchKernelGGL((k_remap_pack<MapFromPoleFlow>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1), dim3(PT_W, PT_TY), 0, st,
                      mf, pw.extW, pw.rows, pw.extW, pw.rows, packed, reinterpret_cast<int4*>(tiles), (size_t)0, nt);
-  if (packed_remap_persistent())
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed_p<MapFromPoleFlow, 0, S360_PF_SIDE>), dim3(packed_remap_grid((size_t)nt)), dim3(PT_W, PT_TY), 0, st,
-                       extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf, warpedExt, pw.extW, pw.rows,
-                       T.bicubic_i, 0, 1, (size_t)0, (size_t)0, cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1);
-  else
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
-                       dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
-                       warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt);
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
+                     dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
+                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   if ((pw.cols & 3) == 0 && (pw.extW & 3) == 0 && pw.cols + ((pw.maxBlendX + 3) & ~3) <= pw.extW &&

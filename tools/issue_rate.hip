@@ -15,6 +15,14 @@
 #define VW4 "v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\ts_waitcnt vmcnt(0)\n\t"
 #define VE4 "v_fma_f32 %0, %0, %8, %9\n\ts_and_b64 vcc, exec, vcc\n\tv_fma_f32 %1, %1, %8, %9\n\ts_or_b64 vcc, vcc, exec\n\tv_fma_f32 %2, %2, %8, %9\n\ts_and_b64 vcc, exec, vcc\n\tv_fma_f32 %3, %3, %8, %9\n\ts_or_b64 vcc, vcc, exec\n\t"
 
+// per-opcode rates (round 5): 32 independent instructions of ONE opcode per loop body — does the opcode issue at v_fma_f32's rate?
+#define P4 "v_perm_b32 %0, %0, %8, %9\n\tv_perm_b32 %1, %1, %8, %9\n\tv_perm_b32 %2, %2, %8, %9\n\tv_perm_b32 %3, %3, %8, %9\n\t"
+#define D4 "v_dot2c_i32_i16 %0, %8, %9\n\tv_dot2c_i32_i16 %1, %8, %9\n\tv_dot2c_i32_i16 %2, %8, %9\n\tv_dot2c_i32_i16 %3, %8, %9\n\t"
+#define M4 "v_min_f32 %0, %0, %8\n\tv_max_f32 %1, %1, %8\n\tv_min_f32 %2, %2, %9\n\tv_max_f32 %3, %3, %9\n\t"
+#define A4 "v_add_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_add_f32 %2, %2, %9\n\tv_mul_f32 %3, %3, %9\n\t"
+#define C4 "v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cndmask_b32 %2, %2, %9, vcc\n\tv_cndmask_b32 %3, %3, %9, vcc\n\t"
+#define I4 "v_add_u32 %0, %0, %8\n\tv_lshlrev_b32 %1, 1, %1\n\tv_and_b32 %2, %2, %9\n\tv_mad_u32_u24 %3, %3, %8, %9\n\t"
+#define DP4 "v_mov_b32_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %3 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b) {
   float x0 = a + threadIdx.x, x1 = b, x2 = a * 2, x3 = b * 3;
@@ -34,6 +42,20 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
       asm volatile(VB4 VB4 VB4 VB4 VB4 VB4 VB4 VB4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
     else if (MODE == 5)
       asm volatile(VW4 VW4 VW4 VW4 VW4 VW4 VW4 VW4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 7)
+      asm volatile(P4 P4 P4 P4 P4 P4 P4 P4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 8)
+      asm volatile(D4 D4 D4 D4 D4 D4 D4 D4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 9)
+      asm volatile(M4 M4 M4 M4 M4 M4 M4 M4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 10)
+      asm volatile(A4 A4 A4 A4 A4 A4 A4 A4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 11)
+      asm volatile(C4 C4 C4 C4 C4 C4 C4 C4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 12)
+      asm volatile(I4 I4 I4 I4 I4 I4 I4 I4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
+    else if (MODE == 13)
+      asm volatile(DP4 DP4 DP4 DP4 DP4 DP4 DP4 DP4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
     else if (MODE == 6)
       asm volatile(VE4 VE4 VE4 VE4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(a), "v"(b) : "scc", "vcc");
   }
@@ -59,9 +81,10 @@ int main() {
   const double ghz = p.clockRate * 1e-6;
   printf("%d CUs, nominal %.2f GHz; 32-instruction loop bodies, instructions per nominal cycle per SIMD:\n", cus, ghz);
   const char* names[] = {"32 VALU", "32 SALU", "16 VALU + 16 SALU", "16 VALU + 16 s_nop", "24 VALU + 8 branch (not taken)",
-                         "24 VALU + 8 s_waitcnt", "16 VALU + 16 s_and/or_b64"};
+                         "24 VALU + 8 s_waitcnt", "16 VALU + 16 s_and/or_b64", "32 v_perm_b32", "32 v_dot2c_i32_i16", "32 v_min/max_f32",
+                         "32 v_add/mul_f32", "32 v_cndmask_b32", "32 int (add/lshl/and/mad24)", "32 v_mov_b32_dpp (row bcast)"};
   const int iters = 200000;
-  for (int m = 0; m < 7; ++m) {
+  for (int m = 0; m < 14; ++m) {
     printf("%-32s", names[m]);
     for (int kw : {1, 2, 4, 8}) {
       const int wgs = cus * kw;
@@ -74,6 +97,13 @@ int main() {
         case 4: sec = run<4>(out, wgs, iters); break;
         case 5: sec = run<5>(out, wgs, iters); break;
         case 6: sec = run<6>(out, wgs, iters); break;
+        case 7: sec = run<7>(out, wgs, iters); break;
+        case 8: sec = run<8>(out, wgs, iters); break;
+        case 9: sec = run<9>(out, wgs, iters); break;
+        case 10: sec = run<10>(out, wgs, iters); break;
+        case 11: sec = run<11>(out, wgs, iters); break;
+        case 12: sec = run<12>(out, wgs, iters); break;
+        case 13: sec = run<13>(out, wgs, iters); break;
       }
       const double instr_per_simd = (double)kw * iters * 34.0;  // + loop counter and branch
       printf("  k=%d: %.3f", kw, instr_per_simd / (sec * ghz * 1e9));
