@@ -1029,7 +1029,9 @@ def main():
                             rec["valu_busy_profiled"] = vbj["families"][k]["valu_busy"]
                             ipf, ir = vbj["families"][k].get("valu_insts_per_frame"), vbj.get("issue_rate")
                             if ipf and ir:  # executed VALU wave-instructions per frame against what the chip issues in the family's time
-                                roof = ir["simds"] * ir["valu_inst_per_cycle_per_simd"] * ir["clock_ghz"] * 1e9
+                                cls = vbj["families"][k].get("rate_class", "fma")  # perm / dot2 / min / max / integer ops issue at half the FMA rate
+                                roof = ir["simds"] * ir["valu_inst_per_cycle_per_simd"][cls] * ir["clock_ghz"] * 1e9
+                                rec["valu_rate_class"] = cls
                                 rec["valu_roof_frac"] = round(ipf / roof / (rec["ms_per_frame"] * 1e-3), 4)
                 vb_note = vbj["source"]
             except Exception:  # noqa: BLE001 - an annotation only

@@ -87,11 +87,26 @@ struct SweepFast {  // reciprocals of the three divisors of the sweep, verified 
 #define S360_DBG_FROM_ENV() 0
 #endif
 
-// errorFunction (PixFlow.h:493-534) with the verified fast divisions / square roots. Sets tinyFlag when an
-// operand falls outside their proven range (the caller then re-evaluates with the IEEE expansion).
-__device__ __forceinline__ float error_fast(const Texels& t, float xR, float yR, float g0x, float g0y, float bfx,
-                                            float bfy, float fdx, float fdy, const SweepConst& c, const SweepFast& fc,
-                                            bool& tinyFlag) {
+// errorFunction (PixFlow.h:493-534) with the verified fast divisions / square roots, in two parts (round 5): what does not
+// depend on I1's texels — the smoothness term sqrt(|blurredFlow - flow|^2) * coef and the two regularisation terms: a square root
+// with its fix-up and two divisions, ~30 instructions — and what does. The latency sweep kernel evaluates the first part between
+// the issue of its bilinear gathers and the data's arrival (it used to sit behind the wait), the same operations on the same
+// operands in the same order: same bits. Sets tinyFlag when an operand falls outside the proven range of the fast division /
+// square root (the caller then re-evaluates with the IEEE expansion).
+struct ErrPre { float smTerm, vTerm, hTerm; unsigned key; };
+__device__ __forceinline__ ErrPre error_fast_pre(float bfx, float bfy, float fdx, float fdy, const SweepConst& c, const SweepFast& fc) {
+  const float dfx = bfx - fdx, dfy = bfy - fdy;
+  const float sm2 = dfx * dfx + dfy * dfy;
+  const float smoothness = sqrt_cr(sm2);
+  const float vn = c.vertCoef * fabsf(fdy), hn = c.horizCoef * fabsf(fdx);
+  ErrPre p;
+  p.smTerm = smoothness * c.smoothnessCoef;
+  p.vTerm = fdiv_m(vn, c.fcols, fc.rcCols);
+  p.hTerm = fdiv_m(hn, c.frows, fc.rcRows);
+  p.key = min(tiny_key(sm2), min(tiny_key(vn), tiny_key(hn)));
+  return p;
+}
+__device__ __forceinline__ float error_fast_post(const Texels& t, float xR, float yR, float g0x, float g0y, const ErrPre& p, bool& tinyFlag) {
   float i1x, i1y;
   {
     const float a1 = t.r0.x, a2 = t.r0.z - t.r0.x, a3 = t.r1.x - t.r0.x, a4 = t.r0.x + t.r1.z - t.r0.z - t.r1.x;
@@ -101,15 +116,15 @@ __device__ __forceinline__ float error_fast(const Texels& t, float xR, float yR,
     const float a1 = t.r0.y, a2 = t.r0.w - t.r0.y, a3 = t.r1.y - t.r0.y, a4 = t.r0.y + t.r1.w - t.r0.w - t.r1.y;
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
-  const float dfx = bfx - fdx, dfy = bfy - fdy;
-  const float sm2 = dfx * dfx + dfy * dfy;
-  const float smoothness = sqrt_cr(sm2);
   const float ex = g0x - i1x, ey = g0y - i1y;
   const float d2 = ex * ex + ey * ey;
-  const float vn = c.vertCoef * fabsf(fdy), hn = c.horizCoef * fabsf(fdx);
-  const unsigned key = min(min(tiny_key(sm2), tiny_key(d2)), min(tiny_key(vn), tiny_key(hn)));
-  tinyFlag = key < kTinyBits - 1u;
-  return sqrt_cr(d2) + smoothness * c.smoothnessCoef + fdiv_m(vn, c.fcols, fc.rcCols) + fdiv_m(hn, c.frows, fc.rcRows);
+  tinyFlag = min(p.key, tiny_key(d2)) < kTinyBits - 1u;
+  return sqrt_cr(d2) + p.smTerm + p.vTerm + p.hTerm;
+}
+__device__ __forceinline__ float error_fast(const Texels& t, float xR, float yR, float g0x, float g0y, float bfx,
+                                            float bfy, float fdx, float fdy, const SweepConst& c, const SweepFast& fc,
+                                            bool& tinyFlag) {
+  return error_fast_post(t, xR, yR, g0x, g0y, error_fast_pre(bfx, bfy, fdx, fdy, c, fc), tinyFlag);
 }
 
 inline SweepConst make_sweep_const(const PixFlowConsts& pc, int w, int h) {

@@ -86,8 +86,13 @@ typedef float f2n __attribute__((ext_vector_type(2)));
 // across steps; __syncthreads()/the s_barrier builtin would drain them on gfx9-class targets).
 #ifdef S360_WAVE_EMULATION
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+#define WG_BARRIER_AFTER(a, b, c, d, e, f, g, h) __syncthreads()
 #else
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... with values that must have been COMPUTED before the barrier is reached: the texel-independent part of the step is meant to
+// run while the gathers are in flight, and without this the compiler sinks it into the block that uses it — behind the wait
+#define WG_BARRIER_AFTER(a, b, c, d, e, f, g, h) \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory")
 #endif
 
 template <int K>
@@ -190,13 +195,12 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       const bool take = active && upd;
       const bool any = run && __ballot(take) != 0ull;
       // (deliberately not initialised: set and read only on the `any` path; zero-filling them cost 14 moves per step)
-      float2 up;
+      float upx, upy, altx, alty;
       float ax, ay, xR, yR;
       f4a8 ta, tb;
+      float preS, preV, preH;
+      unsigned preK;
       if (any) {
-        // up neighbour in every lane (needed by the selection below)
-        up.x = from_row_above<0xF>(upl.x, fl.x);
-        up.y = from_row_above<0xF>(upl.y, fl.y);
         // this lane's candidate: bank 0 current flow, bank 1 left result, bank 2 up result
         float2 cand;
         cand.x = fromLds ? (bank == 0 ? fo.x : upl.x) : fl.x;
@@ -220,9 +224,21 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
         } else {
           ta.x = xR; ta.y = yR; tb.z = mx; tb.w = my;
         }
+        // ---- in the gathers' shadow: everything of this step that does not need the texels ----
+        // up neighbour in every lane (needed by the selection below)
+        upx = from_row_above<0xF>(upl.x, fl.x);
+        upy = from_row_above<0xF>(upl.y, fl.y);
+        // not-updated pixels keep their flow; inactive lanes keep the previous result
+        altx = active ? fo.x : fl.x;
+        alty = active ? fo.y : fl.y;
+        if (FAST) {
+          const ErrPre p = error_fast_pre(rc.z, rc.w, ax, ay, c, fc);
+          preS = p.smTerm; preV = p.vTerm; preH = p.hTerm; preK = p.key;
+        }
       }
       TS(1);
-      wg_barrier();
+      if (FAST && any) { WG_BARRIER_AFTER(preS, preV, preH, preK, upx, upy, altx, alty); }
+      else wg_barrier();
       TS(2);
       // Preload the LDS operands of step s+1. The up value of row 0 is the row-3 result of wave j-1 at column
       // s+1, i.e. its local step s+4 = global step t-1 (kLag = 5): written before the barrier just passed.
@@ -253,7 +269,9 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       float e;
       if (FAST) {
         bool tiny;
-        e = error_fast(tt, xR, yR, rc.x, rc.y, rc.z, rc.w, ax, ay, c, fc, tiny);
+        ErrPre pre;
+        pre.smTerm = preS; pre.vTerm = preV; pre.hTerm = preH; pre.key = preK;
+        e = error_fast_post(tt, xR, yR, rc.x, rc.y, pre, tiny);
         if (__builtin_expect(__ballot(tiny) != 0ull, 0)) {
           Foot ft;
           ft.off = 0; ft.xR = xR; ft.yR = yR;
@@ -276,7 +294,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       float2 f = fo;
       float cur = e0, ex = e0x, ey = e0y;
       if (e1 < cur) { f = fl; cur = e1; ex = e1x; ey = e1y; }
-      if (e2 < cur) { f = up; cur = e2; ex = e2x; ey = e2y; }
+      if (e2 < cur) { f = make_float2(upx, upy); cur = e2; ex = e2x; ey = e2y; }
       const float nx = ex - cur, ny = ey - cur;
       float ggx, ggy;
       if (FAST) {
@@ -294,10 +312,8 @@ __global__ __launch_bounds__((NW + 2) * 64) void k_sweep_lock(const float4* __re
       float2 res;
       res.x = f.x - c.gradStep * ggx;
       res.y = f.y - c.gradStep * ggy;
-      // not-updated pixels keep their flow; inactive lanes keep the previous result
-      const float2 alt = active ? fo : fl;
-      res.x = take ? res.x : alt.x;
-      res.y = take ? res.y : alt.y;
+      res.x = take ? res.x : altx;
+      res.y = take ? res.y : alty;
       fl = res;
       if (active && k == 0) s_out[j][s & (kRingK - 1)][rr] = res;
       TS(5);

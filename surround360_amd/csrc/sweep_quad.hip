@@ -279,6 +279,24 @@ __global__ __launch_bounds__(64) void k_sweep_quad(const float2* __restrict__ re
     const f4a8 ta = *reinterpret_cast<const f4a8*>(&s_win[off]);
     const f4a8 tb = *reinterpret_cast<const f4a8*>(&s_win[off + kWinStride + 1]);
     Texels tt;
+    if constexpr (!decltype(ieee)::value) {
+      // Round 5: the part of errorFunction that does not need the texels (a square root with its fix-up, two divisions: ~30
+      // instructions, sweep_common.hpp) runs while the two LDS reads are in flight — as the compiler scheduled it, the wave
+      // waited for the window right behind the reads and evaluated everything afterwards. Same operations, same order: same bits.
+      ErrPre pre = error_fast_pre(rc.z, rc.w, ax, ay, c, fc);
+#ifndef S360_WAVE_EMULATION
+      asm volatile("; texel-independent terms before the window's data is waited for"
+                   : "+v"(pre.smTerm), "+v"(pre.vTerm), "+v"(pre.hTerm), "+v"(pre.key)
+                   :
+                   : "memory");
+#endif
+      tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
+      tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
+      bool t1;
+      const float e = error_fast_post(tt, __builtin_amdgcn_fractf(k.mx), __builtin_amdgcn_fractf(k.my), rc.x, rc.y, pre, t1);
+      tiny = tiny || t1;
+      return e;
+    }
     tt.r0 = make_float4(ta.x, ta.y, ta.z, ta.w);
     tt.r1 = make_float4(tb.x, tb.y, tb.z, tb.w);
     return error_of(ieee, tt, k, rc, ax, ay, tiny);

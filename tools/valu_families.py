@@ -7,6 +7,10 @@ Usage: python tools/valu_families.py <tag> <busy.json> [<insts.json>] > profiles
 import json
 import sys
 
+RATE_CLASS = {  # what the family's arithmetic is made of (which issue rate is its roof)
+    "project_side": "int", "project_pole": "int", "pole_warp": "int", "novel_view": "int", "flow_median": "int",
+    "flatten": "int", "assemble_pano": "int", "flow_sweep": "fma", "flow_diffusion": "fma", "flow_blur15": "fma", "flow_upscale": "fma",
+    "flow_gradients": "fma"}
 FAMILIES = {  # family -> substrings of the (demangled) kernel names it launches
     "project_side": ["k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 0>"],
     "project_pole": ["k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 1>", "k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 2>"],
@@ -28,9 +32,11 @@ def main():
     busy = json.load(open(sys.argv[2]))
     insts = json.load(open(sys.argv[3]))["kernels"] if len(sys.argv) > 3 else {}
     frames = sum(r["launches"] for n, r in insts.items() if "k_novel_view" in n) or None  # one launch per rendered frame
-    out = {"issue_rate": {"valu_inst_per_cycle_per_simd": 0.434, "clock_ghz": 2.4, "simds": busy["simds"],
-                          "source": "profiles/r05_v2_issue_rate.txt (tools/issue_rate: 32 v_fma_f32 per loop body, 8 waves per SIMD, "
-                                    "every CU busy: 0.434 wave-instructions per nominal cycle and SIMD)"},
+    out = {"issue_rate": {"clock_ghz": 2.4, "simds": busy["simds"],
+                          "valu_inst_per_cycle_per_simd": {"fma": 0.43, "int": 0.25},
+                          "source": "profiles/r05_v5_issue_rate_per_opcode.txt (tools/issue_rate, 8 waves per SIMD, every CU busy, "
+                                    "wave-instructions per nominal cycle and SIMD): v_fma / v_add / v_mul_f32 0.43 (class fma: the doubled "
+                                    "FP32 pipes), v_perm_b32 / v_dot2c_i32_i16 / v_min / v_max_f32 / integer / DPP 0.24-0.26 (class int)"},
            "source": "profiles/%s_valu_busy.txt (tools/valu_busy.py: rocprofv3 --pmc SQ passes of bench.py --inflight 1 --slots 22 "
                      "--no-extras; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (%d SIMDs x the kernel's own duration x %.1f GHz); a "
                      "family's kernels weighted by their time; valu_insts_per_launch = SQ_INSTS_VALU (executed wave-level VALU "
@@ -41,7 +47,8 @@ def main():
         if not ks:
             continue
         ms = sum(r["ms"] for r in ks.values())
-        rec = {"valu_busy": round(sum(r["valu_busy"] * r["ms"] for r in ks.values()) / ms, 3), "kernels": sorted(ks)}
+        rec = {"valu_busy": round(sum(r["valu_busy"] * r["ms"] for r in ks.values()) / ms, 3), "rate_class": RATE_CLASS.get(fam, "fma"),
+               "kernels": sorted(ks)}
         vi = {n: insts[n]["valu_insts_per_launch"] for n in ks if n in insts and "valu_insts_per_launch" in insts[n]}
         if vi:
             rec["valu_insts_per_launch"] = vi
