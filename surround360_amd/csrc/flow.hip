@@ -198,10 +198,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
       launch_resize_linear_f32(st, motionPyr + (size_t)N * lv_.off[l - 1], lv_.w[l - 1], lv_.h[l - 1], ns,
                                motionPyr + (size_t)N * lv_.off[l], lv_.w[l], lv_.h[l], nd, 1, N, 1.f, 0);
     }
-    // rescale the previous flow at each level (PixFlow.h:147-153); level 0 factor is exactly 1
-    for (int l = 1; l < L; ++l)
-      launch_scale_f32(st, (float*)(prevPyr + (size_t)B * lv_.off[l]), (size_t)B * lv_.w[l] * lv_.h[l] * 2,
-                       float(lv_.h[l]) / float(lv_.h[0]));
+    // (the rescale of the previous flow at each level, PixFlow.h:147-153 — level 0's factor is exactly 1 —, is applied where the
+    // level is read: launch_diffusion_adjust below)
   }
 
   float2* cur = M.flowA.as<float2>();
@@ -251,12 +249,11 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     {
       ProfScope ps(P, "flow_diffusion");
-      launch_diffusion(st, cur, oth, wl, hl, nl, B, tFlow, LA(l), idx);
-    }
-    if (usePrev) {
-      ProfScope ps(P, "flow_prev");
-      launch_adjust_toward_prev(st, oth, prevPyr + (size_t)B * lv_.off[l], motionPyr + (size_t)N * lv_.off[l], nl, nl, B,
-                                idx);
+      if (usePrev)  // ... and adjustFlowTowardPrevious in the same pass (the previous flow's level rescaled as it is read)
+        launch_diffusion_adjust(st, cur, oth, wl, hl, nl, B, tFlow, LA(l), idx, prevPyr + (size_t)B * lv_.off[l],
+                                motionPyr + (size_t)N * lv_.off[l], l == 0 ? 1.0f : float(lv_.h[l]) / float(lv_.h[0]));
+      else
+        launch_diffusion(st, cur, oth, wl, hl, nl, B, tFlow, LA(l), idx);
     }
     if (capture_levels) {
       std::vector<float> hbuf(B * nl * 2);

@@ -133,6 +133,12 @@ __global__ __launch_bounds__(256) void k_motion(const uchar4* __restrict__ cur, 
 //        {blurred.x | NaN when the pixel is not updated (PixFlow.h:390), blurred.y}; the other half of what a sweep reads per
 //        pixel is I0's gradient, which the gradient kernel has already written (round 3 wrote a 16-byte record {I0x | NaN, I0y,
 //        blurred} here and re-read the gradient to do so: 40 bytes of traffic per pixel-level for an 8-byte result, now 24).
+// EPI 4 (round 5; temporally chained frames): EPI 1 followed by adjustFlowTowardPrevious (PixFlow.h:185-193) on the same
+//        pixel — flow = flow * (1 - w) + prev * w with w = 1 - motion — and the previous flow's per-level rescale
+//        (PixFlow.h:147-153) applied to the value as it is read. As passes of their own (k_scale_f32 over the previous flow's
+//        pyramid, then k_adjust_toward_prev reading and rewriting the diffused flow at every level) these were 44 bytes of traffic
+//        per pixel-level and 71 launches per flow batch for what is two multiply-adds in this kernel's epilogue; the same float
+//        operations in the same order (Gp = the previous flow's level, recv = the motion level, up.post_scale = the level's factor).
 // Tile: 64x16 outputs for the 3- and 5-tap kernels, 32x32 for the 15-tap ones (29 KB of LDS instead of 35 KB and 1.44x
 // instead of 1.9x row-pass halo work: blur15 + diffusion 100 -> 69 ms of summed kernel time per frame with 16 frames in flight).
 struct UpSrc {  // SRC 2: geometry of the small source image and the scalar applied after the resize
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
   // waiting (profiles/r03_v5_pmc_sq.txt) and this was the second of its two exposed memory round trips per tile.
   constexpr int kColTasks = SB_TW * (SB_TH / 4);
   static_assert(EPI == 0 || kColTasks <= NT, "one column task per thread when the epilogue is prefetched");
-  float pa0[4] = {0.f, 0.f, 0.f, 0.f}, pa1[4] = {0.f, 0.f, 0.f, 0.f};
+  float pa0[4] = {0.f, 0.f, 0.f, 0.f}, pa1[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f};
   float2 pg[4];
   if (EPI != 0 && tid < kColTasks) {
     const int lx = tid % SB_TW, ly0 = (tid / SB_TW) * 4, gx = tx0 + lx;
@@ -175,6 +181,10 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
         pa0[o] = A[b0 + off];
         pa1[o] = A[b1 + off];
         if (EPI == 3) pg[o] = Gp[b0 + off];
+        if (EPI == 4) {
+          pg[o] = Gp[bs * tile.z + off];                         // previous flow (this level, unscaled)
+          pm[o] = static_cast<const float*>(recv)[b1 + off];     // motion of image i1 (PixFlow.h:186)
+        }
       }
     }
   }
@@ -314,10 +324,16 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
       const int gy = ty0 + ly0 + o;
       if (gy >= h) continue;
       const size_t off = (size_t)gy * w + gx;
-      if (EPI == 1) {
+      if (EPI == 1 || EPI == 4) {
         const float cc = 1.0f - pa0[o] * pa1[o];
 #pragma unroll
         for (int k = 0; k < CN; ++k) outv[o][k] = cc * outv[o][k] + (1.0f - cc) * s_in[ly0 + o + R][lx + R][k];
+      }
+      if (EPI == 4) {
+        const float wgt = 1.0f - pm[o];
+        const float px = pg[o].x * up.post_scale, py = pg[o].y * up.post_scale;
+        outv[o][0] = outv[o][0] * (1.0f - wgt) + px * wgt;
+        outv[o][CN - 1] = outv[o][CN - 1] * (1.0f - wgt) + py * wgt;
       }
       if (EPI == 2 || EPI == 3) {
         const bool upd = pa0[o] > 0.9f && pa1[o] > 0.9f;
@@ -611,25 +627,7 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32c2_tiled(const float2* 
   }
 }
 
-__global__ __launch_bounds__(256) void k_scale_f32(float* __restrict__ p, size_t n, float s) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] *= s;
-}
 
-// adjustFlowTowardPrevious (PixFlow.h:185-193), in place.
-__global__ __launch_bounds__(256) void k_adjust_toward_prev(float2* __restrict__ flow, const float2* __restrict__ prev,
-                                                            const float* __restrict__ motion, size_t n, size_t bs,
-                                                            FlowIdx idx) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t o = bs * blockIdx.z + i;
-  const float w = 1.0f - motion[bs * idx.i1[blockIdx.z] + i];
-  float2 f = flow[o];
-  const float2 p = prev[o];
-  f.x = f.x * (1.0f - w) + p.x * w;
-  f.y = f.y * (1.0f - w) + p.y * w;
-  flow[o] = f;
-}
 
 
 // ==========================================================================================
@@ -754,6 +752,13 @@ void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, in
                       const BlurTaps& t, const float* A, const FlowIdx& idx) {
   launch_sepblur_t<7, 2, 1, 0>(st, (const float*)flow, (float*)dst, w, h, bs, B, t, A, idx, nullptr, nullptr);
 }
+// ... followed, on the same pixel, by adjustFlowTowardPrevious with the previous flow's level rescaled as it is read
+void launch_diffusion_adjust(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B, const BlurTaps& t,
+                             const float* A, const FlowIdx& idx, const float2* prev, const float* motion, float prev_scale) {
+  UpSrc up{};
+  up.post_scale = prev_scale;
+  launch_sepblur_t<7, 2, 4, 0>(st, (const float*)flow, (float*)dst, w, h, bs, B, t, A, idx, prev, const_cast<float*>(motion), nullptr, up);
+}
 // resize(flow, originalSize, INTER_LINEAR); flow *= s; GaussianBlur(flow, 3x3) in one pass (PixFlow.h:175-182)
 void launch_upscale_blur(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw, int dh,
                          size_t dbs, int B, float post_scale, const BlurTaps& t, float* const* dst_tab) {
@@ -818,14 +823,6 @@ void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh
   dim3 blk(32, 8);
   hipLaunchKernelGGL(k_resize_cubic_f32c2, grid2d(dw, dh, B, blk), blk, 0, st, src, sw, sh, sbs, dst, dw, dh, dbs, scx,
                      scy, post_scale, src_tab);
-}
-void launch_scale_f32(hipStream_t st, float* p, size_t n, float s) {
-  hipLaunchKernelGGL(k_scale_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, s);
-}
-void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
-                               size_t bs, int B, const FlowIdx& idx) {
-  hipLaunchKernelGGL(k_adjust_toward_prev, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, flow, prev,
-                     motion, n, bs, idx);
 }
 void launch_search_init(hipStream_t st, const float* I, const float* A, int w, int h, size_t pbs, int B,
                         const FlowIdx& idx, float2* flow, int hint, int dist, float* I1eq) {

@@ -37,6 +37,8 @@ void launch_sepblur(hipStream_t st, const float* src, float* dst, int w, int h, 
                     const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_diffusion(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B,
                       const BlurTaps& t, const float* A, const FlowIdx& idx);
+void launch_diffusion_adjust(hipStream_t st, const float2* flow, float2* dst, int w, int h, size_t bs, int B, const BlurTaps& t,
+                             const float* A, const FlowIdx& idx, const float2* prev, const float* motion, float prev_scale);
 void launch_upscale_blur(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw, int dh,
                          size_t dbs, int B, float post_scale, const BlurTaps& t, float* const* dst_tab = nullptr);
 void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, size_t bs, int B, const BlurTaps& t);
@@ -48,9 +50,6 @@ void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, 
                               size_t dbs, int cn, int B, float post_scale, int do_scale);
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
                                int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab = nullptr);
-void launch_scale_f32(hipStream_t st, float* p, size_t n, float s);
-void launch_adjust_toward_prev(hipStream_t st, float2* flow, const float2* prev, const float* motion, size_t n,
-                               size_t bs, int B, const FlowIdx& idx);
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
 // lockstep banded sweep (sweep_lock.hip): nw compute waves (4 rows each) + 2 service waves per workgroup
 int sweep_lock_waves();  // compute waves per workgroup of this process (4 unless S360_LOCK_NW says 2 or 8)
