@@ -528,7 +528,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
         s360_ctx::PackedMap& pk = ensure_packed(c, c->sidePk, c->sideMaps.as<float2>(), F.srcW, F.srcH, camW, camH, P, st);
         launch_remap_cubic_u8c4_packed(st, F.sideSrc.as<uchar4>() + sn * i, F.srcW, F.srcH, c->sideMaps.as<float2>() + pn * i,
                                        pk.packed.as<unsigned>() + pn * i,
-                                       (const char*)pk.tiles.p + 16 * remap_packed_tile_stride(F.srcW, F.srcH, camW, camH) * i,
+                                       (const char*)pk.tiles.p + 16 * remap_packed_tiles(camW, camH) * i,
                                        F.sc->proj.as<uchar4>() + pn * i, camW, camH, F.tab.dev, 0, 0, 1, j - i);
         i = j;
       }

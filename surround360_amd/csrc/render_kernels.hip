@@ -345,7 +345,7 @@ __global__ __launch_bounds__(RT_W* RT_H) void k_remap_cubic_u8c4_tiled(const uch
 // pixels each. Tiles whose box does not fit (map singularities) take the per-tap global gather from the float map.
 constexpr int PT_W = 64, PT_H = 16, PT_TY = 4, PT_CAP = 4096;
 
-template <class MapFn, int PH>
+template <class MapFn>
 __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw, int sh, int dw, int dh,
                                                             unsigned* __restrict__ packed, int4* __restrict__ tiles,
                                                             size_t dbs, int tilesPerImage) {
@@ -355,16 +355,15 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
   __shared__ int s_box[4];
   const int tid = threadIdx.y * PT_W + threadIdx.x;
   const int x = blockIdx.x * PT_W + threadIdx.x;
-  constexpr int NP = PH / PT_TY;  // destination pixels per thread
-  int sx[NP], sy[NP], fxy[NP];
-  bool live[NP];
+  int sx[4], sy[4], fxy[4];
+  bool live[4];
   int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
-  float2 raw[NP];  // (the map / flow values are requested together)
+  float2 raw[4];  // (the four map / flow values are requested together)
 #pragma unroll
-  for (int k = 0; k < NP; ++k) raw[k] = mapfn.load(min(x, dw - 1), min((int)(blockIdx.y * PH + threadIdx.y + PT_TY * k), dh - 1));
+  for (int k = 0; k < 4; ++k) raw[k] = mapfn.load(min(x, dw - 1), min((int)(blockIdx.y * PT_H + threadIdx.y + PT_TY * k), dh - 1));
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const int y = blockIdx.y * PH + threadIdx.y + PT_TY * k;
+  for (int k = 0; k < 4; ++k) {
+    const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
     live[k] = false;
     sx[k] = sy[k] = fxy[k] = 0;
     if (x < dw && y < dh) {
@@ -392,8 +391,8 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
   if (any && ((long long)bw * bh > PT_CAP || bw > 2047 || bh > 1023)) bh = -1;  // too large for the LDS tile / the packed fields
   if (tid == 0) tiles[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = make_int4(bx0, by0, bw, bh);
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const int y = blockIdx.y * PH + threadIdx.y + PT_TY * k;
+  for (int k = 0; k < 4; ++k) {
+    const int y = blockIdx.y * PT_H + threadIdx.y + PT_TY * k;
     if (x < dw && y < dh)
       packed[(size_t)y * dw + x] = (live[k] && bh > 0) ? (0x80000000u | ((unsigned)(sy[k] - by0) << 21) | ((unsigned)(sx[k] - bx0) << 10) | (unsigned)fxy[k]) : 0u;
   }
@@ -403,10 +402,9 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
 // quarter of the tap arithmetic of a 17.7 Mpx image was computed and then overwritten with 255 — and the rounding constant is
 // the accumulators' start value: side projections 0.332 -> 0.300 ms per 8K frame, pole projections 0.269 -> 0.261, pole warp
 // 0.813 -> 0.793.
-// Tile height is a template parameter as well (round 5): 64 x 16 destination pixels per workgroup, or 64 x 64 ("tall") where the
-// destination has at least three times the source's pixels — the pole projections: 8400 x 2104 from a 2048^2 camera, a 64 x 16
-// tile's box is ~20 x 20 source pixels and a workgroup's life was its chain of dependent round trips (tile record -> coordinates +
-// box -> barrier -> weight rows), not its 1024 pixels' taps; a 64 x 64 tile's box is ~31 x 31 (at most 47 x 47) for four times the taps.
+// Measured and NOT adopted: 64 x 64 destination tiles for the pole projections (their 64 x 16 tiles' boxes are ~20 x 20 source
+// pixels; a tall tile's ~31 x 31 for four times the taps per workgroup and per chain of dependent round trips): 0.262 against
+// 0.261 ms per frame (profiles/r05_v9_remap_tall_tiles.json) — that chain is not what the kernel waits for either.
 // Measured twice and NOT adopted: the 32 KB weight table in LDS. It has to be loaded once per workgroup, not once per 64 x 16 tile
 // (that would be the same 32 bytes per pixel again), i.e. PERSISTENT workgroups — 3 per CU at 48 KB of LDS, each XCD's
 // workgroups striding through its contiguous run of tiles. (1) As it stands, load -> barrier -> taps -> barrier per tile: 0.422 /
@@ -416,7 +414,7 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
 // 0.793 of this form on the same box (profiles/r05_v4_remap_persistent_prefetch_ab.json). Twelve waves per CU whose phases line
 // up leave the VALUs idle more than the weight rows' trips to L1 / L2 cost the 32 resident waves of this form (VALU 63 % / 53 %
 // busy, profiles/r05_v3_valu_busy.txt); both variants were bit-exact on the emulation and on the GPU and are gone.
-template <class MapFn, int ALPHA, int PH>
+template <class MapFn, int ALPHA>
 __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const uchar4* __restrict__ src, int sw, int sh,
                                                                          const unsigned* __restrict__ packed,
                                                                          const int4* __restrict__ tiles, MapFn mapfn,
@@ -433,14 +431,11 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
   const int4 box = tiles[(size_t)tilesPerImage * tile.z + (size_t)tile.y * gridDim.x + tile.x];  // (uniform)
   const int bx0 = box.x, by0 = box.y, bw = box.z, bh = box.w;
   const int x = tile.x * PT_W + threadIdx.x;
-  constexpr int NP = PH / PT_TY;  // destination pixels per thread (4; 16 with the tall tiles of the pole projections)
-  unsigned pk[NP];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) pk[k] = 0u;
+  unsigned pk[4] = {0u, 0u, 0u, 0u};
   if (bh > 0 && x < dw) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const int y = tile.y * PH + threadIdx.y + PT_TY * k;
+    for (int k = 0; k < 4; ++k) {
+      const int y = tile.y * PT_H + threadIdx.y + PT_TY * k;
       if (y < dh) pk[k] = packed[(size_t)y * dw + x];
     }
   }
@@ -475,8 +470,8 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
     __syncthreads();
   }
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const int y = tile.y * PH + threadIdx.y + PT_TY * k;
+  for (int k = 0; k < 4; ++k) {
+    const int y = tile.y * PT_H + threadIdx.y + PT_TY * k;
     if (x >= dw || y >= dh) continue;
     uchar4 o = make_uchar4(0, 0, 0, 0);
     if (bh > 0) {
@@ -1621,50 +1616,30 @@ void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, 
                      dim3(RT_W, RT_H), 0, st, src, sw, sh, mf, dst, dw, dh, T.bicubic_i, alpha_mode, yFeatherStart,
                      featherSize, (size_t)sw * sh, (size_t)dw * dh);
 }
-size_t remap_packed_tiles(int dw, int dh) { return (size_t)cdiv(dw, PT_W) * cdiv(dh, PT_H); }  // (an upper bound for the tall tiles)
-// 64 x 64 destination tiles where the map minifies by at least three (in area): the pole projections at panorama sizes
-bool remap_packed_tall(int sw, int sh, int dw, int dh) { return (size_t)dw * dh >= 3 * (size_t)sw * sh; }
-// tile records per image as the pack / remap kernels of (sw, sh) -> (dw, dh) lay them out
-size_t remap_packed_tile_stride(int sw, int sh, int dw, int dh) {
-  return (size_t)cdiv(dw, PT_W) * cdiv(dh, remap_packed_tall(sw, sh, dw, dh) ? 64 : PT_H);
-}
+size_t remap_packed_tiles(int dw, int dh) { return (size_t)cdiv(dw, PT_W) * cdiv(dh, PT_H); }
 void launch_remap_pack_map(hipStream_t st, const float2* map, int sw, int sh, int dw, int dh, unsigned* packed, void* tiles,
                            int batch) {
   MapFromBuffer mf{map, dw};
-  if (remap_packed_tall(sw, sh, dw, dh))
-    hipLaunchKernelGGL((k_remap_pack<MapFromBuffer, 64>), dim3(cdiv(dw, PT_W), cdiv(dh, 64), batch), dim3(PT_W, PT_TY), 0, st, mf, sw,
-                       sh, dw, dh, packed, reinterpret_cast<int4*>(tiles), (size_t)dw * dh, cdiv(dw, PT_W) * cdiv(dh, 64));
-  else
-    hipLaunchKernelGGL((k_remap_pack<MapFromBuffer, PT_H>), dim3(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), dim3(PT_W, PT_TY), 0, st, mf, sw,
-                       sh, dw, dh, packed, reinterpret_cast<int4*>(tiles), (size_t)dw * dh, (int)remap_packed_tiles(dw, dh));
+  hipLaunchKernelGGL((k_remap_pack<MapFromBuffer>), dim3(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), dim3(PT_W, PT_TY), 0, st, mf, sw,
+                     sh, dw, dh, packed, reinterpret_cast<int4*>(tiles), (size_t)dw * dh, (int)remap_packed_tiles(dw, dh));
 }
-template <int PH>
-static void launch_remap_packed_ph(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, const unsigned* packed,
-                                   const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
-                                   int yFeatherStart, int featherSize, int batch) {
-  MapFromBuffer mf{map, dw};
-  const dim3 grid(cdiv(dw, PT_W), cdiv(dh, PH), batch), block(PT_W, PT_TY);
-  const int4* t4 = reinterpret_cast<const int4*>(tiles);
-  const size_t sbs = (size_t)sw * sh, dbs = (size_t)dw * dh;
-  const int nt = cdiv(dw, PT_W) * cdiv(dh, PH);
-  if (alpha_mode == 1)
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1, PH>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
-  else if (alpha_mode == 2)
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 2, PH>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
-  else
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0, PH>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
-}
-// (`packed` / `tiles` as launch_remap_pack_map made them for the same sw, sh, dw, dh: both choose the tile height from those)
 void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, const unsigned* packed,
                                     const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
                                     int yFeatherStart, int featherSize, int batch) {
-  if (remap_packed_tall(sw, sh, dw, dh))
-    launch_remap_packed_ph<64>(st, src, sw, sh, map, packed, tiles, dst, dw, dh, T, alpha_mode, yFeatherStart, featherSize, batch);
+  MapFromBuffer mf{map, dw};
+  const dim3 grid(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), block(PT_W, PT_TY);
+  const int4* t4 = reinterpret_cast<const int4*>(tiles);
+  const size_t sbs = (size_t)sw * sh, dbs = (size_t)dw * dh;
+  const int nt = (int)remap_packed_tiles(dw, dh);
+  if (alpha_mode == 1)
+    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
+  else if (alpha_mode == 2)
+    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 2>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
   else
-    launch_remap_packed_ph<PT_H>(st, src, sw, sh, map, packed, tiles, dst, dw, dh, T, alpha_mode, yFeatherStart, featherSize, batch);
+    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
 }
 void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
                           const DevTables& T) {
@@ -1735,9 +1710,9 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
                              const PoleWarpParams& pw, const DevTables& T, unsigned* packed, void* tiles) {
   MapFromPoleFlow mf{flow, pw};
   const int nt = (int)remap_packed_tiles(pw.extW, pw.rows);
-  hipLaunchKernelGGL((k_remap_pack<MapFromPoleFlow, PT_H>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1), dim3(PT_W, PT_TY), 0, st,
+  hipLaunchKernelGGL((k_remap_pack<MapFromPoleFlow>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1), dim3(PT_W, PT_TY), 0, st,
                      mf, pw.extW, pw.rows, pw.extW, pw.rows, packed, reinterpret_cast<int4*>(tiles), (size_t)0, nt);
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0, PT_H>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
                      dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
                      warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt);
 }

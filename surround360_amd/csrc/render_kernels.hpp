@@ -47,8 +47,7 @@ void launch_remap_cubic_u8c4(hipStream_t st, const uchar4* src, int sw, int sh, 
 // fills `packed` (one dword per destination pixel) and `tiles` (remap_packed_tiles(dw, dh) x 16 bytes per image) from a
 // float map; the remap then reads those instead of the map (the map is only touched by tiles whose source box does not
 // fit in LDS).
-size_t remap_packed_tiles(int dw, int dh);  // upper bound (buffer sizes)
-size_t remap_packed_tile_stride(int sw, int sh, int dw, int dh);  // records per image as the kernels lay them out (batched maps)
+size_t remap_packed_tiles(int dw, int dh);
 void launch_remap_pack_map(hipStream_t st, const float2* map, int sw, int sh, int dw, int dh, unsigned* packed, void* tiles,
                            int batch = 1);
 void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, const unsigned* packed,

@@ -202,7 +202,7 @@ def test_frame_calls_refuse_sizes_no_frame_can_have(rig_json, s360lib):
 
 @pytest.mark.parametrize("eqr_w,eqr_h,cam,final,poles", [(28, 14, 64, (0, 0), 1), (42, 21, 64, (0, 0), 1), (70, 33, 64, (0, 0), 0),
                                                          (28, 300, 64, (0, 0), 1), (28, 14, 8, (3, 2), 1), (140, 70, 4, (300, 300), 1),
-                                                         (504, 252, 96, (0, 0), 1)])  # (pole projections minify by 7: 64 x 64 remap tiles)
+                                                         (504, 252, 96, (0, 0), 1)])  # (pole projections that minify by 7)
 def test_tiny_frames_equal_the_oracle(tmp_path, rig_json, oracle, s360lib, eqr_w, eqr_h, cam, final, poles):
     """Whole frames at the small end of what s360_create accepts — overlap images 4 px wide, 6-row projections, 4 x 4
     cameras magnified 35 times, a 3 x 2 output, feathers as large as the images allow: every pyramid is a single level
