@@ -16,12 +16,13 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=${S360_PROF_DIR:-/tmp/s360_prof}/prof_$TAG  # (rocprofv3 databases: hundreds of MB — outside gpurun_out/, which is merged back and capped)
 mkdir -p $OUT profiles
 ISO="python bench.py --inflight 1 --slots $SLOTS --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/ks.log 2>&1
+# (--no-extras since round 5: the timed region + its check + the single-frame figures; the stream legs would add minutes of tracing)
+rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline > $OUT/ks.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/iso -o iso -- $ISO > $OUT/iso.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f -o f -- $ISO > $OUT/f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w -o w -- $ISO > $OUT/w.log 2>&1
 python tools/rocpd_kernel_stats.py $OUT/ks/ks_results.db \
-  "rocprofv3 --kernel-trace --stats summary ($TAG): python bench.py --steps 8 --warmup 2 --no-cpu-baseline (default: 2 contexts x 22 frame slots)" \
+  "rocprofv3 --kernel-trace --stats summary ($TAG): python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline (default: 2 contexts x 22 frame slots)" \
   "durations from the rocpd kernel dispatch table; launches of the two contexts overlap, so these are NOT isolated durations" \
   > profiles/${TAG}_kernel_stats.txt
 python tools/rocpd_kernel_stats.py $OUT/iso/iso_results.db \
