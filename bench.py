@@ -233,6 +233,7 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420,
                 "note": "one process per frame, process start to exit: frame 1 with --prev_frame_data_dir (28 + 4 flow files and 36 state "
                         "images of frame 0 read, frame 1's written: TRSP:201-255, 413-452), 17 PNG inputs, one 8192x8192 equirect PNG; "
                         "the stream figures above are what a caller gets that keeps the process (--num_frames)"}
+            rec["single_invocation_s"] = rec["single_invocation"]["wall_s"]
             same = np.asarray(Image.open(os.path.join(out, "single_000001.png")))[:, :, ::-1]
             if n >= 2:
                 chain = np.asarray(Image.open(outs[1]))[:, :, ::-1]
@@ -892,6 +893,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
+        "value_note": "aggregate over INDEPENDENT frames (no predecessor: BASELINE configs[2]); temporally chained streams — every preset of "
+                      "the reference — are the `video_streams_batched` leg, one stream the `video_stream` leg, one frame alone `single_frame`",
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
