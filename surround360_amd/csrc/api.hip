@@ -820,12 +820,13 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     if (!F.downRead[b]) S360_HIP(hipEventCreateWithFlags(&F.downRead[b], hipEventDisableTiming));
     S360_HIP(hipStreamWaitEvent(c->stDown, F.outDone[b], 0));
     S360_HIP(hipMemcpyAsync(out_bgr, F.outBGR[b].p, (size_t)c->g.out_width * c->g.out_height * 3, hipMemcpyDeviceToHost, c->stDown));
-    // the frame's error words travel with it (a later frame's finish stage rewrites outErr[b] as soon as downRead[b] has fired)
-    if (F.outErr[b]) S360_HIP(hipMemcpyAsync(c->downErr, F.outErr[b], 3 * sizeof(unsigned), hipMemcpyHostToHost, c->stDown));
+    // the frame's error words travel with it (a later frame's finish stage rewrites them as soon as downRead[b] has fired): a device
+    // -> page-locked host copy on the download's own stream (a host -> host "async" copy would block this thread with the lock held)
+    if (F.outErrDev[b].p) S360_HIP(hipMemcpyAsync(c->downErr, F.outErrDev[b].p, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stDown));
     S360_HIP(hipEventRecord(F.downRead[b], c->stDown));
     S360_HIP(hipEventRecord(c->evDown, c->stDown));
     const hipEvent_t ev = c->evDown;
-    const unsigned* errw = F.outErr[b] ? c->downErr : nullptr;  // (nothing of the slot is touched after the lock is back: it may be gone)
+    const unsigned* errw = F.outErrDev[b].p ? c->downErr : nullptr;  // (nothing of the slot is touched after the lock is back: it may be gone)
     // The wait is most of a frame long: the context is free meanwhile (the next frame's uploads and enqueue need it).
     // One fetching thread per context: evDown is re-recorded by the next call.
     lk.unlock();

@@ -915,11 +915,17 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         S360_HIP(hipHostMalloc((void**)&F.outErr[ob], 4 * sizeof(unsigned), hipHostMallocDefault));
         std::memset(F.outErr[ob], 0, 4 * sizeof(unsigned));
       }
+      if (!F.outErrDev[ob].p) {
+        F.outErrDev[ob].ensure(4 * sizeof(unsigned));
+        S360_HIP(hipMemsetAsync(F.outErrDev[ob].p, 0, 4 * sizeof(unsigned), st));
+      }
       {
         FlowEngine* eng[3] = {c->flow.get(), c->flow_pole.get(), c->flow_pr.get()};
         for (int i = 0; i < 3; ++i) {
-          if (eng[i] && eng[i]->error_word())
+          if (eng[i] && eng[i]->error_word()) {
             S360_HIP(hipMemcpyAsync(&F.outErr[ob][i], eng[i]->error_word(), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            S360_HIP(hipMemcpyAsync(F.outErrDev[ob].as<unsigned>() + i, eng[i]->error_word(), sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+          }
         }
       }
       S360_HIP(hipEventRecord(F.outDone[ob], st));

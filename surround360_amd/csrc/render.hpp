@@ -71,6 +71,7 @@ struct FrameState {
   // that renders behind it (the words are cumulative, so a non-zero value may also come from that next frame's side
   // flows — either way the stream's results are invalid from here on)
   unsigned* outErr[2] = {nullptr, nullptr};
+  DevBuf outErrDev[2];  // the same three words on the device (what a download's own stream copies out with the pixels)
   // s360_frame_download_equirect_of releases the context while it waits: downRead[i] is recorded on the download stream behind
   // its copy of outBGR[i] / outErr[i], and the finish stage that next writes buffer i waits for it (a feeder two frames ahead of
   // the fetching thread must not overwrite a frame that is still being transferred)
