@@ -240,6 +240,37 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420,
                 rec["single_invocation"]["equals_stream_frame"] = bool(np.array_equal(same, chain))
         except Exception as e:  # noqa: BLE001
             rec["single_invocation"] = {"error": repr(e)}
+        # ---- the same files as FOUR streams in one process on this GPU (--num_streams 4: the streams are the frame slots of one
+        # context, frame k of all four in one launch sequence, each with its own temporal state) ----
+        try:
+            ns = 4
+            nf = (n // ns) * ns
+            if nf >= 2 * ns:
+                cb = [program, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", "000000", "--num_frames", str(nf),
+                      "--num_streams", str(ns), "--stream_gpus", "1", "--output_data_dir", out, "--prev_frame_data_dir", "NONE",
+                      "--output_equirect_path", os.path.join(out, "batched_%s.png"), "--sharpening", repr(float(flags.get("sharpening", 0.0))),
+                      "--device", str(device), "--write_state=false", "--v", "1"]
+                for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
+                    cb += ["--" + k, str(flags[k])]
+                cb += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
+                t1 = time.perf_counter()
+                rb = subprocess.run(cb, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
+                wb = time.perf_counter() - t1
+                if rb.returncode != 0:
+                    raise RuntimeError("rc %d: %s" % (rb.returncode, rb.stderr[-300:]))
+                hb = re.search(r"host thread per step:\s+decode \+ upload ([0-9.]+)\s+wait for the encoders ([0-9.]+)\s+wait for the GPU \+ fetch ([0-9.]+)", rb.stderr)
+                first = np.asarray(Image.open(os.path.join(out, "batched_000000.png")))[:, :, ::-1]
+                ref0 = np.asarray(Image.open(outs[0]))[:, :, ::-1]
+                rec["batched_streams"] = {
+                    "streams": ns, "frames": nf, "process_wall_s": round(wb, 2), "frames_per_s_process": nf / wb,
+                    "first_frame_equals_stream": bool(np.array_equal(first, ref0)),
+                    "host_thread_s_per_step": {"decode_and_upload": float(hb.group(1)), "wait_for_encoders": float(hb.group(2)),
+                                               "wait_for_gpu_and_fetch": float(hb.group(3))} if hb else None,
+                    "note": "%d frames as %d streams of %d (segments of the frame range), one process, one context with %d frame slots; PNG "
+                            "files in and out like the stream above (the PNG codecs of %d frames per step share the process's CPUs)" % (
+                                nf, ns, nf // ns, ns, ns)}
+        except Exception as e:  # noqa: BLE001
+            rec["batched_streams"] = {"error": repr(e)}
         return rec, last
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -473,6 +504,8 @@ def main():
     ap.add_argument("--stream-slots", type=int, default=0,
                     help="video_streams_batched leg: streams (frame slots) per context; 0 = as many as fit with both halves of "
                          "every slot's temporal double buffers resident")
+    ap.add_argument("--streams-only", action="store_true",
+                    help="only the video_streams_batched leg (slots-against-frames/s probes: --stream-slots N); prints that leg's record")
     ap.add_argument("--stream-steps", type=int, default=8, help="video_streams_batched leg: timed steps (after 4 run-in steps)")
     ap.add_argument("--video-frames", type=int, default=190,
                     help="frames of the configs[4] stream leg (SURVEY 8d: 190, steady state over frames 10-189)")
@@ -621,7 +654,12 @@ def main():
         c1.close()
         dist.destroy_process_group()
         return
-    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(max(F * S, n_distinct))]
+    frames = [rr.frame_numpy(yaw_deg=0.2 * k, disc_deg=10.0 + 0.5 * k) for k in range(24 if args.streams_only else max(F * S, n_distinct))]
+    if args.streams_only:
+        del rr, wtex
+        torch.cuda.empty_cache()
+        print(json.dumps({"video_streams_batched": streams_batched(R, rig, flags, local_rank, frames, args, dry, None)}))
+        return
 
     def stream_frame(k):  # frame k of the stream: 0,1,..,n-1,n-2,..,1,0,1,.. over the distinct frames held
         if n_distinct >= n_video:
