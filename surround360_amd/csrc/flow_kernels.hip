@@ -55,16 +55,28 @@ __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restr
   int ax[4], ay[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { ax[k] = s_ax[threadIdx.x][k]; ay[k] = s_ay[threadIdx.y][k]; }
+  // Horizontal pass (round 5): the four taps of a row and channel as two v_perm_b32 (byte -> 16-bit lanes of two pixels) + two
+  // v_dot2_i32_i16 with the packed short taps, like the packed remap — 64 operations per pixel instead of 64 byte extractions + 64
+  // 24-bit multiply-adds (the kernel was VALU-bound: 84 % busy, profiles/r05_v10_valu_busy.txt). Integer sums: same bits.
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 w01 = __builtin_bit_cast(s16x2, (unsigned)((ax[0] & 0xffff) | (ax[1] << 16)));
+  const s16x2 w23 = __builtin_bit_cast(s16x2, (unsigned)((ax[2] & 0xffff) | (ax[3] << 16)));
+  const int c0 = clip_idx(sx - 1, sw), c1 = clip_idx(sx, sw), c2 = clip_idx(sx + 1, sw), c3 = clip_idx(sx + 2, sw);
   int hx[4], hy[4], hz[4], hw[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uchar4* S = src + (size_t)clip_idx(sy - 1 + r, sh) * sw;
-    hx[r] = hy[r] = hz[r] = hw[r] = 0;
+    const unsigned* S = reinterpret_cast<const unsigned*>(src + (size_t)clip_idx(sy - 1 + r, sh) * sw);
+    const unsigned p0 = S[c0], p1 = S[c1], p2 = S[c2], p3 = S[c3];
+    int h[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uchar4 p = S[clip_idx(sx - 1 + q, sw)];
-      hx[r] += __mul24((int)p.x, ax[q]); hy[r] += __mul24((int)p.y, ax[q]); hz[r] += __mul24((int)p.z, ax[q]); hw[r] += __mul24((int)p.w, ax[q]);
+    for (int ch = 0; ch < 4; ++ch) {
+      const unsigned sel = 0x0c040c00u + ch * 0x00010001u;
+      const s16x2 lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p1, p0, sel));
+      const s16x2 hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(p3, p2, sel));
+      h[ch] = __builtin_amdgcn_sdot2(lo, w01, 0, false);
+      h[ch] = __builtin_amdgcn_sdot2(hi, w23, h[ch], false);
     }
+    hx[r] = h[0]; hy[r] = h[1]; hz[r] = h[2]; hw[r] = h[3];
   }
   uchar4 o;
   if (dx < (dw & ~1)) {  // SSE2-covered elements

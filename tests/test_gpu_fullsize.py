@@ -250,9 +250,9 @@ def test_config5_batched_chained_streams(frame8k, gpu_rig):
                 if k + 1 == len(order[s]):
                     cb.select_frame_slot(s)
                     last[s] = cb.download_equirect()
-        assert "chain_want" in frame8k, "runs behind test_config5_late_frame_of_a_chain"
-        _cmp("batched stream 0, frame 4 (against the oracle's chain)", last[0], frame8k["chain_want"])
-        for s in (1, 2):
+        if "chain_want" in frame8k:  # (test_config5_late_frame_of_a_chain ran: the oracle's fourth frame of this chain)
+            _cmp("batched stream 0, frame 4 (against the oracle's chain)", last[0], frame8k["chain_want"])
+        for s in (1, 2) if "chain_want" in frame8k else (0, 1, 2):
             for k, f in enumerate(order[s]):
                 c1.upload_frame(*fr[f])
                 c1.render(use_prev=k > 0)
