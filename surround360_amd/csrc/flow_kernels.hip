@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void k_resize_cubic_u8c4(const uchar4* __restr
   for (int k = 0; k < 4; ++k) { ax[k] = s_ax[threadIdx.x][k]; ay[k] = s_ay[threadIdx.y][k]; }
   // Horizontal pass (round 5): the four taps of a row and channel as two v_perm_b32 (byte -> 16-bit lanes of two pixels) + two
   // v_dot2_i32_i16 with the packed short taps, like the packed remap — 64 operations per pixel instead of 64 byte extractions + 64
-  // 24-bit multiply-adds (the kernel was VALU-bound: 84 % busy, profiles/r05_v10_valu_busy.txt). Integer sums: same bits.
+  // 24-bit multiply-adds. Integer sums: same bits. (Measured: entry downscale 0.67 and finish 1.82 ms per frame before and after —
+  // the compiler had folded the byte extractions into the multiply-adds' operands; kept for its shape, not for a gain.)
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   const s16x2 w01 = __builtin_bit_cast(s16x2, (unsigned)((ax[0] & 0xffff) | (ax[1] << 16)));
   const s16x2 w23 = __builtin_bit_cast(s16x2, (unsigned)((ax[2] & 0xffff) | (ax[3] << 16)));
