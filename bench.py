@@ -376,8 +376,9 @@ def streams_batched(R, rig, flags, device, frames, args, dry, g):
         return ring[m if m < n_ring else 2 * (n_ring - 1) - m]
 
     S = args.stream_slots
-    if S <= 0:  # measured at 8K: 5.7 GB per slot + 2.6 GB for the second halves of its temporal double buffers, 6 GB per context
-        S = 2 if dry else max(1, int((0.90 * total_b / 1e9 / F - 6.5) / 8.4))
+    if S <= 0:  # measured at 8K: 5.7 GB per slot + 0.75 GB for the second halves of the flow INPUTS' double buffers (the flows
+        # themselves are updated in place) + 1.7 GB of previous-frame pyramids, 6 GB per context
+        S = 2 if dry else max(1, int((0.90 * total_b / 1e9 / F - 6.5) / 7.6))
     rec = {}
     for attempt in range(4):
         ctxs = []

@@ -695,11 +695,11 @@ int s360_frame_set_prev_side(s360_ctx* c, int pair, const float* flow_l_to_r, co
     const int j = pair - p0;
     const int prv = F.last_side;  // becomes "the previous frame" of the next render
     F.overlaps[prv].ensure(2 * n * on * sizeof(uchar4));
-    F.sideFlows[prv].ensure(2 * n * on * sizeof(float2));
+    F.sideFlows.ensure(2 * n * on * sizeof(float2));
     h2d(c, F.overlaps[prv].as<uchar4>() + on * j, overlap_l, on * sizeof(uchar4));
     h2d(c, F.overlaps[prv].as<uchar4>() + on * (n + j), overlap_r, on * sizeof(uchar4));
-    h2d(c, F.sideFlows[prv].as<float2>() + on * j, flow_l_to_r, on * sizeof(float2));
-    h2d(c, F.sideFlows[prv].as<float2>() + on * (n + j), flow_r_to_l, on * sizeof(float2));
+    h2d(c, F.sideFlows.as<float2>() + on * j, flow_l_to_r, on * sizeof(float2));
+    h2d(c, F.sideFlows.as<float2>() + on * (n + j), flow_r_to_l, on * sizeof(float2));
     S360_HIP(hipStreamSynchronize(c->st));  // the caller's buffers may be reused as soon as this returns
     F.have_prev_side = true;
   });
@@ -715,10 +715,10 @@ int s360_frame_set_prev_pole(s360_ctx* c, int unit, const float* flow, const uin
     const size_t xs = (size_t)extW * std::max(c->g.top_rows, c->g.bottom_rows);  // slot stride (frame_finish)
     const int prv = F.last_pole;  // becomes "the previous frame" of the next render
     F.extImgs[prv].ensure(6 * xs * sizeof(uchar4));
-    F.poleFlows[prv].ensure(4 * xs * sizeof(float2));
+    F.poleFlows.ensure(4 * xs * sizeof(float2));
     h2d(c, F.extImgs[prv].as<uchar4>() + xs * unit, ext_side, xn * sizeof(uchar4));
     h2d(c, F.extImgs[prv].as<uchar4>() + xs * (unit < 2 ? 4 : 5), ext_fisheye, xn * sizeof(uchar4));
-    h2d(c, F.poleFlows[prv].as<float2>() + xs * unit, flow, xn * sizeof(float2));
+    h2d(c, F.poleFlows.as<float2>() + xs * unit, flow, xn * sizeof(float2));
     S360_HIP(hipStreamSynchronize(c->st));  // the caller's buffers may be reused as soon as this returns
     F.extW = extW;
     F.extStride = xs;
@@ -961,18 +961,18 @@ int s360_frame_get_f32(s360_ctx* c, const char* name, int idx, int whc[3], float
     int w = 0, h = 0;
     const int nloc = F.side_p1 - F.side_p0;
     if (n == "flow_l_to_r" || n == "flow_r_to_l") {
-      need(idx >= F.side_p0 && idx < F.side_p1 && F.sideFlows[F.last_side].p, "flow not available");
+      need(idx >= F.side_p0 && idx < F.side_p1 && F.sideFlows.p, "flow not available");
       w = g.overlap_image_width; h = g.cam_image_height;
       const int j = idx - F.side_p0 + (n == "flow_r_to_l" ? nloc : 0);
-      src = F.sideFlows[F.last_side].as<float2>() + (size_t)w * h * j;
+      src = F.sideFlows.as<float2>() + (size_t)w * h * j;
     } else if (n == "flow_bottom_secondary") {
       need(F.prFlow[F.last_pr].p && F.have_prev_pr, "not available (pole removal not run)");
       w = F.poleW; h = F.poleH;
       src = F.prFlow[F.last_pr].p;
     } else if (n == "flow_pole") {
-      need(idx >= 0 && idx < 4 && F.poleFlows[F.last_pole].p, "flow not available");
+      need(idx >= 0 && idx < 4 && F.poleFlows.p, "flow not available");
       w = F.extW; h = idx < 2 ? F.poleRowsT : F.poleRowsB;
-      src = F.poleFlows[F.last_pole].as<float2>() + F.extStride * idx;
+      src = F.poleFlows.as<float2>() + F.extStride * idx;
     } else {
       throw Error(S360_ERR_INVALID_ARG, "unknown intermediate name: " + n);
     }

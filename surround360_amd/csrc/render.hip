@@ -535,7 +535,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
     }
     const int cur = F.cur_side;
     F.overlaps[cur].ensure(2 * n * on * sizeof(uchar4));
-    F.sideFlows[cur].ensure(2 * n * on * sizeof(float2));
+    F.sideFlows.ensure(2 * n * on * sizeof(float2));
     {
       ProfScope ps(prof, "crop_overlaps");
       launch_crop_overlaps(st, F.sc->proj.as<uchar4>(), camW, camH, P, ow, F.overlaps[cur].as<uchar4>(), p0, p1);
@@ -559,8 +559,8 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
         const int base = (int)fb.images.size();
         fb.add_images(F.overlaps[cur].as<uchar4>(), 2 * n, on);
         if (usePrev) fb.add_prev_images(F.overlaps[prv].as<uchar4>(), 2 * n, on);
-        float2* out = F.sideFlows[cur].as<float2>();
-        const float2* pf = usePrev ? F.sideFlows[prv].as<float2>() : nullptr;
+        float2* out = F.sideFlows.as<float2>();
+        const float2* pf = usePrev ? F.sideFlows.as<float2>() : nullptr;  // (in place: read at the flow's entry, written at its end)
         if (ltor)
           for (int j = 0; j < n; ++j) fb.add_flow(base + j, base + n + j, out + on * j, pf ? pf + on * j : nullptr);
         if (rtol)
@@ -587,7 +587,7 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
       nv.disp = g.verge_at_infinity_slab_displacement;
       // pipelined video stream: the previous frame's panoramas must have been assembled from the strips
       if (c->pipeline && c->haveStripsFree) S360_HIP(hipStreamWaitEvent(st, c->evStripsFree, 0));
-      launch_novel_view(st, F.overlaps[cur].as<uchar4>(), F.sideFlows[cur].as<float2>(), F.strips.as<uchar4>(), nv, p0,
+      launch_novel_view(st, F.overlaps[cur].as<uchar4>(), F.sideFlows.as<float2>(), F.strips.as<uchar4>(), nv, p0,
                         p1, F.tab.dev);
     }
     F.side_p0 = p0;
@@ -719,7 +719,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     // ---- pole units (TRSP:811-860): 0 top_left, 1 top_right, 2 bottom_left, 3 bottom_right ----
     const int cur = F.cur_pole;
     F.extImgs[cur].ensure(6 * xs * sizeof(uchar4));
-    F.poleFlows[cur].ensure(4 * xs * sizeof(float2));
+    F.poleFlows.ensure(4 * xs * sizeof(float2));
     uchar4* ext = F.extImgs[cur].as<uchar4>();
     wait_for_uploads(c, st);
     {
@@ -801,8 +801,8 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
           const int sideIdx = (int)fb.images.size();
           fb.images.push_back(ext + u * xs);
           if (usePrev) fb.prev_images.push_back(pext + u * xs);
-          fb.add_flow(sideIdx, fishIdx[pole], F.poleFlows[cur].as<float2>() + u * xs,
-                      usePrev ? F.poleFlows[prv].as<float2>() + u * xs : nullptr);
+          fb.add_flow(sideIdx, fishIdx[pole], F.poleFlows.as<float2>() + u * xs,
+                      usePrev ? F.poleFlows.as<float2>() + u * xs : nullptr);
         }
       }
       c->flow_pole->compute(st, pc, fb, extW, rows, S360_HINT_DOWN);
@@ -825,7 +825,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         for (int u = 0; u < 4; ++u)
           if (pole_mask & (1 << u)) {
             F.sc->poleWarped[u].ensure(en * sizeof(uchar4));
-            dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xs, F.poleFlows[cur].as<float2>() + u * xs, W, rowsOf(u), extW,
+            dev_pole_unit_post(c, ext + (u < 2 ? 4 : 5) * xs, F.poleFlows.as<float2>() + u * xs, W, rowsOf(u), extW,
                                F.sc->poleWarped[u].as<uchar4>(), H);
             F.poleFrame[u] = F.frames_done;
             F.sc->poleOwner[u] = &F;
