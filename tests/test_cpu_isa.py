@@ -61,3 +61,34 @@ def test_register_and_lds_budgets(quad_asm):
         assert meta["private_segment_fixed_size"] == 0, (name, meta)  # nothing in scratch memory
         assert meta["next_free_vgpr"] <= 256 and meta["occupancy"] == 2, (name, meta)
         assert meta["group_segment_fixed_size"] <= 160 * 1024 // 8, (name, meta)  # eight waves per CU
+
+
+def test_latency_kernel_keeps_nothing_in_scratch(tmp_path):
+    """k_sweep_lock (round 5): the texel-independent part of errorFunction is pinned in front of the barrier through the barrier's asm
+    operands. Passed as members of a struct behind a reference those eight operands became eight scratch slots — spill loads and
+    stores inside the steady step; as scalar locals they are registers. Nothing of the latency kernel may live in scratch memory,
+    and the pinned square root must sit between the step's gathers and its barrier."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "sweep_lock.s")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S",
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "surround360_amd", "csrc", "sweep_lock.hip"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    ks = _kernels(text, "k_sweep_lockILi2ELb1")
+    assert len(ks) == 1, sorted(ks)
+    (name, (meta, loops)), = ks.items()
+    assert meta["private_segment_fixed_size"] == 0 and all(lp["scratch"] == 0 for lp in loops), (name, meta)
+    # between a pair of bilinear gathers (two global_load_dwordx4) and the next s_barrier of the steady step: a v_sqrt_f32
+    import isa_loops
+    lines = isa_loops.parse_functions(text)[name]
+    ops = [ln.split()[0] for ln in lines if ln.strip() and not ln.strip().startswith((";", "."))]
+    found = False
+    for i in range(len(ops) - 1):
+        if ops[i] == "global_load_dwordx4" and "global_load_dwordx4" in ops[i + 1:i + 3]:
+            window = ops[i:i + 90]
+            if "s_barrier" in window and "v_sqrt_f32_e32" in window[:window.index("s_barrier")]:
+                found = True
+                break
+    assert found, "no square root between the gathers and the barrier of a step"
