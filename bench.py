@@ -19,10 +19,12 @@ Then, one context alone on the GPU (nothing else in flight, so kernel durations 
     (48 B per pixel-level-sweep) / its average ISOLATED launch duration from HIP events on the library's
     stream / 8 TB/s; `aggregate_frac` is the same bytes over the wall time of the timed region (launches of up to
     `inflight` frames overlapping);
-  * `single_frame`: configs[2] as a latency (on N GPUs: configs[3] — pairs and pole units sharded over the ranks, the two
-    native RCCL exchanges, composite on rank 0 — run by a child process per rank on a rendezvous of its own, so that a
-    fault in that path cannot cost this line), per-kernel-family milliseconds, the warp/blend and flow-stencil kernels
+  * `single_frame`: configs[2] as a latency, per-kernel-family milliseconds, the warp/blend and flow-stencil kernels
     against the HBM roofline, and the same frame with the reference presets' sharpening 0.25;
+  * `sharded_frame` (N > 1): configs[3] — pairs and pole units sharded over the ranks, the two native RCCL exchanges,
+    composite on rank 0 — ms per frame, `rccl_ranks` as the communicator reports it (ncclCommCount), and each exchange's
+    bytes / ms / GB/s against the 153 GB/s xGMI link (HIP events around ncclGroupStart..ncclGroupEnd); run by a child
+    process per rank on a rendezvous of its own, so that a fault in that path cannot cost this line;
   * `config2_flow_pair`: BASELINE configs[1], one 2048x2048 pair, both directions, GPU vs the CPU oracle;
   * `video_stream`: configs[4] on one GPU — 190 frames of a rotating world with a moving disc, every frame
     regularised toward its predecessor's device-resident flows, inputs fed from page-locked host buffers on the upload
@@ -36,7 +38,8 @@ Then, one context alone on the GPU (nothing else in flight, so kernel durations 
     SAME 8K frame once as a process on the host cores (N=1 only), its equirect compared with the GPU's; where oracle/_ref
     is absent the CPU oracle port with the reference's thread shape (kind "port").
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0. `python bench.py --gpus N` without a launcher starts itself under torch.distributed.run
+(one rank per GPU, 127.0.0.1); under the driver's own torch.distributed.run it runs as the rank it is given.
 """
 import argparse
 import json
@@ -512,6 +515,27 @@ def main():
                     help="frames of the configs[4] stream leg (SURVEY 8d: 190, steady state over frames 10-189)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` started directly: become the launcher the contract names — one rank per GPU under
+        # torch.distributed.run on 127.0.0.1 — with the same arguments; rank 0 prints the one JSON line on this process's stdout.
+        import socket
+        port = 29500
+        for _ in range(8):  # a free port whose successor is free as well (the sharded-frame children rendezvous on port + 1)
+            with socket.socket() as a, socket.socket() as b:
+                a.bind(("127.0.0.1", 0))
+                port = a.getsockname()[1]
+                try:
+                    b.bind(("127.0.0.1", port + 1))
+                    break
+                except OSError:
+                    continue
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver shares device memory between processes through dmabuf only
+        env.setdefault("OMP_NUM_THREADS", "1")
+        sys.stdout.flush()
+        os.execve(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env)
+
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # hardware queues for the in-flight frames (read at HIP init)
     import torch
     from surround360_amd import parallel, render as R, synth
@@ -519,9 +543,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d under a launcher that made %d ranks" % (args.gpus, world))
     # Debugging aids for a box with fewer GPUs than ranks (NOT a bench configuration): S360_BENCH_BACKEND=gloo and
     # S360_BENCH_DEVICE=0 run the multi-process control flow with every rank on one device.
     backend = os.environ.get("S360_BENCH_BACKEND", "nccl")
@@ -641,15 +664,72 @@ def main():
         t = torch.tensor([dt1], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt1 = float(t.item())
+        ok = bool(np.array_equal(c1.download_equirect(), single0)) if rank == 0 else True
+        # ---- the two exchanges on their own: every rank enters each one behind a barrier with an idle stream, HIP events on the
+        # library's stream around ncclGroupStart .. ncclGroupEnd (s360_profile_get "exchange_strips" / "exchange_pole_layers");
+        # the buffers hold the frame just rendered, so re-sending them changes nothing ----
+        n_x = 5
+        before = [c1.comm_stats(0), c1.comm_stats(1)]
+        c1.profile_enable(True)
+        for _ in range(n_x):
+            c1.exchange_strips(bounds, needs)
+            csync()
+        for _ in range(n_x):
+            c1.gather_pole_layers(owner, 0)
+            csync()
+        pr = c1.profile_get()
+        c1.profile_enable(False)
+        after = [c1.comm_stats(0), c1.comm_stats(1)]
+        mine = []
+        for i, fam in enumerate(("exchange_strips", "exchange_pole_layers")):
+            calls = max(after[i]["calls"] - before[i]["calls"], 1)
+            mine += [pr.get(fam, (0.0, 0))[0] / calls, (after[i]["bytes_sent"] - before[i]["bytes_sent"]) / calls,
+                     (after[i]["bytes_received"] - before[i]["bytes_received"]) / calls]
+        mine += [float(c1.comm_size()), float(c1.comm_rank())]
+        tm = torch.tensor(mine, dtype=torch.float64, device=red_dev)
+        allm = [torch.zeros_like(tm) for _ in range(world)]
+        dist.all_gather(allm, tm)
+        per = [[float(v) for v in t.tolist()] for t in allm]
         if rank == 0:
-            ok = bool(np.array_equal(c1.download_equirect(), single0))
-            print(json.dumps({"single_frame": {
+            XGMI_LINK_GBPS = 153.0  # MI355X: 7 links per GPU, ~153 GB/s each, point to point
+
+            gq = c1.geometry
+            per_strip = gq.cam_image_height * (flags["eqr_width"] // P) * 4  # one pair's strip of one eye (uchar4)
+            # the busiest single link: the largest (sender -> receiver) transfer of the group — xGMI is point to point, one link per peer
+            link = [max([bin(needs[r]).count("1") * (bounds[q + 1] - bounds[q]) * per_strip
+                         for q in range(world) for r in range(world) if q != r] or [0]), 0]
+
+            def exchange(i, what):
+                ms = [p[3 * i] for p in per]
+                sent = [p[3 * i + 1] for p in per]
+                recv = [p[3 * i + 2] for p in per]
+                worst = max(ms)
+                link_bytes = link[0] if i == 0 else max(sent)  # pole layers: everything an owner sends goes to the root
+                rate = (lambda b: b / worst / 1e6) if worst > 0 else (lambda b: None)  # (the CPU emulation's events read 0 ms)
+                return {"what": what, "ms": worst, "ms_per_rank": [round(v, 4) for v in ms],
+                        "bytes_moved": int(sum(sent)), "bytes_sent_per_rank": [int(v) for v in sent],
+                        "bytes_received_per_rank": [int(v) for v in recv],
+                        "GBps_aggregate": rate(sum(sent)), "GBps_busiest_receiver": rate(max(recv)),
+                        "busiest_link_bytes": int(link_bytes), "GBps_busiest_link": rate(link_bytes),
+                        "xgmi_link_peak_GBps": XGMI_LINK_GBPS,
+                        "frac_of_link_peak": rate(link_bytes) / XGMI_LINK_GBPS if worst > 0 else None,
+                        "timing": "HIP events on the library's stream around ncclGroupStart..ncclGroupEnd, %d calls, every rank behind a "
+                                  "barrier with an idle stream; ms = the slowest rank" % n_x}
+            sizes = sorted({int(p[6]) for p in per})
+            print(json.dumps({"sharded_frame": {
                 "mode": "configs[3]: one frame at a time, 14 pairs sharded over %d GPUs (%s), one native RCCL exchange (grouped "
                         "ncclSend/ncclRecv, s360_frame_exchange_strips) handing the strips to the ranks that assemble an eye, the "
                         "pole units on ranks %s, a second grouped exchange returning their warped layers to rank 0, which "
                         "composites; run in a process of its own per rank beside the bench's resident contexts" % (world, bounds, owner),
-                "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9), "rccl_ranks": world,
-                "equals_single_gpu_frame": ok}}))
+                "ms": 1e3 * dt1 / n_single, "frames_per_s": n_single / max(dt1, 1e-9),
+                "rccl_ranks": sizes[0] if len(sizes) == 1 else sizes,
+                "rccl_ranks_source": "ncclCommCount of every rank's communicator (s360_comm_size); user ranks %s" % sorted(int(p[7]) for p in per),
+                "rccl_library": R.Context.comm_library_path(),
+                "pair_blocks": bounds, "pole_unit_owner": owner,
+                "exchange_strips": exchange(0, "strips of every pair block to the ranks that assemble an eye (SURVEY 8e, TRSP:320-385)"),
+                "exchange_pole_layers": exchange(1, "warped pole layers of the units run off the root, to the root (TRSP:811-860)"),
+                "checked": ok, "equals_single_gpu_frame": ok,
+                "check": "the sharded frame's equirect byte-compared with the same inputs rendered by rank 0 alone"}}))
             sys.stdout.flush()
         dist.barrier()
         c1.close()
@@ -933,7 +1013,8 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
         "value_note": "aggregate over INDEPENDENT frames (no predecessor: BASELINE configs[2]); temporally chained streams — every preset of "
-                      "the reference — are the `video_streams_batched` leg, one stream the `video_stream` leg, one frame alone `single_frame`",
+                      "the reference — are the `video_streams_batched` leg, one stream the `video_stream` leg, one frame alone `single_frame` "
+                      "(N GPUs: `sharded_frame`, configs[3], the one leg with RCCL exchanges)",
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
@@ -946,8 +1027,7 @@ def main():
                    "parallelism": "frames: %d GPU(s) x %d contexts x %d slots, no collective" % (world, F, S),
                    "parallelism_note": "independent frames: each GPU renders whole frames, %d contexts in flight per GPU (one HIP "
                                        "stream each) of %d frame slots, no data-path collective" % (F, S),
-                   "frames_in_flight": F * S, "contexts": F, "slots_per_context": S, "frames_per_step": S,
-                   "rccl_ranks": world},
+                   "frames_in_flight": F * S, "contexts": F, "slots_per_context": S, "frames_per_step": S},
         "roofline": roofline,
         "without_sharpening": {"value": world * steps0 * S / dt0, "unit": "frames/s", "steps": steps0,
                                "ms_per_step": 1e3 * dt0 / steps0,
@@ -1105,11 +1185,15 @@ def main():
             try:
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
                 lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                rec = json.loads(lines[-1])["single_frame"] if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+                rec = json.loads(lines[-1])["sharded_frame"] if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
             except subprocess.TimeoutExpired:
                 rec = {"error": "the sharded-frame processes did not finish in 240 s"}
             if rank == 0:
-                out["single_frame"] = rec
+                out["sharded_frame"] = rec
+                # the only communicator of this run is the sharded frame's: its size as RCCL reports it (absent if that leg failed)
+                if "rccl_ranks" in rec:
+                    out["config"]["rccl_ranks"] = rec["rccl_ranks"]
+                    out["config"]["rccl_ranks_note"] = "communicator of the `sharded_frame` leg (ncclCommCount); the timed region has none"
             # ---- configs[4] on N GPUs, the honest form: ONE stream cannot use more than one GPU (its pole flows are one serial
             # chain per frame and every frame needs its predecessor's flows: DESIGN.md sections 5 and 7), N streams use N —
             # every rank runs a stream of its own on its GPU at the same time (what host/TestRenderStereoPanorama

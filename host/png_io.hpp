@@ -176,6 +176,10 @@ inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
     const int nthreads = std::max(1, std::min(want, nb));
     std::atomic<int> next(0);
     std::atomic<bool> bad(false);
+    // (the bands are raw deflate: the stream's Adler-32 — the trailing 4-byte IDAT — is checked from per-band sums like the
+    // sequential reader's zlib does it, so a state image whose bytes are damaged but still inflate is refused here too)
+    std::vector<uLong> band_adler((size_t)nb, 1);
+    std::vector<size_t> band_len((size_t)nb, 0);
     auto worker = [&] {
       std::vector<uint8_t> buf;
       for (int bi = next.fetch_add(1); bi < nb && !bad.load(); bi = next.fetch_add(1)) {
@@ -192,6 +196,8 @@ inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
         const bool ok = (rc == Z_OK || rc == Z_STREAM_END) && z2.avail_out == 0 && (z2.avail_in == 0 || rc == Z_STREAM_END);
         inflateEnd(&z2);
         if (!ok) { bad = true; return; }
+        band_adler[bi] = adler32(1L, buf.data(), (uInt)buf.size());
+        band_len[bi] = buf.size();
         for (int r = 0; r < rows; ++r) {
           uint8_t* cur = buf.data() + (size_t)r * line + 1;
           if (cur[-1] == 1) { for (size_t i = (size_t)fbpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - fbpp]); }
@@ -207,7 +213,12 @@ inline void read_into(const std::string& path, bool keep_alpha, Image& im) {
     for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
     worker();
     for (auto& t : th) t.join();
-    if (!bad.load()) return;
+    if (!bad.load()) {
+      uLong adler = 1;
+      for (int bi = 0; bi < nb; ++bi) adler = adler32_combine(adler, band_adler[bi], (z_off_t)band_len[bi]);
+      if ((uint32_t)adler == be32(&file[idat_chunks.back().first])) return;
+      // (a mismatch falls through to the sequential reader, whose zlib reports the stream as corrupt)
+    }
   }
   for (const auto& ch : idat_chunks) idat.insert(idat.end(), file.begin() + ch.first, file.begin() + ch.first + ch.second);
   if (idat.empty()) throw std::runtime_error("corrupt PNG data: " + path);

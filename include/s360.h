@@ -196,7 +196,9 @@ int s360_frame_upload_pole_removal(s360_ctx* ctx, const uint8_t* bottom2_bgr, co
                                    const uint8_t* mask2_bgr, int w, int h);
 /* Enqueue the whole frame on the context stream (asynchronous). use_prev != 0 applies the
  * temporal regularisation against the previous s360_frame_render's device-resident state
- * (the reference's --prev_frame_data_dir, TRSP:215-235, 421-436). */
+ * (the reference's --prev_frame_data_dir, TRSP:215-235, 421-436). The flows of that state are updated in place: a render
+ * that FAILS (non-zero return) leaves the slot without temporal state — the next use_prev render of it runs as a first
+ * frame until a render has completed, or state is handed in again with s360_frame_set_prev_side / _pole. */
 int s360_frame_render(s360_ctx* ctx, int use_prev);
 /* Sharded form for multi-GPU: render only side pairs [pair_begin, pair_end) into this
  * context's strip buffers; strips of other pairs are filled in by the caller (RCCL gather) through
@@ -292,6 +294,15 @@ int s360_comm_destroy(s360_ctx* ctx);
  * names it outright; otherwise by soname — a process that already holds an RCCL, e.g. torch's copy, shares it — then
  * /opt/rocm/lib). S360_RCCL_VERBOSE=1 prints it to stderr once. NULL (and s360_last_error) when no librccl can be loaded. */
 const char* s360_comm_library_path(void);
+/* What the context's COMMUNICATOR reports — ncclCommCount / ncclCommUserRank — not what the caller asked for: 0 / -1 when the
+ * context has none (a context that renders whole frames never makes one); -1 on error (s360_last_error). */
+int s360_comm_size(s360_ctx* ctx);
+int s360_comm_rank(s360_ctx* ctx);
+/* What the two exchanges have moved through this context since its communicator was made: which = 0
+ * s360_frame_exchange_strips / _gather_strips, 1 s360_frame_gather_pole_layers; out = {calls, bytes sent, bytes received}.
+ * Their device time is the "exchange_strips" / "exchange_pole_layers" families of s360_profile_get (HIP events on
+ * s360_stream() around ncclGroupStart .. ncclGroupEnd). */
+int s360_comm_stats(s360_ctx* ctx, int which, unsigned long long out[3]);
 /* bounds: nranks + 1 non-decreasing pair indices from 0 to n_side. */
 int s360_frame_gather_strips(s360_ctx* ctx, const int* bounds, int root);
 /* The pole units on several GPUs as well (SURVEY §8e second stage; the reference runs its four poleToSideFlowThread

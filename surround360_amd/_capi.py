@@ -77,7 +77,7 @@ SYMBOLS = [
     "s360_frame_set_prev_side", "s360_frame_set_prev_pole", "s360_frame_strip_ptr", "s360_frame_finish", "s360_frame_download_equirect", "s360_frame_equirect_dev",
     "s360_frame_cubemap", "s360_frame_get_u8", "s360_frame_get_f32", "s360_set_keep_intermediates", "s360_set_sweep_mode", "s360_set_frame_pipelining", "s360_debug_flow_levels",
     "s360_profile_enable", "s360_profile_get", "s360_save_flow_to_file", "s360_read_flow_from_file",
-    "s360_comm_get_unique_id", "s360_comm_library_path", "s360_comm_init_rank", "s360_comm_init_all", "s360_comm_destroy",
+    "s360_comm_get_unique_id", "s360_comm_library_path", "s360_comm_init_rank", "s360_comm_init_all", "s360_comm_destroy", "s360_comm_size", "s360_comm_rank", "s360_comm_stats",
     "s360_frame_gather_strips", "s360_frame_exchange_strips", "s360_frame_pole_units", "s360_frame_gather_pole_layers", "s360_frame_composite", "s360_comm_loopback", "s360_frame_set_partition",
     "s360_frame_download_equirect_of", "s360_set_frame_slots", "s360_select_frame_slot", "s360_frame_render_batch", "s360_frame_render_slots",
     "s360_isp_config_defaults", "s360_isp_config_from_json", "s360_isp_create", "s360_isp_destroy", "s360_isp_process",

@@ -744,6 +744,25 @@ int s360_comm_init_all(s360_ctx* const* ctxs, int n) {
 int s360_comm_destroy(s360_ctx* c) {
   return guard(c, [&] { need(c, "null ctx"); S360_HIP(hipStreamSynchronize(c->st)); comm_destroy(c); });
 }
+int s360_comm_size(s360_ctx* c) {
+  int n = -1;
+  (void)guard(c, [&] { need(c, "null ctx"); n = comm_size(c); });
+  return n;
+}
+int s360_comm_rank(s360_ctx* c) {
+  int r = -1;
+  (void)guard(c, [&] { need(c, "null ctx"); r = comm_rank(c); });
+  return r;
+}
+int s360_comm_stats(s360_ctx* c, int which, unsigned long long out[3]) {
+  return guard(c, [&] {
+    need(c && out, "null argument");
+    need(which == 0 || which == 1, "which: 0 = strips exchange, 1 = pole-layer gather");
+    out[0] = c->comm_stats[which].calls;
+    out[1] = c->comm_stats[which].sent;
+    out[2] = c->comm_stats[which].received;
+  });
+}
 int s360_frame_gather_strips(s360_ctx* c, const int* bounds, int root) {
   return frame_guard(c, [&] { need(c && bounds, "null argument"); no_pipelining(c); frame_gather_strips(c, bounds, root); });
 }

@@ -35,6 +35,8 @@ struct Rccl {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   std::string err, path;
 };
 Rccl& rccl() {
@@ -46,14 +48,14 @@ Rccl& rccl() {
     const char* forced = std::getenv("S360_RCCL_LIB");
     if (forced && forced[0]) {
       R.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
-      if (!R.h) { R.err = std::string("S360_RCCL_LIB=") + forced + ": " + dlerror(); return; }
+      if (!R.h) { const char* de = dlerror(); R.err = std::string("S360_RCCL_LIB=") + forced + ": " + (de ? de : "dlopen failed"); return; }
     } else {
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (R.h) break;
       }
     }
-    if (!R.h) { R.err = std::string("librccl not found: ") + dlerror(); return; }
+    if (!R.h) { const char* de = dlerror(); R.err = std::string("librccl not found: ") + (de ? de : "dlopen failed"); return; }
     auto sym = [&](const char* n) { void* p = dlsym(R.h, n); if (!p) R.err = std::string("librccl lacks ") + n; return p; };
     R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
     R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
@@ -64,10 +66,13 @@ Rccl& rccl() {
     R.Send = (decltype(R.Send))sym("ncclSend");
     R.Recv = (decltype(R.Recv))sym("ncclRecv");
     R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    R.CommCount = (decltype(R.CommCount))sym("ncclCommCount");
+    R.CommUserRank = (decltype(R.CommUserRank))sym("ncclCommUserRank");
     Dl_info di;
-    if (R.GetUniqueId && dladdr((void*)R.GetUniqueId, &di) && di.dli_fname) R.path = di.dli_fname;
+    if (R.GetUniqueId && dladdr((void*)R.GetUniqueId, &di) && di.dli_fname && di.dli_fname[0]) R.path = di.dli_fname;
+    else R.path = "?";  // loaded, but the loader cannot name the file (NULL is kept for "no librccl": s360.h)
     const char* v = std::getenv("S360_RCCL_VERBOSE");
-    if (v && v[0] == '1') std::fprintf(stderr, "libs360: RCCL entry points from %s\n", R.path.empty() ? "?" : R.path.c_str());
+    if (v && v[0] == '1') std::fprintf(stderr, "libs360: RCCL entry points from %s\n", R.path.c_str());
   });
   if (!R.err.empty()) throw Error(S360_ERR_STATE, R.err);
   return R;
@@ -77,10 +82,19 @@ void nccl_ck(ncclResult_t r, const char* what) {
 }
 }  // namespace
 
-const char* comm_library_path() {
-  static std::string p;
-  p = rccl().path;
-  return p.c_str();
+const char* comm_library_path() { return rccl().path.c_str(); }  // (the singleton's string: written once, under call_once)
+// What the COMMUNICATOR says (ncclCommCount / ncclCommUserRank), not what this library remembers having asked for.
+int comm_size(s360_ctx* c) {
+  if (!c->comm) return 0;
+  int n = 0;
+  nccl_ck(rccl().CommCount((ncclComm_t)c->comm, &n), "ncclCommCount");
+  return n;
+}
+int comm_rank(s360_ctx* c) {
+  if (!c->comm) return -1;
+  int r = -1;
+  nccl_ck(rccl().CommUserRank((ncclComm_t)c->comm, &r), "ncclCommUserRank");
+  return r;
 }
 void comm_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == S360_COMM_ID_BYTES, "ncclUniqueId size");
@@ -98,6 +112,7 @@ void comm_init_rank(s360_ctx* c, const void* id128, int rank, int nranks) {
   c->comm = comm;
   c->comm_rank = rank;
   c->comm_size = nranks;
+  c->comm_stats[0] = c->comm_stats[1] = s360_ctx::CommStats();
 }
 void comm_init_all(s360_ctx* const* ctxs, int n) {
   if (n < 1) throw Error(S360_ERR_INVALID_ARG, "no contexts");
@@ -114,6 +129,7 @@ void comm_init_all(s360_ctx* const* ctxs, int n) {
     ctxs[i]->comm = comms[i];
     ctxs[i]->comm_rank = i;
     ctxs[i]->comm_size = n;
+    ctxs[i]->comm_stats[0] = ctxs[i]->comm_stats[1] = s360_ctx::CommStats();
   }
 }
 void comm_destroy(s360_ctx* c) {
@@ -144,18 +160,24 @@ void frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask)
   F.strips.ensure(2 * P * per);
   uint8_t* base = F.strips.as<uint8_t>();
   if (nr > 1) {
+    ProfScope ps(c->prof, "exchange_strips");
     nccl_ck(R.GroupStart(), "ncclGroupStart");
     ncclResult_t rc = ncclSuccess;
     const int mine = bounds[me + 1] - bounds[me];
+    c->comm_stats[0].calls++;
     for (int eye = 0; eye < 2 && rc == ncclSuccess; ++eye) {
       uint8_t* e = base + (size_t)eye * P * per;
       for (int r = 0; r < nr && rc == ncclSuccess; ++r) {
         if (r == me) continue;
         const int n = bounds[r + 1] - bounds[r];
-        if (mine > 0 && ((need_mask[r] >> eye) & 1))  // r assembles this eye: it gets my block
+        if (mine > 0 && ((need_mask[r] >> eye) & 1)) {  // r assembles this eye: it gets my block
           rc = R.Send(e + bounds[me] * per, mine * per, ncclUint8, r, (ncclComm_t)c->comm, c->st);
-        if (rc == ncclSuccess && n > 0 && ((need_mask[me] >> eye) & 1))  // I assemble this eye: r's block comes in
+          c->comm_stats[0].sent += mine * per;
+        }
+        if (rc == ncclSuccess && n > 0 && ((need_mask[me] >> eye) & 1)) {  // I assemble this eye: r's block comes in
           rc = R.Recv(e + bounds[r] * per, n * per, ncclUint8, r, (ncclComm_t)c->comm, c->st);
+          c->comm_stats[0].received += n * per;
+        }
       }
     }
     const ncclResult_t rc2 = R.GroupEnd();
@@ -200,14 +222,19 @@ void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root) {
     if (me == owner[u] || me == root) ++todo;
   }
   if (!todo) return;
+  ProfScope ps(c->prof, "exchange_pole_layers");
   nccl_ck(R.GroupStart(), "ncclGroupStart");
   ncclResult_t rc = ncclSuccess;
+  c->comm_stats[1].calls++;
   for (int u = 0; u < 4 && rc == ncclSuccess; ++u) {
     if (owner[u] < 0 || owner[u] == root) continue;
     const size_t bytes = (size_t)W * (u < 2 ? c->g.top_rows : c->g.bottom_rows) * sizeof(uchar4);
-    if (me == owner[u]) rc = R.Send(F.sc->poleWarped[u].p, bytes, ncclUint8, root, (ncclComm_t)c->comm, c->st);
-    else if (me == root) {
+    if (me == owner[u]) {
+      rc = R.Send(F.sc->poleWarped[u].p, bytes, ncclUint8, root, (ncclComm_t)c->comm, c->st);
+      c->comm_stats[1].sent += bytes;
+    } else if (me == root) {
       rc = R.Recv(F.sc->poleWarped[u].p, bytes, ncclUint8, owner[u], (ncclComm_t)c->comm, c->st);
+      c->comm_stats[1].received += bytes;
       F.poleFrame[u] = F.frames_done;  // this frame's layer (frame_composite refuses an earlier frame's)
       F.sc->poleOwner[u] = &F;
     }

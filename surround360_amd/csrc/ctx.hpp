@@ -52,6 +52,9 @@ struct s360_ctx {
   // RCCL communicator of the sharded frame (comm.cpp); opaque here so that only comm.cpp needs rccl.h
   void* comm = nullptr;
   int comm_rank = 0, comm_size = 1;
+  // what the two exchanges of the sharded frame have moved since the communicator was made (s360_comm_stats):
+  // [0] s360_frame_exchange_strips, [1] s360_frame_gather_pole_layers
+  struct CommStats { unsigned long long calls = 0, sent = 0, received = 0; } comm_stats[2];
   s360::Rig rig;
   s360_params P;
   s360_geometry g;

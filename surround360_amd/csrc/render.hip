@@ -551,6 +551,9 @@ static void side_stage(s360_ctx* c, const std::vector<int>& slotIds, int p0, int
     // hint in that case. Per slot: images [L_0..L_{n-1}, R_0..R_{n-1}], flows [LtoR_0.., RtoL_0..].
     (void)flow_engine(c, 0);
     const PixFlowConsts pc = pixflow_consts_by_name(c->P.side_flow_alg);
+    // The flows are updated in place (previous-flow input and output of one compute): a compute that throws half-way leaves no
+    // usable previous flow, so the slots' temporal state is withdrawn here and given back behind the stage (below).
+    for (FrameState* F : Fs) F->have_prev_side = false;
     auto build = [&](bool ltor, bool rtol) {
       FlowBatch fb;
       for (size_t k = 0; k < Fs.size(); ++k) {
@@ -780,6 +783,10 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
     // computeOpticalFlow(extendedSide, extendedFisheye, ..., DOWN) for every enabled unit (TRSP:438-448)
     (void)flow_engine(c, 1);
     const PixFlowConsts pc = pixflow_consts_by_name(c->P.polar_flow_alg);
+    for (int k : slotIds) {  // in-place flows: see side_stage — withdrawn here, given back behind the stage
+      SlotScope ss(c, k);
+      frame_state(c).have_prev_pole = false;
+    }
     auto run = [&](int mask, int rows) {
       if (!mask) return;
       FlowBatch fb;
@@ -911,10 +918,6 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         }
         launch_pack_bgr(st, eye, outW, eyeH, F.outBGR[ob].as<uint8_t>() + (size_t)e * outW * eyeH * 3);
       }
-      if (!F.outErr[ob]) {
-        S360_HIP(hipHostMalloc((void**)&F.outErr[ob], 4 * sizeof(unsigned), hipHostMallocDefault));
-        std::memset(F.outErr[ob], 0, 4 * sizeof(unsigned));
-      }
       if (!F.outErrDev[ob].p) {
         F.outErrDev[ob].ensure(4 * sizeof(unsigned));
         S360_HIP(hipMemsetAsync(F.outErrDev[ob].p, 0, 4 * sizeof(unsigned), st));
@@ -923,7 +926,6 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         FlowEngine* eng[3] = {c->flow.get(), c->flow_pole.get(), c->flow_pr.get()};
         for (int i = 0; i < 3; ++i) {
           if (eng[i] && eng[i]->error_word()) {
-            S360_HIP(hipMemcpyAsync(&F.outErr[ob][i], eng[i]->error_word(), sizeof(unsigned), hipMemcpyDeviceToHost, st));
             S360_HIP(hipMemcpyAsync(F.outErrDev[ob].as<unsigned>() + i, eng[i]->error_word(), sizeof(unsigned), hipMemcpyDeviceToDevice, st));
           }
         }

@@ -70,14 +70,13 @@ struct FrameState {
   // kernels that fill outBGR[i].
   DevBuf outBGR[2];
   hipEvent_t outDone[2] = {nullptr, nullptr};
-  // pinned snapshot of the three flow engines' sweep error words, copied on the render stream just in front of
-  // outDone[i]: s360_frame_download_equirect_of refuses a frame whose sweeps timed out without waiting for the frame
-  // that renders behind it (the words are cumulative, so a non-zero value may also come from that next frame's side
-  // flows — either way the stream's results are invalid from here on)
-  unsigned* outErr[2] = {nullptr, nullptr};
-  DevBuf outErrDev[2];  // the same three words on the device (what a download's own stream copies out with the pixels)
+  // device snapshot of the three flow engines' sweep error words, copied on the render stream just in front of
+  // outDone[i]; a download's own stream copies it out with the pixels (ctx downErr): s360_frame_download_equirect_of refuses a
+  // frame whose sweeps timed out without waiting for the frame that renders behind it (the words are cumulative, so a
+  // non-zero value may also come from that next frame's side flows — either way the stream's results are invalid from here on)
+  DevBuf outErrDev[2];
   // s360_frame_download_equirect_of releases the context while it waits: downRead[i] is recorded on the download stream behind
-  // its copy of outBGR[i] / outErr[i], and the finish stage that next writes buffer i waits for it (a feeder two frames ahead of
+  // its copy of outBGR[i] / outErrDev[i], and the finish stage that next writes buffer i waits for it (a feeder two frames ahead of
   // the fetching thread must not overwrite a frame that is still being transferred)
   hipEvent_t downRead[2] = {nullptr, nullptr};
   int out_cur = 0;           // buffer of the most recently ENQUEUED frame
@@ -86,7 +85,6 @@ struct FrameState {
   ~FrameState() {
     for (auto& e : outDone) if (e) (void)hipEventDestroy(e);
     for (auto& e : downRead) if (e) (void)hipEventDestroy(e);
-    for (auto& p : outErr) if (p) (void)hipHostFree(p);
   }
   int cur_side = 0, cur_pole = 0, last_side = 0, last_pole = 0;
   bool have_prev_side = false, have_prev_pole = false;
@@ -126,6 +124,8 @@ const char* comm_library_path();  // the file the RCCL entry points were resolve
 void comm_init_rank(s360_ctx* c, const void* id128, int rank, int nranks);
 void comm_init_all(s360_ctx* const* ctxs, int n);
 void comm_destroy(s360_ctx* c);
+int comm_size(s360_ctx* c);  // ncclCommCount of the context's communicator (0: none)
+int comm_rank(s360_ctx* c);  // ncclCommUserRank (-1: none)
 void frame_gather_strips(s360_ctx* c, const int* bounds, int root);
 void frame_exchange_strips(s360_ctx* c, const int* bounds, const int* need_mask);
 void frame_gather_pole_layers(s360_ctx* c, const int* owner, int root);

@@ -286,11 +286,33 @@ class Context:
         check(lib().s360_comm_get_unique_id(buf))
         return buf.raw
 
+    @staticmethod
+    def comm_library_path():
+        """The file the RCCL entry points were resolved from (None: no librccl could be loaded)."""
+        p = lib().s360_comm_library_path()
+        return p.decode() if p else None
+
     def comm_init_rank(self, unique_id, rank, nranks):
         self._ck(lib().s360_comm_init_rank(self.h, C.c_char_p(unique_id), int(rank), int(nranks)))
 
     def comm_destroy(self):
         self._ck(lib().s360_comm_destroy(self.h))
+
+    def comm_size(self):
+        """ncclCommCount of the context's communicator (0: it has none)."""
+        n = lib().s360_comm_size(self.h)
+        if n < 0:
+            self._ck(-1)
+        return n
+
+    def comm_rank(self):
+        return lib().s360_comm_rank(self.h)
+
+    def comm_stats(self, which):
+        """{calls, bytes_sent, bytes_received} of exchange `which` (0 strips, 1 pole layers) since the communicator was made."""
+        out = (C.c_ulonglong * 3)()
+        self._ck(lib().s360_comm_stats(self.h, int(which), out))
+        return {"calls": int(out[0]), "bytes_sent": int(out[1]), "bytes_received": int(out[2])}
 
     def gather_strips(self, bounds, root=0):
         arr = (C.c_int * len(bounds))(*bounds)

@@ -230,6 +230,24 @@ def test_png_writer_parallel_bands(tmp_path):
             subprocess.check_call([exe, p_out, str(tmp_path / "again.png"), "1"])  # our reader accepts its own output
             assert np.array_equal(np.asarray(Image.open(str(tmp_path / "again.png"))), a)
         assert outs[0] == outs[1] == outs[2]  # the file does not depend on the number of threads
+        if h > 1000:
+            # The banded files are inflated band by band as RAW deflate on the parallel path: the stream's Adler-32 (the trailing
+            # 4-byte IDAT) must still be checked there. A file whose trailer is wrong — chunk CRC valid — is refused, like zlib
+            # refuses it on the sequential path (a damaged state image must not feed temporal regularisation).
+            import struct
+            import zlib
+            data = outs[0]
+            assert b"sbNd" in data
+            iend = data.rindex(b"IEND") - 4
+            tail = data[iend - 16:iend]  # length(4) "IDAT" adler(4) crc(4)
+            assert tail[:8] == struct.pack(">I", 4) + b"IDAT"
+            wrong = bytes([tail[8] ^ 0x40]) + tail[9:12]
+            bad = data[:iend - 16] + tail[:8] + wrong + struct.pack(">I", zlib.crc32(b"IDAT" + wrong)) + data[iend:]
+            p_bad = str(tmp_path / "bad_adler.png")
+            open(p_bad, "wb").write(bad)
+            for threads in ("1", "3"):
+                r = subprocess.run([exe, p_bad, str(tmp_path / "never.png"), threads], capture_output=True, text=True)
+                assert r.returncode != 0 and "corrupt PNG" in r.stderr, (threads, r.stderr[-300:])
 
 
 def test_required_flags_and_unknown_flags():

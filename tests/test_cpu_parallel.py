@@ -91,29 +91,61 @@ def test_sharded_frame_across_processes_gloo(tmp_path, emu_programs, world):
     assert r.returncode == 0 and "SHARDED_FRAME_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
-    """bench.py the way the driver launches it for N > 1 — `python -m torch.distributed.run --nproc-per-node 2 bench.py
-    --gpus 2` — on the emulated library (S360_TEST_EMULATED_LIB=1: NOT a measurement; gloo for the timing reductions, the
-    RCCL stand-in between the two processes): one JSON line from rank 0 with n_gpus 2, every timed frame checked, and the
-    sharded single frame (pairs + pole units over both ranks, the two native exchanges) equal to the unsharded one."""
-    port = 31500 + os.getpid() % 2000
-    env = dict(os.environ, EMU_RCCL_DIR=str(tmp_path), EMU_RCCL_STRICT="1", EMU_DEVICES="2", S360_TEST_EMULATED_LIB="1", S360_BENCH_BACKEND="gloo",
-               S360_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--slots", "1", "--inflight", "1", "--video-frames", "14"], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+def _check_two_rank_line(r):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     d = json.loads(lines[0])
     assert "dry_run" in d and "errors" not in d
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["warmup"] == 0
-    assert d["checked"] is True and d["config"]["rccl_ranks"] == 2
+    assert d["checked"] is True
     assert d["checked_frames"] == 2 and d["mismatching_frames_all_ranks"] == 0  # 1 frame in flight per rank, both ranks counted
-    assert d["single_frame"]["rccl_ranks"] == 2 and d["single_frame"]["equals_single_gpu_frame"] is True
+    # configs[3] as a first-class key; rccl_ranks is what the library's communicator says (ncclCommCount through s360_comm_size,
+    # here read back from the RCCL stand-in), and config.rccl_ranks is that number, not WORLD_SIZE
+    sf = d["sharded_frame"]
+    assert "error" not in sf and sf["checked"] is True and sf["equals_single_gpu_frame"] is True
+    assert sf["rccl_ranks"] == 2 and d["config"]["rccl_ranks"] == 2 and sf["ms"] > 0
+    for key in ("exchange_strips", "exchange_pole_layers"):
+        x = sf[key]
+        assert x["bytes_moved"] > 0 and len(x["ms_per_rank"]) == 2 and x["xgmi_link_peak_GBps"] == 153.0
+        assert sum(x["bytes_sent_per_rank"]) == sum(x["bytes_received_per_rank"]) == x["bytes_moved"]
+    # two ranks: each assembles one eye of the poles -> rank 0 sends its block of the right eye, rank 1 its block of both
+    assert sf["exchange_pole_layers"]["bytes_sent_per_rank"][0] == 0 and sf["exchange_pole_layers"]["bytes_received_per_rank"][1] == 0
     # configs[4] on N GPUs: one stream per rank (VERDICT r03, item 7)
     v = d["video_stream"]
     assert "error" not in v and v["streams"] == 2 and len(v["ms_per_frame_of_each_stream"]) == 2 and v["frames_per_s"] > 0
+    return d
+
+
+BENCH_2 = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--slots", "1", "--inflight", "1", "--video-frames", "14"]
+
+
+def _bench_env(tmp_path):
+    return dict(os.environ, EMU_RCCL_DIR=str(tmp_path), EMU_RCCL_STRICT="1", EMU_DEVICES="2", S360_TEST_EMULATED_LIB="1",
+                S360_BENCH_BACKEND="gloo", S360_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
+
+
+def test_bench_script_starts_itself_for_two_gpus(tmp_path, emu_programs):
+    """`python bench.py --gpus 2` with NO launcher (the form of the driver's recorded command, BENCH_rNN.json "cmd"): the script
+    re-executes itself under torch.distributed.run with one rank per GPU and rank 0 prints the one line. On the emulated library
+    (S360_TEST_EMULATED_LIB=1: NOT a measurement; gloo for the timing reductions, the RCCL stand-in between the two processes)."""
+    env = _bench_env(tmp_path)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + BENCH_2, capture_output=True, text=True, env=env,
+                       timeout=1500, cwd=ROOT)
+    _check_two_rank_line(r)
+
+
+@pytest.mark.skipif(os.environ.get("S360_RUN_SLOW") != "1", reason="the same line under an explicit launcher: opt-in (S360_RUN_SLOW=1)")
+def test_bench_script_two_ranks_dry_run(tmp_path, emu_programs):
+    """bench.py the way the contract launches it for N > 1 — `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2`: the same line as the self-started form above."""
+    port = 31500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py")] + BENCH_2, capture_output=True, text=True,
+                       env=_bench_env(tmp_path), timeout=1500, cwd=ROOT)
+    _check_two_rank_line(r)
 
 
 def test_two_streams_on_two_gpus_equal_two_single_runs(tmp_path, emu_programs):

@@ -272,6 +272,8 @@ ncclResult_t ncclGroupEnd() {
 }
 ncclResult_t ncclSend(const void* p, size_t n, ncclDataType_t, int peer, ncclComm_t c, hipStream_t) { return post(true, const_cast<void*>(p), n, peer, c); }
 ncclResult_t ncclRecv(void* p, size_t n, ncclDataType_t, int peer, ncclComm_t c, hipStream_t) { return post(false, p, n, peer, c); }
+ncclResult_t ncclCommCount(const ncclComm_t c, int* n) { if (!c || !n) return ncclInvalidArgument; *n = c->g->n; return ncclSuccess; }
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* r) { if (!c || !r) return ncclInvalidArgument; *r = c->rank; return ncclSuccess; }
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : (t_err.empty() ? "emulated RCCL error" : t_err.c_str()); }
 }
 
@@ -279,7 +281,7 @@ void* emu_rccl_sym(const char* name) {
   const std::string s(name);
 #define S(n) if (s == #n) return (void*)&n
   S(ncclGetUniqueId); S(ncclCommInitRank); S(ncclCommInitAll); S(ncclCommDestroy); S(ncclGroupStart); S(ncclGroupEnd);
-  S(ncclSend); S(ncclRecv); S(ncclGetErrorString);
+  S(ncclSend); S(ncclRecv); S(ncclGetErrorString); S(ncclCommCount); S(ncclCommUserRank);
 #undef S
   return nullptr;
 }

@@ -8,7 +8,8 @@ of taking the rest with it. No curve is measured here; `bench.py --gpus N` (last
   3. a grouped exchange between the ranks: one small 8K-less frame sharded over the N GPUs by host/TestRenderStereoPanorama
      --num_gpus N (pairs + pole units, both RCCL exchanges), two chained frames, every file against the REFERENCE program's
      digests (tests/golden/refprogram_golden.json)
-  4. python -m torch.distributed.run --nproc-per-node N bench.py --gpus N --steps 4 --warmup 2
+  4. python bench.py --gpus N --steps 4 --warmup 2   (no launcher: the script starts itself under torch.distributed.run, the
+     form of the driver's recorded command; tests/test_cpu_parallel.py runs the same form on the emulation)
 Usage: python tools/multi_gpu_check.py [N]     (N defaults to the number of devices)"""
 import json
 import os
@@ -88,9 +89,7 @@ def main():
     steps = [("1 librccl + devices", [sys.executable, __file__, "--step", "1", str(n)], 120),
              ("2 comm_init_all + loopback", [sys.executable, __file__, "--step", "2", str(n)], 300),
              ("3 sharded frames vs the reference program's digests", [sys.executable, __file__, "--step", "3", str(n)], 600),
-             ("4 bench.py --gpus %d" % n, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-                                          "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.join(ROOT, "bench.py"),
-                                          "--gpus", str(n), "--steps", "4", "--warmup", "2"], 1200)]
+             ("4 bench.py --gpus %d" % n, [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2"], 1200)]
     if EMU:
         steps = steps[:3]
     for name, cmd, tmo in steps:
