@@ -126,7 +126,136 @@ def cpu_baseline_8k(side, top, bottom, rig_path=RIG, flags=None):
 REF_PROGRAM = os.path.join(ROOT, "oracle", "_ref", "TestRenderStereoPanorama")
 
 
-def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420, scratch=None):
+ISP_JSON_NEUTRAL = json.dumps({"CameraIsp": {"bayerPattern": "GBRG"}})  # every other key at CameraIsp's defaults (CameraIsp.h:440-462)
+
+
+def write_capture_container(path, isp_dir, cams_by_id, frames_by_id, bits=12):
+    """The synthetic stream as a capture's .bin container (BinaryFootageFile.cpp: a 4096-byte metadata page, then the packed frames
+    interleaved by camera) + one ISP configuration per camera serial: every B,G,R frame mosaiced (GBRG), 8 -> 12 bits, packed the way
+    the sensor packs two samples into three bytes. Camera k of the container carries the k-th smallest serial, which makes it the
+    rig's "cam<k>" (Unpacker.cpp:203-219). frames_by_id[f][id] = H x W x 3 uint8. Returns the packed bytes [f][k] as written."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(cams_by_id)
+    assert sorted(cams_by_id) == sorted("cam%d" % k for k in range(n))
+    serials = [50000 + 11 * k for k in range(n)]
+    os.makedirs(isp_dir, exist_ok=True)
+    for sn in serials:
+        with open(os.path.join(isp_dir, "%d.json" % sn), "w") as f:
+            f.write(ISP_JSON_NEUTRAL)
+    h, w = frames_by_id[0]["cam0"].shape[:2]
+
+    def pack(job):
+        img, serial = job
+        raw = np.empty((h, w), np.uint8)  # GBRG: (0,0) G, (0,1) B, (1,0) R, (1,1) G; images are B,G,R
+        raw[0::2, 0::2] = img[0::2, 0::2, 1]
+        raw[0::2, 1::2] = img[0::2, 1::2, 0]
+        raw[1::2, 0::2] = img[1::2, 0::2, 2]
+        raw[1::2, 1::2] = img[1::2, 1::2, 1]
+        out = np.zeros((h, w // 2, 3), np.uint8)  # 12-bit samples a = v8 << 4, b likewise: bytes a >> 4, (a & 15) | (b & 15) << 4, b >> 4
+        out[..., 0] = raw[:, 0::2]
+        out[..., 2] = raw[:, 1::2]
+        fr = out.reshape(-1)
+        fr[4:8] = np.array([serial], np.uint32).view(np.uint8)  # the camera stamps its serial number over the first samples
+        return fr
+    page = np.zeros(4096, np.uint8)
+    page[:32] = np.array([0xfaceb00c, 1234, 0, 1, w, h, bits, n], np.uint32).view(np.uint8)
+    written = []
+    with open(path, "wb") as f, ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        f.write(page.tobytes())
+        for fr in frames_by_id:
+            row = list(ex.map(pack, [(fr["cam%d" % k], serials[k]) for k in range(n)]))
+            for b in row:
+                f.write(b.tobytes())
+            written.append(row)
+    return written
+
+
+def batched_streams_run(program, common, src_args, out, tag, first, nf, ns, device, timeout):
+    """One --num_streams run of the host program on one GPU (the streams are the frame slots of one context); the record of what
+    it printed (--v 1) and measured."""
+    import re
+    import subprocess
+    cb = [program] + common + src_args + ["--frame_number", first, "--num_frames", str(nf), "--num_streams", str(ns), "--stream_gpus", "1",
+                                         "--output_data_dir", out, "--prev_frame_data_dir", "NONE",
+                                         "--output_equirect_path", os.path.join(out, tag + "_%s.png"), "--device", str(device),
+                                         "--write_state=false", "--v", "1"]
+    t1 = time.perf_counter()
+    rb = subprocess.run(cb, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    wb = time.perf_counter() - t1
+    if rb.returncode != 0:
+        raise RuntimeError("rc %d: %s" % (rb.returncode, rb.stderr[-300:]))
+    hb = re.search(r"host thread per step:\s+decode \+ upload ([0-9.]+)\s+wait for the encoders ([0-9.]+)\s+wait for the GPU \+ fetch ([0-9.]+)", rb.stderr)
+    sm = re.search(r"steady state:\s+(\d+) frames of steps 1\.\.(\d+) in ([0-9.]+)\s+\(([0-9.]+) frames per second", rb.stderr)
+    rec = {"streams": ns, "frames": nf, "process_wall_s": round(wb, 2), "frames_per_s_process": nf / wb,
+           "host_thread_s_per_step": {"decode_and_upload": float(hb.group(1)), "wait_for_encoders": float(hb.group(2)),
+                                      "wait_for_gpu_and_fetch": float(hb.group(3))} if hb else None}
+    if sm:
+        rec.update({"frames_per_s_steady": float(sm.group(4)), "steady_frames": int(sm.group(1)), "steady_seconds": float(sm.group(3)),
+                    "steady_note": "the program's own clock: from the arrival of step 0's frames on the host to the last file written, "
+                                   "the frames of steps 1..%s" % sm.group(2)})
+    return rec
+
+
+def make_bins_leg(get_ctx, rig_path, stream_frame, dry, local_rank):
+    """The `batched_streams_from_bins` leg of end_to_end_files as a closure host_program_stream calls with its scratch directory."""
+
+    def bins_leg(program, common, work, device, timeout):
+        ctx = get_ctx()
+        from PIL import Image
+        from surround360_amd import isp as I
+        ns, per = (2, 2) if dry else (8, 4)
+        nf = ns * per
+        cams = json.load(open(rig_path))["cameras"]
+        side_ids = [c["id"] for c in cams if "side" in c.get("group", "")]
+        other = [c for c in cams if "side" not in c.get("group", "")]
+        top_id = max(other, key=lambda c: c["forward"][2])["id"]
+        bot_id = min(other, key=lambda c: c["forward"][2])["id"]
+        ids = side_ids + [top_id, bot_id]
+        by_id = []
+        for k in range(nf):
+            side, top, bottom = stream_frame(k)
+            by_id.append(dict(zip(ids, list(side) + [top, bottom])))
+        binp, ispd, outb = os.path.join(work, "0.bin"), os.path.join(work, "isp"), os.path.join(work, "out_bins")
+        os.makedirs(outb)
+        t0 = time.perf_counter()
+        written = write_capture_container(binp, ispd, ids, by_id)
+        t_write = time.perf_counter() - t0
+        rb = batched_streams_run(program, common, ["--bin_list", binp, "--isp_dir", ispd], outb, "bins", "000000", nf, ns, device, timeout)
+        # check: the LAST frame of every stream against the same packed frames sent through the C ABI in this process
+        # (s360_frame_upload_packed: the same ISP arithmetic, CameraIspPipe at 16 bits as Unpacker runs it), one stream
+        # after the other in one context, latency sweep kernel, pixels fetched with s360_frame_download_equirect
+        isp = I.CameraIsp(I.config_from_json(ISP_JSON_NEUTRAL, 16, pipe=I.PIPE), device=local_rank)
+        hh, ww = by_id[0][ids[0]].shape[:2]
+        ctx.set_sweep_mode("latency")
+        bad = []
+        Image.MAX_IMAGE_PIXELS = None
+        for st_ in range(ns):
+            for j in range(per):
+                f = st_ * per + j
+                for k, cid in enumerate(side_ids):
+                    ctx.upload_packed(isp, k, written[f][int(cid[3:])], 12, ww, hh)
+                ctx.upload_packed(isp, -1, written[f][int(top_id[3:])], 12, ww, hh)
+                ctx.upload_packed(isp, -2, written[f][int(bot_id[3:])], 12, ww, hh)
+                ctx.render(j > 0)
+            want = ctx.download_equirect()
+            got = np.asarray(Image.open(os.path.join(outb, "bins_%06d.png" % (st_ * per + per - 1))))[:, :, ::-1]
+            if got.shape != want.shape or not np.array_equal(got, want):
+                bad.append(st_)
+        isp.close()
+        rb.update({"checked": not bad, "mismatching_streams": bad, "container_bytes": os.path.getsize(binp),
+                   "container_write_s": round(t_write, 2),
+                   "output_png_bytes_per_frame": sum(os.path.getsize(os.path.join(outb, "bins_%06d.png" % k)) for k in range(nf)) // nf,
+                   "check": "the last frame's file of every stream decoded by PIL (libpng) against s360_frame_download_equirect of "
+                            "the same packed frames rendered through the C ABI in this process",
+                   "note": "%d frames as %d streams of %d, one process, one context with %d frame slots: inputs straight from the "
+                           "capture's .bin container (12-bit packed Bayer, mmap -> s360_frame_upload_packed -> ISP on the device), "
+                           "outputs as PNG files filtered and deflated on the device (s360_frame_download_png): the host inflates "
+                           "and deflates nothing" % (nf, ns, per, ns)})
+        return rb
+    return bins_leg
+
+
+def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420, scratch=None, bins_leg=None):
     """"state both the device-path fps and the end-to-end fps incl. raw I/O". The drop-in host program
     (host/TestRenderStereoPanorama, the reference's binary name / flags / file layout) renders `frames` consecutive
     frames as ONE stream from PNG files on disk to equirect PNG files on disk: 17 PNG decodes per frame, upload, render
@@ -244,36 +373,35 @@ def host_program_stream(frames, rig_path, flags, program, device=0, timeout=420,
         except Exception as e:  # noqa: BLE001
             rec["single_invocation"] = {"error": repr(e)}
         # ---- the same files as FOUR streams in one process on this GPU (--num_streams 4: the streams are the frame slots of one
-        # context, frame k of all four in one launch sequence, each with its own temporal state) ----
+        # context, frame k of all four in one launch sequence, each with its own temporal state); the equirects leave as PNGs the
+        # DEVICE encoded (--device_png, the default: png.hip) ----
+        common = ["--rig_json_file", rig_path, "--sharpening", repr(float(flags.get("sharpening", 0.0)))]
+        for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
+            common += ["--" + k, str(flags[k])]
+        common += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
         try:
             ns = 4
             nf = (n // ns) * ns
             if nf >= 2 * ns:
-                cb = [program, "--rig_json_file", rig_path, "--imgs_dir", imgs, "--frame_number", "000000", "--num_frames", str(nf),
-                      "--num_streams", str(ns), "--stream_gpus", "1", "--output_data_dir", out, "--prev_frame_data_dir", "NONE",
-                      "--output_equirect_path", os.path.join(out, "batched_%s.png"), "--sharpening", repr(float(flags.get("sharpening", 0.0))),
-                      "--device", str(device), "--write_state=false", "--v", "1"]
-                for k in ("eqr_width", "eqr_height", "final_eqr_width", "final_eqr_height"):
-                    cb += ["--" + k, str(flags[k])]
-                cb += [f for f in ("--enable_top", "--enable_bottom") if flags.get(f[2:])]
-                t1 = time.perf_counter()
-                rb = subprocess.run(cb, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
-                wb = time.perf_counter() - t1
-                if rb.returncode != 0:
-                    raise RuntimeError("rc %d: %s" % (rb.returncode, rb.stderr[-300:]))
-                hb = re.search(r"host thread per step:\s+decode \+ upload ([0-9.]+)\s+wait for the encoders ([0-9.]+)\s+wait for the GPU \+ fetch ([0-9.]+)", rb.stderr)
+                rb = batched_streams_run(program, common, ["--imgs_dir", imgs], out, "batched", "000000", nf, ns, device, timeout)
                 first = np.asarray(Image.open(os.path.join(out, "batched_000000.png")))[:, :, ::-1]
                 ref0 = np.asarray(Image.open(outs[0]))[:, :, ::-1]
-                rec["batched_streams"] = {
-                    "streams": ns, "frames": nf, "process_wall_s": round(wb, 2), "frames_per_s_process": nf / wb,
-                    "first_frame_equals_stream": bool(np.array_equal(first, ref0)),
-                    "host_thread_s_per_step": {"decode_and_upload": float(hb.group(1)), "wait_for_encoders": float(hb.group(2)),
-                                               "wait_for_gpu_and_fetch": float(hb.group(3))} if hb else None,
-                    "note": "%d frames as %d streams of %d (segments of the frame range), one process, one context with %d frame slots; PNG "
-                            "files in and out like the stream above (the PNG codecs of %d frames per step share the process's CPUs)" % (
-                                nf, ns, nf // ns, ns, ns)}
+                rb["first_frame_equals_stream"] = bool(np.array_equal(first, ref0))
+                rb["output_png_bytes_per_frame"] = sum(os.path.getsize(os.path.join(out, "batched_%06d.png" % k)) for k in range(nf)) // nf
+                rb["note"] = ("%d frames as %d streams of %d (segments of the frame range), one process, one context with %d frame slots; "
+                              "17 PNG files per frame in (inflated by host threads), one PNG per frame out, filtered and deflated on the "
+                              "device" % (nf, ns, nf // ns, ns))
+                rec["batched_streams"] = rb
         except Exception as e:  # noqa: BLE001
             rec["batched_streams"] = {"error": repr(e)}
+        # ---- the same streams fed from the capture's .bin containers (--bin_list: raw 12-bit Bayer frames, developed by the ISP
+        # on the device — SURVEY 8f row 4) and written as device-encoded PNGs: no pixel is inflated or deflated on the host ----
+        if bins_leg is not None:
+            try:
+                rec["batched_streams_from_bins"] = bins_leg(program, common, work, device, timeout)
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                rec["batched_streams_from_bins"] = {"error": repr(e), "trace": traceback.format_exc()[-400:]}
         return rec, last
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -605,10 +733,13 @@ def main():
         del rr, wtex
         torch.cuda.empty_cache()
         prog = os.path.join(ROOT, "tools", "emu", "TestRenderStereoPanorama") if dry else os.path.join(ROOT, "host", "TestRenderStereoPanorama")
-        res = host_program_stream(fr, rig_path, flags, prog, device=local_rank)
+        c1 = R.Context(rig, R.make_params(**flags), device=local_rank)
+        n14 = min(14, len(fr))
+        res = host_program_stream(fr[:n14], rig_path, flags, prog, device=local_rank,
+                                  bins_leg=make_bins_leg(lambda: c1, rig_path, lambda k: fr[k % len(fr)], dry, local_rank))
         rec = res[0] if isinstance(res, tuple) else res
         if isinstance(res, tuple):  # the same chain through the C ABI in this process
-            c1 = R.Context(rig, R.make_params(**flags), device=local_rank)
+            fr = fr[:n14]
             c1.set_frame_pipelining(True)
             for k, f in enumerate(fr):
                 c1.upload_frame(*f)
@@ -1320,7 +1451,9 @@ def main():
                 n_e2e = min(14, n_distinct)
                 prog = os.path.join(ROOT, "tools", "emu", "TestRenderStereoPanorama") if dry else \
                     os.path.join(ROOT, "host", "TestRenderStereoPanorama")
-                res = host_program_stream([stream_frame(k) for k in range(n_e2e)], rig_path, flags, prog, device=local_rank)
+
+                bins_leg = make_bins_leg(lambda: ctx, rig_path, stream_frame, dry, local_rank)
+                res = host_program_stream([stream_frame(k) for k in range(n_e2e)], rig_path, flags, prog, device=local_rank, bins_leg=bins_leg)
                 if isinstance(res, tuple):
                     rec, last_png = res
                     _, eq_chain = stream(True, n_e2e, True)  # the same chain through the C ABI in this process

@@ -56,6 +56,10 @@ struct Flags {
          {"alsologtostderr", "false"},
          // additions of this implementation (opt-in)
          {"device", "0"}, {"write_state", "true"},
+         // --device_png (default on): the output equirect's PNG is filtered and deflated on the GPU behind the frame's last kernel
+         // (s360_set_png_encode / s360_frame_download_png) and this program only writes the bytes; false: the frame's pixels come
+         // back and host threads encode them (png_io.hpp). Same pixels in the file either way.
+         {"device_png", "true"},
          // --num_gpus G: the 14 side pairs of the frame sharded over G GPUs, one RCCL strip gather
          {"num_gpus", "1"},
          // --num_frames N: frames frame_number .. +N-1 as ONE stream in this process (temporal state stays on the
@@ -80,7 +84,7 @@ struct Flags {
   }
   static bool is_bool(const std::string& k) {
     static const char* b[] = {"save_debug_images", "enable_top", "enable_bottom", "enable_pole_removal", "logtostderr",
-                              "alsologtostderr", "write_state", "soft_isp"};
+                              "alsologtostderr", "write_state", "soft_isp", "device_png"};
     for (auto s : b)
       if (k == s) return true;
     return false;
@@ -185,6 +189,16 @@ void load_png_into(const std::string& path, bool keep_alpha, pngio::Image& im) {
 // 256-thread machine (profiles/r04_v2_end_to_end_*).
 static bool g_fast_exit = false;
 static int g_png_threads = 0;  // 0 = one per band, up to the hardware threads
+// a PNG the device has encoded: nothing left to do but write the bytes (a short write leaves no file behind, like save_png)
+void save_bytes(const std::string& path, const uint8_t* data, size_t n) {
+  try {
+    pngio::OutFile f(path);
+    f.put(data, n);
+    f.close();
+  } catch (const std::exception& e) {
+    die(e.what());
+  }
+}
 void save_png(const std::string& path, const uint8_t* px, int w, int h, int c) {
   try {
     pngio::write(path, px, w, h, c, 1, g_png_threads);
@@ -723,6 +737,8 @@ static int run_job(const Flags& flags) {
     ck(s360_set_frame_pipelining(J.ctx[0], 1), J.ctx[0]);  // pole stage of frame k overlaps side stage of k+1
   }
   if (!F.s("bin_list").empty()) open_bins(J);
+  const bool devPng = F.b("device_png");
+  if (devPng) ck(s360_set_png_encode(J.ctx[0], 1), J.ctx[0]);  // (the root composites and holds the output)
 
   const s360_geometry& g = J.g;
   const std::string prev = F.s("prev_frame_data_dir");
@@ -741,7 +757,7 @@ static int run_job(const Flags& flags) {
 
   // Up to two finished frames are PNG-encoded and written while the next one renders (one encoder per frame, parallel
   // deflate inside it): an 8192 x 8192 file takes longer to encode and write than the frame takes to render.
-  const size_t outBytes = (size_t)g.out_width * g.out_height * 3;
+  const size_t outBytes = devPng ? s360_frame_png_bound(J.ctx[0]) : (size_t)g.out_width * g.out_height * 3;
   constexpr int kMaxEncoders = 4;
   const char* encEnv = std::getenv("S360_ENCODERS");  // (developer switch)
   const int kEncoders = std::max(1, std::min(kMaxEncoders, encEnv ? std::atoi(encEnv) : 3));
@@ -806,7 +822,9 @@ static int run_job(const Flags& flags) {
       tUpload += now_sec() - t1;
     }
     const double tf = now_sec();
-    if (last) ck(s360_frame_download_equirect(J.ctx[0], outBuf[cur].data()), J.ctx[0]);
+    size_t pngBytes = 0;
+    if (devPng) ck(s360_frame_download_png(J.ctx[0], last ? 0 : 1, outBuf[cur].data(), outBuf[cur].size(), &pngBytes), J.ctx[0]);
+    else if (last) ck(s360_frame_download_equirect(J.ctx[0], outBuf[cur].data()), J.ctx[0]);
     else ck(s360_frame_download_equirect_of(J.ctx[0], 1, outBuf[cur].data()), J.ctx[0]);  // frame k, while k+1 renders
     if (!leaving.empty()) {  // frame k is complete, so frame k+1's uploads (enqueued before it rendered) are long done
       ck(s360_frame_uploads_complete(J.ctx[0]), J.ctx[0]);
@@ -819,7 +837,8 @@ static int run_job(const Flags& flags) {
     // segment of one frame is named like the others)
     const std::string outPath = frame_path(F.s("output_equirect_path"), frame);
     const uint8_t* px = outBuf[cur].data();
-    encoder[cur] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });  // TRSP:961
+    if (devPng) encoder[cur] = std::thread([px, outPath, pngBytes] { save_bytes(outPath, px, pngBytes); });
+    else encoder[cur] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });  // TRSP:961
     // the reference writes the state of every frame; a stream only needs it to resume after its last frame. (Beside the
     // equirect's encoder, not in front of it.)
     if (F.b("write_state") && last) write_state(J, frame);
@@ -884,7 +903,6 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
   init_job(J, flags);
   Flags& F = J.F;
   const int verbose = F.i("v");
-  if (!F.s("bin_list").empty()) die("--bin_list is not available with several streams per GPU");
   if (F.i("cubemap_width") > 0 && F.i("cubemap_height") > 0 && !F.s("output_cubemap_path").empty())
     die("--output_cubemap_path is not available with --num_streams");
   const int S = (int)segs.size();
@@ -896,9 +914,16 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
   J.bounds = {0, J.P};
   assign_pole_units(J);
   ck(s360_set_frame_slots(ctx, S), ctx);
+  if (!F.s("bin_list").empty()) {  // every stream's frames straight from the capture's containers: no PNG is inflated
+    F.v["device"] = std::to_string(device);  // (open_bins makes the ISP objects on the job's device)
+    open_bins(J);
+  }
   ck(s360_set_sweep_mode(ctx, "throughput"), ctx);  // many flows per launch: the kernel with the fewest instructions per pixel
   const s360_geometry& g = J.g;
-  const size_t outBytes = (size_t)g.out_width * g.out_height * 3;
+  const bool devPng = F.b("device_png");
+  if (devPng) ck(s360_set_png_encode(ctx, 1), ctx);
+  const size_t outBytes = devPng ? s360_frame_png_bound(ctx) : (size_t)g.out_width * g.out_height * 3;
+  std::vector<size_t> pngBytes(S, 0);
 
   int steps = 0;
   for (const Segment& sg : segs) steps = std::max(steps, sg.n);
@@ -937,7 +962,7 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
   std::vector<pngio::Pixels> outBuf(S);
   for (auto& b : outBuf) b.resize(outBytes);
   std::vector<std::thread> encoder(S);
-  double tGpuWait = 0, tEncWait = 0, tDecWait = 0;
+  double tGpuWait = 0, tEncWait = 0, tDecWait = 0, tStep0 = 0;
   start_decode(0);
   std::vector<FrameInputs> next(S);
   upload_step(0, cur);
@@ -956,10 +981,13 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
     for (int s = 0; s < S; ++s)
       if (k < segs[s].n) {
         ck(s360_select_frame_slot(ctx, s), ctx);
-        ck(s360_frame_download_equirect(ctx, outBuf[s].data()), ctx);  // (the first one waits for the step)
+        // (the first one waits for the step)
+        if (devPng) ck(s360_frame_download_png(ctx, 0, outBuf[s].data(), outBuf[s].size(), &pngBytes[s]), ctx);
+        else ck(s360_frame_download_equirect(ctx, outBuf[s].data()), ctx);
         if (F.b("write_state") && k + 1 == segs[s].n) write_state(J, name[s]);
       }
     tGpuWait += now_sec() - t2;
+    if (k == 0) tStep0 = now_sec();  // the first step's frames have arrived: the steady state is measured from here
     if (k + 1 < steps) {
       ck(s360_frame_uploads_complete(ctx), ctx);
       render_step(k + 1);
@@ -968,7 +996,9 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
       if (k < segs[s].n) {
         const std::string outPath = frame_path(F.s("output_equirect_path"), name[s]);
         const uint8_t* px = outBuf[s].data();
-        encoder[s] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });
+        const size_t nb = pngBytes[s];
+        if (devPng) encoder[s] = std::thread([px, outPath, nb] { save_bytes(outPath, px, nb); });
+        else encoder[s] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });
         name[s] = next_frame_name(name[s]);
         spare[s] = std::move(cur[s]);  // its uploads have run (s360_frame_uploads_complete above, or the step is over)
       }
@@ -986,8 +1016,15 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
                  endTime - startTime, (endTime - startTime) / frames);
     std::fprintf(stderr, "host thread per step:    decode + upload %.3f  wait for the encoders %.3f  wait for the GPU + fetch %.3f\n",
                  tDecWait / steps, tEncWait / steps, tGpuWait / steps);
+    int later = 0;  // frames of the steps behind the first one (which pays for maps, buffers and kernel loading)
+    for (const Segment& sg : segs) later += std::max(0, sg.n - 1);
+    if (later > 0 && endTime > tStep0)
+      std::fprintf(stderr, "steady state:            %d frames of steps 1..%d in %.3f  (%.2f frames per second, files written)\n", later, steps - 1,
+                   endTime - tStep0, later / (endTime - tStep0));
     std::fprintf(stderr, "TOTAL:                   %.3f\n", endTime - startTime);
   }
+  for (auto& kv : J.binCam)
+    if (kv.second.isp) s360_isp_destroy(kv.second.isp);
   s360_destroy(ctx);
   return 0;
 }

@@ -221,6 +221,24 @@ int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
  * frame k+2 is enqueued; from then on the library orders things itself — the frame that reuses k's output buffer (k+2) waits on
  * the device for k's transfer, and k's sweep error words travel with its pixels. One fetching thread per context. */
 int s360_frame_download_equirect_of(s360_ctx* ctx, int age, uint8_t* out_bgr);
+/* ---- the equirect as a PNG FILE, encoded on the device -------------------------------------------------
+ * Replaces imwriteExceptionOnFail(FLAGS_output_equirect_path, ...) (TRSP:938-961; cv::imwrite's PngEncoder: 8-bit RGB, Sub filter,
+ * zlib Z_BEST_SPEED + Z_RLE) for the output frame: with s360_set_png_encode(ctx, 1) every frame rendered from then on is also
+ * filtered (Sub) and deflated (dynamic Huffman over literals + distance-1 matches, one independent segment per band of rows) by
+ * HIP kernels behind its last kernel, and s360_frame_download_png copies the compressed file image instead of the 201 MB of
+ * pixels of an 8K frame; the host side of the call adds what needs no pixel (signature, IHDR, the chunks' CRC-32 on
+ * S360_PNG_CRC_THREADS threads, default 4, the combined Adler-32, IEND). `out` receives a complete PNG file (any reader; the
+ * banded layout of host/png_io.hpp, whose reader inflates the bands in parallel) that decodes to exactly the bytes
+ * s360_frame_download_equirect returns, as R,G,B. cap >= s360_frame_png_bound(ctx); page-locked memory (s360_host_alloc) makes
+ * the copy a direct transfer. age / threading contract: as s360_frame_download_equirect_of (age 0 works without pipelining).
+ * S360_ERR_STATE when that frame was rendered with the encoder off. */
+int s360_set_png_encode(s360_ctx* ctx, int on);
+size_t s360_frame_png_bound(s360_ctx* ctx);
+int s360_frame_download_png(s360_ctx* ctx, int age, uint8_t* out, size_t cap, size_t* n_out);
+/* The same encoder as an operator: any 8-bit B,G,R image in host memory (rows contiguous) -> a PNG file in `out`
+ * (cap >= s360_png_bound(w, h)); synchronous. */
+size_t s360_png_bound(int w, int h);
+int s360_encode_png(s360_ctx* ctx, const uint8_t* bgr, int w, int h, uint8_t* out, size_t cap, size_t* n_out);
 /* Page-locked host buffers for streaming hosts (what the reference's per-frame loop has no need for: its cv::Mat pixels
  * never leave the host, RigDescription.cpp:80-108 / TRSP:961). An image passed to s360_frame_upload_* from such a buffer is
  * sent straight from it — no staging copy inside the library, the call returns in microseconds — and must then stay

@@ -2,6 +2,7 @@
 // the operator-level calls, exception -> error-code translation. No CPU fallback anywhere.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -320,6 +321,7 @@ void s360_destroy(s360_ctx* c) {
   if (c->evMaps) (void)hipEventDestroy(c->evMaps);
   if (c->evDown) (void)hipEventDestroy(c->evDown);
   if (c->downErr) (void)hipHostFree(c->downErr);
+  if (c->pngMetaHost) (void)hipHostFree(c->pngMetaHost);
   if (c->evUpHost) (void)hipEventDestroy(c->evUpHost);
   if (c->stUp) {
     (void)hipStreamDestroy(c->stUp);
@@ -861,6 +863,107 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
         if (e) (void)e->take_error(c->st);
       throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
     }
+  });
+}
+/* ---- the equirect as a PNG file, encoded on the device (png.hip; replaces imwriteExceptionOnFail, TRSP:938-961) ---- */
+static int png_crc_threads() {
+  const char* e = std::getenv("S360_PNG_CRC_THREADS");
+  const int n = e ? std::atoi(e) : 4;
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+int s360_set_png_encode(s360_ctx* c, int on) {
+  return guard(c, [&] { need(c, "null ctx"); c->png_encode = on != 0; });
+}
+size_t s360_png_bound(int w, int h) {
+  size_t n = 0;
+  (void)guard(nullptr, [&] { n = PngPlan::make(w, h).file_bound; });
+  return n;
+}
+size_t s360_frame_png_bound(s360_ctx* c) {
+  size_t n = 0;
+  if (!c) return 0;
+  (void)guard(c, [&] { n = PngPlan::make(c->g.out_width, c->g.out_height).file_bound; });
+  return n;
+}
+// band table to the host (event wait with the context released), then the file image's bytes, then the CRCs off the lock
+static void png_fetch(s360_ctx* c, std::unique_lock<std::recursive_mutex>& lk, const PngPlan& plan, const DevBuf& meta, const DevBuf& file,
+                      hipEvent_t after /* nullable: what the copy waits for */, hipEvent_t readDone /* nullable: recorded behind the copies */,
+                      const void* errDev, uint8_t* out, size_t cap, size_t* n_out, bool release = true) {
+  if (!c->stDown) S360_HIP(hipStreamCreateWithFlags(&c->stDown, hipStreamNonBlocking));
+  if (!c->evDown) S360_HIP(hipEventCreateWithFlags(&c->evDown, hipEventDisableTiming | hipEventBlockingSync));
+  if (!c->downErr) {
+    S360_HIP(hipHostMalloc((void**)&c->downErr, 4 * sizeof(unsigned), hipHostMallocDefault));
+    std::memset(c->downErr, 0, 4 * sizeof(unsigned));
+  }
+  const size_t mbytes = ((size_t)plan.nbands + 1) * sizeof(PngBandMeta);
+  if (c->pngMetaHostBytes < mbytes) {
+    if (c->pngMetaHost) (void)hipHostFree(c->pngMetaHost);
+    c->pngMetaHost = nullptr;
+    c->pngMetaHostBytes = 0;
+    S360_HIP(hipHostMalloc(&c->pngMetaHost, mbytes, hipHostMallocDefault));
+    c->pngMetaHostBytes = mbytes;
+  }
+  if (after) S360_HIP(hipStreamWaitEvent(c->stDown, after, 0));
+  S360_HIP(hipMemcpyAsync(c->pngMetaHost, meta.p, mbytes, hipMemcpyDeviceToHost, c->stDown));
+  if (errDev) S360_HIP(hipMemcpyAsync(c->downErr, errDev, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stDown));
+  S360_HIP(hipEventRecord(c->evDown, c->stDown));
+  hipEvent_t ev = c->evDown;
+  if (release) lk.unlock();
+  hipError_t rc = hipEventSynchronize(ev);
+  if (release) lk.lock();
+  S360_HIP(rc);
+  std::vector<PngBandMeta> m((size_t)plan.nbands + 1);
+  std::memcpy(m.data(), c->pngMetaHost, mbytes);
+  const unsigned errw = errDev ? (c->downErr[0] | c->downErr[1] | c->downErr[2]) : 0u;
+  const size_t end_bands = (size_t)m[plan.nbands].file_off;
+  if (end_bands > plan.file_bound || end_bands + 28 > cap) {
+    if (readDone) S360_HIP(hipEventRecord(readDone, c->stDown));
+    throw Error(S360_ERR_INVALID_ARG, "png: output buffer too small (s360_frame_png_bound / s360_png_bound give the size to allocate)");
+  }
+  S360_HIP(hipMemcpyAsync(out, file.p, end_bands, hipMemcpyDeviceToHost, c->stDown));
+  if (readDone) S360_HIP(hipEventRecord(readDone, c->stDown));
+  S360_HIP(hipEventRecord(c->evDown, c->stDown));
+  ev = c->evDown;
+  if (release) lk.unlock();
+  rc = hipEventSynchronize(ev);
+  if (rc != hipSuccess) { if (release) lk.lock(); S360_HIP(rc); }
+  if (errw) {
+    if (release) lk.lock();
+    for (FlowEngine* e : {c->flow.get(), c->flow_pole.get(), c->flow_pr.get()})
+      if (e) (void)e->take_error(c->st);
+    throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
+  }
+  // the file's frame around the bands and the chunks' CRCs: host work on the caller's buffer, the context stays free meanwhile
+  const size_t n = png_finish_host(out, cap, plan, m.data(), png_crc_threads());
+  if (release) lk.lock();
+  *n_out = n;
+}
+int s360_frame_download_png(s360_ctx* c, int age, uint8_t* out, size_t cap, size_t* n_out) {
+  if (!c) return S360_ERR_INVALID_ARG;
+  return guard_l(c, [&](std::unique_lock<std::recursive_mutex>& lk) {
+    need(out && n_out && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
+    FrameState& F = frame_state(c);
+    need(F.frames_done > age, "that frame has not been rendered");
+    need(age == 0 || (c->pipeline && F.outBGR[F.out_cur ^ 1].p), "age 1 needs s360_set_frame_pipelining (two output buffers)");
+    const int b = age == 0 ? F.out_cur : F.out_cur ^ 1;
+    if (F.pngFrame[b] != F.frames_done - 1 - age || !F.pngFile[b].p)
+      throw Error(S360_ERR_STATE, "that frame was rendered without s360_set_png_encode");
+    if (!F.downRead[b]) S360_HIP(hipEventCreateWithFlags(&F.downRead[b], hipEventDisableTiming));
+    png_fetch(c, lk, F.pngPlan[b], F.pngMeta[b], F.pngFile[b], F.outDone[b], F.downRead[b], F.outErrDev[b].p, out, cap, n_out);
+  });
+}
+int s360_encode_png(s360_ctx* c, const uint8_t* bgr, int w, int h, uint8_t* out, size_t cap, size_t* n_out) {
+  if (!c) return S360_ERR_INVALID_ARG;
+  return guard_l(c, [&](std::unique_lock<std::recursive_mutex>& lk) {
+    need(bgr && out && n_out && w > 0 && h > 0, "bad argument");
+    const PngPlan plan = PngPlan::make(w, h);
+    const size_t nb = (size_t)w * h * 3;
+    c->op_a.ensure((nb + 3) & ~(size_t)3);
+    c->op_b.ensure(plan.file_bound);
+    S360_HIP(hipMemcpyAsync(c->op_a.p, bgr, nb, hipMemcpyHostToDevice, c->st));
+    png_encode_enqueue(c->st, c->op_a.as<uint8_t>(), plan, c->op_c, c->op_d, c->op_b.as<uint8_t>());
+    S360_HIP(hipStreamSynchronize(c->st));
+    png_fetch(c, lk, plan, c->op_d, c->op_b, nullptr, nullptr, nullptr, out, cap, n_out, false);  // (the operator scratch stays locked)
   });
 }
 /* ---- page-locked host buffers for streaming hosts ---- */

@@ -40,6 +40,9 @@ struct s360_ctx {
   hipStream_t stDown = nullptr;  // s360_frame_download_equirect_of: device -> host copy of a finished frame
   hipEvent_t evDown = nullptr;   // ... and what its host thread sleeps on with the context lock released
   unsigned* downErr = nullptr;   // ... and that frame's sweep error words (pinned; copied on stDown with the pixels)
+  bool png_encode = false;       // s360_set_png_encode: every finished frame is also encoded as a PNG on the device
+  void* pngMetaHost = nullptr;   // pinned landing area of a frame's band table (s360_frame_download_png)
+  size_t pngMetaHostBytes = 0;
   hipEvent_t evUpHost = nullptr; // s360_frame_uploads_complete
   static constexpr int kPinChunks = 4;
   static constexpr size_t kPinChunkBytes = (size_t)8 << 20;

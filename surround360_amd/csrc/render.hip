@@ -918,6 +918,13 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
         }
         launch_pack_bgr(st, eye, outW, eyeH, F.outBGR[ob].as<uint8_t>() + (size_t)e * outW * eyeH * 3);
       }
+      if (c->png_encode) {  // imwriteExceptionOnFail's PngEncoder (TRSP:938-961) on the device: png.hip
+        ProfScope ps(prof, "png_encode");
+        F.pngPlan[ob] = PngPlan::make(outW, outH);
+        F.pngFile[ob].ensure(F.pngPlan[ob].file_bound);
+        png_encode_enqueue(st, F.outBGR[ob].as<uint8_t>(), F.pngPlan[ob], F.sc->pngScratch, F.pngMeta[ob], F.pngFile[ob].as<uint8_t>());
+        F.pngFrame[ob] = F.frames_done;
+      }
       if (!F.outErrDev[ob].p) {
         F.outErrDev[ob].ensure(4 * sizeof(unsigned));
         S360_HIP(hipMemsetAsync(F.outErrDev[ob].p, 0, 4 * sizeof(unsigned), st));

@@ -6,6 +6,7 @@
 
 #include "core.hpp"
 #include "ctx.hpp"
+#include "png.hpp"
 #include "render_kernels.hpp"
 
 namespace s360 {
@@ -37,6 +38,7 @@ struct SlotScratch {
                                                                     // split phases two slots could interleave (frame_composite checks)
   DevBuf warpPacked, warpTiles;  // this frame's pole warp as packed coordinates + tile boxes (launch_pole_warp_packed)
   DevBuf eyeFinal[2];
+  DevBuf pngScratch;  // the device PNG encoder's per-band segments before they are gathered into a slot's file image (png.hip)
   // the sharpen passes' low-pass image and float scratch for ONE group of kSharpenGroup images: the eyes of a batch are
   // sharpened group after group on one stream (8 images = 4 slots' eyes are 2 waves per SIMD in the row passes: enough to
   // cover each other's dependent chains), so the 1.1 GB per 8K slot these were is 4.4 GB per context
@@ -79,6 +81,11 @@ struct FrameState {
   // its copy of outBGR[i] / outErrDev[i], and the finish stage that next writes buffer i waits for it (a feeder two frames ahead of
   // the fetching thread must not overwrite a frame that is still being transferred)
   hipEvent_t downRead[2] = {nullptr, nullptr};
+  // s360_set_png_encode: the frame in outBGR[i] also as a PNG file image (band chunks at their final offsets, png.hip) and its
+  // band table, written by the finish stage in front of outDone[i]; pngFrame[i] = the frame (frames_done) they belong to
+  DevBuf pngFile[2], pngMeta[2];
+  PngPlan pngPlan[2];
+  long long pngFrame[2] = {-1, -1};
   int out_cur = 0;           // buffer of the most recently ENQUEUED frame
   long long frames_done = 0;  // frames enqueued so far
   long long poleFrame[4] = {-1, -1, -1, -1};  // the frame (value of frames_done) pole unit u's warped layer was computed / received for

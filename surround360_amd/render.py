@@ -367,6 +367,31 @@ class Context:
         self._ck(lib().s360_frame_download_equirect_of(self.h, int(age), _p(out)))
         return out
 
+    # ---- the equirect as a PNG file, encoded on the device (s360.h; replaces imwriteExceptionOnFail, TRSP:938-961) ----
+    def set_png_encode(self, on=True):
+        self._ck(lib().s360_set_png_encode(self.h, int(bool(on))))
+
+    def download_png(self, age=0, out=None):
+        """The finished frame as the bytes of a complete PNG file (rendered with set_png_encode(True)). `out`: a uint8 buffer of at
+        least s360_frame_png_bound bytes (pinned_empty: one DMA transfer); returns a view of the file's bytes in it."""
+        cap = int(lib().s360_frame_png_bound(self.h))
+        if out is None:
+            out = np.empty(cap, np.uint8)
+        assert out.dtype == np.uint8 and out.ndim == 1 and out.flags["C_CONTIGUOUS"]
+        n = C.c_size_t(0)
+        self._ck(lib().s360_frame_download_png(self.h, int(age), _p(out), C.c_size_t(out.size), C.byref(n)))
+        return out[:n.value]
+
+    def encode_png(self, bgr):
+        """Operator form: an (h, w, 3) uint8 B,G,R image -> the bytes of a PNG file (8-bit RGB), encoded on the device."""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        assert bgr.shape == (h, w, 3)
+        out = np.empty(int(lib().s360_png_bound(w, h)), np.uint8)
+        n = C.c_size_t(0)
+        self._ck(lib().s360_encode_png(self.h, _p(bgr), w, h, _p(out), C.c_size_t(out.size), C.byref(n)))
+        return out[:n.value].tobytes()
+
     def uploads_complete(self):
         """Blocks until every upload enqueued so far has left its host buffer (needed for buffers from pinned_empty only)."""
         self._ck(lib().s360_frame_uploads_complete(self.h))

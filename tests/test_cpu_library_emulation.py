@@ -222,12 +222,14 @@ def test_emulated_sweep_kernels_give_the_same_flows(emu_programs):
 
 
 def test_operator_level_gpu_tests_pass_on_the_emulated_library(emu_programs):
-    """tests/test_gpu_ops.py (every operator of the C ABI against the oracle) and tests/test_gpu_isp.py, unchanged, in a
+    """tests/test_gpu_ops.py (every operator of the C ABI against the oracle), tests/test_gpu_isp.py and tests/test_gpu_png.py (the
+    device PNG encoder against libpng / zlib), unchanged, in a
     process whose Python binding points at the emulated library (tests/conftest.py: S360_TEST_EMULATED_LIB=1)."""
     import sys
     e = dict(os.environ, S360_TEST_EMULATED_LIB="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_isp.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                        os.path.join(ROOT, "tests", "test_gpu_isp.py"), os.path.join(ROOT, "tests", "test_gpu_png.py"),
+                        "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, env=e, timeout=1800, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout, r.stdout[-500:]

@@ -130,8 +130,13 @@ def check_bin_list(unpacker_exe, trsp_exe, tmp_path, bits=12, soft=False, chain=
         want = refprog.png_pixels_bgr(str(a / ("eqr_%s.png" % f)))
         assert np.array_equal(refprog.png_pixels_bgr(str(b / ("eqr_%s.png" % f))), want), ("bins", f)
         assert np.array_equal(refprog.png_pixels_bgr(str(c / ("eqr_%s.png" % f))), want), ("stream", f)
+    # --num_streams 2 --stream_gpus 1: the two frames as two streams in the frame slots of ONE context, both fed from the containers
+    # (frame 1 starts a stream of its own: no previous frame) — and, here, written as PNGs the device encoded
+    alone = run("bins1", bins, "000001", "NONE", ["--output_equirect_path", str(tmp_path / "bins1" / "eqr_000001.png")])
+    e = run("slots2", bins, "000000", "NONE", ["--num_frames", "2", "--num_streams", "2", "--stream_gpus", "1"])
+    assert np.array_equal(refprog.png_pixels_bgr(str(e / "eqr_000000.png")), refprog.png_pixels_bgr(str(a / "eqr_000000.png")))
+    assert np.array_equal(refprog.png_pixels_bgr(str(e / "eqr_000001.png")), refprog.png_pixels_bgr(str(alone / "eqr_000001.png")))
     if two_devices_env:  # --num_streams 2: frame 0 on one device, frame 1 as a stream of its own on the next (each opens the containers)
-        alone = run("bins1", bins, "000001", "NONE", ["--output_equirect_path", str(tmp_path / "bins1" / "eqr_000001.png")])
         d = run("streams2", bins, "000000", "NONE", ["--num_frames", "2", "--num_streams", "2"], env=two_devices_env)
         assert np.array_equal(refprog.png_pixels_bgr(str(d / "eqr_000000.png")), refprog.png_pixels_bgr(str(a / "eqr_000000.png")))
         assert np.array_equal(refprog.png_pixels_bgr(str(d / "eqr_000001.png")), refprog.png_pixels_bgr(str(alone / "eqr_000001.png")))
