@@ -184,11 +184,11 @@ def batched_streams_run(program, common, src_args, out, tag, first, nf, ns, devi
     wb = time.perf_counter() - t1
     if rb.returncode != 0:
         raise RuntimeError("rc %d: %s" % (rb.returncode, rb.stderr[-300:]))
-    hb = re.search(r"host thread per step:\s+decode \+ upload ([0-9.]+)\s+wait for the encoders ([0-9.]+)\s+wait for the GPU \+ fetch ([0-9.]+)", rb.stderr)
+    hb = re.search(r"host thread per step:\s+decode \+ upload ([0-9.]+)\s+wait for the encoders ([0-9.]+)\s+wait for the GPU \+ fetch ([0-9.]+)\s+enqueue ([0-9.]+)", rb.stderr)
     sm = re.search(r"steady state:\s+(\d+) frames of steps 1\.\.(\d+) in ([0-9.]+)\s+\(([0-9.]+) frames per second", rb.stderr)
     rec = {"streams": ns, "frames": nf, "process_wall_s": round(wb, 2), "frames_per_s_process": nf / wb,
            "host_thread_s_per_step": {"decode_and_upload": float(hb.group(1)), "wait_for_encoders": float(hb.group(2)),
-                                      "wait_for_gpu_and_fetch": float(hb.group(3))} if hb else None}
+                                      "wait_for_gpu_and_fetch": float(hb.group(3)), "enqueue_next_step": float(hb.group(4))} if hb else None}
     if sm:
         rec.update({"frames_per_s_steady": float(sm.group(4)), "steady_frames": int(sm.group(1)), "steady_seconds": float(sm.group(3)),
                     "steady_note": "the program's own clock: from the arrival of step 0's frames on the host to the last file written, "

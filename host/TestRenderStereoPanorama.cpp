@@ -914,6 +914,7 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
   J.bounds = {0, J.P};
   assign_pole_units(J);
   ck(s360_set_frame_slots(ctx, S), ctx);
+  ck(s360_set_output_double_buffer(ctx, 1), ctx);  // step k is fetched while step k+1 renders
   if (!F.s("bin_list").empty()) {  // every stream's frames straight from the capture's containers: no PNG is inflated
     F.v["device"] = std::to_string(device);  // (open_bins makes the ISP objects on the job's device)
     open_bins(J);
@@ -962,36 +963,41 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
   std::vector<pngio::Pixels> outBuf(S);
   for (auto& b : outBuf) b.resize(outBytes);
   std::vector<std::thread> encoder(S);
-  double tGpuWait = 0, tEncWait = 0, tDecWait = 0, tStep0 = 0;
+  double tGpuWait = 0, tEncWait = 0, tDecWait = 0, tEnqueue = 0, tStep0 = 0;
   start_decode(0);
   std::vector<FrameInputs> next(S);
   upload_step(0, cur);
   render_step(0);
   start_decode(1);
   for (int k = 0; k < steps; ++k) {
-    // step k+1's images go to the device while step k renders (the uploads wait, on their own stream, for step k's projections)
+    // Step k+1 is uploaded AND enqueued before step k is fetched: every slot has two output buffers (s360_set_output_double_buffer),
+    // so the GPU goes from step k straight into step k+1 while this thread fetches step k's frames (age 1) and hands them to the
+    // writers — enqueueing k+1 only after the fetch left the GPU idle for the length of it (measured: 8 streams from containers
+    // 14 frames per second, the device renders 41).
+    const bool more = k + 1 < steps;
     double t0 = now_sec();
-    if (k + 1 < steps) upload_step(k + 1, next);
+    if (more) upload_step(k + 1, next);  // (the uploads wait, on their own stream, for step k's projections)
     double t1 = now_sec();
     tDecWait += t1 - t0;
+    if (more) render_step(k + 1);
+    double t1b = now_sec();
+    tEnqueue += t1b - t1;
     for (auto& e : encoder)
       if (e.joinable()) e.join();  // step k-1's files are written: their buffers take step k's frames
     double t2 = now_sec();
-    tEncWait += t2 - t1;
+    tEncWait += t2 - t1b;
     for (int s = 0; s < S; ++s)
       if (k < segs[s].n) {
+        const int age = (more && k + 1 < segs[s].n) ? 1 : 0;  // the slot's latest enqueued frame is k+1 unless its stream has ended
         ck(s360_select_frame_slot(ctx, s), ctx);
         // (the first one waits for the step)
-        if (devPng) ck(s360_frame_download_png(ctx, 0, outBuf[s].data(), outBuf[s].size(), &pngBytes[s]), ctx);
-        else ck(s360_frame_download_equirect(ctx, outBuf[s].data()), ctx);
+        if (devPng) ck(s360_frame_download_png(ctx, age, outBuf[s].data(), outBuf[s].size(), &pngBytes[s]), ctx);
+        else ck(s360_frame_download_equirect_of(ctx, age, outBuf[s].data()), ctx);
         if (F.b("write_state") && k + 1 == segs[s].n) write_state(J, name[s]);
       }
     tGpuWait += now_sec() - t2;
     if (k == 0) tStep0 = now_sec();  // the first step's frames have arrived: the steady state is measured from here
-    if (k + 1 < steps) {
-      ck(s360_frame_uploads_complete(ctx), ctx);
-      render_step(k + 1);
-    }
+    if (more) ck(s360_frame_uploads_complete(ctx), ctx);
     for (int s = 0; s < S; ++s)
       if (k < segs[s].n) {
         const std::string outPath = frame_path(F.s("output_equirect_path"), name[s]);
@@ -1014,8 +1020,8 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
     std::fprintf(stderr, "--- Runtime breakdown (sec) ---\n");
     std::fprintf(stderr, "%d streams as frame slots of one context, %d steps, %d frames: %.3f  (%.3f per frame)\n", S, steps, frames,
                  endTime - startTime, (endTime - startTime) / frames);
-    std::fprintf(stderr, "host thread per step:    decode + upload %.3f  wait for the encoders %.3f  wait for the GPU + fetch %.3f\n",
-                 tDecWait / steps, tEncWait / steps, tGpuWait / steps);
+    std::fprintf(stderr, "host thread per step:    decode + upload %.3f  wait for the encoders %.3f  wait for the GPU + fetch %.3f  enqueue %.3f\n",
+                 tDecWait / steps, tEncWait / steps, tGpuWait / steps, tEnqueue / steps);
     int later = 0;  // frames of the steps behind the first one (which pays for maps, buffers and kernel loading)
     for (const Segment& sg : segs) later += std::max(0, sg.n - 1);
     if (later > 0 && endTime > tStep0)

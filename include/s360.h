@@ -221,6 +221,11 @@ int s360_frame_equirect_dev(s360_ctx* ctx, void** dev_ptr, size_t* bytes);
  * frame k+2 is enqueued; from then on the library orders things itself — the frame that reuses k's output buffer (k+2) waits on
  * the device for k's transfer, and k's sweep error words travel with its pixels. One fetching thread per context. */
 int s360_frame_download_equirect_of(s360_ctx* ctx, int age, uint8_t* out_bgr);
+/* Two output buffers per frame slot WITHOUT frame pipelining (which a batch of slots cannot use): finished frames alternate
+ * between them, so a host that renders batches — s360_frame_render_batch / _slots — can enqueue step k+1 first and then fetch
+ * step k's frames (age 1) while k+1 renders, instead of leaving the GPU idle for the length of the fetch. Costs one more
+ * output image (and PNG file image) per slot. */
+int s360_set_output_double_buffer(s360_ctx* ctx, int on);
 /* ---- the equirect as a PNG FILE, encoded on the device -------------------------------------------------
  * Replaces imwriteExceptionOnFail(FLAGS_output_equirect_path, ...) (TRSP:938-961; cv::imwrite's PngEncoder: 8-bit RGB, Sub filter,
  * zlib Z_BEST_SPEED + Z_RLE) for the output frame: with s360_set_png_encode(ctx, 1) every frame rendered from then on is also

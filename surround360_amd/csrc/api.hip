@@ -366,6 +366,15 @@ int s360_set_frame_pipelining(s360_ctx* c, int on) {
     flow_engines_follow_pipelining(c);  // (the streams are idle: the finish stage's engines change buffer sets)
   });
 }
+int s360_set_output_double_buffer(s360_ctx* c, int on) {
+  return guard(c, [&] {
+    need(c, "null ctx");
+    c->make_current();
+    S360_HIP(hipStreamSynchronize(c->st));
+    if (c->st2) S360_HIP(hipStreamSynchronize(c->st2));
+    c->two_outputs = on != 0;
+  });
+}
 int s360_set_sharpening(s360_ctx* c, double sharpening) {
   return guard(c, [&] {
     need(c && sharpening >= 0.0, "bad argument");
@@ -828,7 +837,8 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
     need(out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
     FrameState& F = frame_state(c);
     need(F.frames_done > age, "that frame has not been rendered");
-    need(age == 0 || (c->pipeline && F.outBGR[F.out_cur ^ 1].p), "age 1 needs s360_set_frame_pipelining (two output buffers)");
+    need(age == 0 || ((c->pipeline || c->two_outputs) && F.outBGR[F.out_cur ^ 1].p),
+         "age 1 needs two output buffers (s360_set_frame_pipelining or s360_set_output_double_buffer)");
     const int b = age == 0 ? F.out_cur : F.out_cur ^ 1;
     // wait for THAT frame only (its event sits behind its last kernel), then copy on a stream of its own so that the
     // transfer does not queue behind the kernels of the frame enqueued after it
@@ -944,7 +954,8 @@ int s360_frame_download_png(s360_ctx* c, int age, uint8_t* out, size_t cap, size
     need(out && n_out && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
     FrameState& F = frame_state(c);
     need(F.frames_done > age, "that frame has not been rendered");
-    need(age == 0 || (c->pipeline && F.outBGR[F.out_cur ^ 1].p), "age 1 needs s360_set_frame_pipelining (two output buffers)");
+    need(age == 0 || ((c->pipeline || c->two_outputs) && F.outBGR[F.out_cur ^ 1].p),
+         "age 1 needs two output buffers (s360_set_frame_pipelining or s360_set_output_double_buffer)");
     const int b = age == 0 ? F.out_cur : F.out_cur ^ 1;
     if (F.pngFrame[b] != F.frames_done - 1 - age || !F.pngFile[b].p)
       throw Error(S360_ERR_STATE, "that frame was rendered without s360_set_png_encode");

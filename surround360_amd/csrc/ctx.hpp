@@ -30,6 +30,7 @@ struct s360_ctx {
   // things, each guarded by an event: the strips, the pole source images, and the order side(k) -> finish(k).
   hipStream_t st2 = nullptr;
   bool pipeline = false;
+  bool two_outputs = false;  // s360_set_output_double_buffer: finished frames alternate between two output buffers without pipelining
   hipEvent_t evSideDone = nullptr, evStripsFree = nullptr, evPoleSrcFree = nullptr;
   bool haveStripsFree = false, havePoleSrcFree = false;
   // Uploads (s360_frame_upload_*) never touch the render streams: the caller's buffer is copied through a small ring

@@ -904,7 +904,7 @@ static void finish_stage(s360_ctx* c, const std::vector<int>& slotIds, int pole_
       const int outW = g.out_width, outH = g.out_height, eyeH = outH / 2;
       // frame pipelining (a streaming host fetches frame k while frame k+1 renders) alternates between two output
       // buffers; otherwise the same one is reused
-      const int ob = c->pipeline ? F.out_cur ^ 1 : F.out_cur;
+      const int ob = (c->pipeline || c->two_outputs) ? F.out_cur ^ 1 : F.out_cur;
       F.outBGR[ob].ensure((size_t)outW * outH * 3);
       if (!F.outDone[ob]) S360_HIP(hipEventCreateWithFlags(&F.outDone[ob], hipEventDisableTiming));
       if (F.downRead[ob]) S360_HIP(hipStreamWaitEvent(st, F.downRead[ob], 0));  // a fetch of the frame this buffer held may still run

@@ -368,6 +368,10 @@ class Context:
         return out
 
     # ---- the equirect as a PNG file, encoded on the device (s360.h; replaces imwriteExceptionOnFail, TRSP:938-961) ----
+    def set_output_double_buffer(self, on=True):
+        """Two output buffers per slot without frame pipelining: a batch host enqueues step k+1, then fetches step k (age 1)."""
+        self._ck(lib().s360_set_output_double_buffer(self.h, int(bool(on))))
+
     def set_png_encode(self, on=True):
         self._ck(lib().s360_set_png_encode(self.h, int(bool(on))))
 
