@@ -477,7 +477,7 @@ FLOW_STENCIL_B_PER_PXLEVEL = {"flow_gradients": 24, "flow_blur15": 16, "flow_med
                               "flow_upscale": 16}
 
 
-def streams_batched(R, rig, flags, device, frames, args, dry, g):
+def streams_batched(R, rig, flags, device, frames, args, dry, g, slots=None, timed_steps=None, check=True):
     """bench.py's `video_streams_batched` leg: 2 contexts x S frame slots, one stream per slot (stream s = the synthetic video
     entered at another frame, walked forwards and backwards over the distinct frames held), every step a render_batch(use_prev)
     per context on device-resident temporal state, the step's inputs sent in place from page-locked host memory on the upload
@@ -486,7 +486,7 @@ def streams_batched(R, rig, flags, device, frames, args, dry, g):
     import torch
     from concurrent.futures import ThreadPoolExecutor
     F = 2
-    run_in, timed = 4, max(2, args.stream_steps)
+    run_in, timed = 4, max(2, timed_steps or args.stream_steps)
     n_steps = run_in + timed
     free_b, total_b = (0, 0) if dry else torch.cuda.mem_get_info(device)
     # page-locked ring of distinct frames (read-only: any number of slots may send the same buffers)
@@ -506,7 +506,7 @@ def streams_batched(R, rig, flags, device, frames, args, dry, g):
         m = (k + (3 if n_ring > 8 else 1) * stream) % max(2 * (n_ring - 1), 1)
         return ring[m if m < n_ring else 2 * (n_ring - 1) - m]
 
-    S = args.stream_slots
+    S = slots or args.stream_slots
     if S <= 0:  # measured at 8K: 5.7 GB per slot + 0.75 GB for the second halves of the flow INPUTS' double buffers (the flows
         # themselves are updated in place) + 1.7 GB of previous-frame pyramids, 6 GB per context
         S = 2 if dry else max(1, int((0.90 * total_b / 1e9 / F - 6.5) / 7.6))
@@ -554,6 +554,12 @@ def streams_batched(R, rig, flags, device, frames, args, dry, g):
             if S <= 1 or attempt == 3:
                 raise
             S = max(1, S - 2)
+    if not check:  # a row of `slots_table`: the figure and what it costs in HBM (the full leg checks every stream of its own run)
+        for c in ctxs:
+            c.close()
+        if not dry:
+            torch.cuda.empty_cache()
+        return {"streams": F * S, "slots_per_context": S, "steps": timed, "frames_per_s": timed * F * S / dt, "hbm_used_GB": round(used, 1)}
     last = []
     for c in ctxs:
         for j in range(S):
@@ -1134,6 +1140,41 @@ def main():
         except Exception:
             pass
 
+    # ---- what actually bounds the dominant kernel: its VALU issue (profiles/valu_busy.json, the committed SQ counter passes —
+    # not measured by this run), per instantiation: <true, 3> holds the side flows of a launch (3 lanes per pixel), <true, 4> the
+    # pole flows. valu_roof_frac = executed VALU wave-instructions per frame / (SIMDs x measured FMA issue rate x the sweeps' time).
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_busy.json")) as f:
+            vbj = json.load(f)
+        fs_ = vbj["families"]["flow_sweep"]
+        ir = vbj["issue_rate"]
+        roof = ir["simds"] * ir["valu_inst_per_cycle_per_simd"][fs_.get("rate_class", "fma")] * ir["clock_ghz"] * 1e9
+        sweep_ms_frame = (batched_alone["prof"].get("flow_sweep", (0.0, 0))[0] / S) if batched_alone else tp_prof.get("flow_sweep", (0.0, 0))[0]
+        if fs_.get("valu_insts_per_frame") and sweep_ms_frame > 0:
+            roofline["valu_roof_frac"] = round(fs_["valu_insts_per_frame"] / roof / (sweep_ms_frame * 1e-3), 4)
+            roofline["valu_rate_class"] = fs_.get("rate_class", "fma")
+        roofline["valu_busy"] = fs_["valu_busy"]
+        per = {}
+        tot_ms = sum(r.get("ms", 0.0) for r in fs_.get("per_kernel", {}).values()) or 1.0
+        for name, r in fs_.get("per_kernel", {}).items():
+            key = "side_flows<true,3>" if "<true, 3>" in name else ("pole_flows<true,4>" if "<true, 4>" in name else name[:40])
+            per[key] = {"valu_busy": r.get("valu_busy"), "issuing": r.get("wave_time_issuing"), "waiting": r.get("wave_time_waiting"),
+                        "share_of_sweep_time": round(r.get("ms", 0.0) / tot_ms, 3)}
+            vi = fs_.get("valu_insts_per_launch", {}).get(name)
+            if vi and r.get("ms") and r.get("launches"):
+                per[key]["valu_roof_frac"] = round(vi / roof / (r["ms"] / r["launches"] * 1e-3), 4)
+        if per:
+            roofline["per_instantiation"] = per
+        roofline["valu_source"] = vbj["source"]
+    except Exception:  # noqa: BLE001 - an annotation only
+        pass
+    # ---- the whole path against HBM: SURVEY 8d's compulsory bytes per frame (232 B per flow pixel-level + the warp/blend rows)
+    path_bytes = 232 * (2 * P * side_px + 4 * pole_px) + sum(WARP_BLEND_MB.values()) * 1e6
+    roofline["path_algorithmic_bytes_per_frame"] = path_bytes
+    roofline["path_hbm_frac"] = path_bytes * args.steps * S / dt / 1e9 / HBM_PEAK_GBS
+    if batched_alone:
+        roofline["path_hbm_frac_batch_alone"] = path_bytes * S / (batched_alone["ms_per_batch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+
     out = {
         "metric": "stereo-equirect frames/sec at 8K, 17-cam rig",
         "value": world * args.steps * S / dt,
@@ -1270,6 +1311,19 @@ def main():
                     nbytes = 12 * (28 * side_px + 6 * pole_px) if k == "flow_gradients" else b * pxl
                     gbs = nbytes / (ms * 1e-3) / 1e9
                     fs[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            # counter bytes of the stencil families beside their algorithmic fractions (profiles/stencil_traffic.json: the
+            # committed FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied; not measured by this run)
+            try:
+                with open(os.path.join(ROOT, "profiles", "stencil_traffic.json")) as f:
+                    stj = json.load(f)
+                for k, rec in fs.items():
+                    tr = stj["families"].get(k)
+                    if tr:
+                        rec["traffic_bytes_per_frame"] = round(tr["hbm_bytes_per_frame"])
+                        rec["traffic_GBps"] = round(tr["hbm_bytes_per_frame"] / (rec["ms_per_frame"] * 1e-3) / 1e9, 1)
+                        rec["traffic_frac"] = round(rec["traffic_GBps"] / HBM_PEAK_GBS, 4)
+            except Exception:  # noqa: BLE001 - an annotation only
+                pass
             # Beside each HBM fraction the kernel family's SQ "VALU busy" figure from the committed counter pass (profiles/valu_busy.json;
             # not measured by this run): a VALU-bound kernel is then shown at its bound rather than asserted to be there.
             vb_note = None
@@ -1518,6 +1572,60 @@ def main():
             except Exception as e:  # noqa: BLE001
                 import traceback
                 out["video_streams_batched"] = {"error": repr(e), "trace": traceback.format_exc()[-500:]}
+
+            # ---- what a frame costs in a third of the memory: `value` and the chained figure hold 250-280 GB of the 288; the same
+            # two workloads with fewer frame slots, measured here in fresh contexts (short legs: the rows are throughput against HBM
+            # held, the headline's and the full chained leg's own checks cover the kernels) ----
+            try:
+                table = [{"workload": "independent frames (the headline)", "slots_per_context": S, "contexts": F,
+                          "frames_per_s": out["value"], "hbm_used_GB": hbm_used_gb}]
+
+                def independent_row(S2):
+                    cs = [R.Context(rig, R.make_params(**flags), device=local_rank) for _ in range(F)]
+                    try:
+                        for k, c in enumerate(cs):
+                            c.set_frame_slots(S2)
+                            for j in range(S2):
+                                c.select_frame_slot(j)
+                                c.upload_frame(*frames[k * S2 + j])
+                            c.set_sweep_mode("throughput")
+                        with ThreadPoolExecutor(F) as pool:
+                            def batch(n):
+                                for _ in range(n):
+                                    list(pool.map(lambda c: c.render_batch(False), cs))
+                                for c in cs:
+                                    c.synchronize()
+                            batch(2)
+                            used = 0.0 if dry else (torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9
+                            t = time.perf_counter()
+                            nb = 2 if dry else 6
+                            batch(nb)
+                            dts = time.perf_counter() - t
+                        cs[0].select_frame_slot(0)
+                        same = bool(np.array_equal(cs[0].download_equirect(), single0))
+                        return {"workload": "independent frames", "slots_per_context": S2, "contexts": F, "frames_per_s": nb * F * S2 / dts,
+                                "hbm_used_GB": round(used, 1), "frame_0_equals_single": same}
+                    finally:
+                        for c in cs:
+                            c.close()
+                        if not dry:
+                            torch.cuda.empty_cache()
+                for S2 in ([1] if dry else [8]):
+                    if S2 < S or dry:
+                        table.append(independent_row(S2))
+                vb = out.get("video_streams_batched", {})
+                if "frames_per_s" in vb:
+                    table.append({"workload": "temporally chained streams (video_streams_batched)", "slots_per_context": vb["slots_per_context"],
+                                  "contexts": 2, "frames_per_s": vb["frames_per_s"], "hbm_used_GB": vb["hbm_used_GB"]})
+                for S2 in ([1] if dry else [10, 6]):
+                    if dry or S2 < vb.get("slots_per_context", 0):
+                        r = streams_batched(R, rig, flags, local_rank, frames, args, dry, g, slots=S2, timed_steps=4, check=False)
+                        table.append({"workload": "temporally chained streams", "slots_per_context": r["slots_per_context"], "contexts": 2,
+                                      "frames_per_s": r["frames_per_s"], "hbm_used_GB": r["hbm_used_GB"]})
+                out["slots_table"] = table
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                out["slots_table"] = {"error": repr(e), "trace": traceback.format_exc()[-400:]}
 
     except Exception as e:  # noqa: BLE001 - reported in the JSON line
         import traceback

@@ -9,6 +9,7 @@
 #   3. <tag>_pmc_fetch_write.txt       FETCH_SIZE and WRITE_SIZE in separate --pmc passes of the isolated command
 #                                      (counters are never combined with other trace domains)
 #   4. profiles/sweep_traffic.json     HBM bytes per sweep launch (gfx950: FETCH_SIZE x2 on the read side)
+#   5. profiles/stencil_traffic.json   HBM bytes per frame of the flow-stencil kernel families, same passes, same correction
 set -e
 TAG=${1:?tag}
 SLOTS=${2:-22}
@@ -37,9 +38,11 @@ grep '^{"metric"' $OUT/iso.log | tail -1 > profiles/${TAG}_isolated_bench.json |
   echo
   python tools/rocpd_pmc.py $OUT/w/w_results.db WRITE_SIZE | head -24
 } > profiles/${TAG}_pmc_fetch_write.txt
-python - "$TAG" "$SLOTS" <<'PY'
+python tools/rocpd_pmc.py $OUT/f/f_results.db FETCH_SIZE > $OUT/fetch_full.txt
+python tools/rocpd_pmc.py $OUT/w/w_results.db WRITE_SIZE > $OUT/write_full.txt
+python - "$TAG" "$SLOTS" "$OUT" <<'PY'
 import json, sys
-tag, slots = sys.argv[1], int(sys.argv[2])
+tag, slots, outdir = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 txt = open("profiles/%s_pmc_fetch_write.txt" % tag).read()
 fetch, write = txt.split("\n\n", 1)
 def per_launch(block, kernel):
@@ -64,5 +67,29 @@ for key, kname in (("k_sweep_lock", "k_sweep_lock<"), ("k_sweep_quad", "k_sweep_
 if "k_sweep_quad" in d["kernels"]:
     d["hbm_bytes_per_launch"] = d["kernels"]["k_sweep_quad"]["hbm_bytes_per_launch"]
 json.dump(d, open("profiles/sweep_traffic.json", "w"), indent=1)
+# counter bytes of the flow-stencil families (bench.py puts them beside the algorithmic fractions): all launches of the profiled
+# run / the frames it rendered (one k_novel_view launch per frame)
+FAMILIES = {"flow_median": ["k_median5"], "flow_diffusion": ["k_sepblur<7, 2, 1,"], "flow_blur15": ["k_sepblur<7, 2, 2,", "k_sepblur<7, 2, 3,"],
+            "flow_upscale": ["k_resize_cubic_f32c2"], "flow_gradients": ["k_sepblur<1, 2, 0, 1", "k_sepblur<1, 2, 0, 2"],
+            "flow_pyramid": ["k_resize_linear_f32c1"], "flow_sweep": ["k_sweep_quad<"]}
+def total(block, pats):
+    n, tot = 0, 0.0
+    for line in block.splitlines():
+        if any(p in line for p in pats):
+            f = line.split()
+            n += int(f[-3])
+            tot += float(f[-2]) * int(f[-3])
+    return n, tot
+fetch_all, write_all = open(outdir + "/fetch_full.txt").read(), open(outdir + "/write_full.txt").read()  # (every kernel, not the top 24)
+frames, _ = total(fetch_all, ["k_novel_view"])
+fam = {}
+for name, pats in FAMILIES.items():
+    n, fk = total(fetch_all, pats)
+    _, wk = total(write_all, pats)
+    if n and frames:
+        fam[name] = {"launches_profiled": n, "hbm_bytes_per_frame": (2 * fk + wk) * 1024 / frames,
+                     "fetch_bytes_per_frame_corrected": 2 * fk * 1024 / frames, "write_bytes_per_frame": wk * 1024 / frames}
+json.dump({"source": d["source"], "correction": d["correction"], "frames_profiled": frames, "families": fam},
+          open("profiles/stencil_traffic.json", "w"), indent=1)
 print("profiles written for", tag)
 PY

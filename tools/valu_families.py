@@ -49,6 +49,9 @@ def main():
         ms = sum(r["ms"] for r in ks.values())
         rec = {"valu_busy": round(sum(r["valu_busy"] * r["ms"] for r in ks.values()) / ms, 3), "rate_class": RATE_CLASS.get(fam, "fma"),
                "kernels": sorted(ks)}
+        # per instantiation: what the pass measured for that kernel alone (bench.py's roofline record shows k_sweep_quad's two)
+        rec["per_kernel"] = {n: {k: r[k] for k in ("launches", "ms", "valu_busy", "lds_busy", "wave_time_waiting", "wave_time_issuing") if k in r}
+                             for n, r in ks.items()}
         vi = {n: insts[n]["valu_insts_per_launch"] for n in ks if n in insts and "valu_insts_per_launch" in insts[n]}
         if vi:
             rec["valu_insts_per_launch"] = vi
