@@ -645,6 +645,9 @@ def main():
     ap.add_argument("--streams-only", action="store_true",
                     help="only the video_streams_batched leg (slots-against-frames/s probes: --stream-slots N); prints that leg's record")
     ap.add_argument("--stream-steps", type=int, default=8, help="video_streams_batched leg: timed steps (after 4 run-in steps)")
+    ap.add_argument("--pipeline-batches", action="store_true",
+                    help="timing experiment (needs S360_EXPERIMENT_BATCH_PIPELINE=1): the timed region's batches with frame pipelining — "
+                         "batch k's pole stage on a second stream beside batch k+1's side stage inside ONE context")
     ap.add_argument("--video-frames", type=int, default=190,
                     help="frames of the configs[4] stream leg (SURVEY 8d: 190, steady state over frames 10-189)")
     args = ap.parse_args()
@@ -899,6 +902,8 @@ def main():
             c.upload_frame(*frames[k * S + j])  # inputs resident in HBM before the timed region
         if F * S > 1:
             c.set_sweep_mode("throughput")  # several frames in flight: the kernel with the fewest instructions per pixel
+        if args.pipeline_batches:
+            c.set_frame_pipelining(True)
 
     def sync(barrier=True):
         for c in ctxs:
