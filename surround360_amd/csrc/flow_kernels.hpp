@@ -46,13 +46,18 @@ void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, s
 void launch_blur_to_records(hipStream_t st, const float2* flow, void* rec, int w, int h, size_t bs, int B,
                             const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx,
                             unsigned* rowflags = nullptr);
+// ... with the upscale of the coarser level (launch_resize_cubic_f32c2's arithmetic, into `cur`) in front of it in ONE kernel; false
+// when the shapes do not fit its tiles: the caller runs the two launches instead (same bits)
+bool launch_upscale_blur_to_records(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* cur, void* rec, int w,
+                                    int h, size_t bs, int B, float post_scale, const BlurTaps& t, const float2* G, const float* A,
+                                    const FlowIdx& idx, unsigned* rowflags = nullptr);
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale);
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
                                int dh, size_t dbs, int B, float post_scale, const float2* const* src_tab = nullptr);
 void launch_median5_c2(hipStream_t st, const float2* src, float2* dst, int w, int h, size_t bs, int B);
 // lockstep banded sweep (sweep_lock.hip): nw compute waves (4 rows each) + 2 service waves per workgroup
-int sweep_lock_waves();  // compute waves per workgroup of this process (4 unless S360_LOCK_NW says 2 or 8)
+int sweep_lock_waves();  // compute waves per workgroup: 2 (tools/sweep_microbench builds: S360_LOCK_NW = 1 / 2 / 4)
 int sweep_lock_num_wgs(int h, int nw);
 size_t sweep_lock_handoff_bytes(int w, int h, int B, int nw);
 // rec: per flow and pixel {I0x | NaN = not updated, I0y, blurredFlow} (launch_blur_to_records with G); G: the gradient planes

@@ -619,12 +619,20 @@ static void launch_lock_t(hipStream_t st, const float4* rec, const float2* G, fl
 // Compute waves per workgroup (4 rows each): 2 — one compute wave per SIMD next to the two service waves, bands of 8
 // rows. (Measured on an 8K frame, round 2's bench record: 4 waves 119.2 ms of sweeps per frame, 2 waves with the
 // specialised steady-state steps 117.0 ms, 8 waves 186 ms; the other builds are gone.)
+#ifdef S360_TIMING_EXPERIMENTS  // tools/sweep_microbench only: S360_LOCK_NW = 1 / 2 / 4 compute waves per workgroup (bands of 4 / 8 / 16 rows)
+static int lock_waves_experiment() {
+  static const int v = [] { const char* e = std::getenv("S360_LOCK_NW"); const int n = e ? std::atoi(e) : 2; return (n == 1 || n == 4) ? n : 2; }();
+  return v;
+}
+int sweep_lock_waves() { return lock_waves_experiment(); }
+#else
 int sweep_lock_waves() { return 2; }
+#endif
 
 void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float2* flow, void* handoff,
                        unsigned* errflag, int w, int h, size_t bs, int B, const FlowIdx& idx, int dir,
                        const PixFlowConsts& pc, bool fast) {
-  constexpr int nw = 2;
+  const int nw = sweep_lock_waves();
   const SweepConst c = make_sweep_const(pc, w, h);
   SweepFast fc;
   fc.rcCols = 1.0f / c.fcols;
@@ -636,6 +644,10 @@ void launch_sweep_lock(hipStream_t st, const float4* rec, const float2* G, float
   // (FlowEngine resets the hand-off arena of all its sweep launches with one memset)
   unsigned* hdr = reinterpret_cast<unsigned*>(handoff);
   unsigned long long* H = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(handoff) + 256);
+#ifdef S360_TIMING_EXPERIMENTS
+  if (nw == 1) { launch_lock_t<1, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg); return; }
+  if (nw == 4) { launch_lock_t<4, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg); return; }
+#endif
   if (fast) launch_lock_t<2, true>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
   else launch_lock_t<2, false>(st, rec, G, flow, H, hdr, errflag, w, h, bs, B, idx, dir, c, fc, nwg);
 }
