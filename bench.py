@@ -475,10 +475,6 @@ WARP_BLEND_MB = {"project_side": 176 + 180, "project_pole": 2 * 12.6 + 141, "nov
 # compulsory bytes per pixel-level of the flow stencil families (SURVEY.md §8d pass list, reference dtypes)
 FLOW_STENCIL_B_PER_PXLEVEL = {"flow_gradients": 24, "flow_blur15": 16, "flow_median": 32, "flow_diffusion": 48,
                               "flow_upscale": 16}
-# round 6: the inter-level upscale runs inside the blur kernel (k_upblur_rec) — the `flow_upscale` family is gone and `flow_blur15`
-# carries both of SURVEY 8d's rows (flow blur 8 r / 8 w + upsample 8 r / 8 w = 32 B per pixel-level; the fused kernel's own
-# compulsory traffic is less: the upscaled level is written once and not read back)
-FLOW_BLUR15_FUSED_B = 32
 
 
 def streams_batched(R, rig, flags, device, frames, args, dry, g, slots=None, timed_steps=None, check=True):
@@ -1318,8 +1314,6 @@ def main():
                 if ms > 0:
                     # gradients are per image (28 side images, 6 pole images: 4 B read + 8 B written each)
                     nbytes = 12 * (28 * side_px + 6 * pole_px) if k == "flow_gradients" else b * pxl
-                    if k == "flow_blur15" and lat_prof.get("flow_upscale", (0.0, 0))[0] <= 0:
-                        nbytes = FLOW_BLUR15_FUSED_B * pxl  # (upscale + blur in one kernel)
                     gbs = nbytes / (ms * 1e-3) / 1e9
                     fs[k] = {"ms_per_frame": round(ms, 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
             # counter bytes of the stencil families beside their algorithmic fractions (profiles/stencil_traffic.json: the

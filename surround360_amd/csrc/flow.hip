@@ -206,7 +206,6 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
   float2* oth = M.flowB.as<float2>();
   const float invPyr = 1.0f / pc.pyrScaleFactor;
   if (capture_levels) capture_levels->clear();
-  bool pendingUp = false;  // the previous (coarser) level's result is in `oth` and has not been upscaled into `cur` yet
   for (int l = L - 1; l >= 0; --l) {
     const int wl = lv_.w[l], hl = lv_.h[l];
     const size_t nl = (size_t)wl * hl;
@@ -225,17 +224,8 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
     }
     {
       ProfScope ps(P, "flow_blur15");  // the blurred flow goes straight into the sweeps' half-records
-      unsigned* rowflags = reinterpret_cast<unsigned*>((char*)M.handoff.p + hoff[l] + 2 * handoff_bytes(l));
-      const float2* Gr = sweep_mode_ == 3 ? nullptr : M.G.as<float2>();
-      // below the coarsest level the flow arrives from level l + 1: its upscale (PixFlow.h:170-171) runs inside the blur kernel,
-      // which writes `cur` on the way; where the shapes do not fit that kernel's tiles, as two launches
-      if (pendingUp && !launch_upscale_blur_to_records(st, oth, lv_.w[l + 1], lv_.h[l + 1], (size_t)lv_.w[l + 1] * lv_.h[l + 1], cur,
-                                                       M.rec.p, wl, hl, nl, B, invPyr, tFlow, Gr, LA(l), idx, rowflags)) {
-        launch_resize_cubic_f32c2(st, oth, lv_.w[l + 1], lv_.h[l + 1], (size_t)lv_.w[l + 1] * lv_.h[l + 1], cur, wl, hl, nl, B, invPyr);
-        pendingUp = false;
-      }
-      if (!pendingUp) launch_blur_to_records(st, cur, M.rec.p, wl, hl, nl, B, tFlow, Gr, LA(l), idx, rowflags);
-      pendingUp = false;
+      launch_blur_to_records(st, cur, M.rec.p, wl, hl, nl, B, tFlow, sweep_mode_ == 3 ? nullptr : M.G.as<float2>(), LA(l), idx,
+                             reinterpret_cast<unsigned*>((char*)M.handoff.p + hoff[l] + 2 * handoff_bytes(l)));
     }
     auto sweep = [&](float2* fl, int dir) {
       ProfScope ps(P, "flow_sweep");
@@ -272,7 +262,9 @@ void FlowEngine::compute(hipStream_t st, const PixFlowConsts& pc, const FlowBatc
       capture_levels->push_back(std::move(hbuf));
     }
     if (l > 0) {
-      pendingUp = true;  // level l - 1 takes `oth` through the fused upscale + blur (above): `oth` stays untouched until then
+      ProfScope ps(P, "flow_upscale");
+      launch_resize_cubic_f32c2(st, oth, wl, hl, nl, cur, lv_.w[l - 1], lv_.h[l - 1],
+                                (size_t)lv_.w[l - 1] * lv_.h[l - 1], B, invPyr);
     } else {
       ProfScope ps(P, "flow_final");
       // final upscale + scalar + 3x3 blur fused: the upscaled flow is evaluated while the blur's tile is loaded

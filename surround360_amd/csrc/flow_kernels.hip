@@ -643,180 +643,6 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32c2_tiled(const float2* 
 
 
 
-// ------------------------------------------------------------------------------------------
-// The inter-level upscale (resize INTER_CUBIC to the next level's exact size, then the scalar: PixFlow.h:170-171) fused into the
-// 15x15 blur that feeds the sweeps (PixFlow.h:379-383 -> the sweeps' records): one kernel reads the COARSER level, writes the
-// upscaled flow's tile (the sweeps' input `cur`) and the blurred half- / full records — as two kernels the finer level was written
-// by the resize and read back by the blur (8 B per pixel-level and one launch per level less; the final level already worked
-// this way, launch_upscale_blur). Arithmetic: k_resize_cubic_f32c2_tiled's (coordinates and weights per column / row, horizontal
-// pass over the source window, vertical pass, the scalar), then k_sepblur<7, 2, EPI 2|3>'s passes — same float operations in the
-// same order, so the records and the upscaled flow are bit for bit what the two kernels wrote.
-// A 32x32 tile needs the upscaled flow on 46x46 positions (halo 7, BORDER_REFLECT_101: positions outside the image are copies of
-// positions inside the same tile's range); their source window is at most 48x48 coarse texels for ratios <= 1 (the launcher
-// checks). LDS: {source window, later the blur's input tile} and {horizontal-pass rows, later the blur's row-pass result} share
-// their space: 36 KB.
-constexpr int UB_T = 32, UB_R = 7, UB_I = UB_T + 2 * UB_R, UB_IP = UB_I | 1, UB_S = 48, UB_NT = 384;
-template <int EPI>
-__global__ __launch_bounds__(UB_NT) void k_upblur_rec(const float2* __restrict__ src, int sw, int sh, size_t sbs,
-                                                      float2* __restrict__ cur, int w, int h, size_t bs, double scx, double scy,
-                                                      float post_scale, BlurTaps taps, const float* __restrict__ A, FlowIdx idx,
-                                                      const float2* __restrict__ Gp, void* __restrict__ recv,
-                                                      unsigned* __restrict__ rowflags) {
-  static_assert(EPI == 2 || EPI == 3, "records only");
-  constexpr int R = UB_R;
-  __shared__ float2 s_a[UB_S * UB_S];  // s_src[UB_S][UB_S], then s_in[UB_I][UB_IP]
-  __shared__ float2 s_b[UB_S * UB_I];  // s_h[UB_S][UB_I], then s_mid[UB_I][UB_T + 1]
-  __shared__ float s_ax[UB_I][4], s_ay[UB_I][4];
-  __shared__ int s_sx[UB_I], s_sy[UB_I];
-  static_assert(UB_I * UB_IP <= UB_S * UB_S && UB_I * (UB_T + 1) <= UB_S * UB_I, "aliased LDS regions");
-  float2 (*s_src)[UB_S] = reinterpret_cast<float2 (*)[UB_S]>(s_a);
-  float2 (*s_in)[UB_IP] = reinterpret_cast<float2 (*)[UB_IP]>(s_a);
-  float2 (*s_h)[UB_I] = reinterpret_cast<float2 (*)[UB_I]>(s_b);
-  float2 (*s_mid)[UB_T + 1] = reinterpret_cast<float2 (*)[UB_T + 1]>(s_b);
-  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-  const TileId tile = xcd_tile();
-  const int tx0 = tile.x * UB_T, ty0 = tile.y * UB_T;
-  const int vecEnd = ((w * 2) / 8) * 8;
-  // the epilogue's operands of this thread's column task, requested in front of everything else (see k_sepblur)
-  constexpr int kColTasks = UB_T * (UB_T / 4);
-  static_assert(kColTasks <= UB_NT, "one column task per thread");
-  float pa0[4] = {0.f, 0.f, 0.f, 0.f}, pa1[4] = {0.f, 0.f, 0.f, 0.f};
-  float2 pg[4];
-  if (tid < kColTasks) {
-    const int lx = tid % UB_T, ly0 = (tid / UB_T) * 4, gx = tx0 + lx;
-    const size_t b0 = bs * idx.i0[tile.z], b1 = bs * idx.i1[tile.z];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int gy = ty0 + ly0 + o;
-      pg[o] = make_float2(0.f, 0.f);
-      if (gx < w && gy < h) {
-        const size_t off = (size_t)gy * w + gx;
-        pa0[o] = A[b0 + off];
-        pa1[o] = A[b1 + off];
-        if (EPI == 3) pg[o] = Gp[b0 + off];
-      }
-    }
-  }
-  src += sbs * tile.z;
-  cur += bs * tile.z;
-  // the positions of the finer level this tile needs: [gx0, gx1] x [gy0, gy1], inside the image
-  const int gx0 = max(tx0 - R, 0), gx1 = min(tx0 + UB_T + R - 1, w - 1), nfx = gx1 - gx0 + 1;
-  const int gy0 = max(ty0 - R, 0), gy1 = min(ty0 + UB_T + R - 1, h - 1), nfy = gy1 - gy0 + 1;
-  if (tid < UB_I) {
-    float f;
-    resize_coord(min(gx0 + tid, gx1), scx, &s_sx[tid], &f);
-    cubic_coeffs(f, s_ax[tid]);
-  } else if (tid >= 64 && tid < 64 + UB_I) {
-    float f;
-    resize_coord(min(gy0 + tid - 64, gy1), scy, &s_sy[tid - 64], &f);
-    cubic_coeffs(f, s_ay[tid - 64]);
-  }
-  __syncthreads();
-  const int X0 = clip_idx(s_sx[0] - 1, sw), X1 = clip_idx(s_sx[nfx - 1] + 2, sw);
-  const int Y0 = clip_idx(s_sy[0] - 1, sh), Y1 = clip_idx(s_sy[nfy - 1] + 2, sh);
-  const int W = X1 - X0 + 1, H = Y1 - Y0 + 1;  // <= UB_S x UB_S (the launcher checks)
-  {  // the source window: every element requested before the first is stored
-    constexpr int kIt = (UB_S * UB_S + UB_NT - 1) / UB_NT;
-    float2 v[kIt];
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int i = tid + it * UB_NT, ly = i / UB_S, lx = i - ly * UB_S;
-      v[it] = src[(size_t)(Y0 + min(ly, H - 1)) * sw + X0 + min(lx, W - 1)];
-    }
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int i = tid + it * UB_NT, ly = i / UB_S, lx = i - ly * UB_S;
-      if (ly < H && lx < W) s_src[ly][lx] = v[it];
-    }
-  }
-  __syncthreads();
-  for (int t = tid; t < H * UB_I; t += UB_NT) {  // horizontal pass of every source row of the window
-    const int ly = t / UB_I, k = t - ly * UB_I;
-    if (k >= nfx) continue;
-    const int sx = s_sx[k];
-    const float2 p0 = s_src[ly][clip_idx(sx - 1, sw) - X0], p1 = s_src[ly][clip_idx(sx, sw) - X0],
-                 p2 = s_src[ly][clip_idx(sx + 1, sw) - X0], p3 = s_src[ly][clip_idx(sx + 2, sw) - X0];
-    const float a0 = s_ax[k][0], a1 = s_ax[k][1], a2 = s_ax[k][2], a3 = s_ax[k][3];
-    float2 hv;
-    hv.x = p0.x * a0 + p1.x * a1 + p2.x * a2 + p3.x * a3;
-    hv.y = p0.y * a0 + p1.y * a1 + p2.y * a2 + p3.y * a3;
-    s_h[ly][k] = hv;
-  }
-  __syncthreads();
-  const int ox = gx0 - (tx0 - R), oy = gy0 - (ty0 - R);  // where position (gx0, gy0) sits in the blur's input tile
-  for (int t = tid; t < nfy * UB_I; t += UB_NT) {  // vertical pass + the scalar: the upscaled flow
-    const int r = t / UB_I, k = t - r * UB_I;
-    if (k >= nfx) continue;
-    const int sy = s_sy[r];
-    const float2 h0 = s_h[clip_idx(sy - 1, sh) - Y0][k], h1 = s_h[clip_idx(sy, sh) - Y0][k], h2 = s_h[clip_idx(sy + 1, sh) - Y0][k],
-                 h3 = s_h[clip_idx(sy + 2, sh) - Y0][k];
-    const float b0 = s_ay[r][0], b1 = s_ay[r][1], b2 = s_ay[r][2], b3 = s_ay[r][3];
-    float2 o;
-    o.x = h0.x * b0 + h1.x * b1 + h2.x * b2 + h3.x * b3;
-    o.y = h0.y * b0 + h1.y * b1 + h2.y * b2 + h3.y * b3;
-    o.x *= post_scale;
-    o.y *= post_scale;
-    s_in[oy + r][ox + k] = o;
-    const int gx = gx0 + k, gy = gy0 + r;
-    if (gx >= tx0 && gx < tx0 + UB_T && gy >= ty0 && gy < ty0 + UB_T) cur[(size_t)gy * w + gx] = o;  // the tile's own pixels
-  }
-  __syncthreads();
-  if (tx0 - R < 0 || ty0 - R < 0 || tx0 + UB_T + R > w || ty0 + UB_T + R > h) {  // BORDER_REFLECT_101: a border tile's outside positions
-    for (int t = tid; t < UB_I * UB_I; t += UB_NT) {
-      const int ly = t / UB_I, lx = t - ly * UB_I;
-      const int gx = tx0 - R + lx, gy = ty0 - R + ly;
-      if (gx >= 0 && gx < w && gy >= 0 && gy < h) continue;
-      s_in[ly][lx] = s_in[reflect101(gy, h) - (ty0 - R)][reflect101(gx, w) - (tx0 - R)];
-    }
-    __syncthreads();
-  }
-  // ---- k_sepblur<7, 2, EPI, 0, 32, 32, 384>'s passes ----
-  for (int t = tid; t < UB_I * (UB_T / 4); t += UB_NT) {  // row pass: generic RowFilter, left to right
-    const int ly = t % UB_I, lx0 = (t / UB_I) * 4;
-    float2 v[4 + 2 * R];
-#pragma unroll
-    for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_in[ly][lx0 + j];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      float accx = ((tx0 + lx0 + o) * 2 + 0 < vecEnd) ? 0.0f : -0.0f;
-      float accy = ((tx0 + lx0 + o) * 2 + 1 < vecEnd) ? 0.0f : -0.0f;
-#pragma unroll
-      for (int j = 0; j <= 2 * R; ++j) {
-        const float kk = taps.k[j < R ? R - j : j - R];
-        accx += kk * v[o + j].x;
-        accy += kk * v[o + j].y;
-      }
-      s_mid[ly][lx0 + o] = make_float2(accx, accy);
-    }
-  }
-  __syncthreads();
-  if (tid >= kColTasks) return;
-  {  // column pass: SymmColumnFilter — centre + delta (= +0), then the symmetric pairs; then the record
-    const int lx = tid % UB_T, ly0 = (tid / UB_T) * 4;
-    const int gx = tx0 + lx;
-    float2 v[4 + 2 * R];
-#pragma unroll
-    for (int j = 0; j < 4 + 2 * R; ++j) v[j] = s_mid[ly0 + j][lx];
-    if (gx >= w) return;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      float ax = taps.k[0] * v[o + R].x + 0.0f, ay = taps.k[0] * v[o + R].y + 0.0f;
-#pragma unroll
-      for (int j = 1; j <= R; ++j) {
-        ax += taps.k[j] * (v[o + R + j].x + v[o + R - j].x);
-        ay += taps.k[j] * (v[o + R + j].y + v[o + R - j].y);
-      }
-      const int gy = ty0 + ly0 + o;
-      if (gy >= h) continue;
-      const size_t off = (size_t)gy * w + gx;
-      const bool upd = pa0[o] > 0.9f && pa1[o] > 0.9f;
-      if (EPI == 2) static_cast<float2*>(recv)[bs * tile.z + off] = make_float2(upd ? ax : __int_as_float(0x7fc00000), ay);
-      else static_cast<float4*>(recv)[bs * tile.z + off] = make_float4(upd ? pg[o].x : __int_as_float(0x7fc00000), pg[o].y, ax, ay);
-      if (rowflags && upd) rowflags[(size_t)tile.z * h + gy] = 0u;
-    }
-  }
-}
-
 // ==========================================================================================
 // launchers
 // ---- pixflow_search_20 only: adjustInitialFlow at the coarsest level (PixFlow.h:219-342) ----
@@ -964,6 +790,14 @@ void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, s
   if (t.r != 1) throw std::runtime_error("launch_gradients: 3x3 kernel expected");
   launch_sepblur_t<1, 2, 0, 1>(st, I, (float*)G, w, h, bs, B, t, nullptr, none, nullptr, nullptr);
 }
+// Measured and NOT adopted (round 6, commit ecbd4d5's k_upblur_rec; profiles/r06_v3_upblur_fusion_ab.txt): the inter-level upscale
+// (launch_resize_cubic_f32c2) fused into this blur — one kernel reading the coarser level, writing the upscaled flow's 32x32 tile and
+// the records, the resize's source window and horizontal pass staged in LDS that the blur's tile then reuses (36 KB). Bit-exact (the
+// emulated flow tests and the GPU flow / frame / operator tests passed with it), 8 bytes per pixel-level and one launch per level
+// less — and slower: upscale + blur 3.07 ms per frame against 1.90 as two kernels (22-slot batch alone), 46.8 against 49.0 frames/s
+// in the headline. The blur needs the upscaled flow on 46x46 positions per 32x32 outputs, so the fused kernel evaluates the bicubic
+// resize 2.07 times per pixel where the resize kernel's 64x16 tiles do it once, with two more LDS passes and four more barriers per
+// tile; neither kernel is near the HBM roof (0.2 / 0.36 of it), so the bytes saved buy nothing.
 // 15x15 Gaussian of the flow written straight into what the sweeps read (blurredFlow is only read by them): half-records
 // {blurred.x | NaN = not updated, blurred.y} for the throughput kernel — the other half of a pixel's record is I0's gradient in
 // the gradient planes — or, with G given, full records {I0x | NaN, I0y, blurred.x, blurred.y} for the latency kernel
@@ -972,22 +806,6 @@ void launch_blur_to_records(hipStream_t st, const float2* flow, void* rec, int w
   if (t.r != 7) throw std::runtime_error("launch_blur_to_records: 15x15 kernel expected");
   if (G) launch_sepblur_t<7, 2, 3, 0>(st, (const float*)flow, nullptr, w, h, bs, B, t, A, idx, G, rec, nullptr, UpSrc{}, rowflags);
   else launch_sepblur_t<7, 2, 2, 0>(st, (const float*)flow, nullptr, w, h, bs, B, t, A, idx, nullptr, rec, nullptr, UpSrc{}, rowflags);
-}
-// The inter-level upscale + blur_to_records as one kernel (k_upblur_rec); false = the shapes do not fit its tiles (the caller then
-// runs launch_resize_cubic_f32c2 + launch_blur_to_records, which write the same bits).
-bool launch_upscale_blur_to_records(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* cur, void* rec, int w,
-                                    int h, size_t bs, int B, float post_scale, const BlurTaps& t, const float2* G, const float* A,
-                                    const FlowIdx& idx, unsigned* rowflags) {
-  if (t.r != 7) throw std::runtime_error("launch_upscale_blur_to_records: 15x15 kernel expected");
-  const double scx = 1.0 / ((double)w / (double)sw), scy = 1.0 / ((double)h / (double)sh);
-  // a tile's 46 positions per axis span at most floor(45 * sc) + 1 source columns, + 3 for the cubic taps
-  auto span = [](double sc, int n) { return std::min(n, (int)std::floor((UB_I - 1) * sc) + 2 + 3); };
-  static const bool off = [] { const char* e = std::getenv("S360_NO_UPBLUR_FUSION"); return e && e[0] == '1'; }();  // (A/B timing switch)
-  if (off || !(scx <= 1.0 && scy <= 1.0) || span(scx, sw) > UB_S || span(scy, sh) > UB_S) return false;
-  const dim3 grd((w + UB_T - 1) / UB_T, (h + UB_T - 1) / UB_T, B), blk(64, 6);
-  if (G) hipLaunchKernelGGL(k_upblur_rec<3>, grd, blk, 0, st, src, sw, sh, sbs, cur, w, h, bs, scx, scy, post_scale, t, A, idx, G, rec, rowflags);
-  else hipLaunchKernelGGL(k_upblur_rec<2>, grd, blk, 0, st, src, sw, sh, sbs, cur, w, h, bs, scx, scy, post_scale, t, A, idx, nullptr, rec, rowflags);
-  return true;
 }
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale) {

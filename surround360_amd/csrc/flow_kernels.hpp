@@ -46,11 +46,6 @@ void launch_gradients(hipStream_t st, const float* I, float2* G, int w, int h, s
 void launch_blur_to_records(hipStream_t st, const float2* flow, void* rec, int w, int h, size_t bs, int B,
                             const BlurTaps& t, const float2* G, const float* A, const FlowIdx& idx,
                             unsigned* rowflags = nullptr);
-// ... with the upscale of the coarser level (launch_resize_cubic_f32c2's arithmetic, into `cur`) in front of it in ONE kernel; false
-// when the shapes do not fit its tiles: the caller runs the two launches instead (same bits)
-bool launch_upscale_blur_to_records(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* cur, void* rec, int w,
-                                    int h, size_t bs, int B, float post_scale, const BlurTaps& t, const float2* G, const float* A,
-                                    const FlowIdx& idx, unsigned* rowflags = nullptr);
 void launch_resize_linear_f32(hipStream_t st, const float* src, int sw, int sh, size_t sbs, float* dst, int dw, int dh,
                               size_t dbs, int cn, int B, float post_scale, int do_scale);
 void launch_resize_cubic_f32c2(hipStream_t st, const float2* src, int sw, int sh, size_t sbs, float2* dst, int dw,
