@@ -941,10 +941,12 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
         decoding[s] = std::async(std::launch::async, [&J, nm, recycled] { return load_frame(J, nm, std::move(*recycled)); });
       }
   };
+  std::mutex selMu;
   auto upload_step = [&](int k, std::vector<FrameInputs>& into) {
     for (int s = 0; s < S; ++s)
       if (k < segs[s].n) {
         into[s] = decoding[s].get();
+        std::lock_guard<std::mutex> sel(selMu);  // (slot selection is context state: the fetching thread selects too, for the state files)
         ck(s360_select_frame_slot(ctx, s), ctx);
         upload_frame(J, into[s]);
       }
@@ -963,54 +965,91 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
   std::vector<pngio::Pixels> outBuf(S);
   for (auto& b : outBuf) b.resize(outBytes);
   std::vector<std::thread> encoder(S);
-  double tGpuWait = 0, tEncWait = 0, tDecWait = 0, tEnqueue = 0, tStep0 = 0;
+  double tGpuWait = 0, tEncWait = 0, tDecWait = 0, tEnqueue = 0, tDrainWait = 0, tStep0 = 0;
   start_decode(0);
   std::vector<FrameInputs> next(S);
   upload_step(0, cur);
   render_step(0);
   start_decode(1);
+  // Two host threads. THIS one feeds: step k+1 is uploaded and enqueued while step k renders — every slot has two output buffers
+  // (s360_set_output_double_buffer), so the GPU goes from step k straight into step k+1. The OTHER one drains: it fetches step k's
+  // frames (age 1: the slot's latest enqueued frame is k+1 by then) with the slot named, not selected, and hands them to the file
+  // writers. (Measured on 8 streams from containers: fetch then enqueue on one thread 14 frames per second — the GPU idle for the
+  // length of the fetch —, enqueue then fetch on one thread 31, the device renders 41.) Step k+1 is enqueued only when step k-1 has
+  // been fetched: it composites into the buffers step k-1 left.
+  std::mutex mu;
+  std::condition_variable cv;
+  int enqueued = 0, drained = -1;  // highest step enqueued / fetched
+  std::thread drain([&] {
+    for (int k = 0; k < steps; ++k) {
+      const bool more = k + 1 < steps;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return enqueued >= std::min(k + 1, steps - 1); });
+      }
+      const double t1 = now_sec();
+      for (auto& e : encoder)
+        if (e.joinable()) e.join();  // step k-1's files are written: their buffers take step k's frames
+      const double t2 = now_sec();
+      tEncWait += t2 - t1;
+      for (int s = 0; s < S; ++s)
+        if (k < segs[s].n) {
+          const int age = (more && k + 1 < segs[s].n) ? 1 : 0;  // the slot's latest enqueued frame is k+1 unless its stream has ended
+          // (the first fetch of a step waits for the step)
+          if (devPng) ck(s360_frame_download_png_slot(ctx, s, age, outBuf[s].data(), outBuf[s].size(), &pngBytes[s]), ctx);
+          else ck(s360_frame_download_equirect_slot(ctx, s, age, outBuf[s].data()), ctx);
+          if (F.b("write_state") && k + 1 == segs[s].n) {
+            std::lock_guard<std::mutex> sel(selMu);
+            ck(s360_select_frame_slot(ctx, s), ctx);
+            write_state(J, name[s]);
+          }
+        }
+      tGpuWait += now_sec() - t2;
+      if (k == 0) tStep0 = now_sec();  // the first step's frames have arrived: the steady state is measured from here
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        drained = k;
+      }
+      cv.notify_all();
+      for (int s = 0; s < S; ++s)
+        if (k < segs[s].n) {
+          const std::string outPath = frame_path(F.s("output_equirect_path"), name[s]);
+          const uint8_t* px = outBuf[s].data();
+          const size_t nb = pngBytes[s];
+          if (devPng) encoder[s] = std::thread([px, outPath, nb] { save_bytes(outPath, px, nb); });
+          else encoder[s] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });
+          name[s] = next_frame_name(name[s]);
+        }
+    }
+  });
   for (int k = 0; k < steps; ++k) {
-    // Step k+1 is uploaded AND enqueued before step k is fetched: every slot has two output buffers (s360_set_output_double_buffer),
-    // so the GPU goes from step k straight into step k+1 while this thread fetches step k's frames (age 1) and hands them to the
-    // writers — enqueueing k+1 only after the fetch left the GPU idle for the length of it (measured: 8 streams from containers
-    // 14 frames per second, the device renders 41).
     const bool more = k + 1 < steps;
-    double t0 = now_sec();
+    const double t0 = now_sec();
     if (more) upload_step(k + 1, next);  // (the uploads wait, on their own stream, for step k's projections)
-    double t1 = now_sec();
+    const double t1 = now_sec();
     tDecWait += t1 - t0;
-    if (more) render_step(k + 1);
-    double t1b = now_sec();
-    tEnqueue += t1b - t1;
-    for (auto& e : encoder)
-      if (e.joinable()) e.join();  // step k-1's files are written: their buffers take step k's frames
-    double t2 = now_sec();
-    tEncWait += t2 - t1b;
-    for (int s = 0; s < S; ++s)
-      if (k < segs[s].n) {
-        const int age = (more && k + 1 < segs[s].n) ? 1 : 0;  // the slot's latest enqueued frame is k+1 unless its stream has ended
-        ck(s360_select_frame_slot(ctx, s), ctx);
-        // (the first one waits for the step)
-        if (devPng) ck(s360_frame_download_png(ctx, age, outBuf[s].data(), outBuf[s].size(), &pngBytes[s]), ctx);
-        else ck(s360_frame_download_equirect_of(ctx, age, outBuf[s].data()), ctx);
-        if (F.b("write_state") && k + 1 == segs[s].n) write_state(J, name[s]);
+    if (more) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return drained >= k - 1; });
       }
-    tGpuWait += now_sec() - t2;
-    if (k == 0) tStep0 = now_sec();  // the first step's frames have arrived: the steady state is measured from here
-    if (more) ck(s360_frame_uploads_complete(ctx), ctx);
-    for (int s = 0; s < S; ++s)
-      if (k < segs[s].n) {
-        const std::string outPath = frame_path(F.s("output_equirect_path"), name[s]);
-        const uint8_t* px = outBuf[s].data();
-        const size_t nb = pngBytes[s];
-        if (devPng) encoder[s] = std::thread([px, outPath, nb] { save_bytes(outPath, px, nb); });
-        else encoder[s] = std::thread([px, outPath, &g] { save_png(outPath, px, g.out_width, g.out_height, 3); });
-        name[s] = next_frame_name(name[s]);
-        spare[s] = std::move(cur[s]);  // its uploads have run (s360_frame_uploads_complete above, or the step is over)
+      const double t1a = now_sec();
+      tDrainWait += t1a - t1;
+      render_step(k + 1);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        enqueued = k + 1;
       }
+      cv.notify_all();
+      tEnqueue += now_sec() - t1a;
+      ck(s360_frame_uploads_complete(ctx), ctx);
+    }
+    for (int s = 0; s < S; ++s)
+      if (k < segs[s].n) spare[s] = std::move(cur[s]);  // its uploads have run (s360_frame_uploads_complete of the previous round)
     std::swap(cur, next);
     if (k + 2 < steps) start_decode(k + 2);
   }
+  drain.join();
   for (auto& e : encoder)
     if (e.joinable()) e.join();
   const double endTime = now_sec();
@@ -1020,8 +1059,8 @@ static int run_stream_batch(const Flags& flags, const std::vector<Segment>& segs
     std::fprintf(stderr, "--- Runtime breakdown (sec) ---\n");
     std::fprintf(stderr, "%d streams as frame slots of one context, %d steps, %d frames: %.3f  (%.3f per frame)\n", S, steps, frames,
                  endTime - startTime, (endTime - startTime) / frames);
-    std::fprintf(stderr, "host thread per step:    decode + upload %.3f  wait for the encoders %.3f  wait for the GPU + fetch %.3f  enqueue %.3f\n",
-                 tDecWait / steps, tEncWait / steps, tGpuWait / steps, tEnqueue / steps);
+    std::fprintf(stderr, "host thread per step:    decode + upload %.3f  wait for the encoders %.3f  wait for the GPU + fetch %.3f  enqueue %.3f  wait for the fetching thread %.3f  (feeding thread: decode + upload, enqueue, wait for the fetching thread; fetching thread: the rest)\n",
+                 tDecWait / steps, tEncWait / steps, tGpuWait / steps, tEnqueue / steps, tDrainWait / steps);
     int later = 0;  // frames of the steps behind the first one (which pays for maps, buffers and kernel loading)
     for (const Segment& sg : segs) later += std::max(0, sg.n - 1);
     if (later > 0 && endTime > tStep0)

@@ -226,6 +226,9 @@ int s360_frame_download_equirect_of(s360_ctx* ctx, int age, uint8_t* out_bgr);
  * step k's frames (age 1) while k+1 renders, instead of leaving the GPU idle for the length of the fetch. Costs one more
  * output image (and PNG file image) per slot. */
 int s360_set_output_double_buffer(s360_ctx* ctx, int on);
+/* The same fetch with the frame slot NAMED instead of selected (s360_select_frame_slot is state of the context): the one fetching
+ * thread of a batch host drains step k's slots while another thread selects slots for step k+2's uploads. */
+int s360_frame_download_equirect_slot(s360_ctx* ctx, int slot, int age, uint8_t* out_bgr);
 /* ---- the equirect as a PNG FILE, encoded on the device -------------------------------------------------
  * Replaces imwriteExceptionOnFail(FLAGS_output_equirect_path, ...) (TRSP:938-961; cv::imwrite's PngEncoder: 8-bit RGB, Sub filter,
  * zlib Z_BEST_SPEED + Z_RLE) for the output frame: with s360_set_png_encode(ctx, 1) every frame rendered from then on is also
@@ -240,6 +243,7 @@ int s360_set_output_double_buffer(s360_ctx* ctx, int on);
 int s360_set_png_encode(s360_ctx* ctx, int on);
 size_t s360_frame_png_bound(s360_ctx* ctx);
 int s360_frame_download_png(s360_ctx* ctx, int age, uint8_t* out, size_t cap, size_t* n_out);
+int s360_frame_download_png_slot(s360_ctx* ctx, int slot, int age, uint8_t* out, size_t cap, size_t* n_out);
 /* The same encoder as an operator: any 8-bit B,G,R image in host memory (rows contiguous) -> a PNG file in `out`
  * (cap >= s360_png_bound(w, h)); synchronous. */
 size_t s360_png_bound(int w, int h);

@@ -83,7 +83,7 @@ SYMBOLS = [
     "s360_isp_config_defaults", "s360_isp_config_from_json", "s360_isp_create", "s360_isp_destroy", "s360_isp_process",
     "s360_isp_config_tables", "s360_isp_process_packed", "s360_frame_upload_raw", "s360_frame_upload_packed", "s360_isp_pipe_generated",
     "s360_host_alloc", "s360_host_free", "s360_frame_uploads_complete",
-    "s360_set_output_double_buffer", "s360_set_png_encode", "s360_frame_png_bound", "s360_frame_download_png", "s360_png_bound", "s360_encode_png",
+    "s360_set_output_double_buffer", "s360_set_png_encode", "s360_frame_png_bound", "s360_frame_download_png", "s360_frame_download_png_slot", "s360_frame_download_equirect_slot", "s360_png_bound", "s360_encode_png",
 ]
 
 _lib = None

@@ -831,11 +831,21 @@ int s360_frame_download_equirect(s360_ctx* c, uint8_t* out_bgr) {
     d2h(c, out_bgr, F.outBGR[F.out_cur].p, (size_t)c->g.out_width * c->g.out_height * 3);
   });
 }
-int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
+// the state of frame slot `slot` (-1: the selected one) without touching the selection: a fetching thread names its slot, so that
+// the thread that feeds the context can go on selecting slots for its uploads
+static FrameState& slot_state(s360_ctx* c, int slot) {
+  if (slot < 0) return frame_state(c);
+  need(slot < (int)std::max<size_t>(c->slots.size(), 1), "frame slot out of range");
+  const int saved = c->slot;
+  c->slot = slot;
+  struct Restore { s360_ctx* c; int s; ~Restore() { c->slot = s; } } restore{c, saved};
+  return frame_state(c);
+}
+static int download_equirect_impl(s360_ctx* c, int slot, int age, uint8_t* out_bgr) {
   if (!c) return S360_ERR_INVALID_ARG;
   return guard_l(c, [&](std::unique_lock<std::recursive_mutex>& lk) {
     need(out_bgr && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
-    FrameState& F = frame_state(c);
+    FrameState& F = slot_state(c, slot);
     need(F.frames_done > age, "that frame has not been rendered");
     need(age == 0 || ((c->pipeline || c->two_outputs) && F.outBGR[F.out_cur ^ 1].p),
          "age 1 needs two output buffers (s360_set_frame_pipelining or s360_set_output_double_buffer)");
@@ -874,6 +884,11 @@ int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) {
       throw Error(S360_ERR_HIP, "banded sweep timed out waiting for a neighbour band (results invalid)");
     }
   });
+}
+int s360_frame_download_equirect_of(s360_ctx* c, int age, uint8_t* out_bgr) { return download_equirect_impl(c, -1, age, out_bgr); }
+int s360_frame_download_equirect_slot(s360_ctx* c, int slot, int age, uint8_t* out_bgr) {
+  if (slot < 0) return S360_ERR_INVALID_ARG;
+  return download_equirect_impl(c, slot, age, out_bgr);
 }
 /* ---- the equirect as a PNG file, encoded on the device (png.hip; replaces imwriteExceptionOnFail, TRSP:938-961) ---- */
 static int png_crc_threads() {
@@ -948,11 +963,11 @@ static void png_fetch(s360_ctx* c, std::unique_lock<std::recursive_mutex>& lk, c
   if (release) lk.lock();
   *n_out = n;
 }
-int s360_frame_download_png(s360_ctx* c, int age, uint8_t* out, size_t cap, size_t* n_out) {
+static int download_png_impl(s360_ctx* c, int slot, int age, uint8_t* out, size_t cap, size_t* n_out) {
   if (!c) return S360_ERR_INVALID_ARG;
   return guard_l(c, [&](std::unique_lock<std::recursive_mutex>& lk) {
     need(out && n_out && (age == 0 || age == 1), "bad argument (age is 0 = latest enqueued frame or 1 = the one before)");
-    FrameState& F = frame_state(c);
+    FrameState& F = slot_state(c, slot);
     need(F.frames_done > age, "that frame has not been rendered");
     need(age == 0 || ((c->pipeline || c->two_outputs) && F.outBGR[F.out_cur ^ 1].p),
          "age 1 needs two output buffers (s360_set_frame_pipelining or s360_set_output_double_buffer)");
@@ -962,6 +977,11 @@ int s360_frame_download_png(s360_ctx* c, int age, uint8_t* out, size_t cap, size
     if (!F.downRead[b]) S360_HIP(hipEventCreateWithFlags(&F.downRead[b], hipEventDisableTiming));
     png_fetch(c, lk, F.pngPlan[b], F.pngMeta[b], F.pngFile[b], F.outDone[b], F.downRead[b], F.outErrDev[b].p, out, cap, n_out);
   });
+}
+int s360_frame_download_png(s360_ctx* c, int age, uint8_t* out, size_t cap, size_t* n_out) { return download_png_impl(c, -1, age, out, cap, n_out); }
+int s360_frame_download_png_slot(s360_ctx* c, int slot, int age, uint8_t* out, size_t cap, size_t* n_out) {
+  if (slot < 0) return S360_ERR_INVALID_ARG;
+  return download_png_impl(c, slot, age, out, cap, n_out);
 }
 int s360_encode_png(s360_ctx* c, const uint8_t* bgr, int w, int h, uint8_t* out, size_t cap, size_t* n_out) {
   if (!c) return S360_ERR_INVALID_ARG;
