@@ -78,7 +78,7 @@ def total(block, pats):
         if any(p in line for p in pats):
             f = line.split()
             n += int(f[-3])
-            tot += float(f[-2]) * int(f[-3])
+            tot += float(f[-2])
     return n, tot
 fetch_all, write_all = open(outdir + "/fetch_full.txt").read(), open(outdir + "/write_full.txt").read()  # (every kernel, not the top 24)
 frames, _ = total(fetch_all, ["k_novel_view"])
