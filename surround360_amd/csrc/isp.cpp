@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "json_mini.hpp"
 
@@ -353,6 +355,17 @@ void isp_init(s360_isp* o, int device, const s360_isp_config& cfg) {
 }
 
 static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out);
+// pixels k_isp_stuck may rewrite per frame (S360_ISP_STUCK_BUDGET; 0 = no bound). Default 262 144: about a second of the serial walk.
+static unsigned stuck_pixel_budget() {
+  static const unsigned v = [] {
+    const char* e = std::getenv("S360_ISP_STUCK_BUDGET");
+    if (!e || !e[0]) return 262144u;
+    const long long n = std::atoll(e);
+    return n <= 0 ? 0u : (unsigned)std::min<long long>(n, 0xffffffffll);
+  }();
+  return v;
+}
+
 static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH);
 void isp_process(s360_isp* o, const uint16_t* raw16, int inW, int inH, void* out) {
   refuse_while_feeding(o, "s360_isp_process");
@@ -447,7 +460,11 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
     o->dGreen.ensure(n * sizeof(float));
     o->dFlag.ensure(n);
   }
-  if (o->dev.stuckR > 0) o->dStuck.ensure((n + w) * 5 + (size_t)w * 4 + 64);
+  if (o->dev.stuckR > 0) {
+    o->dStuck.ensure((n + w) * 5 + (size_t)w * 4 + 64);
+    o->dStuckCount.ensure(2 * sizeof(unsigned));
+    if (!o->hStuckCount) S360_HIP(hipHostMalloc((void**)&o->hStuckCount, 2 * sizeof(unsigned), hipHostMallocDefault));
+  }
   if (o->dev.sharpen) {
     o->dLp.ensure(n * 3 * sizeof(float));
     o->dScratch.ensure(n * 3 * sizeof(float));
@@ -472,8 +489,22 @@ static void isp_enqueue(s360_isp* o, hipStream_t st, int inW, int inH) {
   B.curveV = cur->v_.as<float>();
   B.lut = o->dLut.as<float>();
   B.exptab = o->dExp.as<unsigned long long>();
+  B.stuckCount = o->dStuckCount.as<unsigned>();
+  B.stuckBudget = stuck_pixel_budget();
   isp_launch(st, o->dev, o->dRaw.as<unsigned short>(), inW, inH, B, o->dOut.p);
   S360_HIP(hipGetLastError());
+  if (o->dev.stuckR > 0 && B.stuckBudget) {
+    // removeStuckPixels where it changes pixels is a serial walk (k_isp_stuck): the one configuration of the ISP whose cost is not
+    // bounded by the image's size alone. Its verdict comes back with a wait — this configuration pays tens of milliseconds for the
+    // pass itself —, and a frame over the budget is refused instead of rendered from an unfiltered plane.
+    S360_HIP(hipMemcpyAsync(o->hStuckCount, o->dStuckCount.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    S360_HIP(hipStreamSynchronize(st));
+    if (o->hStuckCount[1])
+      throw Error(S360_ERR_INVALID_ARG, "removeStuckPixels (stuckPixelRadius > 0, threshold " + std::to_string(o->dev.stuckThr) +
+                                            ") would rewrite " + std::to_string(o->hStuckCount[0]) + " pixels one after the other (budget " +
+                                            std::to_string(B.stuckBudget) + ", ~1-5 us each in one workgroup): refused; S360_ISP_STUCK_BUDGET=<pixels> "
+                                            "raises the budget, 0 removes it");
+  }
 }
 
 static void isp_run_uploaded(s360_isp* o, int inW, int inH, void* out) {
@@ -513,6 +544,7 @@ const void* isp_enqueue_on(s360_isp* o, hipStream_t st, unsigned long long ctxUi
 }
 
 void isp_release(s360_isp* o) {
+  if (o->hStuckCount) { (void)hipHostFree(o->hStuckCount); o->hStuckCount = nullptr; }
   if (o->st) {
     (void)hipSetDevice(o->device);
     (void)hipStreamSynchronize(o->st);

@@ -24,6 +24,8 @@ struct IspFrameBufs {
   unsigned char *flag, *stuckAct, *stuckAct0;  // k_isp_stuck: stuckAct / stuckCand one row, stuckAct0 / stuckCand0 the image
   float *stuckCand, *stuckCand0;
   int* stuckDirty;  // one row
+  unsigned* stuckCount;  // [0] pixels the pre-pass wants to change, [1] set by k_isp_stuck when that is over `stuckBudget` (pass not run)
+  unsigned stuckBudget;  // 0: unbounded
   const float *curveH, *curveV, *lut;
   const unsigned long long* exptab;
 };
@@ -60,6 +62,8 @@ struct s360_isp {
   std::vector<float> ccm, lut;  // host copies of the derived tables (s360_isp_get_tables)
   s360::DevBuf dToneTab;  // pipe: [4096][3] uint16
   s360::DevBuf dStuck;  // k_isp_stuck: n + w floats, w ints, n + w bytes
+  s360::DevBuf dStuckCount;        // two words (IspFrameBufs::stuckCount)
+  unsigned* hStuckCount = nullptr;  // ... and their page-locked landing place
   s360::DevBuf dGenH, dGenV, dGenTone;  // s360_isp_pipe_generated: the caller's tables
   s360::DevBuf dLut, dExp, dRaw, dPlane, dGV, dGH, dGreen, dFlag, dImg, dLp, dScratch, dState, dOut, dPacked;
   // vignette curves per output size (curveHAtPixel / curveVAtPixel): a rig's side and pole cameras may differ in

@@ -238,7 +238,8 @@ __device__ inline StuckEval stuck_evaluate(const float* __restrict__ plane, int 
 }
 // every pixel against the ORIGINAL image, all workgroups at once: the verdict holds for every pixel that no changed pixel comes near
 __global__ __launch_bounds__(256) void k_isp_stuck_pre(const float* __restrict__ plane, int w, int h, IspDev d, int R, int thr,
-                                                        float dark, float* __restrict__ cand0, unsigned char* __restrict__ act0) {
+                                                        float dark, float* __restrict__ cand0, unsigned char* __restrict__ act0,
+                                                        unsigned* __restrict__ count) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (j >= w) return;
   StuckEval e;
@@ -247,13 +248,21 @@ __global__ __launch_bounds__(256) void k_isp_stuck_pre(const float* __restrict__
   if (j != ((i & 1) == 0 ? w - 1 : 0)) e = stuck_evaluate(plane, w, h, d, R, thr, dark, i, j);  // (`j != jEnd`, CameraIsp.h:1054)
   cand0[(size_t)i * w + j] = e.value;
   act0[(size_t)i * w + j] = e.write ? 1 : 0;
+  if (e.write) atomicAdd(count, 1u);  // (the pixels the serial pass will at least have to rewrite: what it is budgeted on)
 }
 __global__ __launch_bounds__(1024) void k_isp_stuck(float* __restrict__ plane, int w, int h, IspDev d, int R, int thr, float dark,
                                                      const float* __restrict__ cand0, const unsigned char* __restrict__ act0,
                                                      float* __restrict__ cand, unsigned char* __restrict__ act,
-                                                     int* __restrict__ dirtyRow) {
+                                                     int* __restrict__ dirtyRow, unsigned* __restrict__ count, unsigned budget) {
   __shared__ unsigned char s_any[1024];  // per stretch of 64 scan positions: phase A found something to write (w <= 65536)
   const int tid = threadIdx.x;
+  // The walk below is ONE workgroup and costs 1 - 5 us per pixel it rewrites (profiles/r04_v8_stuck_pixel_time.txt: 46 k pixels
+  // 45 ms, 1.9 M pixels 2.2 s; a dark 2048 x 2048 frame with a threshold of 0 would hold the GPU for half a minute in this one
+  // launch). Above the budget the pass is NOT run and the host refuses the frame (isp.cpp): bounded, and said aloud.
+  if (budget && count[0] > budget) {
+    if (tid == 0) count[1] = 1u;
+    return;
+  }
   for (int j = tid; j < w; j += blockDim.x) dirtyRow[j] = -0x3fffffff;  // the last row in which column j changed
   __syncthreads();
   for (int i = 0; i < h; ++i) {
@@ -540,9 +549,11 @@ void isp_launch(hipStream_t st, const IspDev& d, const unsigned short* raw, int 
   hipLaunchKernelGGL(k_isp_front, grd, row, 0, st, raw, inW, inH, B.plane, w, h, d, B.curveH, B.curveV);
   if (d.stuckR > 0)  // removeStuckPixels where it changes pixels (isp_derive leaves stuckR 0 where it is the reference's no-op)
   {
-    hipLaunchKernelGGL(k_isp_stuck_pre, grd, row, 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand0, B.stuckAct0);
+    (void)hipMemsetAsync(B.stuckCount, 0, 2 * sizeof(unsigned), st);
+    hipLaunchKernelGGL(k_isp_stuck_pre, grd, row, 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand0, B.stuckAct0,
+                       B.stuckCount);
     hipLaunchKernelGGL(k_isp_stuck, dim3(1), dim3(1024), 0, st, B.plane, w, h, d, d.stuckR, d.stuckThr, d.stuckDark, B.stuckCand0,
-                       B.stuckAct0, B.stuckCand, B.stuckAct, B.stuckDirty);
+                       B.stuckAct0, B.stuckCand, B.stuckAct, B.stuckDirty, B.stuckCount, B.stuckBudget);
   }
   if (d.demosaic == 0) {
     hipLaunchKernelGGL((k_isp_color<0>), grd, row, 0, st, B.plane, nullptr, w, h, d, B.lut, B.img);

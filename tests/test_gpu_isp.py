@@ -2,6 +2,8 @@
 the reference's own CameraIsp.h (tests/test_cpu_isp.py). Bit-exact: 8- and 16-bit outputs compare as integers."""
 import os
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 
@@ -174,6 +176,35 @@ def test_isp_with_stuck_pixel_radius(oracle, s360lib, case):
     if thr == 1 and radius == 1:  # the pass did something
         off = oracle.isp_run(oracle.isp_config_from_json(isputil.stuck_pixel_config(0, thr, dark), 16), raw)
         assert not np.array_equal(off, want)
+
+
+def test_stuck_pixel_pass_is_bounded(s360lib):
+    """The serial walk of removeStuckPixels costs microseconds per rewritten pixel in ONE workgroup: a frame that would rewrite more
+    pixels than S360_ISP_STUCK_BUDGET (default 262 144; a dark frame with a threshold of 0 or 1) is refused with the count instead
+    of holding the GPU for seconds — and runs when the budget is lifted. (The budget is read once per process: subprocesses.)"""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from surround360_amd import _capi
+if os.environ.get("S360_TEST_EMULATED_LIB") == "1":
+    _capi.LIB_PATH = os.environ.get("S360_TEST_EMULATED_LIB_PATH") or os.path.join(%r, "tools", "libs360_emu.so")
+import isputil
+from surround360_amd import isp as I
+raw = isputil.bayer_frame(160, 120, seed=4)
+isp = I.CameraIsp(I.config_from_json(isputil.stuck_pixel_config(1, 0, 2.0), 16))  # darkness 2.0: every pixel is rewritten
+try:
+    isp.get_image(raw)
+    print("RAN")
+except Exception as e:
+    print("REFUSED", e)
+''' % (ROOT, ROOT, ROOT)
+    for budget, want in (("1000", "REFUSED"), ("0", "RAN"), ("100000", "RAN")):
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, S360_ISP_STUCK_BUDGET=budget), timeout=600)
+        assert r.returncode == 0 and r.stdout.startswith(want), (budget, r.stdout[-300:], r.stderr[-300:])
+        if want == "REFUSED":
+            assert "would rewrite" in r.stdout and "budget 1000" in r.stdout
 
 
 def test_isp_two_sizes_one_object(oracle, s360lib):
