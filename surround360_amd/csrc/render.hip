@@ -67,6 +67,36 @@ void Tables::build(hipStream_t st, int std_feather) {
         else i[mk1 * 4 + mk2] = (short)(i[mk1 * 4 + mk2] - diff);
       }
     }
+  // The table taken apart again (render_kernels.hip, k_remap_cubic_u8c4_packed<.., true>): entry (iy, ix) = round-to-even of the 16
+  // float products t1[iy][k1] * t1[ix][k2] * 32768, saturated to int16, plus ONE residue on one of four taps. Rebuilt here the way
+  // the kernel rebuilds it (float product with x's taps pre-scaled by 2^15 — exact —, the one entry that reaches 32768 clamped, the
+  // 16-bit wrap of the residue add) and compared with all 1024 x 16 entries: only then are the pieces handed to the kernels.
+  std::vector<float> w1(2 * 32 * 4);
+  std::vector<short> res(1024, 0);
+  bool rebuilt = true;
+  for (int k = 0; k < 32; ++k)
+    for (int q = 0; q < 4; ++q) { w1[k * 4 + q] = t1[k][q]; w1[128 + k * 4 + q] = t1[k][q] * 32768.f; }
+  for (int e = 0; e < 1024 && rebuilt; ++e) {
+    const int iy = e >> 5, ix = e & 31;
+    short r[16];
+    for (int k1 = 0; k1 < 4; ++k1)
+      for (int k2 = 0; k2 < 4; ++k2) {
+        volatile float p = w1[iy * 4 + k1] * w1[128 + ix * 4 + k2];  // (volatile: rounded to float here, like the device's v_mul_f32)
+        r[k1 * 4 + k2] = (short)cv_round(std::min((float)p, 32767.f));
+      }
+    int pos = -1, diff = 0;
+    for (int t = 0; t < 16; ++t)
+      if (r[t] != ti[e * 16 + t]) {
+        if (pos >= 0) rebuilt = false;
+        pos = t;
+        diff = (int)ti[e * 16 + t] - (int)r[t];
+      }
+    if (pos >= 0) {
+      const int k1 = pos >> 2, k2 = pos & 3;
+      if (k1 < 2 || k2 < 2 || diff < -8192 || diff > 8191) rebuilt = false;
+      else res[e] = (short)((diff << 2) | ((k1 - 2) * 2 + (k2 - 2)));
+    }
+  }
   std::vector<float> t10(766), t5(766), fs(256);
   for (int s = 0; s < 766; ++s) {
     const float colorDiff = (float)s / 255.0f;
@@ -99,6 +129,17 @@ void Tables::build(hipStream_t st, int std_feather) {
   S360_HIP(hipStreamSynchronize(st));
   dev.bicubic_i = bi.as<short>();
   dev.bicubic_f = bf.as<float>();
+  dev.bicubic_w1 = nullptr;
+  dev.bicubic_res = nullptr;
+  if (rebuilt) {
+    bw1.ensure(w1.size() * sizeof(float));
+    bres.ensure(res.size() * sizeof(short));
+    S360_HIP(hipMemcpyAsync(bw1.p, w1.data(), w1.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    S360_HIP(hipMemcpyAsync(bres.p, res.data(), res.size() * sizeof(short), hipMemcpyHostToDevice, st));
+    S360_HIP(hipStreamSynchronize(st));
+    dev.bicubic_w1 = bw1.as<float>();
+    dev.bicubic_res = bres.as<short>();
+  }
   dev.tanh10 = this->t10.as<float>();
   dev.tanh5 = this->t5.as<float>();
   dev.flat_softmaxL = this->fs.as<float>();

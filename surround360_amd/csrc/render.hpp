@@ -12,7 +12,7 @@
 namespace s360 {
 
 struct Tables {
-  DevBuf bi, bf, t10, t5, fs, gik;
+  DevBuf bi, bf, t10, t5, fs, gik, bw1, bres;
   DevTables dev;
   int gauss_ksize = 0;
   void build(hipStream_t st, int std_alpha_feather_size);

@@ -9,6 +9,7 @@
 #include "render_kernels.hpp"
 
 #include <cstdint>
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -414,14 +415,24 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
 // 0.793 of this form on the same box (profiles/r05_v4_remap_persistent_prefetch_ab.json). Twelve waves per CU whose phases line
 // up leave the VALUs idle more than the weight rows' trips to L1 / L2 cost the 32 resident waves of this form (VALU 63 % / 53 %
 // busy, profiles/r05_v3_valu_busy.txt); both variants were bit-exact on the emulation and on the GPU and are gone.
-template <class MapFn, int ALPHA>
+// WT (round 6): the 16 weights of a pixel are REBUILT from what initInterTab2D makes them of — the 1-D cubic
+// taps of the pixel's two fractions (two 16-byte LDS reads), eight packed multiplies, the round-to-even as eight packed adds of
+// 1.5 * 2^23 (the integer is then the low 16 bits of the sum), eight v_perm_b32 to pack them, and the entry's rounding residue
+// (one LDS read, a packed 16-bit add on its tap) — instead of fetched as 32 bytes from the 32 KB table through L1 / L2. The
+// host has rebuilt all 1024 entries the same way and compared them (Tables::build); bit-identical by construction.
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+template <class MapFn, int ALPHA, bool WT = false>
 __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const uchar4* __restrict__ src, int sw, int sh,
                                                                          const unsigned* __restrict__ packed,
                                                                          const int4* __restrict__ tiles, MapFn mapfn,
                                                                          uchar4* __restrict__ dst, int dw, int dh,
                                                                          const short* __restrict__ tab,
                                                                          int yFeatherStart, int featherSize, size_t sbs,
-                                                                         size_t dbs, int tilesPerImage) {
+                                                                         size_t dbs, int tilesPerImage,
+                                                                         const float* __restrict__ w1, const short* __restrict__ wres) {
+  __shared__ __attribute__((aligned(16))) float s_w1[WT ? 256 : 4];
+  __shared__ short s_res[WT ? 1024 : 2];
   const TileId tile = xcd_tile();  // neighbouring tiles (overlapping source boxes) on the same XCD's L2
   src += sbs * tile.z;
   dst += dbs * tile.z;
@@ -444,6 +455,11 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
     // runtime loop the ~7 pixels of a thread were as many serialised memory round trips
     const unsigned* S32 = reinterpret_cast<const unsigned*>(src);
     unsigned* T32 = reinterpret_cast<unsigned*>(s_tile);
+    if (WT) {  // 1 KB of taps + 2 KB of residues per workgroup (against 32 bytes per pixel = 32 KB per tile from the table)
+      const int tid = threadIdx.y * PT_W + threadIdx.x;
+      s_w1[tid] = w1[tid];
+      reinterpret_cast<uint2*>(s_res)[tid] = reinterpret_cast<const uint2*>(wres)[tid];
+    }
     for (int ly0 = threadIdx.y; ly0 < bh; ly0 += 4 * PT_TY)
       for (int lx0 = threadIdx.x; lx0 < bw; lx0 += 2 * PT_W) {
         unsigned v[4][2];
@@ -479,9 +495,34 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_cubic_u8c4_packed(const u
         const int rx = (pk[k] >> 10) & 2047, ry = (pk[k] >> 21) & 1023;
         // (the weight rows are fetched here, per pixel: requesting all four in front of the barrier cost 30 VGPRs and
         // measured 10 % slower, profiles/r03_v7 vs r3i)
-        const uint4* w4 = reinterpret_cast<const uint4*>(tab + (pk[k] & 1023u) * 16);
-        const uint4 wa = w4[0], wb = w4[1];
-        const unsigned wq[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        unsigned wq[8];
+        if (WT) {
+          const unsigned fxy = pk[k] & 1023u;
+          const float4 wy = *reinterpret_cast<const float4*>(&s_w1[(fxy >> 5) * 4]);
+          const float4 wx = *reinterpret_cast<const float4*>(&s_w1[128 + (fxy & 31u) * 4]);  // (x's taps carry the 2^15)
+          const int rr = s_res[fxy];
+          const f2v x01 = {wx.x, wx.y}, x23 = {wx.z, wx.w};
+          const float wyr[4] = {wy.x, wy.y, wy.z, wy.w};
+          const f2v magic = {12582912.0f, 12582912.0f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            f2v a = x01 * wyr[r], b = x23 * wyr[r];
+            if (r == 1) a.y = fminf(a.y, 32767.0f);  // saturate_cast<short>: the one product that reaches 32768 (both fractions 0)
+            a += magic;
+            b += magic;
+            wq[2 * r] = __builtin_amdgcn_perm(__float_as_uint(a.y), __float_as_uint(a.x), 0x05040100u);
+            wq[2 * r + 1] = __builtin_amdgcn_perm(__float_as_uint(b.y), __float_as_uint(b.x), 0x05040100u);
+          }
+          // the entry's residue on tap (2,2) (2,3) (3,2) or (3,3), added in 16 bits like the table's `(short)(itab - diff)`
+          const unsigned add = ((unsigned)(rr >> 2) & 0xffffu) << (16 * (rr & 1));
+          const unsigned a5 = (rr & 2) ? 0u : add, a7 = (rr & 2) ? add : 0u;
+          wq[5] = __builtin_bit_cast(unsigned, (us2v)(__builtin_bit_cast(us2v, wq[5]) + __builtin_bit_cast(us2v, a5)));
+          wq[7] = __builtin_bit_cast(unsigned, (us2v)(__builtin_bit_cast(us2v, wq[7]) + __builtin_bit_cast(us2v, a7)));
+        } else {
+          const uint4* w4 = reinterpret_cast<const uint4*>(tab + (pk[k] & 1023u) * 16);
+          const uint4 wa = w4[0], wb = w4[1];
+          wq[0] = wa.x; wq[1] = wa.y; wq[2] = wa.z; wq[3] = wa.w; wq[4] = wb.x; wq[5] = wb.y; wq[6] = wb.z; wq[7] = wb.w;
+        }
         const unsigned* T = reinterpret_cast<const unsigned*>(s_tile) + ry * bw + rx;
         int acc[4] = {1 << 14, 1 << 14, 1 << 14, 1 << 14};
 #pragma unroll
@@ -1631,15 +1672,27 @@ void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, i
   const int4* t4 = reinterpret_cast<const int4*>(tiles);
   const size_t sbs = (size_t)sw * sh, dbs = (size_t)dw * dh;
   const int nt = (int)remap_packed_tiles(dw, dh);
+  // (A/B switch of round 6's measurement: S360_REMAP_REBUILD_WEIGHTS=1 takes the WT instantiations for the statically mapped
+  // projections; the outcome is in the kernel's header)
+  static const bool rebuild = [] { const char* e = std::getenv("S360_REMAP_REBUILD_WEIGHTS"); return e && e[0] == '1'; }();
+  if (rebuild && T.bicubic_res && alpha_mode != 2) {
+    if (alpha_mode == 1)
+      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1, true>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
+                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, T.bicubic_w1, T.bicubic_res);
+    else
+      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0, true>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
+                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, T.bicubic_w1, T.bicubic_res);
+    return;
+  }
   if (alpha_mode == 1)
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, (const float*)nullptr, (const short*)nullptr);
   else if (alpha_mode == 2)
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 2>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, (const float*)nullptr, (const short*)nullptr);
   else
     hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt);
+                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, (const float*)nullptr, (const short*)nullptr);
 }
 void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
                           const DevTables& T) {
@@ -1714,7 +1767,7 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
                      mf, pw.extW, pw.rows, pw.extW, pw.rows, packed, reinterpret_cast<int4*>(tiles), (size_t)0, nt);
   hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
                      dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
-                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt);
+                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt, (const float*)nullptr, (const short*)nullptr);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   if ((pw.cols & 3) == 0 && (pw.extW & 3) == 0 && pw.cols + ((pw.maxBlendX + 3) & ~3) <= pw.extW &&

@@ -13,6 +13,11 @@ struct DevCamera {  // Camera (SR/render/Camera.h:87-99) as kernel argument
 // Lookup tables shared by the warp/blend kernels; built on the host (tables.cpp), resident in HBM.
 struct DevTables {
   const short* bicubic_i;   // [1024][16] remap weights, sum == 32768
+  // the same table as what it is made of (initInterTab2D): the 1-D cubic taps [32][4] — x's pre-multiplied by 32768 in the second
+  // half — and, per entry, the tap (2 bits: (2,2) (2,3) (3,2) (3,3)) that took the entry's rounding residue (upper 14 bits,
+  // signed). nullptr when the host's rebuild of all 1024 entries from them did not reproduce bicubic_i.
+  const float* bicubic_w1;  // [2][32][4]
+  const short* bicubic_res; // [1024]
   const float* bicubic_f;   // [1024][16]
   const float* tanh10;      // [766] tanhf(10 * (s/255)), s = sum |dBGR|   (NovelView.cpp:131-138)
   const float* tanh5;       // [766] tanhf(5 * (s/255))                    (CvUtil.cpp:236-242)
