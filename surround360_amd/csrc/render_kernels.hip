@@ -420,6 +420,9 @@ __global__ __launch_bounds__(PT_W* PT_TY) void k_remap_pack(MapFn mapfn, int sw,
 // 1.5 * 2^23 (the integer is then the low 16 bits of the sum), eight v_perm_b32 to pack them, and the entry's rounding residue
 // (one LDS read, a packed 16-bit add on its tap) — instead of fetched as 32 bytes from the 32 KB table through L1 / L2. The
 // host has rebuilt all 1024 entries the same way and compared them (Tables::build); bit-identical by construction.
+// Measured (round 6, alternating on one box, 8K frame, profiles/r06_v5_remap_rebuilt_weights_ab.txt): side projections 0.297 ->
+// 0.272 ms per frame in a batch (0.302 -> 0.287 alone), pole projections 0.263 -> 0.236; the pole warp 0.787 -> 0.865 (it computes
+// more than it waits) and keeps the table. The default for the MapFromBuffer instantiations; S360_REMAP_REBUILD_WEIGHTS=0 = table.
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 template <class MapFn, int ALPHA, bool WT = false>
@@ -1664,6 +1667,10 @@ void launch_remap_pack_map(hipStream_t st, const float2* map, int sw, int sh, in
   hipLaunchKernelGGL((k_remap_pack<MapFromBuffer>), dim3(cdiv(dw, PT_W), cdiv(dh, PT_H), batch), dim3(PT_W, PT_TY), 0, st, mf, sw,
                      sh, dw, dh, packed, reinterpret_cast<int4*>(tiles), (size_t)dw * dh, (int)remap_packed_tiles(dw, dh));
 }
+static bool remap_rebuild_weights() {
+  static const bool on = [] { const char* e = std::getenv("S360_REMAP_REBUILD_WEIGHTS"); return !(e && e[0] == '0'); }();
+  return on;
+}
 void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, int sh, const float2* map, const unsigned* packed,
                                     const void* tiles, uchar4* dst, int dw, int dh, const DevTables& T, int alpha_mode,
                                     int yFeatherStart, int featherSize, int batch) {
@@ -1672,27 +1679,16 @@ void launch_remap_cubic_u8c4_packed(hipStream_t st, const uchar4* src, int sw, i
   const int4* t4 = reinterpret_cast<const int4*>(tiles);
   const size_t sbs = (size_t)sw * sh, dbs = (size_t)dw * dh;
   const int nt = (int)remap_packed_tiles(dw, dh);
-  // (A/B switch of round 6's measurement: S360_REMAP_REBUILD_WEIGHTS=1 takes the WT instantiations for the statically mapped
-  // projections; the outcome is in the kernel's header)
-  static const bool rebuild = [] { const char* e = std::getenv("S360_REMAP_REBUILD_WEIGHTS"); return e && e[0] == '1'; }();
-  if (rebuild && T.bicubic_res && alpha_mode != 2) {
-    if (alpha_mode == 1)
-      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1, true>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, T.bicubic_w1, T.bicubic_res);
-    else
-      hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0, true>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                         T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, T.bicubic_w1, T.bicubic_res);
-    return;
-  }
-  if (alpha_mode == 1)
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 1>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, (const float*)nullptr, (const short*)nullptr);
-  else if (alpha_mode == 2)
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 2>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, (const float*)nullptr, (const short*)nullptr);
-  else
-    hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, 0>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh,
-                       T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, (const float*)nullptr, (const short*)nullptr);
+  // The weights are rebuilt in the kernel (WT) unless the host's rebuild of the table failed or S360_REMAP_REBUILD_WEIGHTS=0 asks
+  // for the table (the A/B switch of round 6's measurement: the kernel's header)
+  const bool wt = remap_rebuild_weights() && T.bicubic_res;
+#define S360_RP(A, W)                                                                                                              \
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromBuffer, A, W>), grid, block, 0, st, src, sw, sh, packed, t4, mf, dst, dw, dh, \
+                     T.bicubic_i, yFeatherStart, featherSize, sbs, dbs, nt, T.bicubic_w1, T.bicubic_res)
+  if (alpha_mode == 1) { if (wt) S360_RP(1, true); else S360_RP(1, false); }
+  else if (alpha_mode == 2) { if (wt) S360_RP(2, true); else S360_RP(2, false); }
+  else { if (wt) S360_RP(0, true); else S360_RP(0, false); }
+#undef S360_RP
 }
 void launch_remap_by_flow(hipStream_t st, const uchar4* src, int w, int h, const float2* flow, uchar4* dst,
                           const DevTables& T) {
@@ -1765,9 +1761,12 @@ void launch_pole_warp_packed(hipStream_t st, const uchar4* extFisheye, const flo
   const int nt = (int)remap_packed_tiles(pw.extW, pw.rows);
   hipLaunchKernelGGL((k_remap_pack<MapFromPoleFlow>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1), dim3(PT_W, PT_TY), 0, st,
                      mf, pw.extW, pw.rows, pw.extW, pw.rows, packed, reinterpret_cast<int4*>(tiles), (size_t)0, nt);
-  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
+  // (the table here: this frame's warp is at 0.78 of the integer issue roof already, and rebuilding the weights — 35 more VALU
+  // operations per pixel — measured 0.865 against 0.787 ms per 8K frame; the statically mapped projections, which wait more than
+  // they compute, gain: profiles/r06_v5_remap_rebuilt_weights_ab.txt)
+  hipLaunchKernelGGL((k_remap_cubic_u8c4_packed<MapFromPoleFlow, 0, false>), dim3(cdiv(pw.extW, PT_W), cdiv(pw.rows, PT_H), 1),
                      dim3(PT_W, PT_TY), 0, st, extFisheye, pw.extW, pw.rows, packed, reinterpret_cast<const int4*>(tiles), mf,
-                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt, (const float*)nullptr, (const short*)nullptr);
+                     warpedExt, pw.extW, pw.rows, T.bicubic_i, 0, 1, (size_t)0, (size_t)0, nt, T.bicubic_w1, T.bicubic_res);
 }
 void launch_pole_finish(hipStream_t st, const uchar4* warpedExt, uchar4* out, int eqrH, const PoleWarpParams& pw) {
   if ((pw.cols & 3) == 0 && (pw.extW & 3) == 0 && pw.cols + ((pw.maxBlendX + 3) & ~3) <= pw.extW &&

@@ -12,8 +12,8 @@ RATE_CLASS = {  # what the family's arithmetic is made of (which issue rate is i
     "flatten": "int", "assemble_pano": "int", "flow_sweep": "fma", "flow_diffusion": "fma", "flow_blur15": "fma", "flow_upscale": "fma",
     "flow_gradients": "fma"}
 FAMILIES = {  # family -> substrings of the (demangled) kernel names it launches
-    "project_side": ["k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 0>"],
-    "project_pole": ["k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 1>", "k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 2>"],
+    "project_side": ["k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 0"],
+    "project_pole": ["k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 1", "k_remap_cubic_u8c4_packed<s360::MapFromBuffer, 2"],
     "novel_view": ["k_novel_view"],
     "pole_warp": ["k_remap_cubic_u8c4_packed<s360::MapFromPoleFlow", "k_remap_pack<s360::MapFromPoleFlow", "k_pole_finish"],
     "flatten": ["k_flatten"],
