@@ -11,9 +11,9 @@
 // byte-aligned raw-deflate segment (a dynamic-Huffman block closed by an empty stored block — zlib's sync flush — and a
 // final block in the last band), so the concatenation is one valid zlib stream for any PNG reader.
 //
-// The work per band (one workgroup of 256 threads; a band is ~196 KB of filtered scanlines, 1024 bands in an 8K frame):
-//   pass 1  the band's B,G,R rows tile by tile through LDS; every thread filters (Sub) and tokenises 16 pixels — literals
-//           and distance-1 matches, i.e. Z_RLE's token set, runs cut at the 48-byte chunk — into the band's histogram;
+// The work per band (one workgroup of 512 threads; a band is ~196 KB of filtered scanlines, 1024 bands in an 8K frame):
+//   pass 1  the band's B,G,R rows tile by tile through LDS; every thread filters (Sub) and tokenises 8 pixels — literals
+//           and distance-1 matches, i.e. Z_RLE's token set, runs cut at the 24-byte chunk — into the band's histogram;
 //           the Adler-32 pieces of the filtered bytes on the way
 //   build   length-limited canonical Huffman code of the literal/length alphabet: rank sort by all threads, the
 //           two-queue merge and the 15-bit limit by one thread, canonical codes by all threads; the exact coded size is
@@ -23,8 +23,13 @@
 // then a layout kernel (prefix sum of the bands' sizes = where each IDAT chunk starts in the file) and a gather kernel that
 // moves every band to its place with the chunk's length and type in front. The host adds what needs no pixel: signature,
 // IHDR, CRC-32 of every chunk (threads), the combined Adler-32, IEND.
-// HBM-bound integer / byte work: algorithmic bytes per 8K frame = 201 MB read twice (the second time mostly from L2) +
-// the compressed size written twice.
+// Algorithmic bytes per 8K frame: 201 MB read twice (the second time mostly from L2) + the compressed size written twice —
+// 0.1 ms of HBM time. What the band kernel is actually bound by is the latency of its per-token chains (a table read, a 64-bit
+// shift-and-or, an LDS atomic per token) at the occupancy its 53 KB of LDS allow. Measured on an 8K frame of the bench
+// (tools/png_time.py, round 6): 1.95 ms with 256 threads x 16 pixels (phase cuts: pass 1 0.55, code build 0.18, pass 2 1.32);
+// privatised histograms, a two-barrier scan and tile loads in flight together changed nothing measurable; 512 threads x 8
+// pixels — twice the waves per CU for the same LDS — 1.49 ms, files 1 % larger (runs cut at 24 bytes instead of 48). The design that
+// would remove the chains — a lane per byte, tokens from ballots, bit offsets from a wave scan — was not built.
 #include "png.hpp"
 
 #include <algorithm>
@@ -39,8 +44,8 @@
 namespace s360 {
 
 namespace {
-constexpr int kT = 256;                         // threads per workgroup
-constexpr int kChunkPx = 16;                    // pixels one thread tokenises per tile
+constexpr int kT = 512;                         // threads per workgroup
+constexpr int kChunkPx = 8;                     // pixels one thread tokenises per tile (a multiple of 4: three dwords)
 constexpr int kChunkBytes = kChunkPx * 3 + 1;   // ... and the most filtered bytes that is (a row's first chunk carries the filter-type byte)
 constexpr int kTilePx = kT * kChunkPx;          // pixels of one row per workgroup iteration
 constexpr int kRawWords = kTilePx * 3 / 4 + 4;  // a tile's bytes + the pixel to its left + alignment slack
@@ -48,6 +53,9 @@ constexpr int kMaxBits = 15;                    // deflate's longest code
 constexpr int kOutWords = (kT * kChunkBytes * kMaxBits + 31) / 32 + 8;
 constexpr int kSyms = 288;                      // literal/length alphabet, padded (286 symbols exist)
 constexpr int kNumLit = 286;
+constexpr int kChunkDw = kChunkPx * 3 / 4;       // dwords of a whole chunk
+constexpr int kChunkB = kChunkPx * 3;            // ... and its bytes
+constexpr int kHistCopies = 8;
 constexpr unsigned kAdler = 65521u;
 constexpr unsigned kStoredMax = 65535u;
 
@@ -55,6 +63,10 @@ struct Smem {
   unsigned raw[kRawWords];
   unsigned out[kOutWords];
   unsigned hist[kSyms];
+  // pass 1 counts into kHistCopies copies, a lane into copy lane % kHistCopies: the Sub-filtered bytes of a smooth image are mostly a
+  // handful of values, and a wave's 64 atomics on one bin are served one after the other (measured on an 8K frame: 1.93 ms for the
+  // band kernel with one copy)
+  unsigned histp[kHistCopies][kSyms];
   unsigned code[kSyms];  // bit-reversed code | length << 16
   unsigned scan[kT];
   unsigned nodeW[2 * kSyms];
@@ -100,12 +112,24 @@ __device__ inline int load_tile(Smem& S, const uint8_t* bgr, unsigned long long 
   const unsigned long long a1 = rowb + (unsigned long long)(px0 + npx) * 3;
   const unsigned long long base = a0 & ~3ull;
   const int nwords = (int)((a1 - base + 3) >> 2);
-  for (int i = threadIdx.x; i < nwords; i += kT) {
+  // every dword of the thread is requested before the first goes to LDS (as a load-store loop these were up to 13 serialised
+  // memory round trips per tile and pass: most of the kernel's time)
+  constexpr int kIt = (kRawWords + kT - 1) / kT;
+  unsigned v[kIt];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int i = threadIdx.x + it * kT;
     const unsigned long long a = base + 4ull * i;
-    unsigned v = 0;
-    if (a + 4 <= total) v = *reinterpret_cast<const unsigned*>(bgr + a);
-    else for (int k = 0; k < 4 && a + k < total; ++k) v |= (unsigned)bgr[a + k] << (8 * k);
-    S.raw[i] = v;
+    v[it] = (i < nwords && a + 4 <= total) ? *reinterpret_cast<const unsigned*>(bgr + a) : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int i = threadIdx.x + it * kT;
+    if (i >= nwords) continue;
+    const unsigned long long a = base + 4ull * i;
+    unsigned w = v[it];
+    if (a + 4 > total) for (int k = 0; k < 4 && a + k < total; ++k) w |= (unsigned)bgr[a + k] << (8 * k);  // (the image's last bytes)
+    S.raw[i] = w;
   }
   return (int)(rowb + (unsigned long long)px0 * 3 - base);
 }
@@ -135,15 +159,88 @@ __device__ inline void chunk_tokens(const uint8_t* rawb, int idx0 /* byte of pix
   if (run >= 3) sink.match(run); else for (int r = 0; r < run; ++r) sink.lit(prev);
 }
 
+// ---- the fast path of a chunk: 16 whole pixels behind the row's first one, no run of three repeats --------------------------
+// (the chunk's filtered bytes are made 4 at a time instead of by byte loops with two LDS byte reads each: the chunk's LDS dwords,
+// funnel shifts to the chunk's alignment, v_perm_b32 from B,G,R to the stream's R,G,B, the left pixel = the same
+// stream three bytes earlier, a byte-wise subtraction in a dword; the run logic works on one repeat flag per byte. A chunk none of
+// whose bytes repeats three times is literals only — one byte-field extract + one table access per byte and pass —, any other takes
+// one loop turn per literal-and-run from the flags.)
+__device__ inline unsigned funnel(unsigned lo, unsigned hi, unsigned sh) {  // the dword at byte offset sh (0..3) of the 8 bytes lo, hi
+  return (unsigned)((((unsigned long long)hi << 32) | lo) >> (8u * sh));
+}
+__device__ inline unsigned sub_bytes(unsigned a, unsigned b) {  // a - b per byte, modulo 256
+  const unsigned H = 0x80808080u;
+  return ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);
+}
+__device__ inline unsigned zero_bytes(unsigned v) { return (v - 0x01010101u) & ~v & 0x80808080u; }  // != 0 iff v has a zero byte
+// F = the chunk's filtered bytes in stream order; idx0 = byte offset of the chunk's first pixel in raw (its left neighbour's three
+// bytes in front of it). Returns the repeat flags: bit j set = byte j equals byte j - 1 (bit 0 never).
+__device__ inline unsigned long long chunk_filtered(const unsigned* __restrict__ raw, int idx0, unsigned (&F)[kChunkDw]) {
+  const int q0 = (idx0 >> 2) - 1;
+  const unsigned sh = (unsigned)idx0 & 3u;
+  unsigned M[kChunkDw + 2], Sd[kChunkDw + 1];  // Sd[k + 1] = the bytes idx0 + 4 k .. + 3, k = -1 .. kChunkDw - 1
+#pragma unroll
+  for (int q = 0; q < kChunkDw + 2; ++q) M[q] = raw[max(q0 + q, 0)];
+#pragma unroll
+  for (int k = 0; k < kChunkDw + 1; ++k) Sd[k] = funnel(M[k], M[k + 1], sh);
+  unsigned T[kChunkDw + 1];  // T[k + 1] = stream bytes 4 k .. 4 k + 3; T[0]: the left pixel's R,G,B in bytes 1..3
+  T[0] = __builtin_amdgcn_perm(Sd[0], Sd[0], 0x01020300u);
+#pragma unroll
+  for (int m = 0; m < kChunkPx / 4; ++m) {  // four pixels = 12 bytes = three dwords at a time
+    const unsigned a = Sd[3 * m + 1], b = Sd[3 * m + 2], c = Sd[3 * m + 3];
+    const unsigned X = funnel(a, b, 3), Y = funnel(b, c, 3);
+    T[3 * m + 1] = __builtin_amdgcn_perm(b, a, 0x05000102u);
+    T[3 * m + 2] = __builtin_amdgcn_perm(Y, X, 0x04050001u);
+    T[3 * m + 3] = __builtin_amdgcn_perm(c, b, 0x05060702u);
+  }
+#pragma unroll
+  for (int k = 0; k < kChunkDw; ++k) F[k] = sub_bytes(T[k + 1], funnel(T[k], T[k + 1], 1));
+  // x = every byte xor its predecessor (the first byte has none: made to differ): a zero byte = a repeat. The repeat flags are
+  // gathered into one bit per byte (exact per-byte zero test, then the four flag bits of a dword multiplied together into a nibble).
+  unsigned long long eq = 0;
+#pragma unroll
+  for (int k = 0; k < kChunkDw; ++k) {
+    const unsigned x = F[k] ^ funnel(k ? F[k - 1] : ~F[0] << 24, F[k], 3);
+    const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);  // 0x80 in every byte of x that is zero
+    eq |= (unsigned long long)((((z >> 7) * 0x00204081u) >> 21) & 15u) << (4 * k);
+  }
+  return eq;
+}
+// byte s (not known at compile time) of the chunk's dwords: a chain of selects (registers cannot be indexed by a lane's value)
+__device__ inline unsigned chunk_byte(const unsigned (&F)[kChunkDw], int s) {
+  const int k = s >> 2;
+  unsigned d = F[0];
+#pragma unroll
+  for (int q = 1; q < kChunkDw; ++q) d = k == q ? F[q] : d;
+  return (d >> (8 * (s & 3))) & 255u;
+}
+// The tokens of a whole chunk from its repeat flags: every byte that does not repeat its predecessor is a literal, the r repeats
+// behind it one distance-1 match (r >= 3) or r literals — chunk_tokens' sequence, with one loop turn per literal-and-run instead of
+// one per byte, and no LDS read on the way.
+template <class Sink>
+__device__ inline void chunk_tokens_eq(const unsigned (&F)[kChunkDw], unsigned long long eq, Sink& sink) {
+  unsigned long long starts = ~eq & ((1ull << kChunkB) - 1ull);
+  while (starts) {
+    const int s = __ffsll((long long)starts) - 1;
+    starts &= starts - 1;
+    const int r = (starts ? __ffsll((long long)starts) - 1 : kChunkB) - s - 1;
+    const int v = (int)chunk_byte(F, s);
+    sink.lit(v);
+    if (r >= 3) sink.match(r);
+    else for (int i = 0; i < r; ++i) sink.lit(v);
+  }
+}
+#define S360_PNG_BYTE(F, j) (((F)[(j) >> 2] >> (8 * ((j)&3))) & 255u)
+
 struct HistSink {
-  Smem& S;
+  unsigned* H;  // this lane's copy of the histogram
   unsigned sum = 0, wsum = 0, j = 0, ebits = 0, nmatch = 0;
   __device__ void byte(int v) { sum += v; wsum += j * v; ++j; }
-  __device__ void lit(int v) { atomicAdd(&S.hist[v], 1u); }
+  __device__ void lit(int v) { atomicAdd(&H[v], 1u); }
   __device__ void match(int L) {
     int sym, eb, ev;
     length_code(L, sym, eb, ev);
-    atomicAdd(&S.hist[sym], 1u);
+    atomicAdd(&H[sym], 1u);
     ebits += eb;
     ++nmatch;
   }
@@ -190,34 +287,38 @@ struct EmitSink {
   }
 };
 
-// exclusive prefix sum over the workgroup's threads; *total = the sum
+// exclusive prefix sum over the workgroup's threads; *total = the sum. Inside a wave by lane shuffles (ds_bpermute: lane - d), the four
+// waves' totals through LDS: two barriers (as a Hillis-Steele scan in LDS it was seventeen, sixteen times per band).
 __device__ inline unsigned block_scan(Smem& S, unsigned v, unsigned* total) {
-  const int t = threadIdx.x;
-  S.scan[t] = v;
-  __syncthreads();
-  for (int off = 1; off < kT; off <<= 1) {
-    const unsigned a = t >= off ? S.scan[t - off] : 0u;
-    __syncthreads();
-    S.scan[t] += a;
-    __syncthreads();
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned up = (unsigned)__builtin_amdgcn_ds_bpermute(4 * max(lane - d, 0), (int)incl);
+    if (lane >= d) incl += up;
   }
-  const unsigned incl = S.scan[t];
-  *total = S.scan[kT - 1];
+  if (lane == 63) S.scan[wv] = incl;
   __syncthreads();
-  return incl - v;
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kT / 64; ++k) {
+    const unsigned w = S.scan[k];
+    if (k < wv) base += w;
+    tot += w;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + incl - v;
 }
 
-// S.out holds `total` bits from bit 0: the whole dwords go to gout[*gw ..], the rest moves to the buffer's front.
+// S.out holds `total` bits from bit 0: the whole dwords go to gout[*gw ..], the rest moves to the buffer's front. (The callers'
+// next barrier — behind the next tile's load, or the explicit one in front of the epilogue — orders the refill after the zeroing.)
 __device__ inline unsigned flush_words(Smem& S, unsigned* gout, unsigned* gw, unsigned total) {
   const int full = (int)(total >> 5);
   for (int i = threadIdx.x; i < full; i += kT) gout[*gw + i] = S.out[i];
-  __syncthreads();
   const unsigned carry = S.out[full];
   __syncthreads();
-  for (int i = threadIdx.x; i <= full; i += kT) S.out[i] = 0u;
-  __syncthreads();
-  if (threadIdx.x == 0) S.out[0] = carry;
-  __syncthreads();
+  for (int i = threadIdx.x; i <= full; i += kT) S.out[i] = i == 0 ? carry : 0u;
   *gw += (unsigned)full;
   return total & 31u;
 }
@@ -243,6 +344,7 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
   unsigned* gout = reinterpret_cast<unsigned*>(scratch + (unsigned long long)b * G.band_stride);
 
   for (int i = t; i < kSyms; i += kT) { S.hist[i] = 0u; S.code[i] = 0u; }
+  for (int i = t; i < kHistCopies * kSyms; i += kT) (&S.histp[0][0])[i] = 0u;
   for (int i = t; i < kOutWords; i += kT) S.out[i] = 0u;
   if (t < 8) S.misc[t] = 0u;
   __syncthreads();
@@ -255,8 +357,31 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
         const int off = load_tile(S, bgr, G.total_bytes, G.w, y0 + r, tl * kTilePx);
         __syncthreads();
         const int cpx = tl * kTilePx + t * kChunkPx, npx = min(kChunkPx, G.w - cpx);
-        if (npx > 0) {
-          HistSink hs{S};
+        unsigned F[kChunkDw];
+        if (npx == kChunkPx && cpx > 0) {  // a whole chunk behind the row's first pixel: from registers
+          const unsigned long long eq = chunk_filtered(S.raw, off + 3 * t * kChunkPx, F);
+          unsigned* H = S.histp[t % kHistCopies];
+          unsigned sum = 0, wsum = 0;
+#pragma unroll
+          for (int k = 0; k < kChunkDw; ++k) {
+            sum = __builtin_amdgcn_sad_u8(F[k], 0u, sum);  // + the four bytes
+            wsum = __builtin_amdgcn_udot4(F[k], 0x03020100u + 0x04040404u * (unsigned)k, wsum, false);  // + sum of index x byte
+          }
+          if (!(eq & (eq >> 1) & (eq >> 2))) {  // no three repeats in a row: literals only
+#pragma unroll
+            for (int j = 0; j < kChunkB; ++j) atomicAdd(&H[S360_PNG_BYTE(F, j)], 1u);
+          } else {
+            HistSink hs{H};
+            chunk_tokens_eq(F, eq, hs);
+            eb += hs.ebits;
+            nm += hs.nmatch;
+          }
+          const unsigned g = (unsigned)r * G.line + 1u + 3u * (unsigned)cpx;
+          s1 = (s1 + sum) % kAdler;
+          const unsigned long long wgt = (unsigned long long)(n - g) * sum - wsum;
+          s2 = (unsigned)((s2 + wgt % kAdler) % kAdler);
+        } else if (npx > 0) {
+          HistSink hs{S.histp[t % kHistCopies]};
           chunk_tokens(rawb, off + 3 * t * kChunkPx, cpx, npx, cpx == 0, hs);
           // bytes [g, g + j) of the band: sum += d, weighted sum += (n - (g + i)) d_i
           const unsigned g = (unsigned)r * G.line + (cpx ? 1u + 3u * (unsigned)cpx : 0u);
@@ -272,7 +397,12 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
     atomicAdd(&S.misc[1], s2);
     atomicAdd(&S.misc[2], eb);
     atomicAdd(&S.misc[3], nm);
-    if (t == 0) atomicAdd(&S.hist[256], 1u);  // end of block
+  }
+  __syncthreads();
+  for (int i = t; i < kSyms; i += kT) {
+    unsigned c = i == 256 ? 1u : 0u;  // (256: the end-of-block symbol)
+    for (int k = 0; k < kHistCopies; ++k) c += S.histp[k][i];
+    S.hist[i] = c;
   }
   __syncthreads();
 
@@ -403,14 +533,38 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
       __syncthreads();
       const int cpx = tl * kTilePx + t * kChunkPx, npx = min(kChunkPx, G.w - cpx);
       unsigned bits = 0;
-      if (npx > 0) {
+      unsigned F[kChunkDw];
+      const bool whole = npx == kChunkPx && cpx > 0;
+      const unsigned long long eq = whole ? chunk_filtered(S.raw, off + 3 * t * kChunkPx, F) : 0ull;
+      const bool fast = whole && !(eq & (eq >> 1) & (eq >> 2));  // literals only
+      if (fast) {
+#pragma unroll
+        for (int j = 0; j < kChunkB; ++j) bits += S.code[S360_PNG_BYTE(F, j)] >> 16;
+      } else if (whole) {
+        CountSink cs{S};
+        chunk_tokens_eq(F, eq, cs);
+        bits = cs.bits;
+      } else if (npx > 0) {
         CountSink cs{S};
         chunk_tokens(rawb, off + 3 * t * kChunkPx, cpx, npx, cpx == 0, cs);
         bits = cs.bits;
       }
       unsigned tot;
       const unsigned excl = block_scan(S, bits, &tot);
-      if (npx > 0) {
+      if (fast) {
+        BitWriter W(S, pend + excl);
+#pragma unroll
+        for (int j = 0; j < kChunkB; ++j) {
+          const unsigned c = S.code[S360_PNG_BYTE(F, j)];
+          W.put(c & 0xffffu, (int)(c >> 16));
+        }
+        W.finish();
+      } else if (whole) {
+        BitWriter W(S, pend + excl);
+        EmitSink es{W};
+        chunk_tokens_eq(F, eq, es);
+        W.finish();
+      } else if (npx > 0) {
         BitWriter W(S, pend + excl);
         EmitSink es{W};
         chunk_tokens(rawb, off + 3 * t * kChunkPx, cpx, npx, cpx == 0, es);
@@ -420,6 +574,7 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
       pend = flush_words(S, gout, &gw, pend + tot);
     }
   // end of block; every band but the last is closed like zlib's sync flush: an empty stored block, which byte-aligns
+  __syncthreads();  // (the last flush has finished clearing the bit buffer)
   if (t == 0) {
     BitWriter W(S, pend);
     W.put(S.code[256] & 0xffffu, (int)(S.code[256] >> 16));

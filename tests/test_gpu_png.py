@@ -111,8 +111,8 @@ def test_encode_png_decodes_to_the_input(ctx, name):
     a = cases()[name]
     png = ctx.encode_png(a)
     rows, nb = decode_check(png, a)
-    if name == "flat":  # 750 000 bytes of one colour: distance-1 matches, not literals
-        assert len(png) < a.size // 25
+    if name == "flat":  # 750 000 bytes of one colour: distance-1 matches (runs are cut at a thread's 24 bytes), not literals
+        assert len(png) < a.size // 20
     if name == "noise":  # nothing to gain: stored blocks, a few bytes of framing per band
         assert len(png) <= a.size + a.shape[0] + (12 + 5) * nb + 200
 

@@ -195,6 +195,17 @@ inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
   return r;
 }
 #define __builtin_amdgcn_perm(a, b, s) emu_perm((unsigned)(a), (unsigned)(b), (unsigned)(s))
+// v_sad_u8 / v_dot4_u32_u8 (png.hip: sums over the four bytes of a dword)
+inline unsigned emu_sad_u8(unsigned a, unsigned b, unsigned c) {
+  for (int i = 0; i < 4; ++i) { const int x = (a >> (8 * i)) & 255, y = (b >> (8 * i)) & 255; c += (unsigned)(x > y ? x - y : y - x); }
+  return c;
+}
+inline unsigned emu_udot4(unsigned a, unsigned b, unsigned c, bool) {
+  for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+  return c;
+}
+#define __builtin_amdgcn_sad_u8(a, b, c) emu_sad_u8((unsigned)(a), (unsigned)(b), (unsigned)(c))
+#define __builtin_amdgcn_udot4(a, b, c, clamp) emu_udot4((unsigned)(a), (unsigned)(b), (unsigned)(c), clamp)
 // v_dot2_i32_i16
 template <typename V>
 inline int emu_sdot2(V a, V b, int c, bool) { return (int)a.x * (int)b.x + (int)a.y * (int)b.y + c; }
