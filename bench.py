@@ -646,7 +646,7 @@ def main():
                     help="only the video_streams_batched leg (slots-against-frames/s probes: --stream-slots N); prints that leg's record")
     ap.add_argument("--stream-steps", type=int, default=8, help="video_streams_batched leg: timed steps (after 4 run-in steps)")
     ap.add_argument("--pipeline-batches", action="store_true",
-                    help="timing experiment (needs S360_EXPERIMENT_BATCH_PIPELINE=1): the timed region's batches with frame pipelining — "
+                    help="the timed region's batches with frame pipelining (s360_set_frame_pipelining on a context of frame slots): "
                          "batch k's pole stage on a second stream beside batch k+1's side stage inside ONE context")
     ap.add_argument("--video-frames", type=int, default=190,
                     help="frames of the configs[4] stream leg (SURVEY 8d: 190, steady state over frames 10-189)")
@@ -1585,8 +1585,8 @@ def main():
                 table = [{"workload": "independent frames (the headline)", "slots_per_context": S, "contexts": F,
                           "frames_per_s": out["value"], "hbm_used_GB": hbm_used_gb}]
 
-                def independent_row(S2):
-                    cs = [R.Context(rig, R.make_params(**flags), device=local_rank) for _ in range(F)]
+                def independent_row(S2, nctx=F, pipelined=False):
+                    cs = [R.Context(rig, R.make_params(**flags), device=local_rank) for _ in range(nctx)]
                     try:
                         for k, c in enumerate(cs):
                             c.set_frame_slots(S2)
@@ -1594,7 +1594,9 @@ def main():
                                 c.select_frame_slot(j)
                                 c.upload_frame(*frames[k * S2 + j])
                             c.set_sweep_mode("throughput")
-                        with ThreadPoolExecutor(F) as pool:
+                            if pipelined:  # batch k's pole stage on a second stream beside batch k+1's side stage
+                                c.set_frame_pipelining(True)
+                        with ThreadPoolExecutor(nctx) as pool:
                             def batch(n):
                                 for _ in range(n):
                                     list(pool.map(lambda c: c.render_batch(False), cs))
@@ -1608,7 +1610,8 @@ def main():
                             dts = time.perf_counter() - t
                         cs[0].select_frame_slot(0)
                         same = bool(np.array_equal(cs[0].download_equirect(), single0))
-                        return {"workload": "independent frames", "slots_per_context": S2, "contexts": F, "frames_per_s": nb * F * S2 / dts,
+                        return {"workload": "independent frames" + (", batches pipelined inside the context (s360_set_frame_pipelining)" if pipelined else ""),
+                                "slots_per_context": S2, "contexts": nctx, "frames_per_s": nb * nctx * S2 / dts,
                                 "hbm_used_GB": round(used, 1), "frame_0_equals_single": same}
                     finally:
                         for c in cs:
@@ -1618,6 +1621,7 @@ def main():
                 for S2 in ([1] if dry else [8]):
                     if S2 < S or dry:
                         table.append(independent_row(S2))
+                table.append(independent_row(2 if dry else S, nctx=1, pipelined=True))  # ONE context: what the second one buys, for less HBM
                 vb = out.get("video_streams_batched", {})
                 if "frames_per_s" in vb:
                     table.append({"workload": "temporally chained streams (video_streams_batched)", "slots_per_context": vb["slots_per_context"],

@@ -222,12 +222,6 @@ FlowEngine& flow_engine(s360_ctx* c, int which) {
   }
   return *e;
 }
-// (timing experiment, round 6: S360_EXPERIMENT_BATCH_PIPELINE=1 lets a batch of slots run with frame pipelining — batch k's pole
-// stage on the second stream beside batch k+1's side stage; the measurement and its outcome are in DESIGN.md section 6)
-static bool batch_pipelining_allowed() {
-  static const bool on = [] { const char* e = std::getenv("S360_EXPERIMENT_BATCH_PIPELINE"); return e && e[0] == '1'; }();
-  return on;
-}
 void set_frame_slots(s360_ctx* c, int n) {
   if (n < 1 || n > 64) throw Error(S360_ERR_INVALID_ARG, "frame slots must be 1..64");
   S360_HIP(hipStreamSynchronize(c->st));
@@ -998,7 +992,8 @@ void frame_composite(s360_ctx* c, int pole_mask) { finish_stage(c, {c->slot}, 0,
 // in ONE batch of the flow kernels, the 4 pole flows of every slot in another. Results per slot are those of
 // s360_frame_render on that slot.
 void frame_render_batch(s360_ctx* c, int use_prev) {
-  if (c->pipeline && !batch_pipelining_allowed()) throw Error(S360_ERR_STATE, "frame pipelining and batched slots are separate modes");
+  // (frame pipelining applies to batches as to frames: batch k's pole stage and composite on the second stream beside batch k+1's
+  // side stage — round 6; the events between the stages are per context, recorded behind the last slot's work of a stage)
   std::vector<int> ids;
   for (int k = 0; k < (int)std::max<size_t>(c->slots.size(), 1); ++k) ids.push_back(k);
   side_stage(c, ids, 0, (int)c->rig.side.size(), use_prev);
@@ -1006,7 +1001,7 @@ void frame_render_batch(s360_ctx* c, int use_prev) {
 }
 
 void frame_render_slots(s360_ctx* c, const int* slots, int n, int use_prev) {
-  if (c->pipeline && !batch_pipelining_allowed()) throw Error(S360_ERR_STATE, "frame pipelining and batched slots are separate modes");
+
   const int have = (int)std::max<size_t>(c->slots.size(), 1);
   std::vector<int> ids(slots, slots + n);
   for (int k = 0; k < n; ++k)

@@ -217,6 +217,46 @@ def test_frame_slots_batch_equals_single(setup):
         cb.close()
 
 
+def test_pipelined_batches_equal_plain_batches(setup):
+    """s360_set_frame_pipelining on a context of frame slots (round 6): three steps of two slots enqueued back to back — step k's
+    pole stage and composite on the second stream beside step k+1's side stage, every slot chained to its own previous frame from
+    the second step on — give, slot by slot and step by step, the bytes of the same batches on one stream; a step for a subset of
+    the slots (s360_frame_render_slots) included."""
+    rig = R.RigDescription(setup["path"])
+    steps = [[rigutil.frame_inputs(setup["path"], CAM, yaw_deg=0.9 * s + 0.3 * k) for s in range(2)] for k in range(3)]
+    outs = []
+    for pipelined in (False, True):
+        c = R.Context(rig, R.make_params(**setup["flags"]))
+        try:
+            c.set_frame_slots(2)
+            c.set_sweep_mode("throughput")
+            c.set_frame_pipelining(pipelined)
+            got = []
+            for k in range(3):
+                for s in range(2):
+                    c.select_frame_slot(s)
+                    c.upload_frame(*steps[k][s])
+                c.render_batch(use_prev=k > 0)  # no synchronisation between the steps
+                if k == 1:  # (a fetch in the middle of the chain: the step behind it is enqueued over it)
+                    c.select_frame_slot(1)
+                    got.append(c.download_equirect())
+            c.select_frame_slot(0)
+            c.upload_frame(*steps[0][0])
+            c.render_slots([0], use_prev=True)  # a fourth step for slot 0 alone
+            for s in range(2):
+                c.select_frame_slot(s)
+                got.append(c.download_equirect())
+                got.append(c.get_f32("flow_pole", 2))
+                got.append(c.get_f32("flow_l_to_r", 5))
+            outs.append(got)
+        finally:
+            c.close()
+    assert len(outs[0]) == len(outs[1]) == 7
+    for i, (a, b) in enumerate(zip(outs[1], outs[0])):
+        _cmp("pipelined batches, item %d" % i, a, b)
+    assert not np.array_equal(outs[0][1], outs[0][4])  # the two slots hold different frames
+
+
 def test_frame_slots_batch_sharpened(setup):
     """--sharpening 0.25 in a batch: the IIR passes of all slots' eyes run in ONE set of launches (a frame's 2 x 4096 row
     chains alone are half a wave per SIMD); slot by slot the bytes of the frame rendered alone."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # VERDICT r05 item 3 on a GPU box (from the repo root): (1) one context alone, 16 slots, batches back to back with and without frame
-# pipelining of the batches (S360_EXPERIMENT_BATCH_PIPELINE=1: batch k's pole stage on a second stream beside batch k+1's side stage);
+# pipelining of the batches (batch k's pole stage on a second stream beside batch k+1's side stage);
 # (2) the default 2-context region the same two ways; (3) a kernel trace of the default command and how much of the pole sweeps' time
 # already runs beside another context's kernels (tools/sweep_overlap.py).   usage: bash tools/overlap_experiment.sh <tag>
 TAG=${1:?tag}; O=gpurun_out/$TAG; mkdir -p $O
@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 B="python bench.py --steps 12 --warmup 4 --no-extras --no-cpu-baseline"
 for inflight in 1 2; do
   $B --inflight $inflight --slots 16 > $O/plain_$inflight.json 2> $O/plain_$inflight.err
-  S360_EXPERIMENT_BATCH_PIPELINE=1 $B --inflight $inflight --slots 16 --pipeline-batches > $O/piped_$inflight.json 2> $O/piped_$inflight.err
+  $B --inflight $inflight --slots 16 --pipeline-batches > $O/piped_$inflight.json 2> $O/piped_$inflight.err
 done
 python - $O <<'PY'
 import json, sys
