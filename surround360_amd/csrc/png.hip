@@ -12,24 +12,29 @@
 // final block in the last band), so the concatenation is one valid zlib stream for any PNG reader.
 //
 // The work per band (one workgroup of 512 threads; a band is ~196 KB of filtered scanlines, 1024 bands in an 8K frame):
-//   pass 1  the band's B,G,R rows tile by tile through LDS; every thread filters (Sub) and tokenises 8 pixels — literals
-//           and distance-1 matches, i.e. Z_RLE's token set, runs cut at the 24-byte chunk — into the band's histogram;
-//           the Adler-32 pieces of the filtered bytes on the way
+//   pass 1  the band's B,G,R rows tile by tile through LDS; A LANE PER BYTE: a wave takes 64 consecutive filtered bytes, every
+//           lane makes its byte (Sub), one ballot of "equals my left neighbour" gives the group's repeat flags, and the tokens —
+//           literals and distance-1 matches, Z_RLE's token set, runs cut at the 64-byte group — follow from the flags with a
+//           shift and a find-first per lane; they go into the band's histogram, the Adler-32 pieces of the bytes on the way
 //   build   length-limited canonical Huffman code of the literal/length alphabet: rank sort by all threads, the
 //           two-queue merge and the 15-bit limit by one thread, canonical codes by all threads; the exact coded size is
 //           then known, and a band that would not shrink goes out as stored blocks instead
-//   pass 2  the same tiles again: bits per chunk, a workgroup prefix sum, every thread ORs its tokens into an LDS bit
-//           buffer at its offset, whole dwords go to HBM coalesced
+//   pass 2  the same tiles again: every wave sums the bits of its groups, the waves' totals give each wave its start, then
+//           per group a wave scan gives every token-starting lane its bit offset and the lane ORs its tokens (one value of up
+//           to 46 bits) into an LDS bit buffer; whole dwords go to HBM coalesced
 // then a layout kernel (prefix sum of the bands' sizes = where each IDAT chunk starts in the file) and a gather kernel that
 // moves every band to its place with the chunk's length and type in front. The host adds what needs no pixel: signature,
 // IHDR, CRC-32 of every chunk (threads), the combined Adler-32, IEND.
 // Algorithmic bytes per 8K frame: 201 MB read twice (the second time mostly from L2) + the compressed size written twice —
-// 0.1 ms of HBM time. What the band kernel is actually bound by is the latency of its per-token chains (a table read, a 64-bit
-// shift-and-or, an LDS atomic per token) at the occupancy its 53 KB of LDS allow. Measured on an 8K frame of the bench
-// (tools/png_time.py, round 6): 1.95 ms with 256 threads x 16 pixels (phase cuts: pass 1 0.55, code build 0.18, pass 2 1.32);
-// privatised histograms, a two-barrier scan and tile loads in flight together changed nothing measurable; 512 threads x 8
-// pixels — twice the waves per CU for the same LDS — 1.49 ms, files 1 % larger (runs cut at 24 bytes instead of 48). The design that
-// would remove the chains — a lane per byte, tokens from ballots, bit offsets from a wave scan — was not built.
+// 0.1 ms of HBM time; the kernel is bound by instructions and LDS latency per byte. History of the band kernel on an 8K frame of the
+// bench (tools/png_time.py, round 6): a THREAD per 16 pixels walking its 48 bytes (byte loops, sinks per token) 1.95 ms — phase
+// cuts: pass 1 0.55, code build 0.18, pass 2 1.32; privatised histograms, a two-barrier scan, tile loads in flight together: nothing
+// measurable; bytes made four at a time with funnel shifts + v_perm_b32 and a token loop over repeat flags: 2.1–2.3 ms (the chains
+// per token stayed); 512 threads x 8 pixels, twice the waves per CU: 1.49 ms; this form — a lane per byte, DPP scan — 1.44 ms and
+// files 1 % smaller (runs up to 63). The SQ counters of this form: 741 M VALU + 301 M SALU + 56 M LDS wave-instructions per frame,
+// i.e. 3.7 VALU instructions per byte over the three passes; at the chip's integer issue rate (0.25 per cycle and SIMD,
+// tools/issue_rate) 741 M take 1.2 ms: the kernel sits at its instruction-issue roof. Less time now means fewer instructions per
+// byte (the filtered bytes made once per tile four at a time, the count pass folded into the emit pass), not more parallelism.
 #include "png.hpp"
 
 #include <algorithm>
@@ -45,16 +50,13 @@ namespace s360 {
 
 namespace {
 constexpr int kT = 512;                         // threads per workgroup
-constexpr int kChunkPx = 8;                     // pixels one thread tokenises per tile (a multiple of 4: three dwords)
-constexpr int kChunkBytes = kChunkPx * 3 + 1;   // ... and the most filtered bytes that is (a row's first chunk carries the filter-type byte)
-constexpr int kTilePx = kT * kChunkPx;          // pixels of one row per workgroup iteration
+constexpr int kTilePx = 4096;                   // pixels of one row per workgroup iteration
 constexpr int kRawWords = kTilePx * 3 / 4 + 4;  // a tile's bytes + the pixel to its left + alignment slack
 constexpr int kMaxBits = 15;                    // deflate's longest code
-constexpr int kOutWords = (kT * kChunkBytes * kMaxBits + 31) / 32 + 8;
+constexpr int kOutWords = ((kTilePx * 3 + 1) * kMaxBits + 31) / 32 + 8;  // a tile's bytes (+ the row's filter-type byte) at the longest code
 constexpr int kSyms = 288;                      // literal/length alphabet, padded (286 symbols exist)
 constexpr int kNumLit = 286;
-constexpr int kChunkDw = kChunkPx * 3 / 4;       // dwords of a whole chunk
-constexpr int kChunkB = kChunkPx * 3;            // ... and its bytes
+constexpr int kWaves = kT / 64;
 constexpr int kHistCopies = 8;
 constexpr unsigned kAdler = 65521u;
 constexpr unsigned kStoredMax = 65535u;
@@ -134,128 +136,67 @@ __device__ inline int load_tile(Smem& S, const uint8_t* bgr, unsigned long long 
   return (int)(rowb + (unsigned long long)px0 * 3 - base);
 }
 
-// The tokens of one chunk — `lead`: the row's filter-type byte (1 = Sub) first, then pixels [cpx, cpx + npx) as R,G,B bytes
-// minus the same channel of the pixel to the left (0 at the row's start) — in stream order. Z_RLE's token set: a byte equal to
-// its predecessor extends a run; a run of >= 3 repeats leaves as ONE distance-1 match, a shorter one as literals.
-template <class Sink>
-__device__ inline void chunk_tokens(const uint8_t* rawb, int idx0 /* byte of pixel cpx's B in rawb */, int cpx, int npx, bool lead,
-                                    Sink& sink) {
-  int prev = -1, run = 0;
-  if (lead) { sink.byte(1); sink.lit(1); prev = 1; }
-  for (int p = 0; p < npx; ++p) {
-    const int i = idx0 + 3 * p;
-    const bool first = cpx + p == 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {  // PNG order R,G,B out of B,G,R
-      const int v = (rawb[i + 2 - c] - (first ? 0 : rawb[i - 1 - c])) & 255;
-      sink.byte(v);
-      if (v == prev) { ++run; continue; }
-      if (run >= 3) sink.match(run); else for (int r = 0; r < run; ++r) sink.lit(prev);
-      run = 0;
-      sink.lit(v);
-      prev = v;
-    }
-  }
-  if (run >= 3) sink.match(run); else for (int r = 0; r < run; ++r) sink.lit(prev);
+// ---- a lane per byte -------------------------------------------------------------------------------------------------------
+// A wave takes 64 consecutive filtered bytes of the tile at a time. Every lane makes its byte (two LDS byte reads: the pixel's
+// channel and the left pixel's), compares it with its left neighbour's (ds_bpermute), and ONE ballot gives the group's repeat
+// flags. Z_RLE's tokens follow from the flags without a serial walk: a lane whose byte does not repeat its predecessor starts a
+// token group — its literal, then the r repeats behind it as one distance-1 match (r >= 3) or as r more literals; r = the run of
+// set flags right behind the lane = a shift and a find-first of the ballot. Runs are cut at the group (63 repeats at most).
+struct Tok {
+  unsigned v;  // the lane's filtered byte
+  int r;       // start lane: repeats behind it; any other lane: -1 (nothing to emit)
+};
+__device__ inline Tok group_tok(const uint8_t* rawb, int off, int px0, int nbytes, int j) {
+  const int lane = threadIdx.x & 63;
+  const bool valid = j < nbytes;
+  const int jj = valid ? j : 0;
+  const int p = jj / 3, c = jj - 3 * p;  // pixel of the tile, channel in PNG order (R,G,B out of B,G,R)
+  const int i = off + 3 * p;
+  const unsigned cur = rawb[i + 2 - c];
+  const unsigned left = (px0 + p == 0) ? 0u : rawb[i - 1 - c];  // Sub: the same channel one pixel to the left, 0 at the row's start
+  Tok t;
+  t.v = (cur - left) & 255u;
+  // the left neighbour's byte: row_bcast:15 brings lanes 15 / 31 / 47 to the first lanes of the next DPP row, row_shr:1 the rest
+  int pvi = __builtin_amdgcn_update_dpp((int)t.v, (int)t.v, 0x142, 0xE, 0x1, false);
+  pvi = __builtin_amdgcn_update_dpp(pvi, (int)t.v, 0x111, 0xF, 0xF, false);
+  const unsigned pv = (unsigned)pvi;
+  const bool eq = valid && lane > 0 && t.v == pv;
+  const unsigned long long E = __ballot(eq);
+  const unsigned long long behind = lane == 63 ? 0ull : E >> (lane + 1);
+  t.r = (valid && !eq) ? __ffsll((long long)~behind) - 1 : -1;
+  return t;
+}
+// bits of a start lane's tokens (its literal, then a match or up to two more literals)
+__device__ inline unsigned tok_bits(const Smem& S, const Tok& t) {
+  if (t.r < 0) return 0u;
+  const unsigned len = S.code[t.v] >> 16;
+  if (t.r < 3) return len * (unsigned)(1 + t.r);
+  int sym, eb, ev;
+  length_code(t.r, sym, eb, ev);
+  return len + (S.code[sym] >> 16) + (unsigned)eb + 1u;  // + the one-bit distance code
+}
+// inclusive prefix sum over the wave's lanes: four row_shr steps inside the 16-lane DPP rows, then row_bcast:15 / :31 across them
+// (as six ds_bpermute steps — LDS round trips, each waiting for the one before — the scan was most of a group's time)
+__device__ inline unsigned wave_scan(unsigned v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return (unsigned)x;
+}
+// up to 64 bits ORed into S.out from bit `o` on
+__device__ inline void or_bits(Smem& S, unsigned o, unsigned long long val) {
+  const unsigned w = o >> 5, sh = o & 31u;
+  const unsigned long long lo = val << sh;
+  const unsigned hi = sh ? (unsigned)(val >> (64u - sh)) : 0u;
+  if ((unsigned)lo) atomicOr(&S.out[w], (unsigned)lo);
+  if ((unsigned)(lo >> 32)) atomicOr(&S.out[w + 1], (unsigned)(lo >> 32));
+  if (hi) atomicOr(&S.out[w + 2], hi);
 }
 
-// ---- the fast path of a chunk: 16 whole pixels behind the row's first one, no run of three repeats --------------------------
-// (the chunk's filtered bytes are made 4 at a time instead of by byte loops with two LDS byte reads each: the chunk's LDS dwords,
-// funnel shifts to the chunk's alignment, v_perm_b32 from B,G,R to the stream's R,G,B, the left pixel = the same
-// stream three bytes earlier, a byte-wise subtraction in a dword; the run logic works on one repeat flag per byte. A chunk none of
-// whose bytes repeats three times is literals only — one byte-field extract + one table access per byte and pass —, any other takes
-// one loop turn per literal-and-run from the flags.)
-__device__ inline unsigned funnel(unsigned lo, unsigned hi, unsigned sh) {  // the dword at byte offset sh (0..3) of the 8 bytes lo, hi
-  return (unsigned)((((unsigned long long)hi << 32) | lo) >> (8u * sh));
-}
-__device__ inline unsigned sub_bytes(unsigned a, unsigned b) {  // a - b per byte, modulo 256
-  const unsigned H = 0x80808080u;
-  return ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);
-}
-__device__ inline unsigned zero_bytes(unsigned v) { return (v - 0x01010101u) & ~v & 0x80808080u; }  // != 0 iff v has a zero byte
-// F = the chunk's filtered bytes in stream order; idx0 = byte offset of the chunk's first pixel in raw (its left neighbour's three
-// bytes in front of it). Returns the repeat flags: bit j set = byte j equals byte j - 1 (bit 0 never).
-__device__ inline unsigned long long chunk_filtered(const unsigned* __restrict__ raw, int idx0, unsigned (&F)[kChunkDw]) {
-  const int q0 = (idx0 >> 2) - 1;
-  const unsigned sh = (unsigned)idx0 & 3u;
-  unsigned M[kChunkDw + 2], Sd[kChunkDw + 1];  // Sd[k + 1] = the bytes idx0 + 4 k .. + 3, k = -1 .. kChunkDw - 1
-#pragma unroll
-  for (int q = 0; q < kChunkDw + 2; ++q) M[q] = raw[max(q0 + q, 0)];
-#pragma unroll
-  for (int k = 0; k < kChunkDw + 1; ++k) Sd[k] = funnel(M[k], M[k + 1], sh);
-  unsigned T[kChunkDw + 1];  // T[k + 1] = stream bytes 4 k .. 4 k + 3; T[0]: the left pixel's R,G,B in bytes 1..3
-  T[0] = __builtin_amdgcn_perm(Sd[0], Sd[0], 0x01020300u);
-#pragma unroll
-  for (int m = 0; m < kChunkPx / 4; ++m) {  // four pixels = 12 bytes = three dwords at a time
-    const unsigned a = Sd[3 * m + 1], b = Sd[3 * m + 2], c = Sd[3 * m + 3];
-    const unsigned X = funnel(a, b, 3), Y = funnel(b, c, 3);
-    T[3 * m + 1] = __builtin_amdgcn_perm(b, a, 0x05000102u);
-    T[3 * m + 2] = __builtin_amdgcn_perm(Y, X, 0x04050001u);
-    T[3 * m + 3] = __builtin_amdgcn_perm(c, b, 0x05060702u);
-  }
-#pragma unroll
-  for (int k = 0; k < kChunkDw; ++k) F[k] = sub_bytes(T[k + 1], funnel(T[k], T[k + 1], 1));
-  // x = every byte xor its predecessor (the first byte has none: made to differ): a zero byte = a repeat. The repeat flags are
-  // gathered into one bit per byte (exact per-byte zero test, then the four flag bits of a dword multiplied together into a nibble).
-  unsigned long long eq = 0;
-#pragma unroll
-  for (int k = 0; k < kChunkDw; ++k) {
-    const unsigned x = F[k] ^ funnel(k ? F[k - 1] : ~F[0] << 24, F[k], 3);
-    const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);  // 0x80 in every byte of x that is zero
-    eq |= (unsigned long long)((((z >> 7) * 0x00204081u) >> 21) & 15u) << (4 * k);
-  }
-  return eq;
-}
-// byte s (not known at compile time) of the chunk's dwords: a chain of selects (registers cannot be indexed by a lane's value)
-__device__ inline unsigned chunk_byte(const unsigned (&F)[kChunkDw], int s) {
-  const int k = s >> 2;
-  unsigned d = F[0];
-#pragma unroll
-  for (int q = 1; q < kChunkDw; ++q) d = k == q ? F[q] : d;
-  return (d >> (8 * (s & 3))) & 255u;
-}
-// The tokens of a whole chunk from its repeat flags: every byte that does not repeat its predecessor is a literal, the r repeats
-// behind it one distance-1 match (r >= 3) or r literals — chunk_tokens' sequence, with one loop turn per literal-and-run instead of
-// one per byte, and no LDS read on the way.
-template <class Sink>
-__device__ inline void chunk_tokens_eq(const unsigned (&F)[kChunkDw], unsigned long long eq, Sink& sink) {
-  unsigned long long starts = ~eq & ((1ull << kChunkB) - 1ull);
-  while (starts) {
-    const int s = __ffsll((long long)starts) - 1;
-    starts &= starts - 1;
-    const int r = (starts ? __ffsll((long long)starts) - 1 : kChunkB) - s - 1;
-    const int v = (int)chunk_byte(F, s);
-    sink.lit(v);
-    if (r >= 3) sink.match(r);
-    else for (int i = 0; i < r; ++i) sink.lit(v);
-  }
-}
-#define S360_PNG_BYTE(F, j) (((F)[(j) >> 2] >> (8 * ((j)&3))) & 255u)
-
-struct HistSink {
-  unsigned* H;  // this lane's copy of the histogram
-  unsigned sum = 0, wsum = 0, j = 0, ebits = 0, nmatch = 0;
-  __device__ void byte(int v) { sum += v; wsum += j * v; ++j; }
-  __device__ void lit(int v) { atomicAdd(&H[v], 1u); }
-  __device__ void match(int L) {
-    int sym, eb, ev;
-    length_code(L, sym, eb, ev);
-    atomicAdd(&H[sym], 1u);
-    ebits += eb;
-    ++nmatch;
-  }
-};
-struct CountSink {
-  const Smem& S;
-  unsigned bits = 0;
-  __device__ void byte(int) {}
-  __device__ void lit(int v) { bits += S.code[v] >> 16; }
-  __device__ void match(int L) {
-    int sym, eb, ev;
-    length_code(L, sym, eb, ev);
-    bits += (S.code[sym] >> 16) + eb + 1;  // + the one-bit distance code
-  }
-};
 struct BitWriter {  // ORs bits into S.out from bit `pos` on (neighbouring threads share the first and the last dword)
   Smem& S;
   unsigned long long acc = 0;
@@ -273,44 +214,6 @@ struct BitWriter {  // ORs bits into S.out from bit `pos` on (neighbouring threa
   __device__ void finish() { if (nacc) atomicOr(&S.out[word], (unsigned)acc); }
   __device__ unsigned pos() const { return (unsigned)word * 32u + (unsigned)nacc; }
 };
-struct EmitSink {
-  BitWriter& W;
-  __device__ void byte(int) {}
-  __device__ void lit(int v) { const unsigned c = W.S.code[v]; W.put(c & 0xffffu, (int)(c >> 16)); }
-  __device__ void match(int L) {
-    int sym, eb, ev;
-    length_code(L, sym, eb, ev);
-    const unsigned c = W.S.code[sym];
-    W.put(c & 0xffffu, (int)(c >> 16));
-    if (eb) W.put((unsigned)ev, eb);
-    W.put(0u, 1);  // distance symbol 0 (distance 1), the only distance code: one bit
-  }
-};
-
-// exclusive prefix sum over the workgroup's threads; *total = the sum. Inside a wave by lane shuffles (ds_bpermute: lane - d), the four
-// waves' totals through LDS: two barriers (as a Hillis-Steele scan in LDS it was seventeen, sixteen times per band).
-__device__ inline unsigned block_scan(Smem& S, unsigned v, unsigned* total) {
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  unsigned incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned up = (unsigned)__builtin_amdgcn_ds_bpermute(4 * max(lane - d, 0), (int)incl);
-    if (lane >= d) incl += up;
-  }
-  if (lane == 63) S.scan[wv] = incl;
-  __syncthreads();
-  unsigned base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kT / 64; ++k) {
-    const unsigned w = S.scan[k];
-    if (k < wv) base += w;
-    tot += w;
-  }
-  *total = tot;
-  __syncthreads();
-  return base + incl - v;
-}
-
 // S.out holds `total` bits from bit 0: the whole dwords go to gout[*gw ..], the rest moves to the buffer's front. (The callers'
 // next barrier — behind the next tile's load, or the explicit one in front of the epilogue — orders the refill after the zeroing.)
 __device__ inline unsigned flush_words(Smem& S, unsigned* gout, unsigned* gw, unsigned total) {
@@ -350,51 +253,45 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
   __syncthreads();
 
   // ---- pass 1: histogram of the tokens, Adler-32 pieces of the filtered bytes ----
+  const int lane = t & 63, wv = t >> 6;
   {
-    unsigned s1 = 0, s2 = 0, eb = 0, nm = 0;
+    unsigned long long sum = 0, wsum = 0;  // this lane's bytes: their sum, and the sum of (n - index in the band) x byte
+    unsigned eb = 0, nm = 0;
+    unsigned* H = S.histp[t % kHistCopies];
     for (int r = 0; r < rows; ++r)
       for (int tl = 0; tl < tiles; ++tl) {
-        const int off = load_tile(S, bgr, G.total_bytes, G.w, y0 + r, tl * kTilePx);
+        const int px0 = tl * kTilePx, npx = min(kTilePx, G.w - px0), nbytes = 3 * npx;
+        const int off = load_tile(S, bgr, G.total_bytes, G.w, y0 + r, px0);
         __syncthreads();
-        const int cpx = tl * kTilePx + t * kChunkPx, npx = min(kChunkPx, G.w - cpx);
-        unsigned F[kChunkDw];
-        if (npx == kChunkPx && cpx > 0) {  // a whole chunk behind the row's first pixel: from registers
-          const unsigned long long eq = chunk_filtered(S.raw, off + 3 * t * kChunkPx, F);
-          unsigned* H = S.histp[t % kHistCopies];
-          unsigned sum = 0, wsum = 0;
-#pragma unroll
-          for (int k = 0; k < kChunkDw; ++k) {
-            sum = __builtin_amdgcn_sad_u8(F[k], 0u, sum);  // + the four bytes
-            wsum = __builtin_amdgcn_udot4(F[k], 0x03020100u + 0x04040404u * (unsigned)k, wsum, false);  // + sum of index x byte
+        const int ng = (nbytes + 63) >> 6, per = (ng + kWaves - 1) / kWaves;
+        const unsigned pos0 = (unsigned)r * G.line + 1u + 3u * (unsigned)px0;  // index in the band of the tile's first byte
+        for (int g = wv * per; g < min((wv + 1) * per, ng); ++g) {
+          const int j = 64 * g + lane;
+          const Tok k = group_tok(rawb, off, px0, nbytes, j);
+          if (j < nbytes) {
+            sum += k.v;
+            wsum += (unsigned long long)(n - (pos0 + (unsigned)j)) * k.v;
           }
-          if (!(eq & (eq >> 1) & (eq >> 2))) {  // no three repeats in a row: literals only
-#pragma unroll
-            for (int j = 0; j < kChunkB; ++j) atomicAdd(&H[S360_PNG_BYTE(F, j)], 1u);
-          } else {
-            HistSink hs{H};
-            chunk_tokens_eq(F, eq, hs);
-            eb += hs.ebits;
-            nm += hs.nmatch;
+          if (k.r >= 0) {
+            atomicAdd(&H[k.v], k.r < 3 ? 1u + (unsigned)k.r : 1u);
+            if (k.r >= 3) {
+              int sym, e, ev;
+              length_code(k.r, sym, e, ev);
+              atomicAdd(&H[sym], 1u);
+              eb += (unsigned)e;
+              ++nm;
+            }
           }
-          const unsigned g = (unsigned)r * G.line + 1u + 3u * (unsigned)cpx;
-          s1 = (s1 + sum) % kAdler;
-          const unsigned long long wgt = (unsigned long long)(n - g) * sum - wsum;
-          s2 = (unsigned)((s2 + wgt % kAdler) % kAdler);
-        } else if (npx > 0) {
-          HistSink hs{S.histp[t % kHistCopies]};
-          chunk_tokens(rawb, off + 3 * t * kChunkPx, cpx, npx, cpx == 0, hs);
-          // bytes [g, g + j) of the band: sum += d, weighted sum += (n - (g + i)) d_i
-          const unsigned g = (unsigned)r * G.line + (cpx ? 1u + 3u * (unsigned)cpx : 0u);
-          s1 = (s1 + hs.sum) % kAdler;
-          const unsigned long long wgt = (unsigned long long)(n - g) * hs.sum - hs.wsum;
-          s2 = (unsigned)((s2 + wgt % kAdler) % kAdler);
-          eb += hs.ebits;
-          nm += hs.nmatch;
+        }
+        if (tl == 0 && t == 0) {  // the row's filter-type byte (1 = Sub): a literal of its own in front of the row
+          atomicAdd(&H[1], 1u);
+          sum += 1;
+          wsum += n - (unsigned)r * G.line;
         }
         __syncthreads();
       }
-    atomicAdd(&S.misc[0], s1);
-    atomicAdd(&S.misc[1], s2);
+    atomicAdd(&S.misc[0], (unsigned)(sum % kAdler));
+    atomicAdd(&S.misc[1], (unsigned)(wsum % kAdler));
     atomicAdd(&S.misc[2], eb);
     atomicAdd(&S.misc[3], nm);
   }
@@ -529,46 +426,51 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
   unsigned pend = flush_words(S, gout, &gw, hdr_bits);
   for (int r = 0; r < rows; ++r)
     for (int tl = 0; tl < tiles; ++tl) {
-      const int off = load_tile(S, bgr, G.total_bytes, G.w, y0 + r, tl * kTilePx);
+      const int px0 = tl * kTilePx, npx = min(kTilePx, G.w - px0), nbytes = 3 * npx;
+      const int off = load_tile(S, bgr, G.total_bytes, G.w, y0 + r, px0);
       __syncthreads();
-      const int cpx = tl * kTilePx + t * kChunkPx, npx = min(kChunkPx, G.w - cpx);
-      unsigned bits = 0;
-      unsigned F[kChunkDw];
-      const bool whole = npx == kChunkPx && cpx > 0;
-      const unsigned long long eq = whole ? chunk_filtered(S.raw, off + 3 * t * kChunkPx, F) : 0ull;
-      const bool fast = whole && !(eq & (eq >> 1) & (eq >> 2));  // literals only
-      if (fast) {
+      const int ng = (nbytes + 63) >> 6, per = (ng + kWaves - 1) / kWaves;
+      const int g0 = wv * per, g1 = min(g0 + per, ng);
+      const bool lead = tl == 0 && wv == 0;  // this wave writes the row's filter-type byte in front of its groups
+      const unsigned leadc = S.code[1];
+      // bits of this wave's groups, then where they start: behind the waves before it
+      unsigned mine = 0;
+      for (int g = g0; g < g1; ++g) mine += tok_bits(S, group_tok(rawb, off, px0, nbytes, 64 * g + lane));
+      mine = (unsigned)__builtin_amdgcn_readlane((int)wave_scan(mine), 63) + (lead ? leadc >> 16 : 0u);
+      if (lane == 0) S.scan[wv] = mine;
+      __syncthreads();
+      unsigned at = pend, tot = 0;
 #pragma unroll
-        for (int j = 0; j < kChunkB; ++j) bits += S.code[S360_PNG_BYTE(F, j)] >> 16;
-      } else if (whole) {
-        CountSink cs{S};
-        chunk_tokens_eq(F, eq, cs);
-        bits = cs.bits;
-      } else if (npx > 0) {
-        CountSink cs{S};
-        chunk_tokens(rawb, off + 3 * t * kChunkPx, cpx, npx, cpx == 0, cs);
-        bits = cs.bits;
+      for (int k = 0; k < kWaves; ++k) {
+        const unsigned w = S.scan[k];
+        if (k < wv) at += w;
+        tot += w;
       }
-      unsigned tot;
-      const unsigned excl = block_scan(S, bits, &tot);
-      if (fast) {
-        BitWriter W(S, pend + excl);
-#pragma unroll
-        for (int j = 0; j < kChunkB; ++j) {
-          const unsigned c = S.code[S360_PNG_BYTE(F, j)];
-          W.put(c & 0xffffu, (int)(c >> 16));
+      if (lead) {
+        if (lane == 0) or_bits(S, at, leadc & 0xffffu);
+        at += leadc >> 16;
+      }
+      for (int g = g0; g < g1; ++g) {
+        const Tok k = group_tok(rawb, off, px0, nbytes, 64 * g + lane);
+        const unsigned bits = tok_bits(S, k);
+        const unsigned incl = wave_scan(bits);
+        if (k.r >= 0) {  // this lane's tokens as one value: the literal, then the match or the literal again
+          const unsigned cl = S.code[k.v], len = cl >> 16;
+          unsigned long long val = cl & 0xffffu;
+          unsigned n2 = len;
+          if (k.r < 3) {
+            for (int q = 0; q < k.r; ++q) { val |= (unsigned long long)(cl & 0xffffu) << n2; n2 += len; }
+          } else {
+            int sym, e, ev;
+            length_code(k.r, sym, e, ev);
+            const unsigned cm = S.code[sym];
+            val |= (unsigned long long)(cm & 0xffffu) << n2;
+            n2 += cm >> 16;
+            val |= (unsigned long long)(unsigned)ev << n2;  // the length's extra bits; the distance symbol behind them is a 0 bit
+          }
+          or_bits(S, at + incl - bits, val);
         }
-        W.finish();
-      } else if (whole) {
-        BitWriter W(S, pend + excl);
-        EmitSink es{W};
-        chunk_tokens_eq(F, eq, es);
-        W.finish();
-      } else if (npx > 0) {
-        BitWriter W(S, pend + excl);
-        EmitSink es{W};
-        chunk_tokens(rawb, off + 3 * t * kChunkPx, cpx, npx, cpx == 0, es);
-        W.finish();
+        at += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
       }
       __syncthreads();
       pend = flush_words(S, gout, &gw, pend + tot);

@@ -250,6 +250,7 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
   else if (ctrl >= 0x101 && ctrl <= 0x10F) from = inrow + (ctrl & 15) <= 15 ? lane + (ctrl & 15) : -1;
   else if (ctrl >= 0x111 && ctrl <= 0x11F) from = inrow >= (ctrl & 15) ? lane - (ctrl & 15) : -1;
   else if (ctrl == 0x142) from = row > 0 ? row * 16 - 1 : -1;
+  else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;  // row_bcast:31
   else if (ctrl >= 0x150 && ctrl <= 0x15F) from = (lane & ~15) | (ctrl & 15);
   else { std::fprintf(stderr, "emu: DPP control 0x%x is not implemented\n", ctrl); std::abort(); }
   unsigned long long v;
