@@ -477,7 +477,7 @@ FLOW_STENCIL_B_PER_PXLEVEL = {"flow_gradients": 24, "flow_blur15": 16, "flow_med
                               "flow_upscale": 16}
 
 
-def streams_batched(R, rig, flags, device, frames, args, dry, g, slots=None, timed_steps=None, check=True):
+def streams_batched(R, rig, flags, device, frames, args, dry, g, slots=None, timed_steps=None, check=True, contexts=2, pipelined=False):
     """bench.py's `video_streams_batched` leg: 2 contexts x S frame slots, one stream per slot (stream s = the synthetic video
     entered at another frame, walked forwards and backwards over the distinct frames held), every step a render_batch(use_prev)
     per context on device-resident temporal state, the step's inputs sent in place from page-locked host memory on the upload
@@ -485,7 +485,7 @@ def streams_batched(R, rig, flags, device, frames, args, dry, g, slots=None, tim
     byte-compared with the same stream rendered frame by frame in a context of its own (latency sweep kernel, s360_frame_render)."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    F = 2
+    F = contexts
     run_in, timed = 4, max(2, timed_steps or args.stream_steps)
     n_steps = run_in + timed
     free_b, total_b = (0, 0) if dry else torch.cuda.mem_get_info(device)
@@ -518,6 +518,8 @@ def streams_batched(R, rig, flags, device, frames, args, dry, g, slots=None, tim
             for c in ctxs:
                 c.set_frame_slots(S)
                 c.set_sweep_mode("throughput")
+                if pipelined:  # step k's pole stage on the second stream beside step k+1's side stage
+                    c.set_frame_pipelining(True)
 
             def step(ci, k):
                 c = ctxs[ci]
@@ -644,6 +646,8 @@ def main():
                          "every slot's temporal double buffers resident")
     ap.add_argument("--streams-only", action="store_true",
                     help="only the video_streams_batched leg (slots-against-frames/s probes: --stream-slots N); prints that leg's record")
+    ap.add_argument("--stream-contexts", type=int, default=2, help="--streams-only: contexts of the leg")
+    ap.add_argument("--stream-pipelined", action="store_true", help="--streams-only: the contexts' steps frame-pipelined (s360_set_frame_pipelining)")
     ap.add_argument("--stream-steps", type=int, default=8, help="video_streams_batched leg: timed steps (after 4 run-in steps)")
     ap.add_argument("--pipeline-batches", action="store_true",
                     help="the timed region's batches with frame pipelining (s360_set_frame_pipelining on a context of frame slots): "
@@ -879,7 +883,8 @@ def main():
     if args.streams_only:
         del rr, wtex
         torch.cuda.empty_cache()
-        print(json.dumps({"video_streams_batched": streams_batched(R, rig, flags, local_rank, frames, args, dry, None)}))
+        print(json.dumps({"video_streams_batched": streams_batched(R, rig, flags, local_rank, frames, args, dry, None,
+                                                                   contexts=max(1, args.stream_contexts), pipelined=args.stream_pipelined)}))
         return
 
     def stream_frame(k):  # frame k of the stream: 0,1,..,n-1,n-2,..,1,0,1,.. over the distinct frames held
@@ -1631,6 +1636,12 @@ def main():
                         r = streams_batched(R, rig, flags, local_rank, frames, args, dry, g, slots=S2, timed_steps=4, check=False)
                         table.append({"workload": "temporally chained streams", "slots_per_context": r["slots_per_context"], "contexts": 2,
                                       "frames_per_s": r["frames_per_s"], "hbm_used_GB": r["hbm_used_GB"]})
+                if True:  # ONE context whose steps are frame-pipelined: the chained workload for hosts with ~190 GB
+                    S1 = 2 if dry else 22
+                    r = streams_batched(R, rig, flags, local_rank, frames, args, dry, g, slots=S1, timed_steps=4, check=False, contexts=1, pipelined=True)
+                    table.append({"workload": "temporally chained streams, steps pipelined inside the context (s360_set_frame_pipelining)",
+                                  "slots_per_context": r["slots_per_context"], "contexts": 1, "frames_per_s": r["frames_per_s"],
+                                  "hbm_used_GB": r["hbm_used_GB"]})
                 out["slots_table"] = table
             except Exception as e:  # noqa: BLE001
                 import traceback
