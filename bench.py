@@ -1636,10 +1636,10 @@ def main():
                         r = streams_batched(R, rig, flags, local_rank, frames, args, dry, g, slots=S2, timed_steps=4, check=False)
                         table.append({"workload": "temporally chained streams", "slots_per_context": r["slots_per_context"], "contexts": 2,
                                       "frames_per_s": r["frames_per_s"], "hbm_used_GB": r["hbm_used_GB"]})
-                if True:  # ONE context whose steps are frame-pipelined: the chained workload for hosts with ~190 GB
-                    S1 = 2 if dry else 22
-                    r = streams_batched(R, rig, flags, local_rank, frames, args, dry, g, slots=S1, timed_steps=4, check=False, contexts=1, pipelined=True)
-                    table.append({"workload": "temporally chained streams, steps pipelined inside the context (s360_set_frame_pipelining)",
+                for pl in (False, True):  # ONE context, plain and with its steps frame-pipelined
+                    r = streams_batched(R, rig, flags, local_rank, frames, args, dry, g, slots=2 if dry else 22, timed_steps=4, check=False,
+                                        contexts=1, pipelined=pl)
+                    table.append({"workload": "temporally chained streams" + (", steps pipelined inside the context (s360_set_frame_pipelining)" if pl else ""),
                                   "slots_per_context": r["slots_per_context"], "contexts": 1, "frames_per_s": r["frames_per_s"],
                                   "hbm_used_GB": r["hbm_used_GB"]})
                 out["slots_table"] = table
