@@ -19,9 +19,10 @@
 //   build   length-limited canonical Huffman code of the literal/length alphabet: rank sort by all threads, the
 //           two-queue merge and the 15-bit limit by one thread, canonical codes by all threads; the exact coded size is
 //           then known, and a band that would not shrink goes out as stored blocks instead
-//   pass 2  the same tiles again: every wave sums the bits of its groups, the waves' totals give each wave its start, then
-//           per group a wave scan gives every token-starting lane its bit offset and the lane ORs its tokens (one value of up
-//           to 46 bits) into an LDS bit buffer; whole dwords go to HBM coalesced
+//   pass 2  the same tiles again, ONE token pass: every wave writes its groups' tokens from bit 0 of a bit-buffer region of its own
+//           in LDS (a DPP scan gives every token-starting lane its offset, the lane ORs its tokens — one value of up to 46 bits),
+//           then the workgroup concatenates the regions behind the bits carried over from the tile before: every thread assembles
+//           whole output dwords from the dwords of the regions that overlap them, and they go to HBM coalesced
 // then a layout kernel (prefix sum of the bands' sizes = where each IDAT chunk starts in the file) and a gather kernel that
 // moves every band to its place with the chunk's length and type in front. The host adds what needs no pixel: signature,
 // IHDR, CRC-32 of every chunk (threads), the combined Adler-32, IEND.
@@ -30,11 +31,12 @@
 // bench (tools/png_time.py, round 6): a THREAD per 16 pixels walking its 48 bytes (byte loops, sinks per token) 1.95 ms — phase
 // cuts: pass 1 0.55, code build 0.18, pass 2 1.32; privatised histograms, a two-barrier scan, tile loads in flight together: nothing
 // measurable; bytes made four at a time with funnel shifts + v_perm_b32 and a token loop over repeat flags: 2.1–2.3 ms (the chains
-// per token stayed); 512 threads x 8 pixels, twice the waves per CU: 1.49 ms; this form — a lane per byte, DPP scan — 1.44 ms and
-// files 1 % smaller (runs up to 63). The SQ counters of this form: 741 M VALU + 301 M SALU + 56 M LDS wave-instructions per frame,
-// i.e. 3.7 VALU instructions per byte over the three passes; at the chip's integer issue rate (0.25 per cycle and SIMD,
-// tools/issue_rate) 741 M take 1.2 ms: the kernel sits at its instruction-issue roof. Less time now means fewer instructions per
-// byte (the filtered bytes made once per tile four at a time, the count pass folded into the emit pass), not more parallelism.
+// per token stayed); 512 threads x 8 pixels, twice the waves per CU: 1.49 ms; a lane per byte with a pass that only counted bits in
+// front of the emitting pass: 1.44 ms at 741 M VALU wave-instructions per frame and 0.89 VALU busy; this form — per-wave regions
+// and a concatenation instead of the counting pass — 1.41 ms at 577 M VALU instructions (2.9 per byte), VALU busy 0.71, waves
+// waiting 0.49 of their time (profiles/r06_v9_png_pmc.txt); phase cuts: pass 1 0.43 ms, code build 0.14, pass 2 0.82. The
+// instruction count fell by 22 % and the time did not: what is left is the workgroup's own critical path — four barriers per tile in
+// pass 2, the one-thread code build, waves of unequal token counts meeting at every barrier — not issue slots and not bytes.
 #include "png.hpp"
 
 #include <algorithm>
@@ -53,10 +55,12 @@ constexpr int kT = 512;                         // threads per workgroup
 constexpr int kTilePx = 4096;                   // pixels of one row per workgroup iteration
 constexpr int kRawWords = kTilePx * 3 / 4 + 4;  // a tile's bytes + the pixel to its left + alignment slack
 constexpr int kMaxBits = 15;                    // deflate's longest code
-constexpr int kOutWords = ((kTilePx * 3 + 1) * kMaxBits + 31) / 32 + 8;  // a tile's bytes (+ the row's filter-type byte) at the longest code
+constexpr int kWaves = kT / 64;
+constexpr int kGroupsPerWave = (kTilePx * 3 / 64 + kWaves - 1) / kWaves;  // 64-byte groups of a tile a wave takes
+constexpr int kRegionWords = kGroupsPerWave * 64 * kMaxBits / 32 + 4;     // a wave's bits of one tile at the longest code (+ the row's filter-type byte, + slack)
+constexpr int kOutWords = kWaves * kRegionWords;
 constexpr int kSyms = 288;                      // literal/length alphabet, padded (286 symbols exist)
 constexpr int kNumLit = 286;
-constexpr int kWaves = kT / 64;
 constexpr int kHistCopies = 8;
 constexpr unsigned kAdler = 65521u;
 constexpr unsigned kStoredMax = 65535u;
@@ -214,15 +218,41 @@ struct BitWriter {  // ORs bits into S.out from bit `pos` on (neighbouring threa
   __device__ void finish() { if (nacc) atomicOr(&S.out[word], (unsigned)acc); }
   __device__ unsigned pos() const { return (unsigned)word * 32u + (unsigned)nacc; }
 };
-// S.out holds `total` bits from bit 0: the whole dwords go to gout[*gw ..], the rest moves to the buffer's front. (The callers'
-// next barrier — behind the next tile's load, or the explicit one in front of the epilogue — orders the refill after the zeroing.)
-__device__ inline unsigned flush_words(Smem& S, unsigned* gout, unsigned* gw, unsigned total) {
-  const int full = (int)(total >> 5);
-  for (int i = threadIdx.x; i < full; i += kT) gout[*gw + i] = S.out[i];
-  const unsigned carry = S.out[full];
+// The bit buffer is one region per wave (S.out[w * kRegionWords ..], S.scan[w] bits in it): a wave writes its tokens from bit 0 of its
+// region without knowing where the waves before it end — no pass that only counts. Here the regions are concatenated behind the
+// `pend` (< 32) bits carried over in `carry`: every thread assembles whole output dwords from the (at most two) dwords of each region
+// that overlaps them, they go to gout[*gw ..], the last partial dword becomes the new carry, the regions are cleared.
+__device__ inline unsigned take_bits(const unsigned* R, unsigned q, unsigned n) {  // n (1..32) bits of R from bit q
+  const unsigned w = q >> 5, sh = q & 31u;
+  const unsigned v = (unsigned)(((((unsigned long long)R[w + 1]) << 32) | R[w]) >> sh);
+  return n < 32u ? v & ((1u << n) - 1u) : v;
+}
+__device__ inline unsigned compact_flush(Smem& S, unsigned* gout, unsigned* gw, unsigned pend, unsigned* carry) {
+  unsigned start[kWaves + 1];
+  start[0] = pend;
+#pragma unroll
+  for (int k = 0; k < kWaves; ++k) start[k + 1] = start[k] + S.scan[k];
+  const unsigned total = start[kWaves], full = total >> 5;
+  for (unsigned i = threadIdx.x; i <= full; i += kT) {
+    const unsigned lo = 32u * i, hi = lo + 32u;
+    unsigned d = i == 0 ? *carry : 0u;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) {
+      const unsigned a = max(lo, start[k]), b = min(hi, start[k + 1]);
+      if (a < b) d |= take_bits(S.out + k * kRegionWords, a - start[k], b - a) << (a - lo);
+    }
+    if (i < full) gout[*gw + i] = d;
+    else S.misc[7] = d;  // the bits behind the last whole dword
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i <= full; i += kT) S.out[i] = i == 0 ? carry : 0u;
-  *gw += (unsigned)full;
+  *carry = S.misc[7];
+  {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int used = (int)(S.scan[wv] >> 5) + 3;
+    for (int i = lane; i < used; i += 64) S.out[wv * kRegionWords + i] = 0u;
+  }
+  *gw += full;
+  __syncthreads();
   return total & 31u;
 }
 
@@ -422,8 +452,10 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
     }
   }
   __syncthreads();
-  unsigned gw = 0;
-  unsigned pend = flush_words(S, gout, &gw, hdr_bits);
+  unsigned gw = 0, carry = 0;
+  if (t < kWaves) S.scan[t] = t == 0 ? hdr_bits : 0u;  // (the header sits in region 0)
+  __syncthreads();
+  unsigned pend = compact_flush(S, gout, &gw, 0u, &carry);
   for (int r = 0; r < rows; ++r)
     for (int tl = 0; tl < tiles; ++tl) {
       const int px0 = tl * kTilePx, npx = min(kTilePx, G.w - px0), nbytes = 3 * npx;
@@ -432,23 +464,12 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
       const int ng = (nbytes + 63) >> 6, per = (ng + kWaves - 1) / kWaves;
       const int g0 = wv * per, g1 = min(g0 + per, ng);
       const bool lead = tl == 0 && wv == 0;  // this wave writes the row's filter-type byte in front of its groups
-      const unsigned leadc = S.code[1];
-      // bits of this wave's groups, then where they start: behind the waves before it
-      unsigned mine = 0;
-      for (int g = g0; g < g1; ++g) mine += tok_bits(S, group_tok(rawb, off, px0, nbytes, 64 * g + lane));
-      mine = (unsigned)__builtin_amdgcn_readlane((int)wave_scan(mine), 63) + (lead ? leadc >> 16 : 0u);
-      if (lane == 0) S.scan[wv] = mine;
-      __syncthreads();
-      unsigned at = pend, tot = 0;
-#pragma unroll
-      for (int k = 0; k < kWaves; ++k) {
-        const unsigned w = S.scan[k];
-        if (k < wv) at += w;
-        tot += w;
-      }
+      const unsigned base = (unsigned)wv * kRegionWords * 32u;  // the wave's region, in bits of S.out
+      unsigned at = 0;
       if (lead) {
-        if (lane == 0) or_bits(S, at, leadc & 0xffffu);
-        at += leadc >> 16;
+        const unsigned leadc = S.code[1];
+        if (lane == 0) or_bits(S, base, leadc & 0xffffu);
+        at = leadc >> 16;
       }
       for (int g = g0; g < g1; ++g) {
         const Tok k = group_tok(rawb, off, px0, nbytes, 64 * g + lane);
@@ -468,31 +489,33 @@ __global__ __launch_bounds__(kT) void k_png_band(const uint8_t* __restrict__ bgr
             n2 += cm >> 16;
             val |= (unsigned long long)(unsigned)ev << n2;  // the length's extra bits; the distance symbol behind them is a 0 bit
           }
-          or_bits(S, at + incl - bits, val);
+          or_bits(S, base + at + incl - bits, val);
         }
         at += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
       }
+      if (lane == 0) S.scan[wv] = at;
       __syncthreads();
-      pend = flush_words(S, gout, &gw, pend + tot);
+      pend = compact_flush(S, gout, &gw, pend, &carry);
     }
   // end of block; every band but the last is closed like zlib's sync flush: an empty stored block, which byte-aligns
-  __syncthreads();  // (the last flush has finished clearing the bit buffer)
   if (t == 0) {
-    BitWriter W(S, pend);
+    BitWriter W(S, 0);  // (region 0 from its first bit: compact_flush puts it behind the `pend` bits carried over)
     W.put(S.code[256] & 0xffffu, (int)(S.code[256] >> 16));
     if (!last) {
       W.put(0u, 3);
-      const unsigned p = W.pos();
+      const unsigned p = pend + W.pos();  // position in the band's stream, modulo 32
       if (p & 7u) W.put(0u, (int)(8u - (p & 7u)));
       W.put(0x0000u, 16);
       W.put(0xffffu, 16);
     }
     W.finish();
-    S.misc[7] = W.pos();
+    S.scan[0] = W.pos();
+  } else if (t < kWaves) {
+    S.scan[t] = 0u;
   }
   __syncthreads();
-  const unsigned endbits = S.misc[7];
-  for (int i = t; i < (int)((endbits + 31) >> 5); i += kT) gout[gw + i] = S.out[i];  // (the band's reserve covers the last dword)
+  pend = compact_flush(S, gout, &gw, pend, &carry);
+  if (t == 0 && pend) gout[gw] = carry;  // (the last band's final bits; the band's reserve covers the dword)
 }
 
 // where every band's IDAT chunk starts in the file: prefix sum of 12 + bytes behind the preamble (one workgroup)
