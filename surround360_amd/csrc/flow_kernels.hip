@@ -321,15 +321,33 @@ __global__ __launch_bounds__(NT) void k_sepblur(const float* __restrict__ src, f
           v[0][j] = s_mid[ly0 + j][lx][0];
         }
       }
+      if (CN == 2) {
+        // both channels of a pixel as one two-float vector: v_pk_add_f32 / v_pk_mul_f32, each half rounded like the scalar
+        // operation (no fused multiply-add). The compiler found this form by itself only where both channels meet the same
+        // epilogue; EPI 2 (channel 0 selected against the NaN mark) ran the column pass as 186 scalar operations.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 p[4 + 2 * R];
 #pragma unroll
-      for (int k = 0; k < CN; ++k)
+        for (int j = 0; j < 4 + 2 * R; ++j) p[j] = f32x2{v[0][j], v[CN - 1][j]};
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          float acc = taps.k[0] * v[k][o + R] + 0.0f;  // SymmColumnFilter: centre + delta (= +0), then symmetric pairs
+          f32x2 acc = taps.k[0] * p[o + R] + 0.0f;  // SymmColumnFilter: centre + delta (= +0), then symmetric pairs
 #pragma unroll
-          for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[k][o + R + j] + v[k][o + R - j]);
-          outv[o][k] = acc;
+          for (int j = 1; j <= R; ++j) acc += taps.k[j] * (p[o + R + j] + p[o + R - j]);
+          outv[o][0] = acc.x;
+          outv[o][CN - 1] = acc.y;
         }
+      } else {
+#pragma unroll
+        for (int k = 0; k < CN; ++k)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            float acc = taps.k[0] * v[k][o + R] + 0.0f;  // SymmColumnFilter: centre + delta (= +0), then symmetric pairs
+#pragma unroll
+            for (int j = 1; j <= R; ++j) acc += taps.k[j] * (v[k][o + R + j] + v[k][o + R - j]);
+            outv[o][k] = acc;
+          }
+      }
     }
     if (gx >= w) continue;
 #pragma unroll

@@ -18,7 +18,7 @@ k zeros followed by ones, so the checks are exhaustive and tiny). The compositio
 random float data against numpy's median, and the script writes straight-line fminf/fmaxf code (SSA form; values
 that are never read are not emitted).
 
-Usage: python tools/gen_median_network.py [T]   (T = outputs per thread, default 8)
+Usage: python tools/gen_median_network.py [T ...]   (T = outputs per thread; default 8, what the kernel uses)
 """
 import itertools
 import os
@@ -101,6 +101,109 @@ def quad_network():
     return prune(base, pats, lambda p, o: o[7:13] == sorted(p[:10] + p[16:26])[7:13]), 32, (list(range(10)), list(range(16, 26)))
 
 
+# ------------------------------------------------------------------------------------------
+# Three-input instructions. gfx950 has v_min3_f32 / v_max3_f32 / v_med3_f32 at the rate of v_min_f32: a stage written with
+# them takes fewer instructions than its compare-exchange network. The compiler finds min(min(a, b), c) by itself but cannot
+# find a median of three, which needs an order fact (a <= b  =>  min(max(a, c), b) = med3(a, c, b)) that only the stage's
+# precondition gives. A stage is therefore kept as a straight-line program over {min, max, min3, max3, med3} and rewritten
+# here: every operation is compared with every single instruction over the values computed before it, on ALL 0/1 inputs that
+# satisfy the stage's precondition (all five functions are monotone, they commute with thresholding, so equality on those
+# inputs is equality on all inputs: the zero-one principle, as for the networks themselves); a replacement is taken when it
+# leaves operations dead.
+def tt_eval(op, a):
+    if op == "fminf":
+        return a[0] & a[1]
+    if op == "fmaxf":
+        return a[0] | a[1]
+    if op == "min3":
+        return a[0] & a[1] & a[2]
+    if op == "max3":
+        return a[0] | a[1] | a[2]
+    return (a[0] & a[1]) | (a[2] & (a[0] | a[1]))  # med3
+
+
+def prog_tables(inputs, ops, patterns):
+    """name -> bitmask over the patterns (bit p = the value under pattern p); patterns: list of {input name: 0/1}"""
+    tt = {n: sum(pat[n] << k for k, pat in enumerate(patterns)) for n in inputs}
+    for (d, op, *a) in ops:
+        tt[d] = tt_eval(op, [tt[x] for x in a])
+    return tt
+
+
+def prog_dce(ops, outputs):
+    need, keep = set(outputs), []
+    for (d, op, *a) in reversed(ops):
+        if d in need:
+            keep.append((d, op, *a))
+            need.update(a)
+    return list(reversed(keep))
+
+
+def prog_optimise(inputs, ops, outputs, patterns):
+    ops = prog_dce(ops, outputs)
+    improved = True
+    while improved:
+        improved = False
+        tt = prog_tables(inputs, ops, patterns)
+        for k in range(len(ops) - 1, -1, -1):
+            d = ops[k][0]
+            T = tt[d]
+            avail = list(inputs) + [o[0] for o in ops[:k]]
+            cands = []
+            sup = [x for x in avail if tt[x] & T == T]      # x >= d everywhere
+            sub = [x for x in avail if tt[x] | T == T]      # x <= d everywhere
+            for grp, op2, op3 in ((sup, "fminf", "min3"), (sub, "fmaxf", "max3")):
+                for x, y in itertools.combinations(grp, 2):
+                    if tt_eval(op2, [tt[x], tt[y]]) == T:
+                        cands.append((d, op2, x, y))
+                for x, y in itertools.combinations(grp, 2):
+                    pxy = tt_eval(op2, [tt[x], tt[y]])
+                    for z in grp:
+                        if z != x and z != y and tt_eval(op2, [pxy, tt[z]]) == T:
+                            cands.append((d, op3, x, y, z))
+            for x, y in itertools.combinations(avail, 2):
+                both, any_ = tt[x] & tt[y], tt[x] | tt[y]
+                if both & T != both or any_ | T != any_:
+                    continue
+                D = tt[x] ^ tt[y]
+                for z in avail:
+                    if z != x and z != y and (tt[z] & D) == (T & D):
+                        cands.append((d, "med3", x, y, z))
+            best = None
+            for c in cands:
+                trial = prog_dce(ops[:k] + [c] + ops[k + 1:], outputs)
+                if len(trial) < len(ops) and (best is None or len(trial) < len(best)):
+                    best = trial
+            if best is not None:
+                ops = best
+                improved = True
+                break
+    return ops
+
+
+def stage_program(net, nwires, in_wires, out_wires, patterns01, contract):
+    """The compare-exchange network `net` as a program over symbolic inputs i0.. on `in_wires` (the other wires hold +inf),
+    rewritten with three-input instructions, and checked against `contract` on every pattern (patterns01: lists of 0/1 per
+    input, in in_wires order)."""
+    E = Emitter()
+    names = ["i%d" % k for k in range(len(in_wires))]
+    w = E.apply(net, nwires, dict(zip(in_wires, names)))
+    outs = [w[k] for k in out_wires]
+    assert INF not in outs
+    pats = [dict(zip(names, p)) for p in patterns01]
+    return finish_stage(names, E.ops, outs, pats, contract)
+
+
+def finish_stage(names, ops, outs, pats, contract):
+    n0 = len(prog_dce(ops, outs))
+    ops = prog_optimise(names, ops, outs, pats)
+    tt = prog_tables(names, ops, pats)
+    for k, pat in enumerate(pats):
+        got = [(tt[o] >> k) & 1 for o in outs]
+        assert got == contract([pat[n] for n in names]), (pat, got)
+    return dict(inputs=names, ops=ops, outs=outs, before=n0)
+
+
 class Emitter:
     """SSA code generation with symbolic +inf padding and dead-code elimination."""
 
@@ -130,6 +233,14 @@ class Emitter:
             w[i], w[j] = lo, hi
         return w
 
+    def inst(self, stage, actual):
+        """One more copy of a stage program on the values `actual`; returns the names of its outputs."""
+        ren = dict(zip(stage["inputs"], actual))
+        for (d, op, *a) in stage["ops"]:
+            ren[d] = self.new()
+            self.ops.append((ren[d], op, *[ren[x] for x in a]))
+        return [ren[o] for o in stage["outs"]]
+
     def binop(self, op, a, b):
         d = self.new()
         self.ops.append((d, op, a, b))
@@ -146,10 +257,46 @@ class Emitter:
         return list(reversed(keep))
 
 
-def build(T):
+def sort5_by_hand():
+    """sort3 (min3 / med3 / max3) + sort2, then the merge of a sorted 3 and a sorted 2 written as rank formulas
+    (k-th smallest of A u D = min over i + j = k of max(A[i-1], D[j-1])): 14 instructions for what is 9 compare-exchanges."""
+    n = ["i%d" % k for k in range(5)]
+    ops = [("A0", "min3", *n[:3]), ("A1", "med3", *n[:3]), ("A2", "max3", *n[:3]), ("D0", "fminf", n[3], n[4]), ("D1", "fmaxf", n[3], n[4]),
+           ("o0", "fminf", "A0", "D0"), ("x1", "fmaxf", "A0", "D0"), ("o1", "min3", "x1", "A1", "D1"),
+           ("x2", "fmaxf", "A1", "D0"), ("y2", "fmaxf", "A0", "D1"), ("o2", "min3", "A2", "x2", "y2"),
+           ("x3", "fminf", "A2", "D1"), ("o3", "max3", "x3", "A1", "D0"), ("o4", "fmaxf", "A2", "D1")]
+    pats = [dict(zip(n, b)) for b in itertools.product([0, 1], repeat=5)]
+    return finish_stage(n, ops, ["o0", "o1", "o2", "o3", "o4"], pats, lambda p: sorted(p))
+
+
+def build_stages():
     s5 = sort5_network()
     m55, m55_n, (m55_a, m55_b) = merge55_network()
     qn, qn_n, (q_a, q_b) = quad_network()
+    st = {}
+    net5 = stage_program(s5, 5, list(range(5)), list(range(5)), [list(b) for b in itertools.product([0, 1], repeat=5)], lambda p: sorted(p))
+    hand5 = sort5_by_hand()
+    st["sort5"] = hand5 if len(hand5["ops"]) <= len(net5["ops"]) else net5
+    st["merge55"] = stage_program(m55, m55_n, m55_a + m55_b, list(range(10)),
+                                  [a + b for a in sorted_patterns(5) for b in sorted_patterns(5)], lambda p: sorted(p))
+    st["quad"] = stage_program(qn, qn_n, q_a + q_b, list(range(7, 13)),
+                               [a + b for a in sorted_patterns(10) for b in sorted_patterns(10)], lambda p: sorted(p)[7:13])
+    # stage 4: rank-5 element of X (6 sorted) u Y (5 sorted) = min over i = 1..6 of max(X[i-1], Y[5-i]); the i = 6 term is X[5]
+    names = ["i%d" % k for k in range(11)]
+    X, Y = names[:6], names[6:]
+    ops, acc = [], X[5]
+    for i in range(1, 6):
+        ops.append(("m%d" % i, "fmaxf", X[i - 1], Y[5 - i]))
+        ops.append(("a%d" % i, "fminf", acc, "m%d" % i))
+        acc = "a%d" % i
+    pats = [dict(zip(names, a + b)) for a in sorted_patterns(6) for b in sorted_patterns(5)]
+    st["final"] = finish_stage(names, ops, [acc], pats, lambda p: [sorted(p)[5]])
+    sizes = dict(sort5=len(s5), merge55=len(m55), quad=len(qn))
+    return st, sizes
+
+
+def build(T):
+    st, sizes = build_stages()
     ncols = T + 4
     assert T % 2 == 0
     E = Emitter()
@@ -161,33 +308,16 @@ def build(T):
             X, Y = quads[o // 2], cols[o + 4]
         else:
             X, Y = quads[(o + 1) // 2], cols[o]
-        # rank-5 element of X (6 sorted) U Y (5 sorted): min over i = 1..6 of max(X[i-1], Y[5-i]); the i = 6 term is X[5]
-        acc = X[5]
-        for i in range(1, 6):
-            acc = E.binop("fminf", acc, E.binop("fmaxf", X[i - 1], Y[5 - i]))
-        outs[o] = acc
+        outs[o] = E.inst(st["final"], X + Y)[0]
 
     # streaming order, left to right: values die as early as possible (the register footprint of the generated code
     # follows the order of this list closely)
     for k in range(ncols // 2):
         for c in (2 * k, 2 * k + 1):
-            w = E.apply(s5, 5, {r: "in[%d]" % (c * 5 + r) for r in range(5)})
-            cols[c] = w[:5]
-        place = {}
-        for r in range(5):
-            place[m55_a[r]] = cols[2 * k][r]
-            place[m55_b[r]] = cols[2 * k + 1][r]
-        w = E.apply(m55, m55_n, place)
-        assert INF not in w[:10]
-        pairs[k] = w[:10]
+            cols[c] = E.inst(st["sort5"], ["in[%d]" % (c * 5 + r) for r in range(5)])
+        pairs[k] = E.inst(st["merge55"], cols[2 * k] + cols[2 * k + 1])
         if k >= 1:
-            place = {}
-            for r in range(10):
-                place[q_a[r]] = pairs[k - 1][r]
-                place[q_b[r]] = pairs[k][r]
-            w = E.apply(qn, qn_n, place)
-            assert INF not in w[7:13]
-            quads[k - 1] = w[7:13]
+            quads[k - 1] = E.inst(st["quad"], pairs[k - 1] + pairs[k])
         # outputs whose quad and single column now exist
         for o in range(T):
             if outs[o] is not None:
@@ -197,20 +327,24 @@ def build(T):
             if q in quads and col in cols:
                 final(o)
     assert all(o is not None for o in outs)
-    ops = E.live_ops(outs)
-    return ops, outs, dict(sort5=len(s5), merge55=len(m55), quad=len(qn))
+    ops = prog_dce(E.ops, outs)
+    sizes["instructions"] = {k: (v["before"], len(v["ops"])) for k, v in st.items()}
+    return ops, outs, sizes
 
 
 def evaluate(ops, outs, vals):
     env = {"in[%d]" % i: v for i, v in enumerate(vals)}
-    for (d, op, a, b) in ops:
-        env[d] = min(env[a], env[b]) if op == "fminf" else max(env[a], env[b])
+    for (d, op, *a) in ops:
+        x = [env[n] for n in a]
+        env[d] = min(x) if op in ("fminf", "min3") else max(x) if op in ("fmaxf", "max3") else sorted(x)[1]
     return [env[o] for o in outs]
 
 
-def main():
-    T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    ops, outs, sizes = build(T)
+C_FORM = {"fminf": "fminf(%s, %s)", "fmaxf": "fmaxf(%s, %s)", "min3": "fminf(fminf(%s, %s), %s)", "max3": "fmaxf(fmaxf(%s, %s), %s)",
+          "med3": "__builtin_amdgcn_fmed3f(%s, %s, %s)"}
+
+
+def check(T, ops, outs):
     # end-to-end check on random data with many ties (small integer values) and on float noise
     rng = np.random.default_rng(5)
     for trial in range(400):
@@ -223,23 +357,35 @@ def main():
         for o in range(T):
             want = np.median(grid[o:o + 5].ravel())
             assert got[o] == want, (trial, o, got[o], want)
-    n_ops = len(ops)
+
+
+def main():
+    Ts = [int(a) for a in sys.argv[1:]] or [8]
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(here, "..", "surround360_amd", "csrc", "median_tile.inc")
     with open(out, "w") as f:
-        f.write("// GENERATED by tools/gen_median_network.py %d — do not edit. Exact 5x5 medians of %d horizontally adjacent pixels\n" % (T, T))
-        f.write("// from %d shared columns: in[c * 5 + r] = value at column c (first window's leftmost column = 0), row r of the\n" % (T + 4))
-        f.write("// 5 window rows. Stage networks (compare-exchanges): sort5 %d, merge(5,5) %d, rank 7..12 of (10,10) %d; %d min/max\n"
-                % (sizes["sort5"], sizes["merge55"], sizes["quad"], n_ops))
-        f.write("// operations in total = %.1f per median (the 99-comparator network on unsorted inputs: 198; 112 with 3-input ops).\n" % (n_ops / T))
-        f.write("// Every stage is verified exhaustively on the 0/1 inputs of its precondition, the composition against numpy.\n")
-        f.write("__device__ __forceinline__ void median5x5_row%d(const float* __restrict__ in, float* __restrict__ out) {\n" % T)
-        for (d, op, a, b) in ops:
-            f.write("  const float %s = %s(%s, %s);\n" % (d, op, a, b))
-        for o, name in enumerate(outs):
-            f.write("  out[%d] = %s;\n" % (o, name))
-        f.write("}\n")
-    print("T=%d: stage CEs %s, %d min/max ops = %.1f per median -> %s" % (T, sizes, n_ops, n_ops / T, os.path.normpath(out)))
+        f.write("// GENERATED by tools/gen_median_network.py %s — do not edit. Exact 5x5 medians of T horizontally adjacent\n" % " ".join(map(str, Ts)))
+        f.write("// pixels from T + 4 shared columns: in[c * 5 + r] = value at column c (first window's leftmost column = 0), row r of\n")
+        f.write("// the 5 window rows. Every stage is verified exhaustively on the 0/1 inputs of its precondition, the composition\n")
+        f.write("// against numpy.\n")
+        for T in Ts:
+            ops, outs, sizes = build(T)
+            check(T, ops, outs)
+            n_ops = len(ops)
+            ins = sizes.pop("instructions")
+            f.write("// T = %d. Stage networks (compare-exchanges): sort5 %d, merge(5,5) %d, rank 7..12 of (10,10) %d; as programs over\n"
+                    % (T, sizes["sort5"], sizes["merge55"], sizes["quad"]))
+            f.write("// v_min / v_max / v_min3 / v_max3 / v_med3 (instructions as min/max pairs -> with three-input forms): %s.\n"
+                    % ", ".join("%s %d -> %d" % (k, v[0], v[1]) for k, v in ins.items()))
+            f.write("// %d instructions in total = %.1f per median (the 99-comparator network on unsorted inputs: 198; 112 with 3-input ops).\n" % (n_ops, n_ops / T))
+            f.write("__device__ __forceinline__ void median5x5_row%d(const float* __restrict__ in, float* __restrict__ out) {\n" % T)
+            for (d, op, *a) in ops:
+                f.write("  const float %s = %s;\n" % (d, C_FORM[op] % tuple(a)))
+            for o, name in enumerate(outs):
+                f.write("  out[%d] = %s;\n" % (o, name))
+            f.write("}\n")
+            print("T=%d: stage CEs %s, instructions per stage (before, after) %s, %d instructions = %.1f per median -> %s"
+                  % (T, sizes, ins, n_ops, n_ops / T, os.path.normpath(out)))
 
 
 if __name__ == "__main__":
