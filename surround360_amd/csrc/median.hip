@@ -207,8 +207,8 @@ static void launch_row8(hipStream_t st, const float2* src, float2* dst, int w, i
   dim3 grd((w + BX * MED_T - 1) / (BX * MED_T), (h + G::BY - 1) / G::BY, B);
   hipLaunchKernelGGL(k_median5_c2_row8<BX>, grd, dim3(256), 0, st, src, dst, w, h, bs);
 }
-// tiles of a launch, the narrow shapes slightly dearer per tile (their two rows per wave cost index arithmetic):
-// tools/median_microbench, profiles/r06_v11_median_microbench.txt
+// tiles of a launch, the narrow shapes slightly dearer per tile. The weights are a hand-set tie-breaker that picks the fastest
+// shape on the five shapes of tools/median_microbench (profiles/r06_v11_median_microbench.txt), not a fit.
 static double median_tile_cost(int w, int h, int bx) {
   const int tw = bx * MED_T, th = 256 / bx;
   const double tiles = double((w + tw - 1) / tw) * double((h + th - 1) / th);

@@ -516,3 +516,14 @@ def test_jpeg_reader_equals_libjpeg(tmp_path):
     ex[0x0112] = 1
     Image.fromarray(scene(32, 32)).save(p, exif=ex)
     assert np.array_equal(decode(p, (32, 32, 3)), np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1])
+
+
+def test_median_networks_are_the_generators_output(tmp_path):
+    """surround360_amd/csrc/median_tile.inc is what tools/gen_median_network.py writes today: the generator checks every stage
+    program (min / max / min3 / max3 / med3) on all 0/1 inputs of its precondition and the composition against numpy's median
+    before it writes anything, so an edited or stale file cannot pass for a verified one."""
+    out = tmp_path / "median_tile.inc"
+    env = dict(os.environ, S360_MEDIAN_INC_OUT=str(out))
+    import sys
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_median_network.py")], check=True, env=env, capture_output=True)
+    assert out.read_bytes() == open(os.path.join(ROOT, "surround360_amd", "csrc", "median_tile.inc"), "rb").read()

@@ -362,7 +362,8 @@ def check(T, ops, outs):
 def main():
     Ts = [int(a) for a in sys.argv[1:]] or [8]
     here = os.path.dirname(os.path.abspath(__file__))
-    out = os.path.join(here, "..", "surround360_amd", "csrc", "median_tile.inc")
+    # S360_MEDIAN_INC_OUT: write somewhere else (tests/test_cpu_host.py compares a fresh run with the committed file)
+    out = os.environ.get("S360_MEDIAN_INC_OUT") or os.path.join(here, "..", "surround360_amd", "csrc", "median_tile.inc")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_median_network.py %s — do not edit. Exact 5x5 medians of T horizontally adjacent\n" % " ".join(map(str, Ts)))
         f.write("// pixels from T + 4 shared columns: in[c * 5 + r] = value at column c (first window's leftmost column = 0), row r of\n")
