@@ -151,3 +151,30 @@ def test_fourteen_threads_share_one_context(ctx, oracle):
     for k in range(14):
         want = oracle.compute_optical_flow(pairs[k][0], pairs[k][1], "pixflow_low", hints[k % 2])
         assert np.array_equal(bits(got[k]), bits(want)), "thread %d" % k
+
+
+@pytest.mark.parametrize("bx", [32, 16, 8, 4])
+def test_median_tile_shapes_give_the_same_flow(bx, oracle, rig_json, tmp_path):
+    """medianBlur(flow, 5) runs with one of four tile shapes per pyramid level (median.hip, launch_median5_c2); S360_MEDIAN_BX forces
+    one shape for every level. The variable is read once per process, so each shape runs in a process of its own; the flow must be
+    the oracle's bit for bit whatever the shape."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (sizes: the replay of this file on the CPU emulation sets TEST_FLOW_SIZES; the entry downscale halves the image, and only
+    # levels at least 64 wide take the tiled kernel, so the first level of a 150-wide pair still walks the forced shape)
+    w, h = [int(v) for v in os.environ.get("TEST_FLOW_SIZES", "297x444").split(",")[0].split("x")]
+    code = ("import os, sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from surround360_amd import _capi, render as R, synth\n"
+            "if os.environ.get('S360_TEST_EMULATED_LIB') == '1':  # tests/conftest.py's developer switch, for this child too\n"
+            "    _capi.LIB_PATH = os.environ.get('S360_TEST_EMULATED_LIB_PATH') or os.path.join(%r, 'tools', 'libs360_emu.so')\n"
+            "c = R.Context(R.RigDescription(sys.argv[2]), R.make_params(eqr_width=1008, eqr_height=504))\n"
+            "i0, i1 = synth.flow_pair(int(sys.argv[3]), int(sys.argv[4]), seed=2)\n"
+            "np.save(sys.argv[1], c.compute_optical_flow(i0, i1, 'pixflow_low', 'LEFT'))\n" % (root, root))
+    out = str(tmp_path / "flow.npy")
+    subprocess.run([sys.executable, "-c", code, out, rig_json, str(w), str(h)], check=True,
+                   env=dict(os.environ, S360_MEDIAN_BX=str(bx)), timeout=600)
+    i0, i1 = synth.flow_pair(w, h, seed=2)
+    want = oracle.compute_optical_flow(i0, i1, "pixflow_low", "LEFT")
+    assert np.array_equal(bits(np.load(out)), bits(want))
